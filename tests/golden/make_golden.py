@@ -1,0 +1,360 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors in this directory by running the REAL reference.
+
+Runs only in the build container (needs /root/reference, which never travels to the GPU box).
+The reference is pure Python; four third-party imports it makes at module import time are absent
+here and are not touched by the hot path's arithmetic, so they are stubbed.
+Nothing of the reference is written into this repo: the outputs are DATA (inputs, parameters,
+expected outputs) stored as .npz.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+Fixtures:
+  g1_squeeze_split.npz   squeeze/unsqueeze, split/cat
+  g2_actnorm.npz         data-dependent init; fwd/rev with logdet in {None, tensor}
+  g3_invconv.npz         C in {12,24,48,96}, non-orthogonal W: fwd, dlogdet, rev
+  g4_coupling_net.npz    f(): 3x3 -> relu -> 1x1 -> relu -> zeros-3x3, all params random
+  g5_flowstep.npz        {invconv,reverse,shuffle} x {additive,affine}: fwd z/logdet, rev x/logdet
+  g6_split2d.npz         fwd logp; rev with injected eps for eps_std in {None, 0, 0.7}
+  g7_glow_tiny.npz       Glow 16x16x3 L=2 K=2 hidden 32 (affine+invconv, additive+reverse):
+                         noise, z, nll, decode with injected eps, data-dependent init
+  g8_glow_celeba64.npz   celeba.json-sized model (64x64x3 L3 K32 w512 affine), B=2, weights from the
+                         oracle's seeded procedure (too big to commit): digests only
+"""
+import os
+import sys
+import types
+
+os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
+sys.dont_write_bytecode = True
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+
+import numpy as np
+import torch
+
+
+def _install_stubs():
+    class EasyDict(dict):
+        def __init__(self, d=None, **kw):
+            super().__init__()
+            for k, v in dict(d or {}, **kw).items():
+                self[k] = v
+
+        def __setitem__(self, k, v):
+            if isinstance(v, dict) and not isinstance(v, EasyDict):
+                v = EasyDict(v)
+            super().__setitem__(k, v)
+
+        def __getattr__(self, k):
+            try:
+                return self[k]
+            except KeyError as e:
+                raise AttributeError(k) from e
+
+        __setattr__ = __setitem__
+
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    mod("cv2")
+    tv = mod("torchvision")
+    tr = mod("torchvision.transforms", transforms=types.SimpleNamespace())
+    ut = mod("torchvision.utils", make_grid=lambda *a, **k: None)
+    tv.transforms, tv.utils = tr, ut
+    mod("tensorboardX", SummaryWriter=object)
+    mod("easydict", EasyDict=EasyDict)
+    return EasyDict
+
+
+EasyDict = _install_stubs()
+sys.path.insert(0, REF)
+os.chdir(REF)
+from network import module as rmod  # noqa: E402
+from network import model as rmodel  # noqa: E402
+from misc import ops as rops  # noqa: E402
+
+sys.path.insert(0, REPO)
+from oracle import glow_oracle as O  # noqa: E402  (only for the seeded weight procedure of G8)
+
+
+def npd(d):
+    return {k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in d.items()}
+
+
+def save(name, d):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **npd(d))
+    print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB, {len(d)} arrays")
+
+
+def randomize_(m, g, std=0.2):
+    """Randomise every parameter of a reference module in place (zero-init layers included)."""
+    with torch.no_grad():
+        for name, p in m.named_parameters():
+            if name.endswith("invconv.weight") or name == "weight" and p.dim() == 2:
+                c = p.shape[0]
+                q = np.linalg.qr(np.random.randn(c, c))[0].astype("float32")
+                p.copy_(torch.from_numpy(q) + 0.1 * torch.randn(c, c, generator=g))
+            elif name.endswith("logs"):
+                p.copy_(torch.randn(p.shape, generator=g) * 0.1)
+            elif name.endswith("bias"):
+                p.copy_(torch.randn(p.shape, generator=g) * 0.1)
+            elif "f.4." in name or "conv2d_zeros" in name or name == "weight" and getattr(m, "logscale_factor", None):
+                p.copy_(torch.randn(p.shape, generator=g) * 0.05)
+            else:
+                p.copy_(torch.randn(p.shape, generator=g) * std)
+    for sub in m.modules():
+        if isinstance(sub, rmod.ActNorm):
+            sub.bias_inited = True
+            sub.logs_inited = True
+
+
+def g1(g):
+    x = torch.randn(2, 3, 8, 8, generator=g)
+    sq = rmod.Squeeze2d.squeeze(x.clone(), 2)
+    x2 = torch.randn(2, 8, 4, 6, generator=g)
+    un = rmod.Squeeze2d.unsqueeze(x2.clone(), 2)
+    t = torch.randn(2, 6, 4, 4, generator=g)
+    s1, s2 = rops.split_channel(t, "simple")
+    c1, c2 = rops.split_channel(t, "cross")
+    save("g1_squeeze_split.npz", dict(x=x, squeezed=sq, x2=x2, unsqueezed=un, t=t, simple_a=s1, simple_b=s2,
+                                      cross_a=c1, cross_b=c2, cat=rops.cat_channel(s1, s2),
+                                      rsum=rops.reduce_sum(t.clone(), dim=[1, 2, 3]),
+                                      rmean=rops.reduce_mean(t.clone(), dim=[0, 2, 3], keepdim=True)))
+
+
+def g2(g):
+    out = {}
+    x = torch.randn(4, 12, 8, 8, generator=g) * 1.7 + 0.3
+    an = rmod.ActNorm(12, scale=1.0)
+    an.train()
+    y, _ = an(x.clone())
+    out.update(init_x=x, init_bias=an.bias.data.clone(), init_logs=an.logs.data.clone(), init_y=y)
+    an3 = rmod.ActNorm(12, scale=3.0)
+    an3.train()
+    an3(x.clone())
+    out.update(init3_bias=an3.bias.data.clone(), init3_logs=an3.logs.data.clone())
+    an = rmod.ActNorm(12)
+    randomize_(an, g)
+    ld = torch.randn(4, generator=g)
+    yf, ldf = an(x.clone(), ld.clone(), reverse=False)
+    yr, ldr = an(x.clone(), ld.clone(), reverse=True)
+    yn, ldn = an(x.clone(), None, reverse=False)
+    assert ldn is None
+    out.update(x=x, bias=an.bias, logs=an.logs, logdet=ld, fwd_y=yf, fwd_logdet=ldf, rev_y=yr, rev_logdet=ldr, fwd_y_nold=yn)
+    save("g2_actnorm.npz", out)
+
+
+def g3(g):
+    out = {}
+    for c in (12, 24, 48, 96):
+        inv = rmod.Invertible1x1Conv(c)
+        randomize_(inv, g)
+        x = torch.randn(2, c, 4, 4, generator=g)
+        ld = torch.randn(2, generator=g)
+        zf, ldf = inv(x.clone(), ld.clone(), reverse=False)
+        zr, ldr = inv(x.clone(), ld.clone(), reverse=True)
+        out.update({f"c{c}_w": inv.weight, f"c{c}_x": x, f"c{c}_logdet": ld, f"c{c}_fwd_z": zf, f"c{c}_fwd_logdet": ldf,
+                    f"c{c}_rev_z": zr, f"c{c}_rev_logdet": ldr})
+    save("g3_invconv.npz", out)
+
+
+def g4(g):
+    net = rmod.f(6, 32, 12)
+    randomize_(net, g)
+    x = torch.randn(4, 6, 8, 8, generator=g)
+    with torch.no_grad():
+        y = net(x.clone())
+    out = {"x": x, "y": y}
+    out.update({"p." + k: v for k, v in net.state_dict().items()})
+    # a Conv2d / Conv2dZeros pair of odd shape (reference test_module.py:31-48 uses 16 -> 5)
+    cv = rmod.Conv2d(16, 5)
+    randomize_(cv, g)
+    cz = rmod.Conv2dZeros(16, 5)
+    randomize_(cz, g)
+    c1 = rmod.Conv2d(16, 7, kernel_size=1)
+    randomize_(c1, g)
+    x2 = torch.randn(2, 16, 4, 4, generator=g)
+    with torch.no_grad():
+        out.update(x2=x2, conv_y=cv(x2.clone()), convz_y=cz(x2.clone()), conv1_y=c1(x2.clone()))
+    out.update({"conv." + k: v for k, v in cv.state_dict().items()})
+    out.update({"convz." + k: v for k, v in cz.state_dict().items()})
+    out.update({"conv1." + k: v for k, v in c1.state_dict().items()})
+    save("g4_coupling_net.npz", out)
+
+
+def g5(g):
+    out = {}
+    for perm in ("invconv", "reverse", "shuffle"):
+        for coup in ("additive", "affine"):
+            tag = f"{perm}_{coup}"
+            st = rmodel.FlowStep(12, 32, permutation=perm, coupling=coup)
+            randomize_(st, g)
+            x = torch.randn(4, 12, 8, 8, generator=g)
+            ld = torch.randn(4, generator=g)
+            with torch.no_grad():
+                z, ldz = st(x.clone(), ld.clone(), reverse=False)
+                xr, ldx = st(x.clone(), ld.clone(), reverse=True)
+            out.update({f"{tag}.x": x, f"{tag}.logdet": ld, f"{tag}.fwd_z": z, f"{tag}.fwd_logdet": ldz,
+                        f"{tag}.rev_x": xr, f"{tag}.rev_logdet": ldx})
+            out.update({f"{tag}.p.{k}": v for k, v in st.state_dict().items()})
+            if perm != "invconv":
+                pm = getattr(st, perm)
+                out[f"{tag}.indices"] = pm.indices.copy()
+                out[f"{tag}.indices_inverse"] = pm.indices_inverse.copy()
+    save("g5_flowstep.npz", out)
+
+
+class EpsTap:
+    """Replace GaussianDiag.eps by a recorder (reference module.py:408-421)."""
+
+    def __init__(self):
+        self.draws, self.stds = [], []
+        self.orig = rmod.GaussianDiag.eps
+
+    def __enter__(self):
+        tap = self
+
+        def eps(shape_tensor, eps_std=None):
+            e = tap.orig(shape_tensor, eps_std)
+            tap.draws.append(e.clone())
+            tap.stds.append(eps_std)
+            return e
+
+        rmod.GaussianDiag.eps = staticmethod(eps)
+        return self
+
+    def __exit__(self, *a):
+        rmod.GaussianDiag.eps = staticmethod(self.orig)
+
+
+def g6(g):
+    sp = rmod.Split2d(12)
+    randomize_(sp, g)
+    x = torch.randn(4, 12, 8, 8, generator=g)
+    ld = torch.randn(4, generator=g)
+    out = {"x": x, "logdet": ld}
+    out.update({"p." + k: v for k, v in sp.state_dict().items()})
+    with torch.no_grad():
+        z1, ldf = sp(x.clone(), ld.clone(), reverse=False)
+        out.update(fwd_z1=z1, fwd_logdet=ldf)
+        for tag, std in (("none", None), ("zero", 0), ("p7", 0.7)):
+            with EpsTap() as tap:
+                torch.manual_seed(77)
+                xr, _ = sp(z1.clone(), 0., reverse=True, eps_std=std)
+            out[f"rev_{tag}_eps"] = tap.draws[0]
+            out[f"rev_{tag}_x"] = xr
+    save("g6_split2d.npz", out)
+
+
+def tiny_hps(coupling, permutation, batch=4):
+    return EasyDict(dict(
+        model=dict(image_shape=[16, 16, 3], hidden_channels=32, K=2, L=2, actnorm_scale=1.0, n_bits_x=8, weight_y=0.0),
+        ablation=dict(learn_top=False, y_condition=False, lu_decomposition=False, flow_permutation=permutation,
+                      flow_coupling=coupling),
+        optim=dict(num_batch_train=batch), dataset=dict(num_classes=1), device=dict(graph=["cpu"])))
+
+
+def run_glow(glow, x, seed):
+    """Forward with recoverable dequantisation noise (reference model.py:421)."""
+    torch.manual_seed(seed)
+    z, nll, _ = glow(x=x.clone(), reverse=False)
+    torch.manual_seed(seed)
+    noise = torch.nn.init.uniform_(torch.empty(*x.shape), 0, 1. / 2 ** glow.hps.model.n_bits_x)
+    return z, nll, noise
+
+
+def g7(g):
+    out = {}
+    for coup, perm in (("affine", "invconv"), ("additive", "reverse")):
+        tag = f"{coup}_{perm}"
+        np.random.seed(5)
+        glow = rmodel.Glow(tiny_hps(coup, perm))
+        x = torch.rand(4, 3, 16, 16, generator=g)
+        # (a) data-dependent init pass on fresh weights with non-zero tails
+        with torch.no_grad():
+            for n, p in glow.named_parameters():
+                if "f.4." in n or "conv2d_zeros" in n:
+                    p.copy_(torch.randn(p.shape, generator=g) * 0.02)
+        pre = {k: v.clone() for k, v in glow.state_dict().items()}
+        glow.train()
+        with torch.no_grad():
+            z0, nll0, noise0 = run_glow(glow, x, 11)
+        post = {k: v.clone() for k, v in glow.state_dict().items()}
+        out.update({f"{tag}.x": x, f"{tag}.init_noise": noise0, f"{tag}.init_z": z0, f"{tag}.init_nll": nll0})
+        out.update({f"{tag}.pre.{k}": v for k, v in pre.items()})
+        out.update({f"{tag}.post.{k}": v for k, v in post.items()})
+        # (b) eval forward with fully randomised weights
+        randomize_(glow, g, std=0.1)
+        with torch.no_grad():
+            glow.h_top.zero_()
+        glow.eval()
+        sd = {k: v.clone() for k, v in glow.state_dict().items()}
+        with torch.no_grad():
+            z, nll, noise = run_glow(glow, x, 12)
+            with EpsTap() as tap:
+                torch.manual_seed(13)
+                xr = glow(z=z.clone(), eps_std=0.6, reverse=True)
+        out.update({f"{tag}.noise": noise, f"{tag}.z": z, f"{tag}.nll": nll, f"{tag}.dec_x": xr})
+        for j, e in enumerate(tap.draws):
+            out[f"{tag}.dec_eps{j}"] = e
+        out.update({f"{tag}.sd.{k}": v for k, v in sd.items()})
+        if perm != "invconv":
+            for i, layer in enumerate(glow.flow.layers):
+                if hasattr(layer, perm):
+                    out[f"{tag}.indices.{i}"] = getattr(layer, perm).indices.copy()
+                    out[f"{tag}.indices_inverse.{i}"] = getattr(layer, perm).indices_inverse.copy()
+    save("g7_glow_tiny.npz", out)
+
+
+def g8():
+    """celeba.json-sized model driven by the ORACLE's seeded weight procedure: commit digests only."""
+    cfg = O.default_cfg(batch=2)
+    hps = EasyDict(dict(
+        model=dict(image_shape=[64, 64, 3], hidden_channels=512, K=32, L=3, actnorm_scale=1.0, n_bits_x=8, weight_y=0.0),
+        ablation=dict(learn_top=False, y_condition=False, lu_decomposition=False, flow_permutation="invconv",
+                      flow_coupling="affine"),
+        optim=dict(num_batch_train=2), dataset=dict(num_classes=40), device=dict(graph=["cpu"])))
+    glow = rmodel.Glow(hps)
+    sd = O.seeded_state_dict(cfg, seed=2384)
+    glow.load_state_dict(sd)
+    x = torch.rand(2, 3, 64, 64, generator=torch.Generator().manual_seed(2384))
+    glow.train()  # data-dependent init on this batch, as trainer.py:112-115
+    with torch.no_grad():
+        z0, nll0, noise0 = run_glow(glow, x, 21)
+    glow.eval()
+    with torch.no_grad():
+        z, nll, noise = run_glow(glow, x, 22)
+        with EpsTap() as tap:
+            torch.manual_seed(23)
+            xr = glow(z=z.clone(), eps_std=0.7, reverse=True)
+    post = glow.state_dict()
+    out = dict(seed=2384, eps_std=0.7, x=x, init_noise=noise0, noise=noise,
+               w_digest=torch.stack([sd["flow.layers.50.f.2.weight"].double().sum(),
+                                     sd["flow.layers.100.f.4.weight"].double().sum(),
+                                     sd["flow.layers.1.invconv.weight"].double().sum()]),
+               init_nll=nll0, init_z_corner=z0[:, :, 0, 0], nll=nll, z_corner=z[:, :, 0, 0],
+               z_sum=z.double().sum(), z_sumsq=(z.double() ** 2).sum(),
+               dec_x_corner=xr[:, :, :4, :4], dec_x_sum=xr.double().sum(),
+               an_bias_1=post["flow.layers.1.actnorm.bias"], an_logs_1=post["flow.layers.1.actnorm.logs"],
+               an_bias_last=post["flow.layers.100.actnorm.bias"], an_logs_last=post["flow.layers.100.actnorm.logs"],
+               f2_logs_50=post["flow.layers.50.f.2.actnorm.logs"])
+    for j, e in enumerate(tap.draws):
+        out[f"dec_eps{j}"] = e
+    save("g8_glow_celeba64.npz", out)
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    np.random.seed(1234)
+    g = torch.Generator().manual_seed(1234)
+    g1(g); g2(g); g3(g); g4(g); g5(g); g6(g); g7(g)
+    g8()
+    leftovers = [os.path.join(r, d) for r, ds, _ in os.walk(REF) for d in ds if d == "__pycache__"]
+    assert not leftovers, f"bytecode written into the reference tree: {leftovers}"

@@ -1,0 +1,155 @@
+"""Pins the CPU oracle (oracle/glow_oracle.py) against vectors recorded from the real reference
+(tests/golden/make_golden.py).  CPU only.  Tolerances: activations max-abs 2e-6 (the reference's
+own tensor_equal eps is 1e-6, misc/ops.py:76), log-determinants rtol 1e-6 + atol 1e-5."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import sub
+from oracle import glow_oracle as O
+
+ATOL = 2e-6
+
+
+def close(a, b, atol=ATOL, rtol=0.0):
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = (a.double() - b.double()).abs()
+    bound = atol + rtol * b.double().abs()
+    assert bool((err <= bound).all()), f"max err {err.max().item():.3e} (bound {bound.min().item():.3e})"
+
+
+def ld_close(a, b):
+    close(a, b, atol=1e-5, rtol=1e-6)
+
+
+def test_g1_squeeze_split(golden):
+    g = golden("g1_squeeze_split")
+    assert torch.equal(O.squeeze2d(g["x"]), g["squeezed"])
+    assert torch.equal(O.unsqueeze2d(g["x2"]), g["unsqueezed"])
+    assert torch.equal(O.unsqueeze2d(O.squeeze2d(g["x"])), g["x"])
+    a, b = O.split_channel(g["t"], "simple")
+    assert torch.equal(a, g["simple_a"]) and torch.equal(b, g["simple_b"])
+    a2, b2 = O.split_channel(g["t"], "cross")
+    assert torch.equal(a2, g["cross_a"]) and torch.equal(b2, g["cross_b"])
+    assert torch.equal(O.cat_channel(a, b), g["cat"])
+    close(O.reduce_sum_dims(g["t"], [1, 2, 3]), g["rsum"])
+    close(O.reduce_mean_dims(g["t"], [0, 2, 3], keepdim=True), g["rmean"])
+
+
+def test_g2_actnorm(golden):
+    g = golden("g2_actnorm")
+    b, l = O.actnorm_init(g["init_x"], 1.0)
+    close(b, g["init_bias"]); close(l, g["init_logs"])
+    close(O.actnorm(g["init_x"], b, l)[0], g["init_y"])
+    b3, l3 = O.actnorm_init(g["init_x"], 3.0)
+    close(b3, g["init3_bias"]); close(l3, g["init3_logs"])
+    y, ld = O.actnorm(g["x"], g["bias"], g["logs"], g["logdet"], reverse=False)
+    close(y, g["fwd_y"]); ld_close(ld, g["fwd_logdet"])
+    y, ld = O.actnorm(g["x"], g["bias"], g["logs"], g["logdet"], reverse=True)
+    close(y, g["rev_y"]); ld_close(ld, g["rev_logdet"])
+    y, ld = O.actnorm(g["x"], g["bias"], g["logs"], None)
+    assert ld is None
+    close(y, g["fwd_y_nold"])
+
+
+@pytest.mark.parametrize("c", [12, 24, 48, 96])
+def test_g3_invconv(golden, c):
+    g = sub(golden("g3_invconv"), f"c{c}_")
+    z, ld = O.invconv(g["x"], g["w"], g["logdet"], reverse=False)
+    close(z, g["fwd_z"]); ld_close(ld, g["fwd_logdet"])
+    z, ld = O.invconv(g["x"], g["w"], g["logdet"], reverse=True)
+    close(z, g["rev_z"], atol=1e-5); ld_close(ld, g["rev_logdet"])
+
+
+def test_g4_coupling_net(golden):
+    g = golden("g4_coupling_net")
+    close(O.coupling_net(g["x"], sub(g, "p."), ""), g["y"])
+    p = sub(g, "conv.")
+    close(O.conv2d_actnorm(g["x2"], p["weight"], p["actnorm.bias"], p["actnorm.logs"]), g["conv_y"])
+    p = sub(g, "conv1.")
+    close(O.conv2d_actnorm(g["x2"], p["weight"], p["actnorm.bias"], p["actnorm.logs"]), g["conv1_y"])
+    p = sub(g, "convz.")
+    close(O.conv2d_zeros(g["x2"], p["weight"], p["bias"], p["logs"]), g["convz_y"])
+
+
+@pytest.mark.parametrize("perm", ["invconv", "reverse", "shuffle"])
+@pytest.mark.parametrize("coup", ["additive", "affine"])
+def test_g5_flowstep(golden, perm, coup):
+    g = sub(golden("g5_flowstep"), f"{perm}_{coup}.")
+    tables = (g["indices"], g["indices_inverse"]) if perm != "invconv" else None
+    z, ld = O.flowstep(g["x"], g["logdet"], sub(g, "p."), "", perm, coup, reverse=False, perm_tables=tables)
+    close(z, g["fwd_z"], atol=5e-6); ld_close(ld, g["fwd_logdet"])
+    x, ld = O.flowstep(g["x"], g["logdet"], sub(g, "p."), "", perm, coup, reverse=True, perm_tables=tables)
+    close(x, g["rev_x"], atol=1e-5); ld_close(ld, g["rev_logdet"])
+    if perm == "reverse":
+        idx, inv = O.permutation_indices(12, shuffle=False)
+        assert np.array_equal(idx, g["indices"]) and np.array_equal(inv, g["indices_inverse"])
+
+
+def test_g6_split2d(golden):
+    g = golden("g6_split2d")
+    z1, ld = O.split2d(g["x"], g["logdet"], sub(g, "p."), "", reverse=False)
+    assert torch.equal(z1, g["fwd_z1"])
+    ld_close(ld, g["fwd_logdet"])
+    for tag in ("none", "zero", "p7"):
+        x, _ = O.split2d(g["fwd_z1"], 0.0, sub(g, "p."), "", reverse=True, eps=g[f"rev_{tag}_eps"])
+        close(x, g[f"rev_{tag}_x"])
+    # eps_std=0 is silently 1.0 -> same std as None
+    assert O.effective_eps_std(None) == 1.0 and O.effective_eps_std(0) == 1.0 and O.effective_eps_std(0.7) == 0.7
+    s_none, s_zero, s_p7 = (g[f"rev_{t}_eps"].std().item() for t in ("none", "zero", "p7"))
+    assert abs(s_none - 1) < 0.1 and abs(s_zero - 1) < 0.1 and abs(s_p7 - 0.7) < 0.07
+
+
+TINY = dict(image_shape=[16, 16, 3], hidden_channels=32, K=2, L=2, actnorm_scale=1.0, n_bits_x=8, batch=4,
+            learn_top=False, y_condition=False)
+
+
+@pytest.mark.parametrize("coup,perm", [("affine", "invconv"), ("additive", "reverse")])
+def test_g7_glow_tiny(golden, coup, perm):
+    g = sub(golden("g7_glow_tiny"), f"{coup}_{perm}.")
+    cfg = dict(TINY, flow_coupling=coup, flow_permutation=perm)
+    layout = O.flow_layout(cfg)
+    assert [k for k, _, _ in layout] == ["squeeze", "step", "step", "split", "squeeze", "step", "step"]
+    tables = None
+    if perm != "invconv":
+        tables = {i: (g[f"indices.{i}"], g[f"indices_inverse.{i}"]) for k, i, _ in layout if k == "step"}
+    sd = sub(g, "sd.")
+    z, nll, _ = O.glow_forward(g["x"], g["noise"], sd, cfg, perm_tables=tables)
+    close(z, g["z"], atol=2e-5); close(nll, g["nll"], atol=2e-6)
+    eps = [g["dec_eps0"]]
+    x = O.glow_reverse(g["z"], sd, cfg, eps, perm_tables=tables)
+    close(x, g["dec_x"], atol=5e-5)
+    if perm == "invconv":  # data-dependent init pass restated for invconv only
+        post = O.glow_init_actnorm(g["x"], g["init_noise"], sub(g, "pre."), cfg)
+        for k, v in sub(g, "post.").items():
+            close(post[k], v, atol=1e-5)
+        z0, nll0, _ = O.glow_forward(g["x"], g["init_noise"], post, cfg)
+        close(z0, g["init_z"], atol=2e-5); close(nll0, g["init_nll"], atol=2e-6)
+
+
+def test_g8_glow_celeba64(golden):
+    """Full-size model (44.1 M parameters) on B=2: the reference, fed the oracle's seeded weights,
+    produced these digests; the oracle must reproduce them from the same seed."""
+    g = golden("g8_glow_celeba64")
+    cfg = O.default_cfg(batch=2)
+    assert abs(O.flop_per_image(cfg) - 3.2092e10) / 3.2092e10 < 1e-3
+    torch.set_num_threads(8)
+    sd = O.seeded_state_dict(cfg, seed=int(g["seed"]))
+    assert sum(v.numel() for v in sd.values()) - sd["h_top"].numel() == 44_052_720
+    dig = torch.stack([sd["flow.layers.50.f.2.weight"].double().sum(), sd["flow.layers.100.f.4.weight"].double().sum(),
+                       sd["flow.layers.1.invconv.weight"].double().sum()])
+    close(dig, g["w_digest"], atol=1e-9)
+    with torch.no_grad():
+        post = O.glow_init_actnorm(g["x"], g["init_noise"], sd, cfg)
+        close(post["flow.layers.1.actnorm.bias"], g["an_bias_1"], atol=1e-6)
+        close(post["flow.layers.1.actnorm.logs"], g["an_logs_1"], atol=1e-6)
+        close(post["flow.layers.100.actnorm.bias"], g["an_bias_last"], atol=1e-4)
+        close(post["flow.layers.100.actnorm.logs"], g["an_logs_last"], atol=1e-4)
+        close(post["flow.layers.50.f.2.actnorm.logs"], g["f2_logs_50"], atol=1e-4)
+        z0, nll0, _ = O.glow_forward(g["x"], g["init_noise"], post, cfg)
+        close(nll0, g["init_nll"], atol=1e-4); close(z0[:, :, 0, 0], g["init_z_corner"], atol=1e-4)
+        z, nll, _ = O.glow_forward(g["x"], g["noise"], post, cfg)
+        close(nll, g["nll"], atol=1e-4); close(z[:, :, 0, 0], g["z_corner"], atol=1e-4)
+        assert abs(z.double().sum().item() - float(g["z_sum"])) < 1e-1
+        x = O.glow_reverse(z, post, cfg, [g["dec_eps0"], g["dec_eps1"]])
+        close(x[:, :, :4, :4], g["dec_x_corner"], atol=1e-4)
