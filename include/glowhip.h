@@ -1,0 +1,183 @@
+/*
+ * glowhip.h -- C ABI of the MI355X-native Glow flow engine (libglowhip.so, gfx950).
+ *
+ * The reference (corenel/pytorch-glow) has no FFI: its hot path is the Python module surface of
+ * network/module.py, network/model.py and misc/ops.py.  Each entry point below names the reference
+ * function (file:line) whose arithmetic it replaces; the Python shells in
+ * pytorch-glow_amd/network/{module,model}.py bind them with ctypes.
+ *
+ * Conventions
+ *   - plain C: device pointers, sizes and an opaque stream handle (a hipStream_t passed as void*);
+ *     no torch / C++ types cross the boundary;
+ *   - every tensor is fp32, NCHW, contiguous unless a stride argument says otherwise; every pointer is
+ *     a DEVICE pointer on the device the stream belongs to (exceptions are marked HOST);
+ *   - no allocation, no host synchronisation, no global mutable state inside: workspaces are passed in;
+ *     calls are asynchronous on `stream` and re-entrant (one plan must not be executed concurrently on
+ *     two streams with the same workspace);
+ *   - return value: 0 on success, a negative GLOWHIP_E* code otherwise; glowhip_last_error() returns a
+ *     thread-local message for the last failure on the calling thread.
+ */
+#ifndef GLOWHIP_H
+#define GLOWHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GLOWHIP_VERSION 100 /* 0.1.0 */
+
+#define GLOWHIP_OK 0
+#define GLOWHIP_EINVAL (-1)    /* bad argument (shape, null pointer, unsupported value) */
+#define GLOWHIP_ELAUNCH (-2)   /* HIP launch / runtime error */
+#define GLOWHIP_EWORKSPACE (-3)/* workspace too small */
+
+typedef void* glowhip_stream_t; /* hipStream_t */
+
+int glowhip_version(void);
+const char* glowhip_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Single-layer primitives (module surface of network/module.py)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Squeeze2d.squeeze / unsqueeze, network/module.py:551-592.
+ * reverse=0: x (N,C,H,W) -> y (N,C*f*f,H/f,W/f), y[n, c*f*f+i*f+j, h, w] = x[n, c, h*f+i, w*f+j]
+ * reverse=1: x (N,C,H,W) -> y (N,C/(f*f),H*f,W*f) (exact inverse).  C,H,W describe the INPUT. */
+int glowhip_squeeze2d(const float* x, float* y, int N, int C, int H, int W, int factor, int reverse,
+                      glowhip_stream_t stream);
+
+/* ActNorm data-dependent initialisation, network/module.py:86-120 (batch_variance=False):
+ * bias[c] = -mean_{n,h,w} x;  logs[c] = log(scale / (sqrt(mean (x+bias)^2) + 1e-6)) / 3.
+ * x may be a channel slice of a wider tensor: element (n,c,p) is x[n*batch_stride + c*HW + p]. */
+int glowhip_actnorm_init(const float* x, long batch_stride, int N, int C, int HW, float scale,
+                         float* bias, float* logs, glowhip_stream_t stream);
+
+/* ActNorm.forward, network/module.py:122-149.  reverse=0: y=(x+bias)*exp(3 logs); reverse=1:
+ * y = x*exp(-3 logs) - bias.  If logdet_out != NULL: logdet_out[n] = (logdet_in ? logdet_in[n] : 0)
+ * +/- 3*sum(logs)*HW. */
+int glowhip_actnorm(const float* x, float* y, const float* bias, const float* logs, int N, int C, int HW,
+                    int reverse, const float* logdet_in, float* logdet_out, glowhip_stream_t stream);
+
+/* In-kernel LU (Gauss-Jordan, partial pivoting, fp64) of one C x C matrix: replaces torch.det /
+ * Tensor.inverse at network/module.py:357,365.  winv (C*C, may be NULL) <- W^-1,
+ * logabsdet (1 float) <- log|det W|.  scratch: >= glowhip_invconv_scratch_bytes(C) bytes. */
+size_t glowhip_invconv_scratch_bytes(int C);
+int glowhip_invconv_prepare(const float* w, int C, float* winv, float* logabsdet, void* scratch,
+                            glowhip_stream_t stream);
+
+/* Invertible1x1Conv.forward, network/module.py:344-369: y[n,o,p] = sum_i m[o,i] x[n,i,p] where m is the
+ * matrix to APPLY (W forward, W^-1 reverse, from glowhip_invconv_prepare).  If logdet_out != NULL:
+ * logdet_out[n] = logdet_in[n] + sign * logabsdet[0] * HW with sign=+1 (reverse=0) / -1 (reverse=1). */
+int glowhip_invconv(const float* x, float* y, const float* m, const float* logabsdet, int N, int C, int HW,
+                    int reverse, const float* logdet_in, float* logdet_out, glowhip_stream_t stream);
+
+/* Permutation2d.forward, network/module.py:392-397: y[:, o] = x[:, idx[o]] (idx: C int32, device). */
+int glowhip_permute_channels(const float* x, float* y, const int32_t* idx, int N, int C, int HW,
+                             glowhip_stream_t stream);
+
+/* Conv2d / Conv2dZeros forward, network/module.py:252-259 and :295-297, 'SAME' padding, stride 1,
+ * ksize in {1,3}:  v = conv(x, w) + (bias ? bias[o] : 0);
+ *                  v = (v + (post_bias ? post_bias[o] : 0)) * (post_logs ? exp(3*post_logs[o]) : 1);
+ *                  y = relu ? max(v,0) : v.
+ * Conv2d(+ActNorm): bias=NULL, post_bias/post_logs = actnorm.bias/logs.  Conv2dZeros: bias, post_logs=logs.
+ * x element (n,ci,p) at x[n*x_batch_stride + ci*H*W + p] (lets z1 = first half of a wider tensor be read
+ * in place); y contiguous (N,Cout,H,W); w (Cout,Cin,k,k). */
+int glowhip_conv2d(const float* x, long x_batch_stride, const float* w, const float* bias, float* y,
+                   int N, int Cin, int H, int W, int Cout, int ksize,
+                   const float* post_bias, const float* post_logs, int relu, glowhip_stream_t stream);
+
+/* GaussianDiag.logp, network/module.py:453-467: out[n] = (in ? in[n] : 0) +
+ * sum_{c,p} -0.5*(log(2pi) + 2*logs + (x-mean)^2/exp(2*logs)).  mean/logs may be NULL (= 0).
+ * Element (n,c,p) of x/mean/logs at base[n*stride + c*HW + p]. */
+int glowhip_gaussian_logp(const float* x, long x_stride, const float* mean, const float* logs, long ml_stride,
+                          int N, int C, int HW, const float* in, float* out, void* scratch8N,
+                          glowhip_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Flow plans: FlowStep / Split2d / Squeeze2d stacks executed by one call
+ * (FlowStep.normal_flow/reverse_flow network/model.py:82-154, Split2d.forward network/module.py:511-536,
+ *  FlowModel.encode/decode network/model.py:263-294, Glow.normal_flow network/model.py:409-452)
+ * ---------------------------------------------------------------------------------------------- */
+enum { GLOWHIP_LAYER_SQUEEZE = 0, GLOWHIP_LAYER_FLOWSTEP = 1, GLOWHIP_LAYER_SPLIT2D = 2 };
+enum { GLOWHIP_PERM_INVCONV = 0, GLOWHIP_PERM_GATHER = 1 };   /* 'invconv' | 'reverse'/'shuffle' */
+enum { GLOWHIP_COUPLING_ADDITIVE = 0, GLOWHIP_COUPLING_AFFINE = 1 };
+
+/* One layer of a FlowModel; C,H,W are the layer's INPUT shape.  Parameter pointers are device pointers
+ * to the live parameters (state_dict layout of the reference).  They are read by
+ * glowhip_plan_pack (derived data) AND by encode/decode (biases, weights of the direct kernels), so
+ * they must stay valid -- same addresses -- for the life of the plan. */
+typedef struct glowhip_layer_desc {
+    int32_t kind;
+    int32_t C, H, W;
+    int32_t hidden;        /* FLOWSTEP: hidden_channels */
+    int32_t permutation;   /* FLOWSTEP: GLOWHIP_PERM_* */
+    int32_t coupling;      /* FLOWSTEP: GLOWHIP_COUPLING_* */
+    int32_t reserved;
+    const float* an_bias;  const float* an_logs;            /* actnorm.{bias,logs}        (C) */
+    const float* invconv_w;                                 /* invconv.weight             (C,C) */
+    const int32_t* perm_idx; const int32_t* perm_idx_inv;   /* Permutation2d tables       (C) */
+    const float* f0_w; const float* f0_an_bias; const float* f0_an_logs; /* f.0: (hid,C/2,3,3),(hid),(hid) */
+    const float* f2_w; const float* f2_an_bias; const float* f2_an_logs; /* f.2: (hid,hid,1,1),(hid),(hid) */
+    const float* f4_w; const float* f4_bias;    const float* f4_logs;    /* f.4 / Split2d.conv2d_zeros:
+                                                                            (Cout,Cin,3,3),(Cout),(Cout) */
+} glowhip_layer_desc;
+
+typedef struct glowhip_plan glowhip_plan;
+
+/* Build a plan (HOST bookkeeping only; descs are copied).  Returns NULL on error. */
+glowhip_plan* glowhip_plan_create(const glowhip_layer_desc* layers, int n_layers);
+void glowhip_plan_destroy(glowhip_plan* plan);
+
+/* Bytes of the persistent packed-parameter buffer / of the per-call workspace for batch N. */
+size_t glowhip_plan_packed_bytes(const glowhip_plan* plan);
+size_t glowhip_plan_workspace_bytes(const glowhip_plan* plan, int N);
+
+/* Re-derive everything that depends only on the parameters (exp(3 logs), K-major re-layout of the
+ * convolution weights for the MFMA kernels, in-kernel LU -> log|det W| and W^-1) into `packed`.
+ * Call after the parameters changed (optimizer step, load_state_dict, ActNorm init). */
+int glowhip_plan_pack(glowhip_plan* plan, void* packed, size_t packed_bytes, glowhip_stream_t stream);
+
+/* FlowModel.encode: x (N, C0,H0,W0 of layer 0) -> z (output shape of the last layer),
+ * logdet_out[n] = (logdet_in ? logdet_in[n] : 0) + sum of all layers' log-determinant terms.
+ * noise (shape of x, may be NULL) is added to x first (dequantisation, network/model.py:421). */
+int glowhip_plan_encode(glowhip_plan* plan, const void* packed, const float* x, const float* noise,
+                        const float* logdet_in, float* z, float* logdet_out, int N,
+                        void* workspace, size_t workspace_bytes, glowhip_stream_t stream);
+
+/* FlowModel.decode: z -> x, layers run in reverse.  eps[k] (device pointer, shape of the k-th Split2d's
+ * z2 in DECODE order, already multiplied by eps_std) is the injected N(0,1) draw of
+ * GaussianDiag.sample (network/module.py:470-483).  logdet_out may be NULL. */
+int glowhip_plan_decode(glowhip_plan* plan, const void* packed, const float* z, const float* const* eps,
+                        int n_eps, const float* logdet_in, float* x, float* logdet_out, int N,
+                        void* workspace, size_t workspace_bytes, glowhip_stream_t stream);
+
+/* Glow.normal_flow (network/model.py:409-452) in one call: z = x + noise; objective = -ln(2^n_bits)*CHW
+ * + encode logdet + logp(z | prior_mean, prior_logs);  nll = -objective / (ln2*CHW).
+ * prior_mean/prior_logs: (N,Cz,Hz,Wz) with batch stride prior_stride, NULL = zeros.
+ * objective_out may be NULL. */
+int glowhip_glow_forward(glowhip_plan* plan, const void* packed, const float* x, const float* noise,
+                         const float* prior_mean, const float* prior_logs, long prior_stride, int n_bits,
+                         float* z, float* nll_out, float* objective_out, int N,
+                         void* workspace, size_t workspace_bytes, glowhip_stream_t stream);
+
+/* Data-dependent ActNorm initialisation pass over a whole plan (first training-mode forward,
+ * network/trainer.py:112-115 + network/module.py:45-46,66-67): runs encode on x and writes every
+ * ActNorm's bias/logs THROUGH the parameter pointers of the layer descs (which must be writable). */
+int glowhip_plan_actnorm_init(glowhip_plan* plan, void* packed, size_t packed_bytes, const float* x,
+                              const float* noise, float actnorm_scale, int N, void* workspace,
+                              size_t workspace_bytes, glowhip_stream_t stream);
+
+/* Output shape of the plan for a given direction (HOST). out[3] = {C,H,W}. */
+int glowhip_plan_output_shape(const glowhip_plan* plan, int reverse, int32_t out[3]);
+
+/* Introspection for tests / benchmarks: which kernels a plan will launch ("mfma" or "direct" per
+ * convolution).  Writes a NUL-terminated description into buf. */
+int glowhip_plan_describe(const glowhip_plan* plan, char* buf, size_t buf_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GLOWHIP_H */

@@ -1,0 +1,205 @@
+"""FlowPlan: Python handle of a `glowhip_plan` (include/glowhip.h) built from live nn.Modules.
+
+A plan is the MI355X-native replacement of the reference's Python loop over ``FlowModel.layers``
+(network/model.py:263-294): the layer list is static, so the whole stack (Squeeze2d / FlowStep / Split2d)
+becomes ONE C call that issues a fixed kernel sequence on torch's current HIP stream.  torch only owns
+the memory (parameters, workspace, packed-parameter buffer).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import LayerDesc, check, lib, ptr, stream_ptr
+
+
+def _param_tensors(layer) -> List[torch.Tensor]:
+    return [p for p in layer.parameters()]
+
+
+class FlowPlan:
+    """One executable stack of flow layers for a fixed input (C, H, W) on one device."""
+
+    def __init__(self, layers: Sequence[torch.nn.Module], in_chw, device: torch.device):
+        self.layers = list(layers)
+        self.in_chw = tuple(int(v) for v in in_chw)
+        self.device = torch.device(device)
+        self._keep = []  # tensors whose addresses the C plan holds
+        descs = (LayerDesc * len(self.layers))()
+        c, h, w = self.in_chw
+        for i, layer in enumerate(self.layers):
+            d = descs[i]
+            d.C, d.H, d.W = c, h, w
+            kind = layer.glowhip_kind
+            d.kind = kind
+            if kind == _lib.LAYER_SQUEEZE:
+                if layer.factor != 2:
+                    raise _lib.GlowHipError("flow plans support Squeeze2d(factor=2) only")
+                c, h, w = c * 4, h // 2, w // 2
+            elif kind == _lib.LAYER_FLOWSTEP:
+                self._fill_flowstep(d, layer)
+            else:
+                self._fill_split(d, layer)
+                c = c // 2
+        self.out_chw = (c, h, w)
+        self._params = [p for layer in self.layers for p in _param_tensors(layer)]
+        for p in self._params:
+            if p.device != self.device:
+                raise _lib.GlowHipError(f"parameter on {p.device}, plan on {self.device}")
+        self._ptr_sig = self._pointer_signature()
+        handle = lib().glowhip_plan_create(descs, len(self.layers))
+        if not handle:
+            raise _lib.GlowHipError("glowhip_plan_create: " + lib().glowhip_last_error().decode())
+        self._h = ctypes.c_void_p(handle)
+        self._descs = descs
+        self.packed_bytes = int(lib().glowhip_plan_packed_bytes(self._h))
+        self.packed = torch.empty(max(self.packed_bytes, 256), dtype=torch.uint8, device=self.device)
+        self._packed_version = None
+        self._ws: Optional[torch.Tensor] = None
+        self.n_split = sum(1 for l in self.layers if l.glowhip_kind == _lib.LAYER_SPLIT2D)
+
+    # ------------------------------------------------------------------ construction helpers
+    def _dev(self, t: torch.Tensor) -> int:
+        if not t.is_cuda:
+            raise _lib.GlowHipError("flow plans need parameters on a HIP device (module.cuda() first)")
+        if not t.is_contiguous() or t.dtype != torch.float32:
+            raise _lib.GlowHipError("parameters must be contiguous fp32")
+        self._keep.append(t)
+        return t.data_ptr()
+
+    def _fill_flowstep(self, d: LayerDesc, step) -> None:
+        d.hidden = step.hidden_channels
+        d.coupling = _lib.COUPLING_AFFINE if step.coupling == 'affine' else _lib.COUPLING_ADDITIVE
+        d.an_bias, d.an_logs = self._dev(step.actnorm.bias), self._dev(step.actnorm.logs)
+        if step.permutation == 'invconv':
+            d.permutation = _lib.PERM_INVCONV
+            d.invconv_w = self._dev(step.invconv.weight)
+        else:
+            d.permutation = _lib.PERM_GATHER
+            perm = getattr(step, step.permutation)
+            idx, inv = perm.device_tables(self.device)
+            self._keep += [idx, inv]
+            d.perm_idx, d.perm_idx_inv = idx.data_ptr(), inv.data_ptr()
+        f0, f2, f4 = step.f[0], step.f[2], step.f[4]
+        d.f0_w, d.f0_an_bias, d.f0_an_logs = self._dev(f0.weight), self._dev(f0.actnorm.bias), self._dev(f0.actnorm.logs)
+        d.f2_w, d.f2_an_bias, d.f2_an_logs = self._dev(f2.weight), self._dev(f2.actnorm.bias), self._dev(f2.actnorm.logs)
+        d.f4_w, d.f4_bias, d.f4_logs = self._dev(f4.weight), self._dev(f4.bias), self._dev(f4.logs)
+
+    def _fill_split(self, d: LayerDesc, split) -> None:
+        cz = split.conv2d_zeros
+        d.f4_w, d.f4_bias, d.f4_logs = self._dev(cz.weight), self._dev(cz.bias), self._dev(cz.logs)
+
+    def _pointer_signature(self):
+        return tuple(p.data_ptr() for p in self._params)
+
+    def _version_signature(self):
+        return tuple(p._version for p in self._params)
+
+    def still_valid(self) -> bool:
+        """False when a parameter was re-allocated (module moved / parameter replaced): rebuild the plan."""
+        return self._pointer_signature() == self._ptr_sig
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                lib().glowhip_plan_destroy(h)
+            except Exception:
+                pass
+
+    # ------------------------------------------------------------------ execution
+    def _workspace(self, n: int) -> torch.Tensor:
+        need = int(lib().glowhip_plan_workspace_bytes(self._h, n))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def pack(self) -> None:
+        """Refresh everything derived from the parameters (exp(3 logs), MFMA weight images, LU)."""
+        check(lib().glowhip_plan_pack(self._h, ptr(self.packed), self.packed.numel(), stream_ptr(self.device)))
+        self._packed_version = self._version_signature()
+
+    def ensure_packed(self, force: bool = False) -> None:
+        if force or self._packed_version != self._version_signature():
+            self.pack()
+
+    def invalidate(self) -> None:
+        self._packed_version = None
+
+    def describe(self) -> str:
+        buf = ctypes.create_string_buffer(1 << 16)
+        check(lib().glowhip_plan_describe(self._h, buf, len(buf)))
+        return buf.value.decode()
+
+    def encode(self, x, noise=None, logdet=None, want_logdet=True, repack=False):
+        n = x.shape[0]
+        assert tuple(x.shape[1:]) == self.in_chw, (x.shape, self.in_chw)
+        self.ensure_packed(repack)
+        z = torch.empty((n,) + self.out_chw, dtype=torch.float32, device=self.device)
+        ld_out = torch.empty(n, dtype=torch.float32, device=self.device) if want_logdet else None
+        ws = self._workspace(n)
+        check(lib().glowhip_plan_encode(self._h, ptr(self.packed), ptr(x), ptr(noise), ptr(logdet), ptr(z), ptr(ld_out), n,
+                                        ptr(ws), ws.numel(), stream_ptr(self.device)))
+        return z, ld_out
+
+    def decode(self, z, eps: Sequence[torch.Tensor], logdet=None, want_logdet=False, repack=False):
+        n = z.shape[0]
+        assert tuple(z.shape[1:]) == self.out_chw, (z.shape, self.out_chw)
+        assert len(eps) >= self.n_split
+        self.ensure_packed(repack)
+        x = torch.empty((n,) + self.in_chw, dtype=torch.float32, device=self.device)
+        ld_out = torch.empty(n, dtype=torch.float32, device=self.device) if want_logdet else None
+        ws = self._workspace(n)
+        arr = (ctypes.c_void_p * max(len(eps), 1))(*[e.data_ptr() for e in eps])
+        check(lib().glowhip_plan_decode(self._h, ptr(self.packed), ptr(z), arr, len(eps), ptr(logdet), ptr(x), ptr(ld_out),
+                                        n, ptr(ws), ws.numel(), stream_ptr(self.device)))
+        return x, ld_out
+
+    def glow_forward(self, x, noise, prior_mean, prior_logs, prior_stride, n_bits, repack=False, out=None):
+        n = x.shape[0]
+        self.ensure_packed(repack)
+        if out is None:
+            z = torch.empty((n,) + self.out_chw, dtype=torch.float32, device=self.device)
+            nll = torch.empty(n, dtype=torch.float32, device=self.device)
+            obj = torch.empty(n, dtype=torch.float32, device=self.device)
+        else:
+            z, nll, obj = out
+        ws = self._workspace(n)
+        check(lib().glowhip_glow_forward(self._h, ptr(self.packed), ptr(x), ptr(noise), ptr(prior_mean), ptr(prior_logs),
+                                         prior_stride, n_bits, ptr(z), ptr(nll), ptr(obj), n, ptr(ws), ws.numel(),
+                                         stream_ptr(self.device)))
+        return z, nll, obj
+
+    def actnorm_init(self, x, noise, actnorm_scale: float) -> None:
+        """Data-dependent init of every ActNorm in the plan from batch x (writes the parameters in place)."""
+        n = x.shape[0]
+        ws = self._workspace(n)
+        check(lib().glowhip_plan_actnorm_init(self._h, ptr(self.packed), self.packed.numel(), ptr(x), ptr(noise),
+                                              float(actnorm_scale), n, ptr(ws), ws.numel(), stream_ptr(self.device)))
+        self._packed_version = self._version_signature()
+
+
+class PlanCache:
+    """Per-module cache of FlowPlans keyed by (input CHW, device); rebuilt when parameters move."""
+
+    def __init__(self):
+        self._plans = {}
+
+    def get(self, layers, in_chw, device) -> FlowPlan:
+        key = (tuple(in_chw), str(device))
+        plan = self._plans.get(key)
+        if plan is None or not plan.still_valid():
+            plan = FlowPlan(layers, in_chw, device)
+            self._plans[key] = plan
+        return plan
+
+    def clear(self):
+        self._plans.clear()
+
+    def invalidate(self):
+        for p in self._plans.values():
+            p.invalidate()

@@ -1,0 +1,83 @@
+// common.h -- shared device helpers and host-side error plumbing for libglowhip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "../../include/glowhip.h"
+
+namespace glowhip {
+
+void set_error(const char* fmt, ...);
+
+#define GH_REQUIRE(cond, ...)                    \
+    do {                                         \
+        if (!(cond)) {                           \
+            ::glowhip::set_error(__VA_ARGS__);   \
+            return GLOWHIP_EINVAL;               \
+        }                                        \
+    } while (0)
+
+#define GH_LAUNCH_CHECK(name)                                                        \
+    do {                                                                             \
+        hipError_t e_ = hipGetLastError();                                           \
+        if (e_ != hipSuccess) {                                                      \
+            ::glowhip::set_error("%s: %s", name, hipGetErrorString(e_));             \
+            return GLOWHIP_ELAUNCH;                                                  \
+        }                                                                            \
+    } while (0)
+
+#define GH_TRY(expr)               \
+    do {                           \
+        int rc_ = (expr);          \
+        if (rc_ != GLOWHIP_OK) return rc_; \
+    } while (0)
+
+constexpr float LOG_2PI_F = 1.8378770664093453f;
+constexpr float LOGSCALE = 3.0f;  // network/module.py:10 logscale_factor
+
+// ---- per-sample log-determinant accumulators ---------------------------------------------------
+// Kept as signed Q31.32 fixed point in a u64 so that atomic accumulation from many workgroups is
+// order-independent (bitwise reproducible), unlike float atomics.
+constexpr double FIX_SCALE = 4294967296.0;
+__device__ __forceinline__ void fix_atomic_add(unsigned long long* acc, double v) {
+    long long q = __double2ll_rn(v * FIX_SCALE);
+    atomicAdd(acc, (unsigned long long)q);
+}
+__device__ __forceinline__ double fix_to_double(unsigned long long a) {
+    return (double)(long long)a * (1.0 / FIX_SCALE);
+}
+
+// ---- wave64 / workgroup reductions (fixed tree => deterministic) ------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;  // valid in lane 0
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+// Sum over a workgroup of NT threads; result valid in thread 0.  red: NT/64 doubles of LDS.
+template <int NT>
+__device__ __forceinline__ double block_sum(double v, double* red) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane == 0) red[wid] = v;
+    __syncthreads();
+    double t = 0.0;
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < NT / 64; ++i) t += red[i];
+    }
+    __syncthreads();
+    return t;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace glowhip

@@ -1,0 +1,43 @@
+// conv_mfma.h -- MFMA (fp32-input, exact fp32) convolution kernels of the coupling network.
+#pragma once
+#include "common.h"
+
+namespace glowhip {
+
+// "Wide" convolutions: many output channels (hidden), ActNorm + ReLU epilogue (f.0 3x3 and f.2 1x1 of
+// network/module.py:300-319).  Implicit GEMM  Y[o][pixel] = sum_k Wt[k][o] * im2col(X)[k][pixel].
+bool conv_mfma_wide_supported(int Cin, int H, int W, int Cout, int ksize);
+size_t conv_mfma_wide_packed_bytes(int Cin, int Cout, int ksize);
+int conv_mfma_wide_pack(const float* w, int Cin, int Cout, int ksize, float* wt, hipStream_t s);
+int launch_conv_mfma_wide(const float* x, long x_bs, const float* wt, const float* post_bias, const float* post_scale,
+                          float* y, int N, int Cin, int H, int W, int Cout, int ksize, hipStream_t s);
+
+// "Tail" convolution: 3x3, few output channels (f.4 / Split2d prior), with the coupling / prior
+// arithmetic and the per-sample log-det reduction fused into the epilogue.
+enum TailMode {
+    TAIL_PLAIN = 0,      // y = (conv + bias) * scale                      -> z2_out (N,Cout,HW)
+    TAIL_AFFINE_FWD,     // z2 = (z2 + shift) * sigmoid(s + 2), acc += sum log sigmoid
+    TAIL_AFFINE_REV,     // z2 = z2 / sigmoid(s + 2) - shift,  acc -= sum log sigmoid
+    TAIL_ADD_FWD,        // z2 = z2 + h
+    TAIL_ADD_REV,        // z2 = z2 - h
+    TAIL_SPLIT_FWD,      // acc += logp(z2 | mean, logs)
+    TAIL_SPLIT_REV,      // z2_out = mean + exp(logs) * eps   (eps passed as z2_in)
+};
+struct TailConvArgs {
+    const float* x; long x_bs;   // (N,Cin,H,W)
+    const float* wp;             // packed weights (conv_mfma_tail_pack)
+    const float* bias;           // (Cout)
+    const float* scale;          // (Cout) exp(3 logs)
+    int N, Cin, H, W, Cout;
+    int mode;
+    const float* z2_in; long z2_in_bs;
+    float* z2_out; long z2_out_bs;
+    unsigned long long* acc;
+};
+bool conv_mfma_tail_supported(int Cin, int H, int W, int Cout);
+size_t conv_mfma_tail_packed_bytes(int Cin, int Cout);
+// paired=1: output channels come in (even, odd) = (shift|mean, scale|logs) pairs (affine coupling, Split2d)
+int conv_mfma_tail_pack(const float* w, int Cin, int Cout, int paired, float* wp, hipStream_t s);
+int launch_conv_mfma_tail(const TailConvArgs& a, hipStream_t s);
+
+}  // namespace glowhip

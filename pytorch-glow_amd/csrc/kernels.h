@@ -1,0 +1,78 @@
+// kernels.h -- internal launcher interface between the plan executor / C-ABI and the kernel files.
+#pragma once
+#include "common.h"
+
+namespace glowhip {
+
+// ---------------------------------------------------------------- pointwise.hip
+int launch_squeeze(const float* x, const float* noise, float* y, int N, int C, int H, int W, int f, int reverse,
+                   hipStream_t s);
+int launch_copy_strided(const float* x, long xbs, float* y, long ybs, int N, long per_sample, hipStream_t s);
+int launch_actnorm_init(const float* x, long xbs, int N, int C, int HW, float scale, float* bias, float* logs,
+                        hipStream_t s);
+
+// Channel mixer: the ActNorm + (Invertible1x1Conv | Permutation2d) pair of a FlowStep as ONE pass.
+struct ChanMixArgs {
+    const float* in_a; long in_a_bs;  // channels [0, Ca)
+    const float* in_b; long in_b_bs;  // channels [Ca, C)  (element (n,c,p) at in_b[n*bs + (c-Ca)*HW + p])
+    int Ca;
+    float* out; long out_bs;
+    const float* bias;     // (C) or null: no ActNorm
+    const float* scale;    // (C) exp(+3 logs) for forward, exp(-3 logs) for reverse
+    const float* matrix;   // (C,C) row-major matrix to apply, or null
+    const int32_t* gather; // (C) channel gather table, or null
+    int reverse;           // 0: actnorm then mix; 1: mix then inverse actnorm
+    int N, C, HW;
+};
+int launch_chanmix(const ChanMixArgs& a, hipStream_t s);
+
+int launch_add_const_logdet(const float* in, float* out, int N, const float* term_a, float mul_a, int count_a,
+                            float sign, hipStream_t s);
+
+// tails of the generic path
+struct CouplingTailArgs {
+    const float* h;        // (N, Cout, HW) contiguous: coupling-net output
+    const float* z2_in; long z2_in_bs;
+    float* z2_out; long z2_out_bs;
+    int N, Ch, HW;         // Ch = channels of z2
+    int affine, reverse;
+    unsigned long long* acc;  // (N) fixed-point logdet accumulators (affine only)
+};
+int launch_coupling_tail(const CouplingTailArgs& a, hipStream_t s);
+
+struct SplitTailArgs {
+    const float* h;        // (N, 2*Ch, HW): prior conv output, mean = even, logs = odd channels
+    const float* z2; long z2_bs;   // forward: z2 to score
+    const float* eps;      // reverse: (N,Ch,HW) injected draw
+    float* z2_out; long z2_out_bs; // reverse: sampled z2
+    int N, Ch, HW, reverse;
+    unsigned long long* acc;
+};
+int launch_split_tail(const SplitTailArgs& a, hipStream_t s);
+
+int launch_gaussian_logp(const float* x, long xbs, const float* mean, const float* logs, long mlbs, int N, int C,
+                         int HW, unsigned long long* acc, hipStream_t s);
+int launch_zero_acc(unsigned long long* acc, int N, hipStream_t s);
+// out[n] = scale * ((in ? in[n] : 0) + offset + sign*(konst ? *konst : 0) + fix(acc[n]))
+int launch_finalize(const float* in, const unsigned long long* acc, const double* konst, double sign, double offset,
+                    double scale, float* out, float* out_unscaled, int N, hipStream_t s);
+
+// ---------------------------------------------------------------- lu.hip
+size_t invconv_scratch_bytes(int C);
+int launch_invconv_prepare(const float* w, int C, float* winv, float* logabsdet, void* scratch, hipStream_t s);
+
+// ---------------------------------------------------------------- conv_direct.hip
+struct ConvArgs {
+    const float* x; long x_bs;
+    const float* w;          // (Cout,Cin,k,k) reference layout
+    const float* bias;       // (Cout) or null, added before post_bias
+    const float* post_bias;  // (Cout) or null
+    const float* post_logs;  // (Cout) or null -> * exp(3*logs)
+    const float* post_scale; // (Cout) or null -> * scale (precomputed exp(3*logs)); wins over post_logs
+    int relu;
+    float* y;                // (N,Cout,H,W) contiguous
+    int N, Cin, H, W, Cout, ksize;
+};
+int launch_conv_direct(const ConvArgs& a, hipStream_t s);
+
+}  // namespace glowhip

@@ -1,0 +1,564 @@
+// plan.hip -- flow plans: the host-side executor that turns a FlowModel (Squeeze2d / FlowStep /
+// Split2d stack, network/model.py:230-294) into a fixed sequence of kernel launches on one HIP stream.
+// There is no tracing compiler: the layer list is static, so the launch sequence is built once and
+// replayed; all scratch comes from a caller-provided workspace, all parameter-derived data (exp(3 logs),
+// K-major MFMA weight images, W^-1, log|det W|) from a caller-provided `packed` buffer refreshed by
+// glowhip_plan_pack.
+#include <math.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+#include "conv_mfma.h"
+
+namespace glowhip {
+
+struct LayerPlan {
+    glowhip_layer_desc d;
+    int Cout = 0;  // output channels of f.4 / of the Split2d prior conv
+    // byte offsets into the packed buffer
+    size_t an_scale = 0, an_inv_scale = 0, winv = 0, logabsdet = 0, konst = 0, lu_scratch = 0;
+    size_t f0_scale = 0, f2_scale = 0, f4_scale = 0;
+    size_t f0_wt = 0, f2_wt = 0, f4_wp = 0;
+    bool mfma_first = false, mfma_mid = false, mfma_last = false;
+};
+
+}  // namespace glowhip
+
+using namespace glowhip;
+
+struct glowhip_plan {
+    std::vector<LayerPlan> layers;
+    size_t packed_bytes = 0;
+    int in_shape[3] = {0, 0, 0}, out_shape[3] = {0, 0, 0};
+    long max_chw = 0;      // max over layer inputs/outputs of C*H*W
+    long max_hidden = 0;   // max over steps of max(hidden, Cout) * H*W
+    int n_split = 0;
+};
+
+namespace glowhip {
+
+static size_t take(size_t& off, size_t bytes) {
+    size_t o = align_up(off, 256);
+    off = o + bytes;
+    return o;
+}
+
+// ---------------------------------------------------------------- pack kernels
+__global__ void __launch_bounds__(256) k_pack_scales(const float* __restrict__ logs, int n, float* __restrict__ scale,
+                                                     float* __restrict__ inv_scale) {
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float l3 = logs[i] * LOGSCALE;
+    scale[i] = expf(l3);
+    if (inv_scale) inv_scale[i] = expf(-l3);
+}
+
+// konst = 3*sum(an_logs)*HW (+ log|det W|*HW); also accumulated into the plan-wide total.
+__global__ void __launch_bounds__(64) k_step_konst(const float* __restrict__ an_logs, int C,
+                                                   const float* __restrict__ logabsdet, int HW,
+                                                   double* __restrict__ konst, double* __restrict__ total) {
+    double acc = 0.0;
+    for (int k = threadIdx.x; k < C; k += 64) acc += (double)(an_logs[k] * LOGSCALE);
+    acc = wave_sum(acc);
+    if (threadIdx.x == 0) {
+        double v = acc * (double)HW;
+        if (logabsdet) v += (double)logabsdet[0] * (double)HW;
+        konst[0] = v;
+        total[0] += v;  // launches are serialised on the stream => deterministic order
+    }
+}
+
+static int pack_scales(const float* logs, int n, float* scale, float* inv, hipStream_t s) {
+    hipLaunchKernelGGL(k_pack_scales, dim3(cdiv(n, 256)), dim3(256), 0, s, logs, n, scale, inv);
+    GH_LAUNCH_CHECK("k_pack_scales");
+    return GLOWHIP_OK;
+}
+
+template <typename T>
+static T* at(const void* base, size_t off) {
+    return (T*)((char*)base + off);
+}
+
+// Workspace carving
+struct Workspace {
+    unsigned long long* acc;
+    float* bufA;
+    float* bufB;
+    float* h1;
+    float* h2;
+};
+
+static size_t workspace_bytes(const glowhip_plan* p, int N) {
+    size_t off = 0;
+    take(off, (size_t)N * 8);
+    take(off, (size_t)N * p->max_chw * 4);
+    take(off, (size_t)N * p->max_chw * 4);
+    take(off, (size_t)N * p->max_hidden * 4);
+    take(off, (size_t)N * p->max_hidden * 4);
+    return align_up(off, 256);
+}
+
+static int carve(const glowhip_plan* p, int N, void* ws, size_t bytes, Workspace& w) {
+    if (bytes < workspace_bytes(p, N) || ws == nullptr) {
+        set_error("workspace too small: need %zu bytes, got %zu", workspace_bytes(p, N), bytes);
+        return GLOWHIP_EWORKSPACE;
+    }
+    size_t off = 0;
+    w.acc = at<unsigned long long>(ws, take(off, (size_t)N * 8));
+    w.bufA = at<float>(ws, take(off, (size_t)N * p->max_chw * 4));
+    w.bufB = at<float>(ws, take(off, (size_t)N * p->max_chw * 4));
+    w.h1 = at<float>(ws, take(off, (size_t)N * p->max_hidden * 4));
+    w.h2 = at<float>(ws, take(off, (size_t)N * p->max_hidden * 4));
+    return GLOWHIP_OK;
+}
+
+// ---------------------------------------------------------------- coupling network f() (network/module.py:300-319)
+// Runs conv3x3 -> actnorm -> relu -> conv1x1 -> actnorm -> relu -> conv3x3(zeros) and applies the
+// coupling to z2.  x1: first-half channels (batch stride x1_bs).
+static int run_coupling(const LayerPlan& L, const void* packed, const float* x1, long x1_bs, const float* z2_in,
+                        long z2_in_bs, float* z2_out, long z2_out_bs, int N, int reverse, const Workspace& w,
+                        hipStream_t s) {
+    const glowhip_layer_desc& d = L.d;
+    const int Ch = d.C / 2, HW = d.H * d.W, hid = d.hidden;
+    // f.0: 3x3, Cin=C/2 -> hidden, ActNorm + ReLU epilogue
+    if (L.mfma_first) {
+        GH_TRY(launch_conv_mfma_wide(x1, x1_bs, at<float>(packed, L.f0_wt), d.f0_an_bias, at<float>(packed, L.f0_scale),
+                                     w.h1, N, Ch, d.H, d.W, hid, 3, s));
+    } else {
+        ConvArgs c{x1, x1_bs, d.f0_w, nullptr, d.f0_an_bias, nullptr, at<float>(packed, L.f0_scale), 1, w.h1,
+                   N, Ch, d.H, d.W, hid, 3};
+        GH_TRY(launch_conv_direct(c, s));
+    }
+    // f.2: 1x1, hidden -> hidden, ActNorm + ReLU epilogue
+    if (L.mfma_mid) {
+        GH_TRY(launch_conv_mfma_wide(w.h1, (long)hid * HW, at<float>(packed, L.f2_wt), d.f2_an_bias,
+                                     at<float>(packed, L.f2_scale), w.h2, N, hid, d.H, d.W, hid, 1, s));
+    } else {
+        ConvArgs c{w.h1, (long)hid * HW, d.f2_w, nullptr, d.f2_an_bias, nullptr, at<float>(packed, L.f2_scale), 1, w.h2,
+                   N, hid, d.H, d.W, hid, 1};
+        GH_TRY(launch_conv_direct(c, s));
+    }
+    // f.4: 3x3 zeros conv (+bias, *exp(3 logs)) and the coupling itself
+    if (L.mfma_last) {
+        TailConvArgs t{};
+        t.x = w.h2; t.x_bs = (long)hid * HW; t.wp = at<float>(packed, L.f4_wp); t.bias = d.f4_bias;
+        t.scale = at<float>(packed, L.f4_scale);
+        t.N = N; t.Cin = hid; t.H = d.H; t.W = d.W; t.Cout = L.Cout;
+        t.mode = d.coupling == GLOWHIP_COUPLING_AFFINE ? (reverse ? TAIL_AFFINE_REV : TAIL_AFFINE_FWD)
+                                                       : (reverse ? TAIL_ADD_REV : TAIL_ADD_FWD);
+        t.z2_in = z2_in; t.z2_in_bs = z2_in_bs; t.z2_out = z2_out; t.z2_out_bs = z2_out_bs; t.acc = w.acc;
+        GH_TRY(launch_conv_mfma_tail(t, s));
+    } else {
+        ConvArgs c{w.h2, (long)hid * HW, d.f4_w, d.f4_bias, nullptr, nullptr, at<float>(packed, L.f4_scale), 0, w.h1,
+                   N, hid, d.H, d.W, L.Cout, 3};
+        GH_TRY(launch_conv_direct(c, s));
+        CouplingTailArgs t{w.h1, z2_in, z2_in_bs, z2_out, z2_out_bs, N, Ch, HW,
+                           d.coupling == GLOWHIP_COUPLING_AFFINE, reverse, w.acc};
+        GH_TRY(launch_coupling_tail(t, s));
+    }
+    return GLOWHIP_OK;
+}
+
+// Split2d prior conv + tail (network/module.py:498-536).  d.C = channels of the un-split tensor.
+static int run_split(const LayerPlan& L, const void* packed, const float* z1, long z1_bs, const float* z2, long z2_bs,
+                     const float* eps, float* z2_out, long z2_out_bs, int N, int reverse, const Workspace& w,
+                     hipStream_t s) {
+    const glowhip_layer_desc& d = L.d;
+    const int Ch = d.C / 2, HW = d.H * d.W;
+    if (L.mfma_last) {
+        TailConvArgs t{};
+        t.x = z1; t.x_bs = z1_bs; t.wp = at<float>(packed, L.f4_wp); t.bias = d.f4_bias;
+        t.scale = at<float>(packed, L.f4_scale);
+        t.N = N; t.Cin = Ch; t.H = d.H; t.W = d.W; t.Cout = L.Cout;
+        t.mode = reverse ? TAIL_SPLIT_REV : TAIL_SPLIT_FWD;
+        t.z2_in = reverse ? eps : z2; t.z2_in_bs = reverse ? (long)Ch * HW : z2_bs;
+        t.z2_out = z2_out; t.z2_out_bs = z2_out_bs; t.acc = w.acc;
+        GH_TRY(launch_conv_mfma_tail(t, s));
+    } else {
+        ConvArgs c{z1, z1_bs, d.f4_w, d.f4_bias, nullptr, nullptr, at<float>(packed, L.f4_scale), 0, w.h1,
+                   N, Ch, d.H, d.W, L.Cout, 3};
+        GH_TRY(launch_conv_direct(c, s));
+        SplitTailArgs t{w.h1, z2, z2_bs, eps, z2_out, z2_out_bs, N, Ch, HW, reverse, w.acc};
+        GH_TRY(launch_split_tail(t, s));
+    }
+    return GLOWHIP_OK;
+}
+
+static float* other_buf(const Workspace& w, const float* cur) { return cur == w.bufA ? w.bufB : w.bufA; }
+
+// ---------------------------------------------------------------- encode (network/model.py:263-276)
+static int run_forward(glowhip_plan* p, const void* packed, const float* x, const float* noise, float* z_out, int N,
+                       const Workspace& w, hipStream_t s) {
+    const float* cur = x;
+    const int nl = (int)p->layers.size();
+    for (int li = 0; li < nl; ++li) {
+        const LayerPlan& L = p->layers[li];
+        const glowhip_layer_desc& d = L.d;
+        float* dst = (li == nl - 1) ? z_out : other_buf(w, cur);
+        const int HW = d.H * d.W;
+        const long chw = (long)d.C * HW;
+        if (d.kind == GLOWHIP_LAYER_SQUEEZE) {
+            GH_TRY(launch_squeeze(cur, noise, dst, N, d.C, d.H, d.W, 2, 0, s));
+            noise = nullptr;
+        } else {
+            if (noise) {  // dequantisation noise with no leading squeeze (only possible at layer 0, cur == x):
+                          // the identity "squeeze" (factor 1) adds it into a workspace buffer
+                GH_TRY(launch_squeeze(cur, noise, w.bufA, N, d.C, d.H, d.W, 1, 0, s));
+                cur = w.bufA;
+                noise = nullptr;
+                if (li != nl - 1) dst = w.bufB;
+            }
+            const int Ch = d.C / 2;
+            if (d.kind == GLOWHIP_LAYER_FLOWSTEP) {
+                ChanMixArgs m{};
+                m.in_a = cur; m.in_a_bs = chw; m.in_b = cur + (long)Ch * HW; m.in_b_bs = chw; m.Ca = Ch;
+                m.out = dst; m.out_bs = chw;
+                m.bias = d.an_bias; m.scale = at<float>(packed, L.an_scale);
+                m.matrix = d.permutation == GLOWHIP_PERM_INVCONV ? d.invconv_w : nullptr;
+                m.gather = d.permutation == GLOWHIP_PERM_GATHER ? d.perm_idx : nullptr;
+                m.reverse = 0; m.N = N; m.C = d.C; m.HW = HW;
+                GH_TRY(launch_chanmix(m, s));
+                float* z2 = dst + (long)Ch * HW;
+                GH_TRY(run_coupling(L, packed, dst, chw, z2, chw, z2, chw, N, 0, w, s));
+            } else {  // SPLIT2D: score z2 under the prior predicted from z1, keep z1
+                GH_TRY(run_split(L, packed, cur, chw, cur + (long)Ch * HW, chw, nullptr, nullptr, 0, N, 0, w, s));
+                GH_TRY(launch_copy_strided(cur, chw, dst, (long)Ch * HW, N, (long)Ch * HW, s));
+            }
+        }
+        cur = dst;
+    }
+    return GLOWHIP_OK;
+}
+
+// ---------------------------------------------------------------- decode (network/model.py:278-294)
+static int run_reverse(glowhip_plan* p, const void* packed, const float* z, const float* const* eps, int n_eps,
+                       float* x_out, int N, const Workspace& w, hipStream_t s) {
+    const float* cur = z;
+    const int nl = (int)p->layers.size();
+    int ke = 0;
+    for (int li = nl - 1; li >= 0; --li) {
+        const LayerPlan& L = p->layers[li];
+        const glowhip_layer_desc& d = L.d;
+        float* dst = (li == 0) ? x_out : other_buf(w, cur);
+        const int HW = d.H * d.W;
+        const long chw = (long)d.C * HW;
+        const int Ch = d.C / 2;
+        if (d.kind == GLOWHIP_LAYER_SQUEEZE) {
+            GH_TRY(launch_squeeze(cur, nullptr, dst, N, d.C * 4, d.H / 2, d.W / 2, 2, 1, s));
+        } else if (d.kind == GLOWHIP_LAYER_FLOWSTEP) {
+            float* z2 = dst + (long)Ch * HW;
+            GH_TRY(run_coupling(L, packed, cur, chw, cur + (long)Ch * HW, chw, z2, chw, N, 1, w, s));
+            ChanMixArgs m{};
+            m.in_a = cur; m.in_a_bs = chw; m.in_b = z2; m.in_b_bs = chw; m.Ca = Ch;
+            m.out = dst; m.out_bs = chw;
+            m.bias = d.an_bias; m.scale = at<float>(packed, L.an_inv_scale);
+            m.matrix = d.permutation == GLOWHIP_PERM_INVCONV ? at<float>(packed, L.winv) : nullptr;
+            m.gather = d.permutation == GLOWHIP_PERM_GATHER ? d.perm_idx_inv : nullptr;
+            m.reverse = 1; m.N = N; m.C = d.C; m.HW = HW;
+            GH_TRY(launch_chanmix(m, s));
+        } else {  // SPLIT2D reverse: z1 = cur (N, C/2, HW) -> cat(z1, mean + exp(logs)*eps)
+            GH_REQUIRE(ke < n_eps && eps && eps[ke], "decode: missing eps draw for Split2d #%d", ke);
+            GH_TRY(run_split(L, packed, cur, (long)Ch * HW, nullptr, 0, eps[ke], dst + (long)Ch * HW, chw, N, 1, w, s));
+            GH_TRY(launch_copy_strided(cur, (long)Ch * HW, dst, chw, N, (long)Ch * HW, s));
+            ++ke;
+        }
+        cur = dst;
+    }
+    return GLOWHIP_OK;
+}
+
+static int check_plan_args(const glowhip_plan* plan, const void* packed, int N) {
+    GH_REQUIRE(plan != nullptr, "null plan");
+    GH_REQUIRE(packed != nullptr, "null packed-parameter buffer (call glowhip_plan_pack first)");
+    GH_REQUIRE(N >= 0 && N <= 65535, "batch size %d out of range", N);
+    return GLOWHIP_OK;
+}
+
+}  // namespace glowhip
+
+// ================================================================================================ C ABI
+extern "C" {
+
+glowhip_plan* glowhip_plan_create(const glowhip_layer_desc* layers, int n_layers) {
+    if (!layers || n_layers <= 0) {
+        set_error("plan_create: empty layer list");
+        return nullptr;
+    }
+    glowhip_plan* p = new glowhip_plan();
+    size_t off = 0;
+    take(off, sizeof(double));  // plan-wide data-independent log-det total at offset 0
+    int C = layers[0].C, H = layers[0].H, W = layers[0].W;
+    p->in_shape[0] = C; p->in_shape[1] = H; p->in_shape[2] = W;
+    for (int i = 0; i < n_layers; ++i) {
+        LayerPlan L;
+        L.d = layers[i];
+        const glowhip_layer_desc& d = L.d;
+        auto fail = [&](const char* why) {
+            set_error("plan_create: layer %d: %s (kind=%d C=%d H=%d W=%d)", i, why, d.kind, d.C, d.H, d.W);
+            delete p;
+            return (glowhip_plan*)nullptr;
+        };
+        if (d.C != C || d.H != H || d.W != W) return fail("input shape does not chain from the previous layer");
+        if (d.C <= 0 || d.H <= 0 || d.W <= 0) return fail("empty shape");
+        p->max_chw = std::max(p->max_chw, (long)C * H * W);
+        if (d.kind == GLOWHIP_LAYER_SQUEEZE) {
+            if (H % 2 || W % 2) return fail("squeeze needs even H and W");
+            C *= 4; H /= 2; W /= 2;
+        } else if (d.kind == GLOWHIP_LAYER_FLOWSTEP) {
+            if (C % 2) return fail("FlowStep needs an even channel count");  // network/model.py:169
+            if (d.hidden <= 0) return fail("hidden_channels must be positive");
+            if (!d.an_bias || !d.an_logs || !d.f0_w || !d.f0_an_bias || !d.f0_an_logs || !d.f2_w || !d.f2_an_bias ||
+                !d.f2_an_logs || !d.f4_w || !d.f4_bias || !d.f4_logs)
+                return fail("missing parameter pointer");
+            if (d.permutation == GLOWHIP_PERM_INVCONV) {
+                if (!d.invconv_w) return fail("missing invconv weight");
+            } else if (d.permutation == GLOWHIP_PERM_GATHER) {
+                if (!d.perm_idx || !d.perm_idx_inv) return fail("missing permutation tables");
+            } else return fail("unknown permutation");
+            if (d.coupling != GLOWHIP_COUPLING_ADDITIVE && d.coupling != GLOWHIP_COUPLING_AFFINE)
+                return fail("unknown coupling");
+            L.Cout = d.coupling == GLOWHIP_COUPLING_AFFINE ? C : C / 2;
+            L.an_scale = take(off, (size_t)C * 4);
+            L.an_inv_scale = take(off, (size_t)C * 4);
+            L.winv = take(off, (size_t)C * C * 4);
+            L.logabsdet = take(off, 4);
+            L.konst = take(off, 8);
+            L.lu_scratch = take(off, invconv_scratch_bytes(C));
+            L.f0_scale = take(off, (size_t)d.hidden * 4);
+            L.f2_scale = take(off, (size_t)d.hidden * 4);
+            L.f4_scale = take(off, (size_t)L.Cout * 4);
+            L.mfma_first = conv_mfma_wide_supported(C / 2, H, W, d.hidden, 3);
+            L.mfma_mid = conv_mfma_wide_supported(d.hidden, H, W, d.hidden, 1);
+            L.mfma_last = conv_mfma_tail_supported(d.hidden, H, W, L.Cout);
+            if (L.mfma_first) L.f0_wt = take(off, conv_mfma_wide_packed_bytes(C / 2, d.hidden, 3));
+            if (L.mfma_mid) L.f2_wt = take(off, conv_mfma_wide_packed_bytes(d.hidden, d.hidden, 1));
+            if (L.mfma_last) L.f4_wp = take(off, conv_mfma_tail_packed_bytes(d.hidden, L.Cout));
+            p->max_hidden = std::max(p->max_hidden, (long)std::max(d.hidden, L.Cout) * H * W);
+        } else if (d.kind == GLOWHIP_LAYER_SPLIT2D) {
+            if (C % 2) return fail("Split2d needs an even channel count");
+            if (!d.f4_w || !d.f4_bias || !d.f4_logs) return fail("missing conv2d_zeros parameter pointer");
+            L.Cout = C;
+            L.f4_scale = take(off, (size_t)C * 4);
+            L.mfma_last = conv_mfma_tail_supported(C / 2, H, W, C);
+            if (L.mfma_last) L.f4_wp = take(off, conv_mfma_tail_packed_bytes(C / 2, C));
+            p->max_hidden = std::max(p->max_hidden, (long)C * H * W);
+            p->n_split++;
+            C /= 2;
+        } else {
+            return fail("unknown layer kind");
+        }
+        p->max_chw = std::max(p->max_chw, (long)C * H * W);
+        p->layers.push_back(L);
+    }
+    p->out_shape[0] = C; p->out_shape[1] = H; p->out_shape[2] = W;
+    p->packed_bytes = align_up(off, 256);
+    return p;
+}
+
+void glowhip_plan_destroy(glowhip_plan* plan) { delete plan; }
+
+size_t glowhip_plan_packed_bytes(const glowhip_plan* plan) { return plan ? plan->packed_bytes : 0; }
+
+size_t glowhip_plan_workspace_bytes(const glowhip_plan* plan, int N) {
+    return (plan && N >= 0) ? workspace_bytes(plan, N) : 0;
+}
+
+int glowhip_plan_output_shape(const glowhip_plan* plan, int reverse, int32_t out[3]) {
+    GH_REQUIRE(plan && out, "plan_output_shape: null argument");
+    for (int i = 0; i < 3; ++i) out[i] = reverse ? plan->in_shape[i] : plan->out_shape[i];
+    return GLOWHIP_OK;
+}
+
+int glowhip_plan_describe(const glowhip_plan* plan, char* buf, size_t buf_bytes) {
+    GH_REQUIRE(plan && buf && buf_bytes > 0, "plan_describe: null argument");
+    std::string sdesc;
+    char line[256];
+    int li = 0;
+    for (const LayerPlan& L : plan->layers) {
+        const glowhip_layer_desc& d = L.d;
+        if (d.kind == GLOWHIP_LAYER_SQUEEZE) snprintf(line, sizeof line, "%d squeeze C=%d H=%d W=%d\n", li, d.C, d.H, d.W);
+        else if (d.kind == GLOWHIP_LAYER_FLOWSTEP)
+            snprintf(line, sizeof line, "%d flowstep C=%d H=%d W=%d hidden=%d f0=%s f2=%s f4=%s\n", li, d.C, d.H, d.W,
+                     d.hidden, L.mfma_first ? "mfma" : "direct", L.mfma_mid ? "mfma" : "direct",
+                     L.mfma_last ? "mfma" : "direct");
+        else snprintf(line, sizeof line, "%d split2d C=%d H=%d W=%d prior=%s\n", li, d.C, d.H, d.W,
+                      L.mfma_last ? "mfma" : "direct");
+        sdesc += line;
+        ++li;
+    }
+    snprintf(buf, buf_bytes, "%s", sdesc.c_str());
+    return GLOWHIP_OK;
+}
+
+static int pack_layer(glowhip_plan* plan, LayerPlan& L, void* packed, hipStream_t s) {
+    const glowhip_layer_desc& d = L.d;
+    double* total = at<double>(packed, 0);
+    if (d.kind == GLOWHIP_LAYER_FLOWSTEP) {
+        const int HW = d.H * d.W;
+        GH_TRY(pack_scales(d.an_logs, d.C, at<float>(packed, L.an_scale), at<float>(packed, L.an_inv_scale), s));
+        GH_TRY(pack_scales(d.f0_an_logs, d.hidden, at<float>(packed, L.f0_scale), nullptr, s));
+        GH_TRY(pack_scales(d.f2_an_logs, d.hidden, at<float>(packed, L.f2_scale), nullptr, s));
+        GH_TRY(pack_scales(d.f4_logs, L.Cout, at<float>(packed, L.f4_scale), nullptr, s));
+        const float* lad = nullptr;
+        if (d.permutation == GLOWHIP_PERM_INVCONV) {
+            GH_TRY(launch_invconv_prepare(d.invconv_w, d.C, at<float>(packed, L.winv), at<float>(packed, L.logabsdet),
+                                          at<void>(packed, L.lu_scratch), s));
+            lad = at<float>(packed, L.logabsdet);
+        }
+        hipLaunchKernelGGL(k_step_konst, dim3(1), dim3(64), 0, s, d.an_logs, d.C, lad, HW, at<double>(packed, L.konst),
+                           total);
+        GH_LAUNCH_CHECK("k_step_konst");
+        if (L.mfma_first) GH_TRY(conv_mfma_wide_pack(d.f0_w, d.C / 2, d.hidden, 3, at<float>(packed, L.f0_wt), s));
+        if (L.mfma_mid) GH_TRY(conv_mfma_wide_pack(d.f2_w, d.hidden, d.hidden, 1, at<float>(packed, L.f2_wt), s));
+        if (L.mfma_last)
+            GH_TRY(conv_mfma_tail_pack(d.f4_w, d.hidden, L.Cout, d.coupling == GLOWHIP_COUPLING_AFFINE,
+                                       at<float>(packed, L.f4_wp), s));
+    } else if (d.kind == GLOWHIP_LAYER_SPLIT2D) {
+        GH_TRY(pack_scales(d.f4_logs, L.Cout, at<float>(packed, L.f4_scale), nullptr, s));
+        if (L.mfma_last) GH_TRY(conv_mfma_tail_pack(d.f4_w, d.C / 2, L.Cout, 1, at<float>(packed, L.f4_wp), s));
+    }
+    return GLOWHIP_OK;
+}
+
+int glowhip_plan_pack(glowhip_plan* plan, void* packed, size_t packed_bytes, glowhip_stream_t stream) {
+    GH_REQUIRE(plan && packed, "plan_pack: null argument");
+    GH_REQUIRE(packed_bytes >= plan->packed_bytes, "plan_pack: packed buffer too small (%zu < %zu)", packed_bytes,
+               plan->packed_bytes);
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(packed, 0, sizeof(double), s) != hipSuccess) {
+        set_error("plan_pack: hipMemsetAsync failed");
+        return GLOWHIP_ELAUNCH;
+    }
+    for (LayerPlan& L : plan->layers) GH_TRY(pack_layer(plan, L, packed, s));
+    return GLOWHIP_OK;
+}
+
+int glowhip_plan_encode(glowhip_plan* plan, const void* packed, const float* x, const float* noise,
+                        const float* logdet_in, float* z, float* logdet_out, int N, void* workspace,
+                        size_t workspace_bytes, glowhip_stream_t stream) {
+    GH_TRY(check_plan_args(plan, packed, N));
+    GH_REQUIRE(x && z, "plan_encode: null tensor");
+    if (N == 0) return GLOWHIP_OK;
+    hipStream_t s = (hipStream_t)stream;
+    Workspace w;
+    GH_TRY(carve(plan, N, workspace, workspace_bytes, w));
+    GH_TRY(launch_zero_acc(w.acc, N, s));
+    GH_TRY(run_forward(plan, packed, x, noise, z, N, w, s));
+    if (logdet_out)
+        GH_TRY(launch_finalize(logdet_in, w.acc, at<double>(packed, 0), 1.0, 0.0, 1.0, logdet_out, nullptr, N, s));
+    return GLOWHIP_OK;
+}
+
+int glowhip_plan_decode(glowhip_plan* plan, const void* packed, const float* z, const float* const* eps, int n_eps,
+                        const float* logdet_in, float* x, float* logdet_out, int N, void* workspace,
+                        size_t workspace_bytes, glowhip_stream_t stream) {
+    GH_TRY(check_plan_args(plan, packed, N));
+    GH_REQUIRE(x && z, "plan_decode: null tensor");
+    GH_REQUIRE(n_eps >= plan->n_split, "plan_decode: %d eps draws given, plan has %d Split2d layers", n_eps,
+               plan->n_split);
+    if (N == 0) return GLOWHIP_OK;
+    hipStream_t s = (hipStream_t)stream;
+    Workspace w;
+    GH_TRY(carve(plan, N, workspace, workspace_bytes, w));
+    GH_TRY(launch_zero_acc(w.acc, N, s));
+    GH_TRY(run_reverse(plan, packed, z, eps, n_eps, x, N, w, s));
+    if (logdet_out)
+        GH_TRY(launch_finalize(logdet_in, w.acc, at<double>(packed, 0), -1.0, 0.0, 1.0, logdet_out, nullptr, N, s));
+    return GLOWHIP_OK;
+}
+
+int glowhip_glow_forward(glowhip_plan* plan, const void* packed, const float* x, const float* noise,
+                         const float* prior_mean, const float* prior_logs, long prior_stride, int n_bits, float* z,
+                         float* nll_out, float* objective_out, int N, void* workspace, size_t workspace_bytes,
+                         glowhip_stream_t stream) {
+    GH_TRY(check_plan_args(plan, packed, N));
+    GH_REQUIRE(x && z && nll_out, "glow_forward: null tensor");
+    GH_REQUIRE(n_bits > 0 && n_bits <= 16, "glow_forward: n_bits=%d", n_bits);
+    if (N == 0) return GLOWHIP_OK;
+    hipStream_t s = (hipStream_t)stream;
+    Workspace w;
+    GH_TRY(carve(plan, N, workspace, workspace_bytes, w));
+    GH_TRY(launch_zero_acc(w.acc, N, s));
+    GH_TRY(run_forward(plan, packed, x, noise, z, N, w, s));
+    const int* o = plan->out_shape;
+    GH_TRY(launch_gaussian_logp(z, (long)o[0] * o[1] * o[2], prior_mean, prior_logs, prior_stride, N, o[0], o[1] * o[2],
+                                w.acc, s));
+    // objective = -ln(n_bins)*CHW + logdet + logp;  nll = -objective / (ln2 * CHW)   (network/model.py:425-450)
+    const double chw = (double)plan->in_shape[0] * plan->in_shape[1] * plan->in_shape[2];
+    const double offset = -log(pow(2.0, n_bits)) * chw;
+    const double scale = -1.0 / (log(2.0) * chw);
+    GH_TRY(launch_finalize(nullptr, w.acc, at<double>(packed, 0), 1.0, offset, scale, nll_out, objective_out, N, s));
+    return GLOWHIP_OK;
+}
+
+int glowhip_plan_actnorm_init(glowhip_plan* plan, void* packed, size_t packed_bytes, const float* x, const float* noise,
+                              float actnorm_scale, int N, void* workspace, size_t workspace_bytes,
+                              glowhip_stream_t stream) {
+    GH_TRY(check_plan_args(plan, packed, N));
+    GH_REQUIRE(x && N > 0, "plan_actnorm_init: empty batch");
+    hipStream_t s = (hipStream_t)stream;
+    Workspace w;
+    GH_TRY(carve(plan, N, workspace, workspace_bytes, w));
+    GH_TRY(launch_zero_acc(w.acc, N, s));
+    // Layer by layer: set the ActNorm statistics from the activations that reach it, refresh the packed
+    // data of that layer, then run the layer forward with the fresh parameters (first training-mode
+    // forward of the reference: network/module.py:45-46,66-67).
+    const float* cur = x;
+    const int nl = (int)plan->layers.size();
+    for (int li = 0; li < nl; ++li) {
+        LayerPlan& L = plan->layers[li];
+        const glowhip_layer_desc& d = L.d;
+        float* dst = other_buf(w, cur);
+        const int HW = d.H * d.W;
+        const long chw = (long)d.C * HW;
+        const int Ch = d.C / 2;
+        if (d.kind == GLOWHIP_LAYER_SQUEEZE) {
+            GH_TRY(launch_squeeze(cur, noise, dst, N, d.C, d.H, d.W, 2, 0, s));
+            noise = nullptr;
+        } else if (d.kind == GLOWHIP_LAYER_SPLIT2D) {
+            GH_TRY(launch_copy_strided(cur, chw, dst, (long)Ch * HW, N, (long)Ch * HW, s));
+        } else {
+            if (noise) {
+                GH_TRY(launch_squeeze(cur, noise, dst, N, d.C, d.H, d.W, 1, 0, s));
+                cur = dst; dst = other_buf(w, cur); noise = nullptr;
+            }
+            const int hid = d.hidden;
+            GH_TRY(launch_actnorm_init(cur, chw, N, d.C, HW, actnorm_scale, (float*)d.an_bias, (float*)d.an_logs, s));
+            GH_TRY(pack_scales(d.an_logs, d.C, at<float>(packed, L.an_scale), at<float>(packed, L.an_inv_scale), s));
+            ChanMixArgs m{};
+            m.in_a = cur; m.in_a_bs = chw; m.in_b = cur + (long)Ch * HW; m.in_b_bs = chw; m.Ca = Ch;
+            m.out = dst; m.out_bs = chw; m.bias = d.an_bias; m.scale = at<float>(packed, L.an_scale);
+            m.matrix = d.permutation == GLOWHIP_PERM_INVCONV ? d.invconv_w : nullptr;
+            m.gather = d.permutation == GLOWHIP_PERM_GATHER ? d.perm_idx : nullptr;
+            m.reverse = 0; m.N = N; m.C = d.C; m.HW = HW;
+            GH_TRY(launch_chanmix(m, s));
+            // f.0: raw conv -> statistics (Conv2d's ActNorm uses scale 1, network/module.py:239)
+            ConvArgs c0{dst, chw, d.f0_w, nullptr, nullptr, nullptr, nullptr, 0, w.h1, N, Ch, d.H, d.W, hid, 3};
+            GH_TRY(launch_conv_direct(c0, s));
+            GH_TRY(launch_actnorm_init(w.h1, (long)hid * HW, N, hid, HW, 1.0f, (float*)d.f0_an_bias, (float*)d.f0_an_logs, s));
+            GH_TRY(pack_scales(d.f0_an_logs, hid, at<float>(packed, L.f0_scale), nullptr, s));
+            c0.post_bias = d.f0_an_bias; c0.post_scale = at<float>(packed, L.f0_scale); c0.relu = 1;
+            GH_TRY(launch_conv_direct(c0, s));
+            ConvArgs c2{w.h1, (long)hid * HW, d.f2_w, nullptr, nullptr, nullptr, nullptr, 0, w.h2, N, hid, d.H, d.W, hid, 1};
+            GH_TRY(launch_conv_direct(c2, s));
+            GH_TRY(launch_actnorm_init(w.h2, (long)hid * HW, N, hid, HW, 1.0f, (float*)d.f2_an_bias, (float*)d.f2_an_logs, s));
+            GH_TRY(pack_scales(d.f2_an_logs, hid, at<float>(packed, L.f2_scale), nullptr, s));
+            c2.post_bias = d.f2_an_bias; c2.post_scale = at<float>(packed, L.f2_scale); c2.relu = 1;
+            GH_TRY(launch_conv_direct(c2, s));
+            GH_TRY(pack_scales(d.f4_logs, L.Cout, at<float>(packed, L.f4_scale), nullptr, s));
+            ConvArgs c4{w.h2, (long)hid * HW, d.f4_w, d.f4_bias, nullptr, nullptr, at<float>(packed, L.f4_scale), 0, w.h1,
+                        N, hid, d.H, d.W, L.Cout, 3};
+            GH_TRY(launch_conv_direct(c4, s));
+            float* z2 = dst + (long)Ch * HW;
+            CouplingTailArgs t{w.h1, z2, chw, z2, chw, N, Ch, HW, d.coupling == GLOWHIP_COUPLING_AFFINE, 0, nullptr};
+            GH_TRY(launch_coupling_tail(t, s));
+        }
+        cur = dst;
+    }
+    // everything derived from the parameters is stale now
+    return glowhip_plan_pack(plan, packed, packed_bytes, stream);
+}
+
+}  // extern "C"

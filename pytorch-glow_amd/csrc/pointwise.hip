@@ -1,0 +1,370 @@
+// pointwise.hip -- HBM-bound kernels of the flow path: squeeze, ActNorm (+ data-dependent init),
+// invertible 1x1 conv / channel permutation (per-pixel channel mixing from LDS-resident pixels),
+// coupling / split tails of the generic path, Gaussian log-density reductions, log-det finalisation.
+//
+// Every kernel reads NCHW with the pixel index on the lane axis, so a wave64 touches 256 contiguous
+// bytes per channel plane (coalesced), and reduces per-sample sums with a fixed shuffle tree plus one
+// fixed-point atomic per workgroup (order-independent => bitwise reproducible).
+#include "kernels.h"
+
+namespace glowhip {
+
+// ------------------------------------------------------------------------------------------------
+// Squeeze2d / unsqueeze (network/module.py:551-592), optional dequantisation-noise add on the input
+// (network/model.py:421).  One thread per OUTPUT element (gather form) => coalesced stores.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_squeeze(const float* __restrict__ x, const float* __restrict__ noise,
+                                                 float* __restrict__ y, long total, int C, int H, int W, int f,
+                                                 int reverse) {
+    long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    long src;
+    if (!reverse) {
+        const int Ho = H / f, Wo = W / f, Co = C * f * f;
+        int w = (int)(idx % Wo);
+        long t = idx / Wo;
+        int h = (int)(t % Ho);
+        t /= Ho;
+        int co = (int)(t % Co);
+        long n = t / Co;
+        int c = co / (f * f), r = co % (f * f), i = r / f, j = r % f;
+        src = ((n * C + c) * H + (h * f + i)) * (long)W + (w * f + j);
+    } else {
+        const int Ho = H * f, Wo = W * f, Co = C / (f * f);
+        int ww = (int)(idx % Wo);
+        long t = idx / Wo;
+        int hh = (int)(t % Ho);
+        t /= Ho;
+        int c = (int)(t % Co);
+        long n = t / Co;
+        int cs = c * f * f + (hh % f) * f + (ww % f);
+        src = ((n * C + cs) * H + hh / f) * (long)W + ww / f;
+    }
+    float v = x[src];
+    if (noise) v += noise[src];
+    y[idx] = v;
+}
+
+int launch_squeeze(const float* x, const float* noise, float* y, int N, int C, int H, int W, int f, int reverse,
+                   hipStream_t s) {
+    GH_REQUIRE(f >= 1, "squeeze2d: factor must be >= 1");
+    if (!reverse) GH_REQUIRE(H % f == 0 && W % f == 0, "squeeze2d: H,W must be divisible by factor");
+    else GH_REQUIRE(C >= f * f && C % (f * f) == 0, "unsqueeze2d: C must be a multiple of factor^2");
+    long total = (long)N * C * H * W;
+    if (total == 0) return GLOWHIP_OK;
+    hipLaunchKernelGGL(k_squeeze, dim3(cdiv(total, 256)), dim3(256), 0, s, x, noise, y, total, C, H, W, f, reverse);
+    GH_LAUNCH_CHECK("k_squeeze");
+    return GLOWHIP_OK;
+}
+
+__global__ void __launch_bounds__(256) k_copy_strided(const float* __restrict__ x, long xbs, float* __restrict__ y,
+                                                      long ybs, long per_sample) {
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= per_sample) return;
+    long n = blockIdx.y;
+    y[n * ybs + i] = x[n * xbs + i];
+}
+
+int launch_copy_strided(const float* x, long xbs, float* y, long ybs, int N, long per_sample, hipStream_t s) {
+    if (N == 0 || per_sample == 0) return GLOWHIP_OK;
+    hipLaunchKernelGGL(k_copy_strided, dim3(cdiv(per_sample, 256), N), dim3(256), 0, s, x, xbs, y, ybs, per_sample);
+    GH_LAUNCH_CHECK("k_copy_strided");
+    return GLOWHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// ActNorm data-dependent init (network/module.py:86-120): one workgroup per channel, two passes
+// (mean, then mean of the centred square), fp64 accumulation, fixed reduction tree.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_actnorm_init(const float* __restrict__ x, long xbs, int N, int HW,
+                                                      float scale, float* __restrict__ bias,
+                                                      float* __restrict__ logs) {
+    __shared__ double red[4];
+    __shared__ float s_bias;
+    const int c = blockIdx.x;
+    const long count = (long)N * HW;
+    const float* xc = x + (long)c * HW;
+    double acc = 0.0;
+    for (long i = threadIdx.x; i < count; i += 256) {
+        long n = i / HW;
+        int p = (int)(i - n * HW);
+        acc += (double)xc[n * xbs + p];
+    }
+    double tot = block_sum<256>(acc, red);
+    if (threadIdx.x == 0) s_bias = (float)(-(tot / (double)count));
+    __syncthreads();
+    const float b = s_bias;
+    acc = 0.0;
+    for (long i = threadIdx.x; i < count; i += 256) {
+        long n = i / HW;
+        int p = (int)(i - n * HW);
+        float d = xc[n * xbs + p] + b;
+        acc += (double)(d * d);
+    }
+    tot = block_sum<256>(acc, red);
+    if (threadIdx.x == 0) {
+        float var = (float)(tot / (double)count);
+        bias[c] = b;
+        logs[c] = logf(scale / (sqrtf(var) + 1e-6f)) / LOGSCALE;
+    }
+}
+
+int launch_actnorm_init(const float* x, long xbs, int N, int C, int HW, float scale, float* bias, float* logs,
+                        hipStream_t s) {
+    GH_REQUIRE(N > 0 && C > 0 && HW > 0, "actnorm_init: empty input");
+    hipLaunchKernelGGL(k_actnorm_init, dim3(C), dim3(256), 0, s, x, xbs, N, HW, scale, bias, logs);
+    GH_LAUNCH_CHECK("k_actnorm_init");
+    return GLOWHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Channel mixer: ActNorm (+bias, *scale) fused with the per-pixel C x C mat-vec of the invertible
+// 1x1 convolution (network/module.py:359-363) or the Permutation2d gather (:392-397).
+// One thread per pixel; the pixel's C activations live in LDS column [c][tid] (conflict-free: lane =
+// bank), the matrix row is wave-uniform and comes through the scalar cache, OB outputs are produced
+// per LDS read.  HBM traffic = read C + write C floats per pixel, the algorithmic minimum.
+// ------------------------------------------------------------------------------------------------
+template <int BS>
+__global__ void __launch_bounds__(BS) k_chanmix(ChanMixArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float v[];  // [C][BS]
+    const int tid = threadIdx.x;
+    const long gp = (long)blockIdx.x * BS + tid;
+    const long total = (long)a.N * a.HW;
+    if (gp >= total) return;
+    const long n = gp / a.HW;
+    const int p = (int)(gp - n * a.HW);
+    const int C = a.C;
+    const float* pa = a.in_a + n * a.in_a_bs + p;
+    const float* pb = a.in_b + n * a.in_b_bs + p;
+    float* po = a.out + n * a.out_bs + p;
+    const bool an = a.bias != nullptr;
+    if (!a.reverse) {
+        for (int c = 0; c < C; ++c) {
+            float xv = (c < a.Ca) ? pa[(long)c * a.HW] : pb[(long)(c - a.Ca) * a.HW];
+            if (an) xv = (xv + a.bias[c]) * a.scale[c];
+            v[c * BS + tid] = xv;
+        }
+    } else {
+        for (int c = 0; c < C; ++c)
+            v[c * BS + tid] = (c < a.Ca) ? pa[(long)c * a.HW] : pb[(long)(c - a.Ca) * a.HW];
+    }
+    constexpr int OB = 4;
+    for (int o = 0; o < C; o += OB) {
+        float r[OB];
+        if (a.matrix) {
+#pragma unroll
+            for (int j = 0; j < OB; ++j) r[j] = 0.f;
+            const float* m = a.matrix + (long)o * C;
+            if (o + OB <= C) {
+                for (int i = 0; i < C; ++i) {
+                    const float vi = v[i * BS + tid];
+#pragma unroll
+                    for (int j = 0; j < OB; ++j) r[j] = fmaf(m[j * C + i], vi, r[j]);
+                }
+            } else {
+                for (int i = 0; i < C; ++i) {
+                    const float vi = v[i * BS + tid];
+#pragma unroll
+                    for (int j = 0; j < OB; ++j)
+                        if (o + j < C) r[j] = fmaf(m[j * C + i], vi, r[j]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < OB; ++j) {
+                int oc = o + j;
+                if (oc < C) r[j] = v[(a.gather ? a.gather[oc] : oc) * BS + tid];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < OB; ++j) {
+            int oc = o + j;
+            if (oc < C) {
+                float out = r[j];
+                if (a.reverse && an) out = out * a.scale[oc] - a.bias[oc];
+                po[(long)oc * a.HW] = out;
+            }
+        }
+    }
+}
+
+int launch_chanmix(const ChanMixArgs& a, hipStream_t s) {
+    GH_REQUIRE(a.C > 0 && a.C <= 512, "channel mixer: C=%d unsupported (1..512)", a.C);
+    const long total = (long)a.N * a.HW;
+    if (total == 0) return GLOWHIP_OK;
+    // > 64 KiB of dynamic LDS must be opted into (the call is host-only bookkeeping and idempotent)
+    if (a.C <= 128) {
+        size_t lds = (size_t)a.C * 256 * sizeof(float);
+        if (lds > 48 * 1024)
+            (void)hipFuncSetAttribute((const void*)k_chanmix<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL(k_chanmix<256>, dim3(cdiv(total, 256)), dim3(256), lds, s, a);
+    } else {
+        size_t lds = (size_t)a.C * 64 * sizeof(float);
+        if (lds > 48 * 1024)
+            (void)hipFuncSetAttribute((const void*)k_chanmix<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL(k_chanmix<64>, dim3(cdiv(total, 64)), dim3(64), lds, s, a);
+    }
+    GH_LAUNCH_CHECK("k_chanmix");
+    return GLOWHIP_OK;
+}
+
+// logdet_out[n] = (in ? in[n] : 0) + sign * mul * sum_k term[k]   (data-independent layer terms)
+__global__ void __launch_bounds__(64) k_add_const_logdet(const float* __restrict__ in, float* __restrict__ out, int N,
+                                                         const float* __restrict__ term, float mul, int count,
+                                                         float sign) {
+    double acc = 0.0;
+    for (int k = threadIdx.x; k < count; k += 64) acc += (double)term[k];
+    acc = wave_sum(acc);
+    acc = __shfl(acc, 0, 64);
+    const float d = (float)(acc * (double)mul) * sign;
+    for (int n = threadIdx.x; n < N; n += 64) out[n] = (in ? in[n] : 0.f) + d;
+}
+
+int launch_add_const_logdet(const float* in, float* out, int N, const float* term, float mul, int count, float sign,
+                            hipStream_t s) {
+    if (N == 0) return GLOWHIP_OK;
+    hipLaunchKernelGGL(k_add_const_logdet, dim3(1), dim3(64), 0, s, in, out, N, term, mul, count, sign);
+    GH_LAUNCH_CHECK("k_add_const_logdet");
+    return GLOWHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Coupling tail of the generic path (network/model.py:105-113 forward, :131-139 reverse).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_coupling_tail(CouplingTailArgs a) {
+    __shared__ double red[4];
+    const long n = blockIdx.y;
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    const long per = (long)a.Ch * a.HW;
+    double ld = 0.0;
+    if (e < per) {
+        const int c = (int)(e / a.HW);
+        const int p = (int)(e - (long)c * a.HW);
+        const float z2 = a.z2_in[n * a.z2_in_bs + e];
+        float out;
+        if (a.affine) {
+            const float* hn = a.h + n * 2 * per;
+            const float shift = hn[(long)(2 * c) * a.HW + p];
+            const float sc = sigmoidf_(hn[(long)(2 * c + 1) * a.HW + p] + 2.0f);
+            out = a.reverse ? (z2 / sc - shift) : ((z2 + shift) * sc);
+            ld = (double)logf(sc);
+        } else {
+            const float hv = a.h[n * per + e];
+            out = a.reverse ? (z2 - hv) : (z2 + hv);
+        }
+        a.z2_out[n * a.z2_out_bs + e] = out;
+    }
+    if (a.affine && a.acc) {
+        double tot = block_sum<256>(ld, red);
+        if (threadIdx.x == 0) fix_atomic_add(a.acc + n, a.reverse ? -tot : tot);
+    }
+}
+
+int launch_coupling_tail(const CouplingTailArgs& a, hipStream_t s) {
+    const long per = (long)a.Ch * a.HW;
+    if (a.N == 0 || per == 0) return GLOWHIP_OK;
+    hipLaunchKernelGGL(k_coupling_tail, dim3(cdiv(per, 256), a.N), dim3(256), 0, s, a);
+    GH_LAUNCH_CHECK("k_coupling_tail");
+    return GLOWHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Split2d tail (network/module.py:526-536) + GaussianDiag (:437-483).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float gauss_logp1(float mean, float logs, float x) {
+    const float d = x - mean;
+    return -0.5f * (LOG_2PI_F + 2.0f * logs + (d * d) / expf(2.0f * logs));
+}
+
+__global__ void __launch_bounds__(256) k_split_tail(SplitTailArgs a) {
+    __shared__ double red[4];
+    const long n = blockIdx.y;
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    const long per = (long)a.Ch * a.HW;
+    double lp = 0.0;
+    if (e < per) {
+        const int c = (int)(e / a.HW);
+        const int p = (int)(e - (long)c * a.HW);
+        const float* hn = a.h + n * 2 * per;
+        const float mean = hn[(long)(2 * c) * a.HW + p];
+        const float logs = hn[(long)(2 * c + 1) * a.HW + p];
+        if (!a.reverse) {
+            lp = (double)gauss_logp1(mean, logs, a.z2[n * a.z2_bs + e]);
+        } else {
+            a.z2_out[n * a.z2_out_bs + e] = mean + expf(logs) * a.eps[n * per + e];
+        }
+    }
+    if (!a.reverse && a.acc) {
+        double tot = block_sum<256>(lp, red);
+        if (threadIdx.x == 0) fix_atomic_add(a.acc + n, tot);
+    }
+}
+
+int launch_split_tail(const SplitTailArgs& a, hipStream_t s) {
+    const long per = (long)a.Ch * a.HW;
+    if (a.N == 0 || per == 0) return GLOWHIP_OK;
+    hipLaunchKernelGGL(k_split_tail, dim3(cdiv(per, 256), a.N), dim3(256), 0, s, a);
+    GH_LAUNCH_CHECK("k_split_tail");
+    return GLOWHIP_OK;
+}
+
+__global__ void __launch_bounds__(256) k_gaussian_logp(const float* __restrict__ x, long xbs,
+                                                       const float* __restrict__ mean,
+                                                       const float* __restrict__ logs, long mlbs, long per,
+                                                       unsigned long long* __restrict__ acc) {
+    __shared__ double red[4];
+    const long n = blockIdx.y;
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    double lp = 0.0;
+    if (e < per) {
+        const float m = mean ? mean[n * mlbs + e] : 0.f;
+        const float l = logs ? logs[n * mlbs + e] : 0.f;
+        lp = (double)gauss_logp1(m, l, x[n * xbs + e]);
+    }
+    double tot = block_sum<256>(lp, red);
+    if (threadIdx.x == 0) fix_atomic_add(acc + n, tot);
+}
+
+int launch_gaussian_logp(const float* x, long xbs, const float* mean, const float* logs, long mlbs, int N, int C,
+                         int HW, unsigned long long* acc, hipStream_t s) {
+    const long per = (long)C * HW;
+    if (N == 0 || per == 0) return GLOWHIP_OK;
+    hipLaunchKernelGGL(k_gaussian_logp, dim3(cdiv(per, 256), N), dim3(256), 0, s, x, xbs, mean, logs, mlbs, per, acc);
+    GH_LAUNCH_CHECK("k_gaussian_logp");
+    return GLOWHIP_OK;
+}
+
+__global__ void __launch_bounds__(256) k_zero_acc(unsigned long long* acc, int N) {
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < N) acc[i] = 0ull;
+}
+
+int launch_zero_acc(unsigned long long* acc, int N, hipStream_t s) {
+    if (N == 0) return GLOWHIP_OK;
+    hipLaunchKernelGGL(k_zero_acc, dim3(cdiv(N, 256)), dim3(256), 0, s, acc, N);
+    GH_LAUNCH_CHECK("k_zero_acc");
+    return GLOWHIP_OK;
+}
+
+__global__ void __launch_bounds__(256) k_finalize(const float* __restrict__ in,
+                                                  const unsigned long long* __restrict__ acc,
+                                                  const double* __restrict__ konst, double sign, double offset,
+                                                  double scale, float* __restrict__ out,
+                                                  float* __restrict__ out_unscaled, int N) {
+    int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    double v = (in ? (double)in[n] : 0.0) + offset + (konst ? sign * konst[0] : 0.0) + (acc ? fix_to_double(acc[n]) : 0.0);
+    if (out_unscaled) out_unscaled[n] = (float)v;
+    if (out) out[n] = (float)(v * scale);
+}
+
+int launch_finalize(const float* in, const unsigned long long* acc, const double* konst, double sign, double offset,
+                    double scale, float* out, float* out_unscaled, int N, hipStream_t s) {
+    if (N == 0) return GLOWHIP_OK;
+    hipLaunchKernelGGL(k_finalize, dim3(cdiv(N, 256)), dim3(256), 0, s, in, acc, konst, sign, offset, scale, out,
+                       out_unscaled, N);
+    GH_LAUNCH_CHECK("k_finalize");
+    return GLOWHIP_OK;
+}
+
+}  // namespace glowhip

@@ -1,0 +1,285 @@
+"""FlowStep / FlowModel / Glow with the reference's surface (corenel/pytorch-glow network/model.py),
+executed as flow plans on libglowhip: one C call per encode / decode / Glow forward.
+
+state_dict keys and shapes equal the reference's, so its snapshots load unchanged.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import _lib
+from .._lib import require_device_tensor
+from .._plan import PlanCache
+from ..misc import util
+from . import module
+from .module import _deepcopy_without_plans, _logdet_arg
+
+
+def _uninited_actnorms(mod):
+    return [m for m in mod.modules() if isinstance(m, module.ActNorm) and not (m.bias_inited and m.logs_inited)]
+
+
+def _all_actnorms(mod):
+    return [m for m in mod.modules() if isinstance(m, module.ActNorm)]
+
+
+def _maybe_data_dependent_init(owner, plan, x, noise, actnorm_scale):
+    """First training-mode forward: set every ActNorm of the plan from this batch
+    (reference network/module.py:45-46,66-67; trainer.py:112-115)."""
+    if not owner.training:
+        return
+    pending = _uninited_actnorms(owner)
+    if not pending:
+        return
+    if len(pending) != len(_all_actnorms(owner)):
+        raise _lib.GlowHipError("partially initialised ActNorm layers: call set_actnorm_inited() or reset all flags")
+    plan.actnorm_init(x, noise, actnorm_scale)
+    for m in pending:
+        m.bias_inited = True
+        m.logs_inited = True
+
+
+class FlowStep(nn.Module):
+    """One step of flow: ActNorm -> permutation (invconv | reverse | shuffle) -> coupling (additive | affine).
+    Reference network/model.py:10-173."""
+
+    flow_permutation_list = ['invconv', 'reverse', 'shuffle']
+    flow_coupling_list = ['additive', 'affine']
+    glowhip_kind = _lib.LAYER_FLOWSTEP
+
+    def __init__(self, in_channels, hidden_channels, permutation='invconv', coupling='additive',
+                 actnorm_scale=1., lu_decomposition=False):
+        super().__init__()
+        assert permutation in self.flow_permutation_list, 'Unsupported flow permutation: {}'.format(permutation)
+        assert coupling in self.flow_coupling_list, 'Unsupported flow coupling: {}'.format(coupling)
+        self.permutation = permutation
+        self.coupling = coupling
+        self.in_channels = in_channels
+        self.hidden_channels = hidden_channels
+        self.actnorm_scale = actnorm_scale
+        self.actnorm = module.ActNorm(num_channels=in_channels, scale=actnorm_scale)
+        if permutation == 'invconv':
+            self.invconv = module.Invertible1x1Conv(num_channels=in_channels, lu_decomposition=lu_decomposition)
+        elif permutation == 'reverse':
+            self.reverse = module.Permutation2d(num_channels=in_channels, shuffle=False)
+        else:
+            self.shuffle = module.Permutation2d(num_channels=in_channels, shuffle=True)
+        if coupling == 'additive':
+            self.f = module.f(in_channels // 2, hidden_channels, in_channels // 2)
+        else:
+            self.f = module.f(in_channels // 2, hidden_channels, in_channels)
+        self._plans = PlanCache()
+
+    def _plan(self, x):
+        return self._plans.get([self], tuple(x.shape[1:]), x.device)
+
+    def normal_flow(self, x, logdet=None):
+        x = require_device_tensor(x, "FlowStep input")
+        plan = self._plan(x)
+        _maybe_data_dependent_init(self, plan, x, None, self.actnorm_scale)
+        ld = _logdet_arg(logdet, x.shape[0], x.device)
+        return plan.encode(x, None, ld, want_logdet=ld is not None)
+
+    def reverse_flow(self, x, logdet=None):
+        x = require_device_tensor(x, "FlowStep input")
+        ld = _logdet_arg(logdet, x.shape[0], x.device)
+        return self._plan(x).decode(x, [], ld, want_logdet=ld is not None)
+
+    def forward(self, x, logdet=None, reverse=False):
+        assert x.shape[1] % 2 == 0
+        return self.reverse_flow(x, logdet) if reverse else self.normal_flow(x, logdet)
+
+    def __deepcopy__(self, memo):
+        return _deepcopy_without_plans(self, memo)
+
+
+class FlowModel(nn.Module):
+    """Multi-scale flow: [Squeeze2d, FlowStep x K, Split2d] x (L-1) + [Squeeze2d, FlowStep x K].
+    Reference network/model.py:176-314.  ``in_shape`` is (H, W, C)."""
+
+    def __init__(self, in_shape, hidden_channels, K, L, permutation='invconv', coupling='additive',
+                 actnorm_scale=1., lu_decomposition=False):
+        super().__init__()
+        self.K = K
+        self.L = L
+        self.actnorm_scale = actnorm_scale
+        assert len(in_shape) == 3
+        assert in_shape[2] == 1 or in_shape[2] == 3
+        nh, nw, nc = in_shape
+        self.in_chw = (nc, nh, nw)
+        self.layers = nn.ModuleList()
+        self.output_shapes = []
+        for i in range(L):
+            self.layers.append(module.Squeeze2d(factor=2))
+            nc, nh, nw = nc * 4, nh // 2, nw // 2
+            self.output_shapes.append([-1, nc, nh, nw])
+            for _ in range(K):
+                self.layers.append(FlowStep(in_channels=nc, hidden_channels=hidden_channels, permutation=permutation,
+                                            coupling=coupling, actnorm_scale=actnorm_scale,
+                                            lu_decomposition=lu_decomposition))
+                self.output_shapes.append([-1, nc, nh, nw])
+            if i < L - 1:
+                self.layers.append(module.Split2d(num_channels=nc))
+                nc = nc // 2
+                self.output_shapes.append([-1, nc, nh, nw])
+        self._plans = PlanCache()
+
+    def plan_for(self, x_or_chw, device=None):
+        if isinstance(x_or_chw, torch.Tensor):
+            return self._plans.get(list(self.layers), tuple(x_or_chw.shape[1:]), x_or_chw.device)
+        return self._plans.get(list(self.layers), tuple(x_or_chw), device)
+
+    def invalidate_packed(self):
+        """Call after writing parameters through ``.data`` (which torch's version counters do not see)."""
+        self._plans.invalidate()
+
+    def encode(self, z, logdet=0.):
+        z = require_device_tensor(z, "FlowModel input")
+        plan = self.plan_for(z)
+        _maybe_data_dependent_init(self, plan, z, None, self.actnorm_scale)
+        ld = _logdet_arg(logdet, z.shape[0], z.device)
+        return plan.encode(z, None, ld, want_logdet=ld is not None)
+
+    def decode(self, z, eps_std=None, eps=None):
+        """``eps``: optional list of injected draws, one per Split2d in decode order (deepest first)."""
+        z = require_device_tensor(z, "FlowModel latent")
+        n = z.shape[0]
+        c, h, w = z.shape[1:]
+        # input CHW of the plan from the latent shape: invert the squeeze/split bookkeeping
+        plan = self._plans.get(list(self.layers), self._input_chw_for_latent((c, h, w)), z.device)
+        if eps is None:
+            eps = self.draw_eps(n, plan, eps_std, z.device)
+        x, _ = plan.decode(z, [require_device_tensor(e, "eps") for e in eps], None, want_logdet=False)
+        return x
+
+    def _input_chw_for_latent(self, chw):
+        c, h, w = chw
+        for i in range(self.L):
+            if i > 0:
+                c = c * 2
+            c, h, w = c // 4, h * 2, w * 2
+        return (c, h, w)
+
+    def split_shapes(self, in_chw):
+        """(C,H,W) of the z2 half dropped at each Split2d, in DECODE order (deepest first)."""
+        c, h, w = in_chw
+        shapes = []
+        for i in range(self.L):
+            c, h, w = c * 4, h // 2, w // 2
+            if i < self.L - 1:
+                c = c // 2
+                shapes.append((c, h, w))
+        return shapes[::-1]
+
+    def draw_eps(self, n, plan, eps_std, device):
+        std = eps_std or 1.  # reference network/module.py:419
+        return [torch.randn((n,) + s, dtype=torch.float32, device=device) * std for s in self.split_shapes(plan.in_chw)]
+
+    def forward(self, z, logdet=0., eps_std=None, reverse=False):
+        if not reverse:
+            return self.encode(z, logdet)
+        return self.decode(z, eps_std)
+
+    def __deepcopy__(self, memo):
+        return _deepcopy_without_plans(self, memo)
+
+
+class Glow(nn.Module):
+    """Glow (reference network/model.py:317-550): dequantisation noise, flow encode, top prior, nll in bits/dim."""
+
+    bce_criterion = nn.BCEWithLogitsLoss()
+    ce_criterion = nn.CrossEntropyLoss()
+
+    def __init__(self, hps):
+        super().__init__()
+        self.hps = hps
+        self.flow = FlowModel(in_shape=hps.model.image_shape, hidden_channels=hps.model.hidden_channels,
+                              K=hps.model.K, L=hps.model.L, permutation=hps.ablation.flow_permutation,
+                              coupling=hps.ablation.flow_coupling, actnorm_scale=hps.model.actnorm_scale,
+                              lu_decomposition=hps.ablation.lu_decomposition)
+        if hps.ablation.learn_top:
+            nc = self.flow.output_shapes[-1][1]
+            self.learn_top = module.Conv2dZeros(in_channels=2 * nc, out_channels=2 * nc)
+        if hps.ablation.y_condition:
+            raise NotImplementedError("class-conditional Glow (y_condition) is outside the flow hot path "
+                                      "(off in every reference profile)")
+        num_device = len(util.get_devices(self.hps.device.graph, verbose=False))
+        assert hps.optim.num_batch_train % num_device == 0
+        self.register_parameter('h_top', nn.Parameter(torch.zeros([hps.optim.num_batch_train // num_device,
+                                                                   self.flow.output_shapes[-1][1] * 2,
+                                                                   self.flow.output_shapes[-1][2],
+                                                                   self.flow.output_shapes[-1][3]])))
+
+    @property
+    def batch_h_top(self):
+        return self.h_top.shape[0]
+
+    def prior(self, y_onehot=None):
+        """Top prior parameters (mean, logs).  The reference asserts h_top == 0 with a host sync on every
+        call (network/model.py:373); the sync is not reproduced.  Returns (None, None) for the all-zero
+        prior so the kernels skip the loads."""
+        if not self.hps.ablation.learn_top:
+            return None, None
+        h = self.learn_top(self.h_top.detach())
+        nc = h.shape[1]
+        return h[:, :nc // 2, ...], h[:, nc // 2:, ...]
+
+    def normal_flow(self, x, y_onehot=None, noise=None, repack=False):
+        """z = x + U(0, 1/2^n_bits); objective = -ln(n_bins)*CHW + logdet + logp(z); nll = -objective/(ln2*CHW).
+        ``noise`` (optional, beyond the reference signature) injects the dequantisation draw."""
+        x = require_device_tensor(x, "Glow input")
+        n_bits = self.hps.model.n_bits_x
+        if noise is None:
+            noise = torch.empty_like(x).uniform_(0, 1. / 2 ** n_bits)
+        else:
+            noise = require_device_tensor(noise, "noise")
+            assert noise.shape == x.shape
+        plan = self.flow.plan_for(x)
+        _maybe_data_dependent_init(self.flow, plan, x, noise, self.flow.actnorm_scale)
+        mean, logs = self.prior(y_onehot)
+        stride = 0
+        if mean is not None:
+            assert mean.shape[0] == x.shape[0], "batch must equal h_top's batch when learn_top is on"
+            stride = mean.stride(0)
+            assert mean[0].is_contiguous() and logs[0].is_contiguous() and logs.stride(0) == stride
+        z, nll, _ = plan.glow_forward(x, noise, mean, logs, stride, n_bits, repack=repack)
+        return z, nll, None
+
+    def reverse_flow(self, z, y_onehot=None, eps_std=None, eps=None):
+        with torch.no_grad():
+            if z is None:
+                mean, logs = self.prior(y_onehot)
+                if mean is None:
+                    c2, h, w = self.h_top.shape[1:]
+                    mean = logs = torch.zeros((self.batch_h_top, c2 // 2, h, w), device=self.h_top.device)
+                z = module.GaussianDiag.sample(mean, logs, eps_std)
+            return self.flow.decode(z, eps_std=eps_std, eps=eps)
+
+    def forward(self, x=None, y_onehot=None, z=None, eps_std=None, reverse=False):
+        if not reverse:
+            return self.normal_flow(x, y_onehot)
+        return self.reverse_flow(z, y_onehot, eps_std)
+
+    @staticmethod
+    def generative_loss(nll):
+        return torch.mean(nll)
+
+    @staticmethod
+    def single_class_loss(y_logits, y):
+        if y_logits is None:
+            return 0
+        return Glow.ce_criterion(y_logits, y.long())
+
+    @staticmethod
+    def multi_class_loss(y_logits, y_onehot):
+        if y_logits is None:
+            return 0
+        return Glow.bce_criterion(y_logits, y_onehot.float())
+
+    def set_actnorm_inited(self, inited=True):
+        for name, m in self.named_modules():
+            if m.__class__.__name__.find("ActNorm") >= 0:
+                m.bias_inited = inited
+                m.logs_inited = inited

@@ -1,0 +1,112 @@
+"""CPU checks of the host-side mirror of the reference interface: constructors, attributes, state_dict
+keys/shapes, profile loading, and that compute refuses to run without a GPU."""
+import copy
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import pytorch_glow_amd as G
+from pytorch_glow_amd.misc import ops, util
+from oracle import glow_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PROFILES = os.path.join(ROOT, "pytorch-glow_amd", "profile")
+
+
+def test_profiles_load_with_reference_schema():
+    hps = util.load_profile(os.path.join(PROFILES, "celeba.json"))
+    assert hps.model.image_shape == [64, 64, 3] and hps.model.K == 32 and hps.model.L == 3
+    assert hps.model.hidden_channels == 512 and hps.ablation.flow_coupling == "affine"
+    assert hps.ablation.flow_permutation == "invconv" and hps.ablation.seed == 2384
+    assert hps.optim.optimizer_args.betas == [0.9, 0.9999]
+    t = util.load_profile(os.path.join(PROFILES, "test.json"))
+    assert t.ablation.flow_coupling == "additive" and t.optim.num_batch_train == 16
+    assert util.load_profile("/nonexistent.json") is None
+
+
+def test_get_devices():
+    assert util.get_devices(["cpu"], verbose=False) == ["cpu"]
+    n = torch.cuda.device_count()
+    got = util.get_devices(["cuda:0", "cuda:1"], verbose=False)
+    assert got == (["cpu"] if n == 0 else list(range(min(n, 2))))
+    with pytest.raises(AssertionError):
+        util.get_devices(["cpu", "cuda:0"], verbose=False)
+
+
+def test_ops_helpers():
+    t = torch.arange(2 * 6 * 4 * 4, dtype=torch.float32).reshape(2, 6, 4, 4)
+    a, b = ops.split_channel(t, "simple")
+    assert torch.equal(a, t[:, :3]) and torch.equal(b, t[:, 3:])
+    c, d = ops.split_channel(t, "cross")
+    assert torch.equal(c, t[:, 0::2]) and torch.equal(d, t[:, 1::2])
+    assert torch.equal(ops.cat_channel(a, b), t)
+    assert ops.count_pixels(t) == 16
+    assert ops.reduce_sum(t, dim=[1, 2, 3]).shape == (2,)
+    assert ops.reduce_mean(t, dim=[0, 2, 3], keepdim=True).shape == (1, 6, 1, 1)
+    assert ops.tensor_equal(t, t + 5e-7) and not ops.tensor_equal(t, t + 1e-3) and not ops.tensor_equal(t, t[:1])
+    assert torch.equal(ops.onehot(torch.tensor([1, 0]), 3), torch.tensor([[0., 1, 0], [1, 0, 0]]))
+
+
+def test_state_dict_matches_reference_layout():
+    hps = util.load_profile(os.path.join(PROFILES, "celeba.json"))
+    glow = G.Glow(hps)
+    sd = glow.state_dict()
+    cfg = O.default_cfg(batch=glow.h_top.shape[0])
+    ref = O.seeded_state_dict(cfg)
+    assert set(sd) == set(ref)
+    for k in ref:
+        assert tuple(sd[k].shape) == tuple(ref[k].shape), k
+    assert sum(v.numel() for k, v in sd.items() if k != "h_top") == 44_052_720
+    assert glow.flow.output_shapes[0] == [-1, 12, 32, 32] and glow.flow.output_shapes[-1] == [-1, 48, 8, 8]
+    assert len(glow.flow.layers) == 101 and glow.flow.K == 32 and glow.flow.L == 3
+    assert tuple(glow.h_top.shape[1:]) == (96, 8, 8) and glow.batch_h_top == glow.h_top.shape[0]
+    # layer kinds at the reference's indices: squeeze 0, steps 1..32, split 33
+    assert isinstance(glow.flow.layers[0], G.Squeeze2d) and isinstance(glow.flow.layers[33], G.Split2d)
+    assert all(isinstance(glow.flow.layers[i], G.FlowStep) for i in range(1, 33))
+    # ActNorm flags are plain attributes, not state (reference module.py:29-30)
+    assert not any("inited" in k for k in sd)
+    glow.set_actnorm_inited()
+    assert all(m.bias_inited and m.logs_inited for m in glow.modules() if isinstance(m, G.ActNorm))
+
+
+def test_inits_follow_reference():
+    np.random.seed(0)
+    st = G.FlowStep(12, 64, permutation="invconv", coupling="affine")
+    w = st.invconv.weight.detach().double()
+    assert torch.allclose(w @ w.T, torch.eye(12, dtype=torch.float64), atol=1e-5)      # QR-orthogonal (module.py:341)
+    assert abs(st.f[0].weight.std().item() - 0.05) < 0.01 and st.f[0].bias is None       # N(0,0.05), no bias
+    assert st.f[2].weight.shape == (64, 64, 1, 1) and st.f[4].weight.shape == (12, 64, 3, 3)
+    assert torch.count_nonzero(st.f[4].weight) == 0 and torch.count_nonzero(st.f[4].logs) == 0
+    add = G.FlowStep(12, 64, coupling="additive")
+    assert add.f[4].weight.shape[0] == 6
+    p = G.Permutation2d(8)
+    assert list(p.indices) == list(range(7, -1, -1)) and list(p.indices_inverse[p.indices]) == list(range(8))
+    s = G.Permutation2d(8, shuffle=True)
+    assert sorted(s.indices) == list(range(8)) and all(s.indices_inverse[s.indices[i]] == i for i in range(8))
+    assert G.Conv2d.get_padding("SAME", 3, 1) == (1, 1) and G.Conv2d.get_padding("VALID", (3, 3), 1) == (0, 0)
+    with pytest.raises(AssertionError):
+        G.FlowStep(12, 8, permutation="bogus")
+    with pytest.raises(AssertionError):
+        G.FlowModel(in_shape=(16, 16, 2), hidden_channels=8, K=1, L=1)
+    lz = G.LinearZeros(16, 16)
+    assert torch.equal(lz(torch.rand(16)), torch.zeros(16))                               # reference test_module.py:22-29
+
+
+def test_deepcopy_and_split_shapes():
+    fm = G.FlowModel(in_shape=(64, 64, 3), hidden_channels=8, K=1, L=3)
+    assert fm.split_shapes((3, 64, 64)) == [(12, 16, 16), (6, 32, 32)]                    # SURVEY R10 decode order
+    assert fm._input_chw_for_latent((48, 8, 8)) == (3, 64, 64)
+    fm2 = copy.deepcopy(fm)
+    assert fm2._plans is not fm._plans
+    assert all(torch.equal(a, b) for a, b in zip(fm.state_dict().values(), fm2.state_dict().values()))
+
+
+def test_cpu_tensors_are_refused_not_silently_computed():
+    x = torch.zeros(2, 4, 4, 4)
+    for call in (lambda: G.ActNorm(4)(x), lambda: G.Squeeze2d()(x), lambda: G.FlowStep(4, 8)(x),
+                 lambda: G.Invertible1x1Conv(4)(x), lambda: G.Conv2d(4, 8)(x), lambda: G.Split2d(4)(x),
+                 lambda: G.Permutation2d(4)(x)):
+        with pytest.raises(G.GlowHipError):
+            call()
