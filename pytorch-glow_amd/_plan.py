@@ -141,6 +141,8 @@ class FlowPlan:
         self.ensure_packed(repack)
         z = torch.empty((n,) + self.out_chw, dtype=torch.float32, device=self.device)
         ld_out = torch.empty(n, dtype=torch.float32, device=self.device) if want_logdet else None
+        if n == 0:
+            return z, ld_out
         ws = self._workspace(n)
         check(lib().glowhip_plan_encode(self._h, ptr(self.packed), ptr(x), ptr(noise), ptr(logdet), ptr(z), ptr(ld_out), n,
                                         ptr(ws), ws.numel(), stream_ptr(self.device)))
@@ -153,6 +155,8 @@ class FlowPlan:
         self.ensure_packed(repack)
         x = torch.empty((n,) + self.in_chw, dtype=torch.float32, device=self.device)
         ld_out = torch.empty(n, dtype=torch.float32, device=self.device) if want_logdet else None
+        if n == 0:
+            return x, ld_out
         ws = self._workspace(n)
         arr = (ctypes.c_void_p * max(len(eps), 1))(*[e.data_ptr() for e in eps])
         check(lib().glowhip_plan_decode(self._h, ptr(self.packed), ptr(z), arr, len(eps), ptr(logdet), ptr(x), ptr(ld_out),
@@ -168,6 +172,8 @@ class FlowPlan:
             obj = torch.empty(n, dtype=torch.float32, device=self.device)
         else:
             z, nll, obj = out
+        if n == 0:
+            return z, nll, obj
         ws = self._workspace(n)
         check(lib().glowhip_glow_forward(self._h, ptr(self.packed), ptr(x), ptr(noise), ptr(prior_mean), ptr(prior_logs),
                                          prior_stride, n_bits, ptr(z), ptr(nll), ptr(obj), n, ptr(ws), ws.numel(),

