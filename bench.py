@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""bench.py -- images/sec of a full Glow forward + log-determinant (Glow.normal_flow) on MI355X.
+
+Workload (BASELINE.json configs[1], per GPU): CelebA-shaped 64x64x3 batch of 64, L=3, K=32, hidden 512,
+affine coupling, invertible 1x1 conv; fp32; synthetic uniform [0,1) images resident in HBM; random-init weights
+of the reference's architecture + data-dependent ActNorm init on the first batch.
+
+One step = dequantisation noise (on-device RNG) -> squeeze/FlowStep/Split2d stack -> top prior -> nll (N,) ->
+sum(nll) [-> RCCL all-reduce of the scalar when N > 1].  Every step also re-derives the parameter-dependent
+data (glowhip_plan_pack: LU of the 96 invconv weights -> log|det W|, exp(3 logs), MFMA weight images), i.e. the
+weights are treated as freshly updated each step exactly as inside a training loop -- nothing is cached across
+steps.  Multi-GPU: one process per GPU, batch sharded (weak scaling, 64 images per GPU), no data-path collective
+other than the scalar loss all-reduce.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel = the 1x1
+512->512 MFMA GEMM, timed live with HIP events around each of its launches in an instrumented pass of the same
+step) and `cpu_baseline` (the CPU oracle timed on this box's host cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, f32 in / f32 accumulate
+BATCH_PER_GPU = 64
+
+
+def build_model(G, util, device, batch, seed=2384):
+    hps = util.load_profile(os.path.join(ROOT, "pytorch-glow_amd", "profile", "celeba.json"))
+    hps.optim.num_batch_train = batch
+    hps.device.graph = ["cuda:0"]  # one process per GPU: one replica per process
+    torch.manual_seed(seed)
+    import numpy as np
+    np.random.seed(seed)
+    glow = G.Glow(hps)
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():  # zero-init tails would make the coupling trivial: give them the survey's N(0, 0.002)
+        for name, p in glow.named_parameters():
+            if ".f.4." in name or "conv2d_zeros" in name:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.002)
+    return glow.to(device), hps
+
+
+def flop_per_image(glow):
+    hid = glow.hps.model.hidden_channels
+    total = 0.0
+    for layer in glow.flow.layers:
+        pass
+    c, h, w = 3, glow.hps.model.image_shape[0], glow.hps.model.image_shape[1]
+    for i in range(glow.flow.L):
+        c, h, w = c * 4, h // 2, w // 2
+        cout = c if glow.hps.ablation.flow_coupling == "affine" else c // 2
+        total += glow.flow.K * 2.0 * h * w * (9 * (c // 2) * hid + hid * hid + 9 * hid * cout + c * c)
+        if i < glow.flow.L - 1:
+            total += 2.0 * h * w * 9 * (c // 2) * c
+            c //= 2
+    return total
+
+
+def cpu_baseline(glow, x_cpu, budget_s=12.0):
+    """Time the CPU oracle (a port of the reference's eager op sequence) on this box's host cores."""
+    from oracle import glow_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = O.default_cfg(batch=x_cpu.shape[0])
+    sd = {k: v.detach().cpu() for k, v in glow.state_dict().items()}
+    noise = torch.rand_like(x_cpu) / 256
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        O.glow_forward(x_cpu, noise, sd, cfg)  # warm-up (oneDNN primitive creation)
+        warm = time.perf_counter() - t0
+        iters, t0 = 0, time.perf_counter()
+        while True:
+            O.glow_forward(x_cpu, noise, sd, cfg)
+            iters += 1
+            el = time.perf_counter() - t0
+            if el >= budget_s or iters >= 8:
+                break
+    return {"value": round(iters * x_cpu.shape[0] / el, 3), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"{iters} x forward of batch {x_cpu.shape[0]} (same model/weights, fp32, torch CPU threads={cores}; "
+                      f"warm-up {warm:.1f}s excluded)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="images per GPU (default: BASELINE config B)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-repack", action="store_true", help="inference mode: keep derived parameter data across steps")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    import pytorch_glow_amd as G
+    from pytorch_glow_amd.misc import util
+    from pytorch_glow_amd import parallel
+
+    B = args.batch
+    glow, hps = build_model(G, util, device, B)
+    x = torch.rand(B, 3, 64, 64, generator=torch.Generator().manual_seed(2384 + rank)).to(device)
+
+    # data-dependent ActNorm init on rank 0's first batch, then broadcast (reference trainer.py:112-115)
+    glow.train()
+    parallel.data_dependent_init(glow, x, rank=rank, world=world)
+    glow.eval()
+    plan = glow.flow.plan_for(x)
+    repack = not args.no_repack
+
+    def step():
+        z, nll, _ = glow.normal_flow(x, None, repack=repack)
+        return parallel.reduce_loss(nll, world)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    total_images = world * B * args.steps
+    value = total_images / dt
+
+    if rank == 0:
+        fpi = flop_per_image(glow)
+        out = {
+            "metric": "images/sec full Glow fwd+logdet, 64x64x3 L=3 K=32, 1/2/4/8 GPU",
+            "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "CelebA 64x64x3 Glow L=3 K=32 hidden=512 affine+invconv, fwd+logdet, "
+                                   f"batch {B}/GPU (BASELINE configs[1])", "global_batch": world * B,
+                       "parallelism": f"dp{world}", "repack_every_step": repack,
+                       "loss_mean_nll_bits_per_dim": round(float(loss) / (world * B), 6)},
+            "model_tflops": round(value * fpi / 1e12, 2),
+            "frac_of_fp32_mfma_peak_whole_model": round(value / world * fpi / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4),
+        }
+        # ---- roofline of the dominant kernel: instrumented pass of the same step, HIP events per launch
+        plan.timing(True)
+        for _ in range(3):
+            step()
+        recs = plan.timing_read()
+        plan.timing(False)
+        hid = hps.model.hidden_channels
+        kinds = {0: "chanmix", 1: "conv_f0_3x3", 2: "conv_f2_1x1", 3: "conv_f4_3x3_tail"}
+        bd = {}
+        dom_ms, dom_flop, dom_n = 0.0, 0.0, 0
+        for kind, layer, mfma, ms in recs:
+            d = plan._descs[layer]
+            key = f"{kinds.get(kind, 'other')}_C{d.C}_{d.H}x{d.W}"
+            bd.setdefault(key, [0.0, 0])
+            bd[key][0] += ms
+            bd[key][1] += 1
+            total_px = B * d.H * d.W
+            uses_128 = (hid // 128) * ((total_px + 127) // 128) >= 512
+            if kind == 2 and mfma and uses_128:  # k_conv_wide<1,128,128,32>
+                dom_ms += ms
+                dom_flop += 2.0 * hid * hid * total_px
+                dom_n += 1
+        achieved = dom_flop / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get("k_conv_wide_1x1_128_hbm_bytes_per_launch")
+        out["roofline"] = {"bound": "mfma", "kernel": "k_conv_wide<1,128,128,32> (f.2: 1x1 conv 512->512 + ActNorm + ReLU)",
+                           "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                           "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+                           "launches": dom_n, "avg_launch_us": round(1e3 * dom_ms / max(dom_n, 1), 2),
+                           "flop_per_launch_avg": dom_flop / max(dom_n, 1)}
+        out["breakdown_ms_per_step"] = {k: round(v[0] / 3, 4) for k, v in sorted(bd.items())}
+        out["breakdown_sum_ms"] = round(sum(v[0] for v in bd.values()) / 3, 3)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(glow, x[:8].cpu())
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -173,6 +173,20 @@ int glowhip_plan_actnorm_init(glowhip_plan* plan, void* packed, size_t packed_by
 /* Output shape of the plan for a given direction (HOST). out[3] = {C,H,W}. */
 int glowhip_plan_output_shape(const glowhip_plan* plan, int reverse, int32_t out[3]);
 
+/* Per-launch timing for benchmarks (HIP events recorded on the execution stream around every kernel of
+ * the coupling path).  enable=1 creates an event pool (host resource), enable=0 destroys it; while enabled
+ * every encode/decode appends records.  glowhip_plan_timing_read synchronises with the recorded events,
+ * copies up to `max` records (launch order) and clears the list. */
+enum { GLOWHIP_K_CHANMIX = 0, GLOWHIP_K_CONV_F0 = 1, GLOWHIP_K_CONV_F2 = 2, GLOWHIP_K_CONV_F4 = 3, GLOWHIP_K_OTHER = 4 };
+typedef struct glowhip_timing_record {
+    int32_t kind;   /* GLOWHIP_K_* */
+    int32_t layer;  /* index into the plan's layer list */
+    int32_t mfma;   /* 1 = MFMA kernel, 0 = direct kernel */
+    float ms;       /* elapsed between the two events */
+} glowhip_timing_record;
+int glowhip_plan_timing_enable(glowhip_plan* plan, int enable);
+int glowhip_plan_timing_read(glowhip_plan* plan, glowhip_timing_record* out, int max, int* n_out);
+
 /* Introspection for tests / benchmarks: which kernels a plan will launch ("mfma" or "direct" per
  * convolution).  Writes a NUL-terminated description into buf. */
 int glowhip_plan_describe(const glowhip_plan* plan, char* buf, size_t buf_bytes);

@@ -41,6 +41,13 @@ class LayerDesc(ctypes.Structure):
     ]
 
 
+class TimingRecord(ctypes.Structure):
+    """Mirror of ``glowhip_timing_record``."""
+    _fields_ = [("kind", c_int32), ("layer", c_int32), ("mfma", c_int32), ("ms", c_float)]
+
+
+K_CHANMIX, K_CONV_F0, K_CONV_F2, K_CONV_F4, K_OTHER = range(5)
+
 _P = c_void_p
 # name -> (restype, argtypes); every symbol include/glowhip.h declares (tests/test_abi.py checks the two agree)
 SIGNATURES = {
@@ -66,6 +73,8 @@ SIGNATURES = {
     "glowhip_plan_actnorm_init": (c_int, [_P, _P, c_size_t, _P, _P, c_float, c_int, _P, c_size_t, _P]),
     "glowhip_plan_output_shape": (c_int, [_P, c_int, POINTER(c_int32)]),
     "glowhip_plan_describe": (c_int, [_P, c_char_p, c_size_t]),
+    "glowhip_plan_timing_enable": (c_int, [_P, c_int]),
+    "glowhip_plan_timing_read": (c_int, [_P, POINTER(TimingRecord), c_int, POINTER(c_int)]),
 }
 
 _lib = None

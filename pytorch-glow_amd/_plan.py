@@ -130,6 +130,17 @@ class FlowPlan:
     def invalidate(self) -> None:
         self._packed_version = None
 
+    def timing(self, enable: bool) -> None:
+        """Record HIP events around every coupling-path kernel launch of subsequent encode/decode calls."""
+        check(lib().glowhip_plan_timing_enable(self._h, int(enable)))
+
+    def timing_read(self, max_records: int = 1 << 16):
+        """[(kind, layer, mfma, ms)] in launch order since the last read (synchronises with the events)."""
+        buf = (_lib.TimingRecord * max_records)()
+        n = ctypes.c_int(0)
+        check(lib().glowhip_plan_timing_read(self._h, buf, max_records, ctypes.byref(n)))
+        return [(buf[i].kind, buf[i].layer, buf[i].mfma, buf[i].ms) for i in range(n.value)]
+
     def describe(self) -> str:
         buf = ctypes.create_string_buffer(1 << 16)
         check(lib().glowhip_plan_describe(self._h, buf, len(buf)))

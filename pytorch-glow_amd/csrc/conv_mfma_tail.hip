@@ -1,0 +1,327 @@
+// conv_mfma_tail.hip -- 3x3 convolution to a few output channels with the coupling / prior arithmetic
+// fused into the epilogue (see the header comment of conv_mfma.hip for the design).
+//
+// MFMA: v_mfma_f32_16x16x4_f32, A = weights [16 out-rows][4 in-channels], B = activations
+// [4 in-channels][16 pixels]; C[row = out-row][col = pixel]: lane l holds rows (l>>4)*4 + {0..3} of pixel
+// l&15.  Out-rows are PERMUTED at pack time so that a lane's four rows are {shift_c0, shift_c1, scale_c0,
+// scale_c1} (or {mean, mean, logs, logs}) of two coupling channels: the whole affine update is lane-local.
+//
+// LDS image of the input: per 32-channel chunk a zero-padded halo tile [32][TR+2][W+8] (data at columns
+// 4..W+3 => 16-byte aligned rows, pad columns 3 and W+4 stay zero), channel stride == 16 (mod 32) floats so
+// the two 16-lane pixel runs of a ds_read_b32 half-wave fall on disjoint banks.  A tap is an LDS address
+// offset; nothing is expanded (no im2col), each input element is fetched from HBM once per block.
+#include "conv_mfma.h"
+
+namespace glowhip {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int TAIL_CK = 32;  // input channels per LDS chunk
+
+__host__ __device__ inline int tail_mt(int Cout, int paired) {
+    const int rows = paired ? 4 * ((Cout / 2 + 1) / 2) : Cout;
+    return (rows + 15) / 16;
+}
+// out-row m -> original output channel (or -1)
+__host__ __device__ inline int tail_row_channel(int m, int Cout, int paired) {
+    if (!paired) return m < Cout ? m : -1;
+    const int g = m >> 2, r = m & 3;
+    const int c = 2 * g + (r & 1);
+    return c < Cout / 2 ? 2 * c + (r >> 1) : -1;
+}
+
+static int tail_tp(int H, int W) {
+    const int HW = H * W;
+    if (W <= 128 && 128 % W == 0 && HW % 128 == 0) return 128;
+    if (W <= 64 && 64 % W == 0 && HW % 64 == 0) return 64;
+    return 0;
+}
+
+static bool tail_paired(int mode) { return mode != TAIL_PLAIN && mode != TAIL_ADD_FWD && mode != TAIL_ADD_REV; }
+
+bool conv_mfma_tail_supported(int Cin, int H, int W, int Cout) {
+    if (W % 4 != 0 || W < 8) return false;
+    if (tail_tp(H, W) == 0) return false;
+    if (Cout > 48 || Cout < 1) return false;
+    const int TP = tail_tp(H, W);
+    if (TAIL_CK * (TP / W + 2) * (W / 4) > 6 * 256) return false;  // halo tile must fit the 6-float4 staging
+    return Cin >= 1;
+}
+
+static int tail_chunks(int Cin) { return (Cin + TAIL_CK - 1) / TAIL_CK; }
+
+size_t conv_mfma_tail_packed_bytes(int Cin, int Cout) {
+    // sized for the larger of the two row layouts (paired rows >= unpaired rows for even Cout)
+    const int mt = tail_mt(Cout, 1) > tail_mt(Cout, 0) ? tail_mt(Cout, 1) : tail_mt(Cout, 0);
+    return (size_t)tail_chunks(Cin) * (TAIL_CK / 4) * 9 * mt * 64 * sizeof(float);
+}
+
+// wp[(((chunk*8 + c4)*9 + tap)*MT + mt)*64 + kq*16 + i] = w[o(mt*16+i)][chunk*32 + c4*4 + kq][tap]
+__global__ void __launch_bounds__(256) k_pack_tail(const float* __restrict__ w, int Cin, int Cout, int paired, int MT,
+                                                   long total, float* __restrict__ wp) {
+    long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const int i = (int)(e & 15), kq = (int)((e >> 4) & 3);
+    long t = e >> 6;
+    const int mt = (int)(t % MT); t /= MT;
+    const int tap = (int)(t % 9); t /= 9;
+    const int c4 = (int)(t % (TAIL_CK / 4));
+    const int chunk = (int)(t / (TAIL_CK / 4));
+    const int ci = chunk * TAIL_CK + c4 * 4 + kq;
+    const int o = tail_row_channel(mt * 16 + i, Cout, paired);
+    wp[e] = (o >= 0 && ci < Cin) ? w[((long)o * Cin + ci) * 9 + tap] : 0.f;
+}
+
+int conv_mfma_tail_pack(const float* w, int Cin, int Cout, int paired, float* wp, hipStream_t s) {
+    const int MT = tail_mt(Cout, paired);
+    const long total = (long)tail_chunks(Cin) * (TAIL_CK / 4) * 9 * MT * 64;
+    hipLaunchKernelGGL(k_pack_tail, dim3(cdiv(total, 256)), dim3(256), 0, s, w, Cin, Cout, paired, MT, total, wp);
+    GH_LAUNCH_CHECK("k_pack_tail");
+    return GLOWHIP_OK;
+}
+
+__device__ __forceinline__ float gauss_logp1_(float mean, float logs, float x) {
+    const float d = x - mean;
+    return -0.5f * (LOG_2PI_F + 2.0f * logs + (d * d) / expf(2.0f * logs));
+}
+
+struct TailGeom {
+    int RS;    // LDS row stride (floats) = W + 8
+    int CHS;   // LDS channel stride (floats), == 16 mod 32
+    int TR;    // image rows per block tile
+    int W4;    // W / 4
+};
+
+template <int MT, int NTW>
+__global__ void __launch_bounds__(256) k_conv_tail(TailConvArgs a, TailGeom g, int paired) {
+    constexpr int TP = 64 * NTW;                       // pixels per block (4 waves x NTW x 16)
+    constexpr int A_FLOATS = (TAIL_CK / 4) * 9 * MT * 64;
+    constexpr int A_F4 = A_FLOATS / 4;
+    constexpr int A_IT = (A_F4 + 255) / 256;
+    constexpr int X_IT_MAX = 6;                        // ceil(32 * (TR+2) * W4 / 256) <= 6 for every supported geometry
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* Xs = lds;                                   // [TAIL_CK][CHS]
+    float* As = lds + TAIL_CK * g.CHS;                 // [8][9][MT][64]
+    __shared__ double red[4];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int HW = a.H * a.W;
+    const long gp0 = (long)blockIdx.x * TP;
+    const long n = gp0 / HW;
+    const int p0 = (int)(gp0 - n * HW);
+    const int y0 = p0 / a.W;
+    const float* xin = a.x + n * a.x_bs;
+
+    // zero the X image once: pad columns / out-of-image rows are never written afterwards
+    for (int e = tid; e < TAIL_CK * g.CHS; e += 256) Xs[e] = 0.f;
+
+    const int rows = g.TR + 2;
+    const int x_per_ch = rows * g.W4;
+    const int x_count = TAIL_CK * x_per_ch;
+    const int nchunks = (a.Cin + TAIL_CK - 1) / TAIL_CK;
+
+    float4 rx[X_IT_MAX];
+    float4 rA[A_IT];
+    int x_dst[X_IT_MAX];
+    long x_src[X_IT_MAX];
+    bool x_rowok[X_IT_MAX];
+    int x_c[X_IT_MAX];
+#pragma unroll
+    for (int it = 0; it < X_IT_MAX; ++it) {
+        const int e = it * 256 + tid;
+        const int c = e / x_per_ch, rem = e - c * x_per_ch;
+        const int r = rem / g.W4, x4 = rem - r * g.W4;
+        const int yy = y0 - 1 + r;
+        x_c[it] = (e < x_count) ? c : TAIL_CK;  // TAIL_CK => never loaded
+        x_rowok[it] = (e < x_count) && yy >= 0 && yy < a.H;
+        x_src[it] = (long)c * HW + (long)yy * a.W + x4 * 4;
+        x_dst[it] = c * g.CHS + r * g.RS + 4 + x4 * 4;
+    }
+    auto load_chunk = [&](int ch) {
+        const int cbase = ch * TAIL_CK;
+#pragma unroll
+        for (int it = 0; it < X_IT_MAX; ++it) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (x_rowok[it] && cbase + x_c[it] < a.Cin)
+                v = *reinterpret_cast<const float4*>(xin + (long)cbase * HW + x_src[it]);
+            rx[it] = v;
+        }
+        const float4* asrc = reinterpret_cast<const float4*>(a.wp + (long)ch * A_FLOATS);
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            const int e = it * 256 + tid;
+            rA[it] = (e < A_F4) ? asrc[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store_chunk = [&]() {
+        // rows outside the image / channels beyond Cin hold zeros in rx: written too, so the halo stays clean
+#pragma unroll
+        for (int it = 0; it < X_IT_MAX; ++it)
+            if (x_c[it] < TAIL_CK) *reinterpret_cast<float4*>(Xs + x_dst[it]) = rx[it];
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            const int e = it * 256 + tid;
+            if (e < A_F4) reinterpret_cast<float4*>(As)[e] = rA[it];
+        }
+    };
+
+    // per-lane LDS offsets of this wave's pixels
+    int boff[NTW];
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+        const int q = (wid * NTW + nt) * 16 + (lane & 15);
+        const int r = q / a.W, x = q - r * a.W;
+        boff[nt] = (r + 1) * g.RS + x + 4 + (lane >> 4) * g.CHS;
+    }
+
+    f32x4 acc[MT][NTW];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) acc[m][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    load_chunk(0);
+    __syncthreads();  // zero-fill done
+    store_chunk();
+    __syncthreads();
+    for (int ch = 0; ch < nchunks; ++ch) {
+        if (ch + 1 < nchunks) load_chunk(ch + 1);
+        const int left = a.Cin - ch * TAIL_CK;
+        const int nc4 = left >= TAIL_CK ? TAIL_CK / 4 : (left + 3) / 4;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int toff = (tap / 3 - 1) * g.RS + (tap % 3 - 1);
+            if (nc4 == TAIL_CK / 4) {
+#pragma unroll
+                for (int c4 = 0; c4 < TAIL_CK / 4; ++c4) {
+                    float av[MT], bv[NTW];
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) av[m] = As[((c4 * 9 + tap) * MT + m) * 64 + lane];
+#pragma unroll
+                    for (int nt = 0; nt < NTW; ++nt) bv[nt] = Xs[boff[nt] + c4 * 4 * g.CHS + toff];
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int nt = 0; nt < NTW; ++nt)
+                            acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bv[nt], acc[m][nt], 0, 0, 0);
+                }
+            } else {
+                for (int c4 = 0; c4 < nc4; ++c4) {
+                    float av[MT], bv[NTW];
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) av[m] = As[((c4 * 9 + tap) * MT + m) * 64 + lane];
+#pragma unroll
+                    for (int nt = 0; nt < NTW; ++nt) bv[nt] = Xs[boff[nt] + c4 * 4 * g.CHS + toff];
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int nt = 0; nt < NTW; ++nt)
+                            acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bv[nt], acc[m][nt], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+        if (ch + 1 < nchunks) {
+            store_chunk();
+            __syncthreads();
+        }
+    }
+
+    // ---------------------------------------------------------------- epilogue
+    double ld = 0.0;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int mrow = m * 16 + (lane >> 4) * 4;
+        float hb[4], hs[4];
+        int oc[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            oc[r] = tail_row_channel(mrow + r, a.Cout, paired);
+            hb[r] = oc[r] >= 0 ? a.bias[oc[r]] : 0.f;
+            hs[r] = oc[r] >= 0 ? a.scale[oc[r]] : 0.f;
+        }
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+            const int p = p0 + (wid * NTW + nt) * 16 + (lane & 15);
+            float hv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) hv[r] = (acc[m][nt][r] + hb[r]) * hs[r];
+            if (paired) {
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    if (oc[e] < 0) continue;
+                    const int c = oc[e] >> 1;  // coupling channel
+                    const float A_ = hv[e], B_ = hv[2 + e];
+                    const long zi = n * a.z2_in_bs + (long)c * HW + p;
+                    const long zo = n * a.z2_out_bs + (long)c * HW + p;
+                    if (a.mode == TAIL_AFFINE_FWD) {
+                        const float sc = sigmoidf_(B_ + 2.0f);
+                        a.z2_out[zo] = (a.z2_in[zi] + A_) * sc;
+                        ld += (double)logf(sc);
+                    } else if (a.mode == TAIL_AFFINE_REV) {
+                        const float sc = sigmoidf_(B_ + 2.0f);
+                        a.z2_out[zo] = a.z2_in[zi] / sc - A_;
+                        ld -= (double)logf(sc);
+                    } else if (a.mode == TAIL_SPLIT_FWD) {
+                        ld += (double)gauss_logp1_(A_, B_, a.z2_in[zi]);
+                    } else {  // TAIL_SPLIT_REV
+                        a.z2_out[zo] = A_ + expf(B_) * a.z2_in[zi];
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (oc[r] < 0) continue;
+                    const long zo = n * a.z2_out_bs + (long)oc[r] * HW + p;
+                    if (a.mode == TAIL_PLAIN) a.z2_out[zo] = hv[r];
+                    else {
+                        const float z2 = a.z2_in[n * a.z2_in_bs + (long)oc[r] * HW + p];
+                        a.z2_out[zo] = a.mode == TAIL_ADD_FWD ? z2 + hv[r] : z2 - hv[r];
+                    }
+                }
+            }
+        }
+    }
+    if (a.acc && (a.mode == TAIL_AFFINE_FWD || a.mode == TAIL_AFFINE_REV || a.mode == TAIL_SPLIT_FWD)) {
+        const double tot = block_sum<256>(ld, red);
+        if (tid == 0) fix_atomic_add(a.acc + n, tot);
+    }
+}
+
+template <int MT, int NTW>
+static int launch_tail_cfg(const TailConvArgs& a, const TailGeom& g, int paired, hipStream_t s) {
+    constexpr int TP = 64 * NTW;
+    const long total_px = (long)a.N * a.H * a.W;
+    const size_t lds = ((size_t)TAIL_CK * g.CHS + (size_t)(TAIL_CK / 4) * 9 * MT * 64) * sizeof(float);
+    if (lds > 48 * 1024)
+        (void)hipFuncSetAttribute((const void*)k_conv_tail<MT, NTW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL((k_conv_tail<MT, NTW>), dim3((unsigned)(total_px / TP)), dim3(256), lds, s, a, g, paired);
+    GH_LAUNCH_CHECK("k_conv_tail");
+    return GLOWHIP_OK;
+}
+
+int launch_conv_mfma_tail(const TailConvArgs& a, hipStream_t s) {
+    GH_REQUIRE(conv_mfma_tail_supported(a.Cin, a.H, a.W, a.Cout), "conv_mfma_tail: unsupported shape");
+    if (a.N == 0) return GLOWHIP_OK;
+    const int paired = tail_paired(a.mode);
+    GH_REQUIRE(!paired || a.Cout % 2 == 0, "conv_mfma_tail: paired mode needs an even Cout");
+    const int TP = tail_tp(a.H, a.W);
+    TailGeom g;
+    g.RS = a.W + 8;
+    g.TR = TP / a.W;
+    g.W4 = a.W / 4;
+    int chs = (g.TR + 2) * g.RS;
+    chs += ((16 - (chs % 32)) + 32) % 32;  // -> == 16 (mod 32)
+    g.CHS = chs;
+    GH_REQUIRE(TAIL_CK * (g.TR + 2) * g.W4 <= 6 * 256, "conv_mfma_tail: halo tile too large");
+    const int MT = tail_mt(a.Cout, paired);
+    const int NTW = TP / 64;
+#define GH_TAIL_CASE(mt, ntw) \
+    if (MT == mt && NTW == ntw) return launch_tail_cfg<mt, ntw>(a, g, paired, s);
+    GH_TAIL_CASE(1, 1) GH_TAIL_CASE(1, 2) GH_TAIL_CASE(2, 1) GH_TAIL_CASE(2, 2) GH_TAIL_CASE(3, 1) GH_TAIL_CASE(3, 2)
+#undef GH_TAIL_CASE
+    set_error("conv_mfma_tail: no kernel for MT=%d NTW=%d", MT, NTW);
+    return GLOWHIP_EINVAL;
+}
+
+}  // namespace glowhip

@@ -28,8 +28,14 @@ struct LayerPlan {
 
 using namespace glowhip;
 
+struct TimingSlot { int kind, layer, mfma; hipEvent_t a, b; };
+
 struct glowhip_plan {
     std::vector<LayerPlan> layers;
+    bool timing = false;
+    std::vector<hipEvent_t> ev_pool;     // unused events
+    std::vector<TimingSlot> ev_used;     // recorded, not yet read
+    int cur_layer = 0;
     size_t packed_bytes = 0;
     int in_shape[3] = {0, 0, 0}, out_shape[3] = {0, 0, 0};
     long max_chw = 0;      // max over layer inputs/outputs of C*H*W
@@ -44,6 +50,19 @@ static size_t take(size_t& off, size_t bytes) {
     off = o + bytes;
     return o;
 }
+
+// ---------------------------------------------------------------- optional per-launch timing
+struct ScopedTimer {
+    glowhip_plan* p; hipStream_t s; TimingSlot slot; bool on;
+    ScopedTimer(glowhip_plan* plan, int kind, int mfma, hipStream_t st) : p(plan), s(st), on(plan && plan->timing) {
+        if (!on) return;
+        auto get = [&]() { hipEvent_t e; if (!p->ev_pool.empty()) { e = p->ev_pool.back(); p->ev_pool.pop_back(); }
+                           else (void)hipEventCreate(&e); return e; };
+        slot.kind = kind; slot.layer = p->cur_layer; slot.mfma = mfma; slot.a = get(); slot.b = get();
+        (void)hipEventRecord(slot.a, s);
+    }
+    ~ScopedTimer() { if (on) { (void)hipEventRecord(slot.b, s); p->ev_used.push_back(slot); } }
+};
 
 // ---------------------------------------------------------------- pack kernels
 __global__ void __launch_bounds__(256) k_pack_scales(const float* __restrict__ logs, int n, float* __restrict__ scale,
@@ -117,12 +136,14 @@ static int carve(const glowhip_plan* p, int N, void* ws, size_t bytes, Workspace
 // ---------------------------------------------------------------- coupling network f() (network/module.py:300-319)
 // Runs conv3x3 -> actnorm -> relu -> conv1x1 -> actnorm -> relu -> conv3x3(zeros) and applies the
 // coupling to z2.  x1: first-half channels (batch stride x1_bs).
-static int run_coupling(const LayerPlan& L, const void* packed, const float* x1, long x1_bs, const float* z2_in,
+static int run_coupling(glowhip_plan* P, const LayerPlan& L, const void* packed, const float* x1, long x1_bs, const float* z2_in,
                         long z2_in_bs, float* z2_out, long z2_out_bs, int N, int reverse, const Workspace& w,
                         hipStream_t s) {
     const glowhip_layer_desc& d = L.d;
     const int Ch = d.C / 2, HW = d.H * d.W, hid = d.hidden;
     // f.0: 3x3, Cin=C/2 -> hidden, ActNorm + ReLU epilogue
+    {
+    ScopedTimer t0(P, GLOWHIP_K_CONV_F0, L.mfma_first, s);
     if (L.mfma_first) {
         GH_TRY(launch_conv_mfma_wide(x1, x1_bs, at<float>(packed, L.f0_wt), d.f0_an_bias, at<float>(packed, L.f0_scale),
                                      w.h1, N, Ch, d.H, d.W, hid, 3, s));
@@ -131,7 +152,10 @@ static int run_coupling(const LayerPlan& L, const void* packed, const float* x1,
                    N, Ch, d.H, d.W, hid, 3};
         GH_TRY(launch_conv_direct(c, s));
     }
+    }
     // f.2: 1x1, hidden -> hidden, ActNorm + ReLU epilogue
+    {
+    ScopedTimer t2(P, GLOWHIP_K_CONV_F2, L.mfma_mid, s);
     if (L.mfma_mid) {
         GH_TRY(launch_conv_mfma_wide(w.h1, (long)hid * HW, at<float>(packed, L.f2_wt), d.f2_an_bias,
                                      at<float>(packed, L.f2_scale), w.h2, N, hid, d.H, d.W, hid, 1, s));
@@ -140,7 +164,9 @@ static int run_coupling(const LayerPlan& L, const void* packed, const float* x1,
                    N, hid, d.H, d.W, hid, 1};
         GH_TRY(launch_conv_direct(c, s));
     }
+    }
     // f.4: 3x3 zeros conv (+bias, *exp(3 logs)) and the coupling itself
+    ScopedTimer t4(P, GLOWHIP_K_CONV_F4, L.mfma_last, s);
     if (L.mfma_last) {
         TailConvArgs t{};
         t.x = w.h2; t.x_bs = (long)hid * HW; t.wp = at<float>(packed, L.f4_wp); t.bias = d.f4_bias;
@@ -196,6 +222,7 @@ static int run_forward(glowhip_plan* p, const void* packed, const float* x, cons
     for (int li = 0; li < nl; ++li) {
         const LayerPlan& L = p->layers[li];
         const glowhip_layer_desc& d = L.d;
+        p->cur_layer = li;
         float* dst = (li == nl - 1) ? z_out : other_buf(w, cur);
         const int HW = d.H * d.W;
         const long chw = (long)d.C * HW;
@@ -219,9 +246,12 @@ static int run_forward(glowhip_plan* p, const void* packed, const float* x, cons
                 m.matrix = d.permutation == GLOWHIP_PERM_INVCONV ? d.invconv_w : nullptr;
                 m.gather = d.permutation == GLOWHIP_PERM_GATHER ? d.perm_idx : nullptr;
                 m.reverse = 0; m.N = N; m.C = d.C; m.HW = HW;
-                GH_TRY(launch_chanmix(m, s));
+                {
+                    ScopedTimer tm(p, GLOWHIP_K_CHANMIX, 0, s);
+                    GH_TRY(launch_chanmix(m, s));
+                }
                 float* z2 = dst + (long)Ch * HW;
-                GH_TRY(run_coupling(L, packed, dst, chw, z2, chw, z2, chw, N, 0, w, s));
+                GH_TRY(run_coupling(p, L, packed, dst, chw, z2, chw, z2, chw, N, 0, w, s));
             } else {  // SPLIT2D: score z2 under the prior predicted from z1, keep z1
                 GH_TRY(run_split(L, packed, cur, chw, cur + (long)Ch * HW, chw, nullptr, nullptr, 0, N, 0, w, s));
                 GH_TRY(launch_copy_strided(cur, chw, dst, (long)Ch * HW, N, (long)Ch * HW, s));
@@ -241,6 +271,7 @@ static int run_reverse(glowhip_plan* p, const void* packed, const float* z, cons
     for (int li = nl - 1; li >= 0; --li) {
         const LayerPlan& L = p->layers[li];
         const glowhip_layer_desc& d = L.d;
+        p->cur_layer = li;
         float* dst = (li == 0) ? x_out : other_buf(w, cur);
         const int HW = d.H * d.W;
         const long chw = (long)d.C * HW;
@@ -249,7 +280,7 @@ static int run_reverse(glowhip_plan* p, const void* packed, const float* z, cons
             GH_TRY(launch_squeeze(cur, nullptr, dst, N, d.C * 4, d.H / 2, d.W / 2, 2, 1, s));
         } else if (d.kind == GLOWHIP_LAYER_FLOWSTEP) {
             float* z2 = dst + (long)Ch * HW;
-            GH_TRY(run_coupling(L, packed, cur, chw, cur + (long)Ch * HW, chw, z2, chw, N, 1, w, s));
+            GH_TRY(run_coupling(p, L, packed, cur, chw, cur + (long)Ch * HW, chw, z2, chw, N, 1, w, s));
             ChanMixArgs m{};
             m.in_a = cur; m.in_a_bs = chw; m.in_b = z2; m.in_b_bs = chw; m.Ca = Ch;
             m.out = dst; m.out_bs = chw;
@@ -257,6 +288,7 @@ static int run_reverse(glowhip_plan* p, const void* packed, const float* z, cons
             m.matrix = d.permutation == GLOWHIP_PERM_INVCONV ? at<float>(packed, L.winv) : nullptr;
             m.gather = d.permutation == GLOWHIP_PERM_GATHER ? d.perm_idx_inv : nullptr;
             m.reverse = 1; m.N = N; m.C = d.C; m.HW = HW;
+            ScopedTimer tm(p, GLOWHIP_K_CHANMIX, 0, s);
             GH_TRY(launch_chanmix(m, s));
         } else {  // SPLIT2D reverse: z1 = cur (N, C/2, HW) -> cat(z1, mean + exp(logs)*eps)
             GH_REQUIRE(ke < n_eps && eps && eps[ke], "decode: missing eps draw for Split2d #%d", ke);
@@ -357,7 +389,40 @@ glowhip_plan* glowhip_plan_create(const glowhip_layer_desc* layers, int n_layers
     return p;
 }
 
-void glowhip_plan_destroy(glowhip_plan* plan) { delete plan; }
+void glowhip_plan_destroy(glowhip_plan* plan) {
+    if (!plan) return;
+    for (hipEvent_t e : plan->ev_pool) (void)hipEventDestroy(e);
+    for (TimingSlot& t : plan->ev_used) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
+    delete plan;
+}
+
+int glowhip_plan_timing_enable(glowhip_plan* plan, int enable) {
+    GH_REQUIRE(plan, "plan_timing_enable: null plan");
+    plan->timing = enable != 0;
+    if (!enable) {
+        for (hipEvent_t e : plan->ev_pool) (void)hipEventDestroy(e);
+        for (TimingSlot& t : plan->ev_used) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
+        plan->ev_pool.clear();
+        plan->ev_used.clear();
+    }
+    return GLOWHIP_OK;
+}
+
+int glowhip_plan_timing_read(glowhip_plan* plan, glowhip_timing_record* out, int max, int* n_out) {
+    GH_REQUIRE(plan && n_out, "plan_timing_read: null argument");
+    int n = 0;
+    for (TimingSlot& t : plan->ev_used) {
+        if (hipEventSynchronize(t.b) != hipSuccess) { set_error("plan_timing_read: hipEventSynchronize failed"); return GLOWHIP_ELAUNCH; }
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, t.a, t.b);
+        if (out && n < max) { out[n].kind = t.kind; out[n].layer = t.layer; out[n].mfma = t.mfma; out[n].ms = ms; ++n; }
+        plan->ev_pool.push_back(t.a);
+        plan->ev_pool.push_back(t.b);
+    }
+    plan->ev_used.clear();
+    *n_out = n;
+    return GLOWHIP_OK;
+}
 
 size_t glowhip_plan_packed_bytes(const glowhip_plan* plan) { return plan ? plan->packed_bytes : 0; }
 

@@ -356,3 +356,85 @@ def test_edge_cases():
     x_ = fm(y, det, reverse=True)
     assert x_.shape == x.shape
     assert fm.output_shapes[-1] == [-1, 48, 2, 2]
+
+
+# ------------------------------------------------------------------------------------------------ MFMA kernels
+def _rand_step(c, hidden, coup, seed):
+    g = torch.Generator().manual_seed(seed)
+    np.random.seed(seed)
+    st = G.FlowStep(c, hidden, permutation="invconv", coupling=coup)
+    with torch.no_grad():
+        for name, p in st.named_parameters():
+            if name == "invconv.weight":
+                p.copy_(torch.from_numpy(np.linalg.qr(np.random.randn(c, c))[0].astype("float32")) +
+                        0.05 * torch.randn(c, c, generator=g))
+            elif name.endswith("logs") or name.endswith("bias"):
+                p.copy_(torch.randn(p.shape, generator=g) * 0.1)
+            elif name.startswith("f.4"):
+                p.copy_(torch.randn(p.shape, generator=g) * 0.02)
+            else:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.05)
+    sd = {k: v.clone() for k, v in st.state_dict().items()}
+    return load_sd(st, sd), sd
+
+
+@pytest.mark.parametrize("c,h,w,hidden,coup,n", [
+    (12, 32, 32, 128, "affine", 3),    # level-1 geometry: tail MT=1 NTW=2, wide 64-tile (small grid)
+    (12, 32, 32, 64, "additive", 2),   # unpaired tail rows
+    (24, 16, 16, 64, "affine", 5),     # level-2 geometry: tail MT=2 NTW=2
+    (48, 8, 8, 128, "affine", 4),      # level-3 geometry: tail MT=3 NTW=1, pixel tiles spanning two images
+    (24, 8, 8, 64, "additive", 3),
+    (12, 64, 16, 64, "affine", 1),     # non-square
+    (4, 8, 16, 64, "affine", 2),       # Cin=2 for f.0 (K=18 padded to 32)
+])
+def test_mfma_flowstep_vs_oracle(c, h, w, hidden, coup, n):
+    st, sd = _rand_step(c, hidden, coup, seed=c * 1000 + h)
+    x = torch.randn(n, c, h, w, generator=torch.Generator().manual_seed(1))
+    ld = torch.randn(n, generator=torch.Generator().manual_seed(2))
+    desc = st._plan(dev(x)).describe()
+    assert "f0=mfma f2=mfma f4=mfma" in desc, desc
+    z, ldz = st(dev(x), dev(ld))
+    zr, ldr = O.flowstep(x, ld, sd, "", "invconv", coup)
+    close(z, zr, 2e-5, what="fwd z"); ld_close(ldz, ldr)
+    xi, ldi = st(dev(x), dev(ld), reverse=True)
+    xr, ldxr = O.flowstep(x, ld, sd, "", "invconv", coup, reverse=True)
+    close(xi, xr, 5e-5, what="rev x"); ld_close(ldi, ldxr)
+
+
+@pytest.mark.parametrize("c,h,w,n", [(12, 32, 32, 3), (24, 16, 16, 2), (48, 8, 8, 5)])
+def test_mfma_split2d_vs_oracle(c, h, w, n):
+    g = torch.Generator().manual_seed(c)
+    sp = G.Split2d(c)
+    with torch.no_grad():
+        for p in sp.parameters():
+            p.copy_(torch.randn(p.shape, generator=g) * 0.05)
+    sd = {k: v.clone() for k, v in sp.state_dict().items()}
+    sp = load_sd(sp, sd)
+    x = torch.randn(n, c, h, w, generator=g)
+    assert "prior=mfma" in sp._plans.get([sp], (c, h, w), torch.device(DEV)).describe()
+    z1, ld = sp(dev(x), 0.)
+    z1r, ldr = O.split2d(x, 0.0, sd, "", reverse=False)
+    assert torch.equal(z1.cpu(), z1r)
+    ld_close(ld, ldr)
+    eps = torch.randn(n, c // 2, h, w, generator=g)
+    xr, _ = sp(dev(z1r), 0., reverse=True, eps=dev(eps))
+    xo, _ = O.split2d(z1r, 0.0, sd, "", reverse=True, eps=eps)
+    close(xr, xo, 1e-5)
+
+
+def test_mfma_transpose_detecting():
+    """MFMA fragment-layout check with asymmetric operands (a swapped C write would pass a symmetric test):
+    1x1 conv with W[o][i] = o*0.001 + i and one-hot inputs; 3x3 conv with a single off-centre tap."""
+    hid = 128
+    st, sd = _rand_step(12, hid, "affine", seed=3)
+    with torch.no_grad():
+        w = (torch.arange(hid).view(hid, 1) * 1e-3 + torch.arange(hid).view(1, hid) * 1e-5).view(hid, hid, 1, 1)
+        st.f[2].weight.copy_(w)
+        w0 = torch.zeros(hid, 6, 3, 3)
+        w0[:, :, 0, 2] = torch.arange(hid).view(hid, 1) * 1e-3 + torch.arange(6).view(1, 6) * 0.1 + 0.05  # tap (ky=0,kx=2)
+        st.f[0].weight.copy_(w0)
+    sd = {k: v.detach().cpu().clone() for k, v in st.state_dict().items()}
+    x = torch.randn(2, 12, 32, 32, generator=torch.Generator().manual_seed(4))
+    z, ld = st(dev(x), 0.)
+    zr, ldr = O.flowstep(x, torch.zeros(2), sd, "", "invconv", "affine")
+    close(z, zr, 5e-5); ld_close(ld, ldr)
