@@ -34,6 +34,22 @@ struct TailConvArgs {
     float* z2_out; long z2_out_bs;
     unsigned long long* acc;
 };
+constexpr int TAIL_CK = 32;  // input channels per LDS chunk of the tail kernel
+// number of 16-row MFMA tiles on the out-channel axis
+__host__ __device__ inline int tail_mt(int Cout, int paired) {
+    const int rows = paired ? 4 * ((Cout / 2 + 1) / 2) : Cout;
+    return (rows + 15) / 16;
+}
+// out-row m -> original output channel (or -1).  paired: a lane's 4 consecutive rows are
+// {even_c0, even_c1, odd_c0, odd_c1} of two coupling channels c0 = 2g, c1 = 2g+1.
+__host__ __device__ inline int tail_row_channel(int m, int Cout, int paired) {
+    if (!paired) return m < Cout ? m : -1;
+    const int g = m >> 2, r = m & 3;
+    const int c = 2 * g + (r & 1);
+    return c < Cout / 2 ? 2 * c + (r >> 1) : -1;
+}
+inline int tail_chunks(int Cin) { return (Cin + TAIL_CK - 1) / TAIL_CK; }
+inline int wide_kpad(int Cin, int ksize) { return (Cin * ksize * ksize + 31) / 32 * 32; }
 bool conv_mfma_tail_supported(int Cin, int H, int W, int Cout);
 size_t conv_mfma_tail_packed_bytes(int Cin, int Cout);
 // paired=1: output channels come in (even, odd) = (shift|mean, scale|logs) pairs (affine coupling, Split2d)

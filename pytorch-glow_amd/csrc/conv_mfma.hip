@@ -43,8 +43,10 @@ k_conv_wide(const float* __restrict__ X, long x_bs, const float* __restrict__ Wt
     constexpr int A_RPP = 256 / A_F4, B_RPP = 256 / B_F4;  // rows per pass
     constexpr int A_PASSES = BK / A_RPP, B_PASSES = BK / B_RPP;
     static_assert(A_PASSES >= 1 && B_PASSES >= 1, "tile too wide for 256 threads");
-    __shared__ __attribute__((aligned(16))) float As[BK][BM];
-    __shared__ __attribute__((aligned(16))) float Bs[BK][BN];
+    // double-buffered K-major operand tiles: ONE barrier per K-tile (the write of tile t+1 goes to the
+    // buffer nobody reads during tile t)
+    __shared__ __attribute__((aligned(16))) float As[2][BK][BM];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN];
 
     const int HW = H * W;
     const long total_px = (long)N * HW;
@@ -93,13 +95,13 @@ k_conv_wide(const float* __restrict__ X, long x_bs, const float* __restrict__ Wt
             rb[ps] = v;
         }
     };
-    auto store_tile = [&]() {
+    auto store_tile = [&](int buf) {
 #pragma unroll
         for (int ps = 0; ps < A_PASSES; ++ps)
-            *reinterpret_cast<float4*>(&As[ps * A_RPP + a_row][a_c4 * 4]) = ra[ps];
+            *reinterpret_cast<float4*>(&As[buf][ps * A_RPP + a_row][a_c4 * 4]) = ra[ps];
 #pragma unroll
         for (int ps = 0; ps < B_PASSES; ++ps)
-            *reinterpret_cast<float4*>(&Bs[ps * B_RPP + b_row][b_c4 * 4]) = rb[ps];
+            *reinterpret_cast<float4*>(&Bs[buf][ps * B_RPP + b_row][b_c4 * 4]) = rb[ps];
     };
 
     f32x16 acc[TM][TN];
@@ -112,29 +114,39 @@ k_conv_wide(const float* __restrict__ X, long x_bs, const float* __restrict__ Wt
 
     const int nkt = Kpad / BK;
     load_tile(0);
-    store_tile();
+    store_tile(0);
     __syncthreads();
     const int kl = lane >> 5, ml = lane & 31;
     for (int kt = 0; kt < nkt; ++kt) {
-        if (kt + 1 < nkt) load_tile(kt + 1);  // in flight under the MFMAs below
+        const int buf = kt & 1;
+        if (kt + 1 < nkt) load_tile(kt + 1);  // HBM/L2 latency hidden under this tile's 64 MFMAs
+        // fragment reads are software-pipelined one k-step ahead of the MFMAs that consume them
+        float a[2][TM], b[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[0][i] = As[buf][kl][wr * WM + i * 32 + ml];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[0][j] = Bs[buf][kl][wc * WN + j * 32 + ml];
 #pragma unroll
         for (int kk = 0; kk < BK / 2; ++kk) {
-            float a[TM], b[TN];
+            const int cur = kk & 1, nxt = cur ^ 1;
+            if (kk + 1 < BK / 2) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = As[kk * 2 + kl][wr * WM + i * 32 + ml];
+                for (int i = 0; i < TM; ++i) a[nxt][i] = As[buf][(kk + 1) * 2 + kl][wr * WM + i * 32 + ml];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = Bs[kk * 2 + kl][wc * WN + j * 32 + ml];
+                for (int j = 0; j < TN; ++j) b[nxt][j] = Bs[buf][(kk + 1) * 2 + kl][wc * WN + j * 32 + ml];
+            }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
+            // pin the issue order: next step's LDS reads go out BEFORE this step's MFMAs (hipcc otherwise sinks
+            // them behind the MFMAs and waits lgkmcnt(0) with the matrix pipe idle)
+            if (kk + 1 < BK / 2) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
         }
+        if (kt + 1 < nkt) store_tile(buf ^ 1);
         __syncthreads();
-        if (kt + 1 < nkt) {
-            store_tile();
-            __syncthreads();
-        }
     }
 
     // ---- epilogue: ActNorm (+bias, *scale) + ReLU, C[row=o][col=pixel]
@@ -169,11 +181,6 @@ bool conv_mfma_wide_supported(int Cin, int H, int W, int Cout, int ksize) {
     if (ksize == 1) return Cin % 32 == 0;
     if (ksize == 3) return W % 4 == 0 && Cin >= 1;
     return false;
-}
-
-static int wide_kpad(int Cin, int ksize) {
-    const int K = Cin * ksize * ksize;
-    return (K + 31) / 32 * 32;
 }
 
 size_t conv_mfma_wide_packed_bytes(int Cin, int Cout, int ksize) {

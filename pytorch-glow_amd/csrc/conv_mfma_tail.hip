@@ -16,20 +16,6 @@ namespace glowhip {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int TAIL_CK = 32;  // input channels per LDS chunk
-
-__host__ __device__ inline int tail_mt(int Cout, int paired) {
-    const int rows = paired ? 4 * ((Cout / 2 + 1) / 2) : Cout;
-    return (rows + 15) / 16;
-}
-// out-row m -> original output channel (or -1)
-__host__ __device__ inline int tail_row_channel(int m, int Cout, int paired) {
-    if (!paired) return m < Cout ? m : -1;
-    const int g = m >> 2, r = m & 3;
-    const int c = 2 * g + (r & 1);
-    return c < Cout / 2 ? 2 * c + (r >> 1) : -1;
-}
-
 static int tail_tp(int H, int W) {
     const int HW = H * W;
     if (W <= 128 && 128 % W == 0 && HW % 128 == 0) return 128;
@@ -47,8 +33,6 @@ bool conv_mfma_tail_supported(int Cin, int H, int W, int Cout) {
     if (TAIL_CK * (TP / W + 2) * (W / 4) > 6 * 256) return false;  // halo tile must fit the 6-float4 staging
     return Cin >= 1;
 }
-
-static int tail_chunks(int Cin) { return (Cin + TAIL_CK - 1) / TAIL_CK; }
 
 size_t conv_mfma_tail_packed_bytes(int Cin, int Cout) {
     // sized for the larger of the two row layouts (paired rows >= unpaired rows for even Cout)
@@ -293,8 +277,8 @@ static int launch_tail_cfg(const TailConvArgs& a, const TailGeom& g, int paired,
     constexpr int TP = 64 * NTW;
     const long total_px = (long)a.N * a.H * a.W;
     const size_t lds = ((size_t)TAIL_CK * g.CHS + (size_t)(TAIL_CK / 4) * 9 * MT * 64) * sizeof(float);
-    if (lds > 48 * 1024)
-        (void)hipFuncSetAttribute((const void*)k_conv_tail<MT, NTW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (lds > 32 * 1024)
+        (void)hipFuncSetAttribute((const void*)k_conv_tail<MT, NTW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((k_conv_tail<MT, NTW>), dim3((unsigned)(total_px / TP)), dim3(256), lds, s, a, g, paired);
     GH_LAUNCH_CHECK("k_conv_tail");
     return GLOWHIP_OK;

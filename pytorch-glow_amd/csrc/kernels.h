@@ -61,6 +61,25 @@ int launch_finalize(const float* in, const unsigned long long* acc, const double
 size_t invconv_scratch_bytes(int C);
 int launch_invconv_prepare(const float* w, int C, float* winv, float* logabsdet, void* scratch, hipStream_t s);
 
+// batched parameter preparation (glowhip_plan_pack): device-resident job tables, offsets into `packed`
+struct StepPrepJob {
+    const float* w;         // invconv weight (C,C) or null (permutation step)
+    const float* an_logs;   // actnorm.logs (C)
+    int C, HW;
+    size_t winv_off, logabsdet_off, konst_off, scratch_off;
+};
+int launch_step_prepare_batched(const StepPrepJob* jobs_dev, int n, int max_lds_c, void* packed, hipStream_t s);
+
+struct ScaleJob { const float* logs; size_t scale_off, inv_off; int n; int has_inv; };
+enum { REPACK_WIDE = 0, REPACK_TAIL = 1 };
+struct RepackJob {
+    const float* w; size_t out_off; int kind;
+    int Cin, Cout, K, Kpad;      // wide: K = Cin*k*k
+    int paired, MT; long total;  // tail
+};
+int launch_pack_batched(const ScaleJob* sj_dev, int n_scale, const RepackJob* rj_dev, int n_repack, void* packed,
+                        hipStream_t s);
+
 // ---------------------------------------------------------------- conv_direct.hip
 struct ConvArgs {
     const float* x; long x_bs;

@@ -10,14 +10,12 @@ size_t invconv_scratch_bytes(int C) { return (size_t)C * 2 * C * sizeof(double);
 
 constexpr int LU_LDS_MAX_C = 64;  // 64 * 128 * 8 B = 64 KiB
 
-template <bool USE_LDS>
-__global__ void __launch_bounds__(256) k_invconv_prepare(const float* __restrict__ w, int C, float* __restrict__ winv,
-                                                         float* __restrict__ logabsdet, double* __restrict__ scratch) {
-    extern __shared__ __attribute__((aligned(16))) double lds_aug[];
+// Workgroup-wide Gauss-Jordan on A = [W | I] (C x 2C doubles, LDS or global).  Returns log|det W| (thread 0).
+__device__ double lu_gauss_jordan(const float* __restrict__ w, int C, float* __restrict__ winv, double* A) {
     __shared__ int s_piv;
     __shared__ double s_logdet;
-    double* A = USE_LDS ? lds_aug : scratch;
     const int tid = threadIdx.x, W2 = 2 * C;
+    __syncthreads();  // s_logdet / A may still be read by a previous use in this workgroup
     for (int e = tid; e < C * W2; e += 256) {
         int r = e / W2, c = e - r * W2;
         A[e] = (c < C) ? (double)w[r * C + c] : ((c - C == r) ? 1.0 : 0.0);
@@ -74,16 +72,67 @@ __global__ void __launch_bounds__(256) k_invconv_prepare(const float* __restrict
             int r = e / C, c = e - r * C;
             winv[e] = (float)A[r * W2 + C + c];
         }
-    if (tid == 0 && logabsdet) logabsdet[0] = (float)s_logdet;
+    return s_logdet;
+}
+
+template <bool USE_LDS>
+__global__ void __launch_bounds__(256) k_invconv_prepare(const float* __restrict__ w, int C, float* __restrict__ winv,
+                                                         float* __restrict__ logabsdet, double* __restrict__ scratch) {
+    extern __shared__ __attribute__((aligned(16))) double lds_aug[];
+    const double ld = lu_gauss_jordan(w, C, winv, USE_LDS ? lds_aug : scratch);
+    if (threadIdx.x == 0 && logabsdet) logabsdet[0] = (float)ld;
+}
+
+// Batched form used by glowhip_plan_pack: one workgroup per FlowStep; also produces the step's
+// data-independent log-det term  konst = 3*sum(actnorm.logs)*HW + log|det W|*HW  (network/module.py:76-82,356-357).
+__global__ void __launch_bounds__(256) k_step_prepare_batched(const StepPrepJob* __restrict__ jobs, char* packed) {
+    extern __shared__ __attribute__((aligned(16))) double lds_aug[];
+    __shared__ double red[4];
+    const StepPrepJob j = jobs[blockIdx.x];
+    double lad = 0.0;
+    if (j.w) {
+        double* A = j.C <= LU_LDS_MAX_C ? lds_aug : (double*)(packed + j.scratch_off);
+        lad = lu_gauss_jordan(j.w, j.C, (float*)(packed + j.winv_off), A);
+    }
+    double acc = 0.0;
+    for (int k = threadIdx.x; k < j.C; k += 256) acc += (double)(j.an_logs[k] * LOGSCALE);
+    const double tot = block_sum<256>(acc, red);
+    if (threadIdx.x == 0) {
+        if (j.w) *(float*)(packed + j.logabsdet_off) = (float)lad;
+        *(double*)(packed + j.konst_off) = tot * (double)j.HW + (j.w ? (double)(float)lad * (double)j.HW : 0.0);
+    }
+}
+
+// plan-wide total of the per-step terms, summed in layer order by one thread (deterministic)
+__global__ void k_sum_konst(const StepPrepJob* __restrict__ jobs, int n, char* packed) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double t = 0.0;
+    for (int i = 0; i < n; ++i) t += *(const double*)(packed + jobs[i].konst_off);
+    *(double*)packed = t;
+}
+
+int launch_step_prepare_batched(const StepPrepJob* jobs_dev, int n, int max_lds_c, void* packed, hipStream_t s) {
+    if (n == 0) {
+        (void)hipMemsetAsync(packed, 0, sizeof(double), s);
+        return GLOWHIP_OK;
+    }
+    const size_t lds = invconv_scratch_bytes(max_lds_c > 0 ? max_lds_c : 1);
+    if (lds > 32 * 1024)
+        (void)hipFuncSetAttribute((const void*)k_step_prepare_batched, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_step_prepare_batched, dim3(n), dim3(256), lds, s, jobs_dev, (char*)packed);
+    GH_LAUNCH_CHECK("k_step_prepare_batched");
+    hipLaunchKernelGGL(k_sum_konst, dim3(1), dim3(64), 0, s, jobs_dev, n, (char*)packed);
+    GH_LAUNCH_CHECK("k_sum_konst");
+    return GLOWHIP_OK;
 }
 
 int launch_invconv_prepare(const float* w, int C, float* winv, float* logabsdet, void* scratch, hipStream_t s) {
     GH_REQUIRE(C > 0 && C <= 1024, "invconv_prepare: C=%d unsupported", C);
     if (C <= LU_LDS_MAX_C) {
         size_t lds = invconv_scratch_bytes(C);
-        if (lds > 48 * 1024)
+        if (lds > 32 * 1024)
             (void)hipFuncSetAttribute((const void*)k_invconv_prepare<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      160 * 1024);
+                                      (int)lds);
         hipLaunchKernelGGL(k_invconv_prepare<true>, dim3(1), dim3(256), lds, s, w, C, winv, logabsdet, (double*)nullptr);
     } else {
         GH_REQUIRE(scratch != nullptr, "invconv_prepare: scratch buffer required for C=%d", C);

@@ -1,0 +1,59 @@
+// pack.hip -- batched re-derivation of parameter-dependent data (glowhip_plan_pack): ONE launch for all
+// exp(3*logs) tables and ONE for all MFMA weight images of a plan, driven by device-resident job tables
+// (a 96-step Glow has ~390 scale jobs and ~290 repack jobs; launching them one by one cost 11 ms per pack).
+#include "kernels.h"
+#include "conv_mfma.h"
+
+namespace glowhip {
+
+__global__ void __launch_bounds__(256) k_pack_scales_batched(const ScaleJob* __restrict__ jobs, char* packed) {
+    const ScaleJob j = jobs[blockIdx.y];
+    float* scale = (float*)(packed + j.scale_off);
+    float* inv = j.has_inv ? (float*)(packed + j.inv_off) : nullptr;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < j.n; i += gridDim.x * 256) {
+        const float l3 = j.logs[i] * LOGSCALE;
+        scale[i] = expf(l3);
+        if (inv) inv[i] = expf(-l3);
+    }
+}
+
+// wide: wt[k][o] = w[o][k] (k = ci*k*k + tap), zero rows k >= K   -- K-major image for k_conv_wide
+// tail: wp[(((chunk*8 + c4)*9 + tap)*MT + mt)*64 + kq*16 + i] = w[o(mt*16+i)][chunk*32 + c4*4 + kq][tap]
+__global__ void __launch_bounds__(256) k_repack_batched(const RepackJob* __restrict__ jobs, char* packed) {
+    const RepackJob j = jobs[blockIdx.y];
+    float* out = (float*)(packed + j.out_off);
+    if (j.kind == REPACK_WIDE) {
+        const long total = (long)j.Kpad * j.Cout;
+        for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+            const int k = (int)(e / j.Cout), o = (int)(e - (long)k * j.Cout);
+            out[e] = (k < j.K) ? j.w[(long)o * j.K + k] : 0.f;
+        }
+    } else {
+        for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < j.total; e += (long)gridDim.x * 256) {
+            const int i = (int)(e & 15), kq = (int)((e >> 4) & 3);
+            long t = e >> 6;
+            const int mt = (int)(t % j.MT); t /= j.MT;
+            const int tap = (int)(t % 9); t /= 9;
+            const int c4 = (int)(t % (TAIL_CK / 4));
+            const int chunk = (int)(t / (TAIL_CK / 4));
+            const int ci = chunk * TAIL_CK + c4 * 4 + kq;
+            const int o = tail_row_channel(mt * 16 + i, j.Cout, j.paired);
+            out[e] = (o >= 0 && ci < j.Cin) ? j.w[((long)o * j.Cin + ci) * 9 + tap] : 0.f;
+        }
+    }
+}
+
+int launch_pack_batched(const ScaleJob* sj_dev, int n_scale, const RepackJob* rj_dev, int n_repack, void* packed,
+                        hipStream_t s) {
+    if (n_scale > 0) {
+        hipLaunchKernelGGL(k_pack_scales_batched, dim3(2, n_scale), dim3(256), 0, s, sj_dev, (char*)packed);
+        GH_LAUNCH_CHECK("k_pack_scales_batched");
+    }
+    if (n_repack > 0) {
+        hipLaunchKernelGGL(k_repack_batched, dim3(64, n_repack), dim3(256), 0, s, rj_dev, (char*)packed);
+        GH_LAUNCH_CHECK("k_repack_batched");
+    }
+    return GLOWHIP_OK;
+}
+
+}  // namespace glowhip

@@ -36,6 +36,12 @@ struct glowhip_plan {
     std::vector<hipEvent_t> ev_pool;     // unused events
     std::vector<TimingSlot> ev_used;     // recorded, not yet read
     int cur_layer = 0;
+    // batched pack: host copies of the job tables + their byte offsets inside `packed`
+    std::vector<StepPrepJob> prep_jobs;
+    std::vector<ScaleJob> scale_jobs;
+    std::vector<RepackJob> repack_jobs;
+    size_t prep_off = 0, scale_off = 0, repack_off = 0;
+    int max_lds_c = 0;
     size_t packed_bytes = 0;
     int in_shape[3] = {0, 0, 0}, out_shape[3] = {0, 0, 0};
     long max_chw = 0;      // max over layer inputs/outputs of C*H*W
@@ -72,21 +78,6 @@ __global__ void __launch_bounds__(256) k_pack_scales(const float* __restrict__ l
     const float l3 = logs[i] * LOGSCALE;
     scale[i] = expf(l3);
     if (inv_scale) inv_scale[i] = expf(-l3);
-}
-
-// konst = 3*sum(an_logs)*HW (+ log|det W|*HW); also accumulated into the plan-wide total.
-__global__ void __launch_bounds__(64) k_step_konst(const float* __restrict__ an_logs, int C,
-                                                   const float* __restrict__ logabsdet, int HW,
-                                                   double* __restrict__ konst, double* __restrict__ total) {
-    double acc = 0.0;
-    for (int k = threadIdx.x; k < C; k += 64) acc += (double)(an_logs[k] * LOGSCALE);
-    acc = wave_sum(acc);
-    if (threadIdx.x == 0) {
-        double v = acc * (double)HW;
-        if (logabsdet) v += (double)logabsdet[0] * (double)HW;
-        konst[0] = v;
-        total[0] += v;  // launches are serialised on the stream => deterministic order
-    }
 }
 
 static int pack_scales(const float* logs, int n, float* scale, float* inv, hipStream_t s) {
@@ -385,6 +376,45 @@ glowhip_plan* glowhip_plan_create(const glowhip_layer_desc* layers, int n_layers
         p->layers.push_back(L);
     }
     p->out_shape[0] = C; p->out_shape[1] = H; p->out_shape[2] = W;
+    // job tables of the batched pack
+    for (const LayerPlan& L : p->layers) {
+        const glowhip_layer_desc& d = L.d;
+        if (d.kind == GLOWHIP_LAYER_FLOWSTEP) {
+            StepPrepJob j{};
+            j.w = d.permutation == GLOWHIP_PERM_INVCONV ? d.invconv_w : nullptr;
+            j.an_logs = d.an_logs; j.C = d.C; j.HW = d.H * d.W;
+            j.winv_off = L.winv; j.logabsdet_off = L.logabsdet; j.konst_off = L.konst; j.scratch_off = L.lu_scratch;
+            p->prep_jobs.push_back(j);
+            if (j.w && d.C <= 64) p->max_lds_c = std::max(p->max_lds_c, d.C);
+            p->scale_jobs.push_back(ScaleJob{d.an_logs, L.an_scale, L.an_inv_scale, d.C, 1});
+            p->scale_jobs.push_back(ScaleJob{d.f0_an_logs, L.f0_scale, 0, d.hidden, 0});
+            p->scale_jobs.push_back(ScaleJob{d.f2_an_logs, L.f2_scale, 0, d.hidden, 0});
+            p->scale_jobs.push_back(ScaleJob{d.f4_logs, L.f4_scale, 0, L.Cout, 0});
+            if (L.mfma_first) {
+                RepackJob r{}; r.w = d.f0_w; r.out_off = L.f0_wt; r.kind = REPACK_WIDE; r.Cin = d.C / 2; r.Cout = d.hidden;
+                r.K = r.Cin * 9; r.Kpad = wide_kpad(r.Cin, 3); p->repack_jobs.push_back(r);
+            }
+            if (L.mfma_mid) {
+                RepackJob r{}; r.w = d.f2_w; r.out_off = L.f2_wt; r.kind = REPACK_WIDE; r.Cin = d.hidden; r.Cout = d.hidden;
+                r.K = r.Cin; r.Kpad = wide_kpad(r.Cin, 1); p->repack_jobs.push_back(r);
+            }
+            if (L.mfma_last) {
+                RepackJob r{}; r.w = d.f4_w; r.out_off = L.f4_wp; r.kind = REPACK_TAIL; r.Cin = d.hidden; r.Cout = L.Cout;
+                r.paired = d.coupling == GLOWHIP_COUPLING_AFFINE; r.MT = tail_mt(L.Cout, r.paired);
+                r.total = (long)tail_chunks(r.Cin) * (TAIL_CK / 4) * 9 * r.MT * 64; p->repack_jobs.push_back(r);
+            }
+        } else if (d.kind == GLOWHIP_LAYER_SPLIT2D) {
+            p->scale_jobs.push_back(ScaleJob{d.f4_logs, L.f4_scale, 0, L.Cout, 0});
+            if (L.mfma_last) {
+                RepackJob r{}; r.w = d.f4_w; r.out_off = L.f4_wp; r.kind = REPACK_TAIL; r.Cin = d.C / 2; r.Cout = L.Cout;
+                r.paired = 1; r.MT = tail_mt(L.Cout, 1);
+                r.total = (long)tail_chunks(r.Cin) * (TAIL_CK / 4) * 9 * r.MT * 64; p->repack_jobs.push_back(r);
+            }
+        }
+    }
+    p->prep_off = take(off, p->prep_jobs.size() * sizeof(StepPrepJob));
+    p->scale_off = take(off, p->scale_jobs.size() * sizeof(ScaleJob));
+    p->repack_off = take(off, p->repack_jobs.size() * sizeof(RepackJob));
     p->packed_bytes = align_up(off, 256);
     return p;
 }
@@ -457,46 +487,25 @@ int glowhip_plan_describe(const glowhip_plan* plan, char* buf, size_t buf_bytes)
     return GLOWHIP_OK;
 }
 
-static int pack_layer(glowhip_plan* plan, LayerPlan& L, void* packed, hipStream_t s) {
-    const glowhip_layer_desc& d = L.d;
-    double* total = at<double>(packed, 0);
-    if (d.kind == GLOWHIP_LAYER_FLOWSTEP) {
-        const int HW = d.H * d.W;
-        GH_TRY(pack_scales(d.an_logs, d.C, at<float>(packed, L.an_scale), at<float>(packed, L.an_inv_scale), s));
-        GH_TRY(pack_scales(d.f0_an_logs, d.hidden, at<float>(packed, L.f0_scale), nullptr, s));
-        GH_TRY(pack_scales(d.f2_an_logs, d.hidden, at<float>(packed, L.f2_scale), nullptr, s));
-        GH_TRY(pack_scales(d.f4_logs, L.Cout, at<float>(packed, L.f4_scale), nullptr, s));
-        const float* lad = nullptr;
-        if (d.permutation == GLOWHIP_PERM_INVCONV) {
-            GH_TRY(launch_invconv_prepare(d.invconv_w, d.C, at<float>(packed, L.winv), at<float>(packed, L.logabsdet),
-                                          at<void>(packed, L.lu_scratch), s));
-            lad = at<float>(packed, L.logabsdet);
-        }
-        hipLaunchKernelGGL(k_step_konst, dim3(1), dim3(64), 0, s, d.an_logs, d.C, lad, HW, at<double>(packed, L.konst),
-                           total);
-        GH_LAUNCH_CHECK("k_step_konst");
-        if (L.mfma_first) GH_TRY(conv_mfma_wide_pack(d.f0_w, d.C / 2, d.hidden, 3, at<float>(packed, L.f0_wt), s));
-        if (L.mfma_mid) GH_TRY(conv_mfma_wide_pack(d.f2_w, d.hidden, d.hidden, 1, at<float>(packed, L.f2_wt), s));
-        if (L.mfma_last)
-            GH_TRY(conv_mfma_tail_pack(d.f4_w, d.hidden, L.Cout, d.coupling == GLOWHIP_COUPLING_AFFINE,
-                                       at<float>(packed, L.f4_wp), s));
-    } else if (d.kind == GLOWHIP_LAYER_SPLIT2D) {
-        GH_TRY(pack_scales(d.f4_logs, L.Cout, at<float>(packed, L.f4_scale), nullptr, s));
-        if (L.mfma_last) GH_TRY(conv_mfma_tail_pack(d.f4_w, d.C / 2, L.Cout, 1, at<float>(packed, L.f4_wp), s));
-    }
-    return GLOWHIP_OK;
-}
-
 int glowhip_plan_pack(glowhip_plan* plan, void* packed, size_t packed_bytes, glowhip_stream_t stream) {
     GH_REQUIRE(plan && packed, "plan_pack: null argument");
     GH_REQUIRE(packed_bytes >= plan->packed_bytes, "plan_pack: packed buffer too small (%zu < %zu)", packed_bytes,
                plan->packed_bytes);
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(packed, 0, sizeof(double), s) != hipSuccess) {
-        set_error("plan_pack: hipMemsetAsync failed");
+    // job tables -> device (plan-constant contents; re-sent because `packed` is caller memory), then 4 launches
+    auto upload = [&](size_t off, const void* src, size_t bytes) {
+        return bytes == 0 || hipMemcpyAsync((char*)packed + off, src, bytes, hipMemcpyHostToDevice, s) == hipSuccess;
+    };
+    if (!upload(plan->prep_off, plan->prep_jobs.data(), plan->prep_jobs.size() * sizeof(StepPrepJob)) ||
+        !upload(plan->scale_off, plan->scale_jobs.data(), plan->scale_jobs.size() * sizeof(ScaleJob)) ||
+        !upload(plan->repack_off, plan->repack_jobs.data(), plan->repack_jobs.size() * sizeof(RepackJob))) {
+        set_error("plan_pack: hipMemcpyAsync of the job tables failed");
         return GLOWHIP_ELAUNCH;
     }
-    for (LayerPlan& L : plan->layers) GH_TRY(pack_layer(plan, L, packed, s));
+    GH_TRY(launch_pack_batched(at<ScaleJob>(packed, plan->scale_off), (int)plan->scale_jobs.size(),
+                               at<RepackJob>(packed, plan->repack_off), (int)plan->repack_jobs.size(), packed, s));
+    GH_TRY(launch_step_prepare_batched(at<StepPrepJob>(packed, plan->prep_off), (int)plan->prep_jobs.size(),
+                                       plan->max_lds_c, packed, s));
     return GLOWHIP_OK;
 }
 

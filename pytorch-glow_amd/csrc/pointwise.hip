@@ -120,69 +120,74 @@ int launch_actnorm_init(const float* x, long xbs, int N, int C, int HW, float sc
 // ------------------------------------------------------------------------------------------------
 // Channel mixer: ActNorm (+bias, *scale) fused with the per-pixel C x C mat-vec of the invertible
 // 1x1 convolution (network/module.py:359-363) or the Permutation2d gather (:392-397).
-// One thread per pixel; the pixel's C activations live in LDS column [c][tid] (conflict-free: lane =
-// bank), the matrix row is wave-uniform and comes through the scalar cache, OB outputs are produced
-// per LDS read.  HBM traffic = read C + write C floats per pixel, the algorithmic minimum.
+// HBM traffic = read C + write C floats per pixel, the algorithmic minimum.
 // ------------------------------------------------------------------------------------------------
-template <int BS>
-__global__ void __launch_bounds__(BS) k_chanmix(ChanMixArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float v[];  // [C][BS]
-    const int tid = threadIdx.x;
-    const long gp = (long)blockIdx.x * BS + tid;
+// 64 pixels x 4 channel groups per workgroup: wave g stages channels g, g+4, ... of the 64 pixels into LDS
+// (column [c][px]: lane = bank, conflict-free) and then produces output channels [g*C/4, (g+1)*C/4) -- the
+// matrix rows a wave needs are wave-uniform (scalar cache), OB outputs share each LDS read.  Splitting the
+// outputs over 4 waves keeps the grid >= 4x larger than one-thread-per-pixel, which is what the deep levels
+// (C=48 on 4096 pixels) need to occupy the chip.
+constexpr int CM_PX = 64;
+__global__ void __launch_bounds__(256) k_chanmix(ChanMixArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float v[];  // [C][CM_PX]
+    const int px = threadIdx.x & (CM_PX - 1);
+    const int og = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave id: provably uniform
+    const long gp = (long)blockIdx.x * CM_PX + px;
     const long total = (long)a.N * a.HW;
-    if (gp >= total) return;
-    const long n = gp / a.HW;
-    const int p = (int)(gp - n * a.HW);
+    const bool valid = gp < total;
+    const long n = valid ? gp / a.HW : 0;
+    const int p = valid ? (int)(gp - n * a.HW) : 0;
     const int C = a.C;
     const float* pa = a.in_a + n * a.in_a_bs + p;
     const float* pb = a.in_b + n * a.in_b_bs + p;
     float* po = a.out + n * a.out_bs + p;
     const bool an = a.bias != nullptr;
-    if (!a.reverse) {
-        for (int c = 0; c < C; ++c) {
-            float xv = (c < a.Ca) ? pa[(long)c * a.HW] : pb[(long)(c - a.Ca) * a.HW];
-            if (an) xv = (xv + a.bias[c]) * a.scale[c];
-            v[c * BS + tid] = xv;
-        }
-    } else {
-        for (int c = 0; c < C; ++c)
-            v[c * BS + tid] = (c < a.Ca) ? pa[(long)c * a.HW] : pb[(long)(c - a.Ca) * a.HW];
+    for (int c = og; c < C; c += 4) {
+        float xv = 0.f;
+        if (valid) xv = (c < a.Ca) ? pa[(long)c * a.HW] : pb[(long)(c - a.Ca) * a.HW];
+        if (!a.reverse && an) xv = (xv + a.bias[c]) * a.scale[c];
+        v[c * CM_PX + px] = xv;
     }
+    __syncthreads();
+    const int per = (C + 3) / 4;
+    const int o_begin = og * per, o_end = min(C, o_begin + per);
     constexpr int OB = 4;
-    for (int o = 0; o < C; o += OB) {
+    for (int o = o_begin; o < o_end; o += OB) {
         float r[OB];
         if (a.matrix) {
 #pragma unroll
             for (int j = 0; j < OB; ++j) r[j] = 0.f;
             const float* m = a.matrix + (long)o * C;
-            if (o + OB <= C) {
+            if (o + OB <= o_end) {
                 for (int i = 0; i < C; ++i) {
-                    const float vi = v[i * BS + tid];
+                    const float vi = v[i * CM_PX + px];
 #pragma unroll
                     for (int j = 0; j < OB; ++j) r[j] = fmaf(m[j * C + i], vi, r[j]);
                 }
             } else {
                 for (int i = 0; i < C; ++i) {
-                    const float vi = v[i * BS + tid];
+                    const float vi = v[i * CM_PX + px];
 #pragma unroll
                     for (int j = 0; j < OB; ++j)
-                        if (o + j < C) r[j] = fmaf(m[j * C + i], vi, r[j]);
+                        if (o + j < o_end) r[j] = fmaf(m[j * C + i], vi, r[j]);
                 }
             }
         } else {
 #pragma unroll
             for (int j = 0; j < OB; ++j) {
-                int oc = o + j;
-                if (oc < C) r[j] = v[(a.gather ? a.gather[oc] : oc) * BS + tid];
+                const int oc = o + j;
+                r[j] = oc < o_end ? v[(a.gather ? a.gather[oc] : oc) * CM_PX + px] : 0.f;
             }
         }
+        if (valid) {
 #pragma unroll
-        for (int j = 0; j < OB; ++j) {
-            int oc = o + j;
-            if (oc < C) {
-                float out = r[j];
-                if (a.reverse && an) out = out * a.scale[oc] - a.bias[oc];
-                po[(long)oc * a.HW] = out;
+            for (int j = 0; j < OB; ++j) {
+                const int oc = o + j;
+                if (oc < o_end) {
+                    float out = r[j];
+                    if (a.reverse && an) out = out * a.scale[oc] - a.bias[oc];
+                    po[(long)oc * a.HW] = out;
+                }
             }
         }
     }
@@ -192,18 +197,10 @@ int launch_chanmix(const ChanMixArgs& a, hipStream_t s) {
     GH_REQUIRE(a.C > 0 && a.C <= 512, "channel mixer: C=%d unsupported (1..512)", a.C);
     const long total = (long)a.N * a.HW;
     if (total == 0) return GLOWHIP_OK;
-    // > 64 KiB of dynamic LDS must be opted into (the call is host-only bookkeeping and idempotent)
-    if (a.C <= 128) {
-        size_t lds = (size_t)a.C * 256 * sizeof(float);
-        if (lds > 48 * 1024)
-            (void)hipFuncSetAttribute((const void*)k_chanmix<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipLaunchKernelGGL(k_chanmix<256>, dim3(cdiv(total, 256)), dim3(256), lds, s, a);
-    } else {
-        size_t lds = (size_t)a.C * 64 * sizeof(float);
-        if (lds > 48 * 1024)
-            (void)hipFuncSetAttribute((const void*)k_chanmix<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipLaunchKernelGGL(k_chanmix<64>, dim3(cdiv(total, 64)), dim3(64), lds, s, a);
-    }
+    const size_t lds = (size_t)a.C * CM_PX * sizeof(float);
+    if (lds > 32 * 1024)
+        (void)hipFuncSetAttribute((const void*)k_chanmix, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_chanmix, dim3(cdiv(total, CM_PX)), dim3(256), lds, s, a);
     GH_LAUNCH_CHECK("k_chanmix");
     return GLOWHIP_OK;
 }

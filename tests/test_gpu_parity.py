@@ -419,7 +419,7 @@ def test_mfma_split2d_vs_oracle(c, h, w, n):
     eps = torch.randn(n, c // 2, h, w, generator=g)
     xr, _ = sp(dev(z1r), 0., reverse=True, eps=dev(eps))
     xo, _ = O.split2d(z1r, 0.0, sd, "", reverse=True, eps=eps)
-    close(xr, xo, 1e-5)
+    close(xr, xo, 2e-5, what="split reverse")
 
 
 def test_mfma_transpose_detecting():
@@ -437,4 +437,5 @@ def test_mfma_transpose_detecting():
     x = torch.randn(2, 12, 32, 32, generator=torch.Generator().manual_seed(4))
     z, ld = st(dev(x), 0.)
     zr, ldr = O.flowstep(x, torch.zeros(2), sd, "", "invconv", "affine")
-    close(z, zr, 5e-5); ld_close(ld, ldr)
+    print("transpose test: |z| max", zr.abs().max().item(), "max err", (z.cpu() - zr).abs().max().item())
+    close(z, zr, 5e-5, rtol=2e-5); ld_close(ld, ldr)

@@ -133,7 +133,6 @@ def test_g8_glow_celeba64(golden):
     g = golden("g8_glow_celeba64")
     cfg = O.default_cfg(batch=2)
     assert abs(O.flop_per_image(cfg) - 3.2092e10) / 3.2092e10 < 1e-3
-    torch.set_num_threads(8)
     sd = O.seeded_state_dict(cfg, seed=int(g["seed"]))
     assert sum(v.numel() for v in sd.values()) - sd["h_top"].numel() == 44_052_720
     dig = torch.stack([sd["flow.layers.50.f.2.weight"].double().sum(), sd["flow.layers.100.f.4.weight"].double().sum(),
