@@ -187,6 +187,10 @@ typedef struct glowhip_timing_record {
 int glowhip_plan_timing_enable(glowhip_plan* plan, int enable);
 int glowhip_plan_timing_read(glowhip_plan* plan, glowhip_timing_record* out, int max, int* n_out);
 
+/* Testing hook: force the pixel tile (16/32/64/128 pixels per workgroup; 0 = automatic, chosen from the grid size)
+ * of the fused tail convolution, so every wave-layout variant can be exercised at any batch size. */
+void glowhip_debug_force_tail_tile(int pixels);
+
 /* Introspection for tests / benchmarks: which kernels a plan will launch ("mfma" or "direct" per
  * convolution).  Writes a NUL-terminated description into buf. */
 int glowhip_plan_describe(const glowhip_plan* plan, char* buf, size_t buf_bytes);

@@ -73,6 +73,7 @@ SIGNATURES = {
     "glowhip_plan_actnorm_init": (c_int, [_P, _P, c_size_t, _P, _P, c_float, c_int, _P, c_size_t, _P]),
     "glowhip_plan_output_shape": (c_int, [_P, c_int, POINTER(c_int32)]),
     "glowhip_plan_describe": (c_int, [_P, c_char_p, c_size_t]),
+    "glowhip_debug_force_tail_tile": (None, [c_int]),
     "glowhip_plan_timing_enable": (c_int, [_P, c_int]),
     "glowhip_plan_timing_read": (c_int, [_P, POINTER(TimingRecord), c_int, POINTER(c_int)]),
 }

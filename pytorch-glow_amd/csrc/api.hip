@@ -3,6 +3,7 @@
 #include <stdio.h>
 
 #include "kernels.h"
+#include "conv_mfma.h"
 
 namespace glowhip {
 static thread_local char g_err[512] = "";
@@ -19,6 +20,7 @@ using namespace glowhip;
 extern "C" {
 
 int glowhip_version(void) { return GLOWHIP_VERSION; }
+void glowhip_debug_force_tail_tile(int pixels) { conv_mfma_tail_force_tile(pixels); }
 const char* glowhip_last_error(void) { return g_err; }
 
 int glowhip_squeeze2d(const float* x, float* y, int N, int C, int H, int W, int factor, int reverse,

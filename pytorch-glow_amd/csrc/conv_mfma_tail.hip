@@ -16,22 +16,33 @@ namespace glowhip {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-static int tail_tp(int H, int W) {
-    const int HW = H * W;
-    if (W <= 128 && 128 % W == 0 && HW % 128 == 0) return 128;
-    if (W <= 64 && 64 % W == 0 && HW % 64 == 0) return 64;
-    return 0;
+// Pixel-tile choice.  A block covers TP = 16*NTW*WN consecutive pixels = whole image rows of ONE image; its 4
+// waves are arranged WN (pixel tiles) x WK (K-split: wave wk takes channel groups c4 = wk, wk+WK, ...), partial
+// sums of the WK waves are reduced through LDS before the epilogue.  Smaller tiles + K-split keep >= 2 blocks per
+// CU on the deep levels (8x8 images: 4096 pixels per step) where a 128-pixel tile would occupy 1/4 of the chip.
+static int g_force_tp = 0;  // testing hook (glowhip_debug_force_tail_tile)
+static bool tp_ok(int tp, int H, int W) {
+    if (tp % W != 0 || (H * W) % tp != 0) return false;
+    return TAIL_CK * (tp / W + 2) * (W / 4) <= 6 * 256;  // halo tile must fit the 6-float4 staging registers
+}
+static int tail_tp(int H, int W, long total_px) {
+    if (g_force_tp && tp_ok(g_force_tp, H, W)) return g_force_tp;
+    const int cand[4] = {128, 64, 32, 16};
+    int smallest = 0;
+    for (int i = 0; i < 4; ++i) {
+        if (!tp_ok(cand[i], H, W)) continue;
+        if (total_px / cand[i] >= 512) return cand[i];
+        smallest = cand[i];
+    }
+    return smallest;
 }
 
 static bool tail_paired(int mode) { return mode != TAIL_PLAIN && mode != TAIL_ADD_FWD && mode != TAIL_ADD_REV; }
 
 bool conv_mfma_tail_supported(int Cin, int H, int W, int Cout) {
     if (W % 4 != 0 || W < 8) return false;
-    if (tail_tp(H, W) == 0) return false;
-    if (Cout > 48 || Cout < 1) return false;
-    const int TP = tail_tp(H, W);
-    if (TAIL_CK * (TP / W + 2) * (W / 4) > 6 * 256) return false;  // halo tile must fit the 6-float4 staging
-    return Cin >= 1;
+    if (Cout > 48 || Cout < 1 || Cin < 1) return false;
+    return tp_ok(128, H, W) || tp_ok(64, H, W) || tp_ok(32, H, W) || tp_ok(16, H, W);
 }
 
 size_t conv_mfma_tail_packed_bytes(int Cin, int Cout) {
@@ -76,9 +87,10 @@ struct TailGeom {
     int W4;    // W / 4
 };
 
-template <int MT, int NTW>
+template <int MT, int NTW, int WN, int WK>
 __global__ void __launch_bounds__(256) k_conv_tail(TailConvArgs a, TailGeom g, int paired) {
-    constexpr int TP = 64 * NTW;                       // pixels per block (4 waves x NTW x 16)
+    static_assert(WN * WK == 4, "4 waves per block");
+    constexpr int TP = 16 * NTW * WN;                  // pixels per block
     constexpr int A_FLOATS = (TAIL_CK / 4) * 9 * MT * 64;
     constexpr int A_F4 = A_FLOATS / 4;
     constexpr int A_IT = (A_F4 + 255) / 256;
@@ -89,6 +101,7 @@ __global__ void __launch_bounds__(256) k_conv_tail(TailConvArgs a, TailGeom g, i
     __shared__ double red[4];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wn = wid % WN, wk = wid / WN;            // pixel-tile column / K-split slice of this wave
     const int HW = a.H * a.W;
     const long gp0 = (long)blockIdx.x * TP;
     const long n = gp0 / HW;
@@ -153,7 +166,7 @@ __global__ void __launch_bounds__(256) k_conv_tail(TailConvArgs a, TailGeom g, i
     int boff[NTW];
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) {
-        const int q = (wid * NTW + nt) * 16 + (lane & 15);
+        const int q = (wn * NTW + nt) * 16 + (lane & 15);
         const int r = q / a.W, x = q - r * a.W;
         boff[nt] = (r + 1) * g.RS + x + 4 + (lane >> 4) * g.CHS;
     }
@@ -172,25 +185,38 @@ __global__ void __launch_bounds__(256) k_conv_tail(TailConvArgs a, TailGeom g, i
         if (ch + 1 < nchunks) load_chunk(ch + 1);
         const int left = a.Cin - ch * TAIL_CK;
         const int nc4 = left >= TAIL_CK ? TAIL_CK / 4 : (left + 3) / 4;
+        if (nc4 == TAIL_CK / 4) {
+            // full chunk: 9 taps x (8/WK) channel groups, flattened and software-pipelined -- the LDS reads of
+            // step s+1 are issued before the MFMAs of step s (pinned with sched_group_barrier)
+            constexpr int CPW = (TAIL_CK / 4) / WK;   // channel groups per wave per tap
+            constexpr int STEPS = 9 * CPW;
+            float av[2][MT], bv[2][NTW];
+            auto fetch = [&](int st, int slot) {
+                const int tap = st / CPW, c4 = wk + (st % CPW) * WK;
+                const int toff = (tap / 3 - 1) * g.RS + (tap % 3 - 1);
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int toff = (tap / 3 - 1) * g.RS + (tap % 3 - 1);
-            if (nc4 == TAIL_CK / 4) {
+                for (int m = 0; m < MT; ++m) av[slot][m] = As[((c4 * 9 + tap) * MT + m) * 64 + lane];
 #pragma unroll
-                for (int c4 = 0; c4 < TAIL_CK / 4; ++c4) {
-                    float av[MT], bv[NTW];
+                for (int nt = 0; nt < NTW; ++nt) bv[slot][nt] = Xs[boff[nt] + c4 * 4 * g.CHS + toff];
+            };
+            fetch(0, 0);
 #pragma unroll
-                    for (int m = 0; m < MT; ++m) av[m] = As[((c4 * 9 + tap) * MT + m) * 64 + lane];
+            for (int st = 0; st < STEPS; ++st) {
+                const int cur = st & 1;
+                if (st + 1 < STEPS) fetch(st + 1, cur ^ 1);
 #pragma unroll
-                    for (int nt = 0; nt < NTW; ++nt) bv[nt] = Xs[boff[nt] + c4 * 4 * g.CHS + toff];
+                for (int m = 0; m < MT; ++m)
 #pragma unroll
-                    for (int m = 0; m < MT; ++m)
+                    for (int nt = 0; nt < NTW; ++nt)
+                        acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cur][m], bv[cur][nt], acc[m][nt], 0, 0, 0);
+                if (st + 1 < STEPS) __builtin_amdgcn_sched_group_barrier(0x100, MT + NTW, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, MT * NTW, 0);
+            }
+        } else {
 #pragma unroll
-                        for (int nt = 0; nt < NTW; ++nt)
-                            acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bv[nt], acc[m][nt], 0, 0, 0);
-                }
-            } else {
-                for (int c4 = 0; c4 < nc4; ++c4) {
+            for (int tap = 0; tap < 9; ++tap) {
+                const int toff = (tap / 3 - 1) * g.RS + (tap % 3 - 1);
+                for (int c4 = wk; c4 < nc4; c4 += WK) {
                     float av[MT], bv[NTW];
 #pragma unroll
                     for (int m = 0; m < MT; ++m) av[m] = As[((c4 * 9 + tap) * MT + m) * 64 + lane];
@@ -211,8 +237,36 @@ __global__ void __launch_bounds__(256) k_conv_tail(TailConvArgs a, TailGeom g, i
         }
     }
 
-    // ---------------------------------------------------------------- epilogue
+    // ---------------------------------------------------------------- K-split reduction (WK > 1)
+    if (WK > 1) {
+        // the chunk loop ended with a barrier: the operand images are dead, reuse LDS as [WK-1][WN][MT*NTW*4][64]
+        float* part = lds;
+        if (wk > 0) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        part[(((wk - 1) * WN + wn) * (MT * NTW * 4) + (m * NTW + nt) * 4 + r) * 64 + lane] = acc[m][nt][r];
+        }
+        __syncthreads();
+        if (wk == 0) {
+#pragma unroll
+            for (int k = 1; k < WK; ++k)   // fixed order => deterministic
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            acc[m][nt][r] += part[(((k - 1) * WN + wn) * (MT * NTW * 4) + (m * NTW + nt) * 4 + r) * 64 + lane];
+        }
+    }
+
+    // ---------------------------------------------------------------- epilogue (waves with wk == 0)
     double ld = 0.0;
+    if (wk == 0) {
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         const int mrow = m * 16 + (lane >> 4) * 4;
@@ -226,7 +280,7 @@ __global__ void __launch_bounds__(256) k_conv_tail(TailConvArgs a, TailGeom g, i
         }
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) {
-            const int p = p0 + (wid * NTW + nt) * 16 + (lane & 15);
+            const int p = p0 + (wn * NTW + nt) * 16 + (lane & 15);
             float hv[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) hv[r] = (acc[m][nt][r] + hb[r]) * hs[r];
@@ -266,20 +320,24 @@ __global__ void __launch_bounds__(256) k_conv_tail(TailConvArgs a, TailGeom g, i
             }
         }
     }
+    }
     if (a.acc && (a.mode == TAIL_AFFINE_FWD || a.mode == TAIL_AFFINE_REV || a.mode == TAIL_SPLIT_FWD)) {
         const double tot = block_sum<256>(ld, red);
         if (tid == 0) fix_atomic_add(a.acc + n, tot);
     }
 }
 
-template <int MT, int NTW>
+template <int MT, int NTW, int WN, int WK>
 static int launch_tail_cfg(const TailConvArgs& a, const TailGeom& g, int paired, hipStream_t s) {
-    constexpr int TP = 64 * NTW;
+    constexpr int TP = 16 * NTW * WN;
     const long total_px = (long)a.N * a.H * a.W;
-    const size_t lds = ((size_t)TAIL_CK * g.CHS + (size_t)(TAIL_CK / 4) * 9 * MT * 64) * sizeof(float);
+    size_t lds = ((size_t)TAIL_CK * g.CHS + (size_t)(TAIL_CK / 4) * 9 * MT * 64) * sizeof(float);
+    const size_t red = (size_t)(WK - 1) * WN * MT * NTW * 4 * 64 * sizeof(float);
+    if (red > lds) lds = red;
     if (lds > 32 * 1024)
-        (void)hipFuncSetAttribute((const void*)k_conv_tail<MT, NTW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((k_conv_tail<MT, NTW>), dim3((unsigned)(total_px / TP)), dim3(256), lds, s, a, g, paired);
+        (void)hipFuncSetAttribute((const void*)k_conv_tail<MT, NTW, WN, WK>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
+    hipLaunchKernelGGL((k_conv_tail<MT, NTW, WN, WK>), dim3((unsigned)(total_px / TP)), dim3(256), lds, s, a, g, paired);
     GH_LAUNCH_CHECK("k_conv_tail");
     return GLOWHIP_OK;
 }
@@ -289,7 +347,8 @@ int launch_conv_mfma_tail(const TailConvArgs& a, hipStream_t s) {
     if (a.N == 0) return GLOWHIP_OK;
     const int paired = tail_paired(a.mode);
     GH_REQUIRE(!paired || a.Cout % 2 == 0, "conv_mfma_tail: paired mode needs an even Cout");
-    const int TP = tail_tp(a.H, a.W);
+    const int TP = tail_tp(a.H, a.W, (long)a.N * a.H * a.W);
+    GH_REQUIRE(TP > 0, "conv_mfma_tail: no pixel tile for %dx%d", a.H, a.W);
     TailGeom g;
     g.RS = a.W + 8;
     g.TR = TP / a.W;
@@ -297,15 +356,20 @@ int launch_conv_mfma_tail(const TailConvArgs& a, hipStream_t s) {
     int chs = (g.TR + 2) * g.RS;
     chs += ((16 - (chs % 32)) + 32) % 32;  // -> == 16 (mod 32)
     g.CHS = chs;
-    GH_REQUIRE(TAIL_CK * (g.TR + 2) * g.W4 <= 6 * 256, "conv_mfma_tail: halo tile too large");
     const int MT = tail_mt(a.Cout, paired);
-    const int NTW = TP / 64;
-#define GH_TAIL_CASE(mt, ntw) \
-    if (MT == mt && NTW == ntw) return launch_tail_cfg<mt, ntw>(a, g, paired, s);
-    GH_TAIL_CASE(1, 1) GH_TAIL_CASE(1, 2) GH_TAIL_CASE(2, 1) GH_TAIL_CASE(2, 2) GH_TAIL_CASE(3, 1) GH_TAIL_CASE(3, 2)
-#undef GH_TAIL_CASE
-    set_error("conv_mfma_tail: no kernel for MT=%d NTW=%d", MT, NTW);
+#define GH_TAIL_TP(mt)                                                            \
+    if (MT == mt) {                                                               \
+        if (TP == 128) return launch_tail_cfg<mt, 2, 4, 1>(a, g, paired, s);      \
+        if (TP == 64) return launch_tail_cfg<mt, 1, 4, 1>(a, g, paired, s);       \
+        if (TP == 32) return launch_tail_cfg<mt, 1, 2, 2>(a, g, paired, s);       \
+        if (TP == 16) return launch_tail_cfg<mt, 1, 1, 4>(a, g, paired, s);       \
+    }
+    GH_TAIL_TP(1) GH_TAIL_TP(2) GH_TAIL_TP(3)
+#undef GH_TAIL_TP
+    set_error("conv_mfma_tail: no kernel for MT=%d TP=%d", MT, TP);
     return GLOWHIP_EINVAL;
 }
+
+void conv_mfma_tail_force_tile(int tp) { g_force_tp = tp; }
 
 }  // namespace glowhip

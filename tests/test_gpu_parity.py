@@ -286,7 +286,8 @@ def test_celeba64_ill_conditioned_not_worse_than_reference_noise():
 
 def test_full_size_properties_b64():
     """BASELINE config B at full batch (64): size-independent properties.
-    (1) encode is per-sample independent: rows of a B=64 call equal the rows of B=8 sub-batches bit for bit;
+    (1) encode is per-sample independent: rows of a B=64 call equal the rows of B=8 sub-batches (to rounding: the
+        kernels pick tile shapes / K-splits from the grid size, so the summation ORDER may differ with B);
     (2) bitwise reproducible run to run (fixed-point log-det accumulators);
     (3) decode(encode(x)) returns x when the dropped halves are re-injected as the exact eps they imply."""
     cfg = O.default_cfg(batch=64)
@@ -306,7 +307,7 @@ def test_full_size_properties_b64():
     assert torch.isfinite(z).all() and torch.isfinite(nll).all()
     for s in range(0, 64, 8):
         zs, ns, _ = glow.normal_flow(x[s:s + 8].contiguous(), None, noise=noise[s:s + 8].contiguous())
-        assert torch.equal(zs, z[s:s + 8]) and torch.equal(ns, nll[s:s + 8]), f"batch slice {s} differs"
+        close(zs, z[s:s + 8], 2e-5, what=f"batch slice {s} z"); close(ns, nll[s:s + 8], 1e-5, what=f"batch slice {s} nll")
     # (3) eps = 0 and zero-mean check is weak; instead: decode with eps chosen so z2 is reproduced exactly is not
     # expressible without the dropped halves, so check the split-free part: the LAST level round-trips.
     last = [l for l in glow.flow.layers][-33:]  # squeeze + 32 steps of level 3
@@ -439,3 +440,22 @@ def test_mfma_transpose_detecting():
     zr, ldr = O.flowstep(x, torch.zeros(2), sd, "", "invconv", "affine")
     print("transpose test: |z| max", zr.abs().max().item(), "max err", (z.cpu() - zr).abs().max().item())
     close(z, zr, 5e-5, rtol=2e-5); ld_close(ld, ldr)
+
+
+@pytest.mark.parametrize("tp", [16, 32, 64, 128])
+@pytest.mark.parametrize("c,h,w", [(12, 32, 32), (24, 16, 16), (48, 8, 8)])
+def test_mfma_tail_every_wave_layout(tp, c, h, w):
+    """Each pixel-tile / K-split variant of the fused tail kernel (WN x WK = 4x1, 2x2, 1x4) on each level geometry."""
+    if (h * w) % tp or tp % w:
+        pytest.skip("tile does not cover whole rows of this image")
+    st, sd = _rand_step(c, 64, "affine", seed=tp + c)
+    x = torch.randn(3, c, h, w, generator=torch.Generator().manual_seed(5))
+    zr, ldr = O.flowstep(x, torch.zeros(3), sd, "", "invconv", "affine")
+    G.lib().glowhip_debug_force_tail_tile(tp)
+    try:
+        z, ld = st(dev(x), 0.)
+        z2, ld2 = st(dev(x), 0.)
+    finally:
+        G.lib().glowhip_debug_force_tail_tile(0)
+    close(z, zr, 2e-5, what=f"tp={tp}"); ld_close(ld, ldr)
+    assert torch.equal(z, z2) and torch.equal(ld, ld2)
