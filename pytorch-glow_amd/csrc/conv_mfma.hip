@@ -45,8 +45,9 @@ k_conv_wide(const float* __restrict__ X, long x_bs, const float* __restrict__ Wt
     static_assert(A_PASSES >= 1 && B_PASSES >= 1, "tile too wide for 256 threads");
     // double-buffered K-major operand tiles: ONE barrier per K-tile (the write of tile t+1 goes to the
     // buffer nobody reads during tile t)
-    __shared__ __attribute__((aligned(16))) float As[2][BK][BM];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN];
+    __shared__ __attribute__((aligned(16))) float smem[2 * BK * BM + 2 * BK * BN];
+    float (*As)[BK][BM] = reinterpret_cast<float (*)[BK][BM]>(smem);
+    float (*Bs)[BK][BN] = reinterpret_cast<float (*)[BK][BN]>(smem + 2 * BK * BM);
 
     const int HW = H * W;
     const long total_px = (long)N * HW;
@@ -68,17 +69,17 @@ k_conv_wide(const float* __restrict__ X, long x_bs, const float* __restrict__ Wt
     const int b_y = b_p / W, b_x = b_p - b_y * W;
     const float* b_img = X + b_n * x_bs;
 
-    float4 ra[A_PASSES], rb[B_PASSES];
+    f32x4 ra[A_PASSES], rb[B_PASSES];  // native vectors: HIP's float4 struct defeats SROA here (array lands in scratch/LDS)
     auto load_tile = [&](int kt) {
 #pragma unroll
         for (int ps = 0; ps < A_PASSES; ++ps)
-            ra[ps] = *reinterpret_cast<const float4*>(a_src + (long)(kt * BK + ps * A_RPP) * M);
+            ra[ps] = *reinterpret_cast<const f32x4*>(a_src + (long)(kt * BK + ps * A_RPP) * M);
 #pragma unroll
         for (int ps = 0; ps < B_PASSES; ++ps) {
             const int k = kt * BK + ps * B_RPP + b_row;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (KS == 1) {
-                if (b_ok) v = *reinterpret_cast<const float4*>(b_img + (long)k * HW + b_p);
+                if (b_ok) v = *reinterpret_cast<const f32x4*>(b_img + (long)k * HW + b_p);
             } else {
                 const int ci = k / 9, tap = k - ci * 9;
                 const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
@@ -86,10 +87,10 @@ k_conv_wide(const float* __restrict__ X, long x_bs, const float* __restrict__ Wt
                 if (b_ok && k < K && yy >= 0 && yy < H) {
                     const float* row = b_img + (long)ci * HW + yy * W;
                     const int x0 = b_x + dx;
-                    v.x = (x0 >= 0) ? row[x0] : 0.f;
-                    v.y = row[x0 + 1];
-                    v.z = row[x0 + 2];
-                    v.w = (x0 + 3 < W) ? row[x0 + 3] : 0.f;
+                    v[0] = (x0 >= 0) ? row[x0] : 0.f;
+                    v[1] = row[x0 + 1];
+                    v[2] = row[x0 + 2];
+                    v[3] = (x0 + 3 < W) ? row[x0 + 3] : 0.f;
                 }
             }
             rb[ps] = v;
@@ -98,10 +99,10 @@ k_conv_wide(const float* __restrict__ X, long x_bs, const float* __restrict__ Wt
     auto store_tile = [&](int buf) {
 #pragma unroll
         for (int ps = 0; ps < A_PASSES; ++ps)
-            *reinterpret_cast<float4*>(&As[buf][ps * A_RPP + a_row][a_c4 * 4]) = ra[ps];
+            *reinterpret_cast<f32x4*>(&As[buf][ps * A_RPP + a_row][a_c4 * 4]) = ra[ps];
 #pragma unroll
         for (int ps = 0; ps < B_PASSES; ++ps)
-            *reinterpret_cast<float4*>(&Bs[buf][ps * B_RPP + b_row][b_c4 * 4]) = rb[ps];
+            *reinterpret_cast<f32x4*>(&Bs[buf][ps * B_RPP + b_row][b_c4 * 4]) = rb[ps];
     };
 
     f32x16 acc[TM][TN];
@@ -149,22 +150,36 @@ k_conv_wide(const float* __restrict__ X, long x_bs, const float* __restrict__ Wt
         __syncthreads();
     }
 
-    // ---- epilogue: ActNorm (+bias, *scale) + ReLU, C[row=o][col=pixel]
+    // ---- epilogue: ActNorm (+bias, *scale) + ReLU on the accumulators, C[row=o][col=pixel], then a transpose
+    // through LDS (the operand buffers are dead) so every lane stores 16 contiguous bytes: 4x fewer store
+    // instructions than the natural one-dword-per-lane layout, which was store-ISSUE-bound.
+    float* stage = smem + wid * (WM * WN);
+    static_assert(2 * BK * (BM + BN) >= 4 * WM * WN, "operand buffers too small to stage the output tile");
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const long gp = (long)tile_n * BN + wc * WN + j * 32 + ml;
-        if (gp >= total_px) continue;
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl;
+            const int o = tile_m * BM + wr * WM + row;
+            const float bo = bias[o], so = scale[o];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) stage[row * WN + j * 32 + ml] = fmaxf((acc[i][j][r] + bo) * so, 0.f);
+        }
+    }
+    // each wave reads back only what it wrote: no workgroup barrier needed, the LDS ops of one wave are ordered
+    constexpr int F4_PER_ROW = WN / 4, ROWS_PER_IT = 64 / F4_PER_ROW;
+    const int rrow = lane / F4_PER_ROW, rc4 = lane % F4_PER_ROW;
+    const long gp = (long)tile_n * BN + wc * WN + rc4 * 4;
+    if (gp < total_px) {
         const long n = gp / HW;
         const int p = (int)(gp - n * HW);
         float* yn = Y + n * (long)M * HW + p;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int o = tile_m * BM + wr * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl;
-                float v = (acc[i][j][r] + bias[o]) * scale[o];
-                yn[(long)o * HW] = fmaxf(v, 0.f);
-            }
+        for (int it = 0; it < WM / ROWS_PER_IT; ++it) {
+            const int row = it * ROWS_PER_IT + rrow;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(stage + row * WN + rc4 * 4);
+            const int o = tile_m * BM + wr * WM + row;
+            *reinterpret_cast<f32x4*>(yn + (long)o * HW) = v;
         }
     }
 }

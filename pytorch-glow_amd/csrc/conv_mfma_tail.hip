@@ -87,10 +87,23 @@ struct TailGeom {
     int W4;    // W / 4
 };
 
-template <int MT, int NTW, int WN, int WK>
-__global__ void __launch_bounds__(256) k_conv_tail(TailConvArgs a, TailGeom g, int paired) {
+__host__ __device__ constexpr int tail_chs(int TR, int W) {   // channel stride == 16 (mod 32) floats
+    return (TR + 2) * (W + 8) + ((16 - ((TR + 2) * (W + 8)) % 32) + 32) % 32;
+}
+
+// WFIX > 0: image width known at compile time (the BASELINE level geometries) => every LDS offset of the
+// unrolled tap/channel pipeline is an instruction immediate instead of a live VGPR; WFIX == 0: runtime geometry.
+template <int MT, int NTW, int WN, int WK, int WFIX>
+__global__ void __launch_bounds__(256) k_conv_tail(TailConvArgs a, TailGeom gr, int paired) {
     static_assert(WN * WK == 4, "4 waves per block");
     constexpr int TP = 16 * NTW * WN;                  // pixels per block
+    TailGeom g = gr;
+    if (WFIX > 0) {
+        g.RS = WFIX + 8;
+        g.TR = TP / (WFIX > 0 ? WFIX : 1);
+        g.W4 = WFIX / 4;
+        g.CHS = tail_chs(TP / (WFIX > 0 ? WFIX : 1), WFIX);
+    }
     constexpr int A_FLOATS = (TAIL_CK / 4) * 9 * MT * 64;
     constexpr int A_F4 = A_FLOATS / 4;
     constexpr int A_IT = (A_F4 + 255) / 256;
@@ -117,8 +130,8 @@ __global__ void __launch_bounds__(256) k_conv_tail(TailConvArgs a, TailGeom g, i
     const int x_count = TAIL_CK * x_per_ch;
     const int nchunks = (a.Cin + TAIL_CK - 1) / TAIL_CK;
 
-    float4 rx[X_IT_MAX];
-    float4 rA[A_IT];
+    f32x4 rx[X_IT_MAX];  // native vectors (HIP's float4 struct arrays are not reliably kept in registers)
+    f32x4 rA[A_IT];
     int x_dst[X_IT_MAX];
     long x_src[X_IT_MAX];
     bool x_rowok[X_IT_MAX];
@@ -138,27 +151,27 @@ __global__ void __launch_bounds__(256) k_conv_tail(TailConvArgs a, TailGeom g, i
         const int cbase = ch * TAIL_CK;
 #pragma unroll
         for (int it = 0; it < X_IT_MAX; ++it) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (x_rowok[it] && cbase + x_c[it] < a.Cin)
-                v = *reinterpret_cast<const float4*>(xin + (long)cbase * HW + x_src[it]);
+                v = *reinterpret_cast<const f32x4*>(xin + (long)cbase * HW + x_src[it]);
             rx[it] = v;
         }
-        const float4* asrc = reinterpret_cast<const float4*>(a.wp + (long)ch * A_FLOATS);
+        const f32x4* asrc = reinterpret_cast<const f32x4*>(a.wp + (long)ch * A_FLOATS);
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
             const int e = it * 256 + tid;
-            rA[it] = (e < A_F4) ? asrc[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+            rA[it] = (e < A_F4) ? asrc[e] : (f32x4){0.f, 0.f, 0.f, 0.f};
         }
     };
     auto store_chunk = [&]() {
         // rows outside the image / channels beyond Cin hold zeros in rx: written too, so the halo stays clean
 #pragma unroll
         for (int it = 0; it < X_IT_MAX; ++it)
-            if (x_c[it] < TAIL_CK) *reinterpret_cast<float4*>(Xs + x_dst[it]) = rx[it];
+            if (x_c[it] < TAIL_CK) *reinterpret_cast<f32x4*>(Xs + x_dst[it]) = rx[it];
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
             const int e = it * 256 + tid;
-            if (e < A_F4) reinterpret_cast<float4*>(As)[e] = rA[it];
+            if (e < A_F4) reinterpret_cast<f32x4*>(As)[e] = rA[it];
         }
     };
 
@@ -327,7 +340,7 @@ __global__ void __launch_bounds__(256) k_conv_tail(TailConvArgs a, TailGeom g, i
     }
 }
 
-template <int MT, int NTW, int WN, int WK>
+template <int MT, int NTW, int WN, int WK, int WFIX = 0>
 static int launch_tail_cfg(const TailConvArgs& a, const TailGeom& g, int paired, hipStream_t s) {
     constexpr int TP = 16 * NTW * WN;
     const long total_px = (long)a.N * a.H * a.W;
@@ -335,9 +348,9 @@ static int launch_tail_cfg(const TailConvArgs& a, const TailGeom& g, int paired,
     const size_t red = (size_t)(WK - 1) * WN * MT * NTW * 4 * 64 * sizeof(float);
     if (red > lds) lds = red;
     if (lds > 32 * 1024)
-        (void)hipFuncSetAttribute((const void*)k_conv_tail<MT, NTW, WN, WK>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute((const void*)k_conv_tail<MT, NTW, WN, WK, WFIX>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);
-    hipLaunchKernelGGL((k_conv_tail<MT, NTW, WN, WK>), dim3((unsigned)(total_px / TP)), dim3(256), lds, s, a, g, paired);
+    hipLaunchKernelGGL((k_conv_tail<MT, NTW, WN, WK, WFIX>), dim3((unsigned)(total_px / TP)), dim3(256), lds, s, a, g, paired);
     GH_LAUNCH_CHECK("k_conv_tail");
     return GLOWHIP_OK;
 }
@@ -353,10 +366,12 @@ int launch_conv_mfma_tail(const TailConvArgs& a, hipStream_t s) {
     g.RS = a.W + 8;
     g.TR = TP / a.W;
     g.W4 = a.W / 4;
-    int chs = (g.TR + 2) * g.RS;
-    chs += ((16 - (chs % 32)) + 32) % 32;  // -> == 16 (mod 32)
-    g.CHS = chs;
+    g.CHS = tail_chs(g.TR, a.W);
     const int MT = tail_mt(a.Cout, paired);
+    // compile-time geometry for the three level shapes of the 64x64 / L=3 model (BASELINE configs B/C)
+    if (MT == 1 && TP == 128 && a.W == 32) return launch_tail_cfg<1, 2, 4, 1, 32>(a, g, paired, s);
+    if (MT == 2 && TP == 32 && a.W == 16) return launch_tail_cfg<2, 1, 2, 2, 16>(a, g, paired, s);
+    if (MT == 3 && TP == 16 && a.W == 8) return launch_tail_cfg<3, 1, 1, 4, 8>(a, g, paired, s);
 #define GH_TAIL_TP(mt)                                                            \
     if (MT == mt) {                                                               \
         if (TP == 128) return launch_tail_cfg<mt, 2, 4, 1>(a, g, paired, s);      \
