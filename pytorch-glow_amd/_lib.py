@@ -15,7 +15,8 @@ from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_long, c_size_t,
 import torch
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG_DIR, "libglowhip.so")
+# GLOWHIP_LIB_PATH: kernel-variant experiments (scripts/) load an alternative build of the same ABI
+LIB_PATH = os.environ.get("GLOWHIP_LIB_PATH") or os.path.join(_PKG_DIR, "libglowhip.so")
 CSRC_DIR = os.path.join(_PKG_DIR, "csrc")
 
 LAYER_SQUEEZE, LAYER_FLOWSTEP, LAYER_SPLIT2D = 0, 1, 2

@@ -12,6 +12,13 @@ int conv_mfma_wide_pack(const float* w, int Cin, int Cout, int ksize, float* wt,
 int launch_conv_mfma_wide(const float* x, long x_bs, const float* wt, const float* post_bias, const float* post_scale,
                           float* y, int N, int Cin, int H, int W, int Cout, int ksize, hipStream_t s);
 
+// f.0 with a stationary LDS pixel window (conv_mfma_first.hip): Cin a multiple of 6 (C/2 of every Glow level).
+bool conv_mfma_first_supported(int Cin, int H, int W, int Cout);
+size_t conv_mfma_first_packed_bytes(int Cin, int Cout);
+// wf: packed image (weights * exp(3 logs), then bias * exp(3 logs)) produced by the REPACK_FIRST job
+int launch_conv_mfma_first(const float* x, long x_bs, const float* wf, const float* bias_scaled, float* y, int N,
+                           int Cin, int H, int W, int Cout, hipStream_t s);
+
 // "Tail" convolution: 3x3, few output channels (f.4 / Split2d prior), with the coupling / prior
 // arithmetic and the per-sample log-det reduction fused into the epilogue.
 enum TailMode {

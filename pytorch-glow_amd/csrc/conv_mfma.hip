@@ -120,7 +120,7 @@ k_conv_wide(const float* __restrict__ X, long x_bs, const float* __restrict__ Wt
     const int kl = lane >> 5, ml = lane & 31;
     for (int kt = 0; kt < nkt; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nkt) load_tile(kt + 1);  // HBM/L2 latency hidden under this tile's 64 MFMAs
+        if (kt + 1 < nkt) load_tile(kt + 1);  // HBM/L2 latency hidden under this tile's MFMAs
         // fragment reads are software-pipelined one k-step ahead of the MFMAs that consume them
         float a[2][TM], b[2][TN];
 #pragma unroll
@@ -141,12 +141,24 @@ k_conv_wide(const float* __restrict__ X, long x_bs, const float* __restrict__ Wt
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
+            // the refill of the OTHER LDS buffer is spread over the last NW k-steps, one ds_write_b128 per step
+            // between MFMA groups: as one burst at the end of the tile it held the LDS for ~400 cycles and the
+            // next tile's first fragment reads (hence the matrix pipe) queued behind it (-14 % measured)
+            constexpr int NW = A_PASSES + B_PASSES;
+            const int wsel = kk - (BK / 2 - NW);
+            if (wsel >= 0 && kt + 1 < nkt) {
+                if (wsel < A_PASSES)
+                    *reinterpret_cast<f32x4*>(&As[buf ^ 1][(wsel % A_PASSES) * A_RPP + a_row][a_c4 * 4]) = ra[wsel % A_PASSES];
+                else
+                    *reinterpret_cast<f32x4*>(&Bs[buf ^ 1][((wsel - A_PASSES) % B_PASSES) * B_RPP + b_row][b_c4 * 4]) =
+                        rb[(wsel - A_PASSES) % B_PASSES];
+            }
             // pin the issue order: next step's LDS reads go out BEFORE this step's MFMAs (hipcc otherwise sinks
             // them behind the MFMAs and waits lgkmcnt(0) with the matrix pipe idle)
             if (kk + 1 < BK / 2) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+            if (wsel >= 0) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
         }
-        if (kt + 1 < nkt) store_tile(buf ^ 1);
         __syncthreads();
     }
 

@@ -71,11 +71,12 @@ struct StepPrepJob {
 int launch_step_prepare_batched(const StepPrepJob* jobs_dev, int n, int max_lds_c, void* packed, hipStream_t s);
 
 struct ScaleJob { const float* logs; size_t scale_off, inv_off; int n; int has_inv; };
-enum { REPACK_WIDE = 0, REPACK_TAIL = 1 };
+enum { REPACK_WIDE = 0, REPACK_TAIL = 1, REPACK_FIRST = 2 };
 struct RepackJob {
     const float* w; size_t out_off; int kind;
     int Cin, Cout, K, Kpad;      // wide: K = Cin*k*k
     int paired, MT; long total;  // tail
+    const float* fold_bias; const float* fold_logs;  // first: ActNorm folded into the image
 };
 int launch_pack_batched(const ScaleJob* sj_dev, int n_scale, const RepackJob* rj_dev, int n_repack, void* packed,
                         hipStream_t s);

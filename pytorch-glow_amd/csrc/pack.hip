@@ -28,6 +28,18 @@ __global__ void __launch_bounds__(256) k_repack_batched(const RepackJob* __restr
             const int k = (int)(e / j.Cout), o = (int)(e - (long)k * j.Cout);
             out[e] = (k < j.K) ? j.w[(long)o * j.K + k] : 0.f;
         }
+    } else if (j.kind == REPACK_FIRST) {
+        // wf[(chunk*54 + tap*6 + cl)][o] = w[o][chunk*6 + cl][tap]   -- (6-channel chunk, tap, channel) K order
+        const long total = (long)9 * j.Cin * j.Cout;
+        for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+            const int o = (int)(e % j.Cout);
+            const int k = (int)(e / j.Cout);
+            const int chunk = k / 54, r = k - chunk * 54;
+            const int tap = r / 6, cl = r - tap * 6;
+            out[e] = j.w[((long)o * j.Cin + chunk * 6 + cl) * 9 + tap] * expf(j.fold_logs[o] * LOGSCALE);
+        }
+        for (long o = (long)blockIdx.x * 256 + threadIdx.x; o < j.Cout; o += (long)gridDim.x * 256)
+            out[total + o] = j.fold_bias[o] * expf(j.fold_logs[o] * LOGSCALE);
     } else {
         for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < j.total; e += (long)gridDim.x * 256) {
             const int i = (int)(e & 15), kq = (int)((e >> 4) & 3);

@@ -22,6 +22,7 @@ struct LayerPlan {
     size_t f0_scale = 0, f2_scale = 0, f4_scale = 0;
     size_t f0_wt = 0, f2_wt = 0, f4_wp = 0;
     bool mfma_first = false, mfma_mid = false, mfma_last = false;
+    bool first_halo = false;  // f.0 on k_conv_first (stationary pixel window) instead of k_conv_wide<3>
 };
 
 }  // namespace glowhip
@@ -134,8 +135,11 @@ static int run_coupling(glowhip_plan* P, const LayerPlan& L, const void* packed,
     const int Ch = d.C / 2, HW = d.H * d.W, hid = d.hidden;
     // f.0: 3x3, Cin=C/2 -> hidden, ActNorm + ReLU epilogue
     {
-    ScopedTimer t0(P, GLOWHIP_K_CONV_F0, L.mfma_first, s);
-    if (L.mfma_first) {
+    ScopedTimer t0(P, GLOWHIP_K_CONV_F0, L.mfma_first || L.first_halo, s);
+    if (L.first_halo) {
+        const float* wf = at<float>(packed, L.f0_wt);
+        GH_TRY(launch_conv_mfma_first(x1, x1_bs, wf, wf + (size_t)9 * Ch * hid, w.h1, N, Ch, d.H, d.W, hid, s));
+    } else if (L.mfma_first) {
         GH_TRY(launch_conv_mfma_wide(x1, x1_bs, at<float>(packed, L.f0_wt), d.f0_an_bias, at<float>(packed, L.f0_scale),
                                      w.h1, N, Ch, d.H, d.W, hid, 3, s));
     } else {
@@ -355,7 +359,9 @@ glowhip_plan* glowhip_plan_create(const glowhip_layer_desc* layers, int n_layers
             L.mfma_first = conv_mfma_wide_supported(C / 2, H, W, d.hidden, 3);
             L.mfma_mid = conv_mfma_wide_supported(d.hidden, H, W, d.hidden, 1);
             L.mfma_last = conv_mfma_tail_supported(d.hidden, H, W, L.Cout);
-            if (L.mfma_first) L.f0_wt = take(off, conv_mfma_wide_packed_bytes(C / 2, d.hidden, 3));
+            L.first_halo = conv_mfma_first_supported(C / 2, H, W, d.hidden);
+            if (L.first_halo) L.f0_wt = take(off, conv_mfma_first_packed_bytes(C / 2, d.hidden));
+            else if (L.mfma_first) L.f0_wt = take(off, conv_mfma_wide_packed_bytes(C / 2, d.hidden, 3));
             if (L.mfma_mid) L.f2_wt = take(off, conv_mfma_wide_packed_bytes(d.hidden, d.hidden, 1));
             if (L.mfma_last) L.f4_wp = take(off, conv_mfma_tail_packed_bytes(d.hidden, L.Cout));
             p->max_hidden = std::max(p->max_hidden, (long)std::max(d.hidden, L.Cout) * H * W);
@@ -390,7 +396,11 @@ glowhip_plan* glowhip_plan_create(const glowhip_layer_desc* layers, int n_layers
             p->scale_jobs.push_back(ScaleJob{d.f0_an_logs, L.f0_scale, 0, d.hidden, 0});
             p->scale_jobs.push_back(ScaleJob{d.f2_an_logs, L.f2_scale, 0, d.hidden, 0});
             p->scale_jobs.push_back(ScaleJob{d.f4_logs, L.f4_scale, 0, L.Cout, 0});
-            if (L.mfma_first) {
+            if (L.first_halo) {
+                RepackJob r{}; r.w = d.f0_w; r.out_off = L.f0_wt; r.kind = REPACK_FIRST; r.Cin = d.C / 2; r.Cout = d.hidden;
+                r.fold_bias = d.f0_an_bias; r.fold_logs = d.f0_an_logs;
+                p->repack_jobs.push_back(r);
+            } else if (L.mfma_first) {
                 RepackJob r{}; r.w = d.f0_w; r.out_off = L.f0_wt; r.kind = REPACK_WIDE; r.Cin = d.C / 2; r.Cout = d.hidden;
                 r.K = r.Cin * 9; r.Kpad = wide_kpad(r.Cin, 3); p->repack_jobs.push_back(r);
             }
@@ -476,7 +486,7 @@ int glowhip_plan_describe(const glowhip_plan* plan, char* buf, size_t buf_bytes)
         if (d.kind == GLOWHIP_LAYER_SQUEEZE) snprintf(line, sizeof line, "%d squeeze C=%d H=%d W=%d\n", li, d.C, d.H, d.W);
         else if (d.kind == GLOWHIP_LAYER_FLOWSTEP)
             snprintf(line, sizeof line, "%d flowstep C=%d H=%d W=%d hidden=%d f0=%s f2=%s f4=%s\n", li, d.C, d.H, d.W,
-                     d.hidden, L.mfma_first ? "mfma" : "direct", L.mfma_mid ? "mfma" : "direct",
+                     d.hidden, L.first_halo ? "mfma-halo" : (L.mfma_first ? "mfma" : "direct"), L.mfma_mid ? "mfma" : "direct",
                      L.mfma_last ? "mfma" : "direct");
         else snprintf(line, sizeof line, "%d split2d C=%d H=%d W=%d prior=%s\n", li, d.C, d.H, d.W,
                       L.mfma_last ? "mfma" : "direct");
