@@ -187,9 +187,10 @@ typedef struct glowhip_timing_record {
 int glowhip_plan_timing_enable(glowhip_plan* plan, int enable);
 int glowhip_plan_timing_read(glowhip_plan* plan, glowhip_timing_record* out, int max, int* n_out);
 
-/* Testing hook: force the pixel tile (16/32/64/128 pixels per workgroup; 0 = automatic, chosen from the grid size)
- * of the fused tail convolution, so every wave-layout variant can be exercised at any batch size. */
-void glowhip_debug_force_tail_tile(int pixels);
+/* Testing hook for the fused tail convolution, so every variant can be exercised at any batch size: low byte =
+ * pixels per workgroup (16/32/64/128; 0 = automatic, chosen by a cost model), | 0x100 = always split the
+ * out-channel tiles over blockIdx.y, | 0x200 = never split. 0 restores automatic selection. */
+void glowhip_debug_force_tail_tile(int pixels_and_flags);
 
 /* Introspection for tests / benchmarks: which kernels a plan will launch ("mfma" or "direct" per
  * convolution).  Writes a NUL-terminated description into buf. */

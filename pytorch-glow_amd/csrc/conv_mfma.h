@@ -12,6 +12,8 @@ int conv_mfma_wide_pack(const float* w, int Cin, int Cout, int ksize, float* wt,
 int launch_conv_mfma_wide(const float* x, long x_bs, const float* wt, const float* post_bias, const float* post_scale,
                           float* y, int N, int Cin, int H, int W, int Cout, int ksize, hipStream_t s);
 
+void conv_mfma_wide_disable_glds(int off);  // testing hook: 1 = use the register-staged k_conv_wide for 1x1 too
+
 // f.0 with a stationary LDS pixel window (conv_mfma_first.hip): Cin a multiple of 6 (C/2 of every Glow level).
 bool conv_mfma_first_supported(int Cin, int H, int W, int Cout);
 size_t conv_mfma_first_packed_bytes(int Cin, int Cout);

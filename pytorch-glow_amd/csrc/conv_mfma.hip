@@ -196,6 +196,168 @@ k_conv_wide(const float* __restrict__ X, long x_bs, const float* __restrict__ Wt
     }
 }
 
+// ================================================================================================
+// k_gemm_glds: the 1x1 convolution (f.2) with operand tiles streamed HBM/L2 -> LDS by the DMA path
+// (global_load_lds_dwordx4: no staging VGPRs, no ds_write pass) into a 4-stage ring of 16-deep K-tiles.
+// Tile t+3 is requested while tile t is multiplied; a stage is consumed after a COUNTED s_waitcnt vmcnt(8)
+// (two younger tiles stay in flight across the barrier) + one raw s_barrier per tile.  All LDS is one array
+// (a second __shared__ object makes hipcc drain vmcnt(0) before every ds_read of such a pipeline).
+// LDS image of a tile = [16][128] floats K-major, written linearly (a wave-instruction fills 1 KiB = two rows),
+// which is exactly the conflict-free layout the MFMA fragment reads want: no swizzle needed.
+// ================================================================================================
+constexpr int GL_BK = 16, GL_ST = 4, GL_BM = 128, GL_BN = 128;
+
+__global__ void __launch_bounds__(256)
+k_gemm_glds(const float* __restrict__ X, long x_bs, const float* __restrict__ Wt, const float* __restrict__ bias,
+            const float* __restrict__ scale, float* __restrict__ Y, int N, int K, int HW, int M) {
+    constexpr int BM = GL_BM, BN = GL_BN, BK = GL_BK;
+    constexpr int WM = 64, WN = 64, TM = 2, TN = 2;
+    constexpr int STAGE = BK * BM + BK * BN;   // floats per stage (16 KiB)
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // GL_ST * STAGE floats = 64 KiB
+
+    const long total_px = (long)N * HW;
+    const int tiles_m = M / BM;
+    const int tiles_n = (int)(total_px / BN);
+    const int logical = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int tile_m = logical % tiles_m, tile_n = logical / tiles_m;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 1, wc = wid & 1;
+    const int kl = lane >> 5, ml = lane & 31;
+
+    // per-lane DMA sources: wave w fills rows 4w..4w+3 of the A tile and of the B tile (two 1-KiB pieces each)
+    const float* a_src = Wt + (long)(4 * wid + kl) * M + (long)tile_m * BM + ml * 4;
+    const long gp = (long)tile_n * BN + ml * 4;
+    const long n = gp / HW;
+    const int p = (int)(gp - n * HW);
+    const float* b_src = X + n * x_bs + p + (long)(4 * wid + kl) * HW;
+    const int nkt = K / BK;
+
+    // one DMA piece (1 KiB) of tile kt: piece 0,1 = this wave's two A row-pairs, 2,3 = its two B row-pairs
+    auto issue_piece = [&](int kt, int piece) {
+        float* st = smem + (kt % GL_ST) * STAGE;
+        const int jj = piece & 1;
+        if (piece < 2)
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(a_src + (long)(kt * BK + 2 * jj) * M),
+                (__attribute__((address_space(3))) void*)(st + (2 * wid + jj) * 256), 16, 0, 0);
+        else
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(b_src + (long)(kt * BK + 2 * jj) * HW),
+                (__attribute__((address_space(3))) void*)(st + BK * BM + (2 * wid + jj) * 256), 16, 0, 0);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+        if (t < nkt) {
+#pragma unroll
+            for (int pc = 0; pc < 4; ++pc) issue_piece(t, pc);
+        }
+    // tile 0 has landed once at most tiles 1 and 2 (4 pieces each per wave) are outstanding
+    if (nkt >= 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (nkt == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    // One continuous stream of k-steps across tiles.  Mid-tile (k-step 4 of 8) the NEXT tile is made visible
+    // (counted vmcnt + raw barrier: the matrix pipe still has this tile's remaining MFMAs queued), so its first
+    // fragments are prefetched before this tile's last MFMAs; that barrier also proves every wave is past tile
+    // kt-1, whose stage is then refilled with tile kt+3, one DMA piece per k-step (an LDS-DMA issue costs ~60-180
+    // cycles: back to back they would idle the pipe, one at a time they hide behind an executing MFMA).
+    float a[2][TM], b[2][TN];
+    {
+        const float* As = smem;
+        const float* Bs = As + BK * BM;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[0][i] = As[kl * BM + wr * WM + i * 32 + ml];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[0][j] = Bs[kl * BN + wc * WN + j * 32 + ml];
+    }
+    for (int kt = 0; kt < nkt; ++kt) {
+        const float* As = smem + (kt % GL_ST) * STAGE;
+        const float* Bs = As + BK * BM;
+        const float* An = smem + ((kt + 1) % GL_ST) * STAGE;
+        const float* Bn = An + BK * BM;
+        const bool has_next = kt + 1 < nkt;
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk) {
+            const int cur = kk & 1, nxt = cur ^ 1;
+            if (kk == 4 && has_next) {
+                if (kt + 2 < nkt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+            }
+            if (kk + 1 < BK / 2) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[nxt][i] = As[((kk + 1) * 2 + kl) * BM + wr * WM + i * 32 + ml];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[nxt][j] = Bs[((kk + 1) * 2 + kl) * BN + wc * WN + j * 32 + ml];
+            } else if (has_next) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[nxt][i] = An[kl * BM + wr * WM + i * 32 + ml];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[nxt][j] = Bn[kl * BN + wc * WN + j * 32 + ml];
+            }
+            const bool dma = kk >= 4 && kt + 3 < nkt;
+            if (dma) issue_piece(kt + 3, kk - 4);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+            if (kk >= 4) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
+        }
+    }
+    __syncthreads();   // all waves done with the operand ring before it is reused as the output staging area
+
+    // ---- epilogue (as k_conv_wide): ActNorm + ReLU, transpose through LDS, 16-byte stores
+    float* stage = smem + wid * (WM * WN);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl;
+            const int o = tile_m * BM + wr * WM + row;
+            const float bo = bias[o], so = scale[o];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) stage[row * WN + j * 32 + ml] = fmaxf((acc[i][j][r] + bo) * so, 0.f);
+        }
+    }
+    constexpr int F4_PER_ROW = WN / 4, ROWS_PER_IT = 64 / F4_PER_ROW;
+    const int rrow = lane / F4_PER_ROW, rc4 = lane % F4_PER_ROW;
+    const long gpo = (long)tile_n * BN + wc * WN + rc4 * 4;
+    const long no = gpo / HW;
+    const int po = (int)(gpo - no * HW);
+    float* yn = Y + no * (long)M * HW + po;
+#pragma unroll
+    for (int it = 0; it < WM / ROWS_PER_IT; ++it) {
+        const int row = it * ROWS_PER_IT + rrow;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(stage + row * WN + rc4 * 4);
+        const int o = tile_m * BM + wr * WM + row;
+        *reinterpret_cast<f32x4*>(yn + (long)o * HW) = v;
+    }
+}
+
+static bool g_disable_glds = false;   // testing hook
+void conv_mfma_wide_disable_glds(int off) { g_disable_glds = off != 0; }
+
+static bool gemm_glds_ok(int Cin, int HW, int Cout, long total_px) {
+    return !g_disable_glds && Cout % GL_BM == 0 && Cin % GL_BK == 0 && Cin >= 3 * GL_BK && HW % 4 == 0 &&
+           total_px % GL_BN == 0;
+}
+
 static int pick_wide_tile(int Cout, long total_px) {
     // 128x128 when the grid still fills the chip (>= 2 tiles per CU), else 64x64
     if (Cout % 128 == 0 && (Cout / 128) * ((total_px + 127) / 128) >= 512) return 128;
@@ -247,6 +409,18 @@ int launch_conv_mfma_wide(const float* x, long x_bs, const float* wt, const floa
     GH_REQUIRE(conv_mfma_wide_supported(Cin, H, W, Cout, ksize), "conv_mfma_wide: unsupported shape");
     if (N == 0) return GLOWHIP_OK;
     const int t = pick_wide_tile(Cout, (long)N * H * W);
+    if (ksize == 1 && t == 128 && gemm_glds_ok(Cin, H * W, Cout, (long)N * H * W)) {
+        const long total_px = (long)N * H * W;
+#ifndef GLOWHIP_EXP_LDSPAD
+#define GLOWHIP_EXP_LDSPAD 0
+#endif
+        const size_t lds = (size_t)GL_ST * (GL_BK * GL_BM + GL_BK * GL_BN) * sizeof(float) + GLOWHIP_EXP_LDSPAD;
+        (void)hipFuncSetAttribute((const void*)k_gemm_glds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_gemm_glds, dim3((unsigned)((Cout / GL_BM) * (total_px / GL_BN))), dim3(256), lds, s, x, x_bs, wt,
+                           post_bias, post_scale, y, N, Cin, H * W, Cout);
+        GH_LAUNCH_CHECK("k_gemm_glds");
+        return GLOWHIP_OK;
+    }
     if (ksize == 1) {
         if (t == 128) return launch_wide_cfg<1, 128>(x, x_bs, wt, post_bias, post_scale, y, N, Cin, H, W, Cout, s);
         return launch_wide_cfg<1, 64>(x, x_bs, wt, post_bias, post_scale, y, N, Cin, H, W, Cout, s);

@@ -20,21 +20,41 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // waves are arranged WN (pixel tiles) x WK (K-split: wave wk takes channel groups c4 = wk, wk+WK, ...), partial
 // sums of the WK waves are reduced through LDS before the epilogue.  Smaller tiles + K-split keep >= 2 blocks per
 // CU on the deep levels (8x8 images: 4096 pixels per step) where a 128-pixel tile would occupy 1/4 of the chip.
-static int g_force_tp = 0;  // testing hook (glowhip_debug_force_tail_tile)
+static int g_force_tp = 0;      // testing hooks (glowhip_debug_force_tail_tile): pixels per block, 0 = automatic
+static int g_force_msplit = -1; // -1 automatic, 0 never, 1 always split the out-channel tiles over blockIdx.y
 static bool tp_ok(int tp, int H, int W) {
     if (tp % W != 0 || (H * W) % tp != 0) return false;
     return TAIL_CK * (tp / W + 2) * (W / 4) <= 6 * 256;  // halo tile must fit the 6-float4 staging registers
 }
-static int tail_tp(int H, int W, long total_px) {
-    if (g_force_tp && tp_ok(g_force_tp, H, W)) return g_force_tp;
+// Choose pixels-per-block and whether to split the out-channel tiles over blockIdx.y with a two-term cost model
+// per CU: matrix-pipe cycles vs. weight-streaming cycles.  Every block streams the weights of its out-channel
+// tiles once (Cin*9*16*4 B per tile; a CU sustains ~10 B/clk of such L2->LDS refills), so many small pixel tiles
+// are stream-bound (the deep levels), while few large ones leave CUs idle.
+struct TailChoice { int tp, msplit; };
+static TailChoice tail_choose(int H, int W, long total_px, int Cin, int mt_total) {
     const int cand[4] = {128, 64, 32, 16};
-    int smallest = 0;
-    for (int i = 0; i < 4; ++i) {
-        if (!tp_ok(cand[i], H, W)) continue;
-        if (total_px / cand[i] >= 512) return cand[i];
-        smallest = cand[i];
+    TailChoice best{0, 0};
+    double best_cost = 1e30;
+    for (int ms = 0; ms <= 1; ++ms) {
+        if (ms == 1 && mt_total == 1) continue;
+        if (g_force_msplit >= 0 && ms != g_force_msplit && mt_total > 1) continue;
+        for (int i = 0; i < 4; ++i) {
+            const int tp = cand[i];
+            if (!tp_ok(tp, H, W)) continue;
+            if (g_force_tp && tp != g_force_tp && tp_ok(g_force_tp, H, W)) continue;
+            const int wk = tp >= 64 ? 1 : (tp == 32 ? 2 : 4), ntw = tp == 128 ? 2 : 1;
+            const int mt_b = ms ? 1 : mt_total;
+            const double blocks = (double)(total_px / tp) * (ms ? mt_total : 1);
+            const double per_cu = blocks <= 256 ? 1.0 : blocks / 256.0;
+            const double mfma = per_cu * ntw * mt_b * ((Cin + 3) / 4 * 9.0 / wk) * 32.0;
+            const double stream = per_cu * (double)Cin * 9 * mt_b * 64 / 10.0;
+            double cost = mfma > stream ? mfma : stream;
+            if (blocks < 512) cost *= 1.15;            // a lone block per CU cannot hide its own refill latency
+            cost += 1e-3 * stream;                       // tie-break: less streaming
+            if (cost < best_cost) { best_cost = cost; best = TailChoice{tp, ms}; }
+        }
     }
-    return smallest;
+    return best;
 }
 
 static bool tail_paired(int mode) { return mode != TAIL_PLAIN && mode != TAIL_ADD_FWD && mode != TAIL_ADD_REV; }
@@ -117,6 +137,7 @@ __global__ void __launch_bounds__(256) k_conv_tail(TailConvArgs a, TailGeom gr, 
     const int wn = wid % WN, wk = wid / WN;            // pixel-tile column / K-split slice of this wave
     const int HW = a.H * a.W;
     const long gp0 = (long)blockIdx.x * TP;
+    const int mt_total = gridDim.y * MT, mt0 = blockIdx.y * MT;
     const long n = gp0 / HW;
     const int p0 = (int)(gp0 - n * HW);
     const int y0 = p0 / a.W;
@@ -156,11 +177,15 @@ __global__ void __launch_bounds__(256) k_conv_tail(TailConvArgs a, TailGeom gr, 
                 v = *reinterpret_cast<const f32x4*>(xin + (long)cbase * HW + x_src[it]);
             rx[it] = v;
         }
-        const f32x4* asrc = reinterpret_cast<const f32x4*>(a.wp + (long)ch * A_FLOATS);
+        // packed weights are [c4][tap][mt_total][64]; this block takes MT consecutive m-tiles from mt0
+        // (M-split over blockIdx.y: a block streams only its own share of the weights)
+        const float* asrc = a.wp + (long)ch * (TAIL_CK / 4) * 9 * mt_total * 64;
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
-            const int e = it * 256 + tid;
-            rA[it] = (e < A_F4) ? asrc[e] : (f32x4){0.f, 0.f, 0.f, 0.f};
+            const int e = it * 256 + tid;                 // float4 index into the block's [8*9][MT*64] image
+            const int row = e / (MT * 16), c = e - row * (MT * 16);
+            rA[it] = (e < A_F4) ? *reinterpret_cast<const f32x4*>(asrc + ((long)row * mt_total + mt0) * 64 + c * 4)
+                                : (f32x4){0.f, 0.f, 0.f, 0.f};
         }
     };
     auto store_chunk = [&]() {
@@ -282,7 +307,7 @@ __global__ void __launch_bounds__(256) k_conv_tail(TailConvArgs a, TailGeom gr, 
     if (wk == 0) {
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
-        const int mrow = m * 16 + (lane >> 4) * 4;
+        const int mrow = (mt0 + m) * 16 + (lane >> 4) * 4;
         float hb[4], hs[4];
         int oc[4];
 #pragma unroll
@@ -341,7 +366,7 @@ __global__ void __launch_bounds__(256) k_conv_tail(TailConvArgs a, TailGeom gr, 
 }
 
 template <int MT, int NTW, int WN, int WK, int WFIX = 0>
-static int launch_tail_cfg(const TailConvArgs& a, const TailGeom& g, int paired, hipStream_t s) {
+static int launch_tail_cfg(const TailConvArgs& a, const TailGeom& g, int paired, hipStream_t s, int msplit = 1) {
     constexpr int TP = 16 * NTW * WN;
     const long total_px = (long)a.N * a.H * a.W;
     size_t lds = ((size_t)TAIL_CK * g.CHS + (size_t)(TAIL_CK / 4) * 9 * MT * 64) * sizeof(float);
@@ -350,7 +375,8 @@ static int launch_tail_cfg(const TailConvArgs& a, const TailGeom& g, int paired,
     if (lds > 32 * 1024)
         (void)hipFuncSetAttribute((const void*)k_conv_tail<MT, NTW, WN, WK, WFIX>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);
-    hipLaunchKernelGGL((k_conv_tail<MT, NTW, WN, WK, WFIX>), dim3((unsigned)(total_px / TP)), dim3(256), lds, s, a, g, paired);
+    hipLaunchKernelGGL((k_conv_tail<MT, NTW, WN, WK, WFIX>), dim3((unsigned)(total_px / TP), msplit), dim3(256), lds, s, a,
+                       g, paired);
     GH_LAUNCH_CHECK("k_conv_tail");
     return GLOWHIP_OK;
 }
@@ -360,24 +386,27 @@ int launch_conv_mfma_tail(const TailConvArgs& a, hipStream_t s) {
     if (a.N == 0) return GLOWHIP_OK;
     const int paired = tail_paired(a.mode);
     GH_REQUIRE(!paired || a.Cout % 2 == 0, "conv_mfma_tail: paired mode needs an even Cout");
-    const int TP = tail_tp(a.H, a.W, (long)a.N * a.H * a.W);
+    const int MTT = tail_mt(a.Cout, paired);   // out-channel tiles in total
+    const TailChoice tc = tail_choose(a.H, a.W, (long)a.N * a.H * a.W, a.Cin, MTT);
+    const int TP = tc.tp;
     GH_REQUIRE(TP > 0, "conv_mfma_tail: no pixel tile for %dx%d", a.H, a.W);
     TailGeom g;
     g.RS = a.W + 8;
     g.TR = TP / a.W;
     g.W4 = a.W / 4;
     g.CHS = tail_chs(g.TR, a.W);
-    const int MT = tail_mt(a.Cout, paired);
+    const int MT = tc.msplit ? 1 : MTT;          // tiles per block
+    const int Y = tc.msplit ? MTT : 1;           // blockIdx.y extent
     // compile-time geometry for the three level shapes of the 64x64 / L=3 model (BASELINE configs B/C)
-    if (MT == 1 && TP == 128 && a.W == 32) return launch_tail_cfg<1, 2, 4, 1, 32>(a, g, paired, s);
-    if (MT == 2 && TP == 32 && a.W == 16) return launch_tail_cfg<2, 1, 2, 2, 16>(a, g, paired, s);
-    if (MT == 3 && TP == 16 && a.W == 8) return launch_tail_cfg<3, 1, 1, 4, 8>(a, g, paired, s);
-#define GH_TAIL_TP(mt)                                                            \
-    if (MT == mt) {                                                               \
-        if (TP == 128) return launch_tail_cfg<mt, 2, 4, 1>(a, g, paired, s);      \
-        if (TP == 64) return launch_tail_cfg<mt, 1, 4, 1>(a, g, paired, s);       \
-        if (TP == 32) return launch_tail_cfg<mt, 1, 2, 2>(a, g, paired, s);       \
-        if (TP == 16) return launch_tail_cfg<mt, 1, 1, 4>(a, g, paired, s);       \
+    if (MT == 1 && TP == 128 && a.W == 32) return launch_tail_cfg<1, 2, 4, 1, 32>(a, g, paired, s, Y);
+    if (MT == 1 && TP == 64 && a.W == 16) return launch_tail_cfg<1, 1, 4, 1, 16>(a, g, paired, s, Y);
+    if (MT == 1 && TP == 64 && a.W == 8) return launch_tail_cfg<1, 1, 4, 1, 8>(a, g, paired, s, Y);
+#define GH_TAIL_TP(mt)                                                               \
+    if (MT == mt) {                                                                  \
+        if (TP == 128) return launch_tail_cfg<mt, 2, 4, 1>(a, g, paired, s, Y);      \
+        if (TP == 64) return launch_tail_cfg<mt, 1, 4, 1>(a, g, paired, s, Y);       \
+        if (TP == 32) return launch_tail_cfg<mt, 1, 2, 2>(a, g, paired, s, Y);       \
+        if (TP == 16) return launch_tail_cfg<mt, 1, 1, 4>(a, g, paired, s, Y);       \
     }
     GH_TAIL_TP(1) GH_TAIL_TP(2) GH_TAIL_TP(3)
 #undef GH_TAIL_TP
@@ -385,6 +414,10 @@ int launch_conv_mfma_tail(const TailConvArgs& a, hipStream_t s) {
     return GLOWHIP_EINVAL;
 }
 
-void conv_mfma_tail_force_tile(int tp) { g_force_tp = tp; }
+// testing hook: tp = pixels per block (0 automatic); bit 8 set => force msplit on (0x100 | tp), bit 9 => force off
+void conv_mfma_tail_force_tile(int v) {
+    g_force_tp = v & 0xff;
+    g_force_msplit = (v & 0x100) ? 1 : ((v & 0x200) ? 0 : -1);
+}
 
 }  // namespace glowhip

@@ -442,16 +442,18 @@ def test_mfma_transpose_detecting():
     close(z, zr, 5e-5, rtol=2e-5); ld_close(ld, ldr)
 
 
+@pytest.mark.parametrize("msplit", [0x100, 0x200])
 @pytest.mark.parametrize("tp", [16, 32, 64, 128])
 @pytest.mark.parametrize("c,h,w", [(12, 32, 32), (24, 16, 16), (48, 8, 8)])
-def test_mfma_tail_every_wave_layout(tp, c, h, w):
-    """Each pixel-tile / K-split variant of the fused tail kernel (WN x WK = 4x1, 2x2, 1x4) on each level geometry."""
+def test_mfma_tail_every_wave_layout(tp, c, h, w, msplit):
+    """Each pixel-tile / K-split variant of the fused tail kernel (WN x WK = 4x1, 2x2, 1x4), with and without the
+    out-channel split over blockIdx.y, on each level geometry."""
     if (h * w) % tp or tp % w:
         pytest.skip("tile does not cover whole rows of this image")
     st, sd = _rand_step(c, 64, "affine", seed=tp + c)
     x = torch.randn(3, c, h, w, generator=torch.Generator().manual_seed(5))
     zr, ldr = O.flowstep(x, torch.zeros(3), sd, "", "invconv", "affine")
-    G.lib().glowhip_debug_force_tail_tile(tp)
+    G.lib().glowhip_debug_force_tail_tile(tp | msplit)
     try:
         z, ld = st(dev(x), 0.)
         z2, ld2 = st(dev(x), 0.)
