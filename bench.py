@@ -13,7 +13,7 @@ steps.  Multi-GPU: one process per GPU, batch sharded (weak scaling, 64 images p
 other than the scalar loss all-reduce.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel = the 1x1
-512->512 MFMA GEMM, timed live with HIP events around each of its launches in an instrumented pass of the same
+512->512 MFMA GEMM `k_gemm_glds`, timed live with HIP events around each of its launches in an instrumented pass of the same
 step) and `cpu_baseline` (the CPU oracle timed on this box's host cores on a bounded sample).
 """
 import argparse
@@ -195,7 +195,7 @@ def main():
             bd[key][1] += 1
             total_px = B * d.H * d.W
             uses_128 = (hid // 128) * ((total_px + 127) // 128) >= 512
-            if kind == 2 and mfma and uses_128:  # k_conv_wide<1,128,128,32>
+            if kind == 2 and mfma and uses_128:  # k_gemm_glds (128x128 tiles: level 1 and level 2 launches)
                 dom_ms += ms
                 dom_flop += 2.0 * hid * hid * total_px
                 dom_n += 1
@@ -203,8 +203,8 @@ def main():
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get("k_conv_wide_1x1_128_hbm_bytes_per_launch")
-        out["roofline"] = {"bound": "mfma", "kernel": "k_conv_wide<1,128,128,32> (f.2: 1x1 conv 512->512 + ActNorm + ReLU)",
+            traffic = json.load(open(tpath)).get("k_gemm_glds_hbm_bytes_per_launch")
+        out["roofline"] = {"bound": "mfma", "kernel": "k_gemm_glds (f.2: 1x1 conv 512->512 + ActNorm + ReLU, 128x128 tiles)",
                            "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
                            "launches": dom_n, "avg_launch_us": round(1e3 * dom_ms / max(dom_n, 1), 2),

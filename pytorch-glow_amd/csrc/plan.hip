@@ -170,6 +170,7 @@ static int run_coupling(glowhip_plan* P, const LayerPlan& L, const void* packed,
         t.mode = d.coupling == GLOWHIP_COUPLING_AFFINE ? (reverse ? TAIL_AFFINE_REV : TAIL_AFFINE_FWD)
                                                        : (reverse ? TAIL_ADD_REV : TAIL_ADD_FWD);
         t.z2_in = z2_in; t.z2_in_bs = z2_in_bs; t.z2_out = z2_out; t.z2_out_bs = z2_out_bs; t.acc = w.acc;
+        t.zeros = at<float>(packed, 64);   // zero block kept by glowhip_plan_pack
         GH_TRY(launch_conv_mfma_tail(t, s));
     } else {
         ConvArgs c{w.h2, (long)hid * HW, d.f4_w, d.f4_bias, nullptr, nullptr, at<float>(packed, L.f4_scale), 0, w.h1,
@@ -196,6 +197,7 @@ static int run_split(const LayerPlan& L, const void* packed, const float* z1, lo
         t.mode = reverse ? TAIL_SPLIT_REV : TAIL_SPLIT_FWD;
         t.z2_in = reverse ? eps : z2; t.z2_in_bs = reverse ? (long)Ch * HW : z2_bs;
         t.z2_out = z2_out; t.z2_out_bs = z2_out_bs; t.acc = w.acc;
+        t.zeros = at<float>(packed, 64);
         GH_TRY(launch_conv_mfma_tail(t, s));
     } else {
         ConvArgs c{z1, z1_bs, d.f4_w, d.f4_bias, nullptr, nullptr, at<float>(packed, L.f4_scale), 0, w.h1,
@@ -315,7 +317,7 @@ glowhip_plan* glowhip_plan_create(const glowhip_layer_desc* layers, int n_layers
     }
     glowhip_plan* p = new glowhip_plan();
     size_t off = 0;
-    take(off, sizeof(double));  // plan-wide data-independent log-det total at offset 0
+    take(off, 256);  // offset 0: plan-wide data-independent log-det total (fp64); offset 64..127: zero block for LDS-DMA padding
     int C = layers[0].C, H = layers[0].H, W = layers[0].W;
     p->in_shape[0] = C; p->in_shape[1] = H; p->in_shape[2] = W;
     for (int i = 0; i < n_layers; ++i) {
@@ -503,6 +505,10 @@ int glowhip_plan_pack(glowhip_plan* plan, void* packed, size_t packed_bytes, glo
                plan->packed_bytes);
     hipStream_t s = (hipStream_t)stream;
     // job tables -> device (plan-constant contents; re-sent because `packed` is caller memory), then 4 launches
+    if (hipMemsetAsync(packed, 0, 256, s) != hipSuccess) {
+        set_error("plan_pack: hipMemsetAsync failed");
+        return GLOWHIP_ELAUNCH;
+    }
     auto upload = [&](size_t off, const void* src, size_t bytes) {
         return bytes == 0 || hipMemcpyAsync((char*)packed + off, src, bytes, hipMemcpyHostToDevice, s) == hipSuccess;
     };
