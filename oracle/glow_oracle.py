@@ -134,8 +134,18 @@ def actnorm(x, bias, logs, logdet=None, reverse: bool = False):
 
 
 # ----------------------------------------------------------------------------- invconv (R5) / permutation (R14)
+STABLE_LOGDET = False  # tests only: see invconv_dlogdet
+
+
 def invconv_dlogdet(weight: torch.Tensor, pixels: int) -> torch.Tensor:
-    """network/module.py:356-357 -- log|det W| * H*W (torch.det = LU with partial pivoting)."""
+    """network/module.py:356-357 -- log|det W| * H*W (torch.det = LU with partial pivoting).
+
+    Reference quirk: `torch.det` forms the PRODUCT of the LU pivots in fp32; at C=384 (config E, deepest level)
+    that product underflows to 0 for a perfectly conditioned orthogonal W and the reference's log-det is -inf.
+    With ``STABLE_LOGDET`` the oracle evaluates sum(log|pivot|) in fp64 instead (what the HIP LU kernel does), so
+    tests can still check the large-C levels; the default restates the reference exactly."""
+    if STABLE_LOGDET:
+        return torch.linalg.slogdet(weight.double())[1].to(weight.dtype) * pixels
     return torch.log(torch.abs(torch.det(weight))) * pixels
 
 

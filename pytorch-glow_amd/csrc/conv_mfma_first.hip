@@ -29,11 +29,14 @@ __host__ __device__ constexpr int first_chs(int TR, int W) {   // == 16 (mod 32)
 }
 
 bool conv_mfma_first_supported(int Cin, int H, int W, int Cout) {
-    if (Cin % FIRST_CK != 0 || Cin > 48) return false;
+    if (Cin % FIRST_CK != 0 || Cin > 192) return false;
     if (Cout % FIRST_BM != 0) return false;
-    if (W != 8 && W != 16 && W != 32) return false;   // instantiated widths (compile-time LDS geometry)
+    if (W != 8 && W != 16 && W != 32 && W != 64 && W != 128) return false;   // instantiated widths
     const int HW = H * W;
-    return HW % 128 == 0 || HW % 64 == 0;
+    const int BN = (HW % 128 == 0) ? 128 : 64;
+    if (HW % BN != 0 || BN % W != 0) return false;
+    // weight double buffer + stationary window must fit the 160 KiB LDS
+    return ((size_t)2 * FIRST_BK * FIRST_BM + (size_t)Cin * first_chs(BN / W, W)) * sizeof(float) <= 150 * 1024;
 }
 
 // packed image: [9*Cin][Cout] weights pre-multiplied by exp(3 logs[o]), then Cout floats bias[o]*exp(3 logs[o])
@@ -189,7 +192,9 @@ int launch_conv_mfma_first(const float* x, long x_bs, const float* wf_, const fl
     // pixel tile: 128 when that still gives >= 512 workgroups (with MB=1), else 64; then fold output-channel
     // tiles into a workgroup (MB) while >= 512 workgroups remain, so the pixel window is reused
     int BN = (HW % 128 == 0 && 128 % W == 0) ? 128 : 64;
-    if (BN == 128 && HW % 64 == 0 && 64 % W == 0 && (total_px / 128) * mtiles < 512) BN = 64;
+    if (BN == 128 && HW % 64 == 0 && 64 % W == 0 && (total_px / 128) * mtiles < 512 &&
+        ((size_t)2 * FIRST_BK * FIRST_BM + (size_t)Cin * first_chs(64 / W, W)) * sizeof(float) <= 150 * 1024)
+        BN = 64;
     int MB = 1;
     while (MB * 2 <= mtiles && mtiles % (MB * 2) == 0 && (total_px / BN) * (mtiles / (MB * 2)) >= 512) MB *= 2;
     FirstGeom g;
@@ -206,7 +211,7 @@ int launch_conv_mfma_first(const float* x, long x_bs, const float* wf_, const fl
         return GLOWHIP_OK;                                                                                           \
     }
     GH_FIRST_CASE(128, 32) GH_FIRST_CASE(64, 32) GH_FIRST_CASE(128, 16) GH_FIRST_CASE(64, 16) GH_FIRST_CASE(64, 8)
-    GH_FIRST_CASE(128, 8)
+    GH_FIRST_CASE(128, 8) GH_FIRST_CASE(128, 64) GH_FIRST_CASE(64, 64) GH_FIRST_CASE(128, 128)
 #undef GH_FIRST_CASE
     set_error("conv_mfma_first: no kernel for BN=%d W=%d", BN, W);
     return GLOWHIP_EINVAL;

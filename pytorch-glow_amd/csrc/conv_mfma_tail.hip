@@ -18,16 +18,31 @@ namespace glowhip {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+__host__ __device__ constexpr int tail_chs(int TR, int W) {   // channel stride == 16 (mod 32) floats
+    return (TR + 2) * (W + 8) + ((16 - ((TR + 2) * (W + 8)) % 32) + 32) % 32;
+}
+
 // Pixel-tile choice.  A block covers TP = 16*NTW*WN consecutive pixels = whole image rows of ONE image; its 4
 // waves are arranged WN (pixel tiles) x WK (K-split: wave wk takes channel groups c4 = wk, wk+WK, ...), partial
 // sums of the WK waves are reduced through LDS before the epilogue.  Smaller tiles + K-split keep >= 2 blocks per
 // CU on the deep levels (8x8 images: 4096 pixels per step) where a 128-pixel tile would occupy 1/4 of the chip.
 static int g_force_tp = 0;      // testing hooks (glowhip_debug_force_tail_tile): pixels per block, 0 = automatic
 static int g_force_msplit = -1; // -1 automatic, 0 never, 1 always split the out-channel tiles over blockIdx.y
-static bool tp_ok(int tp, int H, int W) {
+static bool g_disable_tail_dma = false;
+// register-staged kernels: the halo tile must fit the 6-float4 staging registers
+static bool tp_ok_reg(int tp, int H, int W) {
     if (tp % W != 0 || (H * W) % tp != 0) return false;
-    return TAIL_CK * (tp / W + 2) * (W / 4) <= 6 * 256;  // halo tile must fit the 6-float4 staging registers
+    return TAIL_CK * (tp / W + 2) * (W / 4) <= 6 * 256;
 }
+// LDS-DMA kernels: instantiated widths, 16-channel chunks, 3 stages within the 160 KiB LDS
+static bool tp_ok_dma(int tp, int H, int W, int Cin) {
+    if (g_disable_tail_dma || Cin % 16 != 0 || Cin < 32) return false;
+    if (W != 8 && W != 16 && W != 32 && W != 64 && W != 128) return false;
+    if (tp % W != 0 || (H * W) % tp != 0) return false;
+    const int xf = (16 * tail_chs(tp / W, W) + 255) / 256 * 256;
+    return (size_t)(3 * (xf + 4 * 9 * 64) + 264) * sizeof(float) <= 150 * 1024;
+}
+static bool tp_ok(int tp, int H, int W, int Cin) { return tp_ok_reg(tp, H, W) || tp_ok_dma(tp, H, W, Cin); }
 // Choose pixels-per-block and whether to split the out-channel tiles over blockIdx.y with a two-term cost model
 // per CU: matrix-pipe cycles vs. weight-streaming cycles.  Every block streams the weights of its out-channel
 // tiles once (Cin*9*16*4 B per tile; a CU sustains ~10 B/clk of such L2->LDS refills), so many small pixel tiles
@@ -42,8 +57,12 @@ static TailChoice tail_choose(int H, int W, long total_px, int Cin, int mt_total
         if (g_force_msplit >= 0 && ms != g_force_msplit && mt_total > 1) continue;
         for (int i = 0; i < 4; ++i) {
             const int tp = cand[i];
-            if (!tp_ok(tp, H, W)) continue;
-            if (g_force_tp && tp != g_force_tp && tp_ok(g_force_tp, H, W)) continue;
+            // a DMA-only tile needs the out-channel split (MT == 1 kernels); more than 3 tiles per block do not exist
+            const bool reg = tp_ok_reg(tp, H, W), dmaok = tp_ok_dma(tp, H, W, Cin);
+            if (!(reg || dmaok)) continue;
+            const int mt_blk = ms ? 1 : mt_total;
+            if (mt_blk > 3 || (!reg && mt_blk != 1)) continue;
+            if (g_force_tp && tp != g_force_tp && tp_ok(g_force_tp, H, W, Cin)) continue;
             const int wk = tp >= 64 ? 1 : (tp == 32 ? 2 : 4), ntw = tp == 128 ? 2 : 1;
             const int mt_b = ms ? 1 : mt_total;
             const double blocks = (double)(total_px / tp) * (ms ? mt_total : 1);
@@ -64,8 +83,8 @@ static bool tail_paired(int mode) { return mode != TAIL_PLAIN && mode != TAIL_AD
 
 bool conv_mfma_tail_supported(int Cin, int H, int W, int Cout) {
     if (W % 4 != 0 || W < 8) return false;
-    if (Cout > 48 || Cout < 1 || Cin < 1) return false;
-    return tp_ok(128, H, W) || tp_ok(64, H, W) || tp_ok(32, H, W) || tp_ok(16, H, W);
+    if (Cout > 1024 || Cout < 1 || Cin < 1) return false;
+    return tp_ok(128, H, W, Cin) || tp_ok(64, H, W, Cin) || tp_ok(32, H, W, Cin) || tp_ok(16, H, W, Cin);
 }
 
 size_t conv_mfma_tail_packed_bytes(int Cin, int Cout) {
@@ -171,10 +190,6 @@ struct TailGeom {
     int TR;    // image rows per block tile
     int W4;    // W / 4
 };
-
-__host__ __device__ constexpr int tail_chs(int TR, int W) {   // channel stride == 16 (mod 32) floats
-    return (TR + 2) * (W + 8) + ((16 - ((TR + 2) * (W + 8)) % 32) + 32) % 32;
-}
 
 // WFIX > 0: image width known at compile time (the BASELINE level geometries) => every LDS offset of the
 // unrolled tap/channel pipeline is an instruction immediate instead of a live VGPR; WFIX == 0: runtime geometry.
@@ -555,7 +570,6 @@ __global__ void __launch_bounds__(256) k_conv_tail_dma(TailConvArgs a, int paire
     }
 }
 
-static bool g_disable_tail_dma = false;
 template <int MT, int NTW, int WN, int WK, int WFIX>
 static int launch_tail_dma(const TailConvArgs& a, int paired, hipStream_t s, int msplit) {
     constexpr int TP = 16 * NTW * WN;
@@ -598,6 +612,7 @@ int launch_conv_mfma_tail(const TailConvArgs& a, hipStream_t s) {
     const TailChoice tc = tail_choose(a.H, a.W, (long)a.N * a.H * a.W, a.Cin, MTT);
     const int TP = tc.tp;
     GH_REQUIRE(TP > 0, "conv_mfma_tail: no pixel tile for %dx%d", a.H, a.W);
+    GH_REQUIRE(tp_ok_reg(TP, a.H, a.W) || a.zeros, "conv_mfma_tail: this shape needs the LDS-DMA kernel (zero block missing)");
     TailGeom g;
     g.RS = a.W + 8;
     g.TR = TP / a.W;
@@ -606,15 +621,21 @@ int launch_conv_mfma_tail(const TailConvArgs& a, hipStream_t s) {
     const int MT = tc.msplit ? 1 : MTT;          // tiles per block
     const int Y = tc.msplit ? MTT : 1;           // blockIdx.y extent
     // LDS-DMA pipeline for the level shapes of the 64x64 / L=3 model (needs a global zero block and Cin % 16 == 0)
-    if (!g_disable_tail_dma && a.zeros && a.Cin % 16 == 0 && a.Cin >= 32) {
-#define GH_TAIL_DMA(w)                                                                        \
-        if (MT == 1 && a.W == w) {                                                            \
-            if (TP == 128) return launch_tail_dma<1, 2, 4, 1, w>(a, paired, s, Y);            \
-            if (TP == 64) return launch_tail_dma<1, 1, 4, 1, w>(a, paired, s, Y);             \
-            if (TP == 32) return launch_tail_dma<1, 1, 2, 2, w>(a, paired, s, Y);             \
-            if (TP == 16) return launch_tail_dma<1, 1, 1, 4, w>(a, paired, s, Y);             \
+    if (MT == 1 && a.zeros && tp_ok_dma(TP, a.H, a.W, a.Cin)) {
+        if (a.W == 128 && TP == 128) return launch_tail_dma<1, 2, 4, 1, 128>(a, paired, s, Y);
+        if (a.W == 64 && TP == 128) return launch_tail_dma<1, 2, 4, 1, 64>(a, paired, s, Y);
+        if (a.W == 64 && TP == 64) return launch_tail_dma<1, 1, 4, 1, 64>(a, paired, s, Y);
+        if (a.W == 32 && TP == 128) return launch_tail_dma<1, 2, 4, 1, 32>(a, paired, s, Y);
+        if (a.W == 32 && TP == 64) return launch_tail_dma<1, 1, 4, 1, 32>(a, paired, s, Y);
+        if (a.W == 32 && TP == 32) return launch_tail_dma<1, 1, 2, 2, 32>(a, paired, s, Y);
+#define GH_TAIL_DMA(w)                                                                    \
+        if (a.W == w) {                                                                   \
+            if (TP == 128) return launch_tail_dma<1, 2, 4, 1, w>(a, paired, s, Y);        \
+            if (TP == 64) return launch_tail_dma<1, 1, 4, 1, w>(a, paired, s, Y);         \
+            if (TP == 32) return launch_tail_dma<1, 1, 2, 2, w>(a, paired, s, Y);         \
+            if (TP == 16) return launch_tail_dma<1, 1, 1, 4, w>(a, paired, s, Y);         \
         }
-        GH_TAIL_DMA(32) GH_TAIL_DMA(16) GH_TAIL_DMA(8)
+        GH_TAIL_DMA(16) GH_TAIL_DMA(8)
 #undef GH_TAIL_DMA
     }
     // compile-time geometry for the three level shapes of the 64x64 / L=3 model (BASELINE configs B/C)
