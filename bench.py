@@ -189,8 +189,11 @@ def main():
         }
         # ---- roofline of the dominant kernel: instrumented pass of the same step, HIP events per launch
         plan.timing(True)
-        for _ in range(3):
-            step()
+        for _ in range(3):   # rank-local pass: NO collective here (the other ranks are already past the timed loop)
+            if args.mode == "inverse":
+                glow.reverse_flow(z_top, None, eps_std=0.7)
+            else:
+                glow.normal_flow(x, None, repack=repack)
         recs = plan.timing_read()
         plan.timing(False)
         hid = hps.model.hidden_channels

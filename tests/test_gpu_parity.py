@@ -302,8 +302,9 @@ def test_full_size_properties_b64():
     glow.normal_flow(x, None, noise=noise)  # data-dependent init on the full batch
     glow.eval()
     z, nll, _ = glow.normal_flow(x, None, noise=noise)
-    z2, nll2, _ = glow.normal_flow(x, None, noise=noise)
-    assert torch.equal(z, z2) and torch.equal(nll, nll2), "not bitwise reproducible"
+    for rep in range(25):   # race screen for the LDS-DMA pipelines: a rare early read would show up as a differing run
+        z2, nll2, _ = glow.normal_flow(x, None, noise=noise, repack=(rep % 5 == 0))
+        assert torch.equal(z, z2) and torch.equal(nll, nll2), f"run {rep} not bitwise reproducible"
     assert torch.isfinite(z).all() and torch.isfinite(nll).all()
     for s in range(0, 64, 8):
         zs, ns, _ = glow.normal_flow(x[s:s + 8].contiguous(), None, noise=noise[s:s + 8].contiguous())
