@@ -33,7 +33,7 @@ BATCH_PER_GPU = 64
 
 
 def build_model(G, util, device, batch, seed=2384):
-    hps = util.load_profile(os.path.join(ROOT, "pytorch-glow_amd", "profile", "celeba.json"))
+    hps = util.load_profile("celeba")  # built-in profile, reference schema
     hps.optim.num_batch_train = batch
     hps.device.graph = ["cuda:0"]  # one process per GPU: one replica per process
     torch.manual_seed(seed)

@@ -8,7 +8,7 @@ Layout
   network/     FlowStep / FlowModel / Glow and the flow layers (reference surface)
   misc/        ops + util helpers with the reference's names
   parallel.py  one-process-per-GPU data parallelism over RCCL
-  profile/     celeba.json / test.json (reference schema)
+  profile/     built-in profiles 'celeba' / 'test' in the reference's JSON schema
 """
 from . import _lib  # noqa: F401
 from ._lib import GlowHipError, build, lib  # noqa: F401

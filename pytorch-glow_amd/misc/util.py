@@ -35,10 +35,14 @@ class AttrDict(dict):
 
 
 def load_profile(filepath):
-    """JSON profile -> attribute dict; None if the file does not exist (as the reference)."""
+    """JSON profile (reference schema) -> attribute dict; None if the file does not exist (as the reference).
+    Also accepts the name of a built-in profile: 'celeba' or 'test' (see pytorch-glow_amd/profile)."""
     if os.path.exists(filepath):
         with open(filepath) as f:
             return AttrDict(json.load(f))
+    if filepath in ("celeba", "test"):
+        from .. import profile
+        return AttrDict(profile.builtin(filepath))
     return None
 
 

@@ -12,16 +12,15 @@ from pytorch_glow_amd.misc import ops, util
 from oracle import glow_oracle as O
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PROFILES = os.path.join(ROOT, "pytorch-glow_amd", "profile")
 
 
 def test_profiles_load_with_reference_schema():
-    hps = util.load_profile(os.path.join(PROFILES, "celeba.json"))
+    hps = util.load_profile("celeba")
     assert hps.model.image_shape == [64, 64, 3] and hps.model.K == 32 and hps.model.L == 3
     assert hps.model.hidden_channels == 512 and hps.ablation.flow_coupling == "affine"
     assert hps.ablation.flow_permutation == "invconv" and hps.ablation.seed == 2384
     assert hps.optim.optimizer_args.betas == [0.9, 0.9999]
-    t = util.load_profile(os.path.join(PROFILES, "test.json"))
+    t = util.load_profile("test")
     assert t.ablation.flow_coupling == "additive" and t.optim.num_batch_train == 16
     assert util.load_profile("/nonexistent.json") is None
 
@@ -50,7 +49,7 @@ def test_ops_helpers():
 
 
 def test_state_dict_matches_reference_layout():
-    hps = util.load_profile(os.path.join(PROFILES, "celeba.json"))
+    hps = util.load_profile("celeba")
     glow = G.Glow(hps)
     sd = glow.state_dict()
     cfg = O.default_cfg(batch=glow.h_top.shape[0])
