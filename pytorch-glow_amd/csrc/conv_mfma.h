@@ -65,6 +65,8 @@ size_t conv_mfma_tail_packed_bytes(int Cin, int Cout);
 // paired=1: output channels come in (even, odd) = (shift|mean, scale|logs) pairs (affine coupling, Split2d)
 int conv_mfma_tail_pack(const float* w, int Cin, int Cout, int paired, float* wp, hipStream_t s);
 int launch_conv_mfma_tail(const TailConvArgs& a, hipStream_t s);
-void conv_mfma_tail_force_tile(int tp);  // testing hook: 0 = automatic, else 16/32/64/128 pixels per block
+void conv_mfma_tail_force_tile(int tp);
+int launch_tail_dma_narrow(const TailConvArgs& a, int paired, hipStream_t s, int TP, int Y);  // W in {8,16}
+int launch_tail_dma_wide(const TailConvArgs& a, int paired, hipStream_t s, int TP, int Y);    // W in {32,64,128}  // testing hook: 0 = automatic, else 16/32/64/128 pixels per block
 
 }  // namespace glowhip
