@@ -144,6 +144,8 @@ def main():
     if args.mode == "inverse":
         z_top = torch.randn(B, 48, 8, 8, device=device) * 0.7
 
+    torch.set_grad_enabled(False)   # forward+logdet metric: inference path (no activation tape)
+
     def step():
         if args.mode == "inverse":   # secondary metric: sampling (eps drawn on device, W^-1 from the in-kernel LU)
             plan.ensure_packed(repack)

@@ -173,6 +173,38 @@ int glowhip_plan_actnorm_init(glowhip_plan* plan, void* packed, size_t packed_by
 /* Output shape of the plan for a given direction (HOST). out[3] = {C,H,W}. */
 int glowhip_plan_output_shape(const glowhip_plan* plan, int reverse, int32_t out[3]);
 
+/* ------------------------------------------------------------------------------------------------
+ * Training step (reference network/trainer.py:123-140: forward, loss = mean(nll), backward)
+ * ---------------------------------------------------------------------------------------------- */
+/* Writable fp32 gradient tensors of one layer, same shapes as the parameters named in glowhip_layer_desc.
+ * Entries of parameters a layer does not have (and any gradient the caller does not want) are NULL. */
+typedef struct glowhip_layer_grads {
+    float* an_bias; float* an_logs; float* invconv_w;
+    float* f0_w; float* f0_an_bias; float* f0_an_logs;
+    float* f2_w; float* f2_an_bias; float* f2_an_logs;
+    float* f4_w; float* f4_bias; float* f4_logs;
+} glowhip_layer_grads;
+
+/* Bytes of the activation tape / of the training workspace for batch N. */
+size_t glowhip_plan_tape_bytes(const glowhip_plan* plan, int N);
+size_t glowhip_plan_train_workspace_bytes(const glowhip_plan* plan, int N);
+
+/* glowhip_glow_forward that also records the tape (every layer output + the coupling networks' hidden
+ * activations) needed by glowhip_glow_backward.  Same results as glowhip_glow_forward. */
+int glowhip_glow_forward_train(glowhip_plan* plan, const void* packed, const float* x, const float* noise,
+                               const float* prior_mean, const float* prior_logs, long prior_stride, int n_bits,
+                               float* z, float* nll_out, float* objective_out, int N, void* tape, size_t tape_bytes,
+                               void* workspace, size_t workspace_bytes, glowhip_stream_t stream);
+
+/* Gradients of a scalar loss L given nll_grad[n] = dL/dnll_n (1/B for Glow.generative_loss = mean(nll),
+ * network/model.py:496-506) and optionally z_grad = dL/dz (NULL = 0): every non-NULL entry of grads[layer] is
+ * OVERWRITTEN with dL/dparameter; grad_x (shape of x, may be NULL) receives dL/dx.  `x`, `tape`, `packed` and the
+ * prior arguments must be the ones of the matching glowhip_glow_forward_train call. */
+int glowhip_glow_backward(glowhip_plan* plan, const void* packed, const float* x, const void* tape, size_t tape_bytes,
+                          const float* nll_grad, const float* z_grad, const float* prior_mean,
+                          const float* prior_logs, long prior_stride, const glowhip_layer_grads* grads,
+                          float* grad_x, int N, void* workspace, size_t workspace_bytes, glowhip_stream_t stream);
+
 /* Per-launch timing for benchmarks (HIP events recorded on the execution stream around every kernel of
  * the coupling path).  enable=1 creates an event pool (host resource), enable=0 destroys it; while enabled
  * every encode/decode appends records.  glowhip_plan_timing_read synchronises with the recorded events,

@@ -42,6 +42,12 @@ class LayerDesc(ctypes.Structure):
     ]
 
 
+class LayerGrads(ctypes.Structure):
+    """Mirror of ``glowhip_layer_grads``."""
+    _fields_ = [(n, c_void_p) for n in ("an_bias", "an_logs", "invconv_w", "f0_w", "f0_an_bias", "f0_an_logs",
+                                        "f2_w", "f2_an_bias", "f2_an_logs", "f4_w", "f4_bias", "f4_logs")]
+
+
 class TimingRecord(ctypes.Structure):
     """Mirror of ``glowhip_timing_record``."""
     _fields_ = [("kind", c_int32), ("layer", c_int32), ("mfma", c_int32), ("ms", c_float)]
@@ -75,6 +81,12 @@ SIGNATURES = {
     "glowhip_plan_output_shape": (c_int, [_P, c_int, POINTER(c_int32)]),
     "glowhip_plan_describe": (c_int, [_P, c_char_p, c_size_t]),
     "glowhip_debug_force_tail_tile": (None, [c_int]),
+    "glowhip_plan_tape_bytes": (c_size_t, [_P, c_int]),
+    "glowhip_plan_train_workspace_bytes": (c_size_t, [_P, c_int]),
+    "glowhip_glow_forward_train": (c_int, [_P, _P, _P, _P, _P, _P, c_long, c_int, _P, _P, _P, c_int, _P, c_size_t, _P,
+                                           c_size_t, _P]),
+    "glowhip_glow_backward": (c_int, [_P, _P, _P, _P, c_size_t, _P, _P, _P, _P, c_long, POINTER(LayerGrads), _P, c_int,
+                                      _P, c_size_t, _P]),
     "glowhip_plan_timing_enable": (c_int, [_P, c_int]),
     "glowhip_plan_timing_read": (c_int, [_P, POINTER(TimingRecord), c_int, POINTER(c_int)]),
 }

@@ -191,6 +191,64 @@ class FlowPlan:
                                          stream_ptr(self.device)))
         return z, nll, obj
 
+    # ------------------------------------------------------------------ training step
+    def _grad_fields(self):
+        """[(layer index, LayerGrads field, parameter)] for every parameter the C backward produces a gradient for."""
+        out = []
+        for i, layer in enumerate(self.layers):
+            kind = layer.glowhip_kind
+            if kind == _lib.LAYER_FLOWSTEP:
+                out += [(i, "an_bias", layer.actnorm.bias), (i, "an_logs", layer.actnorm.logs)]
+                if layer.permutation == 'invconv':
+                    out.append((i, "invconv_w", layer.invconv.weight))
+                f0, f2, f4 = layer.f[0], layer.f[2], layer.f[4]
+                out += [(i, "f0_w", f0.weight), (i, "f0_an_bias", f0.actnorm.bias), (i, "f0_an_logs", f0.actnorm.logs),
+                        (i, "f2_w", f2.weight), (i, "f2_an_bias", f2.actnorm.bias), (i, "f2_an_logs", f2.actnorm.logs),
+                        (i, "f4_w", f4.weight), (i, "f4_bias", f4.bias), (i, "f4_logs", f4.logs)]
+            elif kind == _lib.LAYER_SPLIT2D:
+                cz = layer.conv2d_zeros
+                out += [(i, "f4_w", cz.weight), (i, "f4_bias", cz.bias), (i, "f4_logs", cz.logs)]
+        return out
+
+    def trainable_parameters(self):
+        return [p for _, _, p in self._grad_fields()]
+
+    def glow_forward_train(self, x, noise, prior_mean, prior_logs, prior_stride, n_bits):
+        """Forward that records the activation tape; returns (z, nll, tape)."""
+        n = x.shape[0]
+        self.ensure_packed(True)   # weights are expected to have just been updated
+        z = torch.empty((n,) + self.out_chw, dtype=torch.float32, device=self.device)
+        nll = torch.empty(n, dtype=torch.float32, device=self.device)
+        tape = torch.empty(int(lib().glowhip_plan_tape_bytes(self._h, n)), dtype=torch.uint8, device=self.device)
+        ws = self._train_workspace(n)
+        check(lib().glowhip_glow_forward_train(self._h, ptr(self.packed), ptr(x), ptr(noise), ptr(prior_mean),
+                                               ptr(prior_logs), prior_stride, n_bits, ptr(z), ptr(nll), None, n, ptr(tape),
+                                               tape.numel(), ptr(ws), ws.numel(), stream_ptr(self.device)))
+        return z, nll, tape
+
+    def _train_workspace(self, n):
+        need = int(lib().glowhip_plan_train_workspace_bytes(self._h, n))
+        ws = getattr(self, "_tws", None)
+        if ws is None or ws.numel() < need:
+            self._tws = None
+            self._tws = ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return ws
+
+    def glow_backward(self, x, tape, nll_grad, z_grad, prior_mean, prior_logs, prior_stride, want_grad_x=False):
+        """Parameter gradients (list aligned with trainable_parameters()) and optionally dL/dx."""
+        n = x.shape[0]
+        fields = self._grad_fields()
+        grads = [torch.empty_like(p) for _, _, p in fields]
+        arr = (_lib.LayerGrads * len(self.layers))()
+        for (i, name, _), gt in zip(fields, grads):
+            setattr(arr[i], name, gt.data_ptr())
+        gx = torch.empty_like(x) if want_grad_x else None
+        ws = self._train_workspace(n)
+        check(lib().glowhip_glow_backward(self._h, ptr(self.packed), ptr(x), ptr(tape), tape.numel(), ptr(nll_grad),
+                                          ptr(z_grad), ptr(prior_mean), ptr(prior_logs), prior_stride, arr, ptr(gx), n,
+                                          ptr(ws), ws.numel(), stream_ptr(self.device)))
+        return grads, gx
+
     def actnorm_init(self, x, noise, actnorm_scale: float) -> None:
         """Data-dependent init of every ActNorm in the plan from batch x (writes the parameters in place)."""
         n = x.shape[0]

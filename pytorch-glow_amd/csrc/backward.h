@@ -1,0 +1,56 @@
+// backward.h -- launcher interface of the gradient kernels (backward.hip) used by plan_train.hip.
+#pragma once
+#include "common.h"
+
+namespace glowhip {
+
+struct CouplingBwdArgs {
+    const float* hout;       // (N,Cout,HW) saved post-scale output of f.4
+    const float* z2out; long z_bs;   // second half of the step output (z2')
+    const float* g2; long g_bs;      // incoming gradient of z2'   (second half of g_out)
+    float* gy2;                      // outgoing gradient of y2 (same strides as g2; may alias g2)
+    float* gpre;             // (N,Cout,HW) gradient of (conv + bias) of f.4
+    const float* e4;         // (Cout) exp(3 logs)
+    const float* gld;        // (N) dL/dlogdet_n
+    double* acc_b; double* acc_l;    // (Cout) f.4 bias / logs gradient accumulators
+    int N, Ch, Cout, HW, affine;
+};
+int launch_coupling_bwd(const CouplingBwdArgs& a, hipStream_t s);
+
+struct SplitBwdArgs {
+    const float* hout;       // (N,2Ch,HW) saved prior conv output
+    const float* z2; long z_bs;      // the split-off half
+    float* gz2; long g_bs;           // its gradient (written)
+    float* gpre;             // (N,2Ch,HW)
+    const float* e4; const float* gld;
+    double* acc_b; double* acc_l;
+    int N, Ch, HW;
+};
+int launch_split_bwd(const SplitBwdArgs& a, hipStream_t s);
+
+int launch_act_bwd(float* g, const float* h, const float* e, int N, int Cm, int HW, double* acc_b, double* acc_l,
+                   hipStream_t s);
+
+struct ChanMixBwdArgs {
+    const float* x; long x_bs;       // step input
+    const float* gy; float* gx; long g_bs;   // gradient of y in, gradient of x out (may alias)
+    const float* bias; const float* scale;   // actnorm bias, exp(3 logs)
+    const float* matrix;             // W (C,C) or null
+    const int32_t* gather_inv;       // inverse permutation table or null
+    double* acc_w; double* acc_b; double* acc_l;
+    int N, C, HW;
+};
+int launch_chanmix_bwd(const ChanMixBwdArgs& a, hipStream_t s);
+
+int launch_prior_bwd(const float* z, const float* mean, const float* logs, long ml_bs, const float* gld,
+                     const float* gz_in, float* gz, int N, long per, hipStream_t s);
+int launch_weight_flipT(const float* w, float* wT, int Cout, int Cin, int ksize, hipStream_t s);
+int launch_wgrad_direct(const float* gy, const float* x, long x_bs, float* dw, int N, int Cin, int H, int W, int Cout,
+                        int ksize, hipStream_t s);
+int launch_grad_finalize(const double* acc, float* out, int n, const double* gsum, double add_mul, hipStream_t s);
+int launch_grad_finalize_w(const double* acc, float* out, int C, const double* gsum, double hw, const float* winv,
+                           hipStream_t s);
+int launch_sum_gld(const float* gld, int N, double* gsum, hipStream_t s);
+int launch_gld_from_nll(const float* nll_grad, float* gld, int N, double inv, hipStream_t s);
+
+}  // namespace glowhip

@@ -1,0 +1,396 @@
+// backward.hip -- gradient kernels of the flow path (training step).
+//
+// The training forward keeps every layer output and the coupling network's hidden activations on a tape in HBM
+// (11 GB at B=64 for the celeba64 model -- the 288 GB part is what makes this the cheap option; recomputing f()
+// would cost the whole forward again), so the backward is a straight reverse sweep without inverses.
+//
+// This file holds the HBM-bound pieces and the shape-generic (direct) convolution gradients:
+//   k_coupling_bwd   affine/additive coupling tail + Conv2dZeros scale/bias gradients
+//   k_split_bwd      Split2d Gaussian log-density gradients (+ Conv2dZeros scale/bias gradients)
+//   k_act_bwd        ReLU mask + ActNorm scale of a hidden layer, with the ActNorm parameter gradients
+//   k_chanmix_bwd    ActNorm + invertible 1x1 conv: input gradient, dW (incl. d log|det W|), d bias, d logs
+//   k_prior_bwd      top prior: dL/dz of the Gaussian log-density
+//   k_wgrad_direct   dW of a convolution, one workgroup per (out, in) channel pair (generic / cross-check)
+//   k_weight_flipT   w[o][i][tap] -> wT[i][o][8-tap]: the input gradient of a convolution is a convolution with wT
+// Parameter gradients that are reductions over all pixels are accumulated with fp64 atomics (order effects are
+// below fp32 resolution after the final rounding) and converted by k_grad_finalize.
+#include "kernels.h"
+#include "backward.h"
+
+namespace glowhip {
+
+__device__ __forceinline__ void atomic_add_f64(double* p, double v) { atomicAdd(p, v); }
+
+// ------------------------------------------------------------------------------------------------
+// Coupling tail backward (forward: network/model.py:105-113).  Grid (pixel blocks, Ch, N).
+//   affine : shift = hout[2c], r = hout[2c+1], s = sigmoid(r+2), z2' = (y2+shift)*s, logdet += sum log s
+//            g_y2 = g2*s;  g_shift = g2*s;  g_r = (g2*(y2+shift) + gld/s) * s*(1-s)
+//   add    : z2' = y2 + hout[c];  g_y2 = g2;  g_h = g2
+//   Conv2dZeros: hout = (conv + b)*e  =>  g_pre = g_h*e (gradient of conv output and of b), g_logs = 3*sum g_h*hout
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_coupling_bwd(CouplingBwdArgs a) {
+    __shared__ double red[4];
+    const int c = blockIdx.y;
+    const long n = blockIdx.z;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    const bool ok = p < a.HW;
+    const int nsub = a.affine ? 2 : 1;
+    double sb[2] = {0.0, 0.0}, sl[2] = {0.0, 0.0};
+    if (ok) {
+        const float g2 = a.g2[n * a.g_bs + (long)c * a.HW + p];
+        float gh[2];
+        int oc[2];
+        if (a.affine) {
+            oc[0] = 2 * c; oc[1] = 2 * c + 1;
+            const float shift = a.hout[(n * a.Cout + oc[0]) * a.HW + p];
+            const float r = a.hout[(n * a.Cout + oc[1]) * a.HW + p];
+            const float s = sigmoidf_(r + 2.0f);
+            const float z2p = a.z2out[n * a.z_bs + (long)c * a.HW + p];
+            const float y2s = z2p / s;                 // = y2 + shift
+            a.gy2[n * a.g_bs + (long)c * a.HW + p] = g2 * s;
+            gh[0] = g2 * s;
+            gh[1] = (g2 * y2s + a.gld[n] / s) * s * (1.0f - s);
+        } else {
+            oc[0] = c; oc[1] = c;
+            a.gy2[n * a.g_bs + (long)c * a.HW + p] = g2;
+            gh[0] = g2; gh[1] = 0.f;
+        }
+        for (int k = 0; k < nsub; ++k) {
+            const float e = a.e4[oc[k]];
+            const float gpre = gh[k] * e;
+            a.gpre[(n * a.Cout + oc[k]) * a.HW + p] = gpre;
+            sb[k] = (double)gpre;
+            sl[k] = (double)(gh[k] * a.hout[(n * a.Cout + oc[k]) * a.HW + p]) * 3.0;
+        }
+    }
+    for (int k = 0; k < nsub; ++k) {
+        const double tb = block_sum<256>(sb[k], red);
+        const double tl = block_sum<256>(sl[k], red);
+        if (threadIdx.x == 0) {
+            const int o = a.affine ? 2 * c + k : c;
+            atomic_add_f64(a.acc_b + o, tb);
+            atomic_add_f64(a.acc_l + o, tl);
+        }
+    }
+}
+
+int launch_coupling_bwd(const CouplingBwdArgs& a, hipStream_t s) {
+    if (a.N == 0) return GLOWHIP_OK;
+    hipLaunchKernelGGL(k_coupling_bwd, dim3(cdiv(a.HW, 256), a.Ch, a.N), dim3(256), 0, s, a);
+    GH_LAUNCH_CHECK("k_coupling_bwd");
+    return GLOWHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Split2d backward (forward: network/module.py:526-530): logdet += sum logp(z2 | mean, logs), (mean, logs) =
+// even/odd channels of hout = Conv2dZeros(z1).  With d = z2 - mean, q = exp(-2 logs):
+//   g_z2 = gld * (-d*q) (+ incoming gradient of z2 is zero: z2 is dropped),  g_mean = gld * d*q,
+//   g_logs = gld * (d*d*q - 1).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_split_bwd(SplitBwdArgs a) {
+    __shared__ double red[4];
+    const int c = blockIdx.y;
+    const long n = blockIdx.z;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    const bool ok = p < a.HW;
+    double sb[2] = {0.0, 0.0}, sl[2] = {0.0, 0.0};
+    if (ok) {
+        const int Cout = 2 * a.Ch;
+        const float mean = a.hout[(n * Cout + 2 * c) * a.HW + p];
+        const float logs = a.hout[(n * Cout + 2 * c + 1) * a.HW + p];
+        const float z2 = a.z2[n * a.z_bs + (long)c * a.HW + p];
+        const float d = z2 - mean, q = expf(-2.0f * logs);
+        const float gld = a.gld[n];
+        a.gz2[n * a.g_bs + (long)c * a.HW + p] = -gld * d * q;
+        const float gh[2] = {gld * d * q, gld * (d * d * q - 1.0f)};
+        for (int k = 0; k < 2; ++k) {
+            const int o = 2 * c + k;
+            const float gpre = gh[k] * a.e4[o];
+            a.gpre[(n * Cout + o) * a.HW + p] = gpre;
+            sb[k] = (double)gpre;
+            sl[k] = (double)(gh[k] * a.hout[(n * Cout + o) * a.HW + p]) * 3.0;
+        }
+    }
+    for (int k = 0; k < 2; ++k) {
+        const double tb = block_sum<256>(sb[k], red);
+        const double tl = block_sum<256>(sl[k], red);
+        if (threadIdx.x == 0) {
+            atomic_add_f64(a.acc_b + 2 * c + k, tb);
+            atomic_add_f64(a.acc_l + 2 * c + k, tl);
+        }
+    }
+}
+
+int launch_split_bwd(const SplitBwdArgs& a, hipStream_t s) {
+    if (a.N == 0) return GLOWHIP_OK;
+    hipLaunchKernelGGL(k_split_bwd, dim3(cdiv(a.HW, 256), a.Ch, a.N), dim3(256), 0, s, a);
+    GH_LAUNCH_CHECK("k_split_bwd");
+    return GLOWHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Hidden activation backward: h = relu((u + b)*e).  Given g_h (raw) and the saved h:
+//   g_u = g_h * (h > 0) * e;   g_b = sum g_u;   g_logs = 3 * sum g_h*h   (h = (u+b)*e wherever the mask is 1)
+// In place on g (g_h -> g_u).  Grid (pixel blocks, channels, N).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_act_bwd(float* __restrict__ g, const float* __restrict__ h,
+                                                 const float* __restrict__ e, int Cm, int HW,
+                                                 double* __restrict__ acc_b, double* __restrict__ acc_l) {
+    __shared__ double red[4];
+    const int c = blockIdx.y;
+    const long n = blockIdx.z;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    double sb = 0.0, sl = 0.0;
+    if (p < HW) {
+        const long idx = (n * Cm + c) * HW + p;
+        const float hv = h[idx], gh = g[idx];
+        const float gu = hv > 0.f ? gh * e[c] : 0.f;
+        g[idx] = gu;
+        sb = (double)gu;
+        sl = (double)(gh * hv) * 3.0;
+    }
+    const double tb = block_sum<256>(sb, red);
+    const double tl = block_sum<256>(sl, red);
+    if (threadIdx.x == 0) {
+        atomic_add_f64(acc_b + c, tb);
+        atomic_add_f64(acc_l + c, tl);
+    }
+}
+
+int launch_act_bwd(float* g, const float* h, const float* e, int N, int Cm, int HW, double* acc_b, double* acc_l,
+                   hipStream_t s) {
+    if (N == 0) return GLOWHIP_OK;
+    hipLaunchKernelGGL(k_act_bwd, dim3(cdiv(HW, 256), Cm, N), dim3(256), 0, s, g, h, e, Cm, HW, acc_b, acc_l);
+    GH_LAUNCH_CHECK("k_act_bwd");
+    return GLOWHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// ActNorm + invertible 1x1 conv / permutation backward.  Forward: v = (x + b)*e, y = W v (or y[o] = v[idx[o]]).
+//   g_v = W^T g_y (or scatter);  g_x = g_v * e;
+//   dW[o][i] = sum_px g_y[o] v[i]  (+ G*HW*W^-1[i][o] added by k_grad_finalize_w, G = sum_n gld[n])
+//   g_b[c] = sum g_v[c]*e[c];  g_logs[c] = 3*sum g_v[c]*v[c]  (+ 3*HW*G in finalize)
+// 64 pixels per workgroup; x->v, g_y and g_v live in LDS columns [c][px]; the C*C outer-product sums are formed
+// pair-by-pair over the 64 pixels and added with one fp64 atomic per pair per workgroup.
+// ------------------------------------------------------------------------------------------------
+constexpr int CB_PX = 64;
+__global__ void __launch_bounds__(256) k_chanmix_bwd(ChanMixBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int C = a.C;
+    float* v = sm;                   // [C][64]
+    float* gy = sm + C * CB_PX;      // [C][64]
+    float* gv = gy + C * CB_PX;      // [C][64]
+    const int px = threadIdx.x & (CB_PX - 1), grp = threadIdx.x >> 6;
+    const long gp = (long)blockIdx.x * CB_PX + px;
+    const long total = (long)a.N * a.HW;
+    const bool valid = gp < total;
+    const long n = valid ? gp / a.HW : 0;
+    const int p = valid ? (int)(gp - n * a.HW) : 0;
+    for (int c = grp; c < C; c += 4) {
+        float xv = 0.f, g = 0.f;
+        if (valid) {
+            xv = (a.x[n * a.x_bs + (long)c * a.HW + p] + a.bias[c]) * a.scale[c];
+            g = a.gy[n * a.g_bs + (long)c * a.HW + p];
+        }
+        v[c * CB_PX + px] = xv;
+        gy[c * CB_PX + px] = g;
+    }
+    __syncthreads();
+    // g_v = W^T g_y : g_v[i] = sum_o W[o][i] g_y[o]   (gather: g_v[idx[o]] = g_y[o])
+    for (int i = grp; i < C; i += 4) {
+        float r = 0.f;
+        if (a.matrix) {
+            for (int o = 0; o < C; ++o) r = fmaf(a.matrix[o * C + i], gy[o * CB_PX + px], r);
+        } else {
+            r = gy[(a.gather_inv ? a.gather_inv[i] : i) * CB_PX + px];
+        }
+        gv[i * CB_PX + px] = r;
+        if (valid) a.gx[n * a.g_bs + (long)i * a.HW + p] = r * a.scale[i];
+    }
+    __syncthreads();
+    // reductions over the 64 pixels of this workgroup
+    const int tid = threadIdx.x;
+    if (a.matrix) {
+        for (int pair = tid; pair < C * C; pair += 256) {
+            const int o = pair / C, i = pair - o * C;
+            float s = 0.f;
+#pragma unroll 8
+            for (int q = 0; q < CB_PX; ++q) s = fmaf(gy[o * CB_PX + q], v[i * CB_PX + q], s);
+            atomic_add_f64(a.acc_w + pair, (double)s);
+        }
+    }
+    for (int c = tid; c < C; c += 256) {
+        float sb = 0.f, sl = 0.f;
+        for (int q = 0; q < CB_PX; ++q) {
+            sb = fmaf(gv[c * CB_PX + q], a.scale[c], sb);
+            sl = fmaf(gv[c * CB_PX + q], v[c * CB_PX + q], sl);
+        }
+        atomic_add_f64(a.acc_b + c, (double)sb);
+        atomic_add_f64(a.acc_l + c, (double)sl * 3.0);
+    }
+}
+
+int launch_chanmix_bwd(const ChanMixBwdArgs& a, hipStream_t s) {
+    GH_REQUIRE(a.C > 0 && a.C <= 192, "chanmix backward: C=%d unsupported (1..192)", a.C);
+    const long total = (long)a.N * a.HW;
+    if (total == 0) return GLOWHIP_OK;
+    const size_t lds = (size_t)3 * a.C * CB_PX * sizeof(float);
+    if (lds > 32 * 1024)
+        (void)hipFuncSetAttribute((const void*)k_chanmix_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_chanmix_bwd, dim3(cdiv(total, CB_PX)), dim3(256), lds, s, a);
+    GH_LAUNCH_CHECK("k_chanmix_bwd");
+    return GLOWHIP_OK;
+}
+
+// top prior: logp = sum -0.5*(log 2pi + 2 logs + (z-mean)^2 e^{-2 logs});  g_z (+)= gld * -(z-mean) e^{-2 logs}
+__global__ void __launch_bounds__(256) k_prior_bwd(const float* __restrict__ z, const float* __restrict__ mean,
+                                                   const float* __restrict__ logs, long ml_bs,
+                                                   const float* __restrict__ gld, const float* __restrict__ gz_in,
+                                                   float* __restrict__ gz, long per) {
+    const long n = blockIdx.y;
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= per) return;
+    const float m = mean ? mean[n * ml_bs + e] : 0.f;
+    const float l = logs ? logs[n * ml_bs + e] : 0.f;
+    const float g = -gld[n] * (z[n * per + e] - m) * expf(-2.0f * l);
+    gz[n * per + e] = g + (gz_in ? gz_in[n * per + e] : 0.f);
+}
+
+int launch_prior_bwd(const float* z, const float* mean, const float* logs, long ml_bs, const float* gld,
+                     const float* gz_in, float* gz, int N, long per, hipStream_t s) {
+    if (N == 0 || per == 0) return GLOWHIP_OK;
+    hipLaunchKernelGGL(k_prior_bwd, dim3(cdiv(per, 256), N), dim3(256), 0, s, z, mean, logs, ml_bs, gld, gz_in, gz, per);
+    GH_LAUNCH_CHECK("k_prior_bwd");
+    return GLOWHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Generic convolution gradients.
+// ------------------------------------------------------------------------------------------------
+// wT[i][o][t'] = w[o][i][KK-1-t']  (k x k, 'SAME', stride 1: the input gradient is conv(g_y, wT))
+__global__ void __launch_bounds__(256) k_weight_flipT(const float* __restrict__ w, float* __restrict__ wT, int Cout,
+                                                      int Cin, int KK) {
+    const long total = (long)Cout * Cin * KK;
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const int t = (int)(e % KK);
+    const long r = e / KK;
+    const int o = (int)(r % Cout), i = (int)(r / Cout);
+    wT[e] = w[((long)o * Cin + i) * KK + (KK - 1 - t)];
+}
+
+int launch_weight_flipT(const float* w, float* wT, int Cout, int Cin, int ksize, hipStream_t s) {
+    const long total = (long)Cout * Cin * ksize * ksize;
+    hipLaunchKernelGGL(k_weight_flipT, dim3(cdiv(total, 256)), dim3(256), 0, s, w, wT, Cout, Cin, ksize * ksize);
+    GH_LAUNCH_CHECK("k_weight_flipT");
+    return GLOWHIP_OK;
+}
+
+// dW[o][i][ky][kx] = sum_{n,y,x} gy[n,o,y,x] * x[n,i,y+ky-1,x+kx-1].  One workgroup per (o, i).
+template <int KS>
+__global__ void __launch_bounds__(256) k_wgrad_direct(const float* __restrict__ gy, const float* __restrict__ x,
+                                                      long x_bs, float* __restrict__ dw, int N, int Cin, int H, int W,
+                                                      int Cout) {
+    __shared__ double red[4];
+    const int i = blockIdx.x, o = blockIdx.y;
+    const int HW = H * W;
+    constexpr int KK = KS * KS;
+    double acc[KK];
+#pragma unroll
+    for (int t = 0; t < KK; ++t) acc[t] = 0.0;
+    const long count = (long)N * HW;
+    for (long e = threadIdx.x; e < count; e += 256) {
+        const long n = e / HW;
+        const int p = (int)(e - n * HW);
+        const int py = p / W, px = p - py * W;
+        const float g = gy[(n * Cout + o) * HW + p];
+        const float* xc = x + n * x_bs + (long)i * HW;
+#pragma unroll
+        for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < KS; ++kx) {
+                const int yy = py + ky - KS / 2, xx = px + kx - KS / 2;
+                if (yy >= 0 && yy < H && xx >= 0 && xx < W) acc[ky * KS + kx] += (double)(g * xc[yy * W + xx]);
+            }
+    }
+#pragma unroll
+    for (int t = 0; t < KK; ++t) {
+        const double tot = block_sum<256>(acc[t], red);
+        if (threadIdx.x == 0) dw[((long)o * Cin + i) * KK + t] = (float)tot;
+    }
+}
+
+int launch_wgrad_direct(const float* gy, const float* x, long x_bs, float* dw, int N, int Cin, int H, int W, int Cout,
+                        int ksize, hipStream_t s) {
+    GH_REQUIRE(ksize == 1 || ksize == 3, "wgrad: kernel size %d unsupported", ksize);
+    if (ksize == 3) hipLaunchKernelGGL(k_wgrad_direct<3>, dim3(Cin, Cout), dim3(256), 0, s, gy, x, x_bs, dw, N, Cin, H, W, Cout);
+    else hipLaunchKernelGGL(k_wgrad_direct<1>, dim3(Cin, Cout), dim3(256), 0, s, gy, x, x_bs, dw, N, Cin, H, W, Cout);
+    GH_LAUNCH_CHECK("k_wgrad_direct");
+    return GLOWHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// fp64 accumulators -> fp32 gradient tensors.
+//   out[i] = acc[i] * mul + add_const               (plain)
+//   invconv: dW[o][i] = acc[o*C+i] + G*HW*Winv[i*C+o]
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_grad_finalize(const double* __restrict__ acc, float* __restrict__ out, int n,
+                                                       const double* __restrict__ gsum, double add_mul) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    out[i] = (float)(acc[i] + (gsum ? gsum[0] * add_mul : 0.0));
+}
+
+__global__ void __launch_bounds__(256) k_grad_finalize_w(const double* __restrict__ acc, float* __restrict__ out, int C,
+                                                         const double* __restrict__ gsum, double hw,
+                                                         const float* __restrict__ winv) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= C * C) return;
+    const int o = e / C, i = e - o * C;
+    out[e] = (float)(acc[e] + gsum[0] * hw * (double)winv[i * C + o]);
+}
+
+// gsum[0] = sum_n gld[n]  (one small workgroup, fixed order)
+__global__ void __launch_bounds__(64) k_sum_gld(const float* __restrict__ gld, int N, double* __restrict__ gsum) {
+    double a = 0.0;
+    for (int i = threadIdx.x; i < N; i += 64) a += (double)gld[i];
+    a = wave_sum(a);
+    if (threadIdx.x == 0) gsum[0] = a;
+}
+
+int launch_grad_finalize(const double* acc, float* out, int n, const double* gsum, double add_mul, hipStream_t s) {
+    if (n == 0 || out == nullptr) return GLOWHIP_OK;
+    hipLaunchKernelGGL(k_grad_finalize, dim3(cdiv(n, 256)), dim3(256), 0, s, acc, out, n, gsum, add_mul);
+    GH_LAUNCH_CHECK("k_grad_finalize");
+    return GLOWHIP_OK;
+}
+
+int launch_grad_finalize_w(const double* acc, float* out, int C, const double* gsum, double hw, const float* winv,
+                           hipStream_t s) {
+    if (out == nullptr) return GLOWHIP_OK;
+    hipLaunchKernelGGL(k_grad_finalize_w, dim3(cdiv(C * C, 256)), dim3(256), 0, s, acc, out, C, gsum, hw, winv);
+    GH_LAUNCH_CHECK("k_grad_finalize_w");
+    return GLOWHIP_OK;
+}
+
+int launch_sum_gld(const float* gld, int N, double* gsum, hipStream_t s) {
+    hipLaunchKernelGGL(k_sum_gld, dim3(1), dim3(64), 0, s, gld, N, gsum);
+    GH_LAUNCH_CHECK("k_sum_gld");
+    return GLOWHIP_OK;
+}
+
+// gld[n] = -nll_grad[n] / (ln2 * CHW)   (nll = -objective / (ln2*CHW), network/model.py:448-450)
+__global__ void __launch_bounds__(256) k_gld_from_nll(const float* __restrict__ nll_grad, float* __restrict__ gld, int N,
+                                                      double inv) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < N) gld[i] = (float)(-(double)nll_grad[i] * inv);
+}
+
+int launch_gld_from_nll(const float* nll_grad, float* gld, int N, double inv, hipStream_t s) {
+    if (N == 0) return GLOWHIP_OK;
+    hipLaunchKernelGGL(k_gld_from_nll, dim3(cdiv(N, 256)), dim3(256), 0, s, nll_grad, gld, N, inv);
+    GH_LAUNCH_CHECK("k_gld_from_nll");
+    return GLOWHIP_OK;
+}
+
+}  // namespace glowhip

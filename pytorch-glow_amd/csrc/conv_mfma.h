@@ -43,6 +43,7 @@ struct TailConvArgs {
     float* z2_out; long z2_out_bs;
     unsigned long long* acc;
     const float* zeros;          // >= 16 B of zeros in global memory (16-byte aligned), or null: no LDS-DMA kernels
+    float* hout;                 // optional (training tape): (N,Cout,HW) <- (conv + bias) * scale
 };
 constexpr int TAIL_CK = 32;  // input channels per LDS chunk of the tail kernel
 // number of 16-row MFMA tiles on the out-channel axis

@@ -41,6 +41,11 @@ __device__ __forceinline__ double tail_epilogue(const TailConvArgs& a, const f32
             float hv[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) hv[r] = (acc[m][nt][r] + hb[r]) * hs[r];
+            if (a.hout) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (oc[r] >= 0) a.hout[(n * a.Cout + oc[r]) * HW + p] = hv[r];
+            }
             if (paired) {
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {

@@ -9,54 +9,9 @@
 #include <string>
 #include <vector>
 
-#include "kernels.h"
-#include "conv_mfma.h"
+#include "plan_internal.h"
 
 namespace glowhip {
-
-struct LayerPlan {
-    glowhip_layer_desc d;
-    int Cout = 0;  // output channels of f.4 / of the Split2d prior conv
-    // byte offsets into the packed buffer
-    size_t an_scale = 0, an_inv_scale = 0, winv = 0, logabsdet = 0, konst = 0, lu_scratch = 0;
-    size_t f0_scale = 0, f2_scale = 0, f4_scale = 0;
-    size_t f0_wt = 0, f2_wt = 0, f4_wp = 0;
-    bool mfma_first = false, mfma_mid = false, mfma_last = false;
-    bool first_halo = false;  // f.0 on k_conv_first (stationary pixel window) instead of k_conv_wide<3>
-};
-
-}  // namespace glowhip
-
-using namespace glowhip;
-
-struct TimingSlot { int kind, layer, mfma; hipEvent_t a, b; };
-
-struct glowhip_plan {
-    std::vector<LayerPlan> layers;
-    bool timing = false;
-    std::vector<hipEvent_t> ev_pool;     // unused events
-    std::vector<TimingSlot> ev_used;     // recorded, not yet read
-    int cur_layer = 0;
-    // batched pack: host copies of the job tables + their byte offsets inside `packed`
-    std::vector<StepPrepJob> prep_jobs;
-    std::vector<ScaleJob> scale_jobs;
-    std::vector<RepackJob> repack_jobs;
-    size_t prep_off = 0, scale_off = 0, repack_off = 0;
-    int max_lds_c = 0;
-    size_t packed_bytes = 0;
-    int in_shape[3] = {0, 0, 0}, out_shape[3] = {0, 0, 0};
-    long max_chw = 0;      // max over layer inputs/outputs of C*H*W
-    long max_hidden = 0;   // max over steps of max(hidden, Cout) * H*W
-    int n_split = 0;
-};
-
-namespace glowhip {
-
-static size_t take(size_t& off, size_t bytes) {
-    size_t o = align_up(off, 256);
-    off = o + bytes;
-    return o;
-}
 
 // ---------------------------------------------------------------- optional per-launch timing
 struct ScopedTimer {
@@ -85,11 +40,6 @@ static int pack_scales(const float* logs, int n, float* scale, float* inv, hipSt
     hipLaunchKernelGGL(k_pack_scales, dim3(cdiv(n, 256)), dim3(256), 0, s, logs, n, scale, inv);
     GH_LAUNCH_CHECK("k_pack_scales");
     return GLOWHIP_OK;
-}
-
-template <typename T>
-static T* at(const void* base, size_t off) {
-    return (T*)((char*)base + off);
 }
 
 // Workspace carving

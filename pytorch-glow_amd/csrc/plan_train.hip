@@ -1,0 +1,358 @@
+// plan_train.hip -- training step of a flow plan: forward that records a TAPE, and the reverse
+// sweep that turns dL/dnll into parameter gradients.
+//
+// Tape (one contiguous caller-provided buffer): the output of every layer, and per FlowStep the coupling network's
+// hidden activations h1, h2 (N,hidden,H,W) and its post-scale output hout (N,Cout,H,W); per Split2d the prior
+// conv output.  With 288 GB of HBM keeping them (11.6 GB at B=64 for the celeba64 model) is cheaper than the
+// reversible-recompute alternative (a second forward through the MFMA-bound coupling nets).
+//
+// Backward of one FlowStep (reference forward: network/model.py:82-117), all gradients "g_": see backward.hip for the
+// element-wise formulas.  Convolution input gradients are convolutions with flipped/transposed weights and reuse the
+// forward kernels; weight gradients use k_wgrad_direct for now (correctness first -- the MFMA wgrad is the next
+// step of this row).
+#include "plan_internal.h"
+#include "backward.h"
+
+using namespace glowhip;
+
+namespace glowhip {
+
+struct TapeLayer { size_t out = 0, h1 = 0, h2 = 0, hout = 0; };
+
+static size_t tape_layout(const glowhip_plan* p, int N, std::vector<TapeLayer>* tl) {
+    size_t off = 0;
+    if (tl) tl->resize(p->layers.size());
+    for (size_t i = 0; i < p->layers.size(); ++i) {
+        const LayerPlan& L = p->layers[i];
+        const glowhip_layer_desc& d = L.d;
+        TapeLayer t;
+        const size_t hw = (size_t)d.H * d.W;
+        if (d.kind == GLOWHIP_LAYER_SQUEEZE) {
+            t.out = take(off, (size_t)N * d.C * hw * 4);
+        } else if (d.kind == GLOWHIP_LAYER_FLOWSTEP) {
+            t.out = take(off, (size_t)N * d.C * hw * 4);
+            t.h1 = take(off, (size_t)N * d.hidden * hw * 4);
+            t.h2 = take(off, (size_t)N * d.hidden * hw * 4);
+            t.hout = take(off, (size_t)N * L.Cout * hw * 4);
+        } else {
+            t.out = take(off, (size_t)N * (d.C / 2) * hw * 4);
+            t.hout = take(off, (size_t)N * d.C * hw * 4);
+        }
+        if (tl) (*tl)[i] = t;
+    }
+    return align_up(off, 256);
+}
+
+// backward workspace: acc u64 (N) | gld (N) | gsum | gA | gB | gh1 | gh2 | gpre | wT | fp64 accumulators
+struct TrainWs {
+    unsigned long long* acc; float* gld; double* gsum;
+    float* gA; float* gB; float* gh1; float* gh2; float* gpre; float* wT; double* dacc;
+    size_t dacc_doubles;
+};
+
+static size_t max_weight_floats(const glowhip_plan* p) {
+    size_t m = 0;
+    for (const LayerPlan& L : p->layers) {
+        const glowhip_layer_desc& d = L.d;
+        if (d.kind == GLOWHIP_LAYER_FLOWSTEP) {
+            m = std::max(m, (size_t)d.hidden * (d.C / 2) * 9);
+            m = std::max(m, (size_t)d.hidden * d.hidden);
+            m = std::max(m, (size_t)L.Cout * d.hidden * 9);
+        } else if (d.kind == GLOWHIP_LAYER_SPLIT2D) {
+            m = std::max(m, (size_t)d.C * (d.C / 2) * 9);
+        }
+    }
+    return m;
+}
+
+static size_t max_acc_doubles(const glowhip_plan* p) {
+    size_t m = 0;
+    for (const LayerPlan& L : p->layers) {
+        const glowhip_layer_desc& d = L.d;
+        if (d.kind == GLOWHIP_LAYER_FLOWSTEP) m = std::max(m, (size_t)d.C * d.C + 2 * d.C + 4 * d.hidden + 2 * L.Cout);
+        else if (d.kind == GLOWHIP_LAYER_SPLIT2D) m = std::max(m, (size_t)2 * L.Cout);
+    }
+    return m + 64;
+}
+
+static size_t train_ws_layout(const glowhip_plan* p, int N, void* base, TrainWs* w) {
+    size_t off = 0;
+    const size_t o_acc = take(off, (size_t)N * 8), o_gld = take(off, (size_t)N * 4), o_gsum = take(off, 64);
+    const size_t o_gA = take(off, (size_t)N * p->max_chw * 4), o_gB = take(off, (size_t)N * p->max_chw * 4);
+    const size_t o_h1 = take(off, (size_t)N * p->max_hidden * 4), o_h2 = take(off, (size_t)N * p->max_hidden * 4);
+    const size_t o_gpre = take(off, (size_t)N * p->max_chw * 4);
+    const size_t o_wT = take(off, max_weight_floats(p) * 4);
+    const size_t nd = max_acc_doubles(p);
+    const size_t o_dacc = take(off, nd * 8);
+    if (w && base) {
+        w->acc = at<unsigned long long>(base, o_acc); w->gld = at<float>(base, o_gld); w->gsum = at<double>(base, o_gsum);
+        w->gA = at<float>(base, o_gA); w->gB = at<float>(base, o_gB); w->gh1 = at<float>(base, o_h1);
+        w->gh2 = at<float>(base, o_h2); w->gpre = at<float>(base, o_gpre); w->wT = at<float>(base, o_wT);
+        w->dacc = at<double>(base, o_dacc); w->dacc_doubles = nd;
+    }
+    return align_up(off, 256);
+}
+
+// ---------------------------------------------------------------- forward with tape
+static int forward_train(glowhip_plan* p, const void* packed, const float* x, const float* noise, float* z_out, int N,
+                         char* tape, const std::vector<TapeLayer>& tl, unsigned long long* acc, hipStream_t s) {
+    const float* cur = x;
+    const int nl = (int)p->layers.size();
+    for (int li = 0; li < nl; ++li) {
+        const LayerPlan& L = p->layers[li];
+        const glowhip_layer_desc& d = L.d;
+        p->cur_layer = li;
+        float* dst = at<float>(tape, tl[li].out);
+        const int HW = d.H * d.W, Ch = d.C / 2, hid = d.hidden;
+        const long chw = (long)d.C * HW;
+        if (d.kind == GLOWHIP_LAYER_SQUEEZE) {
+            GH_TRY(launch_squeeze(cur, noise, dst, N, d.C, d.H, d.W, 2, 0, s));
+            noise = nullptr;
+        } else if (d.kind == GLOWHIP_LAYER_FLOWSTEP) {
+            GH_REQUIRE(noise == nullptr, "forward_train: the dequantisation noise needs a leading Squeeze2d layer");
+            float* h1 = at<float>(tape, tl[li].h1);
+            float* h2 = at<float>(tape, tl[li].h2);
+            float* hout = at<float>(tape, tl[li].hout);
+            ChanMixArgs m{};
+            m.in_a = cur; m.in_a_bs = chw; m.in_b = cur + (long)Ch * HW; m.in_b_bs = chw; m.Ca = Ch;
+            m.out = dst; m.out_bs = chw; m.bias = d.an_bias; m.scale = at<float>(packed, L.an_scale);
+            m.matrix = d.permutation == GLOWHIP_PERM_INVCONV ? d.invconv_w : nullptr;
+            m.gather = d.permutation == GLOWHIP_PERM_GATHER ? d.perm_idx : nullptr;
+            m.reverse = 0; m.N = N; m.C = d.C; m.HW = HW;
+            GH_TRY(launch_chanmix(m, s));
+            // f.0
+            if (L.first_halo) {
+                const float* wf = at<float>(packed, L.f0_wt);
+                GH_TRY(launch_conv_mfma_first(dst, chw, wf, wf + (size_t)9 * Ch * hid, h1, N, Ch, d.H, d.W, hid, s));
+            } else if (L.mfma_first) {
+                GH_TRY(launch_conv_mfma_wide(dst, chw, at<float>(packed, L.f0_wt), d.f0_an_bias,
+                                             at<float>(packed, L.f0_scale), h1, N, Ch, d.H, d.W, hid, 3, s));
+            } else {
+                ConvArgs c{dst, chw, d.f0_w, nullptr, d.f0_an_bias, nullptr, at<float>(packed, L.f0_scale), 1, h1,
+                           N, Ch, d.H, d.W, hid, 3};
+                GH_TRY(launch_conv_direct(c, s));
+            }
+            // f.2
+            if (L.mfma_mid) {
+                GH_TRY(launch_conv_mfma_wide(h1, (long)hid * HW, at<float>(packed, L.f2_wt), d.f2_an_bias,
+                                             at<float>(packed, L.f2_scale), h2, N, hid, d.H, d.W, hid, 1, s));
+            } else {
+                ConvArgs c{h1, (long)hid * HW, d.f2_w, nullptr, d.f2_an_bias, nullptr, at<float>(packed, L.f2_scale), 1, h2,
+                           N, hid, d.H, d.W, hid, 1};
+                GH_TRY(launch_conv_direct(c, s));
+            }
+            // f.4 + coupling, hout kept
+            float* z2 = dst + (long)Ch * HW;
+            const int affine = d.coupling == GLOWHIP_COUPLING_AFFINE;
+            if (L.mfma_last) {
+                TailConvArgs t{};
+                t.x = h2; t.x_bs = (long)hid * HW; t.wp = at<float>(packed, L.f4_wp); t.bias = d.f4_bias;
+                t.scale = at<float>(packed, L.f4_scale); t.N = N; t.Cin = hid; t.H = d.H; t.W = d.W; t.Cout = L.Cout;
+                t.mode = affine ? TAIL_AFFINE_FWD : TAIL_ADD_FWD;
+                t.z2_in = z2; t.z2_in_bs = chw; t.z2_out = z2; t.z2_out_bs = chw; t.acc = acc;
+                t.zeros = at<float>(packed, 64); t.hout = hout;
+                GH_TRY(launch_conv_mfma_tail(t, s));
+            } else {
+                ConvArgs c{h2, (long)hid * HW, d.f4_w, d.f4_bias, nullptr, nullptr, at<float>(packed, L.f4_scale), 0, hout,
+                           N, hid, d.H, d.W, L.Cout, 3};
+                GH_TRY(launch_conv_direct(c, s));
+                CouplingTailArgs t{hout, z2, chw, z2, chw, N, Ch, HW, affine, 0, acc};
+                GH_TRY(launch_coupling_tail(t, s));
+            }
+        } else {  // SPLIT2D
+            float* hout = at<float>(tape, tl[li].hout);
+            if (L.mfma_last) {
+                TailConvArgs t{};
+                t.x = cur; t.x_bs = chw; t.wp = at<float>(packed, L.f4_wp); t.bias = d.f4_bias;
+                t.scale = at<float>(packed, L.f4_scale); t.N = N; t.Cin = Ch; t.H = d.H; t.W = d.W; t.Cout = L.Cout;
+                t.mode = TAIL_SPLIT_FWD; t.z2_in = cur + (long)Ch * HW; t.z2_in_bs = chw; t.z2_out = nullptr;
+                t.z2_out_bs = 0; t.acc = acc; t.zeros = at<float>(packed, 64); t.hout = hout;
+                GH_TRY(launch_conv_mfma_tail(t, s));
+            } else {
+                ConvArgs c{cur, chw, d.f4_w, d.f4_bias, nullptr, nullptr, at<float>(packed, L.f4_scale), 0, hout,
+                           N, Ch, d.H, d.W, L.Cout, 3};
+                GH_TRY(launch_conv_direct(c, s));
+                SplitTailArgs t{hout, cur + (long)Ch * HW, chw, nullptr, nullptr, 0, N, Ch, HW, 0, acc};
+                GH_TRY(launch_split_tail(t, s));
+            }
+            GH_TRY(launch_copy_strided(cur, chw, dst, (long)Ch * HW, N, (long)Ch * HW, s));
+        }
+        cur = dst;
+    }
+    const int* o = p->out_shape;
+    if (z_out)
+        GH_TRY(launch_copy_strided(cur, (long)o[0] * o[1] * o[2], z_out, (long)o[0] * o[1] * o[2], N,
+                                   (long)o[0] * o[1] * o[2], s));
+    return GLOWHIP_OK;
+}
+
+// input gradient of a 'SAME' convolution y = conv(x, w): g_x (+)= conv(g_y, flipT(w)); generic path
+static int dgrad_direct(const float* gy, const float* w, float* wT, float* gx, int N, int Cin, int H, int W, int Cout,
+                        int ksize, hipStream_t s) {
+    GH_TRY(launch_weight_flipT(w, wT, Cout, Cin, ksize, s));
+    ConvArgs c{gy, (long)Cout * H * W, wT, nullptr, nullptr, nullptr, nullptr, 0, gx, N, Cout, H, W, Cin, ksize};
+    return launch_conv_direct(c, s);
+}
+
+__global__ void __launch_bounds__(256) k_add_inplace(float* __restrict__ dst, long dst_bs, const float* __restrict__ src,
+                                                     long src_bs, long per) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long n = blockIdx.y;
+    if (i < per) dst[n * dst_bs + i] += src[n * src_bs + i];
+}
+
+static int zero_f64(double* p, size_t n, hipStream_t s) {
+    if (hipMemsetAsync(p, 0, n * sizeof(double), s) != hipSuccess) {
+        set_error("backward: hipMemsetAsync failed");
+        return GLOWHIP_ELAUNCH;
+    }
+    return GLOWHIP_OK;
+}
+
+// ---------------------------------------------------------------- backward sweep
+static int backward_sweep(glowhip_plan* p, const void* packed, const float* x_in, const char* tape,
+                          const std::vector<TapeLayer>& tl, const glowhip_layer_grads* grads, float* grad_x, int N,
+                          TrainWs& w, float* g_top, hipStream_t s) {
+    // g: gradient w.r.t. the current layer's OUTPUT (contiguous (N, C_out, H, W)), held in gA/gB
+    float* g = g_top;
+    const int nl = (int)p->layers.size();
+    for (int li = nl - 1; li >= 0; --li) {
+        const LayerPlan& L = p->layers[li];
+        const glowhip_layer_desc& d = L.d;
+        const glowhip_layer_grads& G = grads[li];
+        const float* xin = li > 0 ? at<float>(tape, tl[li - 1].out) : x_in;   // this layer's input
+        float* gnext = (g == w.gA) ? w.gB : w.gA;
+        const int HW = d.H * d.W, Ch = d.C / 2, hid = d.hidden;
+        const long chw = (long)d.C * HW;
+        if (d.kind == GLOWHIP_LAYER_SQUEEZE) {
+            if (li == 0 && grad_x == nullptr) break;      // nobody wants dL/dx
+            float* dst = li == 0 ? grad_x : gnext;
+            GH_TRY(launch_squeeze(g, nullptr, dst, N, d.C * 4, d.H / 2, d.W / 2, 2, 1, s));
+            g = dst;
+        } else if (d.kind == GLOWHIP_LAYER_FLOWSTEP) {
+            const float* out = at<float>(tape, tl[li].out);
+            const float* h1 = at<float>(tape, tl[li].h1);
+            const float* h2 = at<float>(tape, tl[li].h2);
+            const float* hout = at<float>(tape, tl[li].hout);
+            const int affine = d.coupling == GLOWHIP_COUPLING_AFFINE;
+            // accumulators: [W C*C][an_b C][an_l C][f0_b hid][f0_l hid][f2_b hid][f2_l hid][f4_b Cout][f4_l Cout]
+            double* aW = w.dacc; double* aAb = aW + (size_t)d.C * d.C; double* aAl = aAb + d.C;
+            double* a0b = aAl + d.C; double* a0l = a0b + hid; double* a2b = a0l + hid; double* a2l = a2b + hid;
+            double* a4b = a2l + hid; double* a4l = a4b + L.Cout;
+            GH_TRY(zero_f64(w.dacc, (size_t)d.C * d.C + 2 * d.C + 4 * hid + 2 * L.Cout, s));
+            // (a) coupling tail: g (second half) becomes g_y2 in place; gpre = gradient of f.4's (conv + bias)
+            CouplingBwdArgs cb{hout, out + (long)Ch * HW, chw, g + (long)Ch * HW, chw, g + (long)Ch * HW, w.gpre,
+                               at<float>(packed, L.f4_scale), w.gld, a4b, a4l, N, Ch, L.Cout, HW, affine};
+            GH_TRY(launch_coupling_bwd(cb, s));
+            // (b) f.4: weight gradient, then input gradient -> g_h2 (raw), then ReLU/ActNorm of f.2
+            GH_TRY(launch_wgrad_direct(w.gpre, h2, (long)hid * HW, G.f4_w, N, hid, d.H, d.W, L.Cout, 3, s));
+            GH_TRY(dgrad_direct(w.gpre, d.f4_w, w.wT, w.gh2, N, hid, d.H, d.W, L.Cout, 3, s));
+            GH_TRY(launch_act_bwd(w.gh2, h2, at<float>(packed, L.f2_scale), N, hid, HW, a2b, a2l, s));
+            // (c) f.2 (1x1)
+            GH_TRY(launch_wgrad_direct(w.gh2, h1, (long)hid * HW, G.f2_w, N, hid, d.H, d.W, hid, 1, s));
+            GH_TRY(dgrad_direct(w.gh2, d.f2_w, w.wT, w.gh1, N, hid, d.H, d.W, hid, 1, s));
+            GH_TRY(launch_act_bwd(w.gh1, h1, at<float>(packed, L.f0_scale), N, hid, HW, a0b, a0l, s));
+            // (d) f.0: input is y1 = first half of the step output
+            GH_TRY(launch_wgrad_direct(w.gh1, out, chw, G.f0_w, N, Ch, d.H, d.W, hid, 3, s));
+            GH_TRY(dgrad_direct(w.gh1, d.f0_w, w.wT, w.gpre, N, Ch, d.H, d.W, hid, 3, s));   // gpre reused: (N,Ch,HW)
+            hipLaunchKernelGGL(k_add_inplace, dim3(cdiv((long)Ch * HW, 256), N), dim3(256), 0, s, g, chw, w.gpre,
+                               (long)Ch * HW, (long)Ch * HW);
+            GH_LAUNCH_CHECK("k_add_inplace");
+            // (e) ActNorm + invconv / permutation: g (= g_y) -> g_x in place
+            ChanMixBwdArgs mb{xin, chw, g, g, chw, d.an_bias, at<float>(packed, L.an_scale),
+                              d.permutation == GLOWHIP_PERM_INVCONV ? d.invconv_w : nullptr,
+                              d.permutation == GLOWHIP_PERM_GATHER ? d.perm_idx_inv : nullptr, aW, aAb, aAl, N, d.C, HW};
+            GH_TRY(launch_chanmix_bwd(mb, s));
+            // (f) fp64 accumulators -> fp32 gradients (+ the log-det terms that do not depend on the data)
+            if (d.permutation == GLOWHIP_PERM_INVCONV)
+                GH_TRY(launch_grad_finalize_w(aW, G.invconv_w, d.C, w.gsum, (double)HW, at<float>(packed, L.winv), s));
+            GH_TRY(launch_grad_finalize(aAb, G.an_bias, d.C, nullptr, 0.0, s));
+            GH_TRY(launch_grad_finalize(aAl, G.an_logs, d.C, w.gsum, 3.0 * HW, s));
+            GH_TRY(launch_grad_finalize(a0b, G.f0_an_bias, hid, nullptr, 0.0, s));
+            GH_TRY(launch_grad_finalize(a0l, G.f0_an_logs, hid, nullptr, 0.0, s));
+            GH_TRY(launch_grad_finalize(a2b, G.f2_an_bias, hid, nullptr, 0.0, s));
+            GH_TRY(launch_grad_finalize(a2l, G.f2_an_logs, hid, nullptr, 0.0, s));
+            GH_TRY(launch_grad_finalize(a4b, G.f4_bias, L.Cout, nullptr, 0.0, s));
+            GH_TRY(launch_grad_finalize(a4l, G.f4_logs, L.Cout, nullptr, 0.0, s));
+        } else {  // SPLIT2D: output z1 (N,Ch,HW); input x = (z1, z2)
+            const float* hout = at<float>(tape, tl[li].hout);
+            double* a4b = w.dacc; double* a4l = a4b + L.Cout;
+            GH_TRY(zero_f64(w.dacc, (size_t)2 * L.Cout, s));
+            // g_x first half <- g (gradient of z1), second half <- gradient of the log-density
+            GH_TRY(launch_copy_strided(g, (long)Ch * HW, gnext, chw, N, (long)Ch * HW, s));
+            SplitBwdArgs sb{hout, xin + (long)Ch * HW, chw, gnext + (long)Ch * HW, chw, w.gpre,
+                            at<float>(packed, L.f4_scale), w.gld, a4b, a4l, N, Ch, HW};
+            GH_TRY(launch_split_bwd(sb, s));
+            GH_TRY(launch_wgrad_direct(w.gpre, xin, chw, G.f4_w, N, Ch, d.H, d.W, L.Cout, 3, s));
+            GH_TRY(dgrad_direct(w.gpre, d.f4_w, w.wT, w.gh1, N, Ch, d.H, d.W, L.Cout, 3, s));     // (N,Ch,HW)
+            hipLaunchKernelGGL(k_add_inplace, dim3(cdiv((long)Ch * HW, 256), N), dim3(256), 0, s, gnext, chw, w.gh1,
+                               (long)Ch * HW, (long)Ch * HW);
+            GH_LAUNCH_CHECK("k_add_inplace");
+            GH_TRY(launch_grad_finalize(a4b, G.f4_bias, L.Cout, nullptr, 0.0, s));
+            GH_TRY(launch_grad_finalize(a4l, G.f4_logs, L.Cout, nullptr, 0.0, s));
+            g = gnext;
+        }
+    }
+    return GLOWHIP_OK;
+}
+
+}  // namespace glowhip
+
+// ================================================================================================ C ABI
+extern "C" {
+
+size_t glowhip_plan_tape_bytes(const glowhip_plan* plan, int N) {
+    return (plan && N >= 0) ? tape_layout(plan, N, nullptr) : 0;
+}
+
+size_t glowhip_plan_train_workspace_bytes(const glowhip_plan* plan, int N) {
+    return (plan && N >= 0) ? train_ws_layout(plan, N, nullptr, nullptr) : 0;
+}
+
+int glowhip_glow_forward_train(glowhip_plan* plan, const void* packed, const float* x, const float* noise,
+                               const float* prior_mean, const float* prior_logs, long prior_stride, int n_bits,
+                               float* z, float* nll_out, float* objective_out, int N, void* tape, size_t tape_bytes,
+                               void* workspace, size_t workspace_bytes, glowhip_stream_t stream) {
+    GH_REQUIRE(plan && packed && x && z && nll_out && tape && workspace, "glow_forward_train: null argument");
+    GH_REQUIRE(N > 0 && N <= 65535, "glow_forward_train: batch size %d out of range", N);
+    std::vector<TapeLayer> tl;
+    GH_REQUIRE(tape_bytes >= tape_layout(plan, N, &tl), "glow_forward_train: tape too small");
+    TrainWs w;
+    GH_REQUIRE(workspace_bytes >= train_ws_layout(plan, N, workspace, &w), "glow_forward_train: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    GH_TRY(launch_zero_acc(w.acc, N, s));
+    GH_TRY(forward_train(plan, packed, x, noise, z, N, (char*)tape, tl, w.acc, s));
+    const int* o = plan->out_shape;
+    GH_TRY(launch_gaussian_logp(z, (long)o[0] * o[1] * o[2], prior_mean, prior_logs, prior_stride, N, o[0], o[1] * o[2],
+                                w.acc, s));
+    const double chw = (double)plan->in_shape[0] * plan->in_shape[1] * plan->in_shape[2];
+    const double offset = -log(pow(2.0, n_bits)) * chw;
+    const double scale = -1.0 / (log(2.0) * chw);
+    return launch_finalize(nullptr, w.acc, at<double>(packed, 0), 1.0, offset, scale, nll_out, objective_out, N, s);
+}
+
+int glowhip_glow_backward(glowhip_plan* plan, const void* packed, const float* x, const void* tape, size_t tape_bytes,
+                          const float* nll_grad, const float* z_grad, const float* prior_mean, const float* prior_logs,
+                          long prior_stride, const glowhip_layer_grads* grads, float* grad_x, int N, void* workspace,
+                          size_t workspace_bytes, glowhip_stream_t stream) {
+    GH_REQUIRE(plan && packed && x && tape && nll_grad && grads && workspace, "glow_backward: null argument");
+    GH_REQUIRE(N > 0 && N <= 65535, "glow_backward: batch size %d out of range", N);
+    std::vector<TapeLayer> tl;
+    GH_REQUIRE(tape_bytes >= tape_layout(plan, N, &tl), "glow_backward: tape too small");
+    TrainWs w;
+    GH_REQUIRE(workspace_bytes >= train_ws_layout(plan, N, workspace, &w), "glow_backward: workspace too small");
+    for (const LayerPlan& L : plan->layers)
+        GH_REQUIRE(L.d.kind != GLOWHIP_LAYER_FLOWSTEP || L.d.C <= 192, "glow_backward: C=%d not supported yet", L.d.C);
+    hipStream_t s = (hipStream_t)stream;
+    const double chw = (double)plan->in_shape[0] * plan->in_shape[1] * plan->in_shape[2];
+    GH_TRY(launch_gld_from_nll(nll_grad, w.gld, N, 1.0 / (log(2.0) * chw), s));
+    GH_TRY(launch_sum_gld(w.gld, N, w.gsum, s));
+    // top: dL/dz = z_grad + gld * d logp/dz
+    const int* o = plan->out_shape;
+    const long per = (long)o[0] * o[1] * o[2];
+    const float* zt = at<float>(tape, tl.back().out);
+    GH_TRY(launch_prior_bwd(zt, prior_mean, prior_logs, prior_stride, w.gld, z_grad, w.gA, N, per, s));
+    return backward_sweep(plan, packed, x, (const char*)tape, tl, grads, grad_x, N, w, w.gA, s);
+}
+
+}  // extern "C"

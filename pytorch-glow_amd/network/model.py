@@ -186,6 +186,28 @@ class FlowModel(nn.Module):
         return _deepcopy_without_plans(self, memo)
 
 
+class _GlowTrainFn(torch.autograd.Function):
+    """Glow.normal_flow as one autograd node: forward records the HIP activation tape, backward runs the HIP reverse
+    sweep (glowhip_glow_backward) and hands the parameter gradients to autograd."""
+
+    @staticmethod
+    def forward(ctx, plan, x, noise, n_bits, *params):
+        z, nll, tape = plan.glow_forward_train(x, noise, None, None, 0, n_bits)
+        ctx.plan, ctx.tape, ctx.x_in = plan, tape, x
+        ctx.want_gx = x.requires_grad
+        return z, nll
+
+    @staticmethod
+    def backward(ctx, gz, gnll):
+        plan = ctx.plan
+        n = ctx.x_in.shape[0]
+        gnll = torch.zeros(n, device=ctx.x_in.device) if gnll is None else gnll.contiguous().float()
+        gz = None if gz is None else gz.contiguous().float()
+        grads, gx = plan.glow_backward(ctx.x_in, ctx.tape, gnll, gz, None, None, 0, want_grad_x=ctx.want_gx)
+        ctx.tape = None
+        return (None, gx, None, None) + tuple(grads)
+
+
 class Glow(nn.Module):
     """Glow (reference network/model.py:317-550): dequantisation noise, flow encode, top prior, nll in bits/dim."""
 
@@ -244,6 +266,13 @@ class Glow(nn.Module):
             assert mean.shape[0] == x.shape[0], "batch must equal h_top's batch when learn_top is on"
             stride = mean.stride(0)
             assert mean[0].is_contiguous() and logs[0].is_contiguous() and logs.stride(0) == stride
+        params = plan.trainable_parameters()
+        if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+            # training step: one autograd node over the whole flow (HIP forward with tape + HIP backward)
+            if mean is not None:
+                raise NotImplementedError("learn_top with gradients is not on the HIP training path yet")
+            z, nll = _GlowTrainFn.apply(plan, x, noise, n_bits, *params)
+            return z, nll, None
         z, nll, _ = plan.glow_forward(x, noise, mean, logs, stride, n_bits, repack=repack)
         return z, nll, None
 

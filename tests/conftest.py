@@ -60,6 +60,13 @@ def sub(d, prefix):
     return {k[len(prefix):]: v for k, v in d.items() if k.startswith(prefix)}
 
 
+@pytest.fixture(autouse=True)
+def _inference_mode_by_default():
+    """Parity tests exercise the inference path; gradient tests switch autograd on explicitly."""
+    with torch.no_grad():
+        yield
+
+
 @pytest.fixture(scope="session")
 def golden():
     cache = {}
