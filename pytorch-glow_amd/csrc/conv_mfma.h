@@ -9,8 +9,9 @@ namespace glowhip {
 bool conv_mfma_wide_supported(int Cin, int H, int W, int Cout, int ksize);
 size_t conv_mfma_wide_packed_bytes(int Cin, int Cout, int ksize);
 int conv_mfma_wide_pack(const float* w, int Cin, int Cout, int ksize, float* wt, hipStream_t s);
+// post_bias / post_scale may be NULL (0 / 1) and relu = 0 for a plain GEMM (input-gradient use) -- 1x1 LDS-DMA path only
 int launch_conv_mfma_wide(const float* x, long x_bs, const float* wt, const float* post_bias, const float* post_scale,
-                          float* y, int N, int Cin, int H, int W, int Cout, int ksize, hipStream_t s);
+                          float* y, int N, int Cin, int H, int W, int Cout, int ksize, hipStream_t s, int relu = 1);
 
 void conv_mfma_wide_disable_glds(int off);  // testing hook: 1 = use the register-staged k_conv_wide for 1x1 too
 
@@ -19,7 +20,7 @@ bool conv_mfma_first_supported(int Cin, int H, int W, int Cout);
 size_t conv_mfma_first_packed_bytes(int Cin, int Cout);
 // wf: packed image (weights * exp(3 logs), then bias * exp(3 logs)) produced by the REPACK_FIRST job
 int launch_conv_mfma_first(const float* x, long x_bs, const float* wf, const float* bias_scaled, float* y, int N,
-                           int Cin, int H, int W, int Cout, hipStream_t s);
+                           int Cin, int H, int W, int Cout, hipStream_t s, int relu = 1);
 
 // "Tail" convolution: 3x3, few output channels (f.4 / Split2d prior), with the coupling / prior
 // arithmetic and the per-sample log-det reduction fused into the epilogue.

@@ -36,7 +36,7 @@ template <int KS, int BM, int BN, int BK>
 __global__ void __launch_bounds__(256)
 k_conv_wide(const float* __restrict__ X, long x_bs, const float* __restrict__ Wt, const float* __restrict__ bias,
             const float* __restrict__ scale, float* __restrict__ Y, int N, int Cin, int H, int W, int M, int K,
-            int Kpad) {
+            int Kpad, int relu) {
     constexpr int WM = BM / 2, WN = BN / 2;      // per-wave tile
     constexpr int TM = WM / 32, TN = WN / 32;    // 32x32 MFMA tiles per wave
     constexpr int A_F4 = BM / 4, B_F4 = BN / 4;  // float4 per tile row
@@ -173,9 +173,12 @@ k_conv_wide(const float* __restrict__ X, long x_bs, const float* __restrict__ Wt
         for (int r = 0; r < 16; ++r) {
             const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl;
             const int o = tile_m * BM + wr * WM + row;
-            const float bo = bias[o], so = scale[o];
+            const float bo = bias ? bias[o] : 0.f, so = scale ? scale[o] : 1.f;
 #pragma unroll
-            for (int j = 0; j < TN; ++j) stage[row * WN + j * 32 + ml] = fmaxf((acc[i][j][r] + bo) * so, 0.f);
+            for (int j = 0; j < TN; ++j) {
+                const float v = (acc[i][j][r] + bo) * so;
+                stage[row * WN + j * 32 + ml] = relu ? fmaxf(v, 0.f) : v;
+            }
         }
     }
     // each wave reads back only what it wrote: no workgroup barrier needed, the LDS ops of one wave are ordered
@@ -209,7 +212,7 @@ constexpr int GL_BK = 16, GL_ST = 4, GL_BM = 128, GL_BN = 128;
 
 __global__ void __launch_bounds__(256)
 k_gemm_glds(const float* __restrict__ X, long x_bs, const float* __restrict__ Wt, const float* __restrict__ bias,
-            const float* __restrict__ scale, float* __restrict__ Y, int N, int K, int HW, int M) {
+            const float* __restrict__ scale, float* __restrict__ Y, int N, int K, int HW, int M, int relu) {
     constexpr int BM = GL_BM, BN = GL_BN, BK = GL_BK;
     constexpr int WM = 64, WN = 64, TM = 2, TN = 2;
     constexpr int STAGE = BK * BM + BK * BN;   // floats per stage (16 KiB)
@@ -322,7 +325,7 @@ k_gemm_glds(const float* __restrict__ X, long x_bs, const float* __restrict__ Wt
     }
     __syncthreads();   // all waves done with the operand ring before it is reused as the output staging area
 
-    // ---- epilogue (as k_conv_wide): ActNorm + ReLU, transpose through LDS, 16-byte stores
+    // ---- epilogue (as k_conv_wide): ActNorm + ReLU (all optional), transpose through LDS, 16-byte stores
     float* stage = smem + wid * (WM * WN);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -330,9 +333,12 @@ k_gemm_glds(const float* __restrict__ X, long x_bs, const float* __restrict__ Wt
         for (int r = 0; r < 16; ++r) {
             const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl;
             const int o = tile_m * BM + wr * WM + row;
-            const float bo = bias[o], so = scale[o];
+            const float bo = bias ? bias[o] : 0.f, so = scale ? scale[o] : 1.f;
 #pragma unroll
-            for (int j = 0; j < TN; ++j) stage[row * WN + j * 32 + ml] = fmaxf((acc[i][j][r] + bo) * so, 0.f);
+            for (int j = 0; j < TN; ++j) {
+                const float v = (acc[i][j][r] + bo) * so;
+                stage[row * WN + j * 32 + ml] = relu ? fmaxf(v, 0.f) : v;
+            }
         }
     }
     constexpr int F4_PER_ROW = WN / 4, ROWS_PER_IT = 64 / F4_PER_ROW;
@@ -394,18 +400,18 @@ int conv_mfma_wide_pack(const float* w, int Cin, int Cout, int ksize, float* wt,
 
 template <int KS, int BMN>
 static int launch_wide_cfg(const float* x, long x_bs, const float* wt, const float* bias, const float* scale, float* y,
-                           int N, int Cin, int H, int W, int Cout, hipStream_t s) {
+                           int N, int Cin, int H, int W, int Cout, hipStream_t s, int relu) {
     const long total_px = (long)N * H * W;
     const int tiles = (Cout / BMN) * (int)((total_px + BMN - 1) / BMN);
     const int K = Cin * KS * KS;
     hipLaunchKernelGGL((k_conv_wide<KS, BMN, BMN, 32>), dim3(tiles), dim3(256), 0, s, x, x_bs, wt, bias, scale, y, N,
-                       Cin, H, W, Cout, K, wide_kpad(Cin, KS));
+                       Cin, H, W, Cout, K, wide_kpad(Cin, KS), relu);
     GH_LAUNCH_CHECK("k_conv_wide");
     return GLOWHIP_OK;
 }
 
 int launch_conv_mfma_wide(const float* x, long x_bs, const float* wt, const float* post_bias, const float* post_scale,
-                          float* y, int N, int Cin, int H, int W, int Cout, int ksize, hipStream_t s) {
+                          float* y, int N, int Cin, int H, int W, int Cout, int ksize, hipStream_t s, int relu) {
     GH_REQUIRE(conv_mfma_wide_supported(Cin, H, W, Cout, ksize), "conv_mfma_wide: unsupported shape");
     if (N == 0) return GLOWHIP_OK;
     const int t = pick_wide_tile(Cout, (long)N * H * W);
@@ -417,16 +423,16 @@ int launch_conv_mfma_wide(const float* x, long x_bs, const float* wt, const floa
         const size_t lds = (size_t)GL_ST * (GL_BK * GL_BM + GL_BK * GL_BN) * sizeof(float) + GLOWHIP_EXP_LDSPAD;
         (void)hipFuncSetAttribute((const void*)k_gemm_glds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(k_gemm_glds, dim3((unsigned)((Cout / GL_BM) * (total_px / GL_BN))), dim3(256), lds, s, x, x_bs, wt,
-                           post_bias, post_scale, y, N, Cin, H * W, Cout);
+                           post_bias, post_scale, y, N, Cin, H * W, Cout, relu);
         GH_LAUNCH_CHECK("k_gemm_glds");
         return GLOWHIP_OK;
     }
     if (ksize == 1) {
-        if (t == 128) return launch_wide_cfg<1, 128>(x, x_bs, wt, post_bias, post_scale, y, N, Cin, H, W, Cout, s);
-        return launch_wide_cfg<1, 64>(x, x_bs, wt, post_bias, post_scale, y, N, Cin, H, W, Cout, s);
+        if (t == 128) return launch_wide_cfg<1, 128>(x, x_bs, wt, post_bias, post_scale, y, N, Cin, H, W, Cout, s, relu);
+        return launch_wide_cfg<1, 64>(x, x_bs, wt, post_bias, post_scale, y, N, Cin, H, W, Cout, s, relu);
     }
-    if (t == 128) return launch_wide_cfg<3, 128>(x, x_bs, wt, post_bias, post_scale, y, N, Cin, H, W, Cout, s);
-    return launch_wide_cfg<3, 64>(x, x_bs, wt, post_bias, post_scale, y, N, Cin, H, W, Cout, s);
+    if (t == 128) return launch_wide_cfg<3, 128>(x, x_bs, wt, post_bias, post_scale, y, N, Cin, H, W, Cout, s, relu);
+    return launch_wide_cfg<3, 64>(x, x_bs, wt, post_bias, post_scale, y, N, Cin, H, W, Cout, s, relu);
 }
 
 // ================================================================================================

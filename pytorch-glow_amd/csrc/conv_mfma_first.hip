@@ -48,7 +48,7 @@ size_t conv_mfma_first_packed_bytes(int Cin, int Cout) { return ((size_t)9 * Cin
 template <int BN, int WF>
 __global__ void __launch_bounds__(256)
 k_conv_first(const float* __restrict__ X, long x_bs, const float* __restrict__ Wf, const float* __restrict__ bs,
-             float* __restrict__ Y, int N, int Cin, int H, int W, int M, FirstGeom gr) {
+             float* __restrict__ Y, int N, int Cin, int H, int W, int M, FirstGeom gr, int relu) {
     constexpr int BM = FIRST_BM, BK = FIRST_BK;
     constexpr int RS = WF + 8, TR = BN / WF, W4 = WF / 4, CHS = first_chs(BN / WF, WF);
     struct { int RS, CHS, TR, W4, MB; } g = {RS, CHS, TR, W4, gr.MB};
@@ -174,7 +174,7 @@ k_conv_first(const float* __restrict__ X, long x_bs, const float* __restrict__ W
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int o = mt * BM + wr * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl;
-                        yn[(long)o * HW] = fmaxf(acc[i][j][r], 0.f);
+                        yn[(long)o * HW] = relu ? fmaxf(acc[i][j][r], 0.f) : acc[i][j][r];
                     }
                 }
             }
@@ -183,7 +183,8 @@ k_conv_first(const float* __restrict__ X, long x_bs, const float* __restrict__ W
     }
 }
 
-int launch_conv_mfma_first(const float* x, long x_bs, const float* wf_, const float* bias_scaled, float* y, int N, int Cin, int H, int W, int Cout, hipStream_t s) {
+int launch_conv_mfma_first(const float* x, long x_bs, const float* wf_, const float* bias_scaled, float* y, int N,
+                           int Cin, int H, int W, int Cout, hipStream_t s, int relu) {
     GH_REQUIRE(conv_mfma_first_supported(Cin, H, W, Cout), "conv_mfma_first: unsupported shape");
     if (N == 0) return GLOWHIP_OK;
     const int HW = H * W;
@@ -206,7 +207,7 @@ int launch_conv_mfma_first(const float* x, long x_bs, const float* wf_, const fl
         (void)hipFuncSetAttribute((const void*)k_conv_first<bn, wf>, hipFuncAttributeMaxDynamicSharedMemorySize,    \
                                   (int)lds);                                                                         \
         hipLaunchKernelGGL((k_conv_first<bn, wf>), dim3(grid), dim3(256), lds, s, x, x_bs, wf_, bias_scaled, y, N,   \
-                           Cin, H, W, Cout, g);                                                                      \
+                           Cin, H, W, Cout, g, relu);                                                                \
         GH_LAUNCH_CHECK("k_conv_first");                                                                             \
         return GLOWHIP_OK;                                                                                           \
     }

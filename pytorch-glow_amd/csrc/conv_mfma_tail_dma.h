@@ -32,8 +32,8 @@ __device__ __forceinline__ double tail_epilogue(const TailConvArgs& a, const f32
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             oc[r] = tail_row_channel(mrow + r, a.Cout, paired);
-            hb[r] = oc[r] >= 0 ? a.bias[oc[r]] : 0.f;
-            hs[r] = oc[r] >= 0 ? a.scale[oc[r]] : 0.f;
+            hb[r] = (oc[r] >= 0 && a.bias) ? a.bias[oc[r]] : 0.f;
+            hs[r] = oc[r] >= 0 ? (a.scale ? a.scale[oc[r]] : 1.f) : 0.f;
         }
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) {

@@ -76,7 +76,9 @@ struct RepackJob {
     const float* w; size_t out_off; int kind;
     int Cin, Cout, K, Kpad;      // wide: K = Cin*k*k
     int paired, MT; long total;  // tail
-    const float* fold_bias; const float* fold_logs;  // first: ActNorm folded into the image
+    const float* fold_bias; const float* fold_logs;  // first: ActNorm folded into the image (NULL: plain weights)
+    int transposed;              // source is the FORWARD weight (Cin,Cout,3,3) of which this is the input-gradient conv:
+                                 // element (o, ci, tap) = w[ci][o][8 - tap]
 };
 int launch_pack_batched(const ScaleJob* sj_dev, int n_scale, const RepackJob* rj_dev, int n_repack, void* packed,
                         hipStream_t s);

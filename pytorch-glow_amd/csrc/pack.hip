@@ -36,10 +36,12 @@ __global__ void __launch_bounds__(256) k_repack_batched(const RepackJob* __restr
             const int k = (int)(e / j.Cout);
             const int chunk = k / 54, r = k - chunk * 54;
             const int tap = r / 6, cl = r - tap * 6;
-            out[e] = j.w[((long)o * j.Cin + chunk * 6 + cl) * 9 + tap] * expf(j.fold_logs[o] * LOGSCALE);
+            const int ci = chunk * 6 + cl;
+            const float wv = j.transposed ? j.w[((long)ci * j.Cout + o) * 9 + (8 - tap)] : j.w[((long)o * j.Cin + ci) * 9 + tap];
+            out[e] = j.fold_logs ? wv * expf(j.fold_logs[o] * LOGSCALE) : wv;
         }
         for (long o = (long)blockIdx.x * 256 + threadIdx.x; o < j.Cout; o += (long)gridDim.x * 256)
-            out[total + o] = j.fold_bias[o] * expf(j.fold_logs[o] * LOGSCALE);
+            out[total + o] = j.fold_logs ? j.fold_bias[o] * expf(j.fold_logs[o] * LOGSCALE) : 0.f;
     } else {
         for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < j.total; e += (long)gridDim.x * 256) {
             const int i = (int)(e & 15), kq = (int)((e >> 4) & 3);
@@ -50,7 +52,9 @@ __global__ void __launch_bounds__(256) k_repack_batched(const RepackJob* __restr
             const int chunk = (int)(t / (TAIL_CK / 4));
             const int ci = chunk * TAIL_CK + c4 * 4 + kq;
             const int o = tail_row_channel(mt * 16 + i, j.Cout, j.paired);
-            out[e] = (o >= 0 && ci < j.Cin) ? j.w[((long)o * j.Cin + ci) * 9 + tap] : 0.f;
+            out[e] = (o >= 0 && ci < j.Cin)
+                         ? (j.transposed ? j.w[((long)ci * j.Cout + o) * 9 + (8 - tap)] : j.w[((long)o * j.Cin + ci) * 9 + tap])
+                         : 0.f;
         }
     }
 }

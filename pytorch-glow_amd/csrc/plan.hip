@@ -316,6 +316,10 @@ glowhip_plan* glowhip_plan_create(const glowhip_layer_desc* layers, int n_layers
             else if (L.mfma_first) L.f0_wt = take(off, conv_mfma_wide_packed_bytes(C / 2, d.hidden, 3));
             if (L.mfma_mid) L.f2_wt = take(off, conv_mfma_wide_packed_bytes(d.hidden, d.hidden, 1));
             if (L.mfma_last) L.f4_wp = take(off, conv_mfma_tail_packed_bytes(d.hidden, L.Cout));
+            L.dg4_first = conv_mfma_first_supported(L.Cout, H, W, d.hidden);
+            if (L.dg4_first) L.f4T_wf = take(off, conv_mfma_first_packed_bytes(L.Cout, d.hidden));
+            L.dg0_tail = conv_mfma_tail_supported(d.hidden, H, W, C / 2);
+            if (L.dg0_tail) L.f0T_wp = take(off, conv_mfma_tail_packed_bytes(d.hidden, C / 2));
             p->max_hidden = std::max(p->max_hidden, (long)std::max(d.hidden, L.Cout) * H * W);
         } else if (d.kind == GLOWHIP_LAYER_SPLIT2D) {
             if (C % 2) return fail("Split2d needs an even channel count");
@@ -363,6 +367,15 @@ glowhip_plan* glowhip_plan_create(const glowhip_layer_desc* layers, int n_layers
             if (L.mfma_last) {
                 RepackJob r{}; r.w = d.f4_w; r.out_off = L.f4_wp; r.kind = REPACK_TAIL; r.Cin = d.hidden; r.Cout = L.Cout;
                 r.paired = d.coupling == GLOWHIP_COUPLING_AFFINE; r.MT = tail_mt(L.Cout, r.paired);
+                r.total = (long)tail_chunks(r.Cin) * (TAIL_CK / 4) * 9 * r.MT * 64; p->repack_jobs.push_back(r);
+            }
+            if (L.dg4_first) {   // input gradient of f.4 = 3x3 conv Cout -> hidden with w[ci][o][8-tap]
+                RepackJob r{}; r.w = d.f4_w; r.out_off = L.f4T_wf; r.kind = REPACK_FIRST; r.Cin = L.Cout; r.Cout = d.hidden;
+                r.transposed = 1; p->repack_jobs.push_back(r);
+            }
+            if (L.dg0_tail) {    // input gradient of f.0 = 3x3 conv hidden -> C/2
+                RepackJob r{}; r.w = d.f0_w; r.out_off = L.f0T_wp; r.kind = REPACK_TAIL; r.Cin = d.hidden; r.Cout = d.C / 2;
+                r.paired = 0; r.MT = tail_mt(r.Cout, 0); r.transposed = 1;
                 r.total = (long)tail_chunks(r.Cin) * (TAIL_CK / 4) * 9 * r.MT * 64; p->repack_jobs.push_back(r);
             }
         } else if (d.kind == GLOWHIP_LAYER_SPLIT2D) {

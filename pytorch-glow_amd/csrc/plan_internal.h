@@ -17,6 +17,9 @@ struct LayerPlan {
     size_t f0_scale = 0, f2_scale = 0, f4_scale = 0;
     size_t f0_wt = 0, f2_wt = 0, f4_wp = 0;
     bool mfma_first = false, mfma_mid = false, mfma_last = false;
+    // training: input-gradient convolutions run on the forward kernels with flipped/transposed weight images
+    size_t f4T_wf = 0, f0T_wp = 0;
+    bool dg4_first = false, dg0_tail = false;
     bool first_halo = false;  // f.0 on k_conv_first (stationary pixel window) instead of k_conv_wide<3>
 };
 

@@ -246,18 +246,38 @@ static int backward_sweep(glowhip_plan* p, const void* packed, const float* x_in
             GH_TRY(launch_coupling_bwd(cb, s));
             // (b) f.4: weight gradient, then input gradient -> g_h2 (raw), then ReLU/ActNorm of f.2
             GH_TRY(launch_wgrad_direct(w.gpre, h2, (long)hid * HW, G.f4_w, N, hid, d.H, d.W, L.Cout, 3, s));
-            GH_TRY(dgrad_direct(w.gpre, d.f4_w, w.wT, w.gh2, N, hid, d.H, d.W, L.Cout, 3, s));
+            if (L.dg4_first) {
+                const float* wf = at<float>(packed, L.f4T_wf);
+                GH_TRY(launch_conv_mfma_first(w.gpre, (long)L.Cout * HW, wf, wf + (size_t)9 * L.Cout * hid, w.gh2, N, L.Cout,
+                                              d.H, d.W, hid, s, 0));
+            } else {
+                GH_TRY(dgrad_direct(w.gpre, d.f4_w, w.wT, w.gh2, N, hid, d.H, d.W, L.Cout, 3, s));
+            }
             GH_TRY(launch_act_bwd(w.gh2, h2, at<float>(packed, L.f2_scale), N, hid, HW, a2b, a2l, s));
             // (c) f.2 (1x1)
             GH_TRY(launch_wgrad_direct(w.gh2, h1, (long)hid * HW, G.f2_w, N, hid, d.H, d.W, hid, 1, s));
-            GH_TRY(dgrad_direct(w.gh2, d.f2_w, w.wT, w.gh1, N, hid, d.H, d.W, hid, 1, s));
+            if (L.mfma_mid) {   // W2 in its reference layout [o][i] is already the K-major image of the transposed GEMM
+                GH_TRY(launch_conv_mfma_wide(w.gh2, (long)hid * HW, d.f2_w, nullptr, nullptr, w.gh1, N, hid, d.H, d.W, hid, 1,
+                                             s, 0));
+            } else {
+                GH_TRY(dgrad_direct(w.gh2, d.f2_w, w.wT, w.gh1, N, hid, d.H, d.W, hid, 1, s));
+            }
             GH_TRY(launch_act_bwd(w.gh1, h1, at<float>(packed, L.f0_scale), N, hid, HW, a0b, a0l, s));
             // (d) f.0: input is y1 = first half of the step output
             GH_TRY(launch_wgrad_direct(w.gh1, out, chw, G.f0_w, N, Ch, d.H, d.W, hid, 3, s));
-            GH_TRY(dgrad_direct(w.gh1, d.f0_w, w.wT, w.gpre, N, Ch, d.H, d.W, hid, 3, s));   // gpre reused: (N,Ch,HW)
-            hipLaunchKernelGGL(k_add_inplace, dim3(cdiv((long)Ch * HW, 256), N), dim3(256), 0, s, g, chw, w.gpre,
-                               (long)Ch * HW, (long)Ch * HW);
-            GH_LAUNCH_CHECK("k_add_inplace");
+            if (L.dg0_tail) {   // g_y1 += conv(g_u0, flipT(W0)) fused: the tail kernel's additive-coupling epilogue
+                TailConvArgs t{};
+                t.x = w.gh1; t.x_bs = (long)hid * HW; t.wp = at<float>(packed, L.f0T_wp); t.bias = nullptr; t.scale = nullptr;
+                t.N = N; t.Cin = hid; t.H = d.H; t.W = d.W; t.Cout = Ch; t.mode = TAIL_ADD_FWD;
+                t.z2_in = g; t.z2_in_bs = chw; t.z2_out = g; t.z2_out_bs = chw; t.acc = nullptr;
+                t.zeros = at<float>(packed, 64); t.hout = nullptr;
+                GH_TRY(launch_conv_mfma_tail(t, s));
+            } else {
+                GH_TRY(dgrad_direct(w.gh1, d.f0_w, w.wT, w.gpre, N, Ch, d.H, d.W, hid, 3, s));   // gpre reused: (N,Ch,HW)
+                hipLaunchKernelGGL(k_add_inplace, dim3(cdiv((long)Ch * HW, 256), N), dim3(256), 0, s, g, chw, w.gpre,
+                                   (long)Ch * HW, (long)Ch * HW);
+                GH_LAUNCH_CHECK("k_add_inplace");
+            }
             // (e) ActNorm + invconv / permutation: g (= g_y) -> g_x in place
             ChanMixBwdArgs mb{xin, chw, g, g, chw, d.an_bias, at<float>(packed, L.an_scale),
                               d.permutation == GLOWHIP_PERM_INVCONV ? d.invconv_w : nullptr,
