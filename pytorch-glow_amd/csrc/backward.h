@@ -47,6 +47,14 @@ int launch_prior_bwd(const float* z, const float* mean, const float* logs, long 
 int launch_weight_flipT(const float* w, float* wT, int Cout, int Cin, int ksize, hipStream_t s);
 int launch_wgrad_direct(const float* gy, const float* x, long x_bs, float* dw, int N, int Cin, int H, int W, int Cout,
                         int ksize, hipStream_t s);
+// ---- wgrad_mfma.hip
+int launch_shift_expand(const float* src, long src_bs, float* out, int N, int C, int H, int W, int rows_pad, int sign,
+                        hipStream_t s);
+bool wgrad_mfma_supported(int HW, int Mpad, int Npad);
+size_t wgrad_mfma_partial_floats(int Mpad, int Npad, int N, int HW);
+int launch_wgrad_mfma(const float* A, long a_bs, const float* B, long b_bs, float* partial, float* dw, int N, int HW,
+                      int Mpad, int Npad, int Mreal, int Nreal, int mode, hipStream_t s);
+
 int launch_grad_finalize(const double* acc, float* out, int n, const double* gsum, double add_mul, hipStream_t s);
 int launch_grad_finalize_w(const double* acc, float* out, int C, const double* gsum, double hw, const float* winv,
                            hipStream_t s);

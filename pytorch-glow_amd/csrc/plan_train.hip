@@ -47,6 +47,7 @@ static size_t tape_layout(const glowhip_plan* p, int N, std::vector<TapeLayer>* 
 struct TrainWs {
     unsigned long long* acc; float* gld; double* gsum;
     float* gA; float* gB; float* gh1; float* gh2; float* gpre; float* wT; double* dacc;
+    float* col; float* partial;   // shift-expanded small operand / split-K partial tiles of the MFMA weight gradients
     size_t dacc_doubles;
 };
 
@@ -75,6 +76,27 @@ static size_t max_acc_doubles(const glowhip_plan* p) {
     return m + 64;
 }
 
+static int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+static bool wgrad_fast(const LayerPlan& L) {
+    const glowhip_layer_desc& d = L.d;
+    return d.kind == GLOWHIP_LAYER_FLOWSTEP && (d.H * d.W) % 32 == 0 && d.hidden % 128 == 0;
+}
+
+static void wgrad_scratch_floats(const glowhip_plan* p, int N, size_t* col, size_t* partial) {
+    *col = 0; *partial = 0;
+    for (const LayerPlan& L : p->layers) {
+        if (!wgrad_fast(L)) continue;
+        const glowhip_layer_desc& d = L.d;
+        const int HW = d.H * d.W, hid = d.hidden;
+        const int m4 = round_up(L.Cout * 9, 128), n0 = round_up((d.C / 2) * 9, 64);
+        *col = std::max(*col, (size_t)N * std::max(m4, n0) * HW);
+        *partial = std::max(*partial, wgrad_mfma_partial_floats(hid, hid, N, HW));
+        *partial = std::max(*partial, wgrad_mfma_partial_floats(m4, hid, N, HW));
+        *partial = std::max(*partial, wgrad_mfma_partial_floats(hid, n0, N, HW));
+    }
+}
+
 static size_t train_ws_layout(const glowhip_plan* p, int N, void* base, TrainWs* w) {
     size_t off = 0;
     const size_t o_acc = take(off, (size_t)N * 8), o_gld = take(off, (size_t)N * 4), o_gsum = take(off, 64);
@@ -84,7 +106,11 @@ static size_t train_ws_layout(const glowhip_plan* p, int N, void* base, TrainWs*
     const size_t o_wT = take(off, max_weight_floats(p) * 4);
     const size_t nd = max_acc_doubles(p);
     const size_t o_dacc = take(off, nd * 8);
+    size_t colf, partf;
+    wgrad_scratch_floats(p, N, &colf, &partf);
+    const size_t o_col = take(off, colf * 4), o_part = take(off, partf * 4);
     if (w && base) {
+        w->col = at<float>(base, o_col); w->partial = at<float>(base, o_part);
         w->acc = at<unsigned long long>(base, o_acc); w->gld = at<float>(base, o_gld); w->gsum = at<double>(base, o_gsum);
         w->gA = at<float>(base, o_gA); w->gB = at<float>(base, o_gB); w->gh1 = at<float>(base, o_h1);
         w->gh2 = at<float>(base, o_h2); w->gpre = at<float>(base, o_gpre); w->wT = at<float>(base, o_wT);
@@ -245,7 +271,15 @@ static int backward_sweep(glowhip_plan* p, const void* packed, const float* x_in
                                at<float>(packed, L.f4_scale), w.gld, a4b, a4l, N, Ch, L.Cout, HW, affine};
             GH_TRY(launch_coupling_bwd(cb, s));
             // (b) f.4: weight gradient, then input gradient -> g_h2 (raw), then ReLU/ActNorm of f.2
-            GH_TRY(launch_wgrad_direct(w.gpre, h2, (long)hid * HW, G.f4_w, N, hid, d.H, d.W, L.Cout, 3, s));
+            const bool fastw = wgrad_fast(L);
+            if (fastw) {   // dW4[o][i][tap] = sum_p g_pre[o][p - d(tap)] * h2[i][p]
+                const int m4 = round_up(L.Cout * 9, 128);
+                GH_TRY(launch_shift_expand(w.gpre, (long)L.Cout * HW, w.col, N, L.Cout, d.H, d.W, m4, -1, s));
+                GH_TRY(launch_wgrad_mfma(w.col, (long)m4 * HW, h2, (long)hid * HW, w.partial, G.f4_w, N, HW, m4, hid,
+                                         L.Cout * 9, hid, 1, s));
+            } else {
+                GH_TRY(launch_wgrad_direct(w.gpre, h2, (long)hid * HW, G.f4_w, N, hid, d.H, d.W, L.Cout, 3, s));
+            }
             if (L.dg4_first) {
                 const float* wf = at<float>(packed, L.f4T_wf);
                 GH_TRY(launch_conv_mfma_first(w.gpre, (long)L.Cout * HW, wf, wf + (size_t)9 * L.Cout * hid, w.gh2, N, L.Cout,
@@ -255,7 +289,12 @@ static int backward_sweep(glowhip_plan* p, const void* packed, const float* x_in
             }
             GH_TRY(launch_act_bwd(w.gh2, h2, at<float>(packed, L.f2_scale), N, hid, HW, a2b, a2l, s));
             // (c) f.2 (1x1)
-            GH_TRY(launch_wgrad_direct(w.gh2, h1, (long)hid * HW, G.f2_w, N, hid, d.H, d.W, hid, 1, s));
+            if (fastw) {
+                GH_TRY(launch_wgrad_mfma(w.gh2, (long)hid * HW, h1, (long)hid * HW, w.partial, G.f2_w, N, HW, hid, hid, hid, hid,
+                                         0, s));
+            } else {
+                GH_TRY(launch_wgrad_direct(w.gh2, h1, (long)hid * HW, G.f2_w, N, hid, d.H, d.W, hid, 1, s));
+            }
             if (L.mfma_mid) {   // W2 in its reference layout [o][i] is already the K-major image of the transposed GEMM
                 GH_TRY(launch_conv_mfma_wide(w.gh2, (long)hid * HW, d.f2_w, nullptr, nullptr, w.gh1, N, hid, d.H, d.W, hid, 1,
                                              s, 0));
@@ -264,7 +303,14 @@ static int backward_sweep(glowhip_plan* p, const void* packed, const float* x_in
             }
             GH_TRY(launch_act_bwd(w.gh1, h1, at<float>(packed, L.f0_scale), N, hid, HW, a0b, a0l, s));
             // (d) f.0: input is y1 = first half of the step output
-            GH_TRY(launch_wgrad_direct(w.gh1, out, chw, G.f0_w, N, Ch, d.H, d.W, hid, 3, s));
+            if (fastw) {   // dW0[o][i][tap] = sum_p g_u0[o][p] * y1[i][p + d(tap)]
+                const int n0 = round_up(Ch * 9, 64);
+                GH_TRY(launch_shift_expand(out, chw, w.col, N, Ch, d.H, d.W, n0, +1, s));
+                GH_TRY(launch_wgrad_mfma(w.gh1, (long)hid * HW, w.col, (long)n0 * HW, w.partial, G.f0_w, N, HW, hid, n0, hid,
+                                         Ch * 9, 0, s));
+            } else {
+                GH_TRY(launch_wgrad_direct(w.gh1, out, chw, G.f0_w, N, Ch, d.H, d.W, hid, 3, s));
+            }
             if (L.dg0_tail) {   // g_y1 += conv(g_u0, flipT(W0)) fused: the tail kernel's additive-coupling epilogue
                 TailConvArgs t{};
                 t.x = w.gh1; t.x_bs = (long)hid * HW; t.wp = at<float>(packed, L.f0T_wp); t.bias = nullptr; t.scale = nullptr;

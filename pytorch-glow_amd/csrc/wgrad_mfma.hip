@@ -1,0 +1,193 @@
+// wgrad_mfma.hip -- weight gradients of the coupling network's convolutions on the matrix cores.
+//
+// All three are one "NT" GEMM with the reduction over pixels:  C[m][n] = sum_{img,p} A[img][m][p] * B[img][n][p]
+//   f.2 (1x1):  A = g_u2 (512 rows),            B = h1 (512 rows)                     -> dW2[o][i]
+//   f.4 (3x3):  A = shift-expanded g_pre rows (o*9+tap) : g[o][p - d(tap)],  B = h2   -> dW4[o][i][tap]
+//   f.0 (3x3):  A = g_u0 (512 rows),  B = shift-expanded y1 rows (i*9+tap) : y1[i][p + d(tap)] -> dW0[o][i][tap]
+// The 3x3 cases expand the SMALL operand (12..48 resp. 6..24 channels -> x9 rows, a few tens of MB) with a cheap
+// gather kernel instead of teaching the GEMM about taps.  The GEMM is k_conv_wide's K-major LDS / 32x32x2 MFMA
+// loop with a transposing operand loader (rows are pixel-contiguous in HBM, the MFMA wants rows across lanes);
+// the pixel axis is split over workgroups (split-K), partial tiles go to a scratch buffer and a second kernel adds
+// them in a fixed order (deterministic) while scattering into the reference weight layout.
+#include "backward.h"
+
+namespace glowhip {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// out[img][c*9 + tap][p] = src[img][c][p + sign*d(tap)] (0 outside the image); rows >= C*9 up to rows_pad are zero.
+// sign = +1: operand of a forward-style access (x[p + d]); sign = -1: gradient operand (g[p - d]).
+__global__ void __launch_bounds__(256) k_shift_expand(const float* __restrict__ src, long src_bs, float* __restrict__ out,
+                                                      int C, int H, int W, int rows_pad, int sign) {
+    const int HW = H * W;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    const int row = blockIdx.y;
+    const long n = blockIdx.z;
+    if (p >= HW) return;
+    float v = 0.f;
+    if (row < C * 9) {
+        const int c = row / 9, tap = row - c * 9;
+        const int dy = (tap / 3 - 1) * sign, dx = (tap % 3 - 1) * sign;
+        const int y = p / W + dy, x = p % W + dx;
+        if (y >= 0 && y < H && x >= 0 && x < W) v = src[n * src_bs + (long)c * HW + y * W + x];
+    }
+    out[(n * rows_pad + row) * HW + p] = v;
+}
+
+int launch_shift_expand(const float* src, long src_bs, float* out, int N, int C, int H, int W, int rows_pad, int sign,
+                        hipStream_t s) {
+    if (N == 0) return GLOWHIP_OK;
+    hipLaunchKernelGGL(k_shift_expand, dim3(cdiv(H * W, 256), rows_pad, N), dim3(256), 0, s, src, src_bs, out, C, H, W,
+                       rows_pad, sign);
+    GH_LAUNCH_CHECK("k_shift_expand");
+    return GLOWHIP_OK;
+}
+
+// partial[split][m][n] for one BM x BN tile and one slice of the pixel axis
+template <int BN>
+__global__ void __launch_bounds__(256)
+k_wgrad_gemm(const float* __restrict__ A, long a_bs, const float* __restrict__ B, long b_bs, float* __restrict__ partial,
+             int HW, int Mpad, int Npad, int ktiles_total, int ktiles_per_split) {
+    constexpr int BM = 128, BK = 32;
+    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+    constexpr int A_F4 = BM * BK / 4 / 256, B_F4 = BN * BK / 4 / 256;   // float4 per thread per K-tile (4, 4|2)
+    __shared__ __attribute__((aligned(16))) float As[2][BK][BM];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wr = wid >> 1, wc = wid & 1, kl = lane >> 5, ml = lane & 31;
+    const int tiles_n = Npad / BN;
+    const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x % tiles_n;
+    const int split = blockIdx.y;
+    const int kt0 = split * ktiles_per_split;
+    const int kt1 = min(ktiles_total, kt0 + ktiles_per_split);
+    const int tiles_per_img = HW / BK;
+
+    // loader coordinates: each thread owns one row of the tile and 16 (A) / 16|8 (B) consecutive pixels of it
+    const int a_row = tid & (BM - 1), a_q = tid / BM;                 // a_q in {0,1}: pixel quads [a_q*4, a_q*4+4)
+    const int b_row = tid & (BN - 1), b_q = tid / BN;                 // BN=128: {0,1} x 4 quads; BN=64: {0..3} x 2 quads
+    f32x4 ra[A_F4], rb[B_F4];
+    auto load_tile = [&](int kt) {
+        const int img = kt / tiles_per_img, p0 = (kt - img * tiles_per_img) * BK;
+        const float* ap = A + (long)img * a_bs + (long)(tile_m * BM + a_row) * HW + p0 + a_q * (A_F4 * 4);
+        const float* bp = B + (long)img * b_bs + (long)(tile_n * BN + b_row) * HW + p0 + b_q * (B_F4 * 4);
+#pragma unroll
+        for (int j = 0; j < A_F4; ++j) ra[j] = *reinterpret_cast<const f32x4*>(ap + j * 4);
+#pragma unroll
+        for (int j = 0; j < B_F4; ++j) rb[j] = *reinterpret_cast<const f32x4*>(bp + j * 4);
+    };
+    auto store_tile = [&](int buf) {   // transpose: K-major LDS image, lanes = consecutive rows => conflict-free
+#pragma unroll
+        for (int j = 0; j < A_F4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) As[buf][a_q * (A_F4 * 4) + j * 4 + e][a_row] = ra[j][e];
+#pragma unroll
+        for (int j = 0; j < B_F4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) Bs[buf][b_q * (B_F4 * 4) + j * 4 + e][b_row] = rb[j][e];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (kt0 < kt1) {
+        load_tile(kt0);
+        store_tile(0);
+        __syncthreads();
+        for (int kt = kt0; kt < kt1; ++kt) {
+            const int buf = (kt - kt0) & 1;
+            if (kt + 1 < kt1) load_tile(kt + 1);
+            float a[2][TM], b[2][TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[0][i] = As[buf][kl][wr * WM + i * 32 + ml];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[0][j] = Bs[buf][kl][wc * WN + j * 32 + ml];
+#pragma unroll
+            for (int kk = 0; kk < BK / 2; ++kk) {
+                const int cur = kk & 1, nxt = cur ^ 1;
+                if (kk + 1 < BK / 2) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) a[nxt][i] = As[buf][(kk + 1) * 2 + kl][wr * WM + i * 32 + ml];
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) b[nxt][j] = Bs[buf][(kk + 1) * 2 + kl][wc * WN + j * 32 + ml];
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
+                if (kk + 1 < BK / 2) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
+            }
+            if (kt + 1 < kt1) store_tile(buf ^ 1);
+            __syncthreads();
+        }
+    }
+    // partial tile: C[row = m][col = n]
+    float* out = partial + ((long)split * Mpad + tile_m * BM) * Npad + tile_n * BN;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wr * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl;
+                out[(long)row * Npad + wc * WN + j * 32 + ml] = acc[i][j][r];
+            }
+}
+
+// dW[f(m, n)] = sum_split partial[split][m][n], splits added in order.
+//   mode 0: dW[m*Nreal + n]                      (f.2: [512][512];  f.0: [512][Ch*9] = dW0[o][i][tap] flat)
+//   mode 1: m = o*9 + tap, n = i: dW[(o*Nreal + i)*9 + tap]      (f.4: dW4[o][i][tap])
+__global__ void __launch_bounds__(256) k_wgrad_reduce(const float* __restrict__ partial, float* __restrict__ dw, int splits,
+                                                      int Mpad, int Npad, int Mreal, int Nreal, int mode) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long)Mreal * Nreal) return;
+    const int m = (int)(e / Nreal), n = (int)(e - (long)m * Nreal);
+    float s = 0.f;
+    for (int k = 0; k < splits; ++k) s += partial[((long)k * Mpad + m) * Npad + n];
+    if (mode == 0) dw[e] = s;
+    else {
+        const int o = m / 9, tap = m - o * 9;
+        dw[((long)o * Nreal + n) * 9 + tap] = s;
+    }
+}
+
+bool wgrad_mfma_supported(int HW, int Mpad, int Npad) { return HW % 32 == 0 && Mpad % 128 == 0 && Npad % 64 == 0; }
+
+size_t wgrad_mfma_partial_floats(int Mpad, int Npad, int N, int HW) {
+    const int tiles = (Mpad / 128) * (Npad % 128 == 0 ? Npad / 128 : Npad / 64);
+    const int total = (int)((long)N * HW / 32);
+    int splits = std::max(1, std::min(total, (768 + tiles - 1) / tiles));
+    return (size_t)splits * Mpad * Npad;
+}
+
+int launch_wgrad_mfma(const float* A, long a_bs, const float* B, long b_bs, float* partial, float* dw, int N, int HW,
+                      int Mpad, int Npad, int Mreal, int Nreal, int mode, hipStream_t s) {
+    GH_REQUIRE(wgrad_mfma_supported(HW, Mpad, Npad), "wgrad_mfma: unsupported shape");
+    if (N == 0) return GLOWHIP_OK;
+    const bool bn128 = Npad % 128 == 0;
+    const int tiles = (Mpad / 128) * (bn128 ? Npad / 128 : Npad / 64);
+    const int total = (int)((long)N * HW / 32);
+    int splits = std::max(1, std::min(total, (768 + tiles - 1) / tiles));
+    const int per = (total + splits - 1) / splits;
+    splits = (total + per - 1) / per;
+    if (bn128)
+        hipLaunchKernelGGL(k_wgrad_gemm<128>, dim3(tiles, splits), dim3(256), 0, s, A, a_bs, B, b_bs, partial, HW, Mpad, Npad,
+                           total, per);
+    else
+        hipLaunchKernelGGL(k_wgrad_gemm<64>, dim3(tiles, splits), dim3(256), 0, s, A, a_bs, B, b_bs, partial, HW, Mpad, Npad,
+                           total, per);
+    GH_LAUNCH_CHECK("k_wgrad_gemm");
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3(cdiv((long)Mreal * Nreal, 256)), dim3(256), 0, s, partial, dw, splits, Mpad, Npad,
+                       Mreal, Nreal, mode);
+    GH_LAUNCH_CHECK("k_wgrad_reduce");
+    return GLOWHIP_OK;
+}
+
+}  // namespace glowhip
