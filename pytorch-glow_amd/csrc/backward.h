@@ -55,6 +55,13 @@ size_t wgrad_mfma_partial_floats(int Mpad, int Npad, int N, int HW);
 int launch_wgrad_mfma(const float* A, long a_bs, const float* B, long b_bs, float* partial, float* dw, int N, int HW,
                       int Mpad, int Npad, int Mreal, int Nreal, int mode, hipStream_t s);
 
+// one launch for all reduction-type parameter gradients of a backward sweep
+struct GradJob {
+    const double* acc; float* out; int n;
+    double add_mul;          // out[i] = acc[i] + gsum * add_mul            (winv == null)
+    const float* winv; int C; // out[o*C+i] = acc[o*C+i] + gsum * add_mul * winv[i*C+o]   (invconv weight)
+};
+int launch_grad_finalize_batched(const GradJob* jobs_dev, int n_jobs, const double* gsum, hipStream_t s);
 int launch_grad_finalize(const double* acc, float* out, int n, const double* gsum, double add_mul, hipStream_t s);
 int launch_grad_finalize_w(const double* acc, float* out, int C, const double* gsum, double hw, const float* winv,
                            hipStream_t s);

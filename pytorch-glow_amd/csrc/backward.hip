@@ -358,6 +358,30 @@ __global__ void __launch_bounds__(64) k_sum_gld(const float* __restrict__ gld, i
     if (threadIdx.x == 0) gsum[0] = a;
 }
 
+__global__ void __launch_bounds__(256) k_grad_finalize_batched(const GradJob* __restrict__ jobs,
+                                                               const double* __restrict__ gsum) {
+    const GradJob j = jobs[blockIdx.y];
+    if (j.out == nullptr) return;
+    const double g = gsum[0] * j.add_mul;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < j.n; e += gridDim.x * 256) {
+        double v = j.acc[e];
+        if (j.winv) {
+            const int o = e / j.C, i = e - o * j.C;
+            v += g * (double)j.winv[i * j.C + o];
+        } else {
+            v += g;
+        }
+        j.out[e] = (float)v;
+    }
+}
+
+int launch_grad_finalize_batched(const GradJob* jobs_dev, int n_jobs, const double* gsum, hipStream_t s) {
+    if (n_jobs == 0) return GLOWHIP_OK;
+    hipLaunchKernelGGL(k_grad_finalize_batched, dim3(8, n_jobs), dim3(256), 0, s, jobs_dev, gsum);
+    GH_LAUNCH_CHECK("k_grad_finalize_batched");
+    return GLOWHIP_OK;
+}
+
 int launch_grad_finalize(const double* acc, float* out, int n, const double* gsum, double add_mul, hipStream_t s) {
     if (n == 0 || out == nullptr) return GLOWHIP_OK;
     hipLaunchKernelGGL(k_grad_finalize, dim3(cdiv(n, 256)), dim3(256), 0, s, acc, out, n, gsum, add_mul);

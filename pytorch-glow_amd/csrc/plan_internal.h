@@ -6,6 +6,7 @@
 
 #include "kernels.h"
 #include "conv_mfma.h"
+#include "backward.h"
 
 namespace glowhip {
 
@@ -46,6 +47,7 @@ struct glowhip_plan {
     long max_chw = 0;      // max over layer inputs/outputs of C*H*W
     long max_hidden = 0;   // max over steps of max(hidden, Cout) * H*W
     int n_split = 0;
+    std::vector<glowhip::GradJob> grad_jobs;   // host copy of the last backward's finalize table (kept alive for the async copy)
 };
 
 namespace glowhip {

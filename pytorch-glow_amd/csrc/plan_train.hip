@@ -48,6 +48,7 @@ struct TrainWs {
     unsigned long long* acc; float* gld; double* gsum;
     float* gA; float* gB; float* gh1; float* gh2; float* gpre; float* wT; double* dacc;
     float* col; float* partial;   // shift-expanded small operand / split-K partial tiles of the MFMA weight gradients
+    GradJob* jobs;                // device copy of the finalize job table (<= 9 per layer)
     size_t dacc_doubles;
 };
 
@@ -66,13 +67,16 @@ static size_t max_weight_floats(const glowhip_plan* p) {
     return m;
 }
 
+// fp64 accumulators of every layer's reduction-type gradients live side by side: zeroed once, converted once
+static size_t layer_acc_doubles(const LayerPlan& L) {
+    const glowhip_layer_desc& d = L.d;
+    if (d.kind == GLOWHIP_LAYER_FLOWSTEP) return (size_t)d.C * d.C + 2 * d.C + 4 * d.hidden + 2 * L.Cout;
+    if (d.kind == GLOWHIP_LAYER_SPLIT2D) return (size_t)2 * L.Cout;
+    return 0;
+}
 static size_t max_acc_doubles(const glowhip_plan* p) {
     size_t m = 0;
-    for (const LayerPlan& L : p->layers) {
-        const glowhip_layer_desc& d = L.d;
-        if (d.kind == GLOWHIP_LAYER_FLOWSTEP) m = std::max(m, (size_t)d.C * d.C + 2 * d.C + 4 * d.hidden + 2 * L.Cout);
-        else if (d.kind == GLOWHIP_LAYER_SPLIT2D) m = std::max(m, (size_t)2 * L.Cout);
-    }
+    for (const LayerPlan& L : p->layers) m += layer_acc_doubles(L);
     return m + 64;
 }
 
@@ -109,8 +113,9 @@ static size_t train_ws_layout(const glowhip_plan* p, int N, void* base, TrainWs*
     size_t colf, partf;
     wgrad_scratch_floats(p, N, &colf, &partf);
     const size_t o_col = take(off, colf * 4), o_part = take(off, partf * 4);
+    const size_t o_jobs = take(off, p->layers.size() * 9 * sizeof(GradJob));
     if (w && base) {
-        w->col = at<float>(base, o_col); w->partial = at<float>(base, o_part);
+        w->col = at<float>(base, o_col); w->partial = at<float>(base, o_part); w->jobs = at<GradJob>(base, o_jobs);
         w->acc = at<unsigned long long>(base, o_acc); w->gld = at<float>(base, o_gld); w->gsum = at<double>(base, o_gsum);
         w->gA = at<float>(base, o_gA); w->gB = at<float>(base, o_gB); w->gh1 = at<float>(base, o_h1);
         w->gh2 = at<float>(base, o_h2); w->gpre = at<float>(base, o_gpre); w->wT = at<float>(base, o_wT);
@@ -242,6 +247,17 @@ static int backward_sweep(glowhip_plan* p, const void* packed, const float* x_in
     // g: gradient w.r.t. the current layer's OUTPUT (contiguous (N, C_out, H, W)), held in gA/gB
     float* g = g_top;
     const int nl = (int)p->layers.size();
+    std::vector<GradJob>& jobs = p->grad_jobs;
+    jobs.clear();
+    std::vector<size_t> acc_base(nl, 0);
+    {
+        size_t o = 0;
+        for (int i = 0; i < nl; ++i) { acc_base[i] = o; o += layer_acc_doubles(p->layers[i]); }
+        GH_TRY(zero_f64(w.dacc, o, s));
+    }
+    auto fin = [&](const double* acc, float* out, int n, double add_mul, const float* winv = nullptr, int C = 0) {
+        if (out) jobs.push_back(GradJob{acc, out, n, add_mul, winv, C});
+    };
     for (int li = nl - 1; li >= 0; --li) {
         const LayerPlan& L = p->layers[li];
         const glowhip_layer_desc& d = L.d;
@@ -262,10 +278,9 @@ static int backward_sweep(glowhip_plan* p, const void* packed, const float* x_in
             const float* hout = at<float>(tape, tl[li].hout);
             const int affine = d.coupling == GLOWHIP_COUPLING_AFFINE;
             // accumulators: [W C*C][an_b C][an_l C][f0_b hid][f0_l hid][f2_b hid][f2_l hid][f4_b Cout][f4_l Cout]
-            double* aW = w.dacc; double* aAb = aW + (size_t)d.C * d.C; double* aAl = aAb + d.C;
+            double* aW = w.dacc + acc_base[li]; double* aAb = aW + (size_t)d.C * d.C; double* aAl = aAb + d.C;
             double* a0b = aAl + d.C; double* a0l = a0b + hid; double* a2b = a0l + hid; double* a2l = a2b + hid;
             double* a4b = a2l + hid; double* a4l = a4b + L.Cout;
-            GH_TRY(zero_f64(w.dacc, (size_t)d.C * d.C + 2 * d.C + 4 * hid + 2 * L.Cout, s));
             // (a) coupling tail: g (second half) becomes g_y2 in place; gpre = gradient of f.4's (conv + bias)
             CouplingBwdArgs cb{hout, out + (long)Ch * HW, chw, g + (long)Ch * HW, chw, g + (long)Ch * HW, w.gpre,
                                at<float>(packed, L.f4_scale), w.gld, a4b, a4l, N, Ch, L.Cout, HW, affine};
@@ -329,21 +344,17 @@ static int backward_sweep(glowhip_plan* p, const void* packed, const float* x_in
                               d.permutation == GLOWHIP_PERM_INVCONV ? d.invconv_w : nullptr,
                               d.permutation == GLOWHIP_PERM_GATHER ? d.perm_idx_inv : nullptr, aW, aAb, aAl, N, d.C, HW};
             GH_TRY(launch_chanmix_bwd(mb, s));
-            // (f) fp64 accumulators -> fp32 gradients (+ the log-det terms that do not depend on the data)
-            if (d.permutation == GLOWHIP_PERM_INVCONV)
-                GH_TRY(launch_grad_finalize_w(aW, G.invconv_w, d.C, w.gsum, (double)HW, at<float>(packed, L.winv), s));
-            GH_TRY(launch_grad_finalize(aAb, G.an_bias, d.C, nullptr, 0.0, s));
-            GH_TRY(launch_grad_finalize(aAl, G.an_logs, d.C, w.gsum, 3.0 * HW, s));
-            GH_TRY(launch_grad_finalize(a0b, G.f0_an_bias, hid, nullptr, 0.0, s));
-            GH_TRY(launch_grad_finalize(a0l, G.f0_an_logs, hid, nullptr, 0.0, s));
-            GH_TRY(launch_grad_finalize(a2b, G.f2_an_bias, hid, nullptr, 0.0, s));
-            GH_TRY(launch_grad_finalize(a2l, G.f2_an_logs, hid, nullptr, 0.0, s));
-            GH_TRY(launch_grad_finalize(a4b, G.f4_bias, L.Cout, nullptr, 0.0, s));
-            GH_TRY(launch_grad_finalize(a4l, G.f4_logs, L.Cout, nullptr, 0.0, s));
+            // (f) fp64 accumulators -> fp32 gradients (+ the log-det terms that do not depend on the data): queued,
+            // converted by ONE launch after the sweep
+            if (d.permutation == GLOWHIP_PERM_INVCONV) fin(aW, G.invconv_w, d.C * d.C, (double)HW, at<float>(packed, L.winv), d.C);
+            fin(aAb, G.an_bias, d.C, 0.0);
+            fin(aAl, G.an_logs, d.C, 3.0 * HW);
+            fin(a0b, G.f0_an_bias, hid, 0.0); fin(a0l, G.f0_an_logs, hid, 0.0);
+            fin(a2b, G.f2_an_bias, hid, 0.0); fin(a2l, G.f2_an_logs, hid, 0.0);
+            fin(a4b, G.f4_bias, L.Cout, 0.0); fin(a4l, G.f4_logs, L.Cout, 0.0);
         } else {  // SPLIT2D: output z1 (N,Ch,HW); input x = (z1, z2)
             const float* hout = at<float>(tape, tl[li].hout);
-            double* a4b = w.dacc; double* a4l = a4b + L.Cout;
-            GH_TRY(zero_f64(w.dacc, (size_t)2 * L.Cout, s));
+            double* a4b = w.dacc + acc_base[li]; double* a4l = a4b + L.Cout;
             // g_x first half <- g (gradient of z1), second half <- gradient of the log-density
             GH_TRY(launch_copy_strided(g, (long)Ch * HW, gnext, chw, N, (long)Ch * HW, s));
             SplitBwdArgs sb{hout, xin + (long)Ch * HW, chw, gnext + (long)Ch * HW, chw, w.gpre,
@@ -354,10 +365,16 @@ static int backward_sweep(glowhip_plan* p, const void* packed, const float* x_in
             hipLaunchKernelGGL(k_add_inplace, dim3(cdiv((long)Ch * HW, 256), N), dim3(256), 0, s, gnext, chw, w.gh1,
                                (long)Ch * HW, (long)Ch * HW);
             GH_LAUNCH_CHECK("k_add_inplace");
-            GH_TRY(launch_grad_finalize(a4b, G.f4_bias, L.Cout, nullptr, 0.0, s));
-            GH_TRY(launch_grad_finalize(a4l, G.f4_logs, L.Cout, nullptr, 0.0, s));
+            fin(a4b, G.f4_bias, L.Cout, 0.0); fin(a4l, G.f4_logs, L.Cout, 0.0);
             g = gnext;
         }
+    }
+    if (!jobs.empty()) {
+        if (hipMemcpyAsync(w.jobs, jobs.data(), jobs.size() * sizeof(GradJob), hipMemcpyHostToDevice, s) != hipSuccess) {
+            set_error("backward: hipMemcpyAsync of the finalize job table failed");
+            return GLOWHIP_ELAUNCH;
+        }
+        GH_TRY(launch_grad_finalize_batched(w.jobs, (int)jobs.size(), w.gsum, s));
     }
     return GLOWHIP_OK;
 }

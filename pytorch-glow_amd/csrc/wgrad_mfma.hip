@@ -163,7 +163,7 @@ bool wgrad_mfma_supported(int HW, int Mpad, int Npad) { return HW % 32 == 0 && M
 size_t wgrad_mfma_partial_floats(int Mpad, int Npad, int N, int HW) {
     const int tiles = (Mpad / 128) * (Npad % 128 == 0 ? Npad / 128 : Npad / 64);
     const int total = (int)((long)N * HW / 32);
-    int splits = std::max(1, std::min(total, (768 + tiles - 1) / tiles));
+    int splits = std::max(1, std::min(total, (384 + tiles - 1) / tiles));
     return (size_t)splits * Mpad * Npad;
 }
 
@@ -174,7 +174,7 @@ int launch_wgrad_mfma(const float* A, long a_bs, const float* B, long b_bs, floa
     const bool bn128 = Npad % 128 == 0;
     const int tiles = (Mpad / 128) * (bn128 ? Npad / 128 : Npad / 64);
     const int total = (int)((long)N * HW / 32);
-    int splits = std::max(1, std::min(total, (768 + tiles - 1) / tiles));
+    int splits = std::max(1, std::min(total, (384 + tiles - 1) / tiles));   // ~1.5 workgroups per CU
     const int per = (total + splits - 1) / splits;
     splits = (total + per - 1) / per;
     if (bn128)
