@@ -111,8 +111,9 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="images per GPU (default: BASELINE config B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-repack", action="store_true", help="inference mode: keep derived parameter data across steps")
-    ap.add_argument("--mode", choices=["forward", "inverse"], default="forward",
-                    help="forward = the headline metric (Glow.normal_flow); inverse = Glow.reverse_flow sampling throughput")
+    ap.add_argument("--mode", choices=["forward", "inverse", "train"], default="forward",
+                    help="forward = the headline metric (Glow.normal_flow); inverse = Glow.reverse_flow sampling throughput; "
+                         "train = full training step (fwd with tape + HIP backward + RCCL gradient all-reduce + clip + Adam)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -144,9 +145,16 @@ def main():
     if args.mode == "inverse":
         z_top = torch.randn(B, 48, 8, 8, device=device) * 0.7
 
-    torch.set_grad_enabled(False)   # forward+logdet metric: inference path (no activation tape)
+    if args.mode == "train":
+        glow.train()
+        opt = torch.optim.Adam(list(glow.parameters()), lr=1e-3, betas=(0.9, 0.9999), eps=1e-8)  # builder.py:10-13
+    else:
+        torch.set_grad_enabled(False)   # forward+logdet metric: inference path (no activation tape)
 
     def step():
+        if args.mode == "train":     # secondary metric: the reference's training step (trainer.py:123-150)
+            loss, _ = parallel.train_step(glow, opt, x, world=world, max_grad_clip=5, max_grad_norm=100)
+            return loss * (world * B)
         if args.mode == "inverse":   # secondary metric: sampling (eps drawn on device, W^-1 from the in-kernel LU)
             plan.ensure_packed(repack)
             xs = glow.reverse_flow(z_top, None, eps_std=0.7)
@@ -178,7 +186,9 @@ def main():
         fpi = flop_per_image(glow)
         out = {
             "metric": "images/sec full Glow fwd+logdet, 64x64x3 L=3 K=32, 1/2/4/8 GPU" if args.mode == "forward"
-                      else "images/sec Glow inverse (reverse_flow sampling), 64x64x3 L=3 K=32 [secondary metric]",
+                      else "images/sec Glow inverse (reverse_flow sampling), 64x64x3 L=3 K=32 [secondary metric]"
+                      if args.mode == "inverse" else
+                      "images/sec Glow training step (fwd+bwd+allreduce+clip+Adam), 64x64x3 L=3 K=32 [secondary metric]",
             "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -189,6 +199,14 @@ def main():
             "model_tflops": round(value * fpi / 1e12, 2),
             "frac_of_fp32_mfma_peak_whole_model": round(value / world * fpi / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4),
         }
+        if args.mode == "train":
+            out.pop("model_tflops"), out.pop("frac_of_fp32_mfma_peak_whole_model")
+            out["model_tflops_fwd_bwd"] = round(value * 3 * fpi / 1e12, 2)   # backward ~ 2x forward flops
+            print(json.dumps(out), flush=True)
+            if world > 1:
+                dist.barrier()
+                dist.destroy_process_group()
+            return
         # ---- roofline of the dominant kernel: instrumented pass of the same step, HIP events per launch
         plan.timing(True)
         for _ in range(3):   # rank-local pass: NO collective here (the other ranks are already past the timed loop)

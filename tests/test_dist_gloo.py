@@ -95,3 +95,39 @@ def test_world2_init_broadcast_and_loss_allreduce():
     # (3) gathered per-sample nll is in rank order
     assert torch.allclose(r0["allnll"], nll_all, atol=1e-5) and torch.equal(r0["allnll"], r1["allnll"])
     assert torch.allclose(r0["nll"], nll_all[:2], atol=1e-5) and torch.allclose(r1["nll"], nll_all[2:], atol=1e-5)
+
+
+def grad_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(7)
+        m = torch.nn.Sequential(torch.nn.Linear(5, 3), torch.nn.Linear(3, 2))
+        m[1].bias.requires_grad_(False)                      # a parameter without gradient (like h_top)
+        xg = torch.arange(40, dtype=torch.float32).reshape(8, 5) / 10
+        x = parallel.shard_batch(xg, world, rank)
+        with torch.enable_grad():
+            m(x).pow(2).mean().backward()                    # local mean over the shard
+        parallel.allreduce_gradients(m, world)               # -> gradient of the GLOBAL mean
+        ret[rank] = [None if p.grad is None else p.grad.clone() for p in m.parameters()]
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_world2_gradient_allreduce_equals_global_batch_gradient():
+    world = 2
+    ret = mp.Manager().dict()
+    mp.spawn(grad_worker, args=(world, free_port(), ret), nprocs=world, join=True)
+    torch.manual_seed(7)
+    m = torch.nn.Sequential(torch.nn.Linear(5, 3), torch.nn.Linear(3, 2))
+    m[1].bias.requires_grad_(False)
+    xg = torch.arange(40, dtype=torch.float32).reshape(8, 5) / 10
+    with torch.enable_grad():
+        m(xg).pow(2).mean().backward()
+    for r in (0, 1):
+        for got, p in zip(ret[r], m.parameters()):
+            if p.grad is None:
+                assert got is None
+            else:
+                assert torch.allclose(got, p.grad, atol=1e-6)

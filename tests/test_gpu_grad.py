@@ -91,3 +91,26 @@ def test_glow_gradients_vs_autograd_oracle(coup, perm, hidden, image):
     egx = (xd.grad.cpu() - gx_ref).abs().max().item()
     assert egx <= 2e-4 * gx_ref.abs().max().item() + 1e-7, f"dL/dx err {egx:.3e}"
     print(f"worst parameter {worst[0]} at {worst[1]:.2f} of its bound; dL/dx err {egx:.2e}")
+
+
+def test_train_steps_reduce_the_loss():
+    """Three optimiser steps of the reference's training loop (trainer.py:123-150) on the HIP path: data-dependent
+    ActNorm init, forward with tape, HIP backward, clip by value 5 / by norm 100, Adam -- the loss must fall and every
+    parameter stay finite."""
+    from pytorch_glow_amd import parallel
+    torch.manual_seed(0)
+    np.random.seed(0)
+    cfg = O.default_cfg(image_shape=(32, 32, 3), hidden_channels=128, K=2, L=2, batch=8)
+    glow = G.Glow(hps_for(cfg, 8)).to(DEV).train()
+    x = torch.rand(8, 3, 32, 32, device=DEV)
+    with torch.no_grad():
+        glow.normal_flow(x, None)                      # first training-mode forward: ActNorm init
+    opt = torch.optim.Adam([p for p in glow.parameters()], lr=1e-3, betas=(0.9, 0.9999), eps=1e-8)
+    losses = []
+    for _ in range(4):
+        loss, gnorm = parallel.train_step(glow, opt, x, world=1, max_grad_clip=5, max_grad_norm=100)
+        losses.append(loss.item())
+        assert torch.isfinite(gnorm)
+    assert losses[-1] < losses[0], losses
+    assert all(torch.isfinite(p).all() for p in glow.parameters())
+    assert glow.h_top.grad is None
