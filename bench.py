@@ -146,14 +146,14 @@ def main():
         z_top = torch.randn(B, 48, 8, 8, device=device) * 0.7
 
     if args.mode == "train":
-        glow.train()
-        opt = torch.optim.Adam(list(glow.parameters()), lr=1e-3, betas=(0.9, 0.9999), eps=1e-8)  # builder.py:10-13
+        from pytorch_glow_amd import training
+        loop = training.TrainLoop(glow, hps, rank=rank, world=world)   # Adam + noam warm-up + clip 5/100 (celeba profile)
     else:
         torch.set_grad_enabled(False)   # forward+logdet metric: inference path (no activation tape)
 
     def step():
         if args.mode == "train":     # secondary metric: the reference's training step (trainer.py:123-150)
-            loss, _ = parallel.train_step(glow, opt, x, world=world, max_grad_clip=5, max_grad_norm=100)
+            loss, _ = loop.step(x)
             return loss * (world * B)
         if args.mode == "inverse":   # secondary metric: sampling (eps drawn on device, W^-1 from the in-kernel LU)
             plan.ensure_packed(repack)

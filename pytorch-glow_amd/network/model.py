@@ -307,6 +307,10 @@ class Glow(nn.Module):
             return 0
         return Glow.bce_criterion(y_logits, y_onehot.float())
 
+    def actnorm_inited(self):
+        """True when every ActNorm already holds its data-dependent statistics (nothing left for a first batch to do)."""
+        return not _uninited_actnorms(self)
+
     def set_actnorm_inited(self, inited=True):
         for name, m in self.named_modules():
             if m.__class__.__name__.find("ActNorm") >= 0:

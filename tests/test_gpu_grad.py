@@ -114,3 +114,95 @@ def test_train_steps_reduce_the_loss():
     assert losses[-1] < losses[0], losses
     assert all(torch.isfinite(p).all() for p in glow.parameters())
     assert glow.h_top.grad is None
+
+
+def _celeba_geometry_model(K, batch, seed=11):
+    """Config-B channel geometry (64x64x3, L=3, hidden 512, affine + invconv) with a reduced K so the CPU autograd oracle
+    finishes in seconds; bench-style seeded weights (Conv2dZeros ~ N(0, 0.002)) and data-dependent ActNorm init."""
+    cfg = O.default_cfg(K=K, batch=batch)
+    sd = O.seeded_state_dict(cfg, seed=seed, invconv_perturb=0.02)
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(batch, 3, 64, 64, generator=g)
+    noise = torch.rand(batch, 3, 64, 64, generator=g) / 256
+    sd = O.glow_init_actnorm(x, noise, sd, cfg)
+    glow = G.Glow(hps_for(cfg, batch))
+    glow.load_state_dict(sd)
+    glow.set_actnorm_inited()
+    return cfg, sd, glow.to(DEV).train(), x, noise
+
+
+def test_gradients_at_celeba_geometry_vs_autograd_oracle():
+    """Same check on the headline model's layer shapes (C = 12/24/48, hidden 512, 32x32 / 16x16 / 8x8): these are the shapes
+    that take the LDS-DMA GEMM, the DMA tail kernels and the split-K weight-gradient GEMMs.
+
+    The yardstick is the oracle run in fp64.  With 2M hidden activations per layer a few ReLU pre-activations land within
+    fp32 rounding of zero (measured: |x| = 6.9e-8 in layer 2's f.2, channel 81), and ANY fp32 implementation -- the fp32
+    oracle included, which is off by 7e-3 of max|g| on such rows -- may take the other branch there: one flipped element
+    changes one row of one weight gradient.  So: at most 1% of a parameter's entries may exceed the tight bound (a flip
+    touches 1/512 of them), and none may exceed 5% of max|g|."""
+    cfg, sd, glow, x, noise = _celeba_geometry_model(K=3, batch=4)
+    ref, gx_ref, loss_ref = oracle_grads(cfg, {k: v.double() for k, v in sd.items()}, x.double(), noise.double())
+    with torch.enable_grad():
+        xd = x.to(DEV).requires_grad_(True)
+        z, nll, _ = glow.normal_flow(xd, None, noise=noise.to(DEV))
+        loss = G.Glow.generative_loss(nll)
+        loss.backward()
+    assert abs(loss.item() - loss_ref) < 1e-4
+    for name, p in glow.named_parameters():
+        if name == "h_top":
+            continue
+        r = ref[name]
+        err = (p.grad.cpu().double() - r).abs()
+        scale = r.abs().max().item()
+        outliers = (err > 2e-4 * scale + 1e-7).double().mean().item()
+        assert outliers <= 0.01, f"{name}: {outliers:.2%} of the entries off by more than 2e-4 of max|g| = {scale:.3e}"
+        assert err.max().item() <= 0.05 * scale + 1e-7, f"{name}: max err {err.max().item():.3e}, max|g| {scale:.3e}"
+    egx = (xd.grad.cpu().double() - gx_ref).abs()
+    gscale = gx_ref.abs().max().item()
+    assert (egx > 2e-4 * gscale + 1e-7).double().mean().item() <= 0.01 and egx.max().item() <= 0.05 * gscale, \
+        f"dL/dx err {egx.max().item():.3e} vs max|g| {gscale:.3e}"
+
+
+def test_forward_after_an_optimizer_step_matches_oracle():
+    """The optimiser updates the parameters in place; the next forward must see them (derived data is re-packed from the
+    live parameters every training step) and agree with the oracle evaluated on the SAME updated state_dict."""
+    from pytorch_glow_amd import parallel
+    cfg, sd, glow, x, noise = _celeba_geometry_model(K=3, batch=4)
+    opt = torch.optim.Adam(list(glow.parameters()), lr=1e-4, betas=(0.9, 0.9999), eps=1e-8)
+    xd = x.to(DEV)
+    loss0, _ = parallel.train_step(glow, opt, xd, world=1, max_grad_clip=5, max_grad_norm=100)
+    sd1 = {k: v.detach().cpu().clone() for k, v in glow.state_dict().items()}
+    assert max((sd1[k] - sd[k]).abs().max().item() for k in sd if k != "h_top") > 5e-5      # the step moved them
+    z_ref, nll_ref, _ = O.glow_forward(x, noise, sd1, cfg)
+    assert torch.isfinite(nll_ref).all()
+    for mode in ("eval", "train"):
+        getattr(glow, mode)()
+        z, nll, _ = glow.normal_flow(xd, None, noise=noise.to(DEV))
+        assert torch.isfinite(nll).all(), (mode, nll)
+        assert (nll.cpu() - nll_ref).abs().max().item() < 1e-4, (mode, nll.cpu(), nll_ref)
+        assert (z.cpu() - z_ref).abs().max().item() < 1e-4
+
+
+def test_train_loop_follows_the_profile_schedule():
+    """TrainLoop = the reference Trainer's per-step state (trainer.py:85-150): ActNorm init on the first batch, lr from the
+    profile's scheduler written into the optimiser before each step, clipping thresholds from hps.ablation."""
+    from pytorch_glow_amd import training
+    torch.manual_seed(0)
+    np.random.seed(0)
+    cfg = O.default_cfg(image_shape=(32, 32, 3), hidden_channels=128, K=2, L=2, batch=8)
+    hps = hps_for(cfg, 8)
+    hps.optim.update(optimizer="adam", optimizer_args=dict(lr=1e-3, betas=[0.9, 0.9999], eps=1e-8),
+                     lr_scheduler="noam", lr_scheduler_args=dict(warmup_steps=5, min_lr=1e-4))
+    hps.ablation.update(max_grad_clip=5, max_grad_norm=100)
+    glow = G.Glow(hps).to(DEV)
+    loop = training.TrainLoop(glow, hps)
+    x = torch.rand(8, 3, 32, 32, device=DEV)
+    assert not glow.actnorm_inited()
+    losses, lrs = [], []
+    for _ in range(6):
+        loss, _ = loop.step(x)
+        losses.append(loss.item())
+        lrs.append(loop.optimizer.param_groups[0]["lr"])
+    assert glow.actnorm_inited() and loop.global_step == 6
+    assert lrs[:5] == pytest.approx([1e-3 * (i + 1) / 5 for i in range(5)]) and lrs[5] == pytest.approx(1e-3 * (5 / 6) ** 0.5)
+    assert losses[-1] < losses[0]

@@ -109,3 +109,33 @@ def test_cpu_tensors_are_refused_not_silently_computed():
                  lambda: G.Permutation2d(4)(x)):
         with pytest.raises(G.GlowHipError):
             call()
+
+
+def test_lr_schedules_match_reference_formulas():
+    """misc/lr_scheduler.py:4-96: values computed by hand from the reference's formulas."""
+    from pytorch_glow_amd.misc import lr_scheduler as S
+    assert S.constant(1e-3, 77) == 1e-3
+    assert S.noam_decay(1e-3, 0, warmup_steps=4000) == pytest.approx(1e-3 / 4000)
+    assert S.noam_decay(1e-3, 3999, warmup_steps=4000) == pytest.approx(1e-3)
+    assert S.noam_decay(1e-3, 15999, warmup_steps=4000, min_lr=1e-4) == pytest.approx(5e-4)
+    assert S.noam_decay(1e-3, 10 ** 9, warmup_steps=4000, min_lr=1e-4) == 1e-4          # floor after warm-up
+    assert S.linear_anneal(1e-3, 50, num_train=10, warmup_steps=10) == pytest.approx(5e-4)
+    assert S.linear_anneal(1e-3, 500, num_train=10, warmup_steps=10) == 1e-3
+    assert S.step_anneal(1.0, 60001, anneal_rate=0.5, anneal_interval=30000) == 0.25
+    assert S.cyclic_cosine_anneal(1.0, 1, t=100, m=4) == pytest.approx(1.0)
+    assert S.cyclic_cosine_anneal(1.0, 1 + 25 // 2, t=100, m=4) == pytest.approx(0.5 * (np.cos(np.pi * 12 / 25) + 1))
+    assert set(S.SCHEDULES) == {"constant", "noam", "linear", "step", "cyclic_cosine"}          # builder.py:14-20
+
+
+def test_optimizer_and_scheduler_are_built_from_the_profile():
+    from pytorch_glow_amd import training
+    hps = util.load_profile("celeba")
+    w = torch.nn.Parameter(torch.zeros(3))
+    opt = training.build_optimizer(hps, [w])
+    assert isinstance(opt, torch.optim.Adam) and opt.defaults["betas"] == (0.9, 0.9999) and opt.defaults["lr"] == 1e-3
+    sched = training.build_scheduler(hps)
+    assert sched(global_step=0) == pytest.approx(1e-3 / 4000) and sched(global_step=3999) == pytest.approx(1e-3)
+    assert isinstance(training.build_optimizer(util.load_profile("test"), [w]), torch.optim.Adamax)
+    hps.optim.optimizer = "sgd"
+    with pytest.raises(KeyError):
+        training.build_optimizer(hps, [w])
