@@ -221,7 +221,8 @@ int glowhip_plan_timing_read(glowhip_plan* plan, glowhip_timing_record* out, int
 
 /* Testing hook for the fused tail convolution, so every variant can be exercised at any batch size: low byte =
  * pixels per workgroup (16/32/64/128; 0 = automatic, chosen by a cost model), | 0x100 = always split the
- * out-channel tiles over blockIdx.y, | 0x200 = never split. 0 restores automatic selection. */
+ * out-channel tiles over blockIdx.y, | 0x200 = never split, | 0x400 = no LDS-DMA tail kernels, | 0x800 = exact-fp32 MFMA
+ * kernels only (disables the split-half f16 path). 0 restores automatic selection. */
 void glowhip_debug_force_tail_tile(int pixels_and_flags);
 
 /* Introspection for tests / benchmarks: which kernels a plan will launch ("mfma" or "direct" per

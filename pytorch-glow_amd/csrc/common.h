@@ -75,6 +75,13 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
     return t;
 }
 
+// XCD-aware remap (8 XCDs, private L2s): hardware places block b on XCD b%8; give each XCD a contiguous
+// run of logical tiles so the tiles that share an operand panel share an L2.  Bijective for any grid size.
+__device__ __forceinline__ int xcd_remap(int b, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7, xcd = b & 7, slot = b >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+}
+
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

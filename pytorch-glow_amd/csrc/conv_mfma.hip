@@ -22,13 +22,6 @@ namespace glowhip {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// XCD-aware remap (8 XCDs, private L2s): hardware places block b on XCD b%8; give each XCD a contiguous
-// run of logical tiles so the tiles that share an operand panel share an L2.  Bijective for any grid size.
-__device__ __forceinline__ int xcd_remap(int b, int nblk) {
-    const int q = nblk >> 3, r = nblk & 7, xcd = b & 7, slot = b >> 3;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-}
-
 // ================================================================================================
 // k_conv_wide
 // ================================================================================================

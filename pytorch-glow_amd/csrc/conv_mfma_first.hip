@@ -9,6 +9,7 @@
 // chunks with the pixel window stationary.  A k-pair of one MFMA = two adjacent channels of the same tap, so a
 // fragment address is  lane_base(pixel, k&1) + scalar(chunk, tap, channel).
 #include "conv_mfma.h"
+#include "sh.h"
 
 namespace glowhip {
 
@@ -48,7 +49,8 @@ size_t conv_mfma_first_packed_bytes(int Cin, int Cout) { return ((size_t)9 * Cin
 template <int BN, int WF>
 __global__ void __launch_bounds__(256)
 k_conv_first(const float* __restrict__ X, long x_bs, const float* __restrict__ Wf, const float* __restrict__ bs,
-             float* __restrict__ Y, int N, int Cin, int H, int W, int M, FirstGeom gr, int relu) {
+             float* __restrict__ Y, int N, int Cin, int H, int W, int M, FirstGeom gr, int relu,
+             _Float16* __restrict__ Ysh) {
     constexpr int BM = FIRST_BM, BK = FIRST_BK;
     constexpr int RS = WF + 8, TR = BN / WF, W4 = WF / 4, CHS = first_chs(BN / WF, WF);
     struct { int RS, CHS, TR, W4, MB; } g = {RS, CHS, TR, W4, gr.MB};
@@ -165,6 +167,32 @@ k_conv_first(const float* __restrict__ X, long x_bs, const float* __restrict__ W
         if (st + 1 < steps) store_A(buf ^ 1);
         if (ch == nch - 1) {
             // epilogue of this output-channel tile: ActNorm + ReLU, C[row = o][col = pixel]
+            if (Ysh) {
+                // split-half output (sh.h): a lane's 4 consecutive channels of its pixel = 8 bytes of the hi plane and of the lo plane
+                const long P = (long)N * HW;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const long px = n * HW + p0 + wc * WN + j * 32 + ml;
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                        for (int gq = 0; gq < 4; ++gq) {
+                            const int o0 = mt * BM + wr * WM + i * 32 + 8 * gq + 4 * kl;
+                            h4 hi, lo;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const float v = relu ? fmaxf(acc[i][j][4 * gq + q], 0.f) : acc[i][j][4 * gq + q];
+                                _Float16 a, b;
+                                sh_split(v, a, b);
+                                hi[q] = a; lo[q] = b;
+                            }
+                            _Float16* dst = Ysh + ((long)(o0 >> 3) * P + px) * 8 + (o0 & 7);
+                            *reinterpret_cast<h4*>(dst) = hi;
+                            *reinterpret_cast<h4*>(dst + P * (long)M) = lo;
+                        }
+                    }
+                }
+            } else {
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int p = p0 + wc * WN + j * 32 + ml;
@@ -178,13 +206,14 @@ k_conv_first(const float* __restrict__ X, long x_bs, const float* __restrict__ W
                     }
                 }
             }
+            }
         }
         __syncthreads();
     }
 }
 
 int launch_conv_mfma_first(const float* x, long x_bs, const float* wf_, const float* bias_scaled, float* y, int N,
-                           int Cin, int H, int W, int Cout, hipStream_t s, int relu) {
+                           int Cin, int H, int W, int Cout, hipStream_t s, int relu, _Float16* y_sh) {
     GH_REQUIRE(conv_mfma_first_supported(Cin, H, W, Cout), "conv_mfma_first: unsupported shape");
     if (N == 0) return GLOWHIP_OK;
     const int HW = H * W;
@@ -207,7 +236,7 @@ int launch_conv_mfma_first(const float* x, long x_bs, const float* wf_, const fl
         (void)hipFuncSetAttribute((const void*)k_conv_first<bn, wf>, hipFuncAttributeMaxDynamicSharedMemorySize,    \
                                   (int)lds);                                                                         \
         hipLaunchKernelGGL((k_conv_first<bn, wf>), dim3(grid), dim3(256), lds, s, x, x_bs, wf_, bias_scaled, y, N,   \
-                           Cin, H, W, Cout, g, relu);                                                                \
+                           Cin, H, W, Cout, g, relu, y_sh);                                                          \
         GH_LAUNCH_CHECK("k_conv_first");                                                                             \
         return GLOWHIP_OK;                                                                                           \
     }

@@ -1,0 +1,184 @@
+// gemm_sh.hip -- f.2 (1x1 convolution hidden -> hidden + ActNorm + ReLU, network/module.py:300-319) on split-half operands
+// (sh.h): three v_mfma_f32_32x32x16_f16 per k-step (hi*hi into the main accumulator, hi*lo + lo*hi into the cross
+// accumulator) instead of eight v_mfma_f32_32x32x2_f32 -- 16x the matrix rate at 3x the instructions.
+//
+// Workgroup = 128 out-channels x 128 pixels, 4 waves (2 x 2), each wave 64 x 64 = 2 x 2 MFMA tiles x 2 accumulators
+// (128 accumulator registers).  Operands stream HBM/L2 -> LDS through the DMA path (global_load_lds_dwordx4) into a 4-stage ring
+// of 32-deep k-tiles; the LDS image of a stage is [A|B][plane][chunk 4][128 rows][8 halfs] -- written linearly by the DMA
+// (one wave-instruction = 64 rows x 16 B = 1 KiB) and read as conflict-free 16-byte fragments (16 consecutive lanes = 256
+// contiguous bytes = every bank once).  A stage is consumed behind a counted s_waitcnt vmcnt + ONE raw s_barrier per 24
+// MFMAs; that barrier also proves the previous stage is drained, so its slot is refilled right behind it.
+#include "sh.h"
+#include "conv_mfma.h"
+
+namespace glowhip {
+
+constexpr int SH_BM = 128, SH_BN = 128, SH_BK = 32, SH_ST = 4;
+constexpr int SH_STAGE_HALFS = 2 * (2 * (SH_BK / 8) * 128 * 8);   // A + B: 16384 halfs = 32 KiB
+
+template <bool OUT_SH>
+__global__ void __launch_bounds__(256)
+k_gemm_sh(const _Float16* __restrict__ X, long P, const _Float16* __restrict__ Wsh, const float* __restrict__ bias,
+          float* __restrict__ Yf, _Float16* __restrict__ Ysh, int K, int M, int HW, int relu) {
+    extern __shared__ __attribute__((aligned(16))) _Float16 smem_h[];   // SH_ST stages
+    const int tiles_m = M / SH_BM;
+    const int tiles_n = (int)((P + SH_BN - 1) / SH_BN);
+    const int logical = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int tile_m = logical % tiles_m, tile_n = logical / tiles_m;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 1, wc = wid & 1;
+    const int kl = lane >> 5, ml = lane & 31;
+    const long w_plane = (long)K * M, x_plane = P * (long)K;
+
+    // DMA sources of this lane: wave w streams chunk w of every stage; 4 A pieces (plane x 64-row half) + 4 B pieces
+    const _Float16* a_src = Wsh + ((long)wid * M + tile_m * SH_BM + lane) * 8;
+    long px0 = (long)tile_n * SH_BN + lane, px1 = px0 + 64;
+    px0 = px0 < P ? px0 : P - 1;   // ragged last tile: clamp the fetch, the stores are predicated
+    px1 = px1 < P ? px1 : P - 1;
+    const _Float16* b_src0 = X + ((long)wid * P + px0) * 8;
+    const _Float16* b_src1 = X + ((long)wid * P + px1) * 8;
+    const int nkt = K / SH_BK;
+
+    auto issue_piece = [&](int kt, int piece) {   // piece 0..3: A (plane = piece>>1, half = piece&1); 4..7: B likewise
+        _Float16* st = smem_h + (kt % SH_ST) * SH_STAGE_HALFS;
+        const int plane = (piece >> 1) & 1, half = piece & 1;
+        if (piece < 4) {
+            const _Float16* src = a_src + plane * w_plane + ((long)kt * 4 * M + half * 64) * 8;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(st + ((plane * 4 + wid) * 128 + half * 64) * 8),
+                                             16, 0, 0);
+        } else {
+            const _Float16* src = (half ? b_src1 : b_src0) + plane * x_plane + (long)kt * 4 * P * 8;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(st + 8192 + ((plane * 4 + wid) * 128 + half * 64) * 8),
+                                             16, 0, 0);
+        }
+    };
+
+    f32x16_t accm[2][2], accx[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { accm[i][j][r] = 0.f; accx[i][j][r] = 0.f; }
+
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+        if (t < nkt) {
+#pragma unroll
+            for (int pc = 0; pc < 8; ++pc) issue_piece(t, pc);
+        }
+
+    for (int kt = 0; kt < nkt; ++kt) {
+        if (kt + 2 < nkt) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const _Float16* As = smem_h + (kt % SH_ST) * SH_STAGE_HALFS;
+        const _Float16* Bs = As + 8192;
+        const bool refill = kt + 3 < nkt;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int chunk = 2 * s + kl;
+            h8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                ah[i] = *reinterpret_cast<const h8*>(As + ((0 * 4 + chunk) * 128 + wr * 64 + i * 32 + ml) * 8);
+                al[i] = *reinterpret_cast<const h8*>(As + ((1 * 4 + chunk) * 128 + wr * 64 + i * 32 + ml) * 8);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                bh[j] = *reinterpret_cast<const h8*>(Bs + ((0 * 4 + chunk) * 128 + wc * 64 + j * 32 + ml) * 8);
+                bl[j] = *reinterpret_cast<const h8*>(Bs + ((1 * 4 + chunk) * 128 + wc * 64 + j * 32 + ml) * 8);
+            }
+            if (refill) {
+#pragma unroll
+                for (int pc = 0; pc < 4; ++pc) issue_piece(kt + 3, s * 4 + pc);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    accm[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], accm[i][j], 0, 0, 0);
+                    accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], accx[i][j], 0, 0, 0);
+                    accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], accx[i][j], 0, 0, 0);
+                }
+        }
+    }
+
+    // ---- epilogue: main + cross / 2^11 + folded ActNorm bias, ReLU; C[row = channel][col = pixel]:
+    // lane (kl, ml) holds pixel ml and channels 8*(r>>2) + 4*kl + (r&3) of each 32-row tile
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const long px = (long)tile_n * SH_BN + wc * 64 + j * 32 + ml;
+        const bool ok = px < P;
+        const long n = px / HW;
+        const int p = (int)(px - n * HW);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int o0 = tile_m * SH_BM + wr * 64 + i * 32 + 8 * g + 4 * kl;
+                const f32x4_t b4 = *reinterpret_cast<const f32x4_t*>(bias + o0);
+                float v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float t = accm[i][j][4 * g + q] + accx[i][j][4 * g + q] * SH_LO_INV + b4[q];
+                    v[q] = relu ? fmaxf(t, 0.f) : t;
+                }
+                if (OUT_SH) {
+                    h4 hi, lo;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        _Float16 a, b;
+                        sh_split(v[q], a, b);
+                        hi[q] = a; lo[q] = b;
+                    }
+                    if (ok) {
+                        _Float16* dst = Ysh + ((long)(o0 >> 3) * P + px) * 8 + (o0 & 7);
+                        *reinterpret_cast<h4*>(dst) = hi;
+                        *reinterpret_cast<h4*>(dst + P * (long)M) = lo;
+                    }
+                } else if (ok) {
+                    float* dst = Yf + (n * M + o0) * (long)HW + p;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) dst[(long)q * HW] = v[q];
+                }
+            }
+        }
+    }
+}
+
+bool gemm_sh_supported(int K, int M, int H, int W) {
+    return M % SH_BM == 0 && K % SH_BK == 0 && K >= SH_BK;
+}
+
+size_t gemm_sh_packed_bytes(int K, int M) {
+    return align_up((size_t)2 * K * M * sizeof(_Float16), 16) + (size_t)M * sizeof(float);
+}
+
+int launch_gemm_sh(const _Float16* x_sh, const void* wsh, float* y_f32, _Float16* y_sh, int N, int K, int HW, int M, int relu,
+                   hipStream_t s) {
+    GH_REQUIRE(gemm_sh_supported(K, M, 1, 1), "gemm_sh: unsupported shape K=%d M=%d", K, M);
+    GH_REQUIRE((y_f32 != nullptr) != (y_sh != nullptr), "gemm_sh: exactly one output");
+    if (N == 0) return GLOWHIP_OK;
+    const long P = (long)N * HW;
+    const _Float16* w = (const _Float16*)wsh;
+    const float* bias = (const float*)((const char*)wsh + align_up((size_t)2 * K * M * sizeof(_Float16), 16));
+    const size_t lds = (size_t)SH_ST * SH_STAGE_HALFS * sizeof(_Float16);
+    const unsigned grid = (unsigned)((M / SH_BM) * ((P + SH_BN - 1) / SH_BN));
+    if (y_sh) {
+        (void)hipFuncSetAttribute((const void*)k_gemm_sh<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_gemm_sh<true>, dim3(grid), dim3(256), lds, s, x_sh, P, w, bias, nullptr, y_sh, K, M, HW, relu);
+    } else {
+        (void)hipFuncSetAttribute((const void*)k_gemm_sh<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_gemm_sh<false>, dim3(grid), dim3(256), lds, s, x_sh, P, w, bias, y_f32, nullptr, K, M, HW, relu);
+    }
+    GH_LAUNCH_CHECK("k_gemm_sh");
+    return GLOWHIP_OK;
+}
+
+}  // namespace glowhip

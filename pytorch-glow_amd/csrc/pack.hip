@@ -3,8 +3,11 @@
 // (a 96-step Glow has ~390 scale jobs and ~290 repack jobs; launching them one by one cost 11 ms per pack).
 #include "kernels.h"
 #include "conv_mfma.h"
+#include "sh.h"
 
 namespace glowhip {
+
+__device__ __forceinline__ size_t align_up_dev(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 __global__ void __launch_bounds__(256) k_pack_scales_batched(const ScaleJob* __restrict__ jobs, char* packed) {
     const ScaleJob j = jobs[blockIdx.y];
@@ -42,6 +45,23 @@ __global__ void __launch_bounds__(256) k_repack_batched(const RepackJob* __restr
         }
         for (long o = (long)blockIdx.x * 256 + threadIdx.x; o < j.Cout; o += (long)gridDim.x * 256)
             out[total + o] = j.fold_logs ? j.fold_bias[o] * expf(j.fold_logs[o] * LOGSCALE) : 0.f;
+    } else if (j.kind == REPACK_SH_GEMM) {
+        // split-half GEMM image (sh.h): half [plane][K/8][M][8] of w[o][k] * exp(3 logs[o]), then M floats bias * exp(3 logs)
+        const long total = (long)j.K * j.Cout;
+        _Float16* oh = (_Float16*)out;
+        for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+            const int k8 = (int)(e & 7);
+            const int o = (int)((e >> 3) % j.Cout);
+            const int k = (int)((e >> 3) / j.Cout) * 8 + k8;
+            const float wv = j.w[(long)o * j.K + k] * (j.fold_logs ? expf(j.fold_logs[o] * LOGSCALE) : 1.f);
+            _Float16 hi, lo;
+            sh_split(wv, hi, lo);
+            oh[e] = hi;
+            oh[total + e] = lo;
+        }
+        float* fb = (float*)((char*)out + align_up_dev((size_t)2 * total * sizeof(_Float16), 16));
+        for (long o = (long)blockIdx.x * 256 + threadIdx.x; o < j.Cout; o += (long)gridDim.x * 256)
+            fb[o] = j.fold_logs ? j.fold_bias[o] * expf(j.fold_logs[o] * LOGSCALE) : 0.f;
     } else {
         for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < j.total; e += (long)gridDim.x * 256) {
             const int i = (int)(e & 15), kq = (int)((e >> 4) & 3);

@@ -78,17 +78,22 @@ static int carve(const glowhip_plan* p, int N, void* ws, size_t bytes, Workspace
 // ---------------------------------------------------------------- coupling network f() (network/module.py:300-319)
 // Runs conv3x3 -> actnorm -> relu -> conv1x1 -> actnorm -> relu -> conv3x3(zeros) and applies the
 // coupling to z2.  x1: first-half channels (batch stride x1_bs).
+static bool g_sh_disabled = false;
+void plan_disable_sh(int off) { g_sh_disabled = off != 0; }
+
 static int run_coupling(glowhip_plan* P, const LayerPlan& L, const void* packed, const float* x1, long x1_bs, const float* z2_in,
                         long z2_in_bs, float* z2_out, long z2_out_bs, int N, int reverse, const Workspace& w,
                         hipStream_t s) {
     const glowhip_layer_desc& d = L.d;
     const int Ch = d.C / 2, HW = d.H * d.W, hid = d.hidden;
+    const bool use_sh = L.sh_mid && !g_sh_disabled;
     // f.0: 3x3, Cin=C/2 -> hidden, ActNorm + ReLU epilogue
     {
     ScopedTimer t0(P, GLOWHIP_K_CONV_F0, L.mfma_first || L.first_halo, s);
     if (L.first_halo) {
         const float* wf = at<float>(packed, L.f0_wt);
-        GH_TRY(launch_conv_mfma_first(x1, x1_bs, wf, wf + (size_t)9 * Ch * hid, w.h1, N, Ch, d.H, d.W, hid, s));
+        GH_TRY(launch_conv_mfma_first(x1, x1_bs, wf, wf + (size_t)9 * Ch * hid, w.h1, N, Ch, d.H, d.W, hid, s, 1,
+                                      use_sh ? (_Float16*)w.h1 : nullptr));
     } else if (L.mfma_first) {
         GH_TRY(launch_conv_mfma_wide(x1, x1_bs, at<float>(packed, L.f0_wt), d.f0_an_bias, at<float>(packed, L.f0_scale),
                                      w.h1, N, Ch, d.H, d.W, hid, 3, s));
@@ -101,7 +106,9 @@ static int run_coupling(glowhip_plan* P, const LayerPlan& L, const void* packed,
     // f.2: 1x1, hidden -> hidden, ActNorm + ReLU epilogue
     {
     ScopedTimer t2(P, GLOWHIP_K_CONV_F2, L.mfma_mid, s);
-    if (L.mfma_mid) {
+    if (use_sh) {
+        GH_TRY(launch_gemm_sh((const _Float16*)w.h1, at<char>(packed, L.f2_sh), w.h2, nullptr, N, hid, HW, hid, 1, s));
+    } else if (L.mfma_mid) {
         GH_TRY(launch_conv_mfma_wide(w.h1, (long)hid * HW, at<float>(packed, L.f2_wt), d.f2_an_bias,
                                      at<float>(packed, L.f2_scale), w.h2, N, hid, d.H, d.W, hid, 1, s));
     } else {
@@ -315,6 +322,8 @@ glowhip_plan* glowhip_plan_create(const glowhip_layer_desc* layers, int n_layers
             if (L.first_halo) L.f0_wt = take(off, conv_mfma_first_packed_bytes(C / 2, d.hidden));
             else if (L.mfma_first) L.f0_wt = take(off, conv_mfma_wide_packed_bytes(C / 2, d.hidden, 3));
             if (L.mfma_mid) L.f2_wt = take(off, conv_mfma_wide_packed_bytes(d.hidden, d.hidden, 1));
+            L.sh_mid = L.first_halo && gemm_sh_supported(d.hidden, d.hidden, H, W);
+            if (L.sh_mid) L.f2_sh = take(off, gemm_sh_packed_bytes(d.hidden, d.hidden));
             if (L.mfma_last) L.f4_wp = take(off, conv_mfma_tail_packed_bytes(d.hidden, L.Cout));
             L.dg4_first = conv_mfma_first_supported(L.Cout, H, W, d.hidden);
             if (L.dg4_first) L.f4T_wf = take(off, conv_mfma_first_packed_bytes(L.Cout, d.hidden));
@@ -363,6 +372,10 @@ glowhip_plan* glowhip_plan_create(const glowhip_layer_desc* layers, int n_layers
             if (L.mfma_mid) {
                 RepackJob r{}; r.w = d.f2_w; r.out_off = L.f2_wt; r.kind = REPACK_WIDE; r.Cin = d.hidden; r.Cout = d.hidden;
                 r.K = r.Cin; r.Kpad = wide_kpad(r.Cin, 1); p->repack_jobs.push_back(r);
+            }
+            if (L.sh_mid) {
+                RepackJob r{}; r.w = d.f2_w; r.out_off = L.f2_sh; r.kind = REPACK_SH_GEMM; r.Cin = d.hidden; r.Cout = d.hidden;
+                r.K = d.hidden; r.fold_bias = d.f2_an_bias; r.fold_logs = d.f2_an_logs; p->repack_jobs.push_back(r);
             }
             if (L.mfma_last) {
                 RepackJob r{}; r.w = d.f4_w; r.out_off = L.f4_wp; r.kind = REPACK_TAIL; r.Cin = d.hidden; r.Cout = L.Cout;

@@ -6,6 +6,7 @@
 
 #include "kernels.h"
 #include "conv_mfma.h"
+#include "sh.h"
 #include "backward.h"
 
 namespace glowhip {
@@ -21,6 +22,8 @@ struct LayerPlan {
     // training: input-gradient convolutions run on the forward kernels with flipped/transposed weight images
     size_t f4T_wf = 0, f0T_wp = 0;
     bool dg4_first = false, dg0_tail = false;
+    // split-half path (sh.h): f.0 writes h1 as an SH tensor, f.2 runs on the f16 matrix pipe (gemm_sh.hip)
+    bool sh_mid = false; size_t f2_sh = 0;
     bool first_halo = false;  // f.0 on k_conv_first (stationary pixel window) instead of k_conv_wide<3>
 };
 

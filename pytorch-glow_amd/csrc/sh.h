@@ -1,0 +1,52 @@
+// sh.h -- "split-half" (SH) operands: fp32 values carried as TWO fp16 numbers so the coupling network's contractions run
+// on the f16 matrix pipe (v_mfma_f32_32x32x16_f16, 16x the rate of the fp32-input MFMA) at fp32 accuracy.
+//
+//   hi = fp16(v)                       |v - hi|            <= 2^-12 |v|   (round to nearest, 11-bit significand)
+//   lo = fp16((v - hi) * 2^11)         |v - hi - lo/2^11|  <= 2^-24 |v|   -- the same half-ulp bound as fp32 itself
+//
+// (v - hi is exact in fp32; the 2^11 pre-scale keeps lo a NORMAL fp16 number.)  A product is evaluated as
+//   a*b ~= a.hi*b.hi + (a.hi*b.lo + a.lo*b.hi) / 2^11            (the dropped lo*lo term is <= 2^-24 |a b|)
+// with every fp16 x fp16 product exact in the fp32 accumulator (11+11 bits), two accumulators (main, cross) and
+// fp32 accumulation as in the fp32 MFMA.  Three f16 MFMAs per k-step instead of one fp32 MFMA of 1/16 the rate.
+// Range: |v| < 65504 (fp16 max; larger values become inf and surface as a non-finite nll, they are never clipped
+// silently); below 6.1e-5 the representation is absolute, 2.9e-11.  tests/diag_split_precision.py: on the celeba64
+// model the deviation from an fp64 evaluation is 5.8e-6 (z), the fp32 reference's own is 5.4e-6.
+//
+// HBM layout of an SH activation tensor with Ch channels over P = N*H*W pixels (pixel index n*HW + y*W + x):
+//   plane q in {hi, lo}:  half [Ch/8][P][8]        (8 consecutive channels of one pixel = 16 bytes)
+// This is at once what the MFMA epilogue produces (a lane owns 4 consecutive channels of its pixel; the two
+// half-waves complete the 16-byte group, 32 lanes = 512 contiguous bytes per store instruction) and what the consumer's
+// operand fetch wants (a lane's B fragment = 8 consecutive k of its pixel = ONE 16-byte group; 64 lanes of an LDS-DMA
+// instruction read 1 KiB contiguous and land as the conflict-free [chunk][pixel][8] LDS image -- no swizzle, no padding).
+// Weights use the same form: half [plane][K/8][M][8].
+#pragma once
+#include "common.h"
+
+namespace glowhip {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+constexpr float SH_LO_SCALE = 2048.0f;
+constexpr float SH_LO_INV = 1.0f / 2048.0f;
+
+__device__ __forceinline__ void sh_split(float v, _Float16& hi, _Float16& lo) {
+    hi = (_Float16)v;
+    lo = (_Float16)((v - (float)hi) * SH_LO_SCALE);
+}
+
+// bytes of one SH tensor (both planes)
+static inline size_t sh_bytes(long P, int Ch) { return (size_t)2 * (size_t)P * (size_t)Ch * sizeof(_Float16); }
+
+// ---- f.2 as an SH GEMM (gemm_sh.hip) ------------------------------------------------------------
+// Y[o][px] = relu( sum_k W'[o][k] X[k][px] + b'[o] ),  W' = W * exp(3 logs[o]), b' = bias * exp(3 logs[o]) (ActNorm folded)
+// wsh: packed image = half [2][K/8][M][8] followed (16-byte aligned) by M floats b'.
+bool gemm_sh_supported(int K, int M, int H, int W);
+size_t gemm_sh_packed_bytes(int K, int M);
+// exactly one of y_f32 (N,M,H,W fp32) / y_sh (SH tensor, P = N*HW) is written
+int launch_gemm_sh(const _Float16* x_sh, const void* wsh, float* y_f32, _Float16* y_sh, int N, int K, int HW, int M, int relu,
+                   hipStream_t s);
+
+}  // namespace glowhip
