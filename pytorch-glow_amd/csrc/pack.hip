@@ -62,6 +62,22 @@ __global__ void __launch_bounds__(256) k_repack_batched(const RepackJob* __restr
         float* fb = (float*)((char*)out + align_up_dev((size_t)2 * total * sizeof(_Float16), 16));
         for (long o = (long)blockIdx.x * 256 + threadIdx.x; o < j.Cout; o += (long)gridDim.x * 256)
             fb[o] = j.fold_logs ? j.fold_bias[o] * expf(j.fold_logs[o] * LOGSCALE) : 0.f;
+    } else if (j.kind == REPACK_SH_TAIL) {
+        // split-half tail image (tail_sh.hip): half [plane][Cin/8][Mpad][8], row m = tap*Cout + co, zero rows m >= 9*Cout
+        const int Mpad = j.Kpad;
+        const long total = (long)j.Cin * Mpad;
+        _Float16* oh = (_Float16*)out;
+        for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+            const int k8 = (int)(e & 7);
+            const int m = (int)((e >> 3) % Mpad);
+            const int k = (int)((e >> 3) / Mpad) * 8 + k8;
+            const int tap = m / j.Cout, co = m - tap * j.Cout;
+            const float wv = m < 9 * j.Cout ? j.w[((long)co * j.Cin + k) * 9 + tap] : 0.f;
+            _Float16 hi, lo;
+            sh_split(wv, hi, lo);
+            oh[e] = hi;
+            oh[total + e] = lo;
+        }
     } else {
         for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < j.total; e += (long)gridDim.x * 256) {
             const int i = (int)(e & 15), kq = (int)((e >> 4) & 3);

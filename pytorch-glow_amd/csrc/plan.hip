@@ -78,8 +78,8 @@ static int carve(const glowhip_plan* p, int N, void* ws, size_t bytes, Workspace
 // ---------------------------------------------------------------- coupling network f() (network/module.py:300-319)
 // Runs conv3x3 -> actnorm -> relu -> conv1x1 -> actnorm -> relu -> conv3x3(zeros) and applies the
 // coupling to z2.  x1: first-half channels (batch stride x1_bs).
-static bool g_sh_disabled = false;
-void plan_disable_sh(int off) { g_sh_disabled = off != 0; }
+static bool g_sh_disabled = false, g_sh_tail_disabled = false;
+void plan_disable_sh(int off) { g_sh_disabled = (off & 1) != 0; g_sh_tail_disabled = (off & 2) != 0; }
 
 static int run_coupling(glowhip_plan* P, const LayerPlan& L, const void* packed, const float* x1, long x1_bs, const float* z2_in,
                         long z2_in_bs, float* z2_out, long z2_out_bs, int N, int reverse, const Workspace& w,
@@ -87,6 +87,7 @@ static int run_coupling(glowhip_plan* P, const LayerPlan& L, const void* packed,
     const glowhip_layer_desc& d = L.d;
     const int Ch = d.C / 2, HW = d.H * d.W, hid = d.hidden;
     const bool use_sh = L.sh_mid && !g_sh_disabled;
+    const bool use_sh_tail = use_sh && L.sh_tail && !g_sh_tail_disabled;
     // f.0: 3x3, Cin=C/2 -> hidden, ActNorm + ReLU epilogue
     {
     ScopedTimer t0(P, GLOWHIP_K_CONV_F0, L.mfma_first || L.first_halo, s);
@@ -107,7 +108,8 @@ static int run_coupling(glowhip_plan* P, const LayerPlan& L, const void* packed,
     {
     ScopedTimer t2(P, GLOWHIP_K_CONV_F2, L.mfma_mid, s);
     if (use_sh) {
-        GH_TRY(launch_gemm_sh((const _Float16*)w.h1, at<char>(packed, L.f2_sh), w.h2, nullptr, N, hid, HW, hid, 1, s));
+        GH_TRY(launch_gemm_sh((const _Float16*)w.h1, at<char>(packed, L.f2_sh), use_sh_tail ? nullptr : w.h2,
+                              use_sh_tail ? (_Float16*)w.h2 : nullptr, N, hid, HW, hid, 1, s));
     } else if (L.mfma_mid) {
         GH_TRY(launch_conv_mfma_wide(w.h1, (long)hid * HW, at<float>(packed, L.f2_wt), d.f2_an_bias,
                                      at<float>(packed, L.f2_scale), w.h2, N, hid, d.H, d.W, hid, 1, s));
@@ -119,7 +121,17 @@ static int run_coupling(glowhip_plan* P, const LayerPlan& L, const void* packed,
     }
     // f.4: 3x3 zeros conv (+bias, *exp(3 logs)) and the coupling itself
     ScopedTimer t4(P, GLOWHIP_K_CONV_F4, L.mfma_last, s);
-    if (L.mfma_last) {
+    if (use_sh_tail) {
+        TailShArgs t{};
+        t.x_sh = (const _Float16*)w.h2; t.P = (long)N * HW; t.wsh = at<char>(packed, L.f4_sh); t.bias = d.f4_bias;
+        t.scale = at<float>(packed, L.f4_scale);
+        t.N = N; t.Cin = hid; t.H = d.H; t.W = d.W; t.Cout = L.Cout;
+        t.mode = d.coupling == GLOWHIP_COUPLING_AFFINE ? (reverse ? TAIL_AFFINE_REV : TAIL_AFFINE_FWD)
+                                                       : (reverse ? TAIL_ADD_REV : TAIL_ADD_FWD);
+        t.z2_in = z2_in; t.z2_in_bs = z2_in_bs; t.z2_out = z2_out; t.z2_out_bs = z2_out_bs; t.acc = w.acc;
+        t.zeros = at<float>(packed, 64);
+        GH_TRY(launch_tail_sh(t, s));
+    } else if (L.mfma_last) {
         TailConvArgs t{};
         t.x = w.h2; t.x_bs = (long)hid * HW; t.wp = at<float>(packed, L.f4_wp); t.bias = d.f4_bias;
         t.scale = at<float>(packed, L.f4_scale);
@@ -324,6 +336,8 @@ glowhip_plan* glowhip_plan_create(const glowhip_layer_desc* layers, int n_layers
             if (L.mfma_mid) L.f2_wt = take(off, conv_mfma_wide_packed_bytes(d.hidden, d.hidden, 1));
             L.sh_mid = L.first_halo && gemm_sh_supported(d.hidden, d.hidden, H, W);
             if (L.sh_mid) L.f2_sh = take(off, gemm_sh_packed_bytes(d.hidden, d.hidden));
+            L.sh_tail = L.sh_mid && tail_sh_supported(d.hidden, H, W, L.Cout);
+            if (L.sh_tail) L.f4_sh = take(off, tail_sh_packed_bytes(d.hidden, H, W, L.Cout));
             if (L.mfma_last) L.f4_wp = take(off, conv_mfma_tail_packed_bytes(d.hidden, L.Cout));
             L.dg4_first = conv_mfma_first_supported(L.Cout, H, W, d.hidden);
             if (L.dg4_first) L.f4T_wf = take(off, conv_mfma_first_packed_bytes(L.Cout, d.hidden));
@@ -376,6 +390,10 @@ glowhip_plan* glowhip_plan_create(const glowhip_layer_desc* layers, int n_layers
             if (L.sh_mid) {
                 RepackJob r{}; r.w = d.f2_w; r.out_off = L.f2_sh; r.kind = REPACK_SH_GEMM; r.Cin = d.hidden; r.Cout = d.hidden;
                 r.K = d.hidden; r.fold_bias = d.f2_an_bias; r.fold_logs = d.f2_an_logs; p->repack_jobs.push_back(r);
+            }
+            if (L.sh_tail) {
+                RepackJob r{}; r.w = d.f4_w; r.out_off = L.f4_sh; r.kind = REPACK_SH_TAIL; r.Cin = d.hidden; r.Cout = L.Cout;
+                r.Kpad = tail_sh_mpad(d.hidden, d.H, d.W, L.Cout); p->repack_jobs.push_back(r);
             }
             if (L.mfma_last) {
                 RepackJob r{}; r.w = d.f4_w; r.out_off = L.f4_wp; r.kind = REPACK_TAIL; r.Cin = d.hidden; r.Cout = L.Cout;

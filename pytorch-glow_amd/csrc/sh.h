@@ -49,4 +49,22 @@ size_t gemm_sh_packed_bytes(int K, int M);
 int launch_gemm_sh(const _Float16* x_sh, const void* wsh, float* y_f32, _Float16* y_sh, int N, int K, int HW, int M, int relu,
                    hipStream_t s);
 
+// ---- f.4 + coupling on SH operands (tail_sh.hip) ---------------------------------------------------
+struct TailShArgs {
+    const _Float16* x_sh; long P;     // h2 as an SH tensor of P = N*H*W pixels, Cin channels
+    const void* wsh;                  // packed image: half [2][Cin/8][Mpad][8], row m = tap*Cout + co (REPACK_SH_TAIL)
+    const float* bias;                // (Cout)
+    const float* scale;               // (Cout) exp(3 logs)
+    int N, Cin, H, W, Cout;
+    int mode;                         // TailMode (conv_mfma.h): the four coupling modes
+    const float* z2_in; long z2_in_bs;
+    float* z2_out; long z2_out_bs;
+    unsigned long long* acc;
+    const float* zeros;               // >= 16 B of zeros in global memory
+};
+bool tail_sh_supported(int Cin, int H, int W, int Cout);
+size_t tail_sh_packed_bytes(int Cin, int H, int W, int Cout);
+int tail_sh_mpad(int Cin, int H, int W, int Cout);   // padded row count of the packed image
+int launch_tail_sh(const TailShArgs& a, hipStream_t s);
+
 }  // namespace glowhip
