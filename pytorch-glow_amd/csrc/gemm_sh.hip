@@ -13,11 +13,12 @@
 
 namespace glowhip {
 
-constexpr int SH_BM = 128, SH_BN = 128, SH_BK = 32, SH_ST = 4;
-constexpr int SH_STAGE_HALFS = 2 * (2 * (SH_BK / 8) * 128 * 8);   // A + B: 16384 halfs = 32 KiB
+constexpr int SH_BM = 128, SH_BN = 128, SH_BK = 16, SH_ST = 4;
+constexpr int SH_A_HALFS = 2 * (SH_BK / 8) * 128 * 8;              // [plane][chunk 2][128][8] = 4096 halfs
+constexpr int SH_STAGE_HALFS = 2 * SH_A_HALFS;                    // A + B: 16 KiB -> 64 KiB ring, two workgroups per CU
 
 template <bool OUT_SH>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)
 k_gemm_sh(const _Float16* __restrict__ X, long P, const _Float16* __restrict__ Wsh, const float* __restrict__ bias,
           float* __restrict__ Yf, _Float16* __restrict__ Ysh, int K, int M, int HW, int relu) {
     extern __shared__ __attribute__((aligned(16))) _Float16 smem_h[];   // SH_ST stages
@@ -31,28 +32,30 @@ k_gemm_sh(const _Float16* __restrict__ X, long P, const _Float16* __restrict__ W
     const int kl = lane >> 5, ml = lane & 31;
     const long w_plane = (long)K * M, x_plane = P * (long)K;
 
-    // DMA sources of this lane: wave w streams chunk w of every stage; 4 A pieces (plane x 64-row half) + 4 B pieces
-    const _Float16* a_src = Wsh + ((long)wid * M + tile_m * SH_BM + lane) * 8;
+    // DMA sources of this lane: wave w streams (plane = w>>1, chunk = w&1) of every stage: 2 A pieces (64-row halves) + 2 B pieces
+    const int dpl = wid >> 1, dch = wid & 1;
+    const _Float16* a_src = Wsh + dpl * w_plane + ((long)dch * M + tile_m * SH_BM + lane) * 8;
     long px0 = (long)tile_n * SH_BN + lane, px1 = px0 + 64;
     px0 = px0 < P ? px0 : P - 1;   // ragged last tile: clamp the fetch, the stores are predicated
     px1 = px1 < P ? px1 : P - 1;
-    const _Float16* b_src0 = X + ((long)wid * P + px0) * 8;
-    const _Float16* b_src1 = X + ((long)wid * P + px1) * 8;
+    const _Float16* b_src0 = X + dpl * x_plane + ((long)dch * P + px0) * 8;
+    const _Float16* b_src1 = X + dpl * x_plane + ((long)dch * P + px1) * 8;
+#ifdef GLOWHIP_EXP_NOLOOP
+    const int nkt = 3;
+#else
     const int nkt = K / SH_BK;
+#endif
 
-    auto issue_piece = [&](int kt, int piece) {   // piece 0..3: A (plane = piece>>1, half = piece&1); 4..7: B likewise
-        _Float16* st = smem_h + (kt % SH_ST) * SH_STAGE_HALFS;
-        const int plane = (piece >> 1) & 1, half = piece & 1;
-        if (piece < 4) {
-            const _Float16* src = a_src + plane * w_plane + ((long)kt * 4 * M + half * 64) * 8;
+    auto issue_piece = [&](int kt, int piece) {   // piece 0,1: A halves; 2,3: B halves
+        _Float16* st = smem_h + (kt % SH_ST) * SH_STAGE_HALFS + ((dpl * 2 + dch) * 128 + (piece & 1) * 64) * 8;
+        if (piece < 2) {
+            const _Float16* src = a_src + ((long)kt * 2 * M + (piece & 1) * 64) * 8;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(st + ((plane * 4 + wid) * 128 + half * 64) * 8),
-                                             16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)st, 16, 0, 0);
         } else {
-            const _Float16* src = (half ? b_src1 : b_src0) + plane * x_plane + (long)kt * 4 * P * 8;
+            const _Float16* src = ((piece & 1) ? b_src1 : b_src0) + (long)kt * 2 * P * 8;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(st + 8192 + ((plane * 4 + wid) * 128 + half * 64) * 8),
-                                             16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(st + SH_A_HALFS), 16, 0, 0);
         }
     };
 
@@ -65,48 +68,52 @@ k_gemm_sh(const _Float16* __restrict__ X, long P, const _Float16* __restrict__ W
             for (int r = 0; r < 16; ++r) { accm[i][j][r] = 0.f; accx[i][j][r] = 0.f; }
 
 #pragma unroll
-    for (int t = 0; t < 3; ++t)
+    for (int t = 0; t < SH_ST - 1; ++t)
         if (t < nkt) {
 #pragma unroll
-            for (int pc = 0; pc < 8; ++pc) issue_piece(t, pc);
+            for (int pc = 0; pc < 4; ++pc) issue_piece(t, pc);
         }
 
+    const int a_off = (kl * 128 + wr * 64 + ml) * 8, b_off = SH_A_HALFS + (kl * 128 + wc * 64 + ml) * 8;
     for (int kt = 0; kt < nkt; ++kt) {
-        if (kt + 2 < nkt) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        else if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        if (SH_ST == 4 && kt + 2 < nkt) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        const _Float16* As = smem_h + (kt % SH_ST) * SH_STAGE_HALFS;
-        const _Float16* Bs = As + 8192;
-        const bool refill = kt + 3 < nkt;
+        const _Float16* st = smem_h + (kt % SH_ST) * SH_STAGE_HALFS;
+        h8 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int chunk = 2 * s + kl;
-            h8 ah[2], al[2], bh[2], bl[2];
+        for (int i = 0; i < 2; ++i) {
+            ah[i] = *reinterpret_cast<const h8*>(st + a_off + i * 256);
+            al[i] = *reinterpret_cast<const h8*>(st + a_off + i * 256 + 2 * 128 * 8);
+        }
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                ah[i] = *reinterpret_cast<const h8*>(As + ((0 * 4 + chunk) * 128 + wr * 64 + i * 32 + ml) * 8);
-                al[i] = *reinterpret_cast<const h8*>(As + ((1 * 4 + chunk) * 128 + wr * 64 + i * 32 + ml) * 8);
-            }
+        for (int j = 0; j < 2; ++j) {
+            bh[j] = *reinterpret_cast<const h8*>(st + b_off + j * 256);
+            bl[j] = *reinterpret_cast<const h8*>(st + b_off + j * 256 + 2 * 128 * 8);
+        }
+#ifndef GLOWHIP_EXP_NOREFILL
+        if (kt + SH_ST - 1 < nkt) {
+#pragma unroll
+            for (int pc = 0; pc < 4; ++pc) issue_piece(kt + SH_ST - 1, pc);
+        }
+#endif
+#ifdef GLOWHIP_EXP_NOMFMA
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) { accm[i][j][0] += (float)ah[i][0] * (float)bl[j][0]; accx[i][j][0] += (float)al[i][0] * (float)bh[j][0]; }
+#else
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                bh[j] = *reinterpret_cast<const h8*>(Bs + ((0 * 4 + chunk) * 128 + wc * 64 + j * 32 + ml) * 8);
-                bl[j] = *reinterpret_cast<const h8*>(Bs + ((1 * 4 + chunk) * 128 + wc * 64 + j * 32 + ml) * 8);
+                accm[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], accm[i][j], 0, 0, 0);
+                accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], accx[i][j], 0, 0, 0);
+                accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], accx[i][j], 0, 0, 0);
             }
-            if (refill) {
-#pragma unroll
-                for (int pc = 0; pc < 4; ++pc) issue_piece(kt + 3, s * 4 + pc);
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    accm[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], accm[i][j], 0, 0, 0);
-                    accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], accx[i][j], 0, 0, 0);
-                    accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], accx[i][j], 0, 0, 0);
-                }
-        }
+#endif
     }
 
     // ---- epilogue: main + cross / 2^11 + folded ActNorm bias, ReLU; C[row = channel][col = pixel]:
@@ -114,7 +121,11 @@ k_gemm_sh(const _Float16* __restrict__ X, long P, const _Float16* __restrict__ W
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const long px = (long)tile_n * SH_BN + wc * 64 + j * 32 + ml;
+#ifdef GLOWHIP_EXP_NOSTORE
+        const bool ok = px < P && relu == 77;
+#else
         const bool ok = px < P;
+#endif
         const long n = px / HW;
         const int p = (int)(px - n * HW);
 #pragma unroll

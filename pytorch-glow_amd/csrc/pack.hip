@@ -63,20 +63,23 @@ __global__ void __launch_bounds__(256) k_repack_batched(const RepackJob* __restr
         for (long o = (long)blockIdx.x * 256 + threadIdx.x; o < j.Cout; o += (long)gridDim.x * 256)
             fb[o] = j.fold_logs ? j.fold_bias[o] * expf(j.fold_logs[o] * LOGSCALE) : 0.f;
     } else if (j.kind == REPACK_SH_TAIL) {
-        // split-half tail image (tail_sh.hip): half [plane][Cin/8][Mpad][8], row m = tap*Cout + co, zero rows m >= 9*Cout
-        const int Mpad = j.Kpad;
-        const long total = (long)j.Cin * Mpad;
+        // split-half tail image (tail_sh.hip): half [group][plane][Cin/8][Mpad][8], row m = tap*Cg + co_in_group, zero rows
+        // m >= 9*Cg; j.MT = channel groups, j.Kpad = Mpad
+        const int Mpad = j.Kpad, groups = j.MT, Cg = j.Cout / groups;
+        const long per_plane = (long)j.Cin * Mpad, total = per_plane * groups;
         _Float16* oh = (_Float16*)out;
         for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-            const int k8 = (int)(e & 7);
-            const int m = (int)((e >> 3) % Mpad);
-            const int k = (int)((e >> 3) / Mpad) * 8 + k8;
-            const int tap = m / j.Cout, co = m - tap * j.Cout;
-            const float wv = m < 9 * j.Cout ? j.w[((long)co * j.Cin + k) * 9 + tap] : 0.f;
+            const int g = (int)(e / per_plane);
+            const long el = e - (long)g * per_plane;
+            const int k8 = (int)(el & 7);
+            const int m = (int)((el >> 3) % Mpad);
+            const int k = (int)((el >> 3) / Mpad) * 8 + k8;
+            const int tap = m / Cg, co = g * Cg + (m - tap * Cg);
+            const float wv = m < 9 * Cg ? j.w[((long)co * j.Cin + k) * 9 + tap] : 0.f;
             _Float16 hi, lo;
             sh_split(wv, hi, lo);
-            oh[e] = hi;
-            oh[total + e] = lo;
+            oh[(long)g * 2 * per_plane + el] = hi;
+            oh[(long)g * 2 * per_plane + per_plane + el] = lo;
         }
     } else {
         for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < j.total; e += (long)gridDim.x * 256) {

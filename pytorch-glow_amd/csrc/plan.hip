@@ -393,7 +393,7 @@ glowhip_plan* glowhip_plan_create(const glowhip_layer_desc* layers, int n_layers
             }
             if (L.sh_tail) {
                 RepackJob r{}; r.w = d.f4_w; r.out_off = L.f4_sh; r.kind = REPACK_SH_TAIL; r.Cin = d.hidden; r.Cout = L.Cout;
-                r.Kpad = tail_sh_mpad(d.hidden, d.H, d.W, L.Cout); p->repack_jobs.push_back(r);
+                r.Kpad = tail_sh_mpad(d.hidden, d.H, d.W, L.Cout, &r.MT); p->repack_jobs.push_back(r);
             }
             if (L.mfma_last) {
                 RepackJob r{}; r.w = d.f4_w; r.out_off = L.f4_wp; r.kind = REPACK_TAIL; r.Cin = d.hidden; r.Cout = L.Cout;

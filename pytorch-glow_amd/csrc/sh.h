@@ -52,7 +52,7 @@ int launch_gemm_sh(const _Float16* x_sh, const void* wsh, float* y_f32, _Float16
 // ---- f.4 + coupling on SH operands (tail_sh.hip) ---------------------------------------------------
 struct TailShArgs {
     const _Float16* x_sh; long P;     // h2 as an SH tensor of P = N*H*W pixels, Cin channels
-    const void* wsh;                  // packed image: half [2][Cin/8][Mpad][8], row m = tap*Cout + co (REPACK_SH_TAIL)
+    const void* wsh;                  // packed image: half [group][2][Cin/8][Mpad][8], row m = tap*Cg + co_in_group (REPACK_SH_TAIL)
     const float* bias;                // (Cout)
     const float* scale;               // (Cout) exp(3 logs)
     int N, Cin, H, W, Cout;
@@ -64,7 +64,7 @@ struct TailShArgs {
 };
 bool tail_sh_supported(int Cin, int H, int W, int Cout);
 size_t tail_sh_packed_bytes(int Cin, int H, int W, int Cout);
-int tail_sh_mpad(int Cin, int H, int W, int Cout);   // padded row count of the packed image
+int tail_sh_mpad(int Cin, int H, int W, int Cout, int* groups);   // padded rows per channel group of the packed image
 int launch_tail_sh(const TailShArgs& a, hipStream_t s);
 
 }  // namespace glowhip

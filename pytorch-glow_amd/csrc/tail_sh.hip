@@ -27,9 +27,11 @@ __device__ __forceinline__ float tsh_gauss_logp1(float mean, float logs, float x
 }
 
 template <int MW, int NW, int PPW>
-__global__ void __launch_bounds__(256) k_tail_sh(TailShArgs a, int WGM, int R, int Mpad, int Nwpad, int wshift) {
+__global__ void __launch_bounds__(256) k_tail_sh(TailShArgs a, int WGM, int R, int Mpad, int Nwpad, int wshift, int groups) {
     extern __shared__ __attribute__((aligned(16))) _Float16 smem_t[];
-    const int W = a.W, H = a.H, HW = H * W, K = a.Cin, Cout = a.Cout;
+    const int W = a.W, H = a.H, HW = H * W, K = a.Cin;
+    const int Cout = a.Cout / groups;                  // output channels of this workgroup's group (blockIdx.y)
+    const int c0 = blockIdx.y * Cout;
     const int Nw = (R + 2) * W;
     const int a_halfs = 4 * Mpad * 8;                  // [plane 2][chunk 2][Mpad][8]
     const int stage_halfs = a_halfs + 4 * Nwpad * 8;
@@ -61,7 +63,7 @@ __global__ void __launch_bounds__(256) k_tail_sh(TailShArgs a, int WGM, int R, i
         const int q = wid + 4 * i;
         if (q < 4 * pa) {
             const int pc = q / pa, rp = q - pc * pa;   // pc = plane*2 + chunk
-            src[i] = (const _Float16*)a.wsh + (pc >> 1) * w_plane + ((long)(pc & 1) * Mpad + rp * 64 + lane) * 8;
+            src[i] = (const _Float16*)a.wsh + ((long)blockIdx.y * 2 + (pc >> 1)) * w_plane + ((long)(pc & 1) * Mpad + rp * 64 + lane) * 8;
             adv[i] = (long)2 * Mpad * 8;
             ldso[i] = (pc * Mpad + rp * 64) * 8;
         } else if (q < PT) {
@@ -107,12 +109,14 @@ __global__ void __launch_bounds__(256) k_tail_sh(TailShArgs a, int WGM, int R, i
     for (int kt = 0; kt < nkt; ++kt) {
         // stage kt has landed once at most the two younger stages (PPW pieces each) are outstanding
         if (kt + 2 < nkt) {
-            if (PPW == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            if (PPW == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if (PPW == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else if (PPW == 5) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
             else if (PPW == 6) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
         } else if (kt + 1 < nkt) {
-            if (PPW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            if (PPW == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else if (PPW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             else if (PPW == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
             else if (PPW == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
@@ -182,11 +186,12 @@ __global__ void __launch_bounds__(256) k_tail_sh(TailShArgs a, int WGM, int R, i
                 if (paired) so += tp[Nwt];
             }
         const int p = (y0 + r) * W + x;
-        const long zi = n * a.z2_in_bs + (long)c * HW + p;
-        const long zo = n * a.z2_out_bs + (long)c * HW + p;
-        const float A_ = (se + a.bias[ce]) * a.scale[ce];
+        const int cg = (paired ? c0 / 2 : c0) + c;     // coupling channel in the full tensor
+        const long zi = n * a.z2_in_bs + (long)cg * HW + p;
+        const long zo = n * a.z2_out_bs + (long)cg * HW + p;
+        const float A_ = (se + a.bias[c0 + ce]) * a.scale[c0 + ce];
         if (paired) {
-            const float B_ = (so + a.bias[ce + 1]) * a.scale[ce + 1];
+            const float B_ = (so + a.bias[c0 + ce + 1]) * a.scale[c0 + ce + 1];
             const float sc = sigmoidf_(B_ + 2.0f);
             if (a.mode == TAIL_AFFINE_FWD) {
                 a.z2_out[zo] = (a.z2_in[zi] + A_) * sc;
@@ -206,20 +211,24 @@ __global__ void __launch_bounds__(256) k_tail_sh(TailShArgs a, int WGM, int R, i
     }
 }
 
-// ---- configuration: rows per workgroup by image width, wave grid by tile counts
-struct TailShCfg { int MW, NW, PPW, WGM, R, Mpad, Nwpad, wshift; };
+// ---- configuration: rows per workgroup by image width, channel groups over blockIdx.y, wave grid by tile counts
+struct TailShCfg { int MW, NW, PPW, WGM, R, Mpad, Nwpad, wshift, groups; };
 
 static bool tail_sh_config(int Cin, int H, int W, int Cout, TailShCfg* out) {
     if (Cin % 16 != 0 || Cin < 48) return false;
-    int R, wshift;
-    if (W == 32) { R = 4; wshift = 5; }
-    else if (W == 16) { R = 4; wshift = 4; }
-    else if (W == 8) { R = 2; wshift = 3; }
+    int R = 4, wshift;
+    if (W == 32) wshift = 5;
+    else if (W == 16) wshift = 4;
+    else if (W == 8) wshift = 3;
     else return false;
     if (H % R != 0) return false;
+    // 12 output channels (108 GEMM rows) per workgroup: the deep levels' many channels become many workgroups, and
+    // a workgroup's weight stream stays at 2 DMA pieces per wave and stage
+    const int groups = (Cout % 12 == 0 && H * W <= 64) ? Cout / 12 : 1;   // (measured: at 16x16 one group of 24 channels is faster)
+    const int Cg = Cout / groups;
     const int Nw = (R + 2) * W;
-    const int Mt = (9 * Cout + 31) / 32, Nt = (Nw + 31) / 32;
-    static const int inst[][3] = {{2, 3, 5}, {2, 3, 6}, {4, 1, 9}, {2, 2, 5}, {2, 2, 4}, {2, 1, 5}};
+    const int Mt = (9 * Cg + 31) / 32, Nt = (Nw + 31) / 32;
+    static const int inst[][3] = {{2, 3, 5}, {2, 2, 4}, {2, 1, 3}, {2, 2, 5}, {2, 3, 6}, {4, 1, 9}, {2, 1, 5}};
     int best = -1, best_cost = 1 << 30;
     TailShCfg bc{};
     for (int WGM = 1; WGM <= 4; WGM *= 2) {
@@ -231,12 +240,12 @@ static bool tail_sh_config(int Cin, int H, int W, int Cout, TailShCfg* out) {
         for (size_t i = 0; i < sizeof(inst) / sizeof(inst[0]); ++i)
             if (inst[i][0] == MW && inst[i][1] == NW && inst[i][2] == PPW && MW * NW < best_cost) {
                 best = (int)i; best_cost = MW * NW;
-                bc = TailShCfg{MW, NW, PPW, WGM, R, Mpad, Nwpad, wshift};
+                bc = TailShCfg{MW, NW, PPW, WGM, R, Mpad, Nwpad, wshift, groups};
             }
     }
     if (best < 0) return false;
     const size_t ring = (size_t)TSH_ST * 4 * (bc.Mpad + bc.Nwpad) * 8 * sizeof(_Float16);
-    const size_t tb = align_up((size_t)9 * Cout * (Nw + 8) * sizeof(float), 16);
+    const size_t tb = align_up((size_t)9 * Cg * (Nw + 8) * sizeof(float), 16);
     if (std::max(ring, tb) + 1024 + 64 > 160 * 1024) return false;
     if (out) *out = bc;
     return true;
@@ -247,12 +256,14 @@ bool tail_sh_supported(int Cin, int H, int W, int Cout) { return tail_sh_config(
 size_t tail_sh_packed_bytes(int Cin, int H, int W, int Cout) {
     TailShCfg c;
     if (!tail_sh_config(Cin, H, W, Cout, &c)) return 0;
-    return (size_t)2 * Cin * c.Mpad * sizeof(_Float16);
+    return (size_t)c.groups * 2 * Cin * c.Mpad * sizeof(_Float16);
 }
 
-int tail_sh_mpad(int Cin, int H, int W, int Cout) {
+int tail_sh_mpad(int Cin, int H, int W, int Cout, int* groups) {
     TailShCfg c;
-    return tail_sh_config(Cin, H, W, Cout, &c) ? c.Mpad : 0;
+    if (!tail_sh_config(Cin, H, W, Cout, &c)) return 0;
+    if (groups) *groups = c.groups;
+    return c.Mpad;
 }
 
 int launch_tail_sh(const TailShArgs& a, hipStream_t s) {
@@ -263,19 +274,20 @@ int launch_tail_sh(const TailShArgs& a, hipStream_t s) {
     if (a.N == 0) return GLOWHIP_OK;
     const int Nw = (c.R + 2) * a.W;
     const size_t ring = (size_t)TSH_ST * 4 * (c.Mpad + c.Nwpad) * 8 * sizeof(_Float16);
-    const size_t tb = align_up((size_t)9 * a.Cout * (Nw + 8) * sizeof(float), 16);
+    const size_t tb = align_up((size_t)9 * (a.Cout / c.groups) * (Nw + 8) * sizeof(float), 16);
     const size_t lds = std::max(ring, tb) + 1024 + 64;
     const unsigned grid = (unsigned)(a.N * (a.H / c.R));
 #define GH_TSH_CASE(mw, nw, ppw)                                                                                      \
     if (c.MW == mw && c.NW == nw && c.PPW == ppw) {                                                                   \
         (void)hipFuncSetAttribute((const void*)k_tail_sh<mw, nw, ppw>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
                                   (int)lds);                                                                          \
-        hipLaunchKernelGGL((k_tail_sh<mw, nw, ppw>), dim3(grid), dim3(256), lds, s, a, c.WGM, c.R, c.Mpad, c.Nwpad,  \
-                           c.wshift);                                                                                 \
+        hipLaunchKernelGGL((k_tail_sh<mw, nw, ppw>), dim3(grid, c.groups), dim3(256), lds, s, a, c.WGM, c.R, c.Mpad,  \
+                           c.Nwpad, c.wshift, c.groups);                                                              \
         GH_LAUNCH_CHECK("k_tail_sh");                                                                                 \
         return GLOWHIP_OK;                                                                                            \
     }
     GH_TSH_CASE(2, 3, 5) GH_TSH_CASE(2, 3, 6) GH_TSH_CASE(4, 1, 9) GH_TSH_CASE(2, 2, 5) GH_TSH_CASE(2, 2, 4) GH_TSH_CASE(2, 1, 5)
+    GH_TSH_CASE(2, 1, 3)
 #undef GH_TSH_CASE
     set_error("tail_sh: no kernel instance");
     return GLOWHIP_EINVAL;
