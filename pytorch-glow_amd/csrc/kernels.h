@@ -71,7 +71,7 @@ struct StepPrepJob {
 int launch_step_prepare_batched(const StepPrepJob* jobs_dev, int n, int max_lds_c, void* packed, hipStream_t s);
 
 struct ScaleJob { const float* logs; size_t scale_off, inv_off; int n; int has_inv; };
-enum { REPACK_WIDE = 0, REPACK_TAIL = 1, REPACK_FIRST = 2, REPACK_SH_GEMM = 3, REPACK_SH_TAIL = 4 };
+enum { REPACK_WIDE = 0, REPACK_TAIL = 1, REPACK_FIRST = 2, REPACK_SH_GEMM = 3, REPACK_SH_TAIL = 4, REPACK_SH_FIRST = 5 };
 struct RepackJob {
     const float* w; size_t out_off; int kind;
     int Cin, Cout, K, Kpad;      // wide: K = Cin*k*k

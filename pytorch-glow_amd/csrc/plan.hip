@@ -78,8 +78,10 @@ static int carve(const glowhip_plan* p, int N, void* ws, size_t bytes, Workspace
 // ---------------------------------------------------------------- coupling network f() (network/module.py:300-319)
 // Runs conv3x3 -> actnorm -> relu -> conv1x1 -> actnorm -> relu -> conv3x3(zeros) and applies the
 // coupling to z2.  x1: first-half channels (batch stride x1_bs).
-static bool g_sh_disabled = false, g_sh_tail_disabled = false;
-void plan_disable_sh(int off) { g_sh_disabled = (off & 1) != 0; g_sh_tail_disabled = (off & 2) != 0; }
+static bool g_sh_disabled = false, g_sh_tail_disabled = false, g_sh_first_disabled = false;
+void plan_disable_sh(int off) {
+    g_sh_disabled = (off & 1) != 0; g_sh_tail_disabled = (off & 2) != 0; g_sh_first_disabled = (off & 4) != 0;
+}
 
 static int run_coupling(glowhip_plan* P, const LayerPlan& L, const void* packed, const float* x1, long x1_bs, const float* z2_in,
                         long z2_in_bs, float* z2_out, long z2_out_bs, int N, int reverse, const Workspace& w,
@@ -91,7 +93,9 @@ static int run_coupling(glowhip_plan* P, const LayerPlan& L, const void* packed,
     // f.0: 3x3, Cin=C/2 -> hidden, ActNorm + ReLU epilogue
     {
     ScopedTimer t0(P, GLOWHIP_K_CONV_F0, L.mfma_first || L.first_halo, s);
-    if (L.first_halo) {
+    if (use_sh && L.sh_first && !g_sh_first_disabled) {
+        GH_TRY(launch_first_sh(x1, x1_bs, at<char>(packed, L.f0_sh), (_Float16*)w.h1, N, Ch, d.H, d.W, hid, 1, s));
+    } else if (L.first_halo) {
         const float* wf = at<float>(packed, L.f0_wt);
         GH_TRY(launch_conv_mfma_first(x1, x1_bs, wf, wf + (size_t)9 * Ch * hid, w.h1, N, Ch, d.H, d.W, hid, s, 1,
                                       use_sh ? (_Float16*)w.h1 : nullptr));
@@ -336,6 +340,8 @@ glowhip_plan* glowhip_plan_create(const glowhip_layer_desc* layers, int n_layers
             if (L.mfma_mid) L.f2_wt = take(off, conv_mfma_wide_packed_bytes(d.hidden, d.hidden, 1));
             L.sh_mid = L.first_halo && gemm_sh_supported(d.hidden, d.hidden, H, W);
             if (L.sh_mid) L.f2_sh = take(off, gemm_sh_packed_bytes(d.hidden, d.hidden));
+            L.sh_first = L.sh_mid && first_sh_supported(C / 2, H, W, d.hidden);
+            if (L.sh_first) L.f0_sh = take(off, first_sh_packed_bytes(C / 2, d.hidden));
             L.sh_tail = L.sh_mid && tail_sh_supported(d.hidden, H, W, L.Cout);
             if (L.sh_tail) L.f4_sh = take(off, tail_sh_packed_bytes(d.hidden, H, W, L.Cout));
             if (L.mfma_last) L.f4_wp = take(off, conv_mfma_tail_packed_bytes(d.hidden, L.Cout));
@@ -390,6 +396,11 @@ glowhip_plan* glowhip_plan_create(const glowhip_layer_desc* layers, int n_layers
             if (L.sh_mid) {
                 RepackJob r{}; r.w = d.f2_w; r.out_off = L.f2_sh; r.kind = REPACK_SH_GEMM; r.Cin = d.hidden; r.Cout = d.hidden;
                 r.K = d.hidden; r.fold_bias = d.f2_an_bias; r.fold_logs = d.f2_an_logs; p->repack_jobs.push_back(r);
+            }
+            if (L.sh_first) {
+                RepackJob r{}; r.w = d.f0_w; r.out_off = L.f0_sh; r.kind = REPACK_SH_FIRST; r.Cin = d.C / 2; r.Cout = d.hidden;
+                r.K = (9 * ((r.Cin + 7) / 8) + 1) & ~1; r.fold_bias = d.f0_an_bias; r.fold_logs = d.f0_an_logs;
+                p->repack_jobs.push_back(r);
             }
             if (L.sh_tail) {
                 RepackJob r{}; r.w = d.f4_w; r.out_off = L.f4_sh; r.kind = REPACK_SH_TAIL; r.Cin = d.hidden; r.Cout = L.Cout;

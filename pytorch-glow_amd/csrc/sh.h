@@ -49,6 +49,13 @@ size_t gemm_sh_packed_bytes(int K, int M);
 int launch_gemm_sh(const _Float16* x_sh, const void* wsh, float* y_f32, _Float16* y_sh, int N, int K, int HW, int M, int relu,
                    hipStream_t s);
 
+// ---- f.0 on SH operands (first_sh.hip): fp32 z in, SH h1 out -----------------------------------------
+// wsh: half [2][G][Cout][8] (k group g = tap * nchunk + chunk, 8 channels each; ActNorm scale folded), then Cout floats b'
+bool first_sh_supported(int Cin, int H, int W, int Cout);
+size_t first_sh_packed_bytes(int Cin, int Cout);
+int launch_first_sh(const float* x, long x_bs, const void* wsh, _Float16* y_sh, int N, int Cin, int H, int W, int Cout,
+                    int relu, hipStream_t s);
+
 // ---- f.4 + coupling on SH operands (tail_sh.hip) ---------------------------------------------------
 struct TailShArgs {
     const _Float16* x_sh; long P;     // h2 as an SH tensor of P = N*H*W pixels, Cin channels
