@@ -14,12 +14,11 @@
 
 namespace glowhip {
 
-template <int NT>
+template <int NT, int R>
 __global__ void __launch_bounds__(256)
 k_first_sh(const float* __restrict__ X, long x_bs, const _Float16* __restrict__ Wsh, const float* __restrict__ bias,
            _Float16* __restrict__ Ysh, int N, int Cin, int H, int W, int M, int wshift, int relu) {
     extern __shared__ __attribute__((aligned(16))) _Float16 smem_f[];
-    constexpr int R = 4;
     const int HW = H * W, WP = W + 2, Wpx = (R + 2) * WP;
     const int nchunk = (Cin + 7) >> 3;
     const int G = (9 * nchunk + 1) & ~1;              // 8-wide k groups, padded to an even count (k16 steps)
@@ -126,12 +125,13 @@ k_first_sh(const float* __restrict__ X, long x_bs, const _Float16* __restrict__ 
     }
 }
 
+static int first_sh_rows(int W) { return W == 32 ? 2 : 4; }   // 64 / 64 / 32 pixels per workgroup: 3+ workgroups per CU
 static int first_sh_groups(int Cin) { return (9 * ((Cin + 7) / 8) + 1) & ~1; }
 
 bool first_sh_supported(int Cin, int H, int W, int Cout) {
     if (Cout % 128 != 0 || Cin < 1 || Cin > 64) return false;
     if (W != 8 && W != 16 && W != 32) return false;
-    return H % 4 == 0;
+    return H % first_sh_rows(W) == 0;
 }
 
 size_t first_sh_packed_bytes(int Cin, int Cout) {
@@ -145,17 +145,18 @@ int launch_first_sh(const float* x, long x_bs, const void* wsh, _Float16* y_sh, 
     const int G = first_sh_groups(Cin), nchunk = (Cin + 7) / 8;
     const _Float16* w = (const _Float16*)wsh;
     const float* bias = (const float*)((const char*)wsh + align_up((size_t)2 * G * Cout * 8 * sizeof(_Float16), 16));
-    const size_t lds = (size_t)2 * nchunk * 6 * (W + 2) * 8 * sizeof(_Float16);
-    const unsigned grid = (unsigned)(N * (H / 4));
+    const int R = first_sh_rows(W);
+    const size_t lds = (size_t)2 * nchunk * (R + 2) * (W + 2) * 8 * sizeof(_Float16);
+    const unsigned grid = (unsigned)(N * (H / R));
     const int wshift = W == 32 ? 5 : (W == 16 ? 4 : 3);
-#define GH_FSH_CASE(nt)                                                                                               \
-    if (4 * W == 32 * nt) {                                                                                           \
-        hipLaunchKernelGGL((k_first_sh<nt>), dim3(grid, Cout / 128), dim3(256), lds, s, x, x_bs, w, bias, y_sh, N, Cin, H, W, \
+#define GH_FSH_CASE(nt, r)                                                                                            \
+    if (R == r && r * W == 32 * nt) {                                                                                           \
+        hipLaunchKernelGGL((k_first_sh<nt, r>), dim3(grid, Cout / 128), dim3(256), lds, s, x, x_bs, w, bias, y_sh, N, Cin, H, W, \
                            Cout, wshift, relu);                                                                       \
         GH_LAUNCH_CHECK("k_first_sh");                                                                                \
         return GLOWHIP_OK;                                                                                            \
     }
-    GH_FSH_CASE(4) GH_FSH_CASE(2) GH_FSH_CASE(1)
+    GH_FSH_CASE(2, 2) GH_FSH_CASE(2, 4) GH_FSH_CASE(1, 4)
 #undef GH_FSH_CASE
     set_error("first_sh: no kernel instance");
     return GLOWHIP_EINVAL;

@@ -17,6 +17,58 @@ constexpr int SH_BM = 128, SH_BN = 128, SH_BK = 16, SH_ST = 4;
 constexpr int SH_A_HALFS = 2 * (SH_BK / 8) * 128 * 8;              // [plane][chunk 2][128][8] = 4096 halfs
 constexpr int SH_STAGE_HALFS = 2 * SH_A_HALFS;                    // A + B: 16 KiB -> 64 KiB ring, two workgroups per CU
 
+// Epilogue shared by the GEMM variants: main + cross / 2^11 + folded ActNorm bias, ReLU; C[row = channel][col = pixel]:
+// lane (kl, ml) holds pixel ml and channels 8*(r>>2) + 4*kl + (r&3) of each 32-row tile.
+template <bool OUT_SH>
+__device__ __forceinline__ void gemm_sh_epilogue(const f32x16_t (&accm)[2][2], const f32x16_t (&accx)[2][2],
+                                                 const float* __restrict__ bias, float* __restrict__ Yf,
+                                                 _Float16* __restrict__ Ysh, long P, int M, int HW, int relu, int tile_m,
+                                                 int tile_n, int wr, int wc, int kl, int ml) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const long px = (long)tile_n * SH_BN + wc * 64 + j * 32 + ml;
+#ifdef GLOWHIP_EXP_NOSTORE
+        const bool ok = px < P && relu == 77;
+#else
+        const bool ok = px < P;
+#endif
+        const long n = px / HW;
+        const int p = (int)(px - n * HW);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int o0 = tile_m * SH_BM + wr * 64 + i * 32 + 8 * g + 4 * kl;
+                const f32x4_t b4 = *reinterpret_cast<const f32x4_t*>(bias + o0);
+                float v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float t = accm[i][j][4 * g + q] + accx[i][j][4 * g + q] * SH_LO_INV + b4[q];
+                    v[q] = relu ? fmaxf(t, 0.f) : t;
+                }
+                if (OUT_SH) {
+                    h4 hi, lo;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        _Float16 a, b;
+                        sh_split(v[q], a, b);
+                        hi[q] = a; lo[q] = b;
+                    }
+                    if (ok) {
+                        _Float16* dst = Ysh + ((long)(o0 >> 3) * P + px) * 8 + (o0 & 7);
+                        *reinterpret_cast<h4*>(dst) = hi;
+                        *reinterpret_cast<h4*>(dst + P * (long)M) = lo;
+                    }
+                } else if (ok) {
+                    float* dst = Yf + (n * M + o0) * (long)HW + p;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) dst[(long)q * HW] = v[q];
+                }
+            }
+        }
+    }
+}
+
 template <bool OUT_SH>
 __global__ void __launch_bounds__(256, 2)
 k_gemm_sh(const _Float16* __restrict__ X, long P, const _Float16* __restrict__ Wsh, const float* __restrict__ bias,
@@ -116,51 +168,7 @@ k_gemm_sh(const _Float16* __restrict__ X, long P, const _Float16* __restrict__ W
 #endif
     }
 
-    // ---- epilogue: main + cross / 2^11 + folded ActNorm bias, ReLU; C[row = channel][col = pixel]:
-    // lane (kl, ml) holds pixel ml and channels 8*(r>>2) + 4*kl + (r&3) of each 32-row tile
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const long px = (long)tile_n * SH_BN + wc * 64 + j * 32 + ml;
-#ifdef GLOWHIP_EXP_NOSTORE
-        const bool ok = px < P && relu == 77;
-#else
-        const bool ok = px < P;
-#endif
-        const long n = px / HW;
-        const int p = (int)(px - n * HW);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int o0 = tile_m * SH_BM + wr * 64 + i * 32 + 8 * g + 4 * kl;
-                const f32x4_t b4 = *reinterpret_cast<const f32x4_t*>(bias + o0);
-                float v[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float t = accm[i][j][4 * g + q] + accx[i][j][4 * g + q] * SH_LO_INV + b4[q];
-                    v[q] = relu ? fmaxf(t, 0.f) : t;
-                }
-                if (OUT_SH) {
-                    h4 hi, lo;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        _Float16 a, b;
-                        sh_split(v[q], a, b);
-                        hi[q] = a; lo[q] = b;
-                    }
-                    if (ok) {
-                        _Float16* dst = Ysh + ((long)(o0 >> 3) * P + px) * 8 + (o0 & 7);
-                        *reinterpret_cast<h4*>(dst) = hi;
-                        *reinterpret_cast<h4*>(dst + P * (long)M) = lo;
-                    }
-                } else if (ok) {
-                    float* dst = Yf + (n * M + o0) * (long)HW + p;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) dst[(long)q * HW] = v[q];
-                }
-            }
-        }
-    }
+    gemm_sh_epilogue<OUT_SH>(accm, accx, bias, Yf, Ysh, P, M, HW, relu, tile_m, tile_n, wr, wc, kl, ml);
 }
 
 bool gemm_sh_supported(int K, int M, int H, int W) {

@@ -492,9 +492,15 @@ int glowhip_plan_describe(const glowhip_plan* plan, char* buf, size_t buf_bytes)
         const glowhip_layer_desc& d = L.d;
         if (d.kind == GLOWHIP_LAYER_SQUEEZE) snprintf(line, sizeof line, "%d squeeze C=%d H=%d W=%d\n", li, d.C, d.H, d.W);
         else if (d.kind == GLOWHIP_LAYER_FLOWSTEP)
-            snprintf(line, sizeof line, "%d flowstep C=%d H=%d W=%d hidden=%d f0=%s f2=%s f4=%s\n", li, d.C, d.H, d.W,
-                     d.hidden, L.first_halo ? "mfma-halo" : (L.mfma_first ? "mfma" : "direct"), L.mfma_mid ? "mfma" : "direct",
-                     L.mfma_last ? "mfma" : "direct");
+        {
+            // "-sh": split-half f16 matrix-pipe kernels (sh.h) are selected for this convolution (unless disabled by the
+            // debug switch); the name before it is the exact-fp32 kernel that would run otherwise
+            const bool sh = L.sh_mid && !g_sh_disabled;
+            snprintf(line, sizeof line, "%d flowstep C=%d H=%d W=%d hidden=%d f0=%s%s f2=%s%s f4=%s%s\n", li, d.C, d.H, d.W,
+                     d.hidden, L.first_halo ? "mfma-halo" : (L.mfma_first ? "mfma" : "direct"),
+                     sh && L.sh_first && !g_sh_first_disabled ? "-sh" : "", L.mfma_mid ? "mfma" : "direct", sh ? "-sh" : "",
+                     L.mfma_last ? "mfma" : "direct", sh && L.sh_tail && !g_sh_tail_disabled ? "-sh" : "");
+        }
         else snprintf(line, sizeof line, "%d split2d C=%d H=%d W=%d prior=%s\n", li, d.C, d.H, d.W,
                       L.mfma_last ? "mfma" : "direct");
         sdesc += line;
