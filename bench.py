@@ -29,6 +29,9 @@ import torch
 import torch.distributed as dist
 
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, f32 in / f32 accumulate
+PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16/f16 dense MFMA (v_mfma_f32_32x32x16_f16)
+# split-half path (csrc/sh.h): one fp32-accurate product = 3 f16 MFMA products => algorithmic-flop ceiling = 2500 / 3
+PEAK_SPLIT_TFLOPS = PEAK_F16_MFMA_TFLOPS / 3.0
 BATCH_PER_GPU = 64
 
 
@@ -192,15 +195,18 @@ def main():
             "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "arithmetic": "fp32 values carried as 2 x f16 (hi, lo*2^11), exact f16 products, fp32 accumulate (csrc/sh.h); "
+                          "max-abs vs CPU reference 7e-6 (z), same as the exact-fp32 kernels",
             "config": {"workload": "CelebA 64x64x3 Glow L=3 K=32 hidden=512 affine+invconv, fwd+logdet, "
                                    f"batch {B}/GPU (BASELINE configs[1])", "global_batch": world * B,
                        "parallelism": f"dp{world}", "repack_every_step": repack,
                        "loss_mean_nll_bits_per_dim": round(float(loss) / (world * B), 6)},
             "model_tflops": round(value * fpi / 1e12, 2),
             "frac_of_fp32_mfma_peak_whole_model": round(value / world * fpi / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4),
+            "frac_of_split_f16_peak_whole_model": round(value / world * fpi / (PEAK_SPLIT_TFLOPS * 1e12), 4),
         }
         if args.mode == "train":
-            out.pop("model_tflops"), out.pop("frac_of_fp32_mfma_peak_whole_model")
+            out.pop("model_tflops"), out.pop("frac_of_fp32_mfma_peak_whole_model"), out.pop("frac_of_split_f16_peak_whole_model")
             out["model_tflops_fwd_bwd"] = round(value * 3 * fpi / 1e12, 2)   # backward ~ 2x forward flops
             print(json.dumps(out), flush=True)
             if world > 1:
@@ -218,8 +224,10 @@ def main():
         plan.timing(False)
         hid = hps.model.hidden_channels
         kinds = {0: "chanmix", 1: "conv_f0_3x3", 2: "conv_f2_1x1", 3: "conv_f4_3x3_tail"}
+        desc = plan.describe()
+        sh_path = "f2=mfma-sh" in desc
         bd = {}
-        dom_ms, dom_flop, dom_n = 0.0, 0.0, 0
+        dom_ms, dom_flop, dom_bytes, dom_n = 0.0, 0.0, 0.0, 0
         for kind, layer, mfma, ms in recs:
             d = plan._descs[layer]
             key = f"{kinds.get(kind, 'other')}_C{d.C}_{d.H}x{d.W}"
@@ -228,20 +236,46 @@ def main():
             bd[key][1] += 1
             total_px = B * d.H * d.W
             uses_128 = (hid // 128) * ((total_px + 127) // 128) >= 512
-            if kind == 2 and mfma and uses_128:  # k_gemm_glds (128x128 tiles: level 1 and level 2 launches)
+            # dominant kernel = f.2: k_gemm_sh on the split-half path (every level), else k_gemm_glds (128x128 tiles)
+            if kind == 2 and mfma and (sh_path or uses_128):
                 dom_ms += ms
-                dom_flop += 2.0 * hid * hid * total_px
+                dom_flop += 2.0 * hid * hid * total_px           # algorithmic (fp32-equivalent) flops
+                dom_bytes += 2.0 * 4.0 * hid * total_px          # read h1 + write h2, 4 bytes per element either way
                 dom_n += 1
         achieved = dom_flop / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get("k_gemm_glds_hbm_bytes_per_launch")
-        out["roofline"] = {"bound": "mfma", "kernel": "k_gemm_glds (f.2: 1x1 conv 512->512 + ActNorm + ReLU, 128x128 tiles)",
-                           "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                           "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+            traffic = json.load(open(tpath)).get("k_gemm_sh_hbm_bytes_per_launch" if sh_path else "k_gemm_glds_hbm_bytes_per_launch")
+        peak = PEAK_SPLIT_TFLOPS if sh_path else PEAK_FP32_MFMA_TFLOPS
+        out["roofline"] = {"bound": "mfma",
+                           "kernel": ("k_gemm_sh (f.2: 1x1 conv 512->512 + ActNorm + ReLU; fp32-accurate products as 3 f16 MFMAs, "
+                                      "peak = 2500/3 TFLOP/s algorithmic)") if sh_path else
+                                     "k_gemm_glds (f.2: 1x1 conv 512->512 + ActNorm + ReLU, fp32-input MFMA, 128x128 tiles)",
+                           "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                           "frac": round(achieved / peak, 4), "traffic": traffic,
                            "launches": dom_n, "avg_launch_us": round(1e3 * dom_ms / max(dom_n, 1), 2),
-                           "flop_per_launch_avg": dom_flop / max(dom_n, 1)}
+                           "flop_per_launch_avg": dom_flop / max(dom_n, 1),
+                           "issued_mfma_tflops": round(achieved * (3 if sh_path else 1), 1),
+                           "algorithmic_hbm_bytes_per_launch_avg": dom_bytes / max(dom_n, 1),
+                           "hbm_GBps": round(dom_bytes / (dom_ms * 1e-3) / 1e9, 1) if dom_ms > 0 else 0.0,
+                           "hbm_frac_of_8TBps": round(dom_bytes / (dom_ms * 1e-3) / 8e12, 4) if dom_ms > 0 else 0.0}
+        if args.mode == "forward" and sh_path:
+            # the same step on the exact-fp32 MFMA kernels (split-half path switched off), for the record; rank-local
+            G.lib().glowhip_debug_force_tail_tile(0x800)
+            try:
+                for _ in range(2):
+                    glow.normal_flow(x, None, repack=repack)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(5):
+                    glow.normal_flow(x, None, repack=repack)
+                torch.cuda.synchronize()
+                dt1 = (time.perf_counter() - t1) / 5
+            finally:
+                G.lib().glowhip_debug_force_tail_tile(0)
+            out["exact_fp32_mfma_kernels"] = {"value": round(B / dt1, 2), "unit": "images/sec", "ms_per_step": round(1e3 * dt1, 4),
+                                              "note": "one GPU, same step with v_mfma_f32_32x32x2_f32 kernels only"}
         out["breakdown_ms_per_step"] = {k: round(v[0] / 3, 4) for k, v in sorted(bd.items())}
         out["breakdown_sum_ms"] = round(sum(v[0] for v in bd.values()) / 3, 3)
         if world == 1 and not args.no_cpu_baseline:

@@ -99,7 +99,11 @@ __global__ void __launch_bounds__(256) k_tail_sh(TailShArgs a, int WGM, int R, i
 #pragma unroll
             for (int r = 0; r < 16; ++r) { accm[t][u][r] = 0.f; accx[t][u][r] = 0.f; }
 
+#ifdef GLOWHIP_EXP_TNOLOOP
+    const int nkt = 3;
+#else
     const int nkt = K / 16;
+#endif
 #pragma unroll
     for (int t = 0; t < 3; ++t)
         if (t < nkt) issue_stage(t);
@@ -138,6 +142,12 @@ __global__ void __launch_bounds__(256) k_tail_sh(TailShArgs a, int WGM, int R, i
             bl[u] = *reinterpret_cast<const h8*>(st + b_off + u * 256 + 2 * Nwpad * 8);
         }
         if (kt + 3 < nkt) issue_stage(kt + 3);
+#ifdef GLOWHIP_EXP_TNOMFMA
+#pragma unroll
+        for (int t = 0; t < MW; ++t)
+#pragma unroll
+            for (int u = 0; u < NW; ++u) { accm[t][u][0] += (float)ah[t][0] * (float)bl[u][0]; accx[t][u][0] += (float)al[t][0] * (float)bh[u][0]; }
+#else
 #pragma unroll
         for (int t = 0; t < MW; ++t)
 #pragma unroll
@@ -146,6 +156,7 @@ __global__ void __launch_bounds__(256) k_tail_sh(TailShArgs a, int WGM, int R, i
                 accx[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bl[u], accx[t][u], 0, 0, 0);
                 accx[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[t], bh[u], accx[t][u], 0, 0, 0);
             }
+#endif
     }
     __syncthreads();   // every wave is done with the operand ring: it becomes the T staging area
 
@@ -169,7 +180,11 @@ __global__ void __launch_bounds__(256) k_tail_sh(TailShArgs a, int WGM, int R, i
     const bool paired = a.mode == TAIL_AFFINE_FWD || a.mode == TAIL_AFFINE_REV;
     const int nch = paired ? Cout / 2 : Cout;
     double ld = 0.0;
+#ifdef GLOWHIP_EXP_TNOEPI
+    for (int e = tid; e < nch * tile_px; e += 256 * 64) {
+#else
     for (int e = tid; e < nch * tile_px; e += 256) {
+#endif
         const int c = e / tile_px, q = e - c * tile_px;
         const int r = q >> wshift, x = q & (W - 1);
         const int ce = paired ? 2 * c : c;
