@@ -134,6 +134,9 @@ def main():
     from pytorch_glow_amd.misc import util
     from pytorch_glow_amd import parallel
 
+    dbg = int(os.environ.get("GLOWHIP_DEBUG_FLAGS", "0"), 0)   # kernel-variant A/B runs (scripts/ab_flags.sh); 0 = product default
+    if dbg:
+        G.lib().glowhip_debug_force_tail_tile(dbg)
     B = args.batch
     glow, hps = build_model(G, util, device, B)
     x = torch.rand(B, 3, 64, 64, generator=torch.Generator().manual_seed(2384 + rank)).to(device)

@@ -73,5 +73,6 @@ bool tail_sh_supported(int Cin, int H, int W, int Cout);
 size_t tail_sh_packed_bytes(int Cin, int H, int W, int Cout);
 int tail_sh_mpad(int Cin, int H, int W, int Cout, int* groups);   // padded rows per channel group of the packed image
 int launch_tail_sh(const TailShArgs& a, hipStream_t s);
+void tail_sh_force_ks(int ks);   // testing hook: k-steps per ring stage (0 = automatic)
 
 }  // namespace glowhip

@@ -19,24 +19,25 @@
 
 namespace glowhip {
 
-constexpr int TSH_ST = 4;
 
 __device__ __forceinline__ float tsh_gauss_logp1(float mean, float logs, float x) {
     const float d = x - mean;
     return -0.5f * (LOG_2PI_F + 2.0f * logs + (d * d) / expf(2.0f * logs));
 }
 
-template <int MW, int NW, int PPW>
+// KS = 16-deep k-steps per ring stage, ST = ring stages; PPW1 = DMA pieces per wave and k-step
+template <int MW, int NW, int PPW1, int KS, int ST>
 __global__ void __launch_bounds__(256) k_tail_sh(TailShArgs a, int WGM, int R, int Mpad, int Nwpad, int wshift, int groups) {
     extern __shared__ __attribute__((aligned(16))) _Float16 smem_t[];
     const int W = a.W, H = a.H, HW = H * W, K = a.Cin;
     const int Cout = a.Cout / groups;                  // output channels of this workgroup's group (blockIdx.y)
     const int c0 = blockIdx.y * Cout;
     const int Nw = (R + 2) * W;
-    const int a_halfs = 4 * Mpad * 8;                  // [plane 2][chunk 2][Mpad][8]
-    const int stage_halfs = a_halfs + 4 * Nwpad * 8;
+    constexpr int PPW = PPW1 * KS, NCH = 2 * KS;       // pieces per wave and stage; 8-channel chunks per stage
+    const int a_halfs = 2 * NCH * Mpad * 8;            // [plane 2][chunk NCH][Mpad][8]
+    const int stage_halfs = a_halfs + 2 * NCH * Nwpad * 8;
     const int M9 = 9 * Cout, Nwt = Nw + 8;
-    const size_t ring_bytes = (size_t)TSH_ST * stage_halfs * sizeof(_Float16);
+    const size_t ring_bytes = (size_t)ST * stage_halfs * sizeof(_Float16);
     const size_t t_bytes = ((size_t)M9 * Nwt * sizeof(float) + 15) & ~(size_t)15;
     char* tailp = (char*)smem_t + (ring_bytes > t_bytes ? ring_bytes : t_bytes);
     _Float16* dummy = (_Float16*)tailp;                // 1 KiB landing area of padding DMA pieces
@@ -52,7 +53,7 @@ __global__ void __launch_bounds__(256) k_tail_sh(TailShArgs a, int WGM, int R, i
     const int y0 = (int)(blockIdx.x - n * bpi) * R;
     const long P = a.P;
     const long w_plane = (long)K * Mpad, x_plane = P * (long)K;
-    const int pa = Mpad >> 6, pb = Nwpad >> 6, PT = 4 * (pa + pb);
+    const int pa = Mpad >> 6, pb = Nwpad >> 6, PT = 2 * NCH * (pa + pb);
 
     // ---- DMA pieces of this wave: q = wid + 4*i.  A pieces first ((plane, chunk, 64-row group)), then B pieces
     const _Float16* src[PPW];
@@ -61,27 +62,29 @@ __global__ void __launch_bounds__(256) k_tail_sh(TailShArgs a, int WGM, int R, i
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
         const int q = wid + 4 * i;
-        if (q < 4 * pa) {
-            const int pc = q / pa, rp = q - pc * pa;   // pc = plane*2 + chunk
-            src[i] = (const _Float16*)a.wsh + ((long)blockIdx.y * 2 + (pc >> 1)) * w_plane + ((long)(pc & 1) * Mpad + rp * 64 + lane) * 8;
-            adv[i] = (long)2 * Mpad * 8;
+        if (q < 2 * NCH * pa) {
+            const int pc = q / pa, rp = q - pc * pa;   // pc = plane*NCH + chunk
+            const int pl = pc / NCH, chk = pc - pl * NCH;
+            src[i] = (const _Float16*)a.wsh + ((long)blockIdx.y * 2 + pl) * w_plane + ((long)chk * Mpad + rp * 64 + lane) * 8;
+            adv[i] = (long)NCH * Mpad * 8;
             ldso[i] = (pc * Mpad + rp * 64) * 8;
         } else if (q < PT) {
-            const int qb = q - 4 * pa;
+            const int qb = q - 2 * NCH * pa;
             const int pc = qb / pb, sp = qb - pc * pb;
+            const int pl = pc / NCH, chk = pc - pl * NCH;
             const int slot = sp * 64 + lane;           // window pixel
             const int yy = y0 - 1 + (slot >> wshift);
             const bool ok = slot < Nw && yy >= 0 && yy < H;
             const long gpx = n * HW + (long)(y0 - 1) * W + slot;
-            src[i] = ok ? a.x_sh + (pc >> 1) * x_plane + ((long)(pc & 1) * P + gpx) * 8 : (const _Float16*)a.zeros;
-            adv[i] = ok ? (long)2 * P * 8 : 0;
+            src[i] = ok ? a.x_sh + pl * x_plane + ((long)chk * P + gpx) * 8 : (const _Float16*)a.zeros;
+            adv[i] = ok ? (long)NCH * P * 8 : 0;
             ldso[i] = a_halfs + (pc * Nwpad + sp * 64) * 8;
         } else {
             src[i] = (const _Float16*)a.zeros; adv[i] = 0; ldso[i] = -1;
         }
     }
     auto issue_stage = [&](int kt) {
-        _Float16* st = smem_t + (kt % TSH_ST) * stage_halfs;
+        _Float16* st = smem_t + (kt % ST) * stage_halfs;
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
             _Float16* dst = ldso[i] >= 0 ? st + ldso[i] : dummy;
@@ -100,63 +103,54 @@ __global__ void __launch_bounds__(256) k_tail_sh(TailShArgs a, int WGM, int R, i
             for (int r = 0; r < 16; ++r) { accm[t][u][r] = 0.f; accx[t][u][r] = 0.f; }
 
 #ifdef GLOWHIP_EXP_TNOLOOP
-    const int nkt = 3;
+    const int nkt = ST - 1;
 #else
-    const int nkt = K / 16;
+    const int nkt = K / (16 * KS);
 #endif
 #pragma unroll
-    for (int t = 0; t < 3; ++t)
+    for (int t = 0; t < ST - 1; ++t)
         if (t < nkt) issue_stage(t);
 
-    const int a_off = (kl * Mpad + wm * MW * 32 + ml) * 8;         // + t*256 ; lo plane: + 2*Mpad*8
+    const int a_off = (kl * Mpad + wm * MW * 32 + ml) * 8;         // + ks*2*Mpad*8 + t*256 ; lo plane: + NCH*Mpad*8
     const int b_off = a_halfs + (kl * Nwpad + wn * NW * 32 + ml) * 8;
     for (int kt = 0; kt < nkt; ++kt) {
-        // stage kt has landed once at most the two younger stages (PPW pieces each) are outstanding
-        if (kt + 2 < nkt) {
-            if (PPW == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else if (PPW == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else if (PPW == 5) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-            else if (PPW == 6) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
-        } else if (kt + 1 < nkt) {
-            if (PPW == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-            else if (PPW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else if (PPW == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-            else if (PPW == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        // stage kt has landed once at most the ST-2 younger stages (PPW pieces each) are outstanding
+        if (kt + ST - 2 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((ST - 2) * PPW) : "memory");
+        else if (ST == 4 && kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        const _Float16* st = smem_t + (kt % TSH_ST) * stage_halfs;
-        h8 ah[MW], al[MW], bh[NW], bl[NW];
+        const _Float16* st = smem_t + (kt % ST) * stage_halfs;
+        if (kt + ST - 1 < nkt) issue_stage(kt + ST - 1);
 #pragma unroll
-        for (int t = 0; t < MW; ++t) {
-            ah[t] = *reinterpret_cast<const h8*>(st + a_off + t * 256);
-            al[t] = *reinterpret_cast<const h8*>(st + a_off + t * 256 + 2 * Mpad * 8);
-        }
+        for (int ks = 0; ks < KS; ++ks) {
+            h8 ah[MW], al[MW], bh[NW], bl[NW];
 #pragma unroll
-        for (int u = 0; u < NW; ++u) {
-            bh[u] = *reinterpret_cast<const h8*>(st + b_off + u * 256);
-            bl[u] = *reinterpret_cast<const h8*>(st + b_off + u * 256 + 2 * Nwpad * 8);
-        }
-        if (kt + 3 < nkt) issue_stage(kt + 3);
-#ifdef GLOWHIP_EXP_TNOMFMA
-#pragma unroll
-        for (int t = 0; t < MW; ++t)
-#pragma unroll
-            for (int u = 0; u < NW; ++u) { accm[t][u][0] += (float)ah[t][0] * (float)bl[u][0]; accx[t][u][0] += (float)al[t][0] * (float)bh[u][0]; }
-#else
-#pragma unroll
-        for (int t = 0; t < MW; ++t)
+            for (int t = 0; t < MW; ++t) {
+                ah[t] = *reinterpret_cast<const h8*>(st + a_off + ks * 2 * Mpad * 8 + t * 256);
+                al[t] = *reinterpret_cast<const h8*>(st + a_off + ks * 2 * Mpad * 8 + t * 256 + NCH * Mpad * 8);
+            }
 #pragma unroll
             for (int u = 0; u < NW; ++u) {
-                accm[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bh[u], accm[t][u], 0, 0, 0);
-                accx[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bl[u], accx[t][u], 0, 0, 0);
-                accx[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[t], bh[u], accx[t][u], 0, 0, 0);
+                bh[u] = *reinterpret_cast<const h8*>(st + b_off + ks * 2 * Nwpad * 8 + u * 256);
+                bl[u] = *reinterpret_cast<const h8*>(st + b_off + ks * 2 * Nwpad * 8 + u * 256 + NCH * Nwpad * 8);
             }
+#ifdef GLOWHIP_EXP_TNOMFMA
+#pragma unroll
+            for (int t = 0; t < MW; ++t)
+#pragma unroll
+                for (int u = 0; u < NW; ++u) { accm[t][u][0] += (float)ah[t][0] * (float)bl[u][0]; accx[t][u][0] += (float)al[t][0] * (float)bh[u][0]; }
+#else
+#pragma unroll
+            for (int t = 0; t < MW; ++t)
+#pragma unroll
+                for (int u = 0; u < NW; ++u) {
+                    accm[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bh[u], accm[t][u], 0, 0, 0);
+                    accx[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bl[u], accx[t][u], 0, 0, 0);
+                    accx[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[t], bh[u], accx[t][u], 0, 0, 0);
+                }
 #endif
+        }
     }
     __syncthreads();   // every wave is done with the operand ring: it becomes the T staging area
 
@@ -227,7 +221,10 @@ __global__ void __launch_bounds__(256) k_tail_sh(TailShArgs a, int WGM, int R, i
 }
 
 // ---- configuration: rows per workgroup by image width, channel groups over blockIdx.y, wave grid by tile counts
-struct TailShCfg { int MW, NW, PPW, WGM, R, Mpad, Nwpad, wshift, groups; };
+struct TailShCfg { int MW, NW, PPW, WGM, R, Mpad, Nwpad, wshift, groups, KS, ST; };
+
+static int g_tail_sh_ks = 0;   // testing hook: force k-steps per stage (0 = automatic)
+void tail_sh_force_ks(int ks) { g_tail_sh_ks = ks; }
 
 static bool tail_sh_config(int Cin, int H, int W, int Cout, TailShCfg* out) {
     if (Cin % 16 != 0 || Cin < 48) return false;
@@ -255,11 +252,16 @@ static bool tail_sh_config(int Cin, int H, int W, int Cout, TailShCfg* out) {
         for (size_t i = 0; i < sizeof(inst) / sizeof(inst[0]); ++i)
             if (inst[i][0] == MW && inst[i][1] == NW && inst[i][2] == PPW && MW * NW < best_cost) {
                 best = (int)i; best_cost = MW * NW;
-                bc = TailShCfg{MW, NW, PPW, WGM, R, Mpad, Nwpad, wshift, groups};
+                bc = TailShCfg{MW, NW, PPW, WGM, R, Mpad, Nwpad, wshift, groups, 1, 4};
             }
     }
     if (best < 0) return false;
-    const size_t ring = (size_t)TSH_ST * 4 * (bc.Mpad + bc.Nwpad) * 8 * sizeof(_Float16);
+    // ring geometry: 16-deep stages x 4 by default; 32/64-deep variants exist for A/B runs (instantiated combinations only)
+    int ks = g_tail_sh_ks ? g_tail_sh_ks : 1;   // measured: deeper stages (32/64) are slower on every level
+    if (!((bc.MW == 2 && bc.NW == 1 && bc.PPW == 3 && ks == 4) || (bc.MW == 2 && bc.NW == 3 && ks == 2))) ks = 1;
+    if (Cin % (16 * ks) != 0) ks = 1;
+    bc.KS = ks; bc.ST = ks == 1 ? 4 : 3;
+    const size_t ring = (size_t)bc.ST * 4 * bc.KS * (bc.Mpad + bc.Nwpad) * 8 * sizeof(_Float16);
     const size_t tb = align_up((size_t)9 * Cg * (Nw + 8) * sizeof(float), 16);
     if (std::max(ring, tb) + 1024 + 64 > 160 * 1024) return false;
     if (out) *out = bc;
@@ -288,21 +290,22 @@ int launch_tail_sh(const TailShArgs& a, hipStream_t s) {
                "tail_sh: coupling modes only");
     if (a.N == 0) return GLOWHIP_OK;
     const int Nw = (c.R + 2) * a.W;
-    const size_t ring = (size_t)TSH_ST * 4 * (c.Mpad + c.Nwpad) * 8 * sizeof(_Float16);
+    const size_t ring = (size_t)c.ST * 4 * c.KS * (c.Mpad + c.Nwpad) * 8 * sizeof(_Float16);
     const size_t tb = align_up((size_t)9 * (a.Cout / c.groups) * (Nw + 8) * sizeof(float), 16);
     const size_t lds = std::max(ring, tb) + 1024 + 64;
     const unsigned grid = (unsigned)(a.N * (a.H / c.R));
-#define GH_TSH_CASE(mw, nw, ppw)                                                                                      \
-    if (c.MW == mw && c.NW == nw && c.PPW == ppw) {                                                                   \
-        (void)hipFuncSetAttribute((const void*)k_tail_sh<mw, nw, ppw>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
-                                  (int)lds);                                                                          \
-        hipLaunchKernelGGL((k_tail_sh<mw, nw, ppw>), dim3(grid, c.groups), dim3(256), lds, s, a, c.WGM, c.R, c.Mpad,  \
-                           c.Nwpad, c.wshift, c.groups);                                                              \
+#define GH_TSH_CASE(mw, nw, ppw, ks, st)                                                                              \
+    if (c.MW == mw && c.NW == nw && c.PPW == ppw && c.KS == ks && c.ST == st) {                                       \
+        (void)hipFuncSetAttribute((const void*)k_tail_sh<mw, nw, ppw, ks, st>,                                        \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
+        hipLaunchKernelGGL((k_tail_sh<mw, nw, ppw, ks, st>), dim3(grid, c.groups), dim3(256), lds, s, a, c.WGM, c.R,  \
+                           c.Mpad, c.Nwpad, c.wshift, c.groups);                                                      \
         GH_LAUNCH_CHECK("k_tail_sh");                                                                                 \
         return GLOWHIP_OK;                                                                                            \
     }
-    GH_TSH_CASE(2, 3, 5) GH_TSH_CASE(2, 3, 6) GH_TSH_CASE(4, 1, 9) GH_TSH_CASE(2, 2, 5) GH_TSH_CASE(2, 2, 4) GH_TSH_CASE(2, 1, 5)
-    GH_TSH_CASE(2, 1, 3)
+    GH_TSH_CASE(2, 3, 5, 1, 4) GH_TSH_CASE(2, 3, 6, 1, 4) GH_TSH_CASE(4, 1, 9, 1, 4) GH_TSH_CASE(2, 2, 5, 1, 4)
+    GH_TSH_CASE(2, 2, 4, 1, 4) GH_TSH_CASE(2, 1, 5, 1, 4) GH_TSH_CASE(2, 1, 3, 1, 4)
+    GH_TSH_CASE(2, 1, 3, 4, 3) GH_TSH_CASE(2, 3, 5, 2, 3) GH_TSH_CASE(2, 3, 6, 2, 3)
 #undef GH_TSH_CASE
     set_error("tail_sh: no kernel instance");
     return GLOWHIP_EINVAL;
