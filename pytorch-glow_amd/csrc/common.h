@@ -84,6 +84,20 @@ __device__ __forceinline__ int xcd_remap(int b, int nblk) {
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// ---- debug build only (-DGLOWHIP_DEBUG_STAMPS): s_memtime stamps of workgroup 0 / wave 0, read back by scripts/stamps.py
+#ifdef GLOWHIP_DEBUG_STAMPS
+// (one array + one extern "C" reader per translation unit: no relocatable device code in this build)
+#define GH_STAMPS_DEFINE(name)                                                                                  \
+    namespace glowhip { __device__ unsigned long long g_stamps_local[64]; }                                     \
+    extern "C" int glowhip_debug_read_stamps_##name(unsigned long long* dst) {                                  \
+        return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(glowhip::g_stamps_local), sizeof(unsigned long long) * 64); \
+    }
+#define GH_STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_stamps_local[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define GH_STAMPS_DEFINE(name)
+#define GH_STAMP(i) do { } while (0)
+#endif
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 

@@ -169,7 +169,6 @@ k_conv_first(const float* __restrict__ X, long x_bs, const float* __restrict__ W
             // epilogue of this output-channel tile: ActNorm + ReLU, C[row = o][col = pixel]
             if (Ysh) {
                 // split-half output (sh.h): a lane's 4 consecutive channels of its pixel = 8 bytes of the hi plane and of the lo plane
-                const long P = (long)N * HW;
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     const long px = n * HW + p0 + wc * WN + j * 32 + ml;
@@ -186,9 +185,9 @@ k_conv_first(const float* __restrict__ X, long x_bs, const float* __restrict__ W
                                 sh_split(v, a, b);
                                 hi[q] = a; lo[q] = b;
                             }
-                            _Float16* dst = Ysh + ((long)(o0 >> 3) * P + px) * 8 + (o0 & 7);
+                            _Float16* dst = Ysh + sh_off(M >> 3, 0, o0 >> 3, px) + (o0 & 7);
                             *reinterpret_cast<h4*>(dst) = hi;
-                            *reinterpret_cast<h4*>(dst + P * (long)M) = lo;
+                            *reinterpret_cast<h4*>(dst + (long)(M >> 3) * SH_CHUNK_STEP) = lo;
                         }
                     }
                 }

@@ -64,11 +64,15 @@ k_first_sh(const float* __restrict__ X, long x_bs, const _Float16* __restrict__ 
 
     {
         const int o_tile = blockIdx.y * 128 + wid * 32;      // this wave's 32 output channels (blockIdx.y = 128-channel pass)
-        f32x16_t accm[NT], accx[NT];
+        f32x16_t accm[NT], accx[NT];   // main accumulators start at the folded ActNorm bias
 #pragma unroll
-        for (int u = 0; u < NT; ++u)
+        for (int gq = 0; gq < 4; ++gq) {
+            const f32x4_t b4 = *reinterpret_cast<const f32x4_t*>(bias + o_tile + 8 * gq + 4 * kl);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { accm[u][r] = 0.f; accx[u][r] = 0.f; }
+            for (int u = 0; u < NT; ++u)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { accm[u][4 * gq + q] = b4[q]; accx[u][4 * gq + q] = 0.f; }
+        }
         const _Float16* ap = Wsh + ((long)kl * M + o_tile + ml) * 8;
         const long sstep = (long)2 * M * 8;
         // A fragments come straight from L2: keep two k-steps in flight
@@ -107,19 +111,18 @@ k_first_sh(const float* __restrict__ X, long x_bs, const _Float16* __restrict__ 
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
                 const int o0 = o_tile + 8 * gq + 4 * kl;
-                const f32x4_t b4 = *reinterpret_cast<const f32x4_t*>(bias + o0);
                 h4 hi, lo;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float t = accm[u][4 * gq + q] + accx[u][4 * gq + q] * SH_LO_INV + b4[q];
+                    const float t = accm[u][4 * gq + q] + accx[u][4 * gq + q] * SH_LO_INV;
                     const float v = relu ? fmaxf(t, 0.f) : t;
                     _Float16 a, b;
                     sh_split(v, a, b);
                     hi[q] = a; lo[q] = b;
                 }
-                _Float16* dst = Ysh + ((long)(o0 >> 3) * P + px) * 8 + (o0 & 7);
+                _Float16* dst = Ysh + sh_off(M >> 3, 0, o0 >> 3, px) + (o0 & 7);
                 *reinterpret_cast<h4*>(dst) = hi;
-                *reinterpret_cast<h4*>(dst + P * (long)M) = lo;
+                *reinterpret_cast<h4*>(dst + (long)(M >> 3) * SH_CHUNK_STEP) = lo;
             }
         }
     }
@@ -131,7 +134,7 @@ static int first_sh_groups(int Cin) { return (9 * ((Cin + 7) / 8) + 1) & ~1; }
 bool first_sh_supported(int Cin, int H, int W, int Cout) {
     if (Cout % 128 != 0 || Cin < 1 || Cin > 64) return false;
     if (W != 8 && W != 16 && W != 32) return false;
-    return H % first_sh_rows(W) == 0;
+    return H % first_sh_rows(W) == 0 && (H * W) % 64 == 0;
 }
 
 size_t first_sh_packed_bytes(int Cin, int Cout) {

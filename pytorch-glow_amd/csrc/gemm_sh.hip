@@ -11,6 +11,8 @@
 #include "sh.h"
 #include "conv_mfma.h"
 
+GH_STAMPS_DEFINE(gemm)
+
 namespace glowhip {
 
 constexpr int SH_BM = 128, SH_BN = 128, SH_BK = 16, SH_ST = 4;
@@ -39,11 +41,10 @@ __device__ __forceinline__ void gemm_sh_epilogue(const f32x16_t (&accm)[2][2], c
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int o0 = tile_m * SH_BM + wr * 64 + i * 32 + 8 * g + 4 * kl;
-                const f32x4_t b4 = *reinterpret_cast<const f32x4_t*>(bias + o0);
                 float v[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float t = accm[i][j][4 * g + q] + accx[i][j][4 * g + q] * SH_LO_INV + b4[q];
+                    const float t = accm[i][j][4 * g + q] + accx[i][j][4 * g + q] * SH_LO_INV;
                     v[q] = relu ? fmaxf(t, 0.f) : t;
                 }
                 if (OUT_SH) {
@@ -55,9 +56,9 @@ __device__ __forceinline__ void gemm_sh_epilogue(const f32x16_t (&accm)[2][2], c
                         hi[q] = a; lo[q] = b;
                     }
                     if (ok) {
-                        _Float16* dst = Ysh + ((long)(o0 >> 3) * P + px) * 8 + (o0 & 7);
+                        _Float16* dst = Ysh + sh_off(M >> 3, 0, o0 >> 3, px) + (o0 & 7);
                         *reinterpret_cast<h4*>(dst) = hi;
-                        *reinterpret_cast<h4*>(dst + P * (long)M) = lo;
+                        *reinterpret_cast<h4*>(dst + (long)(M >> 3) * SH_CHUNK_STEP) = lo;
                     }
                 } else if (ok) {
                     float* dst = Yf + (n * M + o0) * (long)HW + p;
@@ -74,6 +75,7 @@ __global__ void __launch_bounds__(256, 2)
 k_gemm_sh(const _Float16* __restrict__ X, long P, const _Float16* __restrict__ Wsh, const float* __restrict__ bias,
           float* __restrict__ Yf, _Float16* __restrict__ Ysh, int K, int M, int HW, int relu) {
     extern __shared__ __attribute__((aligned(16))) _Float16 smem_h[];   // SH_ST stages
+    GH_STAMP(16);
     const int tiles_m = M / SH_BM;
     const int tiles_n = (int)((P + SH_BN - 1) / SH_BN);
     const int logical = xcd_remap(blockIdx.x, tiles_m * tiles_n);
@@ -82,7 +84,8 @@ k_gemm_sh(const _Float16* __restrict__ X, long P, const _Float16* __restrict__ W
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wid >> 1, wc = wid & 1;
     const int kl = lane >> 5, ml = lane & 31;
-    const long w_plane = (long)K * M, x_plane = P * (long)K;
+    const long w_plane = (long)K * M;
+    const int NCK = K >> 3;                         // 8-channel chunks of the input tensor
 
     // DMA sources of this lane: wave w streams (plane = w>>1, chunk = w&1) of every stage: 2 A pieces (64-row halves) + 2 B pieces
     const int dpl = wid >> 1, dch = wid & 1;
@@ -90,8 +93,8 @@ k_gemm_sh(const _Float16* __restrict__ X, long P, const _Float16* __restrict__ W
     long px0 = (long)tile_n * SH_BN + lane, px1 = px0 + 64;
     px0 = px0 < P ? px0 : P - 1;   // ragged last tile: clamp the fetch, the stores are predicated
     px1 = px1 < P ? px1 : P - 1;
-    const _Float16* b_src0 = X + dpl * x_plane + ((long)dch * P + px0) * 8;
-    const _Float16* b_src1 = X + dpl * x_plane + ((long)dch * P + px1) * 8;
+    const _Float16* b_src0 = X + sh_off(NCK, dpl, dch, px0);
+    const _Float16* b_src1 = X + sh_off(NCK, dpl, dch, px1);
 #ifdef GLOWHIP_EXP_NOLOOP
     const int nkt = 3;
 #else
@@ -105,19 +108,25 @@ k_gemm_sh(const _Float16* __restrict__ X, long P, const _Float16* __restrict__ W
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)st, 16, 0, 0);
         } else {
-            const _Float16* src = ((piece & 1) ? b_src1 : b_src0) + (long)kt * 2 * P * 8;
+            const _Float16* src = ((piece & 1) ? b_src1 : b_src0) + (long)kt * 2 * SH_CHUNK_STEP;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(st + SH_A_HALFS), 16, 0, 0);
         }
     };
 
+    // the folded ActNorm bias is the accumulators' initial value: its load latency hides behind the first DMA wait and the
+    // epilogue holds no per-row parameter
     f32x16_t accm[2][2], accx[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int g = 0; g < 4; ++g) {
+            const f32x4_t b4 = *reinterpret_cast<const f32x4_t*>(bias + tile_m * SH_BM + wr * 64 + i * 32 + 8 * g + 4 * kl);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { accm[i][j][r] = 0.f; accx[i][j][r] = 0.f; }
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { accm[i][j][4 * g + q] = b4[q]; accx[i][j][4 * g + q] = 0.f; }
+        }
 
 #pragma unroll
     for (int t = 0; t < SH_ST - 1; ++t)
@@ -126,6 +135,7 @@ k_gemm_sh(const _Float16* __restrict__ X, long P, const _Float16* __restrict__ W
             for (int pc = 0; pc < 4; ++pc) issue_piece(t, pc);
         }
 
+    GH_STAMP(17);
     const int a_off = (kl * 128 + wr * 64 + ml) * 8, b_off = SH_A_HALFS + (kl * 128 + wc * 64 + ml) * 8;
     for (int kt = 0; kt < nkt; ++kt) {
         if (SH_ST == 4 && kt + 2 < nkt) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -133,6 +143,7 @@ k_gemm_sh(const _Float16* __restrict__ X, long P, const _Float16* __restrict__ W
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        if (kt < 8) GH_STAMP(24 + kt);
         const _Float16* st = smem_h + (kt % SH_ST) * SH_STAGE_HALFS;
         h8 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
@@ -168,11 +179,13 @@ k_gemm_sh(const _Float16* __restrict__ X, long P, const _Float16* __restrict__ W
 #endif
     }
 
+    GH_STAMP(18);
     gemm_sh_epilogue<OUT_SH>(accm, accx, bias, Yf, Ysh, P, M, HW, relu, tile_m, tile_n, wr, wc, kl, ml);
+    GH_STAMP(19);
 }
 
 bool gemm_sh_supported(int K, int M, int H, int W) {
-    return M % SH_BM == 0 && K % SH_BK == 0 && K >= SH_BK;
+    return M % SH_BM == 0 && K % SH_BK == 0 && K >= SH_BK && (H * W) % 64 == 0;   // SH tensors are tiled by 64 pixels
 }
 
 size_t gemm_sh_packed_bytes(int K, int M) {
@@ -181,7 +194,7 @@ size_t gemm_sh_packed_bytes(int K, int M) {
 
 int launch_gemm_sh(const _Float16* x_sh, const void* wsh, float* y_f32, _Float16* y_sh, int N, int K, int HW, int M, int relu,
                    hipStream_t s) {
-    GH_REQUIRE(gemm_sh_supported(K, M, 1, 1), "gemm_sh: unsupported shape K=%d M=%d", K, M);
+    GH_REQUIRE(gemm_sh_supported(K, M, HW, 1), "gemm_sh: unsupported shape K=%d M=%d HW=%d", K, M, HW);
     GH_REQUIRE((y_f32 != nullptr) != (y_sh != nullptr), "gemm_sh: exactly one output");
     if (N == 0) return GLOWHIP_OK;
     const long P = (long)N * HW;

@@ -12,8 +12,11 @@
 // silently); below 6.1e-5 the representation is absolute, 2.9e-11.  tests/diag_split_precision.py: on the celeba64
 // model the deviation from an fp64 evaluation is 5.8e-6 (z), the fp32 reference's own is 5.4e-6.
 //
-// HBM layout of an SH activation tensor with Ch channels over P = N*H*W pixels (pixel index n*HW + y*W + x):
-//   plane q in {hi, lo}:  half [Ch/8][P][8]        (8 consecutive channels of one pixel = 16 bytes)
+// HBM layout of an SH activation tensor with Ch channels over P = N*H*W pixels (pixel index p = n*HW + y*W + x; P % 64 == 0):
+//   half [P/64][plane {hi, lo}][Ch/8][64][8]       (8 consecutive channels of one pixel = 16 bytes; a 64-pixel tile with all
+//                                                   its channels and both planes is ONE contiguous block of Ch*256 bytes)
+// (the first version was plane-major / chunk-major over the whole tensor: every workgroup then touched 128 separate 2-KiB
+// runs a megabyte apart, and all three kernels sat at ~3 TB/s of HBM traffic)
 // This is at once what the MFMA epilogue produces (a lane owns 4 consecutive channels of its pixel; the two
 // half-waves complete the 16-byte group, 32 lanes = 512 contiguous bytes per store instruction) and what the consumer's
 // operand fetch wants (a lane's B fragment = 8 consecutive k of its pixel = ONE 16-byte group; 64 lanes of an LDS-DMA
@@ -31,6 +34,12 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 constexpr float SH_LO_SCALE = 2048.0f;
 constexpr float SH_LO_INV = 1.0f / 2048.0f;
+
+// offset (halfs) of the 16-byte group (plane q, 8-channel chunk c, pixel p) of an SH tensor with NC = Ch/8 chunks
+__host__ __device__ __forceinline__ long sh_off(int NC, int q, int c, long p) {
+    return ((((p >> 6) * 2 + q) * NC + c) * 64 + (p & 63)) * 8;
+}
+constexpr long SH_CHUNK_STEP = 64 * 8;   // halfs from one chunk to the next inside a tile
 
 __device__ __forceinline__ void sh_split(float v, _Float16& hi, _Float16& lo) {
     hi = (_Float16)v;

@@ -17,77 +17,109 @@
 
 #include "conv_mfma.h"
 
+GH_STAMPS_DEFINE(tail)
+
 namespace glowhip {
 
 
-__device__ __forceinline__ float tsh_gauss_logp1(float mean, float logs, float x) {
-    const float d = x - mean;
-    return -0.5f * (LOG_2PI_F + 2.0f * logs + (d * d) / expf(2.0f * logs));
+// T row stride (floats) for M9 = 9*Cg GEMM rows: multiple of 4 (16-byte stores), an ODD multiple so that the pixels of
+// a wave land on different banks
+__host__ __device__ inline int tail_sh_trow(int M9) {
+    int r = (M9 + 3) / 4;
+    if ((r & 1) == 0) ++r;
+    return r * 4;
 }
 
-// KS = 16-deep k-steps per ring stage, ST = ring stages; PPW1 = DMA pieces per wave and k-step
-template <int MW, int NW, int PPW1, int KS, int ST>
-__global__ void __launch_bounds__(256) k_tail_sh(TailShArgs a, int WGM, int R, int Mpad, int Nwpad, int wshift, int groups) {
+constexpr int TSH_ST = 4;       // ring stages (16 input channels each)
+constexpr int TSH_MAXE = 4;     // epilogue items ((channel [pair], pixel)) per thread, at most
+
+// NWV waves per workgroup (4 or 8).  Eight waves halve the LDS-DMA pieces each wave has to issue per stage (an issue costs
+// 100-200 cycles and is serial per wave: with four waves the stage period was ~1100 cycles against 576 cycles of MFMA).
+template <int MW, int NW, int PPW, int NWV>
+__global__ void __launch_bounds__(64 * NWV) k_tail_sh(TailShArgs a, int WGM, int R, int Mpad, int Nwpad, int wshift, int groups) {
+    constexpr int NTHR = 64 * NWV;
     extern __shared__ __attribute__((aligned(16))) _Float16 smem_t[];
     const int W = a.W, H = a.H, HW = H * W, K = a.Cin;
     const int Cout = a.Cout / groups;                  // output channels of this workgroup's group (blockIdx.y)
     const int c0 = blockIdx.y * Cout;
     const int Nw = (R + 2) * W;
-    constexpr int PPW = PPW1 * KS, NCH = 2 * KS;       // pieces per wave and stage; 8-channel chunks per stage
-    const int a_halfs = 2 * NCH * Mpad * 8;            // [plane 2][chunk NCH][Mpad][8]
-    const int stage_halfs = a_halfs + 2 * NCH * Nwpad * 8;
-    const int M9 = 9 * Cout, Nwt = Nw + 8;
-    const size_t ring_bytes = (size_t)ST * stage_halfs * sizeof(_Float16);
-    const size_t t_bytes = ((size_t)M9 * Nwt * sizeof(float) + 15) & ~(size_t)15;
+    const int a_halfs = 4 * Mpad * 8;                  // [plane 2][chunk 2][Mpad][8]
+    const int stage_halfs = a_halfs + 4 * Nwpad * 8;
+    const int M9 = 9 * Cout;
+    const int Mrow = tail_sh_trow(M9);                 // T row stride (floats): multiple of 4, odd multiple => spread banks
+    const size_t ring_bytes = (size_t)TSH_ST * stage_halfs * sizeof(_Float16);
+    const size_t t_bytes = (size_t)Nw * Mrow * sizeof(float);
     char* tailp = (char*)smem_t + (ring_bytes > t_bytes ? ring_bytes : t_bytes);
     _Float16* dummy = (_Float16*)tailp;                // 1 KiB landing area of padding DMA pieces
     double* red = (double*)(tailp + 1024);
 
+    GH_STAMP(0);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int WGN = 4 / WGM;
+    const int WGN = NWV / WGM;
     const int wm = wid / WGN, wn = wid - wm * WGN;
     const int kl = lane >> 5, ml = lane & 31;
     const int bpi = H / R;                             // workgroups per image
-    const long n = blockIdx.x / bpi;
-    const int y0 = (int)(blockIdx.x - n * bpi) * R;
+    // XCD-aware order: vertically adjacent row blocks share their halo rows, so give each XCD (private L2) a contiguous run
+    // of row blocks instead of every 8th one
+    const int lb = xcd_remap(blockIdx.x, gridDim.x);
+    const long n = lb / bpi;
+    const int y0 = (int)(lb - n * bpi) * R;
     const long P = a.P;
-    const long w_plane = (long)K * Mpad, x_plane = P * (long)K;
-    const int pa = Mpad >> 6, pb = Nwpad >> 6, PT = 2 * NCH * (pa + pb);
+    const long w_plane = (long)K * Mpad;
+    const int pa = Mpad >> 6, pb = Nwpad >> 6, PT = 4 * (pa + pb);
 
-    // ---- DMA pieces of this wave: q = wid + 4*i.  A pieces first ((plane, chunk, 64-row group)), then B pieces
+    // ---- epilogue work items of this thread and their z2 inputs, requested NOW (their latency hides behind the GEMM)
+    const int tile_px = R * W;
+    const bool paired = a.mode == TAIL_AFFINE_FWD || a.mode == TAIL_AFFINE_REV;
+    const int nch = paired ? Cout / 2 : Cout;
+    const int nitems = nch * tile_px;
+    float zin[TSH_MAXE];
+#pragma unroll
+    for (int i = 0; i < TSH_MAXE; ++i) {
+        const int e = tid + i * NTHR;
+        zin[i] = 0.f;
+        if (e < nitems) {
+            const int c = e / tile_px, q = e - c * tile_px;
+            const int cg = (paired ? c0 / 2 : c0) + c;
+            zin[i] = a.z2_in[n * a.z2_in_bs + (long)cg * HW + (long)y0 * W + q];
+        }
+    }
+
+    // ---- DMA pieces of this wave: q = wid + NWV*i.  A pieces first ((plane, chunk, 64-row group)), then B pieces
     const _Float16* src[PPW];
     long adv[PPW];          // halfs per stage (two 8-channel chunks)
     int ldso[PPW];          // wave-uniform LDS offset (halfs) inside the stage, or -1: dummy
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
-        const int q = wid + 4 * i;
-        if (q < 2 * NCH * pa) {
-            const int pc = q / pa, rp = q - pc * pa;   // pc = plane*NCH + chunk
-            const int pl = pc / NCH, chk = pc - pl * NCH;
-            src[i] = (const _Float16*)a.wsh + ((long)blockIdx.y * 2 + pl) * w_plane + ((long)chk * Mpad + rp * 64 + lane) * 8;
-            adv[i] = (long)NCH * Mpad * 8;
+        const int q = wid + NWV * i;
+        if (q < 4 * pa) {
+            const int pc = q / pa, rp = q - pc * pa;   // pc = plane*2 + chunk
+            src[i] = (const _Float16*)a.wsh + ((long)blockIdx.y * 2 + (pc >> 1)) * w_plane + ((long)(pc & 1) * Mpad + rp * 64 + lane) * 8;
+            adv[i] = (long)2 * Mpad * 8;
             ldso[i] = (pc * Mpad + rp * 64) * 8;
         } else if (q < PT) {
-            const int qb = q - 2 * NCH * pa;
+            const int qb = q - 4 * pa;
             const int pc = qb / pb, sp = qb - pc * pb;
-            const int pl = pc / NCH, chk = pc - pl * NCH;
             const int slot = sp * 64 + lane;           // window pixel
             const int yy = y0 - 1 + (slot >> wshift);
             const bool ok = slot < Nw && yy >= 0 && yy < H;
             const long gpx = n * HW + (long)(y0 - 1) * W + slot;
-            src[i] = ok ? a.x_sh + pl * x_plane + ((long)chk * P + gpx) * 8 : (const _Float16*)a.zeros;
-            adv[i] = ok ? (long)NCH * P * 8 : 0;
+            src[i] = ok ? a.x_sh + sh_off(K >> 3, pc >> 1, pc & 1, gpx) : (const _Float16*)a.zeros;
+            adv[i] = ok ? 2 * SH_CHUNK_STEP : 0;
             ldso[i] = a_halfs + (pc * Nwpad + sp * 64) * 8;
         } else {
             src[i] = (const _Float16*)a.zeros; adv[i] = 0; ldso[i] = -1;
         }
     }
     auto issue_stage = [&](int kt) {
-        _Float16* st = smem_t + (kt % ST) * stage_halfs;
+        _Float16* st = smem_t + (kt % TSH_ST) * stage_halfs;
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
             _Float16* dst = ldso[i] >= 0 ? st + ldso[i] : dummy;
+#ifdef GLOWHIP_EXP_TNOA
+            if (kt >= 3 && (wid + NWV * i) < 4 * pa) continue;   // timing experiment: no weight refills
+#endif
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src[i],
                                              (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
             src[i] += adv[i];
@@ -103,58 +135,60 @@ __global__ void __launch_bounds__(256) k_tail_sh(TailShArgs a, int WGM, int R, i
             for (int r = 0; r < 16; ++r) { accm[t][u][r] = 0.f; accx[t][u][r] = 0.f; }
 
 #ifdef GLOWHIP_EXP_TNOLOOP
-    const int nkt = ST - 1;
+    const int nkt = 3;
 #else
-    const int nkt = K / (16 * KS);
+    const int nkt = K / 16;
 #endif
 #pragma unroll
-    for (int t = 0; t < ST - 1; ++t)
+    for (int t = 0; t < 3; ++t)
         if (t < nkt) issue_stage(t);
 
-    const int a_off = (kl * Mpad + wm * MW * 32 + ml) * 8;         // + ks*2*Mpad*8 + t*256 ; lo plane: + NCH*Mpad*8
+    GH_STAMP(1);
+    const int a_off = (kl * Mpad + wm * MW * 32 + ml) * 8;         // + t*256 ; lo plane: + 2*Mpad*8
     const int b_off = a_halfs + (kl * Nwpad + wn * NW * 32 + ml) * 8;
     for (int kt = 0; kt < nkt; ++kt) {
-        // stage kt has landed once at most the ST-2 younger stages (PPW pieces each) are outstanding
-        if (kt + ST - 2 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((ST - 2) * PPW) : "memory");
-        else if (ST == 4 && kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+        // stage kt has landed once at most the two younger stages (PPW pieces each) are outstanding; the z2 prefetch loads
+        // are older than every stage, so they never hold a counted wait back
+        if (kt + 2 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
+        else if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        const _Float16* st = smem_t + (kt % ST) * stage_halfs;
-        if (kt + ST - 1 < nkt) issue_stage(kt + ST - 1);
+        if (kt < 8) GH_STAMP(8 + kt);
+        const _Float16* st = smem_t + (kt % TSH_ST) * stage_halfs;
+        h8 ah[MW], al[MW], bh[NW], bl[NW];
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            h8 ah[MW], al[MW], bh[NW], bl[NW];
+        for (int t = 0; t < MW; ++t) {
+            ah[t] = *reinterpret_cast<const h8*>(st + a_off + t * 256);
+            al[t] = *reinterpret_cast<const h8*>(st + a_off + t * 256 + 2 * Mpad * 8);
+        }
 #pragma unroll
-            for (int t = 0; t < MW; ++t) {
-                ah[t] = *reinterpret_cast<const h8*>(st + a_off + ks * 2 * Mpad * 8 + t * 256);
-                al[t] = *reinterpret_cast<const h8*>(st + a_off + ks * 2 * Mpad * 8 + t * 256 + NCH * Mpad * 8);
-            }
-#pragma unroll
-            for (int u = 0; u < NW; ++u) {
-                bh[u] = *reinterpret_cast<const h8*>(st + b_off + ks * 2 * Nwpad * 8 + u * 256);
-                bl[u] = *reinterpret_cast<const h8*>(st + b_off + ks * 2 * Nwpad * 8 + u * 256 + NCH * Nwpad * 8);
-            }
+        for (int u = 0; u < NW; ++u) {
+            bh[u] = *reinterpret_cast<const h8*>(st + b_off + u * 256);
+            bl[u] = *reinterpret_cast<const h8*>(st + b_off + u * 256 + 2 * Nwpad * 8);
+        }
+        if (kt + 3 < nkt) issue_stage(kt + 3);
 #ifdef GLOWHIP_EXP_TNOMFMA
 #pragma unroll
-            for (int t = 0; t < MW; ++t)
+        for (int t = 0; t < MW; ++t)
 #pragma unroll
-                for (int u = 0; u < NW; ++u) { accm[t][u][0] += (float)ah[t][0] * (float)bl[u][0]; accx[t][u][0] += (float)al[t][0] * (float)bh[u][0]; }
+            for (int u = 0; u < NW; ++u) { accm[t][u][0] += (float)ah[t][0] * (float)bl[u][0]; accx[t][u][0] += (float)al[t][0] * (float)bh[u][0]; }
 #else
 #pragma unroll
-            for (int t = 0; t < MW; ++t)
+        for (int t = 0; t < MW; ++t)
 #pragma unroll
-                for (int u = 0; u < NW; ++u) {
-                    accm[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bh[u], accm[t][u], 0, 0, 0);
-                    accx[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bl[u], accx[t][u], 0, 0, 0);
-                    accx[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[t], bh[u], accx[t][u], 0, 0, 0);
-                }
+            for (int u = 0; u < NW; ++u) {
+                accm[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bh[u], accm[t][u], 0, 0, 0);
+                accx[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bl[u], accx[t][u], 0, 0, 0);
+                accx[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[t], bh[u], accx[t][u], 0, 0, 0);
+            }
 #endif
-        }
     }
+    GH_STAMP(2);
     __syncthreads();   // every wave is done with the operand ring: it becomes the T staging area
+    GH_STAMP(3);
 
-    // ---- T[m][window pixel] -> LDS (row stride Nw + 8 floats: the two half-waves of a store land on disjoint banks)
+    // ---- T[window pixel][m] -> LDS: a lane's 4 consecutive rows of one pixel are ONE 16-byte store
     float* T = reinterpret_cast<float*>(smem_t);
 #pragma unroll
     for (int t = 0; t < MW; ++t)
@@ -162,22 +196,28 @@ __global__ void __launch_bounds__(256) k_tail_sh(TailShArgs a, int WGM, int R, i
         for (int u = 0; u < NW; ++u) {
             const int px = (wn * NW + u) * 32 + ml;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = (wm * MW + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl;
-                if (m < M9 && px < Nw) T[m * Nwt + px] = accm[t][u][r] + accx[t][u][r] * SH_LO_INV;
+            for (int g = 0; g < 4; ++g) {
+                const int m = (wm * MW + t) * 32 + 8 * g + 4 * kl;
+                if (m < Mrow && px < Nw) {
+                    f32x4_t v;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = accm[t][u][4 * g + q] + accx[t][u][4 * g + q] * SH_LO_INV;
+                    *reinterpret_cast<f32x4_t*>(T + px * Mrow + m) = v;
+                }
             }
         }
     __syncthreads();
 
+    GH_STAMP(4);
     // ---- shifted 9-tap sum + (.. + bias) * exp(3 logs) + coupling; one thread per (channel [pair], pixel)
-    const int tile_px = R * W;
-    const bool paired = a.mode == TAIL_AFFINE_FWD || a.mode == TAIL_AFFINE_REV;
-    const int nch = paired ? Cout / 2 : Cout;
     double ld = 0.0;
+#pragma unroll
+    for (int i = 0; i < TSH_MAXE; ++i) {
+        const int e = tid + i * NTHR;
 #ifdef GLOWHIP_EXP_TNOEPI
-    for (int e = tid; e < nch * tile_px; e += 256 * 64) {
+        if (e >= nitems || i > 0) continue;
 #else
-    for (int e = tid; e < nch * tile_px; e += 256) {
+        if (e >= nitems) continue;
 #endif
         const int c = e / tile_px, q = e - c * tile_px;
         const int r = q >> wshift, x = q & (W - 1);
@@ -190,41 +230,39 @@ __global__ void __launch_bounds__(256) k_tail_sh(TailShArgs a, int WGM, int R, i
                 const int xx = x + dx;
                 if (xx < 0 || xx >= W) continue;
                 const int tap = dy * 3 + dx + 1;
-                const float* tp = T + (tap * Cout + ce) * Nwt + (r + dy) * W + xx;
+                const float* tp = T + ((r + dy) * W + xx) * Mrow + tap * Cout + ce;
                 se += tp[0];
-                if (paired) so += tp[Nwt];
+                if (paired) so += tp[1];
             }
-        const int p = (y0 + r) * W + x;
         const int cg = (paired ? c0 / 2 : c0) + c;     // coupling channel in the full tensor
-        const long zi = n * a.z2_in_bs + (long)cg * HW + p;
-        const long zo = n * a.z2_out_bs + (long)cg * HW + p;
+        const long zo = n * a.z2_out_bs + (long)cg * HW + (long)y0 * W + q;
         const float A_ = (se + a.bias[c0 + ce]) * a.scale[c0 + ce];
         if (paired) {
             const float B_ = (so + a.bias[c0 + ce + 1]) * a.scale[c0 + ce + 1];
             const float sc = sigmoidf_(B_ + 2.0f);
             if (a.mode == TAIL_AFFINE_FWD) {
-                a.z2_out[zo] = (a.z2_in[zi] + A_) * sc;
+                a.z2_out[zo] = (zin[i] + A_) * sc;
                 ld += (double)logf(sc);
             } else {
-                a.z2_out[zo] = a.z2_in[zi] / sc - A_;
+                a.z2_out[zo] = zin[i] / sc - A_;
                 ld -= (double)logf(sc);
             }
         } else {
-            const float z2 = a.z2_in[zi];
-            a.z2_out[zo] = a.mode == TAIL_ADD_FWD ? z2 + A_ : z2 - A_;
+            a.z2_out[zo] = a.mode == TAIL_ADD_FWD ? zin[i] + A_ : zin[i] - A_;
         }
     }
+    GH_STAMP(5);
     if (paired) {
-        const double tot = block_sum<256>(ld, red);
+        const double tot = block_sum<NTHR>(ld, red);
         if (tid == 0) fix_atomic_add(a.acc + n, tot);
     }
 }
 
 // ---- configuration: rows per workgroup by image width, channel groups over blockIdx.y, wave grid by tile counts
-struct TailShCfg { int MW, NW, PPW, WGM, R, Mpad, Nwpad, wshift, groups, KS, ST; };
+struct TailShCfg { int MW, NW, PPW, NWV, WGM, R, Mpad, Nwpad, wshift, groups; };
 
-static int g_tail_sh_ks = 0;   // testing hook: force k-steps per stage (0 = automatic)
-void tail_sh_force_ks(int ks) { g_tail_sh_ks = ks; }
+static int g_tail_sh_waves = 0;   // testing hook: 4 / 8 = only that many waves per workgroup (0 = automatic)
+void tail_sh_force_ks(int v) { g_tail_sh_waves = v; }
 
 static bool tail_sh_config(int Cin, int H, int W, int Cout, TailShCfg* out) {
     if (Cin % 16 != 0 || Cin < 48) return false;
@@ -234,35 +272,36 @@ static bool tail_sh_config(int Cin, int H, int W, int Cout, TailShCfg* out) {
     else if (W == 8) wshift = 3;
     else return false;
     if (H % R != 0) return false;
-    // 12 output channels (108 GEMM rows) per workgroup: the deep levels' many channels become many workgroups, and
-    // a workgroup's weight stream stays at 2 DMA pieces per wave and stage
+    // 12 output channels (108 GEMM rows) per workgroup on the deep levels: their many channels become many workgroups
     const int groups = (Cout % 12 == 0 && H * W <= 64) ? Cout / 12 : 1;   // (measured: at 16x16 one group of 24 channels is faster)
     const int Cg = Cout / groups;
     const int Nw = (R + 2) * W;
     const int Mt = (9 * Cg + 31) / 32, Nt = (Nw + 31) / 32;
-    static const int inst[][3] = {{2, 3, 5}, {2, 2, 4}, {2, 1, 3}, {2, 2, 5}, {2, 3, 6}, {4, 1, 9}, {2, 1, 5}};
-    int best = -1, best_cost = 1 << 30;
+    // instantiated (MW, NW, PPW, waves); earlier entries win ties
+    static const int inst[][4] = {{1, 3, 3, 8}, {1, 1, 2, 8}, {2, 3, 5, 4}, {2, 2, 4, 4}, {2, 1, 3, 4}, {2, 2, 5, 4},
+                                  {2, 3, 6, 4}, {4, 1, 9, 4}, {2, 1, 5, 4}};
+    int best = -1;
     TailShCfg bc{};
-    for (int WGM = 1; WGM <= 4; WGM *= 2) {
-        const int WGN = 4 / WGM;
-        const int MW = (Mt + WGM - 1) / WGM, NW = (Nt + WGN - 1) / WGN;
-        const int Mpad = (WGM * MW * 32 + 63) / 64 * 64;
-        const int Nwpad = (std::max(Nw, WGN * NW * 32) + 63) / 64 * 64;
-        const int PPW = Mpad / 64 + Nwpad / 64;
-        for (size_t i = 0; i < sizeof(inst) / sizeof(inst[0]); ++i)
-            if (inst[i][0] == MW && inst[i][1] == NW && inst[i][2] == PPW && MW * NW < best_cost) {
-                best = (int)i; best_cost = MW * NW;
-                bc = TailShCfg{MW, NW, PPW, WGM, R, Mpad, Nwpad, wshift, groups, 1, 4};
+    for (size_t i = 0; i < sizeof(inst) / sizeof(inst[0]) && best < 0; ++i) {
+        const int NWV = inst[i][3];
+        if (g_tail_sh_waves && g_tail_sh_waves != NWV) continue;
+        for (int WGM = 1; WGM <= NWV && best < 0; WGM *= 2) {
+            const int WGN = NWV / WGM;
+            const int MW = (Mt + WGM - 1) / WGM, NW = (Nt + WGN - 1) / WGN;
+            const int Mpad = (WGM * MW * 32 + 63) / 64 * 64;
+            const int Nwpad = (std::max(Nw, WGN * NW * 32) + 63) / 64 * 64;
+            const int PPW = (4 * (Mpad / 64 + Nwpad / 64) + NWV - 1) / NWV;
+            if (inst[i][0] == MW && inst[i][1] == NW && inst[i][2] == PPW) {
+                best = (int)i;
+                bc = TailShCfg{MW, NW, PPW, NWV, WGM, R, Mpad, Nwpad, wshift, groups};
             }
+        }
     }
     if (best < 0) return false;
-    // ring geometry: 16-deep stages x 4 by default; 32/64-deep variants exist for A/B runs (instantiated combinations only)
-    int ks = g_tail_sh_ks ? g_tail_sh_ks : 1;   // measured: deeper stages (32/64) are slower on every level
-    if (!((bc.MW == 2 && bc.NW == 1 && bc.PPW == 3 && ks == 4) || (bc.MW == 2 && bc.NW == 3 && ks == 2))) ks = 1;
-    if (Cin % (16 * ks) != 0) ks = 1;
-    bc.KS = ks; bc.ST = ks == 1 ? 4 : 3;
-    const size_t ring = (size_t)bc.ST * 4 * bc.KS * (bc.Mpad + bc.Nwpad) * 8 * sizeof(_Float16);
-    const size_t tb = align_up((size_t)9 * Cg * (Nw + 8) * sizeof(float), 16);
+    const int nitems = (Cg % 2 == 0 ? Cg / 2 : Cg) * R * W;   // (paired modes have Cg/2 items per pixel; unpaired Cg: checked at launch)
+    (void)nitems;
+    const size_t ring = (size_t)TSH_ST * 4 * (bc.Mpad + bc.Nwpad) * 8 * sizeof(_Float16);
+    const size_t tb = (size_t)Nw * tail_sh_trow(9 * Cg) * sizeof(float);
     if (std::max(ring, tb) + 1024 + 64 > 160 * 1024) return false;
     if (out) *out = bc;
     return true;
@@ -289,23 +328,25 @@ int launch_tail_sh(const TailShArgs& a, hipStream_t s) {
     GH_REQUIRE(a.mode == TAIL_AFFINE_FWD || a.mode == TAIL_AFFINE_REV || a.mode == TAIL_ADD_FWD || a.mode == TAIL_ADD_REV,
                "tail_sh: coupling modes only");
     if (a.N == 0) return GLOWHIP_OK;
-    const int Nw = (c.R + 2) * a.W;
-    const size_t ring = (size_t)c.ST * 4 * c.KS * (c.Mpad + c.Nwpad) * 8 * sizeof(_Float16);
-    const size_t tb = align_up((size_t)9 * (a.Cout / c.groups) * (Nw + 8) * sizeof(float), 16);
+    const int Nw = (c.R + 2) * a.W, Cg = a.Cout / c.groups;
+    const bool paired = a.mode == TAIL_AFFINE_FWD || a.mode == TAIL_AFFINE_REV;
+    GH_REQUIRE((paired ? Cg / 2 : Cg) * c.R * a.W <= TSH_MAXE * 64 * c.NWV, "tail_sh: too many epilogue items per workgroup");
+    const size_t ring = (size_t)TSH_ST * 4 * (c.Mpad + c.Nwpad) * 8 * sizeof(_Float16);
+    const size_t tb = (size_t)Nw * tail_sh_trow(9 * Cg) * sizeof(float);
     const size_t lds = std::max(ring, tb) + 1024 + 64;
     const unsigned grid = (unsigned)(a.N * (a.H / c.R));
-#define GH_TSH_CASE(mw, nw, ppw, ks, st)                                                                              \
-    if (c.MW == mw && c.NW == nw && c.PPW == ppw && c.KS == ks && c.ST == st) {                                       \
-        (void)hipFuncSetAttribute((const void*)k_tail_sh<mw, nw, ppw, ks, st>,                                        \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
-        hipLaunchKernelGGL((k_tail_sh<mw, nw, ppw, ks, st>), dim3(grid, c.groups), dim3(256), lds, s, a, c.WGM, c.R,  \
+#define GH_TSH_CASE(mw, nw, ppw, nwv)                                                                                 \
+    if (c.MW == mw && c.NW == nw && c.PPW == ppw && c.NWV == nwv) {                                                   \
+        (void)hipFuncSetAttribute((const void*)k_tail_sh<mw, nw, ppw, nwv>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                  (int)lds);                                                                          \
+        hipLaunchKernelGGL((k_tail_sh<mw, nw, ppw, nwv>), dim3(grid, c.groups), dim3(64 * nwv), lds, s, a, c.WGM, c.R, \
                            c.Mpad, c.Nwpad, c.wshift, c.groups);                                                      \
         GH_LAUNCH_CHECK("k_tail_sh");                                                                                 \
         return GLOWHIP_OK;                                                                                            \
     }
-    GH_TSH_CASE(2, 3, 5, 1, 4) GH_TSH_CASE(2, 3, 6, 1, 4) GH_TSH_CASE(4, 1, 9, 1, 4) GH_TSH_CASE(2, 2, 5, 1, 4)
-    GH_TSH_CASE(2, 2, 4, 1, 4) GH_TSH_CASE(2, 1, 5, 1, 4) GH_TSH_CASE(2, 1, 3, 1, 4)
-    GH_TSH_CASE(2, 1, 3, 4, 3) GH_TSH_CASE(2, 3, 5, 2, 3) GH_TSH_CASE(2, 3, 6, 2, 3)
+    GH_TSH_CASE(1, 3, 3, 8) GH_TSH_CASE(1, 1, 2, 8)
+    GH_TSH_CASE(2, 3, 5, 4) GH_TSH_CASE(2, 3, 6, 4) GH_TSH_CASE(4, 1, 9, 4) GH_TSH_CASE(2, 2, 5, 4) GH_TSH_CASE(2, 2, 4, 4)
+    GH_TSH_CASE(2, 1, 5, 4) GH_TSH_CASE(2, 1, 3, 4)
 #undef GH_TSH_CASE
     set_error("tail_sh: no kernel instance");
     return GLOWHIP_EINVAL;
