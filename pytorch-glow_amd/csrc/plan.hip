@@ -78,9 +78,10 @@ static int carve(const glowhip_plan* p, int N, void* ws, size_t bytes, Workspace
 // ---------------------------------------------------------------- coupling network f() (network/module.py:300-319)
 // Runs conv3x3 -> actnorm -> relu -> conv1x1 -> actnorm -> relu -> conv3x3(zeros) and applies the
 // coupling to z2.  x1: first-half channels (batch stride x1_bs).
-static bool g_sh_disabled = false, g_sh_tail_disabled = false, g_sh_first_disabled = false;
+static bool g_sh_disabled = false, g_sh_tail_disabled = false, g_sh_first_disabled = false, g_sh_f02_disabled = false;
 void plan_disable_sh(int off) {
     g_sh_disabled = (off & 1) != 0; g_sh_tail_disabled = (off & 2) != 0; g_sh_first_disabled = (off & 4) != 0;
+    g_sh_f02_disabled = (off & 8) != 0;
 }
 
 static int run_coupling(glowhip_plan* P, const LayerPlan& L, const void* packed, const float* x1, long x1_bs, const float* z2_in,
@@ -90,8 +91,16 @@ static int run_coupling(glowhip_plan* P, const LayerPlan& L, const void* packed,
     const int Ch = d.C / 2, HW = d.H * d.W, hid = d.hidden;
     const bool use_sh = L.sh_mid && !g_sh_disabled;
     const bool use_sh_tail = use_sh && L.sh_tail && !g_sh_tail_disabled;
+    // fused f.0 + f.2 only when its one-workgroup-per-64-pixels grid still covers most of the chip (measured: with 64
+    // workgroups at the 8x8 level of a 64-image batch the two separate kernels are faster)
+    const bool use_f02 = use_sh_tail && L.sh_f02 && !g_sh_f02_disabled && (long)N * HW / 64 >= 192;
+    if (use_f02) {   // f.0 + f.2 fused: h1 stays in LDS (f02_sh.hip)
+        ScopedTimer t2(P, GLOWHIP_K_CONV_F2, 1, s);
+        GH_TRY(launch_f02_sh(x1, x1_bs, at<char>(packed, L.f0_sh), at<char>(packed, L.f2_sh), (_Float16*)w.h2, N, Ch, d.H, d.W,
+                             hid, s));
+    }
     // f.0: 3x3, Cin=C/2 -> hidden, ActNorm + ReLU epilogue
-    {
+    if (!use_f02) {
     ScopedTimer t0(P, GLOWHIP_K_CONV_F0, L.mfma_first || L.first_halo, s);
     if (use_sh && L.sh_first && !g_sh_first_disabled) {
         GH_TRY(launch_first_sh(x1, x1_bs, at<char>(packed, L.f0_sh), (_Float16*)w.h1, N, Ch, d.H, d.W, hid, 1, s));
@@ -109,7 +118,7 @@ static int run_coupling(glowhip_plan* P, const LayerPlan& L, const void* packed,
     }
     }
     // f.2: 1x1, hidden -> hidden, ActNorm + ReLU epilogue
-    {
+    if (!use_f02) {
     ScopedTimer t2(P, GLOWHIP_K_CONV_F2, L.mfma_mid, s);
     if (use_sh) {
         GH_TRY(launch_gemm_sh((const _Float16*)w.h1, at<char>(packed, L.f2_sh), use_sh_tail ? nullptr : w.h2,
@@ -343,6 +352,7 @@ glowhip_plan* glowhip_plan_create(const glowhip_layer_desc* layers, int n_layers
             L.sh_first = L.sh_mid && first_sh_supported(C / 2, H, W, d.hidden);
             if (L.sh_first) L.f0_sh = take(off, first_sh_packed_bytes(C / 2, d.hidden));
             L.sh_tail = L.sh_mid && tail_sh_supported(d.hidden, H, W, L.Cout);
+            L.sh_f02 = L.sh_first && L.sh_tail && f02_sh_supported(C / 2, H, W, d.hidden);
             if (L.sh_tail) L.f4_sh = take(off, tail_sh_packed_bytes(d.hidden, H, W, L.Cout));
             if (L.mfma_last) L.f4_wp = take(off, conv_mfma_tail_packed_bytes(d.hidden, L.Cout));
             L.dg4_first = conv_mfma_first_supported(L.Cout, H, W, d.hidden);
@@ -498,7 +508,8 @@ int glowhip_plan_describe(const glowhip_plan* plan, char* buf, size_t buf_bytes)
             const bool sh = L.sh_mid && !g_sh_disabled;
             snprintf(line, sizeof line, "%d flowstep C=%d H=%d W=%d hidden=%d f0=%s%s f2=%s%s f4=%s%s\n", li, d.C, d.H, d.W,
                      d.hidden, L.first_halo ? "mfma-halo" : (L.mfma_first ? "mfma" : "direct"),
-                     sh && L.sh_first && !g_sh_first_disabled ? "-sh" : "", L.mfma_mid ? "mfma" : "direct", sh ? "-sh" : "",
+                     sh && L.sh_first && !g_sh_first_disabled ? (L.sh_f02 && L.sh_tail && !g_sh_tail_disabled && !g_sh_f02_disabled ? "-sh-fused" : "-sh") : "",
+                     L.mfma_mid ? "mfma" : "direct", sh ? "-sh" : "",
                      L.mfma_last ? "mfma" : "direct", sh && L.sh_tail && !g_sh_tail_disabled ? "-sh" : "");
         }
         else snprintf(line, sizeof line, "%d split2d C=%d H=%d W=%d prior=%s\n", li, d.C, d.H, d.W,

@@ -25,6 +25,7 @@ struct LayerPlan {
     // split-half path (sh.h): f.0 writes h1 as an SH tensor, f.2 runs on the f16 matrix pipe (gemm_sh.hip)
     bool sh_mid = false; size_t f2_sh = 0;
     bool sh_first = false; size_t f0_sh = 0;  // f.0 itself on the f16 pipe (first_sh.hip)
+    bool sh_f02 = false;                       // f.0 + f.2 as one kernel (f02_sh.hip), h1 never written
     bool sh_tail = false; size_t f4_sh = 0;   // f.2 writes h2 as an SH tensor, f.4 + coupling on tail_sh.hip
     bool first_halo = false;  // f.0 on k_conv_first (stationary pixel window) instead of k_conv_wide<3>
 };

@@ -65,6 +65,11 @@ size_t first_sh_packed_bytes(int Cin, int Cout);
 int launch_first_sh(const float* x, long x_bs, const void* wsh, _Float16* y_sh, int N, int Cin, int H, int W, int Cout,
                     int relu, hipStream_t s);
 
+// ---- f.0 + f.2 fused (f02_sh.hip): fp32 z in, SH h2 out; h1 stays in LDS ----------------------------------
+bool f02_sh_supported(int Cin, int H, int W, int hidden);
+int launch_f02_sh(const float* x, long x_bs, const void* w0_first_sh_image, const void* w2_gemm_sh_image, _Float16* y_sh, int N,
+                  int Cin, int H, int W, int hidden, hipStream_t s);
+
 // ---- f.4 + coupling on SH operands (tail_sh.hip) ---------------------------------------------------
 struct TailShArgs {
     const _Float16* x_sh; long P;     // h2 as an SH tensor of P = N*H*W pixels, Cin channels

@@ -23,5 +23,8 @@ t[16:32] = list(buf)[16:32]
 def rel(idx, base): return [(t[i] - t[base]) for i in idx]
 print("tail:  prologue issued %d | first 8 stage starts %s | loop end %d | after sync %d | T written %d | tap sums done %d" % (
     t[1]-t[0], rel(range(8,16),0), t[2]-t[0], t[3]-t[0], t[4]-t[0], t[5]-t[0]))
+G.lib().glowhip_debug_read_stamps_f02(buf)
+u = list(buf)
+print("f02:   window built %d | phase 1 done %d | after barrier %d | phase 2 loop done %d | end %d" % (u[33]-u[32], u[34]-u[32], u[35]-u[32], u[36]-u[32], u[37]-u[32]))
 print("gemm:  prologue issued %d | first 8 stage starts %s | loop end %d | epilogue end %d" % (
     t[17]-t[16], rel(range(24,32),16), t[18]-t[16], t[19]-t[16]))
