@@ -229,31 +229,40 @@ def main():
         kinds = {0: "chanmix", 1: "conv_f0_3x3", 2: "conv_f2_1x1", 3: "conv_f4_3x3_tail"}
         desc = plan.describe()
         sh_path = "f2=mfma-sh" in desc
+        fused = {int(l.split()[0]) for l in desc.splitlines() if "-sh-fused" in l}   # layers whose f.0 + f.2 run as k_f02_sh
         bd = {}
         dom_ms, dom_flop, dom_bytes, dom_n = 0.0, 0.0, 0.0, 0
         for kind, layer, mfma, ms in recs:
             d = plan._descs[layer]
             key = f"{kinds.get(kind, 'other')}_C{d.C}_{d.H}x{d.W}"
+            if kind == 2 and layer in fused and B * d.H * d.W // 64 >= 192:
+                key = f"conv_f0+f2_fused_C{d.C}_{d.H}x{d.W}"
             bd.setdefault(key, [0.0, 0])
             bd[key][0] += ms
             bd[key][1] += 1
             total_px = B * d.H * d.W
             uses_128 = (hid // 128) * ((total_px + 127) // 128) >= 512
-            # dominant kernel = f.2: k_gemm_sh on the split-half path (every level), else k_gemm_glds (128x128 tiles)
-            if kind == 2 and mfma and (sh_path or uses_128):
+            if sh_path:
+                # dominant kernel = k_f02_sh: f.0 (3x3, C/2 -> hidden) + f.2 (1x1, hidden -> hidden) fused, h1 never in HBM
+                if key.startswith("conv_f0+f2_fused"):
+                    dom_ms += ms
+                    dom_flop += (2.0 * hid * hid + 2.0 * 9 * (d.C // 2) * hid) * total_px   # algorithmic (fp32-equivalent)
+                    dom_bytes += 4.0 * (d.C // 2) * total_px + 4.0 * hid * total_px           # read z1, write h2
+                    dom_n += 1
+            elif kind == 2 and mfma and uses_128:   # exact-fp32 path: k_gemm_glds (128x128 tiles)
                 dom_ms += ms
-                dom_flop += 2.0 * hid * hid * total_px           # algorithmic (fp32-equivalent) flops
-                dom_bytes += 2.0 * 4.0 * hid * total_px          # read h1 + write h2, 4 bytes per element either way
+                dom_flop += 2.0 * hid * hid * total_px
+                dom_bytes += 2.0 * 4.0 * hid * total_px
                 dom_n += 1
         achieved = dom_flop / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get("k_gemm_sh_hbm_bytes_per_launch" if sh_path else "k_gemm_glds_hbm_bytes_per_launch")
+            traffic = json.load(open(tpath)).get("k_f02_sh_hbm_bytes_per_launch" if sh_path else "k_gemm_glds_hbm_bytes_per_launch")
         peak = PEAK_SPLIT_TFLOPS if sh_path else PEAK_FP32_MFMA_TFLOPS
         out["roofline"] = {"bound": "mfma",
-                           "kernel": ("k_gemm_sh (f.2: 1x1 conv 512->512 + ActNorm + ReLU; fp32-accurate products as 3 f16 MFMAs, "
-                                      "peak = 2500/3 TFLOP/s algorithmic)") if sh_path else
+                           "kernel": ("k_f02_sh (f.0 3x3 conv C/2->512 + f.2 1x1 conv 512->512, both with ActNorm + ReLU, fused; "
+                                      "fp32-accurate products as 3 f16 MFMAs, peak = 2500/3 TFLOP/s algorithmic)") if sh_path else
                                      "k_gemm_glds (f.2: 1x1 conv 512->512 + ActNorm + ReLU, fp32-input MFMA, 128x128 tiles)",
                            "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                            "frac": round(achieved / peak, 4), "traffic": traffic,

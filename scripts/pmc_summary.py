@@ -23,17 +23,18 @@ def per_launch(agg, pat):
     sel = {k: v for k, v in agg.items() if pat in k[0]}
     tot = sum(v[0] for v in sel.values()); n = sum(v[1] for v in sel.values())
     return tot / n * 1024.0, {str(k[1]): v[0] / v[1] for k, v in sel.items()}
-f, fd = per_launch(fetch, "k_gemm_sh")
-w, wd = per_launch(write, "k_gemm_sh")
+f, fd = per_launch(fetch, "k_f02_sh")
+w, wd = per_launch(write, "k_f02_sh")
 out = json.load(open(os.path.join(root, "profiles", "pmc_traffic.json")))
-out["k_gemm_sh_hbm_bytes_per_launch"] = int(2 * f + w)
-out["k_gemm_sh_detail"] = {
+out.pop("k_gemm_sh_hbm_bytes_per_launch", None); out.pop("k_gemm_sh_detail", None)
+out["k_f02_sh_hbm_bytes_per_launch"] = int(2 * f + w)
+out["k_f02_sh_detail"] = {
     "fetch_bytes_corrected_x2": int(2 * f), "write_bytes": int(w),
     "FETCH_SIZE_KB_raw_by_grid_threads": fd, "WRITE_SIZE_KB_by_grid_threads": wd,
-    "algorithmic_bytes_avg": int(2 * 4 * 512 * 64 * (1024 + 256 + 64) / 3),
+    "algorithmic_bytes_avg": int((4 * 512 + 4 * 9) * 64 * (1024 + 256) / 2),   # write h2 + read z1 (6 / 12 channels), levels 1 and 2
     "method": "separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of `bench.py --steps 2 --warmup 1` (scripts/prof_pmc.sh); "
               "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B for 16 B/lane coalesced reads), "
-              "KB->bytes x1024; average over all launches of k_gemm_sh (levels 1, 2, 3 in equal numbers), as bench.py's roofline does",
+              "KB->bytes x1024; average over all launches of k_f02_sh (levels 1 and 2 in equal numbers; the weight stream, 1.2 MB per workgroup, is served by L2), as bench.py's roofline does",
 }
 json.dump(out, open(os.path.join(root, "profiles", "pmc_traffic.json"), "w"), indent=1)
-print(json.dumps({k: out[k] for k in ("k_gemm_sh_hbm_bytes_per_launch", "k_gemm_sh_detail")}, indent=1))
+print(json.dumps({k: out[k] for k in ("k_f02_sh_hbm_bytes_per_launch", "k_f02_sh_detail")}, indent=1))
