@@ -345,7 +345,7 @@ void conv_mfma_tail_force_tile(int v) {
     g_force_tp = v & 0xff;
     g_force_msplit = (v & 0x100) ? 1 : ((v & 0x200) ? 0 : -1);
     g_disable_tail_dma = (v & 0x400) != 0;   // | 0x400: register-staged kernels only
-    plan_disable_sh(((v & 0x800) ? 1 : 0) | ((v & 0x1000) ? 2 : 0) | ((v & 0x2000) ? 4 : 0) | ((v & 0x4000) ? 8 : 0));   // | 0x800: exact-fp32 MFMA kernels only; | 0x1000: fp32 tail behind the SH GEMM
+    plan_disable_sh(((v & 0x800) ? 1 : 0) | ((v & 0x1000) ? 2 : 0) | ((v & 0x2000) ? 4 : 0) | ((v & 0x4000) ? 8 : 0) | ((v & 0x8000) ? 16 : 0));   // | 0x800: exact-fp32 MFMA kernels only; | 0x1000: fp32 tail behind the SH GEMM
 }
 
 }  // namespace glowhip

@@ -78,15 +78,22 @@ static int carve(const glowhip_plan* p, int N, void* ws, size_t bytes, Workspace
 // ---------------------------------------------------------------- coupling network f() (network/module.py:300-319)
 // Runs conv3x3 -> actnorm -> relu -> conv1x1 -> actnorm -> relu -> conv3x3(zeros) and applies the
 // coupling to z2.  x1: first-half channels (batch stride x1_bs).
-static bool g_sh_disabled = false, g_sh_tail_disabled = false, g_sh_first_disabled = false, g_sh_f02_disabled = false;
+static bool g_sh_disabled = false, g_sh_tail_disabled = false, g_sh_first_disabled = false, g_sh_f02_disabled = false,
+            g_sh_mix_disabled = false;
 void plan_disable_sh(int off) {
     g_sh_disabled = (off & 1) != 0; g_sh_tail_disabled = (off & 2) != 0; g_sh_first_disabled = (off & 4) != 0;
     g_sh_f02_disabled = (off & 8) != 0;
+    g_sh_mix_disabled = (off & 16) != 0;
 }
+
+// Mixer of the NEXT step for tail_sh.hip to apply (forward only); C = 0: none
+struct NextMix { int C; float* out; long out_bs; const float* bias; const float* scale; const float* matrix; const int32_t* gather; };
+
+static bool tail_runs_sh(const LayerPlan& L) { return L.sh_mid && L.sh_tail && !g_sh_disabled && !g_sh_tail_disabled; }
 
 static int run_coupling(glowhip_plan* P, const LayerPlan& L, const void* packed, const float* x1, long x1_bs, const float* z2_in,
                         long z2_in_bs, float* z2_out, long z2_out_bs, int N, int reverse, const Workspace& w,
-                        hipStream_t s) {
+                        hipStream_t s, const NextMix* mix = nullptr) {
     const glowhip_layer_desc& d = L.d;
     const int Ch = d.C / 2, HW = d.H * d.W, hid = d.hidden;
     const bool use_sh = L.sh_mid && !g_sh_disabled;
@@ -143,6 +150,10 @@ static int run_coupling(glowhip_plan* P, const LayerPlan& L, const void* packed,
                                                        : (reverse ? TAIL_ADD_REV : TAIL_ADD_FWD);
         t.z2_in = z2_in; t.z2_in_bs = z2_in_bs; t.z2_out = z2_out; t.z2_out_bs = z2_out_bs; t.acc = w.acc;
         t.zeros = at<float>(packed, 64);
+        if (mix && mix->C) {
+            t.mix_C = mix->C; t.mix_z1 = x1; t.mix_z1_bs = x1_bs; t.mix_out = mix->out; t.mix_out_bs = mix->out_bs;
+            t.mix_bias = mix->bias; t.mix_scale = mix->scale; t.mix_matrix = mix->matrix; t.mix_gather = mix->gather;
+        }
         GH_TRY(launch_tail_sh(t, s));
     } else if (L.mfma_last) {
         TailConvArgs t{};
@@ -198,6 +209,7 @@ static int run_forward(glowhip_plan* p, const void* packed, const float* x, cons
                        const Workspace& w, hipStream_t s) {
     const float* cur = x;
     const int nl = (int)p->layers.size();
+    bool premixed = false;   // `cur` already holds this step's ActNorm + permutation output (applied by the previous tail)
     for (int li = 0; li < nl; ++li) {
         const LayerPlan& L = p->layers[li];
         const glowhip_layer_desc& d = L.d;
@@ -218,19 +230,36 @@ static int run_forward(glowhip_plan* p, const void* packed, const float* x, cons
             }
             const int Ch = d.C / 2;
             if (d.kind == GLOWHIP_LAYER_FLOWSTEP) {
-                ChanMixArgs m{};
-                m.in_a = cur; m.in_a_bs = chw; m.in_b = cur + (long)Ch * HW; m.in_b_bs = chw; m.Ca = Ch;
-                m.out = dst; m.out_bs = chw;
-                m.bias = d.an_bias; m.scale = at<float>(packed, L.an_scale);
-                m.matrix = d.permutation == GLOWHIP_PERM_INVCONV ? d.invconv_w : nullptr;
-                m.gather = d.permutation == GLOWHIP_PERM_GATHER ? d.perm_idx : nullptr;
-                m.reverse = 0; m.N = N; m.C = d.C; m.HW = HW;
-                {
+                if (premixed) {
+                    dst = const_cast<float*>(cur);   // the step runs in place on the already mixed buffer
+                } else {
+                    ChanMixArgs m{};
+                    m.in_a = cur; m.in_a_bs = chw; m.in_b = cur + (long)Ch * HW; m.in_b_bs = chw; m.Ca = Ch;
+                    m.out = dst; m.out_bs = chw;
+                    m.bias = d.an_bias; m.scale = at<float>(packed, L.an_scale);
+                    m.matrix = d.permutation == GLOWHIP_PERM_INVCONV ? d.invconv_w : nullptr;
+                    m.gather = d.permutation == GLOWHIP_PERM_GATHER ? d.perm_idx : nullptr;
+                    m.reverse = 0; m.N = N; m.C = d.C; m.HW = HW;
                     ScopedTimer tm(p, GLOWHIP_K_CHANMIX, 0, s);
                     GH_TRY(launch_chanmix(m, s));
                 }
+                // Let this step's tail apply the NEXT step's channel mixer (one launch less per step) when the next layer is
+                // a FlowStep of the same shape that may run in place (i.e. is not the one writing z_out)
+                NextMix nm{};
+                if (li + 1 < nl - 1 && !g_sh_mix_disabled && tail_runs_sh(L)) {
+                    const LayerPlan& Ln = p->layers[li + 1];
+                    const glowhip_layer_desc& dn = Ln.d;
+                    if (dn.kind == GLOWHIP_LAYER_FLOWSTEP && dn.C == d.C && dn.H == d.H && dn.W == d.W &&
+                        tail_sh_mix_supported(d.hidden, d.H, d.W, L.Cout, d.C)) {
+                        nm.C = d.C; nm.out = dst; nm.out_bs = chw;
+                        nm.bias = dn.an_bias; nm.scale = at<float>(packed, Ln.an_scale);
+                        nm.matrix = dn.permutation == GLOWHIP_PERM_INVCONV ? dn.invconv_w : nullptr;
+                        nm.gather = dn.permutation == GLOWHIP_PERM_GATHER ? dn.perm_idx : nullptr;
+                    }
+                }
                 float* z2 = dst + (long)Ch * HW;
-                GH_TRY(run_coupling(p, L, packed, dst, chw, z2, chw, z2, chw, N, 0, w, s));
+                GH_TRY(run_coupling(p, L, packed, dst, chw, z2, chw, z2, chw, N, 0, w, s, &nm));
+                premixed = nm.C != 0;
             } else {  // SPLIT2D: score z2 under the prior predicted from z1, keep z1
                 GH_TRY(run_split(L, packed, cur, chw, cur + (long)Ch * HW, chw, nullptr, nullptr, 0, N, 0, w, s));
                 GH_TRY(launch_copy_strided(cur, chw, dst, (long)Ch * HW, N, (long)Ch * HW, s));

@@ -82,7 +82,18 @@ struct TailShArgs {
     float* z2_out; long z2_out_bs;
     unsigned long long* acc;
     const float* zeros;               // >= 16 B of zeros in global memory
+    // Optional: the NEXT FlowStep's channel mixer (ActNorm + invertible 1x1 conv / permutation, forward) applied to this
+    // step's output z = (z1, z2_out) before it is written: y = M ((z + bias) * scale) goes to mix_out (N,C,H,W; may be the
+    // buffer z lives in -- a workgroup reads and writes only its own pixels) and z2_out is not written.  Saves the
+    // k_chanmix launch of the next step.  mix_C = 0: off.  Needs one channel group (all of z2 in one workgroup).
+    int mix_C;
+    const float* mix_z1; long mix_z1_bs;      // z1 of this step (first C/2 channels)
+    float* mix_out; long mix_out_bs;
+    const float* mix_bias; const float* mix_scale;   // (C) of the next step's ActNorm: bias, exp(3 logs)
+    const float* mix_matrix;                  // (C,C) row-major, or null
+    const int32_t* mix_gather;                // (C) gather table, or null
 };
+bool tail_sh_mix_supported(int Cin, int H, int W, int Cout, int C);
 bool tail_sh_supported(int Cin, int H, int W, int Cout);
 size_t tail_sh_packed_bytes(int Cin, int H, int W, int Cout);
 int tail_sh_mpad(int Cin, int H, int W, int Cout, int* groups);   // padded rows per channel group of the packed image

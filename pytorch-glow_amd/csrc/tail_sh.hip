@@ -74,17 +74,23 @@ __global__ void __launch_bounds__(64 * NWV) k_tail_sh(TailShArgs a, int WGM, int
     const bool paired = a.mode == TAIL_AFFINE_FWD || a.mode == TAIL_AFFINE_REV;
     const int nch = paired ? Cout / 2 : Cout;
     const int nitems = nch * tile_px;
-    float zin[TSH_MAXE];
+    float zin[TSH_MAXE], z1in[TSH_MAXE];
 #pragma unroll
     for (int i = 0; i < TSH_MAXE; ++i) {
         const int e = tid + i * NTHR;
-        zin[i] = 0.f;
+        zin[i] = 0.f; z1in[i] = 0.f;
         if (e < nitems) {
             const int c = e / tile_px, q = e - c * tile_px;
             const int cg = (paired ? c0 / 2 : c0) + c;
             zin[i] = a.z2_in[n * a.z2_in_bs + (long)cg * HW + (long)y0 * W + q];
+            if (a.mix_C) z1in[i] = a.mix_z1[n * a.mix_z1_bs + (long)c * HW + (long)y0 * W + q];
         }
     }
+    // fused mixer of the next step: its matrix (or gather table) into LDS now, its inputs staged after the tap sums
+    float* mixv = reinterpret_cast<float*>(tailp + 1024 + 64);   // [C][tile_px], then [C*C] matrix
+    float* mixm = mixv + a.mix_C * tile_px;
+    if (a.mix_C && a.mix_matrix)
+        for (int e = tid; e < a.mix_C * a.mix_C; e += NTHR) mixm[e] = a.mix_matrix[e];
 
     // ---- DMA pieces of this wave: q = wid + NWV*i.  A pieces first ((plane, chunk, 64-row group)), then B pieces
     const _Float16* src[PPW];
@@ -237,18 +243,42 @@ __global__ void __launch_bounds__(64 * NWV) k_tail_sh(TailShArgs a, int WGM, int
         const int cg = (paired ? c0 / 2 : c0) + c;     // coupling channel in the full tensor
         const long zo = n * a.z2_out_bs + (long)cg * HW + (long)y0 * W + q;
         const float A_ = (se + a.bias[c0 + ce]) * a.scale[c0 + ce];
+        float zres;
         if (paired) {
             const float B_ = (so + a.bias[c0 + ce + 1]) * a.scale[c0 + ce + 1];
             const float sc = sigmoidf_(B_ + 2.0f);
             if (a.mode == TAIL_AFFINE_FWD) {
-                a.z2_out[zo] = (zin[i] + A_) * sc;
+                zres = (zin[i] + A_) * sc;
                 ld += (double)logf(sc);
             } else {
-                a.z2_out[zo] = zin[i] / sc - A_;
+                zres = zin[i] / sc - A_;
                 ld -= (double)logf(sc);
             }
         } else {
-            a.z2_out[zo] = a.mode == TAIL_ADD_FWD ? zin[i] + A_ : zin[i] - A_;
+            zres = a.mode == TAIL_ADD_FWD ? zin[i] + A_ : zin[i] - A_;
+        }
+        if (a.mix_C) {   // ActNorm of the next step on both halves of this pixel's channel c, staged for the mixer
+            const int Chh = a.mix_C >> 1;
+            mixv[c * tile_px + q] = (z1in[i] + a.mix_bias[c]) * a.mix_scale[c];
+            mixv[(Chh + c) * tile_px + q] = (zres + a.mix_bias[Chh + c]) * a.mix_scale[Chh + c];
+        } else {
+            a.z2_out[zo] = zres;
+        }
+    }
+    if (a.mix_C) {
+        __syncthreads();
+        const int C = a.mix_C;
+        for (int e = tid; e < C * tile_px; e += NTHR) {
+            const int o = e / tile_px, q = e - o * tile_px;
+            float r;
+            if (a.mix_matrix) {   // same operation order as k_chanmix: r = fma(m[o][i], v[i], r), i ascending
+                r = 0.f;
+                const float* m = mixm + o * C;
+                for (int i = 0; i < C; ++i) r = fmaf(m[i], mixv[i * tile_px + q], r);
+            } else {
+                r = mixv[(a.mix_gather ? a.mix_gather[o] : o) * tile_px + q];
+            }
+            a.mix_out[n * a.mix_out_bs + (long)o * HW + (long)y0 * W + q] = r;
         }
     }
     GH_STAMP(5);
@@ -309,6 +339,18 @@ static bool tail_sh_config(int Cin, int H, int W, int Cout, TailShCfg* out) {
 
 bool tail_sh_supported(int Cin, int H, int W, int Cout) { return tail_sh_config(Cin, H, W, Cout, nullptr); }
 
+static size_t tail_sh_mix_bytes(int C, int R, int W) { return ((size_t)C * R * W + (size_t)C * C) * sizeof(float); }
+
+// the fused mixer needs every channel of z2 in one workgroup (one channel group) and its scratch inside the LDS
+bool tail_sh_mix_supported(int Cin, int H, int W, int Cout, int C) {
+    TailShCfg c;
+    if (!tail_sh_config(Cin, H, W, Cout, &c) || c.groups != 1 || C > 64) return false;
+    const int Nw = (c.R + 2) * W;
+    const size_t ring = (size_t)TSH_ST * 4 * (c.Mpad + c.Nwpad) * 8 * sizeof(_Float16);
+    const size_t tb = (size_t)Nw * tail_sh_trow(9 * Cout) * sizeof(float);
+    return std::max(ring, tb) + 1024 + 64 + tail_sh_mix_bytes(C, c.R, W) <= 160 * 1024;
+}
+
 size_t tail_sh_packed_bytes(int Cin, int H, int W, int Cout) {
     TailShCfg c;
     if (!tail_sh_config(Cin, H, W, Cout, &c)) return 0;
@@ -333,7 +375,9 @@ int launch_tail_sh(const TailShArgs& a, hipStream_t s) {
     GH_REQUIRE((paired ? Cg / 2 : Cg) * c.R * a.W <= TSH_MAXE * 64 * c.NWV, "tail_sh: too many epilogue items per workgroup");
     const size_t ring = (size_t)TSH_ST * 4 * (c.Mpad + c.Nwpad) * 8 * sizeof(_Float16);
     const size_t tb = (size_t)Nw * tail_sh_trow(9 * Cg) * sizeof(float);
-    const size_t lds = std::max(ring, tb) + 1024 + 64;
+    GH_REQUIRE(a.mix_C == 0 || (tail_sh_mix_supported(a.Cin, a.H, a.W, a.Cout, a.mix_C) && a.mix_z1 && a.mix_out && a.mix_bias &&
+                                a.mix_scale), "tail_sh: fused mixer unsupported for this shape");
+    const size_t lds = std::max(ring, tb) + 1024 + 64 + (a.mix_C ? tail_sh_mix_bytes(a.mix_C, c.R, a.W) : 0);
     const unsigned grid = (unsigned)(a.N * (a.H / c.R));
 #define GH_TSH_CASE(mw, nw, ppw, nwv)                                                                                 \
     if (c.MW == mw && c.NW == nw && c.PPW == ppw && c.NWV == nwv) {                                                   \
