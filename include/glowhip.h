@@ -139,6 +139,13 @@ size_t glowhip_plan_workspace_bytes(const glowhip_plan* plan, int N);
  * convolution weights for the MFMA kernels, in-kernel LU -> log|det W| and W^-1) into `packed`.
  * Call after the parameters changed (optimizer step, load_state_dict, ActNorm init). */
 int glowhip_plan_pack(glowhip_plan* plan, void* packed, size_t packed_bytes, glowhip_stream_t stream);
+/* The same, restricted to the weight images a caller is going to use: GLOWHIP_PACK_INFERENCE = what encode / decode /
+ * glow_forward read (the split-half images where those kernels apply), GLOWHIP_PACK_TRAINING = what glow_forward_train /
+ * glow_backward read (exact-fp32 images + the flipped/transposed input-gradient images).  glowhip_plan_pack = both.
+ * Scale tables, W^-1 and log|det W| are always refreshed. */
+#define GLOWHIP_PACK_INFERENCE 1
+#define GLOWHIP_PACK_TRAINING 2
+int glowhip_plan_pack_for(glowhip_plan* plan, void* packed, size_t packed_bytes, int use, glowhip_stream_t stream);
 
 /* FlowModel.encode: x (N, C0,H0,W0 of layer 0) -> z (output shape of the last layer),
  * logdet_out[n] = (logdet_in ? logdet_in[n] : 0) + sum of all layers' log-determinant terms.

@@ -118,14 +118,19 @@ class FlowPlan:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._ws
 
-    def pack(self) -> None:
-        """Refresh everything derived from the parameters (exp(3 logs), MFMA weight images, LU)."""
-        check(lib().glowhip_plan_pack(self._h, ptr(self.packed), self.packed.numel(), stream_ptr(self.device)))
-        self._packed_version = self._version_signature()
+    PACK_INFERENCE, PACK_TRAINING = 1, 2   # glowhip.h GLOWHIP_PACK_*
 
-    def ensure_packed(self, force: bool = False) -> None:
-        if force or self._packed_version != self._version_signature():
-            self.pack()
+    def pack(self, use: int = 3) -> None:
+        """Refresh what is derived from the parameters (exp(3 logs), LU, and the weight images `use` asks for: the inference
+        kernels' and/or the training kernels')."""
+        check(lib().glowhip_plan_pack_for(self._h, ptr(self.packed), self.packed.numel(), use, stream_ptr(self.device)))
+        self._packed_version = self._version_signature()
+        self._packed_use = use
+
+    def ensure_packed(self, force: bool = False, use: int = 1) -> None:
+        have = getattr(self, "_packed_use", 0)
+        if force or self._packed_version != self._version_signature() or (use & ~have):
+            self.pack(use)
 
     def invalidate(self) -> None:
         self._packed_version = None
@@ -216,7 +221,7 @@ class FlowPlan:
     def glow_forward_train(self, x, noise, prior_mean, prior_logs, prior_stride, n_bits):
         """Forward that records the activation tape; returns (z, nll, tape)."""
         n = x.shape[0]
-        self.ensure_packed(True)   # weights are expected to have just been updated
+        self.ensure_packed(True, use=self.PACK_TRAINING)   # weights are expected to have just been updated
         z = torch.empty((n,) + self.out_chw, dtype=torch.float32, device=self.device)
         nll = torch.empty(n, dtype=torch.float32, device=self.device)
         tape = torch.empty(int(lib().glowhip_plan_tape_bytes(self._h, n)), dtype=torch.uint8, device=self.device)
@@ -255,7 +260,8 @@ class FlowPlan:
         ws = self._workspace(n)
         check(lib().glowhip_plan_actnorm_init(self._h, ptr(self.packed), self.packed.numel(), ptr(x), ptr(noise),
                                               float(actnorm_scale), n, ptr(ws), ws.numel(), stream_ptr(self.device)))
-        self._packed_version = self._version_signature()
+        self._packed_version = self._version_signature()   # the init pass ends with a full glowhip_plan_pack
+        self._packed_use = 3
 
 
 class PlanCache:

@@ -77,6 +77,7 @@ struct RepackJob {
     int Cin, Cout, K, Kpad;      // wide: K = Cin*k*k
     int paired, MT; long total;  // tail
     const float* fold_bias; const float* fold_logs;  // first: ActNorm folded into the image (NULL: plain weights)
+    int use;                     // who reads this image: bit 0 = inference kernels (encode/decode/glow_forward), bit 1 = training
     int transposed;              // source is the FORWARD weight (Cin,Cout,3,3) of which this is the input-gradient conv:
                                  // element (o, ci, tap) = w[ci][o][8 - tap]
 };

@@ -422,48 +422,49 @@ glowhip_plan* glowhip_plan_create(const glowhip_layer_desc* layers, int n_layers
             p->scale_jobs.push_back(ScaleJob{d.f4_logs, L.f4_scale, 0, L.Cout, 0});
             if (L.first_halo) {
                 RepackJob r{}; r.w = d.f0_w; r.out_off = L.f0_wt; r.kind = REPACK_FIRST; r.Cin = d.C / 2; r.Cout = d.hidden;
-                r.fold_bias = d.f0_an_bias; r.fold_logs = d.f0_an_logs;
+                r.fold_bias = d.f0_an_bias; r.fold_logs = d.f0_an_logs; r.use = 2 | (L.sh_first ? 0 : 1);
                 p->repack_jobs.push_back(r);
             } else if (L.mfma_first) {
                 RepackJob r{}; r.w = d.f0_w; r.out_off = L.f0_wt; r.kind = REPACK_WIDE; r.Cin = d.C / 2; r.Cout = d.hidden;
-                r.K = r.Cin * 9; r.Kpad = wide_kpad(r.Cin, 3); p->repack_jobs.push_back(r);
+                r.K = r.Cin * 9; r.Kpad = wide_kpad(r.Cin, 3); r.use = 3; p->repack_jobs.push_back(r);
             }
             if (L.mfma_mid) {
                 RepackJob r{}; r.w = d.f2_w; r.out_off = L.f2_wt; r.kind = REPACK_WIDE; r.Cin = d.hidden; r.Cout = d.hidden;
-                r.K = r.Cin; r.Kpad = wide_kpad(r.Cin, 1); p->repack_jobs.push_back(r);
+                r.K = r.Cin; r.Kpad = wide_kpad(r.Cin, 1); r.use = 2 | (L.sh_mid ? 0 : 1); p->repack_jobs.push_back(r);
             }
             if (L.sh_mid) {
                 RepackJob r{}; r.w = d.f2_w; r.out_off = L.f2_sh; r.kind = REPACK_SH_GEMM; r.Cin = d.hidden; r.Cout = d.hidden;
-                r.K = d.hidden; r.fold_bias = d.f2_an_bias; r.fold_logs = d.f2_an_logs; p->repack_jobs.push_back(r);
+                r.K = d.hidden; r.fold_bias = d.f2_an_bias; r.fold_logs = d.f2_an_logs; r.use = 1; p->repack_jobs.push_back(r);
             }
             if (L.sh_first) {
                 RepackJob r{}; r.w = d.f0_w; r.out_off = L.f0_sh; r.kind = REPACK_SH_FIRST; r.Cin = d.C / 2; r.Cout = d.hidden;
-                r.K = (9 * ((r.Cin + 7) / 8) + 1) & ~1; r.fold_bias = d.f0_an_bias; r.fold_logs = d.f0_an_logs;
+                r.K = (9 * ((r.Cin + 7) / 8) + 1) & ~1; r.fold_bias = d.f0_an_bias; r.fold_logs = d.f0_an_logs; r.use = 1;
                 p->repack_jobs.push_back(r);
             }
             if (L.sh_tail) {
                 RepackJob r{}; r.w = d.f4_w; r.out_off = L.f4_sh; r.kind = REPACK_SH_TAIL; r.Cin = d.hidden; r.Cout = L.Cout;
-                r.Kpad = tail_sh_mpad(d.hidden, d.H, d.W, L.Cout, &r.MT); p->repack_jobs.push_back(r);
+                r.Kpad = tail_sh_mpad(d.hidden, d.H, d.W, L.Cout, &r.MT); r.use = 1; p->repack_jobs.push_back(r);
             }
             if (L.mfma_last) {
                 RepackJob r{}; r.w = d.f4_w; r.out_off = L.f4_wp; r.kind = REPACK_TAIL; r.Cin = d.hidden; r.Cout = L.Cout;
                 r.paired = d.coupling == GLOWHIP_COUPLING_AFFINE; r.MT = tail_mt(L.Cout, r.paired);
+                r.use = 2 | (L.sh_tail ? 0 : 1);
                 r.total = (long)tail_chunks(r.Cin) * (TAIL_CK / 4) * 9 * r.MT * 64; p->repack_jobs.push_back(r);
             }
             if (L.dg4_first) {   // input gradient of f.4 = 3x3 conv Cout -> hidden with w[ci][o][8-tap]
                 RepackJob r{}; r.w = d.f4_w; r.out_off = L.f4T_wf; r.kind = REPACK_FIRST; r.Cin = L.Cout; r.Cout = d.hidden;
-                r.transposed = 1; p->repack_jobs.push_back(r);
+                r.transposed = 1; r.use = 2; p->repack_jobs.push_back(r);
             }
             if (L.dg0_tail) {    // input gradient of f.0 = 3x3 conv hidden -> C/2
                 RepackJob r{}; r.w = d.f0_w; r.out_off = L.f0T_wp; r.kind = REPACK_TAIL; r.Cin = d.hidden; r.Cout = d.C / 2;
-                r.paired = 0; r.MT = tail_mt(r.Cout, 0); r.transposed = 1;
+                r.paired = 0; r.MT = tail_mt(r.Cout, 0); r.transposed = 1; r.use = 2;
                 r.total = (long)tail_chunks(r.Cin) * (TAIL_CK / 4) * 9 * r.MT * 64; p->repack_jobs.push_back(r);
             }
         } else if (d.kind == GLOWHIP_LAYER_SPLIT2D) {
             p->scale_jobs.push_back(ScaleJob{d.f4_logs, L.f4_scale, 0, L.Cout, 0});
             if (L.mfma_last) {
                 RepackJob r{}; r.w = d.f4_w; r.out_off = L.f4_wp; r.kind = REPACK_TAIL; r.Cin = d.C / 2; r.Cout = L.Cout;
-                r.paired = 1; r.MT = tail_mt(L.Cout, 1);
+                r.paired = 1; r.MT = tail_mt(L.Cout, 1); r.use = 3;
                 r.total = (long)tail_chunks(r.Cin) * (TAIL_CK / 4) * 9 * r.MT * 64; p->repack_jobs.push_back(r);
             }
         }
@@ -551,7 +552,17 @@ int glowhip_plan_describe(const glowhip_plan* plan, char* buf, size_t buf_bytes)
 }
 
 int glowhip_plan_pack(glowhip_plan* plan, void* packed, size_t packed_bytes, glowhip_stream_t stream) {
+    return glowhip_plan_pack_for(plan, packed, packed_bytes, GLOWHIP_PACK_INFERENCE | GLOWHIP_PACK_TRAINING, stream);
+}
+
+int glowhip_plan_pack_for(glowhip_plan* plan, void* packed, size_t packed_bytes, int use, glowhip_stream_t stream) {
     GH_REQUIRE(plan && packed, "plan_pack: null argument");
+    GH_REQUIRE(use & (GLOWHIP_PACK_INFERENCE | GLOWHIP_PACK_TRAINING), "plan_pack: empty use mask");
+    // with a kernel family switched off through the debug hook the other family's images are needed after all
+    if (g_sh_disabled || g_sh_tail_disabled || g_sh_first_disabled) use = GLOWHIP_PACK_INFERENCE | GLOWHIP_PACK_TRAINING;
+    plan->repack_sel.clear();
+    for (const RepackJob& r : plan->repack_jobs)
+        if (r.use & use) plan->repack_sel.push_back(r);
     GH_REQUIRE(packed_bytes >= plan->packed_bytes, "plan_pack: packed buffer too small (%zu < %zu)", packed_bytes,
                plan->packed_bytes);
     hipStream_t s = (hipStream_t)stream;
@@ -565,12 +576,12 @@ int glowhip_plan_pack(glowhip_plan* plan, void* packed, size_t packed_bytes, glo
     };
     if (!upload(plan->prep_off, plan->prep_jobs.data(), plan->prep_jobs.size() * sizeof(StepPrepJob)) ||
         !upload(plan->scale_off, plan->scale_jobs.data(), plan->scale_jobs.size() * sizeof(ScaleJob)) ||
-        !upload(plan->repack_off, plan->repack_jobs.data(), plan->repack_jobs.size() * sizeof(RepackJob))) {
+        !upload(plan->repack_off, plan->repack_sel.data(), plan->repack_sel.size() * sizeof(RepackJob))) {
         set_error("plan_pack: hipMemcpyAsync of the job tables failed");
         return GLOWHIP_ELAUNCH;
     }
     GH_TRY(launch_pack_batched(at<ScaleJob>(packed, plan->scale_off), (int)plan->scale_jobs.size(),
-                               at<RepackJob>(packed, plan->repack_off), (int)plan->repack_jobs.size(), packed, s));
+                               at<RepackJob>(packed, plan->repack_off), (int)plan->repack_sel.size(), packed, s));
     GH_TRY(launch_step_prepare_batched(at<StepPrepJob>(packed, plan->prep_off), (int)plan->prep_jobs.size(),
                                        plan->max_lds_c, packed, s));
     return GLOWHIP_OK;

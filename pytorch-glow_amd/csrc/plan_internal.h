@@ -46,6 +46,7 @@ struct glowhip_plan {
     std::vector<StepPrepJob> prep_jobs;
     std::vector<ScaleJob> scale_jobs;
     std::vector<RepackJob> repack_jobs;
+    std::vector<RepackJob> repack_sel;    // the subset selected by the last glowhip_plan_pack_for (kept alive for the async copy)
     size_t prep_off = 0, scale_off = 0, repack_off = 0;
     int max_lds_c = 0;
     size_t packed_bytes = 0;
