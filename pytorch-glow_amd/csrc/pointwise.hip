@@ -127,12 +127,16 @@ int launch_actnorm_init(const float* x, long xbs, int N, int C, int HW, float sc
 // matrix rows a wave needs are wave-uniform (scalar cache), OB outputs share each LDS read.  Splitting the
 // outputs over 4 waves keeps the grid >= 4x larger than one-thread-per-pixel, which is what the deep levels
 // (C=48 on 4096 pixels) need to occupy the chip.
-constexpr int CM_PX = 64;
-__global__ void __launch_bounds__(256) k_chanmix(ChanMixArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float v[];  // [C][CM_PX]
-    const int px = threadIdx.x & (CM_PX - 1);
-    const int og = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave id: provably uniform
-    const long gp = (long)blockIdx.x * CM_PX + px;
+// PX pixels per workgroup, 256 / PX output groups per pixel: 64 x 4 for the large levels (the output group is the wave id, so
+// the matrix row is a scalar operand), 16 x 16 for the deep ones (4096 pixels x 48 channels would otherwise be 64
+// workgroups of 576 serial FMAs per thread: 16 us for 9 MFLOP).
+template <int PX>
+__global__ void __launch_bounds__(256) k_chanmix(ChanMixArgs a, int stage_matrix) {
+    constexpr int OG = 256 / PX;
+    extern __shared__ __attribute__((aligned(16))) float v[];  // [C][PX]
+    const int px = threadIdx.x & (PX - 1);
+    const int og = PX == 64 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : (int)(threadIdx.x / PX);
+    const long gp = (long)blockIdx.x * PX + px;
     const long total = (long)a.N * a.HW;
     const bool valid = gp < total;
     const long n = valid ? gp / a.HW : 0;
@@ -142,14 +146,19 @@ __global__ void __launch_bounds__(256) k_chanmix(ChanMixArgs a) {
     const float* pb = a.in_b + n * a.in_b_bs + p;
     float* po = a.out + n * a.out_bs + p;
     const bool an = a.bias != nullptr;
-    for (int c = og; c < C; c += 4) {
+    for (int c = og; c < C; c += OG) {
         float xv = 0.f;
         if (valid) xv = (c < a.Ca) ? pa[(long)c * a.HW] : pb[(long)(c - a.Ca) * a.HW];
         if (!a.reverse && an) xv = (xv + a.bias[c]) * a.scale[c];
-        v[c * CM_PX + px] = xv;
+        v[c * PX + px] = xv;
     }
+    // the matrix goes through LDS as well (one coalesced pass): read from global inside the FMA loop, its C*C dependent
+    // loads were the whole run time of this kernel at the deep levels
+    float* mlds = v + C * PX;
+    if (a.matrix && stage_matrix)
+        for (int e = threadIdx.x; e < C * C; e += 256) mlds[e] = a.matrix[e];
     __syncthreads();
-    const int per = (C + 3) / 4;
+    const int per = (C + OG - 1) / OG;
     const int o_begin = og * per, o_end = min(C, o_begin + per);
     constexpr int OB = 4;
     for (int o = o_begin; o < o_end; o += OB) {
@@ -157,16 +166,16 @@ __global__ void __launch_bounds__(256) k_chanmix(ChanMixArgs a) {
         if (a.matrix) {
 #pragma unroll
             for (int j = 0; j < OB; ++j) r[j] = 0.f;
-            const float* m = a.matrix + (long)o * C;
+            const float* m = stage_matrix ? mlds + o * C : a.matrix + (long)o * C;
             if (o + OB <= o_end) {
                 for (int i = 0; i < C; ++i) {
-                    const float vi = v[i * CM_PX + px];
+                    const float vi = v[i * PX + px];
 #pragma unroll
                     for (int j = 0; j < OB; ++j) r[j] = fmaf(m[j * C + i], vi, r[j]);
                 }
             } else {
                 for (int i = 0; i < C; ++i) {
-                    const float vi = v[i * CM_PX + px];
+                    const float vi = v[i * PX + px];
 #pragma unroll
                     for (int j = 0; j < OB; ++j)
                         if (o + j < o_end) r[j] = fmaf(m[j * C + i], vi, r[j]);
@@ -176,7 +185,7 @@ __global__ void __launch_bounds__(256) k_chanmix(ChanMixArgs a) {
 #pragma unroll
             for (int j = 0; j < OB; ++j) {
                 const int oc = o + j;
-                r[j] = oc < o_end ? v[(a.gather ? a.gather[oc] : oc) * CM_PX + px] : 0.f;
+                r[j] = oc < o_end ? v[(a.gather ? a.gather[oc] : oc) * PX + px] : 0.f;
             }
         }
         if (valid) {
@@ -197,10 +206,17 @@ int launch_chanmix(const ChanMixArgs& a, hipStream_t s) {
     GH_REQUIRE(a.C > 0 && a.C <= 512, "channel mixer: C=%d unsupported (1..512)", a.C);
     const long total = (long)a.N * a.HW;
     if (total == 0) return GLOWHIP_OK;
-    const size_t lds = (size_t)a.C * CM_PX * sizeof(float);
+    const int stage = (size_t)a.C * a.C * sizeof(float) <= 48 * 1024;   // C <= 110: the matrix fits next to the pixel tile
+    const size_t mbytes = stage ? (size_t)a.C * a.C * sizeof(float) : 0;
+    if (total < 16384 && a.C >= 16 && stage) {   // deep levels: 16 pixels x 16 output groups per workgroup
+        hipLaunchKernelGGL(k_chanmix<16>, dim3(cdiv(total, 16)), dim3(256), (size_t)a.C * 16 * sizeof(float) + mbytes, s, a, stage);
+        GH_LAUNCH_CHECK("k_chanmix");
+        return GLOWHIP_OK;
+    }
+    const size_t lds = (size_t)a.C * 64 * sizeof(float) + mbytes;
     if (lds > 32 * 1024)
-        (void)hipFuncSetAttribute((const void*)k_chanmix, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_chanmix, dim3(cdiv(total, CM_PX)), dim3(256), lds, s, a);
+        (void)hipFuncSetAttribute((const void*)k_chanmix<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_chanmix<64>, dim3(cdiv(total, 64)), dim3(256), lds, s, a, stage);
     GH_LAUNCH_CHECK("k_chanmix");
     return GLOWHIP_OK;
 }
