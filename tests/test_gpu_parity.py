@@ -550,3 +550,44 @@ def test_deep_multiscale_configs_vs_oracle(name, image, L, K, hidden, batch):
     desc = glow.flow.plan_for(dev(x)).describe()
     print(f"{name}: max-abs z {ez:.2e} nll {en:.2e} decode {ex:.2e}; direct-kernel layers: "
           f"{sum('direct' in l for l in desc.splitlines())}/{len(desc.splitlines())}")
+
+
+@pytest.mark.parametrize("coup,perm", [("affine", "invconv"), ("additive", "reverse"), ("affine", "shuffle"),
+                                       ("additive", "invconv")])
+def test_split_half_stack_every_coupling_and_permutation(coup, perm):
+    """A 3-level stack (32^2, 16^2, 8^2 pixels; hidden 128; odd batch) whose FlowSteps all take the split-half kernels: the
+    fused f.0+f.2 kernel, the taps-as-rows tail with both coupling kinds, and the tail applying the NEXT step's channel
+    mixer -- as a matrix (invconv) and as a gather (reverse / shuffle).  Checked against the oracle, forward and inverse,
+    and against the same run with the mixer fusion switched off: the fused mixer keeps k_chanmix's operation order, so the
+    two must agree bit for bit."""
+    batch = 3
+    cfg = O.default_cfg(image_shape=(64, 64, 3), hidden_channels=128, K=3, L=3, flow_permutation=perm, flow_coupling=coup,
+                        batch=batch)
+    sd = O.seeded_state_dict(cfg, seed=21, zeros_std=0.02, invconv_perturb=0.02)
+    np.random.seed(5)
+    glow = make_glow(cfg, sd, batch)
+    tables = None
+    if perm != "invconv":
+        tables = {i: (torch.from_numpy(getattr(l, perm).indices), torch.from_numpy(getattr(l, perm).indices_inverse))
+                  for i, l in enumerate(glow.flow.layers) if hasattr(l, perm)}
+    x = torch.rand(batch, 3, 64, 64, generator=torch.Generator().manual_seed(4))
+    noise = torch.rand(batch, 3, 64, 64, generator=torch.Generator().manual_seed(5)) / 256
+    with torch.no_grad():
+        z_ref, nll_ref, _ = O.glow_forward(x, noise, sd, cfg, perm_tables=tables)
+    desc = glow.flow.plan_for(dev(x)).describe()
+    steps = [l for l in desc.splitlines() if "flowstep" in l]
+    assert all("f2=mfma-sh" in l and "f4=mfma-sh" in l and "-sh-fused" in l for l in steps), desc
+    z, nll, _ = glow.normal_flow(dev(x), None, noise=dev(noise))
+    close(z, z_ref, 1e-4, what="z"); close(nll, nll_ref, 1e-4, what="nll")
+    G.lib().glowhip_debug_force_tail_tile(0x8000)      # the same without the mixer fused into the tails
+    try:
+        z_u, nll_u, _ = glow.normal_flow(dev(x), None, noise=dev(noise))
+    finally:
+        G.lib().glowhip_debug_force_tail_tile(0)
+    assert torch.equal(z, z_u) and torch.equal(nll, nll_u)
+    eps = [torch.randn(batch, *s, generator=torch.Generator().manual_seed(6 + i)) * 0.7
+           for i, s in enumerate(glow.flow.split_shapes((3, 64, 64)))]
+    with torch.no_grad():
+        x_ref = O.glow_reverse(z_ref, sd, cfg, eps, perm_tables=tables)
+    xr = glow.reverse_flow(dev(z_ref), None, eps=[dev(e) for e in eps])
+    close(xr, x_ref, 1e-4, what="decode")
