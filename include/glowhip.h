@@ -228,8 +228,12 @@ int glowhip_plan_timing_read(glowhip_plan* plan, glowhip_timing_record* out, int
 
 /* Testing hook for the fused tail convolution, so every variant can be exercised at any batch size: low byte =
  * pixels per workgroup (16/32/64/128; 0 = automatic, chosen by a cost model), | 0x100 = always split the
- * out-channel tiles over blockIdx.y, | 0x200 = never split, | 0x400 = no LDS-DMA tail kernels, | 0x800 = exact-fp32 MFMA
- * kernels only (disables the split-half f16 path). 0 restores automatic selection. */
+ * out-channel tiles over blockIdx.y, | 0x200 = never split, | 0x400 = no LDS-DMA tail kernels.
+ * Kernel-family switches (A/B runs, and the parity tests of the exact-fp32 kernels): | 0x800 = exact-fp32 MFMA kernels only
+ * (split-half f16 path off), | 0x1000 = fp32 tail behind the split-half GEMM, | 0x2000 = fp32-MFMA f.0 writing the
+ * split-half tensor, | 0x4000 = f.0 and f.2 as separate kernels, | 0x8000 = k_chanmix instead of the mixer fused into the
+ * previous tail; bits 16..19 = 4 or 8: only that wave count of the split-half tail.  0 restores automatic selection.
+ * Process-wide, not thread safe: a testing hook, not part of the operator surface. */
 void glowhip_debug_force_tail_tile(int pixels_and_flags);
 
 /* Introspection for tests / benchmarks: which kernels a plan will launch ("mfma" or "direct" per

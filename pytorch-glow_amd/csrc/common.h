@@ -92,7 +92,10 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf
     extern "C" int glowhip_debug_read_stamps_##name(unsigned long long* dst) {                                  \
         return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(glowhip::g_stamps_local), sizeof(unsigned long long) * 64); \
     }
-#define GH_STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_stamps_local[i] = __builtin_readcyclecounter(); } while (0)
+#ifndef GH_STAMP_BLOCK
+#define GH_STAMP_BLOCK 0
+#endif
+#define GH_STAMP(i) do { if (blockIdx.x == GH_STAMP_BLOCK && blockIdx.y == 0 && threadIdx.x == 0) g_stamps_local[i] = __builtin_readcyclecounter(); } while (0)
 #else
 #define GH_STAMPS_DEFINE(name)
 #define GH_STAMP(i) do { } while (0)

@@ -11,6 +11,7 @@
 // the two 16-lane pixel runs of a ds_read_b32 half-wave fall on disjoint banks.  A tap is an LDS address
 // offset; nothing is expanded (no im2col), each input element is fetched from HBM once per block.
 #include "conv_mfma_tail_dma.h"
+#include "sh.h"
 
 namespace glowhip {
 
@@ -345,7 +346,11 @@ void conv_mfma_tail_force_tile(int v) {
     g_force_tp = v & 0xff;
     g_force_msplit = (v & 0x100) ? 1 : ((v & 0x200) ? 0 : -1);
     g_disable_tail_dma = (v & 0x400) != 0;   // | 0x400: register-staged kernels only
-    plan_disable_sh(((v & 0x800) ? 1 : 0) | ((v & 0x1000) ? 2 : 0) | ((v & 0x2000) ? 4 : 0) | ((v & 0x4000) ? 8 : 0) | ((v & 0x8000) ? 16 : 0));   // | 0x800: exact-fp32 MFMA kernels only; | 0x1000: fp32 tail behind the SH GEMM
+    // split-half path switches (include/glowhip.h): 0x800 whole path off, 0x1000 tail, 0x2000 f.0, 0x4000 f.0+f.2 fusion,
+    // 0x8000 next-step mixer inside the tail; bits 16..19: 4 / 8 = only those wave counts of k_tail_sh
+    plan_disable_sh(((v & 0x800) ? 1 : 0) | ((v & 0x1000) ? 2 : 0) | ((v & 0x2000) ? 4 : 0) | ((v & 0x4000) ? 8 : 0) |
+                    ((v & 0x8000) ? 16 : 0));
+    tail_sh_force_waves((v >> 16) & 0xf);
 }
 
 }  // namespace glowhip

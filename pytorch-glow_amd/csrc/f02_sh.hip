@@ -6,9 +6,9 @@
 //
 // Workgroup = one 64-pixel SH tile (R = 64 / W image rows), 8 waves.
 //   phase 0: the z1 window (R + 2 rows, zero padded, channels in chunks of 8) is split into halves and stored in LDS;
-//   phase 1: h1 in 32-channel x 32-pixel MFMA jobs dealt round-robin to the waves (weights straight from L2 as A
-//            fragments, window fragments from LDS at tap-shifted addresses); each job ends by writing its (hi, lo) halves
-//            into the LDS image [plane][chunk][64 pixels][8] -- exactly the B-operand layout of phase 2;
+//   phase 1: h1 by MFMA, a wave taking two 32-channel groups x both 32-pixel halves at a time (weights straight from L2 as
+//            A fragments, window fragments from LDS at tap-shifted addresses), written as (hi, lo) halves into the LDS
+//            image [plane][chunk][64 pixels][8] -- exactly the B-operand layout of phase 2;
 //   phase 2: the 1x1 convolution over ALL of K with the B operand resident: no ring, no barrier, no counted waits -- a
 //            wave owns 64 output channels x 64 pixels and free-runs, its A fragments (W2', two k-steps ahead) coming from L2.
 // ONE barrier separates the phases.  The redundant work of tiling (each f.2 row tile recomputing h1) is avoided by giving the

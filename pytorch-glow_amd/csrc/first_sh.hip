@@ -29,7 +29,6 @@ k_first_sh(const float* __restrict__ X, long x_bs, const _Float16* __restrict__ 
     const int bpi = H / R;
     const long n = blockIdx.x / bpi;
     const int y0 = (int)(blockIdx.x - n * bpi) * R;
-    const long P = (long)N * HW;
     const long plane_h = (long)nchunk * Wpx * 8;      // halfs per LDS plane
 
     // ---- window: fp32 -> (hi, lo), one (chunk, window pixel) slot = 8 channels = 16 B per plane

@@ -29,11 +29,7 @@ __device__ __forceinline__ void gemm_sh_epilogue(const f32x16_t (&accm)[2][2], c
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const long px = (long)tile_n * SH_BN + wc * 64 + j * 32 + ml;
-#ifdef GLOWHIP_EXP_NOSTORE
-        const bool ok = px < P && relu == 77;
-#else
         const bool ok = px < P;
-#endif
         const long n = px / HW;
         const int p = (int)(px - n * HW);
 #pragma unroll
@@ -95,11 +91,7 @@ k_gemm_sh(const _Float16* __restrict__ X, long P, const _Float16* __restrict__ W
     px1 = px1 < P ? px1 : P - 1;
     const _Float16* b_src0 = X + sh_off(NCK, dpl, dch, px0);
     const _Float16* b_src1 = X + sh_off(NCK, dpl, dch, px1);
-#ifdef GLOWHIP_EXP_NOLOOP
-    const int nkt = 3;
-#else
     const int nkt = K / SH_BK;
-#endif
 
     auto issue_piece = [&](int kt, int piece) {   // piece 0,1: A halves; 2,3: B halves
         _Float16* st = smem_h + (kt % SH_ST) * SH_STAGE_HALFS + ((dpl * 2 + dch) * 128 + (piece & 1) * 64) * 8;
@@ -156,18 +148,10 @@ k_gemm_sh(const _Float16* __restrict__ X, long P, const _Float16* __restrict__ W
             bh[j] = *reinterpret_cast<const h8*>(st + b_off + j * 256);
             bl[j] = *reinterpret_cast<const h8*>(st + b_off + j * 256 + 2 * 128 * 8);
         }
-#ifndef GLOWHIP_EXP_NOREFILL
         if (kt + SH_ST - 1 < nkt) {
 #pragma unroll
             for (int pc = 0; pc < 4; ++pc) issue_piece(kt + SH_ST - 1, pc);
         }
-#endif
-#ifdef GLOWHIP_EXP_NOMFMA
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) { accm[i][j][0] += (float)ah[i][0] * (float)bl[j][0]; accx[i][j][0] += (float)al[i][0] * (float)bh[j][0]; }
-#else
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -176,7 +160,6 @@ k_gemm_sh(const _Float16* __restrict__ X, long P, const _Float16* __restrict__ W
                 accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], accx[i][j], 0, 0, 0);
                 accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], accx[i][j], 0, 0, 0);
             }
-#endif
     }
 
     GH_STAMP(18);

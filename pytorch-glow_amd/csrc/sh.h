@@ -98,6 +98,6 @@ bool tail_sh_supported(int Cin, int H, int W, int Cout);
 size_t tail_sh_packed_bytes(int Cin, int H, int W, int Cout);
 int tail_sh_mpad(int Cin, int H, int W, int Cout, int* groups);   // padded rows per channel group of the packed image
 int launch_tail_sh(const TailShArgs& a, hipStream_t s);
-void tail_sh_force_ks(int ks);   // testing hook: k-steps per ring stage (0 = automatic)
+void tail_sh_force_waves(int nwaves);   // testing hook: only the 4- or the 8-wave variants (0 = automatic)
 
 }  // namespace glowhip

@@ -65,7 +65,6 @@ __global__ void __launch_bounds__(64 * NWV) k_tail_sh(TailShArgs a, int WGM, int
     const int lb = xcd_remap(blockIdx.x, gridDim.x);
     const long n = lb / bpi;
     const int y0 = (int)(lb - n * bpi) * R;
-    const long P = a.P;
     const long w_plane = (long)K * Mpad;
     const int pa = Mpad >> 6, pb = Nwpad >> 6, PT = 4 * (pa + pb);
 
@@ -123,9 +122,6 @@ __global__ void __launch_bounds__(64 * NWV) k_tail_sh(TailShArgs a, int WGM, int
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
             _Float16* dst = ldso[i] >= 0 ? st + ldso[i] : dummy;
-#ifdef GLOWHIP_EXP_TNOA
-            if (kt >= 3 && (wid + NWV * i) < 4 * pa) continue;   // timing experiment: no weight refills
-#endif
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src[i],
                                              (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
             src[i] += adv[i];
@@ -140,11 +136,7 @@ __global__ void __launch_bounds__(64 * NWV) k_tail_sh(TailShArgs a, int WGM, int
 #pragma unroll
             for (int r = 0; r < 16; ++r) { accm[t][u][r] = 0.f; accx[t][u][r] = 0.f; }
 
-#ifdef GLOWHIP_EXP_TNOLOOP
-    const int nkt = 3;
-#else
     const int nkt = K / 16;
-#endif
 #pragma unroll
     for (int t = 0; t < 3; ++t)
         if (t < nkt) issue_stage(t);
@@ -174,12 +166,6 @@ __global__ void __launch_bounds__(64 * NWV) k_tail_sh(TailShArgs a, int WGM, int
             bl[u] = *reinterpret_cast<const h8*>(st + b_off + u * 256 + 2 * Nwpad * 8);
         }
         if (kt + 3 < nkt) issue_stage(kt + 3);
-#ifdef GLOWHIP_EXP_TNOMFMA
-#pragma unroll
-        for (int t = 0; t < MW; ++t)
-#pragma unroll
-            for (int u = 0; u < NW; ++u) { accm[t][u][0] += (float)ah[t][0] * (float)bl[u][0]; accx[t][u][0] += (float)al[t][0] * (float)bh[u][0]; }
-#else
 #pragma unroll
         for (int t = 0; t < MW; ++t)
 #pragma unroll
@@ -188,7 +174,6 @@ __global__ void __launch_bounds__(64 * NWV) k_tail_sh(TailShArgs a, int WGM, int
                 accx[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bl[u], accx[t][u], 0, 0, 0);
                 accx[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[t], bh[u], accx[t][u], 0, 0, 0);
             }
-#endif
     }
     GH_STAMP(2);
     __syncthreads();   // every wave is done with the operand ring: it becomes the T staging area
@@ -220,11 +205,7 @@ __global__ void __launch_bounds__(64 * NWV) k_tail_sh(TailShArgs a, int WGM, int
 #pragma unroll
     for (int i = 0; i < TSH_MAXE; ++i) {
         const int e = tid + i * NTHR;
-#ifdef GLOWHIP_EXP_TNOEPI
-        if (e >= nitems || i > 0) continue;
-#else
         if (e >= nitems) continue;
-#endif
         const int c = e / tile_px, q = e - c * tile_px;
         const int r = q >> wshift, x = q & (W - 1);
         const int ce = paired ? 2 * c : c;
@@ -292,7 +273,7 @@ __global__ void __launch_bounds__(64 * NWV) k_tail_sh(TailShArgs a, int WGM, int
 struct TailShCfg { int MW, NW, PPW, NWV, WGM, R, Mpad, Nwpad, wshift, groups; };
 
 static int g_tail_sh_waves = 0;   // testing hook: 4 / 8 = only that many waves per workgroup (0 = automatic)
-void tail_sh_force_ks(int v) { g_tail_sh_waves = v; }
+void tail_sh_force_waves(int v) { g_tail_sh_waves = v; }
 
 static bool tail_sh_config(int Cin, int H, int W, int Cout, TailShCfg* out) {
     if (Cin % 16 != 0 || Cin < 48) return false;
@@ -308,7 +289,7 @@ static bool tail_sh_config(int Cin, int H, int W, int Cout, TailShCfg* out) {
     const int Nw = (R + 2) * W;
     const int Mt = (9 * Cg + 31) / 32, Nt = (Nw + 31) / 32;
     // instantiated (MW, NW, PPW, waves); earlier entries win ties
-    static const int inst[][4] = {{1, 3, 3, 8}, {1, 1, 2, 8}, {2, 3, 5, 4}, {2, 2, 4, 4}, {2, 1, 3, 4}, {2, 2, 5, 4},
+    static const int inst[][4] = {{1, 3, 3, 8}, {2, 1, 3, 4} /* 8x8 level: measured faster than {1,1,2,8} */, {1, 1, 2, 8}, {2, 3, 5, 4}, {2, 2, 4, 4}, {2, 2, 5, 4},
                                   {2, 3, 6, 4}, {4, 1, 9, 4}, {2, 1, 5, 4}};
     int best = -1;
     TailShCfg bc{};
@@ -328,8 +309,6 @@ static bool tail_sh_config(int Cin, int H, int W, int Cout, TailShCfg* out) {
         }
     }
     if (best < 0) return false;
-    const int nitems = (Cg % 2 == 0 ? Cg / 2 : Cg) * R * W;   // (paired modes have Cg/2 items per pixel; unpaired Cg: checked at launch)
-    (void)nitems;
     const size_t ring = (size_t)TSH_ST * 4 * (bc.Mpad + bc.Nwpad) * 8 * sizeof(_Float16);
     const size_t tb = (size_t)Nw * tail_sh_trow(9 * Cg) * sizeof(float);
     if (std::max(ring, tb) + 1024 + 64 > 160 * 1024) return false;
