@@ -272,12 +272,17 @@ __global__ void __launch_bounds__(64 * NWV) k_tail_sh(TailShArgs a, int WGM, int
 // ---- configuration: rows per workgroup by image width, channel groups over blockIdx.y, wave grid by tile counts
 struct TailShCfg { int MW, NW, PPW, NWV, WGM, R, Mpad, Nwpad, wshift, groups; };
 
+static int g_tail_sh_rows8 = 1;   // 32-pixel-wide levels: 8 image rows per workgroup (halo overhead 10/8 instead of 6/4)
 static int g_tail_sh_waves = 0;   // testing hook: 4 / 8 = only that many waves per workgroup (0 = automatic)
-void tail_sh_force_waves(int v) { g_tail_sh_waves = v; }
+void tail_sh_force_waves(int v) { g_tail_sh_waves = v & 12; g_tail_sh_rows8 = !(v & 1); }   // | 1: 4-row workgroups everywhere
 
-static bool tail_sh_config(int Cin, int H, int W, int Cout, TailShCfg* out) {
+// N = batch size when known (launch), 0 at plan time.  The packed weight image depends on Mpad only, which the 8-row variant
+// must share with the 4-row one (checked by the caller).
+static bool tail_sh_config(int Cin, int H, int W, int Cout, TailShCfg* out, int N = 0) {
     if (Cin % 16 != 0 || Cin < 48) return false;
-    int R = 4, wshift;
+    // 32-pixel-wide levels: 8 image rows per workgroup when that still gives most CUs a workgroup (halo overhead 10/8
+    // instead of 6/4: measured 45 vs 58 us at level 1, B=64)
+    int R = g_tail_sh_rows8 && W == 32 && H % 8 == 0 && Cout <= 12 && (long)N * (H / 8) >= 192 ? 8 : 4, wshift;
     if (W == 32) wshift = 5;
     else if (W == 16) wshift = 4;
     else if (W == 8) wshift = 3;
@@ -289,7 +294,7 @@ static bool tail_sh_config(int Cin, int H, int W, int Cout, TailShCfg* out) {
     const int Nw = (R + 2) * W;
     const int Mt = (9 * Cg + 31) / 32, Nt = (Nw + 31) / 32;
     // instantiated (MW, NW, PPW, waves); earlier entries win ties
-    static const int inst[][4] = {{1, 3, 3, 8}, {2, 1, 3, 4} /* 8x8 level: measured faster than {1,1,2,8} */, {1, 1, 2, 8}, {2, 3, 5, 4}, {2, 2, 4, 4}, {2, 2, 5, 4},
+    static const int inst[][4] = {{1, 5, 4, 8}, {1, 3, 3, 8}, {2, 1, 3, 4} /* 8x8 level: measured faster than {1,1,2,8} */, {1, 1, 2, 8}, {2, 3, 5, 4}, {2, 2, 4, 4}, {2, 2, 5, 4},
                                   {2, 3, 6, 4}, {4, 1, 9, 4}, {2, 1, 5, 4}};
     int best = -1;
     TailShCfg bc{};
@@ -344,8 +349,14 @@ int tail_sh_mpad(int Cin, int H, int W, int Cout, int* groups) {
 }
 
 int launch_tail_sh(const TailShArgs& a, hipStream_t s) {
-    TailShCfg c;
-    GH_REQUIRE(tail_sh_config(a.Cin, a.H, a.W, a.Cout, &c), "tail_sh: unsupported shape");
+    TailShCfg c, c4;
+    GH_REQUIRE(tail_sh_config(a.Cin, a.H, a.W, a.Cout, &c4), "tail_sh: unsupported shape");
+    if (!tail_sh_config(a.Cin, a.H, a.W, a.Cout, &c, a.N) || c.Mpad != c4.Mpad || c.groups != c4.groups) c = c4;
+    {   // the larger variant also has to fit the fused mixer's scratch
+        const size_t ring8 = (size_t)TSH_ST * 4 * (c.Mpad + c.Nwpad) * 8 * sizeof(_Float16);
+        const size_t tb8 = (size_t)(c.R + 2) * a.W * tail_sh_trow(9 * (a.Cout / c.groups)) * sizeof(float);
+        if (std::max(ring8, tb8) + 1024 + 64 + (a.mix_C ? tail_sh_mix_bytes(a.mix_C, c.R, a.W) : 0) > 160 * 1024) c = c4;
+    }
     GH_REQUIRE(a.mode == TAIL_AFFINE_FWD || a.mode == TAIL_AFFINE_REV || a.mode == TAIL_ADD_FWD || a.mode == TAIL_ADD_REV,
                "tail_sh: coupling modes only");
     if (a.N == 0) return GLOWHIP_OK;
@@ -367,7 +378,7 @@ int launch_tail_sh(const TailShArgs& a, hipStream_t s) {
         GH_LAUNCH_CHECK("k_tail_sh");                                                                                 \
         return GLOWHIP_OK;                                                                                            \
     }
-    GH_TSH_CASE(1, 3, 3, 8) GH_TSH_CASE(1, 1, 2, 8)
+    GH_TSH_CASE(1, 5, 4, 8) GH_TSH_CASE(1, 3, 3, 8) GH_TSH_CASE(1, 1, 2, 8)
     GH_TSH_CASE(2, 3, 5, 4) GH_TSH_CASE(2, 3, 6, 4) GH_TSH_CASE(4, 1, 9, 4) GH_TSH_CASE(2, 2, 5, 4) GH_TSH_CASE(2, 2, 4, 4)
     GH_TSH_CASE(2, 1, 5, 4) GH_TSH_CASE(2, 1, 3, 4)
 #undef GH_TSH_CASE
