@@ -206,3 +206,34 @@ def test_train_loop_follows_the_profile_schedule():
     assert glow.actnorm_inited() and loop.global_step == 6
     assert lrs[:5] == pytest.approx([1e-3 * (i + 1) / 5 for i in range(5)]) and lrs[5] == pytest.approx(1e-3 * (5 / 6) ** 0.5)
     assert losses[-1] < losses[0]
+
+
+def test_inference_and_training_weight_images_do_not_go_stale():
+    """glowhip_plan_pack_for refreshes only the images one kernel family reads (split-half for inference, exact-fp32 +
+    transposed for training).  Alternating the two, and updating a parameter in place in between, must never leave a kernel
+    with an old image."""
+    cfg, sd, glow, x, noise = _celeba_geometry_model(K=2, batch=4)
+    xd, nd = x.to(DEV), noise.to(DEV)
+    glow.eval()
+    z0, nll0, _ = glow.normal_flow(xd, None, noise=nd)                       # inference images
+    glow.train()
+    with torch.enable_grad():
+        zt, nllt, _ = glow.normal_flow(xd, None, noise=nd)                   # training images only
+        nllt.mean().backward()
+    assert (nllt.detach() - nll0).abs().max().item() < 1e-5                  # two kernel families, same function
+    glow.eval()
+    z1, nll1, _ = glow.normal_flow(xd, None, noise=nd)                       # inference again
+    assert torch.equal(z0, z1) and torch.equal(nll0, nll1)
+    with torch.no_grad():                                                    # in-place update, as an optimiser does
+        f = glow.flow.layers[1].f                                            # every packed weight of one coupling net
+        f[0].weight.mul_(1.25); f[2].weight.mul_(1.25)
+        f[4].weight.add_(0.004 * torch.randn_like(f[4].weight))
+    sd2 = {k: v.detach().cpu().clone() for k, v in glow.state_dict().items()}
+    z_ref, nll_ref, _ = O.glow_forward(x, noise, sd2, cfg)
+    z2, nll2, _ = glow.normal_flow(xd, None, noise=nd)
+    assert (z2 - z1).abs().max().item() > 1e-3                               # the update is visible at all
+    assert (z2.cpu() - z_ref).abs().max().item() < 1e-4 and (nll2.cpu() - nll_ref).abs().max().item() < 1e-4
+    glow.train()
+    with torch.enable_grad():
+        zt2, nllt2, _ = glow.normal_flow(xd, None, noise=nd)
+    assert (nllt2.detach().cpu() - nll_ref).abs().max().item() < 1e-4
