@@ -458,3 +458,29 @@ def flop_per_image(cfg) -> float:
         elif kind == "split":
             total += 2.0 * p * 9 * c * (2 * c)
     return total
+
+
+# ----------------------------------------------------------------------------- Inferer (next row N3)
+def attribute_delta(zs, ys, batch_size: int, per_batch=None):
+    """`Inferer.compute_attribute_delta`, network/inferer.py:104-153, on latents already computed: `zs` (S, C, H, W) and
+    `ys` (S, classes) in DATA-LOADER ORDER, consumed in batches of `batch_size` (drop_last).  Per class: mean latent of the
+    samples that have the attribute minus the mean of those that do not (empty sets count as one sample of zeros, :146-147).
+    `per_batch` = how many samples of each batch enter the sums: the reference loops `for i in range(len(batch))` over the
+    batch DICT (:131), i.e. 2 for {'x', 'y_onehot'}; None = all of them."""
+    zs = np.asarray(zs, dtype=np.float64)
+    ys = np.asarray(ys)
+    S, K = ys.shape
+    pos = np.zeros((K,) + zs.shape[1:]); neg = np.zeros_like(pos)
+    n_pos = np.zeros(K); n_neg = np.zeros(K)
+    for b0 in range(0, S - batch_size + 1, batch_size):
+        take = batch_size if per_batch is None else per_batch
+        for i in range(b0, b0 + take):
+            for c in range(K):
+                if ys[i, c] > 0:
+                    pos[c] += zs[i]; n_pos[c] += 1
+                else:
+                    neg[c] += zs[i]; n_neg[c] += 1
+    out = np.zeros_like(pos)
+    for c in range(K):
+        out[c] = pos[c] / max(1.0, n_pos[c]) - neg[c] / max(1.0, n_neg[c])
+    return out

@@ -627,7 +627,7 @@ int glowhip_glow_forward(glowhip_plan* plan, const void* packed, const float* x,
                          glowhip_stream_t stream) {
     GH_TRY(check_plan_args(plan, packed, N));
     GH_REQUIRE(x && z && nll_out, "glow_forward: null tensor");
-    GH_REQUIRE(n_bits > 0 && n_bits <= 16, "glow_forward: n_bits=%d", n_bits);
+    GH_REQUIRE(n_bits > 0 && n_bits <= 30, "glow_forward: n_bits=%d", n_bits);
     if (N == 0) return GLOWHIP_OK;
     hipStream_t s = (hipStream_t)stream;
     Workspace w;

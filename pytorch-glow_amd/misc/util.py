@@ -1,10 +1,15 @@
-"""The slice of the reference's misc/util.py the flow path needs: profile loading (attribute-style
-dict, since `easydict` is not a dependency here), device-list parsing and seeding.
-Reference: misc/util.py:18-29 (load_profile), :34-75 (get_devices), :515-524 (manual_seed)."""
+"""The slice of the reference's misc/util.py the flow path and its two callers (Builder, Inferer) need: profile loading
+(attribute-style dict, since `easydict` is not a dependency here), device-list parsing, seeding, result directories, the
+snapshot format and the small tensor helpers of the inference application.
+Reference: misc/util.py:18-29 (load_profile), :34-75 (get_devices), :154-222 (result sub-directories), :247-376
+(snapshots), :487-511 (deltaz), :515-524 (manual_seed), :538-588 (check_path, make_batch, make_interpolation_vector).
+Not here: the image codecs (cv2 / PIL / torchvision) and the stdout tee -- data formats outside the flow path."""
+import glob
 import json
 import os
 import random
 import re
+import shutil
 
 import numpy as np
 import torch
@@ -78,3 +83,126 @@ def manual_seed(seed):
     torch.manual_seed(seed)
     if torch.cuda.is_available():
         torch.cuda.manual_seed_all(seed)
+
+
+# ----------------------------------------------------------------------------- result directories (util.py:154-222)
+def check_path(path):
+    if not os.path.exists(path):
+        os.makedirs(path)
+
+
+def create_result_subdir(result_dir, desc, profile):
+    """`<result_dir>/<run id>-<desc>` with the next free 3-digit run id; the profile is exported as config.json."""
+    run_id = 0
+    for fname in glob.glob(os.path.join(result_dir, '*')):
+        found = re.findall(r'^([\d]+)-', os.path.basename(fname))
+        if found:
+            run_id = max(run_id, int(found[0]) + 1)
+    result_subdir = os.path.join(result_dir, '{:03d}-{:s}'.format(run_id, desc))
+    check_path(result_subdir)
+    print("[Builder] Saving results to {}".format(result_subdir))
+    with open(os.path.join(result_subdir, 'config.json'), 'w') as f:
+        json.dump(profile, f)
+    return result_subdir
+
+
+def locate_result_subdir(result_dir, run_id_or_result_subdir):
+    """A run's directory by path, by name, or by (unique) run-id prefix under result_dir[/results|/networks]; else None."""
+    if isinstance(run_id_or_result_subdir, str) and os.path.isdir(run_id_or_result_subdir):
+        return run_id_or_result_subdir
+    for sub in ('', 'results', 'networks'):
+        base = os.path.join(result_dir, sub) if sub else result_dir
+        d = os.path.join(base, str(run_id_or_result_subdir))
+        if os.path.isdir(d):
+            return d
+        prefix = '{:03d}'.format(run_id_or_result_subdir) if isinstance(run_id_or_result_subdir, int) \
+            else str(run_id_or_result_subdir)
+        dirs = [d for d in sorted(glob.glob(os.path.join(base, prefix + '-*'))) if os.path.isdir(d)]
+        if len(dirs) == 1:
+            return dirs[0]
+    print('[Builder] Cannot locate result subdir for run: {}'.format(run_id_or_result_subdir))
+    return None
+
+
+# ----------------------------------------------------------------------------- snapshots (util.py:247-376)
+def get_model_name(step):
+    return 'network-snapshot-{:06d}.pth'.format(step)
+
+
+def get_best_model_name():
+    return 'network-snapshot-best.pth'
+
+
+def get_last_model_name(result_subdir):
+    steps = [int(m.group(1)) for m in (re.search(r'network-snapshot-([\d]+).pth', f) for f in os.listdir(result_subdir))
+             if m and os.path.isfile(os.path.join(result_subdir, m.string))]
+    return get_model_name(max(steps, default=-1))
+
+
+def save_model(result_subdir, step, graph, optimizer, seconds, is_best, criterion_dict=None):
+    """The reference's snapshot: a torch.save'd dict {step, graph (state_dict), optimizer, criterion, seconds}; a
+    DataParallel-style wrapper is unwrapped through `.module`.  Snapshots are interchangeable with the reference's."""
+    state = {
+        'step': step,
+        'graph': graph.module.state_dict() if hasattr(graph, "module") else graph.state_dict(),
+        'optimizer': optimizer.state_dict(),
+        'criterion': {} if criterion_dict is None else {k: v.state_dict() for k, v in criterion_dict.items()},
+        'seconds': seconds,
+    }
+    save_path = os.path.join(result_subdir, get_model_name(step))
+    torch.save(state, save_path)
+    if is_best:
+        shutil.copy(save_path, os.path.join(result_subdir, get_best_model_name()))
+
+
+def load_model(result_subdir, step_or_model_path, graph, optimizer=None, criterion_dict=None, device=None):
+    """Load a snapshot (a step number, 'best', or a path) into `graph` (+ optimizer / criteria), mark every ActNorm as
+    initialised and return the snapshot dict.  Reads the reference's own .pth files."""
+    model_path = step_or_model_path
+    if isinstance(step_or_model_path, int):
+        model_path = get_model_name(step_or_model_path)
+    if step_or_model_path == 'best':
+        model_path = get_best_model_name()
+    if step_or_model_path == 'latest':
+        model_path = get_last_model_name(result_subdir)   # (the reference sets None here and then fails in os.path.exists)
+    if not os.path.exists(model_path):
+        model_path = os.path.join(result_subdir or '', model_path)
+        if not os.path.exists(model_path):
+            raise FileNotFoundError('Failed to find model snapshot with {}'.format(step_or_model_path))
+    if isinstance(device, int):
+        device = 'cuda:{}'.format(device)
+    state = torch.load(model_path, map_location=device)
+    graph.load_state_dict(state['graph'])
+    graph.set_actnorm_inited()
+    if optimizer is not None:
+        optimizer.load_state_dict(state['optimizer'])
+    if criterion_dict is not None:
+        for k in criterion_dict.keys():
+            criterion_dict[k].load_state_dict(state['criterion'][k])
+    print('[Builder] Load model snapshot successfully from {}'.format(model_path))
+    return state
+
+
+# ----------------------------------------------------------------------------- inference helpers (util.py:487-588)
+def save_deltaz(deltaz, save_dir):
+    check_path(save_dir)
+    np.save(os.path.join(save_dir, 'deltaz.npy'), deltaz)
+
+
+def load_deltaz(path):
+    if os.path.exists(path):
+        return np.load(path)
+
+
+def make_batch(tensor, batch_size):
+    assert len(tensor.shape) == 3, 'Assume 3D input tensor'
+    return tensor.unsqueeze(0).repeat(batch_size, 1, 1, 1)
+
+
+def make_interpolation_vector(num_classes, step=0.25, minimum=-1., maximum=1.):
+    """(num_classes, levels, num_classes): class c sweeps minimum..maximum in `step`s, the others stay 0."""
+    num_levels = int((maximum - minimum) / step) + 1
+    vec = np.zeros([num_classes, num_levels, num_classes])
+    for cls in range(num_classes):
+        vec[cls, :, cls] = [-1. + step * i for i in range(num_levels)]   # (starts at -1 whatever `minimum` is: util.py:579)
+    return vec

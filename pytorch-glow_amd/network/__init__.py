@@ -1,7 +1,10 @@
-"""Flow layers and models (host-side mirror of the reference's ``network`` package for the flow hot path).
-Builder / Trainer / Inferer of the reference are orchestration around this path and are not part of it."""
+"""Flow layers and models (host-side mirror of the reference's ``network`` package for the flow hot path), plus the two
+callers either side of it: `Builder` (model / optimiser / schedule / snapshot glue) and `Inferer` (the inverse-path
+application).  The reference's `Trainer` loop lives in `pytorch_glow_amd.training.TrainLoop` (its I/O is out of scope)."""
 from . import model as _model
 from . import module as _module
+from .builder import Builder
+from .inferer import Inferer
 
 _LAYERS = ("ActNorm", "LinearZeros", "Conv2d", "Conv2dZeros", "CouplingNet", "f", "Invertible1x1Conv",
            "Permutation2d", "GaussianDiag", "Split2d", "Squeeze2d")
@@ -12,4 +15,4 @@ for _n in _LAYERS:
 for _n in _MODELS:
     globals()[_n] = getattr(_model, _n)
 
-__all__ = _MODELS + _LAYERS
+__all__ = _MODELS + _LAYERS + ("Builder", "Inferer")

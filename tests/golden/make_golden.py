@@ -18,6 +18,10 @@ Fixtures:
   g6_split2d.npz         fwd logp; rev with injected eps for eps_std in {None, 0, 0.7}
   g7_glow_tiny.npz       Glow 16x16x3 L=2 K=2 hidden 32 (affine+invconv, additive+reverse):
                          noise, z, nll, decode with injected eps, data-dependent init
+  g9_inferer.npz + g9_reference_snapshot.pth
+                         a snapshot WRITTEN BY the reference (misc/util.py save_model, after one Adam step) and what the
+                         reference's Inferer (network/inferer.py) computes from it: encode, attribute deltaz (with the data
+                         loader order it used), make_interpolation_vector
   g8_glow_celeba64.npz   celeba.json-sized model (64x64x3 L3 K32 w512 affine), B=2, weights from the
                          oracle's seeded procedure (too big to commit): digests only
 """
@@ -350,11 +354,87 @@ def g8():
     save("g8_glow_celeba64.npz", out)
 
 
+def g9(g):
+    """Builder / Inferer row: reference-written snapshot + reference Inferer outputs.  n_bits_x = 24 makes the dequantisation
+    noise (<= 6e-8) irrelevant, so the outputs do not depend on a random stream the HIP path cannot replay."""
+    import shutil, tempfile
+    from misc import util as rutil
+    from network import inferer as rinf
+    hps = tiny_hps("affine", "invconv", batch=4)
+    hps.model.n_bits_x = 24
+    hps.dataset = EasyDict(num_classes=3, num_workers=0)
+    np.random.seed(9)
+    glow = rmodel.Glow(hps)
+    randomize_(glow, g, std=0.1)
+    with torch.no_grad():
+        glow.h_top.zero_()
+    xs = torch.rand(12, 3, 16, 16, generator=g)
+    ys = (torch.rand(12, 3, generator=g) > 0.5).float()
+    # one optimiser step so that the snapshot carries a real Adam state
+    opt = torch.optim.Adam(glow.parameters(), lr=1e-4, betas=(0.9, 0.9999), eps=1e-8)
+    # (the reference's own backward trips over its in-place coupling ops under this torch version: synthetic gradients)
+    for p_ in glow.parameters():
+        p_.grad = torch.randn(p_.shape, generator=g) * 1e-2
+    opt.step()
+    for p_ in glow.parameters():
+        p_.grad = None
+    with torch.no_grad():
+        glow.h_top.zero_()
+    glow.eval()
+    tmp = tempfile.mkdtemp()
+    rutil.save_model(tmp, 7, glow, opt, 1.5, is_best=True)
+    shutil.copy(os.path.join(tmp, rutil.get_model_name(7)), os.path.join(HERE, "g9_reference_snapshot.pth"))
+    shutil.rmtree(tmp)
+
+    inf = rinf.Inferer(hps, glow, devices=["cpu"], data_device="cpu")
+    with torch.no_grad():
+        z_all = torch.cat([glow(x=xs[i:i + 4].clone())[0] for i in range(0, 12, 4)])
+        nll_all = torch.cat([glow(x=xs[i:i + 4].clone())[1] for i in range(0, 12, 4)])
+    z_enc = inf.encode(xs[5].clone())
+
+    order = []
+
+    class DS(torch.utils.data.Dataset):
+        def __len__(self):
+            return 12
+
+        def __getitem__(self, i):
+            order.append(i)
+            return {"x": xs[i].clone(), "y_onehot": ys[i].clone()}
+
+    # The accumulation `attrs_z_pos[cls] += z[i]` (numpy array += torch tensor, inferer.py:139) raises under numpy 2; the loop is
+    # run unchanged on a graph wrapper that hands z over as a numpy array.
+    class NumpyZ:
+        def __init__(self, graph):
+            self.graph, self.h_top, self.flow = graph, graph.h_top, graph.flow
+
+        def eval(self):
+            return self
+
+        def __call__(self, x):
+            z, nll, yl = self.graph(x)
+            return z.numpy(), nll, yl
+
+    inf2 = rinf.Inferer(hps, NumpyZ(glow), devices=["cpu"], data_device="cpu")
+    torch.manual_seed(77)
+    deltaz = inf2.compute_attribute_delta(DS())
+    out = dict(xs=xs, ys=ys, z_all=z_all, nll_all=nll_all, z_enc=z_enc, enc_index=5, deltaz=deltaz,
+               order=np.asarray(order), loader_seed=77, step=7, seconds=1.5,
+               interp=rutil.make_interpolation_vector(3, step=0.5), model_name=np.frombuffer(rutil.get_model_name(7).encode(), dtype=np.uint8),
+               best_name=np.frombuffer(rutil.get_best_model_name().encode(), dtype=np.uint8))
+    save("g9_inferer.npz", out)
+    print("g9 snapshot:", os.path.getsize(os.path.join(HERE, "g9_reference_snapshot.pth")) // 1024, "KiB; loader order", order)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     np.random.seed(1234)
     g = torch.Generator().manual_seed(1234)
+    if os.environ.get("ONLY") == "g9":
+        g9(torch.Generator().manual_seed(99))
+        sys.exit(0)
     g1(g); g2(g); g3(g); g4(g); g5(g); g6(g); g7(g)
     g8()
+    g9(torch.Generator().manual_seed(99))
     leftovers = [os.path.join(r, d) for r, ds, _ in os.walk(REF) for d in ds if d == "__pycache__"]
     assert not leftovers, f"bytecode written into the reference tree: {leftovers}"

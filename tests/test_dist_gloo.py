@@ -2,6 +2,8 @@
 all-reduce, nll gather.  The per-rank compute is injected (CPU oracle) because the HIP path needs a GPU; what is
 under test is the exchange logic of pytorch-glow_amd/parallel.py."""
 import os
+
+import numpy as np
 import socket
 
 import pytest
@@ -131,3 +133,51 @@ def test_world2_gradient_allreduce_equals_global_batch_gradient():
                 assert got is None
             else:
                 assert torch.allclose(got, p.grad, atol=1e-6)
+
+
+class _StubFlow:
+    output_shapes = [[-1, 2, 2, 2]]
+
+
+class _StubGraph(torch.nn.Module):
+    """CPU stand-in for Glow in the Inferer's data-parallel bookkeeping test: z = a fixed linear image of x."""
+    def __init__(self):
+        super().__init__()
+        self.h_top = torch.nn.Parameter(torch.zeros(2, 4, 2, 2), requires_grad=False)
+        self.flow = _StubFlow()
+
+    def forward(self, x=None, **kw):
+        return x[:, :2, :2, :2] * 2.0 + 1.0, None, None
+
+
+def inferer_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pytorch_glow_amd.network import Inferer
+        from pytorch_glow_amd.misc import util
+        hps = util.AttrDict(dict(dataset=dict(num_classes=3, num_workers=0), ablation=dict(y_condition=False)))
+        g = torch.Generator().manual_seed(3)
+        xs = torch.rand(8, 3, 4, 4, generator=g); ys = (torch.rand(8, 3, generator=g) > 0.5).float()
+        mine = list(range(rank * 4, rank * 4 + 4))                  # each rank sees its half of the data set
+        data = [{"x": xs[i], "y_onehot": ys[i]} for i in mine]
+        inf = Inferer(hps, _StubGraph(), devices=["cpu"], data_device="cpu")
+        ret[rank] = inf.compute_attribute_delta(data, shuffle=False, world=world)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_world2_attribute_delta_equals_single_process():
+    """Ranks accumulate over different batches; one all-reduce of sums and counts at the end gives every rank the deltaz of
+    the whole data set (checked against the oracle's restatement)."""
+    from oracle import glow_oracle as O
+    world = 2
+    ret = mp.Manager().dict()
+    mp.spawn(inferer_worker, args=(world, free_port(), ret), nprocs=world, join=True)
+    g = torch.Generator().manual_seed(3)
+    xs = torch.rand(8, 3, 4, 4, generator=g); ys = (torch.rand(8, 3, generator=g) > 0.5).float()
+    zs = (xs[:, :2, :2, :2] * 2.0 + 1.0).numpy()
+    want = O.attribute_delta(zs, ys.numpy(), batch_size=2)
+    for r in (0, 1):
+        assert np.abs(ret[r] - want).max() < 1e-6

@@ -139,3 +139,74 @@ def test_optimizer_and_scheduler_are_built_from_the_profile():
     hps.optim.optimizer = "sgd"
     with pytest.raises(KeyError):
         training.build_optimizer(hps, [w])
+
+
+# ----------------------------------------------------------------------------- Builder / Inferer glue (next rows N2, N3)
+def _g9_hps(batch=4):
+    return util.AttrDict(dict(
+        profile="g9", model=dict(image_shape=[16, 16, 3], hidden_channels=32, K=2, L=2, actnorm_scale=1.0, n_bits_x=24, weight_y=0.0),
+        ablation=dict(learn_top=False, y_condition=False, lu_decomposition=False, flow_permutation="invconv",
+                      flow_coupling="affine", max_grad_clip=5, max_grad_norm=100, seed=1),
+        optim=dict(optimizer="adam", optimizer_args=dict(lr=1e-4, betas=[0.9, 0.9999], eps=1e-8), lr_scheduler="noam",
+                   lr_scheduler_args=dict(warmup_steps=10, min_lr=1e-5), num_batch_train=batch),
+        dataset=dict(num_classes=3, num_workers=0), device=dict(graph=["cuda:0"], data=["cuda:0"]),
+        general=dict(result_dir=".", warm_start=True, pre_trained="", resume_run_id="", resume_step="")))
+
+
+def test_reference_snapshot_loads_into_this_glow():
+    """tests/golden/g9_reference_snapshot.pth was written by the REFERENCE's util.save_model: same keys, same shapes, and the
+    Adam state fits an optimiser built over this package's parameters (snapshots are interchangeable)."""
+    from conftest import GOLDEN, load_golden
+    g = load_golden("g9_inferer")
+    hps = _g9_hps()
+    glow = G.Glow(hps)
+    opt = torch.optim.Adam(glow.parameters(), lr=1e-4)
+    state = util.load_model(GOLDEN, os.path.join(GOLDEN, "g9_reference_snapshot.pth"), glow, optimizer=opt, device="cpu")
+    assert set(state) == {"step", "graph", "optimizer", "criterion", "seconds"}
+    assert state["step"] == int(g["step"]) and state["seconds"] == pytest.approx(float(g["seconds"]))
+    assert all(m.bias_inited and m.logs_inited for m in glow.modules() if isinstance(m, G.ActNorm))
+    assert len(opt.state) == sum(1 for _ in glow.parameters())
+    assert bytes(g["model_name"].astype(np.uint8)).decode() == util.get_model_name(7)
+    assert bytes(g["best_name"].astype(np.uint8)).decode() == util.get_best_model_name()
+    assert np.array_equal(util.make_interpolation_vector(3, step=0.5), g["interp"].numpy())
+
+
+def test_snapshot_roundtrip_and_result_dirs(tmp_path):
+    hps = _g9_hps()
+    root = str(tmp_path)
+    d0 = util.create_result_subdir(root, "exp", dict(hps))
+    d1 = util.create_result_subdir(root, "exp", dict(hps))
+    assert os.path.basename(d0) == "000-exp" and os.path.basename(d1) == "001-exp" and os.path.exists(os.path.join(d1, "config.json"))
+    assert util.locate_result_subdir(root, 1) == d1 and util.locate_result_subdir(root, d0) == d0
+    assert util.locate_result_subdir(root, 7) is None
+    glow = G.Glow(hps)
+    with torch.no_grad():
+        for p in glow.parameters():
+            p.copy_(torch.randn_like(p) * 0.1)
+    opt = torch.optim.Adam(glow.parameters(), lr=1e-4)
+    util.save_model(d1, 3, glow, opt, 2.0, is_best=False)
+    util.save_model(d1, 12, glow, opt, 4.0, is_best=True)
+    assert util.get_last_model_name(d1) == "network-snapshot-000012.pth"
+    assert os.path.exists(os.path.join(d1, util.get_best_model_name()))
+    other = G.Glow(hps)
+    for key in (3, "best", "latest", os.path.join(d1, util.get_model_name(12))):
+        st = util.load_model(d1, key, other, device="cpu")
+        assert st["step"] == (3 if key == 3 else 12)
+    assert all(torch.equal(a, b) for a, b in zip(glow.state_dict().values(), other.state_dict().values()))
+    with pytest.raises(FileNotFoundError):
+        util.load_model(d1, 99, other)
+    t = torch.arange(12.).view(3, 2, 2)
+    assert util.make_batch(t, 4).shape == (4, 3, 2, 2) and torch.equal(util.make_batch(t, 4)[3], t)
+    util.save_deltaz(np.ones((3, 2)), os.path.join(root, "dz"))
+    assert np.array_equal(util.load_deltaz(os.path.join(root, "dz", "deltaz.npy")), np.ones((3, 2)))
+    assert util.load_deltaz(os.path.join(root, "missing.npy")) is None
+
+
+def test_builder_needs_a_hip_device_and_knows_the_reference_tables():
+    from pytorch_glow_amd.network import Builder
+    assert set(Builder.optimizer_dict) == {"adam", "adamax"}
+    assert set(Builder.lr_scheduler_dict) == {"constant", "noam", "linear", "step", "cyclic_cosine"}
+    hps = _g9_hps()
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="HIP device"):
+            Builder(hps).build(training=False)

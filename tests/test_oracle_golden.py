@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import sub
+from conftest import load_golden, sub
 from oracle import glow_oracle as O
 
 ATOL = 2e-6
@@ -152,3 +152,16 @@ def test_g8_glow_celeba64(golden):
         assert abs(z.double().sum().item() - float(g["z_sum"])) < 1e-1
         x = O.glow_reverse(z, post, cfg, [g["dec_eps0"], g["dec_eps1"]])
         close(x[:, :, :4, :4], g["dec_x_corner"], atol=1e-4)
+
+
+def test_g9_attribute_delta_restatement_matches_the_reference_inferer():
+    """oracle.attribute_delta (including the reference's two-samples-per-batch loop) against deltaz computed by the real
+    `Inferer.compute_attribute_delta` on latents of the real Glow, in the data-loader order the reference used."""
+    g = load_golden("g9_inferer")
+    order = g["order"].astype(int)
+    zs, ys = g["z_all"].numpy()[order], g["ys"].numpy()[order]
+    deltaz = g["deltaz"].numpy()
+    ref_mode = O.attribute_delta(zs, ys, batch_size=4, per_batch=2)
+    assert np.abs(ref_mode - deltaz).max() < 1e-6
+    every = O.attribute_delta(zs, ys, batch_size=4)
+    assert np.abs(every - deltaz).max() > 1e-3      # the documented behaviour (all samples) is a different number
