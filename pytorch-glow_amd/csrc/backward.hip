@@ -16,6 +16,7 @@
 // below fp32 resolution after the final rounding) and converted by k_grad_finalize.
 #include "kernels.h"
 #include "backward.h"
+#include "sh.h"
 
 namespace glowhip {
 
@@ -157,9 +158,51 @@ __global__ void __launch_bounds__(256) k_act_bwd(float* __restrict__ g, const fl
     }
 }
 
+// The same, and the masked gradient ALSO as a split-half tensor (sh.h) for the f16-pipe input-gradient GEMM that follows.
+// Workgroup = 64 pixels (one SH tile) x 8 channels (one 16-byte group per pixel and plane); a wave owns 2 channels, so the
+// per-channel sums are plain wave reductions.
+__global__ void __launch_bounds__(256) k_act_bwd_sh(float* __restrict__ g, const float* __restrict__ h,
+                                                    const float* __restrict__ e, int Cm, int HW, double* __restrict__ acc_b,
+                                                    double* __restrict__ acc_l, _Float16* __restrict__ gsh) {
+    __shared__ __attribute__((aligned(16))) _Float16 st[2][64][8];
+    const int px = threadIdx.x & 63, cq = threadIdx.x >> 6;
+    const int chunk = blockIdx.y;
+    const long n = blockIdx.z;
+    const int p = blockIdx.x * 64 + px;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int c = chunk * 8 + cq * 2 + k;
+        const long idx = (n * Cm + c) * HW + p;
+        const float hv = h[idx], gh = g[idx];
+        const float gu = hv > 0.f ? gh * e[c] : 0.f;
+        g[idx] = gu;
+        _Float16 a, b;
+        sh_split(gu, a, b);
+        st[0][px][cq * 2 + k] = a;
+        st[1][px][cq * 2 + k] = b;
+        const double tb = wave_sum((double)gu), tl = wave_sum((double)(gh * hv) * 3.0);
+        if (px == 0) {
+            atomic_add_f64(acc_b + c, tb);
+            atomic_add_f64(acc_l + c, tl);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int q = threadIdx.x >> 6, x = threadIdx.x & 63;
+        const long gp = n * HW + (long)blockIdx.x * 64 + x;
+        *reinterpret_cast<h8*>(gsh + sh_off(Cm >> 3, q, chunk, gp)) = *reinterpret_cast<const h8*>(&st[q][x][0]);
+    }
+}
+
 int launch_act_bwd(float* g, const float* h, const float* e, int N, int Cm, int HW, double* acc_b, double* acc_l,
-                   hipStream_t s) {
+                   hipStream_t s, _Float16* g_sh) {
     if (N == 0) return GLOWHIP_OK;
+    if (g_sh) {
+        GH_REQUIRE(HW % 64 == 0 && Cm % 8 == 0, "act_bwd: split-half copy needs HW %% 64 == 0 and channels %% 8 == 0");
+        hipLaunchKernelGGL(k_act_bwd_sh, dim3(HW / 64, Cm / 8, N), dim3(256), 0, s, g, h, e, Cm, HW, acc_b, acc_l, g_sh);
+        GH_LAUNCH_CHECK("k_act_bwd_sh");
+        return GLOWHIP_OK;
+    }
     hipLaunchKernelGGL(k_act_bwd, dim3(cdiv(HW, 256), Cm, N), dim3(256), 0, s, g, h, e, Cm, HW, acc_b, acc_l);
     GH_LAUNCH_CHECK("k_act_bwd");
     return GLOWHIP_OK;

@@ -19,7 +19,7 @@ void conv_mfma_wide_disable_glds(int off);  // testing hook: 1 = use the registe
 bool conv_mfma_first_supported(int Cin, int H, int W, int Cout);
 size_t conv_mfma_first_packed_bytes(int Cin, int Cout);
 // wf: packed image (weights * exp(3 logs), then bias * exp(3 logs)) produced by the REPACK_FIRST job
-// y_sh non-NULL: write the result as a split-half tensor (sh.h) of N*H*W pixels instead of fp32 NCHW `y`
+// y_sh non-NULL: write the result as a split-half tensor (sh.h) of N*H*W pixels; y non-NULL: as fp32 NCHW (either or both)
 int launch_conv_mfma_first(const float* x, long x_bs, const float* wf, const float* bias_scaled, float* y, int N,
                            int Cin, int H, int W, int Cout, hipStream_t s, int relu = 1, _Float16* y_sh = nullptr);
 
@@ -70,6 +70,7 @@ int conv_mfma_tail_pack(const float* w, int Cin, int Cout, int paired, float* wp
 int launch_conv_mfma_tail(const TailConvArgs& a, hipStream_t s);
 void conv_mfma_tail_force_tile(int tp);
 void plan_disable_sh(int off);   // testing hook (plan.hip)
+void plan_train_disable_sh(int off);   // testing hook (plan_train.hip)
 int launch_tail_dma_narrow(const TailConvArgs& a, int paired, hipStream_t s, int TP, int Y);  // W in {8,16}
 int launch_tail_dma_wide(const TailConvArgs& a, int paired, hipStream_t s, int TP, int Y);    // W in {32,64,128}  // testing hook: 0 = automatic, else 16/32/64/128 pixels per block
 

@@ -191,7 +191,8 @@ k_conv_first(const float* __restrict__ X, long x_bs, const float* __restrict__ W
                         }
                     }
                 }
-            } else {
+            }
+            if (Y) {   // fp32 NCHW output (both may be requested: the training forward keeps fp32 on the tape)
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int p = p0 + wc * WN + j * 32 + ml;

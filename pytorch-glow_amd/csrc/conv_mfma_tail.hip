@@ -351,6 +351,7 @@ void conv_mfma_tail_force_tile(int v) {
     plan_disable_sh(((v & 0x800) ? 1 : 0) | ((v & 0x1000) ? 2 : 0) | ((v & 0x2000) ? 4 : 0) | ((v & 0x4000) ? 8 : 0) |
                     ((v & 0x8000) ? 16 : 0));
     tail_sh_force_waves((v >> 16) & 0xf);
+    plan_train_disable_sh((v & 0x800) ? 1 : 0);
 }
 
 }  // namespace glowhip

@@ -53,7 +53,8 @@ __global__ void __launch_bounds__(256) k_repack_batched(const RepackJob* __restr
             const int k8 = (int)(e & 7);
             const int o = (int)((e >> 3) % j.Cout);
             const int k = (int)((e >> 3) / j.Cout) * 8 + k8;
-            const float wv = j.w[(long)o * j.K + k] * (j.fold_logs ? expf(j.fold_logs[o] * LOGSCALE) : 1.f);
+            const float wv = (j.transposed ? j.w[(long)k * j.Cout + o] : j.w[(long)o * j.K + k]) *
+                             (j.fold_logs ? expf(j.fold_logs[o] * LOGSCALE) : 1.f);
             _Float16 hi, lo;
             sh_split(wv, hi, lo);
             oh[e] = hi;

@@ -113,8 +113,8 @@ static int run_coupling(glowhip_plan* P, const LayerPlan& L, const void* packed,
         GH_TRY(launch_first_sh(x1, x1_bs, at<char>(packed, L.f0_sh), (_Float16*)w.h1, N, Ch, d.H, d.W, hid, 1, s));
     } else if (L.first_halo) {
         const float* wf = at<float>(packed, L.f0_wt);
-        GH_TRY(launch_conv_mfma_first(x1, x1_bs, wf, wf + (size_t)9 * Ch * hid, w.h1, N, Ch, d.H, d.W, hid, s, 1,
-                                      use_sh ? (_Float16*)w.h1 : nullptr));
+        GH_TRY(launch_conv_mfma_first(x1, x1_bs, wf, wf + (size_t)9 * Ch * hid, use_sh ? nullptr : w.h1, N, Ch, d.H, d.W, hid,
+                                      s, 1, use_sh ? (_Float16*)w.h1 : nullptr));
     } else if (L.mfma_first) {
         GH_TRY(launch_conv_mfma_wide(x1, x1_bs, at<float>(packed, L.f0_wt), d.f0_an_bias, at<float>(packed, L.f0_scale),
                                      w.h1, N, Ch, d.H, d.W, hid, 3, s));
@@ -377,7 +377,7 @@ glowhip_plan* glowhip_plan_create(const glowhip_layer_desc* layers, int n_layers
             else if (L.mfma_first) L.f0_wt = take(off, conv_mfma_wide_packed_bytes(C / 2, d.hidden, 3));
             if (L.mfma_mid) L.f2_wt = take(off, conv_mfma_wide_packed_bytes(d.hidden, d.hidden, 1));
             L.sh_mid = L.first_halo && gemm_sh_supported(d.hidden, d.hidden, H, W);
-            if (L.sh_mid) L.f2_sh = take(off, gemm_sh_packed_bytes(d.hidden, d.hidden));
+            if (L.sh_mid) { L.f2_sh = take(off, gemm_sh_packed_bytes(d.hidden, d.hidden)); L.f2T_sh = take(off, gemm_sh_packed_bytes(d.hidden, d.hidden)); }
             L.sh_first = L.sh_mid && first_sh_supported(C / 2, H, W, d.hidden);
             if (L.sh_first) L.f0_sh = take(off, first_sh_packed_bytes(C / 2, d.hidden));
             L.sh_tail = L.sh_mid && tail_sh_supported(d.hidden, H, W, L.Cout);
@@ -434,7 +434,10 @@ glowhip_plan* glowhip_plan_create(const glowhip_layer_desc* layers, int n_layers
             }
             if (L.sh_mid) {
                 RepackJob r{}; r.w = d.f2_w; r.out_off = L.f2_sh; r.kind = REPACK_SH_GEMM; r.Cin = d.hidden; r.Cout = d.hidden;
-                r.K = d.hidden; r.fold_bias = d.f2_an_bias; r.fold_logs = d.f2_an_logs; r.use = 1; p->repack_jobs.push_back(r);
+                r.K = d.hidden; r.fold_bias = d.f2_an_bias; r.fold_logs = d.f2_an_logs; r.use = 3; p->repack_jobs.push_back(r);
+                // input gradient of f.2 on the same kernel: W2^T, nothing folded (training only)
+                RepackJob t{}; t.w = d.f2_w; t.out_off = L.f2T_sh; t.kind = REPACK_SH_GEMM; t.Cin = d.hidden; t.Cout = d.hidden;
+                t.K = d.hidden; t.transposed = 1; t.use = 2; p->repack_jobs.push_back(t);
             }
             if (L.sh_first) {
                 RepackJob r{}; r.w = d.f0_w; r.out_off = L.f0_sh; r.kind = REPACK_SH_FIRST; r.Cin = d.C / 2; r.Cout = d.hidden;

@@ -47,6 +47,7 @@ static size_t tape_layout(const glowhip_plan* p, int N, std::vector<TapeLayer>* 
 struct TrainWs {
     unsigned long long* acc; float* gld; double* gsum;
     float* gA; float* gB; float* gh1; float* gh2; float* gpre; float* wT; double* dacc;
+    float* gsh;                   // split-half copy of a hidden-layer gradient (input of the f16-pipe dgrad GEMM) / of h1 (forward)
     float* col; float* partial;   // shift-expanded small operand / split-K partial tiles of the MFMA weight gradients
     GradJob* jobs;                // device copy of the finalize job table (<= 9 per layer)
     size_t dacc_doubles;
@@ -82,6 +83,10 @@ static size_t max_acc_doubles(const glowhip_plan* p) {
 
 static int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
+static bool g_train_sh = true;   // testing hook: 0 = exact-fp32 kernels for f.2 in the training step too
+static bool train_sh_enabled() { return g_train_sh; }
+void plan_train_disable_sh(int off) { g_train_sh = off == 0; }
+
 static bool wgrad_fast(const LayerPlan& L) {
     const glowhip_layer_desc& d = L.d;
     return d.kind == GLOWHIP_LAYER_FLOWSTEP && (d.H * d.W) % 32 == 0 && d.hidden % 128 == 0;
@@ -107,6 +112,7 @@ static size_t train_ws_layout(const glowhip_plan* p, int N, void* base, TrainWs*
     const size_t o_gA = take(off, (size_t)N * p->max_chw * 4), o_gB = take(off, (size_t)N * p->max_chw * 4);
     const size_t o_h1 = take(off, (size_t)N * p->max_hidden * 4), o_h2 = take(off, (size_t)N * p->max_hidden * 4);
     const size_t o_gpre = take(off, (size_t)N * p->max_chw * 4);
+    const size_t o_gsh = take(off, (size_t)N * p->max_hidden * 4);
     const size_t o_wT = take(off, max_weight_floats(p) * 4);
     const size_t nd = max_acc_doubles(p);
     const size_t o_dacc = take(off, nd * 8);
@@ -119,14 +125,15 @@ static size_t train_ws_layout(const glowhip_plan* p, int N, void* base, TrainWs*
         w->acc = at<unsigned long long>(base, o_acc); w->gld = at<float>(base, o_gld); w->gsum = at<double>(base, o_gsum);
         w->gA = at<float>(base, o_gA); w->gB = at<float>(base, o_gB); w->gh1 = at<float>(base, o_h1);
         w->gh2 = at<float>(base, o_h2); w->gpre = at<float>(base, o_gpre); w->wT = at<float>(base, o_wT);
-        w->dacc = at<double>(base, o_dacc); w->dacc_doubles = nd;
+        w->dacc = at<double>(base, o_dacc); w->dacc_doubles = nd; w->gsh = at<float>(base, o_gsh);
     }
     return align_up(off, 256);
 }
 
 // ---------------------------------------------------------------- forward with tape
 static int forward_train(glowhip_plan* p, const void* packed, const float* x, const float* noise, float* z_out, int N,
-                         char* tape, const std::vector<TapeLayer>& tl, unsigned long long* acc, hipStream_t s) {
+                         char* tape, const std::vector<TapeLayer>& tl, unsigned long long* acc, float* sh_scratch,
+                         hipStream_t s) {
     const float* cur = x;
     const int nl = (int)p->layers.size();
     for (int li = 0; li < nl; ++li) {
@@ -152,9 +159,13 @@ static int forward_train(glowhip_plan* p, const void* packed, const float* x, co
             m.reverse = 0; m.N = N; m.C = d.C; m.HW = HW;
             GH_TRY(launch_chanmix(m, s));
             // f.0
+            // f.2 on the f16 matrix pipe (gemm_sh.hip) when f.0 can hand it h1 as a split-half tensor next to the fp32 copy
+            // the tape keeps; the tape itself stays fp32 (the weight-gradient GEMMs read it)
+            const bool sh2 = L.first_halo && L.sh_mid && train_sh_enabled();
             if (L.first_halo) {
                 const float* wf = at<float>(packed, L.f0_wt);
-                GH_TRY(launch_conv_mfma_first(dst, chw, wf, wf + (size_t)9 * Ch * hid, h1, N, Ch, d.H, d.W, hid, s));
+                GH_TRY(launch_conv_mfma_first(dst, chw, wf, wf + (size_t)9 * Ch * hid, h1, N, Ch, d.H, d.W, hid, s, 1,
+                                              sh2 ? (_Float16*)sh_scratch : nullptr));
             } else if (L.mfma_first) {
                 GH_TRY(launch_conv_mfma_wide(dst, chw, at<float>(packed, L.f0_wt), d.f0_an_bias,
                                              at<float>(packed, L.f0_scale), h1, N, Ch, d.H, d.W, hid, 3, s));
@@ -164,7 +175,9 @@ static int forward_train(glowhip_plan* p, const void* packed, const float* x, co
                 GH_TRY(launch_conv_direct(c, s));
             }
             // f.2
-            if (L.mfma_mid) {
+            if (sh2) {
+                GH_TRY(launch_gemm_sh((const _Float16*)sh_scratch, at<char>(packed, L.f2_sh), h2, nullptr, N, hid, HW, hid, 1, s));
+            } else if (L.mfma_mid) {
                 GH_TRY(launch_conv_mfma_wide(h1, (long)hid * HW, at<float>(packed, L.f2_wt), d.f2_an_bias,
                                              at<float>(packed, L.f2_scale), h2, N, hid, d.H, d.W, hid, 1, s));
             } else {
@@ -302,7 +315,9 @@ static int backward_sweep(glowhip_plan* p, const void* packed, const float* x_in
             } else {
                 GH_TRY(dgrad_direct(w.gpre, d.f4_w, w.wT, w.gh2, N, hid, d.H, d.W, L.Cout, 3, s));
             }
-            GH_TRY(launch_act_bwd(w.gh2, h2, at<float>(packed, L.f2_scale), N, hid, HW, a2b, a2l, s));
+            const bool shd = L.sh_mid && train_sh_enabled() && HW % 64 == 0;   // f.2's input gradient on the f16 pipe
+            GH_TRY(launch_act_bwd(w.gh2, h2, at<float>(packed, L.f2_scale), N, hid, HW, a2b, a2l, s,
+                                  shd ? (_Float16*)w.gsh : nullptr));
             // (c) f.2 (1x1)
             if (fastw) {
                 GH_TRY(launch_wgrad_mfma(w.gh2, (long)hid * HW, h1, (long)hid * HW, w.partial, G.f2_w, N, HW, hid, hid, hid, hid,
@@ -310,7 +325,9 @@ static int backward_sweep(glowhip_plan* p, const void* packed, const float* x_in
             } else {
                 GH_TRY(launch_wgrad_direct(w.gh2, h1, (long)hid * HW, G.f2_w, N, hid, d.H, d.W, hid, 1, s));
             }
-            if (L.mfma_mid) {   // W2 in its reference layout [o][i] is already the K-major image of the transposed GEMM
+            if (shd) {
+                GH_TRY(launch_gemm_sh((const _Float16*)w.gsh, at<char>(packed, L.f2T_sh), w.gh1, nullptr, N, hid, HW, hid, 0, s));
+            } else if (L.mfma_mid) {   // W2 in its reference layout [o][i] is already the K-major image of the transposed GEMM
                 GH_TRY(launch_conv_mfma_wide(w.gh2, (long)hid * HW, d.f2_w, nullptr, nullptr, w.gh1, N, hid, d.H, d.W, hid, 1,
                                              s, 0));
             } else {
@@ -404,7 +421,7 @@ int glowhip_glow_forward_train(glowhip_plan* plan, const void* packed, const flo
     GH_REQUIRE(workspace_bytes >= train_ws_layout(plan, N, workspace, &w), "glow_forward_train: workspace too small");
     hipStream_t s = (hipStream_t)stream;
     GH_TRY(launch_zero_acc(w.acc, N, s));
-    GH_TRY(forward_train(plan, packed, x, noise, z, N, (char*)tape, tl, w.acc, s));
+    GH_TRY(forward_train(plan, packed, x, noise, z, N, (char*)tape, tl, w.acc, w.gsh, s));
     const int* o = plan->out_shape;
     GH_TRY(launch_gaussian_logp(z, (long)o[0] * o[1] * o[2], prior_mean, prior_logs, prior_stride, N, o[0], o[1] * o[2],
                                 w.acc, s));
