@@ -170,6 +170,14 @@ int glowhip_glow_forward(glowhip_plan* plan, const void* packed, const float* x,
                          float* z, float* nll_out, float* objective_out, int N,
                          void* workspace, size_t workspace_bytes, glowhip_stream_t stream);
 
+/* The same from 8-bit pixels (N,C,H,W) as a data loader holds them: x = x_u8 / divisor (255 for torchvision's ToTensor,
+ * dataset/celeba.py:74-86) + noise, converted inside the plan's leading Squeeze2d -- no fp32 copy of the batch is ever
+ * made.  The plan must start with a Squeeze2d layer. */
+int glowhip_glow_forward_u8(glowhip_plan* plan, const void* packed, const uint8_t* x_u8, float divisor, const float* noise,
+                            const float* prior_mean, const float* prior_logs, long prior_stride, int n_bits, float* z,
+                            float* nll_out, float* objective_out, int N, void* workspace, size_t workspace_bytes,
+                            glowhip_stream_t stream);
+
 /* Data-dependent ActNorm initialisation pass over a whole plan (first training-mode forward,
  * network/trainer.py:112-115 + network/module.py:45-46,66-67): runs encode on x and writes every
  * ActNorm's bias/logs THROUGH the parameter pointers of the layer descs (which must be writable). */

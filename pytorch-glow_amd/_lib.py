@@ -78,6 +78,7 @@ SIGNATURES = {
     "glowhip_plan_encode": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, _P, c_size_t, _P]),
     "glowhip_plan_decode": (c_int, [_P, _P, _P, POINTER(c_void_p), c_int, _P, _P, _P, c_int, _P, c_size_t, _P]),
     "glowhip_glow_forward": (c_int, [_P, _P, _P, _P, _P, _P, c_long, c_int, _P, _P, _P, c_int, _P, c_size_t, _P]),
+    "glowhip_glow_forward_u8": (c_int, [_P, _P, _P, c_float, _P, _P, _P, c_long, c_int, _P, _P, _P, c_int, _P, c_size_t, _P]),
     "glowhip_plan_actnorm_init": (c_int, [_P, _P, c_size_t, _P, _P, c_float, c_int, _P, c_size_t, _P]),
     "glowhip_plan_output_shape": (c_int, [_P, c_int, POINTER(c_int32)]),
     "glowhip_plan_describe": (c_int, [_P, c_char_p, c_size_t]),
@@ -142,13 +143,16 @@ def ptr(t) -> c_void_p:
     return c_void_p(None) if t is None else c_void_p(t.data_ptr())
 
 
-def require_device_tensor(t: torch.Tensor, what: str = "input") -> torch.Tensor:
-    """The HIP path only takes fp32 tensors resident on a GPU; anything else is an error, not a fallback."""
+def require_device_tensor(t: torch.Tensor, what: str = "input", allow_uint8: bool = False) -> torch.Tensor:
+    """The HIP path only takes fp32 tensors resident on a GPU (the Glow input also as 8-bit pixels); anything else is an
+    error, not a fallback."""
     if not isinstance(t, torch.Tensor):
         raise TypeError(f"{what}: expected a torch.Tensor, got {type(t).__name__}")
     if not t.is_cuda:
         raise GlowHipError(f"{what} is on {t.device}: the Glow flow path runs only on a HIP device "
                            "(there is no CPU fallback; use oracle/ for CPU checks in tests)")
+    if allow_uint8 and t.dtype == torch.uint8:
+        return t.contiguous()
     if t.dtype != torch.float32:
         raise GlowHipError(f"{what}: dtype {t.dtype} unsupported, the path computes in fp32")
     return t.contiguous()

@@ -191,6 +191,11 @@ class FlowPlan:
         if n == 0:
             return z, nll, obj
         ws = self._workspace(n)
+        if x.dtype == torch.uint8:   # 8-bit pixels straight from the data loader: converted inside the leading squeeze
+            check(lib().glowhip_glow_forward_u8(self._h, ptr(self.packed), ptr(x), 255.0, ptr(noise), ptr(prior_mean),
+                                                ptr(prior_logs), prior_stride, n_bits, ptr(z), ptr(nll), ptr(obj), n, ptr(ws),
+                                                ws.numel(), stream_ptr(self.device)))
+            return z, nll, obj
         check(lib().glowhip_glow_forward(self._h, ptr(self.packed), ptr(x), ptr(noise), ptr(prior_mean), ptr(prior_logs),
                                          prior_stride, n_bits, ptr(z), ptr(nll), ptr(obj), n, ptr(ws), ws.numel(),
                                          stream_ptr(self.device)))

@@ -7,6 +7,8 @@ namespace glowhip {
 // ---------------------------------------------------------------- pointwise.hip
 int launch_squeeze(const float* x, const float* noise, float* y, int N, int C, int H, int W, int f, int reverse,
                    hipStream_t s);
+int launch_squeeze_u8(const uint8_t* x, const float* noise, float* y, int N, int C, int H, int W, int f, float divisor,
+                      hipStream_t s);
 int launch_copy_strided(const float* x, long xbs, float* y, long ybs, int N, long per_sample, hipStream_t s);
 int launch_actnorm_init(const float* x, long xbs, int N, int C, int HW, float scale, float* bias, float* logs,
                         hipStream_t s);

@@ -206,11 +206,11 @@ static float* other_buf(const Workspace& w, const float* cur) { return cur == w.
 
 // ---------------------------------------------------------------- encode (network/model.py:263-276)
 static int run_forward(glowhip_plan* p, const void* packed, const float* x, const float* noise, float* z_out, int N,
-                       const Workspace& w, hipStream_t s) {
+                       const Workspace& w, hipStream_t s, int first_layer = 0) {
     const float* cur = x;
     const int nl = (int)p->layers.size();
     bool premixed = false;   // `cur` already holds this step's ActNorm + permutation output (applied by the previous tail)
-    for (int li = 0; li < nl; ++li) {
+    for (int li = first_layer; li < nl; ++li) {
         const LayerPlan& L = p->layers[li];
         const glowhip_layer_desc& d = L.d;
         p->cur_layer = li;
@@ -646,6 +646,34 @@ int glowhip_glow_forward(glowhip_plan* plan, const void* packed, const float* x,
     const double scale = -1.0 / (log(2.0) * chw);
     GH_TRY(launch_finalize(nullptr, w.acc, at<double>(packed, 0), 1.0, offset, scale, nll_out, objective_out, N, s));
     return GLOWHIP_OK;
+}
+
+// Glow.normal_flow from 8-bit pixels: the leading Squeeze2d reads the bytes itself
+int glowhip_glow_forward_u8(glowhip_plan* plan, const void* packed, const uint8_t* x_u8, float divisor, const float* noise,
+                            const float* prior_mean, const float* prior_logs, long prior_stride, int n_bits, float* z,
+                            float* nll_out, float* objective_out, int N, void* workspace, size_t workspace_bytes,
+                            glowhip_stream_t stream) {
+    GH_TRY(check_plan_args(plan, packed, N));
+    GH_REQUIRE(x_u8 && z && nll_out, "glow_forward_u8: null tensor");
+    GH_REQUIRE(divisor > 0.f, "glow_forward_u8: divisor must be positive");
+    GH_REQUIRE(n_bits > 0 && n_bits <= 30, "glow_forward_u8: n_bits=%d", n_bits);
+    GH_REQUIRE(plan->layers.size() >= 2 && plan->layers[0].d.kind == GLOWHIP_LAYER_SQUEEZE,
+               "glow_forward_u8: the plan must start with a Squeeze2d layer (and not end with it)");
+    if (N == 0) return GLOWHIP_OK;
+    hipStream_t s = (hipStream_t)stream;
+    Workspace w;
+    GH_TRY(carve(plan, N, workspace, workspace_bytes, w));
+    GH_TRY(launch_zero_acc(w.acc, N, s));
+    const glowhip_layer_desc& d0 = plan->layers[0].d;
+    plan->cur_layer = 0;
+    GH_TRY(launch_squeeze_u8(x_u8, noise, w.bufA, N, d0.C, d0.H, d0.W, 2, divisor, s));
+    GH_TRY(run_forward(plan, packed, w.bufA, nullptr, z, N, w, s, 1));
+    const int* o = plan->out_shape;
+    GH_TRY(launch_gaussian_logp(z, (long)o[0] * o[1] * o[2], prior_mean, prior_logs, prior_stride, N, o[0], o[1] * o[2],
+                                w.acc, s));
+    const double chw = (double)plan->in_shape[0] * plan->in_shape[1] * plan->in_shape[2];
+    return launch_finalize(nullptr, w.acc, at<double>(packed, 0), 1.0, -log(pow(2.0, n_bits)) * chw, -1.0 / (log(2.0) * chw),
+                           nll_out, objective_out, N, s);
 }
 
 int glowhip_plan_actnorm_init(glowhip_plan* plan, void* packed, size_t packed_bytes, const float* x, const float* noise,

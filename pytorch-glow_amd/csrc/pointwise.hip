@@ -45,6 +45,37 @@ __global__ void __launch_bounds__(256) k_squeeze(const float* __restrict__ x, co
     y[idx] = v;
 }
 
+// The same gather from 8-bit pixels: y = u8 / divisor (+ noise) -- `ToTensor` (dataset/celeba.py:74-86, train.py:40-45),
+// the dequantisation noise (network/model.py:421) and the first squeeze in one pass over a quarter of the bytes.
+__global__ void __launch_bounds__(256) k_squeeze_u8(const uint8_t* __restrict__ x, const float* __restrict__ noise,
+                                                    float* __restrict__ y, long total, int C, int H, int W, int f,
+                                                    float divisor) {
+    long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int Ho = H / f, Wo = W / f, Co = C * f * f;
+    int w = (int)(idx % Wo);
+    long t = idx / Wo;
+    int h = (int)(t % Ho);
+    t /= Ho;
+    int co = (int)(t % Co);
+    long n = t / Co;
+    int c = co / (f * f), r = co % (f * f), i = r / f, j = r % f;
+    const long src = ((n * C + c) * H + (h * f + i)) * (long)W + (w * f + j);
+    float v = (float)x[src] / divisor;
+    if (noise) v += noise[src];
+    y[idx] = v;
+}
+
+int launch_squeeze_u8(const uint8_t* x, const float* noise, float* y, int N, int C, int H, int W, int f, float divisor,
+                      hipStream_t s) {
+    GH_REQUIRE(f >= 1 && H % f == 0 && W % f == 0, "squeeze2d(u8): H,W must be divisible by the factor");
+    long total = (long)N * C * H * W;
+    if (total == 0) return GLOWHIP_OK;
+    hipLaunchKernelGGL(k_squeeze_u8, dim3(cdiv(total, 256)), dim3(256), 0, s, x, noise, y, total, C, H, W, f, divisor);
+    GH_LAUNCH_CHECK("k_squeeze_u8");
+    return GLOWHIP_OK;
+}
+
 int launch_squeeze(const float* x, const float* noise, float* y, int N, int C, int H, int W, int f, int reverse,
                    hipStream_t s) {
     GH_REQUIRE(f >= 1, "squeeze2d: factor must be >= 1");

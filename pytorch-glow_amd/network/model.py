@@ -251,10 +251,12 @@ class Glow(nn.Module):
     def normal_flow(self, x, y_onehot=None, noise=None, repack=False):
         """z = x + U(0, 1/2^n_bits); objective = -ln(n_bins)*CHW + logdet + logp(z); nll = -objective/(ln2*CHW).
         ``noise`` (optional, beyond the reference signature) injects the dequantisation draw."""
-        x = require_device_tensor(x, "Glow input")
+        x = require_device_tensor(x, "Glow input", allow_uint8=True)   # uint8 = pixels as loaded, scaled by 1/255 in-kernel
+        if x.dtype == torch.uint8 and (self.training or torch.is_grad_enabled()):
+            x = x.float() / 255.0   # the ActNorm init pass and the training step take fp32; inference reads the bytes itself
         n_bits = self.hps.model.n_bits_x
         if noise is None:
-            noise = torch.empty_like(x).uniform_(0, 1. / 2 ** n_bits)
+            noise = torch.empty(x.shape, dtype=torch.float32, device=x.device).uniform_(0, 1. / 2 ** n_bits)
         else:
             noise = require_device_tensor(noise, "noise")
             assert noise.shape == x.shape

@@ -591,3 +591,21 @@ def test_split_half_stack_every_coupling_and_permutation(coup, perm):
         x_ref = O.glow_reverse(z_ref, sd, cfg, eps, perm_tables=tables)
     xr = glow.reverse_flow(dev(z_ref), None, eps=[dev(e) for e in eps])
     close(xr, x_ref, 1e-4, what="decode")
+
+
+def test_uint8_pixels_equal_the_float_path_bitwise():
+    """`Glow.normal_flow` on 8-bit pixels (as a data loader holds them) converts inside the leading squeeze
+    kernel; x/255 is the ToTensor arithmetic, so the result must equal the fp32 path on u8.float()/255 bit for bit."""
+    cfg = O.default_cfg(image_shape=(64, 64, 3), hidden_channels=128, K=2, L=3, batch=3)
+    sd = O.seeded_state_dict(cfg, seed=8, zeros_std=0.02)
+    glow = make_glow(cfg, sd, 3)
+    u8 = torch.randint(0, 256, (3, 3, 64, 64), dtype=torch.uint8, generator=torch.Generator().manual_seed(1))
+    noise = torch.rand(3, 3, 64, 64, generator=torch.Generator().manual_seed(2)) / 256
+    xf = u8.float() / 255.0
+    z8, nll8, _ = glow.normal_flow(u8.to(DEV), None, noise=dev(noise))
+    zf, nllf, _ = glow.normal_flow(dev(xf), None, noise=dev(noise))
+    assert torch.equal(z8, zf) and torch.equal(nll8, nllf)
+    z_ref, nll_ref, _ = O.glow_forward(xf, noise, sd, cfg)
+    close(z8, z_ref, 1e-4, what="z"); close(nll8, nll_ref, 1e-4, what="nll")
+    with pytest.raises(G.GlowHipError):
+        glow.normal_flow(u8.to(DEV).to(torch.int16), None)
