@@ -4,10 +4,12 @@
 //
 // Workgroup = 128 out-channels x 128 pixels, 4 waves (2 x 2), each wave 64 x 64 = 2 x 2 MFMA tiles x 2 accumulators
 // (128 accumulator registers).  Operands stream HBM/L2 -> LDS through the DMA path (global_load_lds_dwordx4) into a 4-stage ring
-// of 32-deep k-tiles; the LDS image of a stage is [A|B][plane][chunk 4][128 rows][8 halfs] -- written linearly by the DMA
-// (one wave-instruction = 64 rows x 16 B = 1 KiB) and read as conflict-free 16-byte fragments (16 consecutive lanes = 256
-// contiguous bytes = every bank once).  A stage is consumed behind a counted s_waitcnt vmcnt + ONE raw s_barrier per 24
-// MFMAs; that barrier also proves the previous stage is drained, so its slot is refilled right behind it.
+// of 16-deep k-tiles (64 KiB: two workgroups per CU, so one's epilogue overlaps the other's loop); the LDS image of a stage is
+// [A|B][plane][chunk 2][128 rows][8 halfs] -- written linearly by the DMA (one wave-instruction = 64 rows x 16 B = 1 KiB) and
+// read as conflict-free 16-byte fragments (16 consecutive lanes = 256 contiguous bytes = every bank once).  A stage is
+// consumed behind a counted s_waitcnt vmcnt + ONE raw s_barrier per 12 MFMAs; that barrier also proves the previous stage is
+// drained, so its slot is refilled right behind it.  In the product path this kernel serves the levels the fused f.0+f.2
+// kernel (f02_sh.hip) does not take, and f.2 of the training step (forward and input gradient).
 #include "sh.h"
 #include "conv_mfma.h"
 
