@@ -262,7 +262,7 @@ int launch_f02_sh(const float* x, long x_bs, const void* w0, const void* w2, _Fl
     GH_REQUIRE(f02_sh_supported(Cin, H, W, hidden), "f02_sh: unsupported shape");
     if (N == 0) return GLOWHIP_OK;
     const int nchunk = (Cin + 7) / 8, G = (9 * nchunk + 1) & ~1;
-    const int wshift = W == 32 ? 5 : (W == 16 ? 4 : 3);
+    const int wshift = W == 64 ? 6 : (W == 32 ? 5 : (W == 16 ? 4 : 3));
     const int R = 64 / W;
     const float* b0 = (const float*)((const char*)w0 + align_up((size_t)2 * G * hidden * 8 * sizeof(_Float16), 16));
     const float* b2 = (const float*)((const char*)w2 + align_up((size_t)2 * hidden * hidden * sizeof(_Float16), 16));

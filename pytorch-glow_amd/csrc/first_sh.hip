@@ -127,12 +127,12 @@ k_first_sh(const float* __restrict__ X, long x_bs, const _Float16* __restrict__ 
     }
 }
 
-static int first_sh_rows(int W) { return W == 32 ? 2 : 4; }   // 64 / 64 / 32 pixels per workgroup: 3+ workgroups per CU
+static int first_sh_rows(int W) { return W == 64 ? 1 : (W == 32 ? 2 : 4); }   // 64 / 64 / 64 / 32 pixels per workgroup
 static int first_sh_groups(int Cin) { return (9 * ((Cin + 7) / 8) + 1) & ~1; }
 
 bool first_sh_supported(int Cin, int H, int W, int Cout) {
     if (Cout % 128 != 0 || Cin < 1 || Cin > 64) return false;
-    if (W != 8 && W != 16 && W != 32) return false;
+    if (W != 8 && W != 16 && W != 32 && W != 64) return false;
     return H % first_sh_rows(W) == 0 && (H * W) % 64 == 0;
 }
 
@@ -150,7 +150,7 @@ int launch_first_sh(const float* x, long x_bs, const void* wsh, _Float16* y_sh, 
     const int R = first_sh_rows(W);
     const size_t lds = (size_t)2 * nchunk * (R + 2) * (W + 2) * 8 * sizeof(_Float16);
     const unsigned grid = (unsigned)(N * (H / R));
-    const int wshift = W == 32 ? 5 : (W == 16 ? 4 : 3);
+    const int wshift = W == 64 ? 6 : (W == 32 ? 5 : (W == 16 ? 4 : 3));
 #define GH_FSH_CASE(nt, r)                                                                                            \
     if (R == r && r * W == 32 * nt) {                                                                                           \
         hipLaunchKernelGGL((k_first_sh<nt, r>), dim3(grid, Cout / 128), dim3(256), lds, s, x, x_bs, w, bias, y_sh, N, Cin, H, W, \
@@ -158,7 +158,7 @@ int launch_first_sh(const float* x, long x_bs, const void* wsh, _Float16* y_sh, 
         GH_LAUNCH_CHECK("k_first_sh");                                                                                \
         return GLOWHIP_OK;                                                                                            \
     }
-    GH_FSH_CASE(2, 2) GH_FSH_CASE(2, 4) GH_FSH_CASE(1, 4)
+    GH_FSH_CASE(2, 1) GH_FSH_CASE(2, 2) GH_FSH_CASE(2, 4) GH_FSH_CASE(1, 4)
 #undef GH_FSH_CASE
     set_error("first_sh: no kernel instance");
     return GLOWHIP_EINVAL;

@@ -283,7 +283,8 @@ static bool tail_sh_config(int Cin, int H, int W, int Cout, TailShCfg* out, int 
     // 32-pixel-wide levels: 8 image rows per workgroup when that still gives most CUs a workgroup (halo overhead 10/8
     // instead of 6/4: measured 45 vs 58 us at level 1, B=64)
     int R = g_tail_sh_rows8 && W == 32 && H % 8 == 0 && Cout <= 12 && (long)N * (H / 8) >= 192 ? 8 : 4, wshift;
-    if (W == 32) wshift = 5;
+    if (W == 64) { wshift = 6; R = 2; }   // 128-pixel workgroups: the T staging area (window x 9*Cg floats) has to fit the LDS
+    else if (W == 32) wshift = 5;
     else if (W == 16) wshift = 4;
     else if (W == 8) wshift = 3;
     else return false;
@@ -294,7 +295,7 @@ static bool tail_sh_config(int Cin, int H, int W, int Cout, TailShCfg* out, int 
     const int Nw = (R + 2) * W;
     const int Mt = (9 * Cg + 31) / 32, Nt = (Nw + 31) / 32;
     // instantiated (MW, NW, PPW, waves); earlier entries win ties
-    static const int inst[][4] = {{1, 5, 4, 8}, {1, 3, 3, 8}, {2, 1, 3, 4} /* 8x8 level: measured faster than {1,1,2,8} */, {1, 1, 2, 8}, {2, 3, 5, 4}, {2, 2, 4, 4}, {2, 2, 5, 4},
+    static const int inst[][4] = {{1, 5, 4, 8}, {1, 3, 3, 8}, {1, 4, 3, 8}, {2, 1, 3, 4} /* 8x8 level: measured faster than {1,1,2,8} */, {1, 1, 2, 8}, {2, 3, 5, 4}, {2, 2, 4, 4}, {2, 2, 5, 4},
                                   {2, 3, 6, 4}, {4, 1, 9, 4}, {2, 1, 5, 4}};
     int best = -1;
     TailShCfg bc{};
@@ -378,7 +379,7 @@ int launch_tail_sh(const TailShArgs& a, hipStream_t s) {
         GH_LAUNCH_CHECK("k_tail_sh");                                                                                 \
         return GLOWHIP_OK;                                                                                            \
     }
-    GH_TSH_CASE(1, 5, 4, 8) GH_TSH_CASE(1, 3, 3, 8) GH_TSH_CASE(1, 1, 2, 8)
+    GH_TSH_CASE(1, 5, 4, 8) GH_TSH_CASE(1, 3, 3, 8) GH_TSH_CASE(1, 4, 3, 8) GH_TSH_CASE(1, 1, 2, 8)
     GH_TSH_CASE(2, 3, 5, 4) GH_TSH_CASE(2, 3, 6, 4) GH_TSH_CASE(4, 1, 9, 4) GH_TSH_CASE(2, 2, 5, 4) GH_TSH_CASE(2, 2, 4, 4)
     GH_TSH_CASE(2, 1, 5, 4) GH_TSH_CASE(2, 1, 3, 4)
 #undef GH_TSH_CASE

@@ -14,7 +14,7 @@ rng = random.Random(int(os.environ.get("SEED", "0")))
 n_cases = int(os.environ.get("CASES", "24"))
 worst = 0.0
 for case in range(n_cases):
-    image = rng.choice([16, 32, 64])
+    image = rng.choice([16, 32, 64, 128] if os.environ.get("BIG") else [16, 32, 64])
     L = rng.choice([1, 2, 3]) if image > 16 else rng.choice([1, 2])
     K = rng.choice([1, 2, 3])
     hidden = rng.choice([64, 128, 256, 512])
