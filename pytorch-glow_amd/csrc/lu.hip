@@ -10,17 +10,25 @@ size_t invconv_scratch_bytes(int C) { return (size_t)C * 2 * C * sizeof(double);
 
 constexpr int LU_LDS_MAX_C = 64;  // 64 * 128 * 8 B = 64 KiB
 
-// Workgroup-wide Gauss-Jordan on A = [W | I] (C x 2C doubles, LDS or global).  Returns log|det W| (thread 0).
+// Workgroup-wide Gauss-Jordan on A = [W | I] (C x 2C doubles, LDS or global).  Returns log|det W| (thread 192).
+// Three barriers per pivot: (1) pivot row and value published by wave 0; (2) rows k and p swapped with the pivot row scaled
+// on the way (two rows, one pass); (3) column k eliminated from every other row.  Column k of the left half is never read
+// again, so it is not cleared.  log|pivot| is summed by a lane of the LAST wave while the others eliminate.
 __device__ double lu_gauss_jordan(const float* __restrict__ w, int C, float* __restrict__ winv, double* A) {
     __shared__ int s_piv;
-    __shared__ double s_logdet;
+    __shared__ double s_pivval;
     const int tid = threadIdx.x, W2 = 2 * C;
-    __syncthreads();  // s_logdet / A may still be read by a previous use in this workgroup
-    for (int e = tid; e < C * W2; e += 256) {
-        int r = e / W2, c = e - r * W2;
-        A[e] = (c < C) ? (double)w[r * C + c] : ((c - C == r) ? 1.0 : 0.0);
+    __syncthreads();  // A may still be read by a previous use in this workgroup
+    {
+        int r = tid / W2, c = tid - r * W2;
+        const int dr = 256 / W2, dc = 256 - dr * W2;
+        for (int e = tid; e < C * W2; e += 256) {
+            A[e] = (c < C) ? (double)w[r * C + c] : ((c - C == r) ? 1.0 : 0.0);
+            r += dr; c += dc;
+            if (c >= W2) { c -= W2; ++r; }
+        }
     }
-    if (tid == 0) s_logdet = 0.0;
+    double logdet = 0.0;   // meaningful in thread 192
     __syncthreads();
     for (int k = 0; k < C; ++k) {
         // partial pivoting: first wave finds argmax |A[r][k]|, r >= k (ties -> lowest row: deterministic)
@@ -37,34 +45,29 @@ __device__ double lu_gauss_jordan(const float* __restrict__ w, int C, float* __r
                 int oi = __shfl_down(bi, o, 64);
                 if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
             }
-            if (tid == 0) s_piv = bi;
+            if (tid == 0) { s_piv = bi; s_pivval = A[bi * W2 + k]; }
         }
         __syncthreads();
         const int pr = s_piv;
-        if (pr != k) {
-            for (int c = tid; c < W2; c += 256) {
-                double t = A[k * W2 + c];
-                A[k * W2 + c] = A[pr * W2 + c];
-                A[pr * W2 + c] = t;
+        const double piv = s_pivval;
+        if (tid == 192) logdet += log(fabs(piv));
+        // rows k <-> pr, the new row k divided by the pivot (each column owned by one thread)
+        for (int c = tid; c < W2; c += 256) {
+            const double tk = A[pr * W2 + c], tp = A[k * W2 + c];
+            A[k * W2 + c] = tk / piv;
+            if (pr != k) A[pr * W2 + c] = tp;
+        }
+        __syncthreads();
+        // eliminate column k from every other row: A[r][c] -= A[r][k] * A[k][c] for c != k (column k itself is dead)
+        {
+            int r = tid / W2, c = tid - r * W2;
+            const int dr = 256 / W2, dc = 256 - dr * W2;
+            for (int e = tid; e < C * W2; e += 256) {
+                if (r != k && c != k) A[e] = fma(-A[r * W2 + k], A[k * W2 + c], A[e]);
+                r += dr; c += dc;
+                if (c >= W2) { c -= W2; ++r; }
             }
         }
-        __syncthreads();
-        const double piv = A[k * W2 + k];
-        if (tid == 0) s_logdet += log(fabs(piv));
-        __syncthreads();  // everyone has read piv before the row is scaled
-        const double inv = 1.0 / piv;
-        for (int c = tid; c < W2; c += 256) A[k * W2 + c] *= inv;
-        __syncthreads();
-        // eliminate column k from every other row; the column's multipliers are read before any write
-        // to column k because each (r, c) element is owned by exactly one thread and c==k is written last
-        for (int e = tid; e < C * W2; e += 256) {
-            int r = e / W2, c = e - r * W2;
-            if (r == k || c == k) continue;
-            A[e] = fma(-A[r * W2 + k], A[k * W2 + c], A[e]);
-        }
-        __syncthreads();
-        for (int r = tid; r < C; r += 256)
-            if (r != k) A[r * W2 + k] = 0.0;
         __syncthreads();
     }
     if (winv)
@@ -72,6 +75,9 @@ __device__ double lu_gauss_jordan(const float* __restrict__ w, int C, float* __r
             int r = e / C, c = e - r * C;
             winv[e] = (float)A[r * W2 + C + c];
         }
+    __shared__ double s_logdet;
+    if (tid == 192) s_logdet = logdet;
+    __syncthreads();
     return s_logdet;
 }
 
@@ -103,12 +109,19 @@ __global__ void __launch_bounds__(256) k_step_prepare_batched(const StepPrepJob*
     }
 }
 
-// plan-wide total of the per-step terms, summed in layer order by one thread (deterministic)
-__global__ void k_sum_konst(const StepPrepJob* __restrict__ jobs, int n, char* packed) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// plan-wide total of the per-step terms: fetched in parallel, summed in layer order by one thread (deterministic)
+__global__ void __launch_bounds__(256) k_sum_konst(const StepPrepJob* __restrict__ jobs, int n, char* packed) {
+    __shared__ double v[256];
     double t = 0.0;
-    for (int i = 0; i < n; ++i) t += *(const double*)(packed + jobs[i].konst_off);
-    *(double*)packed = t;
+    for (int base = 0; base < n; base += 256) {
+        const int i = base + threadIdx.x;
+        v[threadIdx.x] = i < n ? *(const double*)(packed + jobs[i].konst_off) : 0.0;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            for (int q = 0; q < 256 && base + q < n; ++q) t += v[q];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *(double*)packed = t;
 }
 
 int launch_step_prepare_batched(const StepPrepJob* jobs_dev, int n, int max_lds_c, void* packed, hipStream_t s) {
@@ -121,7 +134,7 @@ int launch_step_prepare_batched(const StepPrepJob* jobs_dev, int n, int max_lds_
         (void)hipFuncSetAttribute((const void*)k_step_prepare_batched, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k_step_prepare_batched, dim3(n), dim3(256), lds, s, jobs_dev, (char*)packed);
     GH_LAUNCH_CHECK("k_step_prepare_batched");
-    hipLaunchKernelGGL(k_sum_konst, dim3(1), dim3(64), 0, s, jobs_dev, n, (char*)packed);
+    hipLaunchKernelGGL(k_sum_konst, dim3(1), dim3(256), 0, s, jobs_dev, n, (char*)packed);
     GH_LAUNCH_CHECK("k_sum_konst");
     return GLOWHIP_OK;
 }
