@@ -43,7 +43,6 @@ __global__ void __launch_bounds__(256) k_coupling_bwd(CouplingBwdArgs a) {
         int oc[2];
         if (a.affine) {
             oc[0] = 2 * c; oc[1] = 2 * c + 1;
-            const float shift = a.hout[(n * a.Cout + oc[0]) * a.HW + p];
             const float r = a.hout[(n * a.Cout + oc[1]) * a.HW + p];
             const float s = sigmoidf_(r + 2.0f);
             const float z2p = a.z2out[n * a.z_bs + (long)c * a.HW + p];
