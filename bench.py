@@ -1,46 +1,63 @@
 #!/usr/bin/env python3
 """bench.py -- images/sec of a full Glow forward + log-determinant (Glow.normal_flow) on MI355X.
 
-Workload (BASELINE.json configs[1], per GPU): CelebA-shaped 64x64x3 batch of 64, L=3, K=32, hidden 512,
+Workload (default, BASELINE.json configs[1], per GPU): CelebA-shaped 64x64x3 batch of 64, L=3, K=32, hidden 512,
 affine coupling, invertible 1x1 conv; fp32; synthetic uniform [0,1) images resident in HBM; random-init weights
-of the reference's architecture + data-dependent ActNorm init on the first batch.
+of the reference's architecture + data-dependent ActNorm init on the first batch.  `--config D` / `--config E` run
+BASELINE configs[3] / [4] (128x128 L=4 K=48, 32 images per GPU; 256x256 L=6 K=32, 16 images per GPU) as secondary lines.
 
 One step = dequantisation noise (on-device RNG) -> squeeze/FlowStep/Split2d stack -> top prior -> nll (N,) ->
 sum(nll) [-> RCCL all-reduce of the scalar when N > 1].  Every step also re-derives the parameter-dependent
-data (glowhip_plan_pack: LU of the 96 invconv weights -> log|det W|, exp(3 logs), MFMA weight images), i.e. the
+data (glowhip_plan_pack: LU of the invconv weights -> log|det W|, exp(3 logs), MFMA weight images), i.e. the
 weights are treated as freshly updated each step exactly as inside a training loop -- nothing is cached across
-steps.  Multi-GPU: one process per GPU, batch sharded (weak scaling, 64 images per GPU), no data-path collective
+steps.  Multi-GPU: one process per GPU, batch sharded (weak scaling, fixed images per GPU), no data-path collective
 other than the scalar loss all-reduce.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel = the 1x1
-512->512 MFMA GEMM `k_gemm_glds`, timed live with HIP events around each of its launches in an instrumented pass of the same
-step) and `cpu_baseline` (the CPU oracle timed on this box's host cores on a bounded sample).
+`python bench.py --gpus N` launches its N ranks ITSELF (one child process per GPU, spawned before anything touches a
+GPU; RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in the children's environment, RCCL rendezvous on
+127.0.0.1).  Started under `python -m torch.distributed.run` (RANK and WORLD_SIZE already set) it is one rank of that job.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel timed live with HIP events
+around each of its launches in an instrumented pass of the same step) and `cpu_baseline` (the CPU oracle timed on this
+box's host cores on a bounded sample).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch
-import torch.distributed as dist
-
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, f32 in / f32 accumulate
 PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16/f16 dense MFMA (v_mfma_f32_32x32x16_f16)
 # split-half path (csrc/sh.h): one fp32-accurate product = 3 f16 MFMA products => algorithmic-flop ceiling = 2500 / 3
 PEAK_SPLIT_TFLOPS = PEAK_F16_MFMA_TFLOPS / 3.0
-BATCH_PER_GPU = 64
+
+# BASELINE.json configs (per-GPU batches: SURVEY.md section 8 "B B=64; C 64/GPU; D 32/GPU; E 16/GPU")
+CONFIGS = {
+    "B": dict(image=64, L=3, K=32, hidden=512, batch=64, cpu_sample=64,
+              label="CelebA 64x64x3 Glow L=3 K=32 hidden=512 affine+invconv", ref="BASELINE configs[1]"),
+    "D": dict(image=128, L=4, K=48, hidden=512, batch=32, cpu_sample=4,
+              label="CelebA 128x128x3 Glow L=4 K=48 hidden=512 affine+invconv", ref="BASELINE configs[3]"),
+    "E": dict(image=256, L=6, K=32, hidden=512, batch=16, cpu_sample=1,
+              label="256x256x3 Glow L=6 K=32 hidden=512 affine+invconv (openai/glow full config)", ref="BASELINE configs[4]"),
+}
+HEADLINE_METRIC = "images/sec full Glow fwd+logdet, 64x64x3 L=3 K=32, 1/2/4/8 GPU"
 
 
-def build_model(G, util, device, batch, seed=2384):
+def build_model(G, util, device, cfg, batch, seed=2384):
+    import numpy as np
+    import torch
     hps = util.load_profile("celeba")  # built-in profile, reference schema
+    hps.model.image_shape = [cfg["image"], cfg["image"], 3]
+    hps.model.L, hps.model.K, hps.model.hidden_channels = cfg["L"], cfg["K"], cfg["hidden"]
     hps.optim.num_batch_train = batch
     hps.device.graph = ["cuda:0"]  # one process per GPU: one replica per process
     torch.manual_seed(seed)
-    import numpy as np
     np.random.seed(seed)
     glow = G.Glow(hps)
     g = torch.Generator().manual_seed(seed)
@@ -52,10 +69,9 @@ def build_model(G, util, device, batch, seed=2384):
 
 
 def flop_per_image(glow):
+    """Contraction FLOPs of one forward (SURVEY.md section 8d formula: 2 FLOP per MAC, convolutions + invconv)."""
     hid = glow.hps.model.hidden_channels
     total = 0.0
-    for layer in glow.flow.layers:
-        pass
     c, h, w = 3, glow.hps.model.image_shape[0], glow.hps.model.image_shape[1]
     for i in range(glow.flow.L):
         c, h, w = c * 4, h // 2, w // 2
@@ -80,30 +96,67 @@ def usable_cores(cap=32):
     return max(1, min(n, cap))
 
 
-def cpu_baseline(glow, x_cpu, budget_s=12.0):
-    """Time the CPU oracle (a port of the reference's eager op sequence) on this box's host cores."""
+def cpu_baseline(glow, x_cpu, cfg, budget_s=25.0):
+    """Time the CPU oracle (a port of the reference's eager op sequence) on this box's host cores: one warm-up forward, then
+    up to 3 timed forwards of the same batch (median), bounded by `budget_s` of CPU work."""
+    import torch
     from oracle import glow_oracle as O
     cores = usable_cores()
     torch.set_num_threads(cores)
-    cfg = O.default_cfg(batch=x_cpu.shape[0])
+    ocfg = O.default_cfg(image_shape=(cfg["image"], cfg["image"], 3), hidden_channels=cfg["hidden"], K=cfg["K"], L=cfg["L"],
+                         batch=x_cpu.shape[0])
     sd = {k: v.detach().cpu() for k, v in glow.state_dict().items()}
     noise = torch.rand_like(x_cpu) / 256
+    times = []
     with torch.no_grad():
         t0 = time.perf_counter()
-        O.glow_forward(x_cpu, noise, sd, cfg)  # warm-up (oneDNN primitive creation)
+        O.glow_forward(x_cpu, noise, sd, ocfg)  # warm-up (oneDNN primitive creation)
         warm = time.perf_counter() - t0
-        iters, t0 = 0, time.perf_counter()
-        while warm < 60.0:  # if even the warm-up was pathological, report it instead of burning minutes
-            O.glow_forward(x_cpu, noise, sd, cfg)
-            iters += 1
-            el = time.perf_counter() - t0
-            if el >= budget_s or iters >= 8:
-                break
-        if iters == 0:
-            iters, el = 1, warm
-    return {"value": round(iters * x_cpu.shape[0] / el, 3), "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": f"{iters} x forward of batch {x_cpu.shape[0]} (same model/weights, fp32, torch CPU threads={cores}; "
-                      f"warm-up {warm:.1f}s excluded)"}
+        spent = warm
+        while len(times) < 3 and (not times or spent + times[-1] <= budget_s):
+            t0 = time.perf_counter()
+            O.glow_forward(x_cpu, noise, sd, ocfg)
+            times.append(time.perf_counter() - t0)
+            spent += times[-1]
+    med = sorted(times)[len(times) // 2]
+    return {"value": round(x_cpu.shape[0] / med, 3), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"median of {len(times)} forwards of batch {x_cpu.shape[0]} after one warm-up ({warm:.1f}s, excluded); same "
+                      f"model/weights as the GPU run, fp32, torch CPU threads={cores}; oracle/glow_oracle.py"}
+
+
+# ------------------------------------------------------------------------------------------------ rank launcher
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(n):
+    """Start one child per GPU (this process never touches a GPU), wait for all, return the worst exit code."""
+    port = os.environ.get("MASTER_PORT") or str(free_port())
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=port,
+                   GLOWHIP_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    pending = dict(enumerate(procs))
+    while pending:
+        for r, p in list(pending.items()):
+            code = p.poll()
+            if code is None:
+                continue
+            del pending[r]
+            if code != 0:
+                rc = rc or code
+                print(f"bench.py: rank {r} exited with code {code}; stopping the other ranks", file=sys.stderr, flush=True)
+                for q in pending.values():   # exact PIDs of our own children
+                    q.terminate()
+        time.sleep(0.05)
+    return rc
 
 
 def main():
@@ -111,7 +164,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="images per GPU (default: BASELINE config B)")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="B", help="BASELINE.json workload: B = configs[1] (headline), "
+                    "D = configs[3] (128x128 L=4 K=48), E = configs[4] (256x256 L=6 K=32)")
+    ap.add_argument("--batch", type=int, default=0, help="images per GPU (default: the config's: 64 / 32 / 16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-repack", action="store_true", help="inference mode: keep derived parameter data across steps")
     ap.add_argument("--mode", choices=["forward", "inverse", "train"], default="forward",
@@ -119,16 +174,26 @@ def main():
                          "train = full training step (fwd with tape + HIP backward + RCCL gradient all-reduce + clip + Adam)")
     args = ap.parse_args()
 
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and ("RANK" not in os.environ or env_world == 1):
+        # not under a launcher: become the launcher.  Nothing in this process has touched a GPU (torch is not even imported).
+        sys.exit(spawn_ranks(args.gpus))
+    assert env_world == args.gpus, f"--gpus {args.gpus} but the launcher set WORLD_SIZE={env_world}"
+
+    import torch
+    import torch.distributed as dist
+
     rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = env_world
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a GPU"
+    assert torch.cuda.device_count() > local_rank, f"rank {rank}: no GPU {local_rank} (device_count={torch.cuda.device_count()})"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)
+        assert dist.get_world_size() == args.gpus, f"{dist.get_world_size()} ranks joined, --gpus {args.gpus}"
 
     import pytorch_glow_amd as G
     from pytorch_glow_amd.misc import util
@@ -137,9 +202,10 @@ def main():
     dbg = int(os.environ.get("GLOWHIP_DEBUG_FLAGS", "0"), 0)   # kernel-variant A/B runs (scripts/ab_flags.sh); 0 = product default
     if dbg:
         G.lib().glowhip_debug_force_tail_tile(dbg)
-    B = args.batch
-    glow, hps = build_model(G, util, device, B)
-    x = torch.rand(B, 3, 64, 64, generator=torch.Generator().manual_seed(2384 + rank)).to(device)
+    cfg = CONFIGS[args.config]
+    B = args.batch or cfg["batch"]
+    glow, hps = build_model(G, util, device, cfg, B)
+    x = torch.rand(B, 3, cfg["image"], cfg["image"], generator=torch.Generator().manual_seed(2384 + rank)).to(device)
 
     # data-dependent ActNorm init on rank 0's first batch, then broadcast (reference trainer.py:112-115)
     glow.train()
@@ -149,7 +215,7 @@ def main():
     repack = not args.no_repack
 
     if args.mode == "inverse":
-        z_top = torch.randn(B, 48, 8, 8, device=device) * 0.7
+        z_top = torch.randn((B,) + tuple(plan.out_chw), device=device) * 0.7
 
     if args.mode == "train":
         from pytorch_glow_amd import training
@@ -176,11 +242,17 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
+    # per-step stamps: events on torch's current stream = the stream every kernel of the step is launched on; no host sync
+    # inside the timed region
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         loss = step()
+        marks[i + 1].record()
     sync()
     dt = time.perf_counter() - t0
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -190,20 +262,25 @@ def main():
 
     if rank == 0:
         fpi = flop_per_image(glow)
+        what = {"forward": "fwd+logdet", "inverse": "inverse (reverse_flow sampling)",
+                "train": "training step (fwd+bwd+allreduce+clip+Adam)"}[args.mode]
+        if args.mode == "forward" and args.config == "B":
+            metric = HEADLINE_METRIC
+        else:
+            metric = f"images/sec Glow {what}, {cfg['image']}x{cfg['image']}x3 L={cfg['L']} K={cfg['K']} [secondary metric]"
         out = {
-            "metric": "images/sec full Glow fwd+logdet, 64x64x3 L=3 K=32, 1/2/4/8 GPU" if args.mode == "forward"
-                      else "images/sec Glow inverse (reverse_flow sampling), 64x64x3 L=3 K=32 [secondary metric]"
-                      if args.mode == "inverse" else
-                      "images/sec Glow training step (fwd+bwd+allreduce+clip+Adam), 64x64x3 L=3 K=32 [secondary metric]",
+            "metric": metric,
             "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "arithmetic": "fp32 values carried as 2 x f16 (hi, lo*2^11), exact f16 products, fp32 accumulate (csrc/sh.h); "
+            "ms_per_step_min": round(per_step[0], 4), "ms_per_step_median": round(per_step[len(per_step) // 2], 4),
+            "ms_per_step_max": round(per_step[-1], 4),
+            "rccl_world_size": dist.get_world_size() if world > 1 else 1,
+            "arithmetic": "fp32 values carried as 2 x f16 (hi, lo), exact f16 products, fp32 accumulate (csrc/sh.h); "
                           "max-abs vs CPU reference 7e-6 (z), same as the exact-fp32 kernels",
-            "config": {"workload": "CelebA 64x64x3 Glow L=3 K=32 hidden=512 affine+invconv, fwd+logdet, "
-                                   f"batch {B}/GPU (BASELINE configs[1])", "global_batch": world * B,
+            "config": {"workload": f"{cfg['label']}, {what}, batch {B}/GPU ({cfg['ref']})", "global_batch": world * B,
                        "parallelism": f"dp{world}", "repack_every_step": repack,
-                       "loss_mean_nll_bits_per_dim": round(float(loss) / (world * B), 6)},
+                       "loss_mean_nll_bits_per_dim": round(float(loss) / (world * B), 6) if args.mode != "inverse" else None},
             "model_tflops": round(value * fpi / 1e12, 2),
             "frac_of_fp32_mfma_peak_whole_model": round(value / world * fpi / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4),
             "frac_of_split_f16_peak_whole_model": round(value / world * fpi / (PEAK_SPLIT_TFLOPS * 1e12), 4),
@@ -227,15 +304,15 @@ def main():
         plan.timing(False)
         hid = hps.model.hidden_channels
         kinds = {0: "chanmix", 1: "conv_f0_3x3", 2: "conv_f2_1x1", 3: "conv_f4_3x3_tail"}
-        desc = plan.describe()
+        desc = plan.describe(B)
         sh_path = "f2=mfma-sh" in desc
-        fused = {int(l.split()[0]) for l in desc.splitlines() if "-sh-fused" in l}   # layers whose f.0 + f.2 run as k_f02_sh
+        fused = {int(l.split()[0]) for l in desc.splitlines() if "-sh-fused" in l}   # layers whose f.0 + f.2 run as k_f02_sh at this N
         bd = {}
         dom_ms, dom_flop, dom_bytes, dom_n = 0.0, 0.0, 0.0, 0
         for kind, layer, mfma, ms in recs:
             d = plan._descs[layer]
             key = f"{kinds.get(kind, 'other')}_C{d.C}_{d.H}x{d.W}"
-            if kind == 2 and layer in fused and B * d.H * d.W // 64 >= 192:
+            if kind == 2 and layer in fused:
                 key = f"conv_f0+f2_fused_C{d.C}_{d.H}x{d.W}"
             bd.setdefault(key, [0.0, 0])
             bd[key][0] += ms
@@ -255,24 +332,27 @@ def main():
                 dom_bytes += 2.0 * 4.0 * hid * total_px
                 dom_n += 1
         achieved = dom_flop / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
-        traffic = None
+        traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get("k_f02_sh_hbm_bytes_per_launch" if sh_path else "k_gemm_glds_hbm_bytes_per_launch")
+        if os.path.exists(tpath) and args.config == "B" and B == 64 and args.mode == "forward":
+            tj = json.load(open(tpath))
+            traffic = tj.get("k_f02_sh_hbm_bytes_per_launch" if sh_path else "k_gemm_glds_hbm_bytes_per_launch")
+            traffic_src = {"file": "profiles/pmc_traffic.json", "collected_at_commit": tj.get("commit"),
+                           "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (scripts/prof_pmc.sh), not re-measured by this run"}
         peak = PEAK_SPLIT_TFLOPS if sh_path else PEAK_FP32_MFMA_TFLOPS
         out["roofline"] = {"bound": "mfma",
                            "kernel": ("k_f02_sh (f.0 3x3 conv C/2->512 + f.2 1x1 conv 512->512, both with ActNorm + ReLU, fused; "
                                       "fp32-accurate products as 3 f16 MFMAs, peak = 2500/3 TFLOP/s algorithmic)") if sh_path else
                                      "k_gemm_glds (f.2: 1x1 conv 512->512 + ActNorm + ReLU, fp32-input MFMA, 128x128 tiles)",
                            "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                           "frac": round(achieved / peak, 4), "traffic": traffic,
+                           "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                            "launches": dom_n, "avg_launch_us": round(1e3 * dom_ms / max(dom_n, 1), 2),
                            "flop_per_launch_avg": dom_flop / max(dom_n, 1),
                            "issued_mfma_tflops": round(achieved * (3 if sh_path else 1), 1),
                            "algorithmic_hbm_bytes_per_launch_avg": dom_bytes / max(dom_n, 1),
                            "hbm_GBps": round(dom_bytes / (dom_ms * 1e-3) / 1e9, 1) if dom_ms > 0 else 0.0,
                            "hbm_frac_of_8TBps": round(dom_bytes / (dom_ms * 1e-3) / 8e12, 4) if dom_ms > 0 else 0.0}
-        if args.mode == "forward" and sh_path:
+        if args.mode == "forward" and sh_path and args.config == "B":
             # the same step on the exact-fp32 MFMA kernels (split-half path switched off), for the record; rank-local
             G.lib().glowhip_debug_force_tail_tile(0x800)
             try:
@@ -290,8 +370,9 @@ def main():
                                               "note": "one GPU, same step with v_mfma_f32_32x32x2_f32 kernels only"}
         out["breakdown_ms_per_step"] = {k: round(v[0] / 3, 4) for k, v in sorted(bd.items())}
         out["breakdown_sum_ms"] = round(sum(v[0] for v in bd.values()) / 3, 3)
+        out["kernel_launches_per_step"] = plan.launch_counts(reset=True) if hasattr(plan, "launch_counts") else None
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(glow, x[:4].cpu())
+            out["cpu_baseline"] = cpu_baseline(glow, x[:min(B, cfg["cpu_sample"])].cpu(), cfg)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -247,6 +247,12 @@ void glowhip_debug_force_tail_tile(int pixels_and_flags);
 /* Introspection for tests / benchmarks: which kernels a plan will launch ("mfma" or "direct" per
  * convolution).  Writes a NUL-terminated description into buf. */
 int glowhip_plan_describe(const glowhip_plan* plan, char* buf, size_t buf_bytes);
+/* The same for a given batch size N: kernel choices that depend on how many workgroups a launch would have (the fused
+ * f.0 + f.2 kernel runs only when N*H*W/64 workgroups cover the chip) are resolved as encode/decode would resolve them. */
+int glowhip_plan_describe_for(const glowhip_plan* plan, int N, char* buf, size_t buf_bytes);
+/* Run-time evidence of kernel selection: "kernel_family=launches\n" lines for every kernel family this plan has launched
+ * (coupling path of encode / decode / glow_forward) since creation or the last reset.  HOST bookkeeping, counted at launch. */
+int glowhip_plan_launch_counts(glowhip_plan* plan, char* buf, size_t buf_bytes, int reset);
 
 #ifdef __cplusplus
 }

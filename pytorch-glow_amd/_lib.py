@@ -82,6 +82,8 @@ SIGNATURES = {
     "glowhip_plan_actnorm_init": (c_int, [_P, _P, c_size_t, _P, _P, c_float, c_int, _P, c_size_t, _P]),
     "glowhip_plan_output_shape": (c_int, [_P, c_int, POINTER(c_int32)]),
     "glowhip_plan_describe": (c_int, [_P, c_char_p, c_size_t]),
+    "glowhip_plan_describe_for": (c_int, [_P, c_int, c_char_p, c_size_t]),
+    "glowhip_plan_launch_counts": (c_int, [_P, c_char_p, c_size_t, c_int]),
     "glowhip_debug_force_tail_tile": (None, [c_int]),
     "glowhip_plan_tape_bytes": (c_size_t, [_P, c_int]),
     "glowhip_plan_train_workspace_bytes": (c_size_t, [_P, c_int]),

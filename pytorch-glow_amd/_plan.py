@@ -146,10 +146,18 @@ class FlowPlan:
         check(lib().glowhip_plan_timing_read(self._h, buf, max_records, ctypes.byref(n)))
         return [(buf[i].kind, buf[i].layer, buf[i].mfma, buf[i].ms) for i in range(n.value)]
 
-    def describe(self) -> str:
+    def describe(self, n: int = 0) -> str:
+        """Kernel selection per layer; with a batch size ``n`` the choices that depend on the grid size are resolved as a
+        call with that batch resolves them (n = 0: what the shapes support)."""
         buf = ctypes.create_string_buffer(1 << 16)
-        check(lib().glowhip_plan_describe(self._h, buf, len(buf)))
+        check(lib().glowhip_plan_describe_for(self._h, int(n), buf, len(buf)))
         return buf.value.decode()
+
+    def launch_counts(self, reset: bool = False) -> dict:
+        """{kernel family: launches} recorded by the C executor as it launched them (run-time evidence, not a prediction)."""
+        buf = ctypes.create_string_buffer(1 << 14)
+        check(lib().glowhip_plan_launch_counts(self._h, buf, len(buf), int(reset)))
+        return {k: int(v) for k, v in (line.split("=") for line in buf.value.decode().splitlines() if line)}
 
     def encode(self, x, noise=None, logdet=None, want_logdet=True, repack=False):
         n = x.shape[0]

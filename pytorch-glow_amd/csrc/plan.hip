@@ -89,6 +89,10 @@ void plan_disable_sh(int off) {
 // Mixer of the NEXT step for tail_sh.hip to apply (forward only); C = 0: none
 struct NextMix { int C; float* out; long out_bs; const float* bias; const float* scale; const float* matrix; const int32_t* gather; };
 
+// fused f.0 + f.2 only when its one-workgroup-per-64-pixels grid still covers most of the chip (measured: with 64
+// workgroups at the 8x8 level of a 64-image batch the two separate kernels are faster).  N = 0: batch unknown (plan time)
+static bool f02_runs_at(int N, int HW) { return N <= 0 || (long)N * HW / 64 >= 192; }
+
 static bool tail_runs_sh(const LayerPlan& L) { return L.sh_mid && L.sh_tail && !g_sh_disabled && !g_sh_tail_disabled; }
 
 static int run_coupling(glowhip_plan* P, const LayerPlan& L, const void* packed, const float* x1, long x1_bs, const float* z2_in,
@@ -98,11 +102,10 @@ static int run_coupling(glowhip_plan* P, const LayerPlan& L, const void* packed,
     const int Ch = d.C / 2, HW = d.H * d.W, hid = d.hidden;
     const bool use_sh = L.sh_mid && !g_sh_disabled;
     const bool use_sh_tail = use_sh && L.sh_tail && !g_sh_tail_disabled;
-    // fused f.0 + f.2 only when its one-workgroup-per-64-pixels grid still covers most of the chip (measured: with 64
-    // workgroups at the 8x8 level of a 64-image batch the two separate kernels are faster)
-    const bool use_f02 = use_sh_tail && L.sh_f02 && !g_sh_f02_disabled && (long)N * HW / 64 >= 192;
+    const bool use_f02 = use_sh_tail && L.sh_f02 && !g_sh_f02_disabled && f02_runs_at(N, HW);
     if (use_f02) {   // f.0 + f.2 fused: h1 stays in LDS (f02_sh.hip)
         ScopedTimer t2(P, GLOWHIP_K_CONV_F2, 1, s);
+        count_launch(P, "k_f02_sh");
         GH_TRY(launch_f02_sh(x1, x1_bs, at<char>(packed, L.f0_sh), at<char>(packed, L.f2_sh), (_Float16*)w.h2, N, Ch, d.H, d.W,
                              hid, s));
     }
@@ -110,17 +113,21 @@ static int run_coupling(glowhip_plan* P, const LayerPlan& L, const void* packed,
     if (!use_f02) {
     ScopedTimer t0(P, GLOWHIP_K_CONV_F0, L.mfma_first || L.first_halo, s);
     if (use_sh && L.sh_first && !g_sh_first_disabled) {
+        count_launch(P, "k_first_sh");
         GH_TRY(launch_first_sh(x1, x1_bs, at<char>(packed, L.f0_sh), (_Float16*)w.h1, N, Ch, d.H, d.W, hid, 1, s));
     } else if (L.first_halo) {
         const float* wf = at<float>(packed, L.f0_wt);
+        count_launch(P, "k_conv_first_f32");
         GH_TRY(launch_conv_mfma_first(x1, x1_bs, wf, wf + (size_t)9 * Ch * hid, use_sh ? nullptr : w.h1, N, Ch, d.H, d.W, hid,
                                       s, 1, use_sh ? (_Float16*)w.h1 : nullptr));
     } else if (L.mfma_first) {
+        count_launch(P, "k_conv_wide_f32");
         GH_TRY(launch_conv_mfma_wide(x1, x1_bs, at<float>(packed, L.f0_wt), d.f0_an_bias, at<float>(packed, L.f0_scale),
                                      w.h1, N, Ch, d.H, d.W, hid, 3, s));
     } else {
         ConvArgs c{x1, x1_bs, d.f0_w, nullptr, d.f0_an_bias, nullptr, at<float>(packed, L.f0_scale), 1, w.h1,
                    N, Ch, d.H, d.W, hid, 3};
+        count_launch(P, "k_conv_direct");
         GH_TRY(launch_conv_direct(c, s));
     }
     }
@@ -128,14 +135,17 @@ static int run_coupling(glowhip_plan* P, const LayerPlan& L, const void* packed,
     if (!use_f02) {
     ScopedTimer t2(P, GLOWHIP_K_CONV_F2, L.mfma_mid, s);
     if (use_sh) {
+        count_launch(P, "k_gemm_sh");
         GH_TRY(launch_gemm_sh((const _Float16*)w.h1, at<char>(packed, L.f2_sh), use_sh_tail ? nullptr : w.h2,
                               use_sh_tail ? (_Float16*)w.h2 : nullptr, N, hid, HW, hid, 1, s));
     } else if (L.mfma_mid) {
+        count_launch(P, "k_gemm_f32");
         GH_TRY(launch_conv_mfma_wide(w.h1, (long)hid * HW, at<float>(packed, L.f2_wt), d.f2_an_bias,
                                      at<float>(packed, L.f2_scale), w.h2, N, hid, d.H, d.W, hid, 1, s));
     } else {
         ConvArgs c{w.h1, (long)hid * HW, d.f2_w, nullptr, d.f2_an_bias, nullptr, at<float>(packed, L.f2_scale), 1, w.h2,
                    N, hid, d.H, d.W, hid, 1};
+        count_launch(P, "k_conv_direct");
         GH_TRY(launch_conv_direct(c, s));
     }
     }
@@ -154,6 +164,7 @@ static int run_coupling(glowhip_plan* P, const LayerPlan& L, const void* packed,
             t.mix_C = mix->C; t.mix_z1 = x1; t.mix_z1_bs = x1_bs; t.mix_out = mix->out; t.mix_out_bs = mix->out_bs;
             t.mix_bias = mix->bias; t.mix_scale = mix->scale; t.mix_matrix = mix->matrix; t.mix_gather = mix->gather;
         }
+        count_launch(P, t.mix_C ? "k_tail_sh+mixer" : "k_tail_sh");
         GH_TRY(launch_tail_sh(t, s));
     } else if (L.mfma_last) {
         TailConvArgs t{};
@@ -164,10 +175,12 @@ static int run_coupling(glowhip_plan* P, const LayerPlan& L, const void* packed,
                                                        : (reverse ? TAIL_ADD_REV : TAIL_ADD_FWD);
         t.z2_in = z2_in; t.z2_in_bs = z2_in_bs; t.z2_out = z2_out; t.z2_out_bs = z2_out_bs; t.acc = w.acc;
         t.zeros = at<float>(packed, 64);   // zero block kept by glowhip_plan_pack
+        count_launch(P, "k_conv_tail_f32");
         GH_TRY(launch_conv_mfma_tail(t, s));
     } else {
         ConvArgs c{w.h2, (long)hid * HW, d.f4_w, d.f4_bias, nullptr, nullptr, at<float>(packed, L.f4_scale), 0, w.h1,
                    N, hid, d.H, d.W, L.Cout, 3};
+        count_launch(P, "k_conv_direct");
         GH_TRY(launch_conv_direct(c, s));
         CouplingTailArgs t{w.h1, z2_in, z2_in_bs, z2_out, z2_out_bs, N, Ch, HW,
                            d.coupling == GLOWHIP_COUPLING_AFFINE, reverse, w.acc};
@@ -241,6 +254,7 @@ static int run_forward(glowhip_plan* p, const void* packed, const float* x, cons
                     m.gather = d.permutation == GLOWHIP_PERM_GATHER ? d.perm_idx : nullptr;
                     m.reverse = 0; m.N = N; m.C = d.C; m.HW = HW;
                     ScopedTimer tm(p, GLOWHIP_K_CHANMIX, 0, s);
+                    count_launch(p, "k_chanmix");
                     GH_TRY(launch_chanmix(m, s));
                 }
                 // Let this step's tail apply the NEXT step's channel mixer (one launch less per step) when the next layer is
@@ -297,6 +311,7 @@ static int run_reverse(glowhip_plan* p, const void* packed, const float* z, cons
             m.gather = d.permutation == GLOWHIP_PERM_GATHER ? d.perm_idx_inv : nullptr;
             m.reverse = 1; m.N = N; m.C = d.C; m.HW = HW;
             ScopedTimer tm(p, GLOWHIP_K_CHANMIX, 0, s);
+            count_launch(p, "k_chanmix");
             GH_TRY(launch_chanmix(m, s));
         } else {  // SPLIT2D reverse: z1 = cur (N, C/2, HW) -> cat(z1, mean + exp(logs)*eps)
             GH_REQUIRE(ke < n_eps && eps && eps[ke], "decode: missing eps draw for Split2d #%d", ke);
@@ -527,6 +542,20 @@ int glowhip_plan_output_shape(const glowhip_plan* plan, int reverse, int32_t out
 }
 
 int glowhip_plan_describe(const glowhip_plan* plan, char* buf, size_t buf_bytes) {
+    return glowhip_plan_describe_for(plan, 0, buf, buf_bytes);
+}
+
+int glowhip_plan_launch_counts(glowhip_plan* plan, char* buf, size_t buf_bytes, int reset) {
+    GH_REQUIRE(plan && buf && buf_bytes > 0, "plan_launch_counts: null argument");
+    std::string out;
+    for (const auto& kv : plan->launch_counts) out += kv.first + "=" + std::to_string(kv.second) + "\n";
+    GH_REQUIRE(out.size() < buf_bytes, "plan_launch_counts: buffer too small");
+    snprintf(buf, buf_bytes, "%s", out.c_str());
+    if (reset) plan->launch_counts.clear();
+    return GLOWHIP_OK;
+}
+
+int glowhip_plan_describe_for(const glowhip_plan* plan, int N, char* buf, size_t buf_bytes) {
     GH_REQUIRE(plan && buf && buf_bytes > 0, "plan_describe: null argument");
     std::string sdesc;
     char line[256];
@@ -541,7 +570,7 @@ int glowhip_plan_describe(const glowhip_plan* plan, char* buf, size_t buf_bytes)
             const bool sh = L.sh_mid && !g_sh_disabled;
             snprintf(line, sizeof line, "%d flowstep C=%d H=%d W=%d hidden=%d f0=%s%s f2=%s%s f4=%s%s\n", li, d.C, d.H, d.W,
                      d.hidden, L.first_halo ? "mfma-halo" : (L.mfma_first ? "mfma" : "direct"),
-                     sh && L.sh_first && !g_sh_first_disabled ? (L.sh_f02 && L.sh_tail && !g_sh_tail_disabled && !g_sh_f02_disabled ? "-sh-fused" : "-sh") : "",
+                     sh && L.sh_first && !g_sh_first_disabled ? (L.sh_f02 && L.sh_tail && !g_sh_tail_disabled && !g_sh_f02_disabled && f02_runs_at(N, d.H * d.W) ? "-sh-fused" : "-sh") : "",
                      L.mfma_mid ? "mfma" : "direct", sh ? "-sh" : "",
                      L.mfma_last ? "mfma" : "direct", sh && L.sh_tail && !g_sh_tail_disabled ? "-sh" : "");
         }

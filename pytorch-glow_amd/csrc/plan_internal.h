@@ -1,6 +1,7 @@
 // plan_internal.h -- plan data structures shared by plan.hip (inference executor) and plan_train.hip
 // (training forward with a tape + backward executor).
 #pragma once
+#include <map>
 #include <string>
 #include <vector>
 
@@ -55,9 +56,12 @@ struct glowhip_plan {
     long max_hidden = 0;   // max over steps of max(hidden, Cout) * H*W
     int n_split = 0;
     std::vector<glowhip::GradJob> grad_jobs;   // host copy of the last backward's finalize table (kept alive for the async copy)
+    std::map<std::string, long> launch_counts; // run-time record of which kernel families this plan launched (glowhip_plan_launch_counts)
 };
 
 namespace glowhip {
+
+static inline void count_launch(glowhip_plan* p, const char* name) { if (p) ++p->launch_counts[name]; }
 
 static inline size_t take(size_t& off, size_t bytes) {
     size_t o = align_up(off, 256);

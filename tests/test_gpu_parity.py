@@ -555,12 +555,13 @@ def test_deep_multiscale_configs_vs_oracle(name, image, L, K, hidden, batch):
 @pytest.mark.parametrize("coup,perm", [("affine", "invconv"), ("additive", "reverse"), ("affine", "shuffle"),
                                        ("additive", "invconv")])
 def test_split_half_stack_every_coupling_and_permutation(coup, perm):
-    """A 3-level stack (32^2, 16^2, 8^2 pixels; hidden 128; odd batch) whose FlowSteps all take the split-half kernels: the
-    fused f.0+f.2 kernel, the taps-as-rows tail with both coupling kinds, and the tail applying the NEXT step's channel
+    """A 3-level stack (32^2, 16^2, 8^2 pixels; hidden 128; batch 12) whose FlowSteps all take the split-half kernels: the
+    fused f.0+f.2 kernel at level 1 (192 workgroups at this batch -- asserted from the executor's launch counters), the
+    separate f.0 / f.2 pair below it, the taps-as-rows tail with both coupling kinds, and the tail applying the NEXT step's channel
     mixer -- as a matrix (invconv) and as a gather (reverse / shuffle).  Checked against the oracle, forward and inverse,
     and against the same run with the mixer fusion switched off: the fused mixer keeps k_chanmix's operation order, so the
     two must agree bit for bit."""
-    batch = 3
+    batch = 12
     cfg = O.default_cfg(image_shape=(64, 64, 3), hidden_channels=128, K=3, L=3, flow_permutation=perm, flow_coupling=coup,
                         batch=batch)
     sd = O.seeded_state_dict(cfg, seed=21, zeros_std=0.02, invconv_perturb=0.02)
@@ -574,10 +575,15 @@ def test_split_half_stack_every_coupling_and_permutation(coup, perm):
     noise = torch.rand(batch, 3, 64, 64, generator=torch.Generator().manual_seed(5)) / 256
     with torch.no_grad():
         z_ref, nll_ref, _ = O.glow_forward(x, noise, sd, cfg, perm_tables=tables)
-    desc = glow.flow.plan_for(dev(x)).describe()
+    plan = glow.flow.plan_for(dev(x))
+    desc = plan.describe(batch)
     steps = [l for l in desc.splitlines() if "flowstep" in l]
-    assert all("f2=mfma-sh" in l and "f4=mfma-sh" in l and "-sh-fused" in l for l in steps), desc
+    assert all("f2=mfma-sh" in l and "f4=mfma-sh" in l for l in steps), desc
+    plan.launch_counts(reset=True)
     z, nll, _ = glow.normal_flow(dev(x), None, noise=dev(noise))
+    counts = plan.launch_counts(reset=True)
+    assert counts.get("k_f02_sh", 0) == 3 and counts.get("k_gemm_sh", 0) == 6, counts     # level 1 fused, levels 2-3 separate
+    assert counts.get("k_tail_sh+mixer", 0) >= 4 and counts.get("k_conv_direct", 0) == 0, counts
     close(z, z_ref, 1e-4, what="z"); close(nll, nll_ref, 1e-4, what="nll")
     G.lib().glowhip_debug_force_tail_tile(0x8000)      # the same without the mixer fused into the tails
     try:
