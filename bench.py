@@ -159,6 +159,44 @@ def spawn_ranks(n):
     return rc
 
 
+def dry_run_cpu(args, rank, world):
+    """The N-rank protocol of the real run -- rendezvous, warm-up, barrier, K timed steps, barrier, MAX over ranks, one JSON line
+    on rank 0 -- with empty steps on a gloo group.  Measures nothing; proves the launcher and the collective sequence."""
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+        assert dist.get_world_size() == args.gpus
+    def step():
+        s = torch.ones(()) * (rank + 1)
+        if world > 1:
+            dist.all_reduce(s)
+        return s
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        print(json.dumps({"metric": "dry run (no GPU work)", "dry_run": True, "value": 0.0, "unit": "images/sec", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / max(args.steps, 1), 4),
+                          "rccl_world_size": dist.get_world_size() if world > 1 else 1,
+                          "allreduce_check": float(loss), "scaling": "weak"}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -172,6 +210,8 @@ def main():
     ap.add_argument("--mode", choices=["forward", "inverse", "train"], default="forward",
                     help="forward = the headline metric (Glow.normal_flow); inverse = Glow.reverse_flow sampling throughput; "
                          "train = full training step (fwd with tape + HIP backward + RCCL gradient all-reduce + clip + Adam)")
+    ap.add_argument("--dry-run-cpu", action="store_true", help="launcher / rendezvous / timing-protocol check without a GPU: the "
+                    "ranks join a gloo group and time empty steps (tests/test_host.py); prints a line marked dry_run")
     args = ap.parse_args()
 
     env_world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -186,6 +226,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = env_world
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.dry_run_cpu:
+        return dry_run_cpu(args, rank, world)
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     assert torch.cuda.device_count() > local_rank, f"rank {rank}: no GPU {local_rank} (device_count={torch.cuda.device_count()})"
     torch.cuda.set_device(local_rank)

@@ -181,3 +181,27 @@ def test_world2_attribute_delta_equals_single_process():
     want = O.attribute_delta(zs, ys.numpy(), batch_size=2)
     for r in (0, 1):
         assert np.abs(ret[r] - want).max() < 1e-6
+
+
+def test_bench_launches_its_own_ranks_dry_run():
+    """`python bench.py --gpus 2` with no launcher around it spawns its two ranks itself (before touching any GPU), the ranks
+    rendezvous on 127.0.0.1, run the timed-loop protocol (warm-up, barrier, K steps, barrier, MAX over ranks) and rank 0
+    prints ONE JSON line carrying n_gpus = 2 and the observed world size.  --dry-run-cpu swaps RCCL for gloo and the step
+    for an empty one, so the launcher and the collective sequence are exercised where there is no GPU."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run-cpu", "--steps", "3",
+                          "--warmup", "1"], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["rccl_world_size"] == 2 and rec["steps"] == 3 and rec["warmup"] == 1
+    assert rec["allreduce_check"] == 3.0     # 1 + 2: both ranks took part in the step's collective
+    # a failing rank takes the job down with a non-zero exit code instead of hanging the others
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=300, env=dict(env, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES=""))
+    assert bad.returncode != 0

@@ -22,15 +22,21 @@ def _case(image, L, K, hidden, batch, seed=5, coup="affine", perm="invconv"):
     g = torch.Generator().manual_seed(seed)
     x = torch.rand(batch, 3, image, image, generator=g)
     noise = torch.rand(batch, 3, image, image, generator=g) / 256
-    sd = O.glow_init_actnorm(x, noise, sd, cfg)
-    z_ref, nll_ref, _ = O.glow_forward(x, noise, sd, cfg)
+    if perm == "invconv":
+        sd = O.glow_init_actnorm(x, noise, sd, cfg)      # (the oracle restates the init pass for invconv models)
+    np.random.seed(seed)
     glow = make_glow(cfg, sd, batch)
+    tables = None
+    if perm != "invconv":
+        tables = {i: (torch.from_numpy(getattr(l, perm).indices), torch.from_numpy(getattr(l, perm).indices_inverse))
+                  for i, l in enumerate(glow.flow.layers) if hasattr(l, perm)}
+    z_ref, nll_ref, _ = O.glow_forward(x, noise, sd, cfg, perm_tables=tables)
     plan = glow.flow.plan_for(dev(x))
     plan.launch_counts(reset=True)
     z, nll, _ = glow.normal_flow(dev(x), None, noise=dev(noise))
     fwd = plan.launch_counts(reset=True)
     eps = [torch.randn(batch, *s, generator=g) * 0.7 for s in glow.flow.split_shapes((3, image, image))]
-    x_ref = O.glow_reverse(z_ref, sd, cfg, eps)
+    x_ref = O.glow_reverse(z_ref, sd, cfg, eps, perm_tables=tables)
     xr = glow.reverse_flow(dev(z_ref), None, eps=[dev(e) for e in eps])
     rev = plan.launch_counts(reset=True)
     ez = close(z, z_ref, 1e-4, what="z"); en = close(nll, nll_ref, 1e-4, what="nll"); ex = close(xr, x_ref, 1e-4, what="decode")
