@@ -224,7 +224,8 @@ int glowhip_glow_backward(glowhip_plan* plan, const void* packed, const float* x
  * the coupling path).  enable=1 creates an event pool (host resource), enable=0 destroys it; while enabled
  * every encode/decode appends records.  glowhip_plan_timing_read synchronises with the recorded events,
  * copies up to `max` records (launch order) and clears the list. */
-enum { GLOWHIP_K_CHANMIX = 0, GLOWHIP_K_CONV_F0 = 1, GLOWHIP_K_CONV_F2 = 2, GLOWHIP_K_CONV_F4 = 3, GLOWHIP_K_OTHER = 4 };
+enum { GLOWHIP_K_CHANMIX = 0, GLOWHIP_K_CONV_F0 = 1, GLOWHIP_K_CONV_F2 = 2, GLOWHIP_K_CONV_F4 = 3, GLOWHIP_K_OTHER = 4,
+       GLOWHIP_K_CNET = 5 /* whole coupling network + finishing kernel */ };
 typedef struct glowhip_timing_record {
     int32_t kind;   /* GLOWHIP_K_* */
     int32_t layer;  /* index into the plan's layer list */
@@ -240,7 +241,9 @@ int glowhip_plan_timing_read(glowhip_plan* plan, glowhip_timing_record* out, int
  * Kernel-family switches (A/B runs, and the parity tests of the exact-fp32 kernels): | 0x800 = exact-fp32 MFMA kernels only
  * (split-half f16 path off), | 0x1000 = fp32 tail behind the split-half GEMM, | 0x2000 = fp32-MFMA f.0 writing the
  * split-half tensor, | 0x4000 = f.0 and f.2 as separate kernels, | 0x8000 = k_chanmix instead of the mixer fused into the
- * previous tail; bits 16..19 = 4 or 8: only that wave count of the split-half tail.  0 restores automatic selection.
+ * previous tail; bits 16..19 = 4 or 8: only that wave count of the split-half tail; | 0x100000 = the one-kernel coupling
+ * network (cnet) off; | 0x200000 = cnet computes f.0 + f.2 only; bits 22..24 = 1, 2 or 4: that many row splits of cnet.
+ * 0 restores automatic selection.
  * Process-wide, not thread safe: a testing hook, not part of the operator surface. */
 void glowhip_debug_force_tail_tile(int pixels_and_flags);
 

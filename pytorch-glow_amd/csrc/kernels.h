@@ -73,7 +73,8 @@ struct StepPrepJob {
 int launch_step_prepare_batched(const StepPrepJob* jobs_dev, int n, int max_lds_c, void* packed, hipStream_t s);
 
 struct ScaleJob { const float* logs; size_t scale_off, inv_off; int n; int has_inv; };
-enum { REPACK_WIDE = 0, REPACK_TAIL = 1, REPACK_FIRST = 2, REPACK_SH_GEMM = 3, REPACK_SH_TAIL = 4, REPACK_SH_FIRST = 5 };
+enum { REPACK_WIDE = 0, REPACK_TAIL = 1, REPACK_FIRST = 2, REPACK_SH_GEMM = 3, REPACK_SH_TAIL = 4, REPACK_SH_FIRST = 5,
+       REPACK_SH2_GEMM = 6, REPACK_SH2_FIRST = 7, REPACK_SH2_TAIL = 8 };   // true-scale split-half images with per-row scales (sh.h SH2)
 struct RepackJob {
     const float* w; size_t out_off; int kind;
     int Cin, Cout, K, Kpad;      // wide: K = Cin*k*k

@@ -24,6 +24,7 @@ __global__ void __launch_bounds__(256) k_pack_scales_batched(const ScaleJob* __r
 // tail: wp[(((chunk*8 + c4)*9 + tap)*MT + mt)*64 + kq*16 + i] = w[o(mt*16+i)][chunk*32 + c4*4 + kq][tap]
 __global__ void __launch_bounds__(256) k_repack_batched(const RepackJob* __restrict__ jobs, char* packed) {
     const RepackJob j = jobs[blockIdx.y];
+    if (j.kind >= REPACK_SH2_GEMM) return;   // k_repack_sh2_batched
     float* out = (float*)(packed + j.out_off);
     if (j.kind == REPACK_WIDE) {
         const long total = (long)j.Kpad * j.Cout;
@@ -121,6 +122,73 @@ __global__ void __launch_bounds__(256) k_repack_batched(const RepackJob* __restr
     }
 }
 
+// SH2 images (sh.h): half [plane][Kp/8][M][8] of w'[r][k] * 2^e[r], then M floats row scale, then M floats bias.  ONE WAVE PER
+// OUTPUT ROW: the row's largest |w'| fixes its exponent e (largest value in [2^12, 2^13)), which needs the whole row first.
+//   SH2_GEMM  (f.2): row o, k = input channel;           w' = w[o][k] exp(3 logs[o]);  rowscale = 2^-e, bias = b' * 16
+//   SH2_FIRST (f.0): row o, k = (tap, chunk, 8 channels); same folding; j.K = G groups
+//   SH2_TAIL  (f.4): row m = tap * Cout + co (< j.Kpad = Mpad4 rows, zero beyond 9 Cout), k = input channel;
+//                    rowscale = 2^-e / 16 (undoes the activation scale as well), no bias
+__global__ void __launch_bounds__(256) k_repack_sh2_batched(const RepackJob* __restrict__ jobs, char* packed) {
+    const RepackJob j = jobs[blockIdx.y];
+    if (j.kind < REPACK_SH2_GEMM) return;
+    const int lane = threadIdx.x & 63;
+    const int M = j.kind == REPACK_SH2_TAIL ? j.Kpad : j.Cout;
+    const int Kp = j.kind == REPACK_SH2_FIRST ? j.K * 8 : j.Cin;
+    const int ngroups = Kp / 8;
+    _Float16* oh = (_Float16*)(packed + j.out_off);
+    float* rowscale = (float*)(packed + j.out_off + (size_t)2 * Kp * M * sizeof(_Float16));
+    float* rbias = rowscale + M;
+    const int nchunk = (j.Cin + 7) / 8;
+    for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < M; r += gridDim.x * 4) {
+        float fold = 1.f;
+        if (j.kind != REPACK_SH2_TAIL && j.fold_logs) fold = expf(j.fold_logs[r] * LOGSCALE);
+        auto value = [&](int k) -> float {
+            if (j.kind == REPACK_SH2_GEMM) return j.w[(long)r * j.Cin + k] * fold;
+            if (j.kind == REPACK_SH2_FIRST) {
+                const int gi = k >> 3, k8 = k & 7;
+                const int tap = gi / nchunk, ci = (gi - tap * nchunk) * 8 + k8;
+                return (gi < 9 * nchunk && ci < j.Cin) ? j.w[((long)r * j.Cin + ci) * 9 + tap] * fold : 0.f;
+            }
+            const int tap = r / j.Cout, co = r - tap * j.Cout;
+            return r < 9 * j.Cout ? j.w[((long)co * j.Cin + k) * 9 + tap] : 0.f;
+        };
+        float mx = 0.f;
+        for (int gi = lane; gi < ngroups; gi += 64)
+#pragma unroll
+            for (int k8 = 0; k8 < 8; ++k8) mx = fmaxf(mx, fabsf(value(gi * 8 + k8)));
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        int e = 0;
+        if (mx > 0.f && mx < 3.0e38f) {
+            int ex;
+            (void)frexpf(mx, &ex);          // mx = f * 2^ex, f in [0.5, 1)
+            e = 13 - ex;                    // mx * 2^e in [2^12, 2^13)
+            e = e > 100 ? 100 : (e < -100 ? -100 : e);
+        }
+        const float up = ldexpf(1.f, e);
+        for (int gi = lane; gi < ngroups; gi += 64) {
+            h8 hi, lo;
+#pragma unroll
+            for (int k8 = 0; k8 < 8; ++k8) {
+                _Float16 a, b;
+                sh2_split(value(gi * 8 + k8) * up, a, b);
+                hi[k8] = a; lo[k8] = b;
+            }
+            *reinterpret_cast<h8*>(oh + ((long)gi * M + r) * 8) = hi;
+            *reinterpret_cast<h8*>(oh + ((long)(ngroups + gi) * M + r) * 8) = lo;
+        }
+        if (lane == 0) {
+            if (j.kind == REPACK_SH2_TAIL) {
+                rowscale[r] = ldexpf(1.f, -e) * SH2_ACT_INV;
+                rbias[r] = 0.f;
+            } else {
+                rowscale[r] = ldexpf(1.f, -e);
+                rbias[r] = (j.fold_bias ? j.fold_bias[r] * fold : 0.f) * SH2_ACT_SCALE;
+            }
+        }
+    }
+}
+
 int launch_pack_batched(const ScaleJob* sj_dev, int n_scale, const RepackJob* rj_dev, int n_repack, void* packed,
                         hipStream_t s) {
     if (n_scale > 0) {
@@ -130,6 +198,8 @@ int launch_pack_batched(const ScaleJob* sj_dev, int n_scale, const RepackJob* rj
     if (n_repack > 0) {
         hipLaunchKernelGGL(k_repack_batched, dim3(64, n_repack), dim3(256), 0, s, rj_dev, (char*)packed);
         GH_LAUNCH_CHECK("k_repack_batched");
+        hipLaunchKernelGGL(k_repack_sh2_batched, dim3(128, n_repack), dim3(256), 0, s, rj_dev, (char*)packed);
+        GH_LAUNCH_CHECK("k_repack_sh2_batched");
     }
     return GLOWHIP_OK;
 }

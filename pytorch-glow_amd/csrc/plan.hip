@@ -79,11 +79,13 @@ static int carve(const glowhip_plan* p, int N, void* ws, size_t bytes, Workspace
 // Runs conv3x3 -> actnorm -> relu -> conv1x1 -> actnorm -> relu -> conv3x3(zeros) and applies the
 // coupling to z2.  x1: first-half channels (batch stride x1_bs).
 static bool g_sh_disabled = false, g_sh_tail_disabled = false, g_sh_first_disabled = false, g_sh_f02_disabled = false,
-            g_sh_mix_disabled = false;
+            g_sh_mix_disabled = false, g_cnet_disabled = false, g_cnet_h2_only = false;
 void plan_disable_sh(int off) {
     g_sh_disabled = (off & 1) != 0; g_sh_tail_disabled = (off & 2) != 0; g_sh_first_disabled = (off & 4) != 0;
     g_sh_f02_disabled = (off & 8) != 0;
     g_sh_mix_disabled = (off & 16) != 0;
+    g_cnet_disabled = (off & 32) != 0;     // the one-kernel coupling network (cnet_sh.hip) off: the round-1 kernel pairs run
+    g_cnet_h2_only = (off & 64) != 0;      // cnet computes f.0 + f.2 only and hands h2 to k_tail_sh (testing)
 }
 
 // Mixer of the NEXT step for tail_sh.hip to apply (forward only); C = 0: none
@@ -94,6 +96,31 @@ struct NextMix { int C; float* out; long out_bs; const float* bias; const float*
 static bool f02_runs_at(int N, int HW) { return N <= 0 || (long)N * HW / 64 >= 192; }
 
 static bool tail_runs_sh(const LayerPlan& L) { return L.sh_mid && L.sh_tail && !g_sh_disabled && !g_sh_tail_disabled; }
+static bool cnet_runs(const LayerPlan& L) { return L.cnet && !g_sh_disabled && !g_cnet_disabled; }
+
+// Channel mixer a coupling kernel applies to the finished pixels: forward = the NEXT step's ActNorm + permutation, reverse
+// (cnet only) = THIS step's inverse permutation + inverse ActNorm
+struct CnetIo { const float* z_in; long z_in_bs; float* z_out; long z_out_bs; int mix_C, mix_reverse;
+                const float* mix_bias; const float* mix_scale; const float* mix_matrix; const int32_t* mix_gather; };
+
+static int run_cnet(glowhip_plan* P, const LayerPlan& L, const void* packed, const CnetIo& io, int N, int reverse,
+                    const Workspace& w, hipStream_t s) {
+    const glowhip_layer_desc& d = L.d;
+    CnetArgs c{};
+    c.x = io.z_in; c.x_bs = io.z_in_bs;
+    c.w0 = at<char>(packed, L.cn_w0); c.w2 = at<char>(packed, L.cn_w2); c.w4 = at<char>(packed, L.cn_w4);
+    c.N = N; c.Cin = d.C / 2; c.H = d.H; c.W = d.W; c.hidden = d.hidden; c.Cout = L.Cout;
+    c.scratch = w.h1;
+    c.bias = d.f4_bias; c.scale = at<float>(packed, L.f4_scale);
+    c.mode = d.coupling == GLOWHIP_COUPLING_AFFINE ? (reverse ? TAIL_AFFINE_REV : TAIL_AFFINE_FWD)
+                                                   : (reverse ? TAIL_ADD_REV : TAIL_ADD_FWD);
+    c.z_in = io.z_in; c.z_in_bs = io.z_in_bs; c.z_out = io.z_out; c.z_out_bs = io.z_out_bs; c.acc = w.acc;
+    c.mix_C = io.mix_C; c.mix_reverse = io.mix_reverse; c.mix_bias = io.mix_bias; c.mix_scale = io.mix_scale;
+    c.mix_matrix = io.mix_matrix; c.mix_gather = io.mix_gather;
+    ScopedTimer t(P, GLOWHIP_K_CNET, 1, s);
+    count_launch(P, io.mix_C ? "k_cnet+mixer" : "k_cnet");
+    return launch_cnet(c, s);
+}
 
 static int run_coupling(glowhip_plan* P, const LayerPlan& L, const void* packed, const float* x1, long x1_bs, const float* z2_in,
                         long z2_in_bs, float* z2_out, long z2_out_bs, int N, int reverse, const Workspace& w,
@@ -103,14 +130,23 @@ static int run_coupling(glowhip_plan* P, const LayerPlan& L, const void* packed,
     const bool use_sh = L.sh_mid && !g_sh_disabled;
     const bool use_sh_tail = use_sh && L.sh_tail && !g_sh_tail_disabled;
     const bool use_f02 = use_sh_tail && L.sh_f02 && !g_sh_f02_disabled && f02_runs_at(N, HW);
-    if (use_f02) {   // f.0 + f.2 fused: h1 stays in LDS (f02_sh.hip)
+    const bool cnet_h2 = use_sh_tail && L.cnet && g_cnet_h2_only && !g_cnet_disabled;
+    if (cnet_h2) {   // testing: f.0 + f.2 by the cnet kernel, h2 handed to k_tail_sh as an SH tensor
+        ScopedTimer t2(P, GLOWHIP_K_CONV_F2, 1, s);
+        count_launch(P, "k_cnet_h2");
+        CnetArgs c{};
+        c.x = x1; c.x_bs = x1_bs; c.w0 = at<char>(packed, L.cn_w0); c.w2 = at<char>(packed, L.cn_w2); c.w4 = at<char>(packed, L.cn_w4);
+        c.N = N; c.Cin = Ch; c.H = d.H; c.W = d.W; c.hidden = hid; c.Cout = L.Cout; c.scratch = w.h1; c.y_sh = (_Float16*)w.h2;
+        c.mode = TAIL_ADD_FWD;
+        GH_TRY(launch_cnet(c, s));
+    } else if (use_f02) {   // f.0 + f.2 fused: h1 stays in LDS (f02_sh.hip)
         ScopedTimer t2(P, GLOWHIP_K_CONV_F2, 1, s);
         count_launch(P, "k_f02_sh");
         GH_TRY(launch_f02_sh(x1, x1_bs, at<char>(packed, L.f0_sh), at<char>(packed, L.f2_sh), (_Float16*)w.h2, N, Ch, d.H, d.W,
                              hid, s));
     }
     // f.0: 3x3, Cin=C/2 -> hidden, ActNorm + ReLU epilogue
-    if (!use_f02) {
+    if (!use_f02 && !cnet_h2) {
     ScopedTimer t0(P, GLOWHIP_K_CONV_F0, L.mfma_first || L.first_halo, s);
     if (use_sh && L.sh_first && !g_sh_first_disabled) {
         count_launch(P, "k_first_sh");
@@ -132,7 +168,7 @@ static int run_coupling(glowhip_plan* P, const LayerPlan& L, const void* packed,
     }
     }
     // f.2: 1x1, hidden -> hidden, ActNorm + ReLU epilogue
-    if (!use_f02) {
+    if (!use_f02 && !cnet_h2) {
     ScopedTimer t2(P, GLOWHIP_K_CONV_F2, L.mfma_mid, s);
     if (use_sh) {
         count_launch(P, "k_gemm_sh");
@@ -260,11 +296,12 @@ static int run_forward(glowhip_plan* p, const void* packed, const float* x, cons
                 // Let this step's tail apply the NEXT step's channel mixer (one launch less per step) when the next layer is
                 // a FlowStep of the same shape that may run in place (i.e. is not the one writing z_out)
                 NextMix nm{};
-                if (li + 1 < nl - 1 && !g_sh_mix_disabled && tail_runs_sh(L)) {
+                const bool by_cnet = cnet_runs(L) && !g_cnet_h2_only;
+                if (li + 1 < nl - 1 && !g_sh_mix_disabled && (by_cnet || tail_runs_sh(L))) {
                     const LayerPlan& Ln = p->layers[li + 1];
                     const glowhip_layer_desc& dn = Ln.d;
                     if (dn.kind == GLOWHIP_LAYER_FLOWSTEP && dn.C == d.C && dn.H == d.H && dn.W == d.W &&
-                        tail_sh_mix_supported(d.hidden, d.H, d.W, L.Cout, d.C)) {
+                        (by_cnet ? d.C <= 96 : tail_sh_mix_supported(d.hidden, d.H, d.W, L.Cout, d.C))) {
                         nm.C = d.C; nm.out = dst; nm.out_bs = chw;
                         nm.bias = dn.an_bias; nm.scale = at<float>(packed, Ln.an_scale);
                         nm.matrix = dn.permutation == GLOWHIP_PERM_INVCONV ? dn.invconv_w : nullptr;
@@ -272,7 +309,12 @@ static int run_forward(glowhip_plan* p, const void* packed, const float* x, cons
                     }
                 }
                 float* z2 = dst + (long)Ch * HW;
-                GH_TRY(run_coupling(p, L, packed, dst, chw, z2, chw, z2, chw, N, 0, w, s, &nm));
+                if (by_cnet) {
+                    CnetIo io{dst, chw, dst, chw, nm.C, 0, nm.bias, nm.scale, nm.matrix, nm.gather};
+                    GH_TRY(run_cnet(p, L, packed, io, N, 0, w, s));
+                } else {
+                    GH_TRY(run_coupling(p, L, packed, dst, chw, z2, chw, z2, chw, N, 0, w, s, &nm));
+                }
                 premixed = nm.C != 0;
             } else {  // SPLIT2D: score z2 under the prior predicted from z1, keep z1
                 GH_TRY(run_split(L, packed, cur, chw, cur + (long)Ch * HW, chw, nullptr, nullptr, 0, N, 0, w, s));
@@ -302,6 +344,14 @@ static int run_reverse(glowhip_plan* p, const void* packed, const float* z, cons
             GH_TRY(launch_squeeze(cur, nullptr, dst, N, d.C * 4, d.H / 2, d.W / 2, 2, 1, s));
         } else if (d.kind == GLOWHIP_LAYER_FLOWSTEP) {
             float* z2 = dst + (long)Ch * HW;
+            if (cnet_runs(L) && !g_cnet_h2_only && d.C <= 96) {   // coupling^-1, permutation^-1 and ActNorm^-1 by the finishing kernel
+                CnetIo io{cur, chw, dst, chw, d.C, 1, d.an_bias, at<float>(packed, L.an_inv_scale),
+                          d.permutation == GLOWHIP_PERM_INVCONV ? at<float>(packed, L.winv) : nullptr,
+                          d.permutation == GLOWHIP_PERM_GATHER ? d.perm_idx_inv : nullptr};
+                GH_TRY(run_cnet(p, L, packed, io, N, 1, w, s));
+                cur = dst;
+                continue;
+            }
             GH_TRY(run_coupling(p, L, packed, cur, chw, cur + (long)Ch * HW, chw, z2, chw, N, 1, w, s));
             ChanMixArgs m{};
             m.in_a = cur; m.in_a_bs = chw; m.in_b = z2; m.in_b_bs = chw; m.Ca = Ch;
@@ -398,6 +448,13 @@ glowhip_plan* glowhip_plan_create(const glowhip_layer_desc* layers, int n_layers
             L.sh_tail = L.sh_mid && tail_sh_supported(d.hidden, H, W, L.Cout);
             L.sh_f02 = L.sh_first && L.sh_tail && f02_sh_supported(C / 2, H, W, d.hidden);
             if (L.sh_tail) L.f4_sh = take(off, tail_sh_packed_bytes(d.hidden, H, W, L.Cout));
+            L.cnet = cnet_supported(C / 2, H, W, d.hidden, L.Cout);
+            if (L.cnet) {
+                L.cn_w0 = take(off, sh2_image_bytes(cnet_g0(C / 2) * 8, d.hidden));
+                L.cn_w2 = take(off, sh2_image_bytes(d.hidden, d.hidden));
+                L.cn_w4 = take(off, sh2_image_bytes(d.hidden, cnet_mpad4(L.Cout)));
+                p->max_hidden = std::max(p->max_hidden, (long)cnet_scratch_floats_per_sample(H, W, L.Cout));
+            }
             if (L.mfma_last) L.f4_wp = take(off, conv_mfma_tail_packed_bytes(d.hidden, L.Cout));
             L.dg4_first = conv_mfma_first_supported(L.Cout, H, W, d.hidden);
             if (L.dg4_first) L.f4T_wf = take(off, conv_mfma_first_packed_bytes(L.Cout, d.hidden));
@@ -458,6 +515,15 @@ glowhip_plan* glowhip_plan_create(const glowhip_layer_desc* layers, int n_layers
                 RepackJob r{}; r.w = d.f0_w; r.out_off = L.f0_sh; r.kind = REPACK_SH_FIRST; r.Cin = d.C / 2; r.Cout = d.hidden;
                 r.K = (9 * ((r.Cin + 7) / 8) + 1) & ~1; r.fold_bias = d.f0_an_bias; r.fold_logs = d.f0_an_logs; r.use = 1;
                 p->repack_jobs.push_back(r);
+            }
+            if (L.cnet) {
+                RepackJob r0{}; r0.w = d.f0_w; r0.out_off = L.cn_w0; r0.kind = REPACK_SH2_FIRST; r0.Cin = d.C / 2; r0.Cout = d.hidden;
+                r0.K = cnet_g0(d.C / 2); r0.fold_bias = d.f0_an_bias; r0.fold_logs = d.f0_an_logs; r0.use = 1;
+                p->repack_jobs.push_back(r0);
+                RepackJob r2{}; r2.w = d.f2_w; r2.out_off = L.cn_w2; r2.kind = REPACK_SH2_GEMM; r2.Cin = d.hidden; r2.Cout = d.hidden;
+                r2.K = d.hidden; r2.fold_bias = d.f2_an_bias; r2.fold_logs = d.f2_an_logs; r2.use = 1; p->repack_jobs.push_back(r2);
+                RepackJob r4{}; r4.w = d.f4_w; r4.out_off = L.cn_w4; r4.kind = REPACK_SH2_TAIL; r4.Cin = d.hidden; r4.Cout = L.Cout;
+                r4.Kpad = cnet_mpad4(L.Cout); r4.use = 1; p->repack_jobs.push_back(r4);
             }
             if (L.sh_tail) {
                 RepackJob r{}; r.w = d.f4_w; r.out_off = L.f4_sh; r.kind = REPACK_SH_TAIL; r.Cin = d.hidden; r.Cout = L.Cout;
@@ -568,6 +634,10 @@ int glowhip_plan_describe_for(const glowhip_plan* plan, int N, char* buf, size_t
             // "-sh": split-half f16 matrix-pipe kernels (sh.h) are selected for this convolution (unless disabled by the
             // debug switch); the name before it is the exact-fp32 kernel that would run otherwise
             const bool sh = L.sh_mid && !g_sh_disabled;
+            if (cnet_runs(L) && !g_cnet_h2_only)
+                snprintf(line, sizeof line, "%d flowstep C=%d H=%d W=%d hidden=%d f=cnet-sh2 (f.0+f.2+f.4 one kernel + finish)\n", li, d.C, d.H,
+                         d.W, d.hidden);
+            else
             snprintf(line, sizeof line, "%d flowstep C=%d H=%d W=%d hidden=%d f0=%s%s f2=%s%s f4=%s%s\n", li, d.C, d.H, d.W,
                      d.hidden, L.first_halo ? "mfma-halo" : (L.mfma_first ? "mfma" : "direct"),
                      sh && L.sh_first && !g_sh_first_disabled ? (L.sh_f02 && L.sh_tail && !g_sh_tail_disabled && !g_sh_f02_disabled && f02_runs_at(N, d.H * d.W) ? "-sh-fused" : "-sh") : "",
@@ -591,7 +661,7 @@ int glowhip_plan_pack_for(glowhip_plan* plan, void* packed, size_t packed_bytes,
     GH_REQUIRE(plan && packed, "plan_pack: null argument");
     GH_REQUIRE(use & (GLOWHIP_PACK_INFERENCE | GLOWHIP_PACK_TRAINING), "plan_pack: empty use mask");
     // with a kernel family switched off through the debug hook the other family's images are needed after all
-    if (g_sh_disabled || g_sh_tail_disabled || g_sh_first_disabled) use = GLOWHIP_PACK_INFERENCE | GLOWHIP_PACK_TRAINING;
+    if (g_sh_disabled || g_sh_tail_disabled || g_sh_first_disabled || g_cnet_disabled) use = GLOWHIP_PACK_INFERENCE | GLOWHIP_PACK_TRAINING;
     plan->repack_sel.clear();
     for (const RepackJob& r : plan->repack_jobs)
         if (r.use & use) plan->repack_sel.push_back(r);

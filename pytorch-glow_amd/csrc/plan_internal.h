@@ -28,6 +28,7 @@ struct LayerPlan {
     bool sh_first = false; size_t f0_sh = 0;  // f.0 itself on the f16 pipe (first_sh.hip)
     bool sh_f02 = false;                       // f.0 + f.2 as one kernel (f02_sh.hip), h1 never written
     bool sh_tail = false; size_t f4_sh = 0;   // f.2 writes h2 as an SH tensor, f.4 + coupling on tail_sh.hip
+    bool cnet = false; size_t cn_w0 = 0, cn_w2 = 0, cn_w4 = 0;   // whole coupling network as one kernel (cnet_sh.hip), SH2 images
     bool first_halo = false;  // f.0 on k_conv_first (stationary pixel window) instead of k_conv_wide<3>
 };
 

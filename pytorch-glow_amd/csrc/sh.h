@@ -100,4 +100,56 @@ int tail_sh_mpad(int Cin, int H, int W, int Cout, int* groups);   // padded rows
 int launch_tail_sh(const TailShArgs& a, hipStream_t s);
 void tail_sh_force_waves(int nwaves);   // testing hook: only the 4- or the 8-wave variants (0 = automatic)
 
+// =====================================================================================================================
+// SH2: split-half operands at their TRUE scale -> ONE accumulator per output (cnet_sh.hip)
+// =====================================================================================================================
+// Every operand is first multiplied by an exact power of two that places it high in the fp16 range, then split
+//   hi = fp16(V),  lo = fp16(V - hi)            (V = v * 2^e; no 2^11 pre-scale of lo)
+// and a product is accumulated in a SINGLE fp32 accumulator:  acc += a.hi*b.hi + a.hi*b.lo + a.lo*b.hi  (three MFMAs, each
+// fp16 x fp16 product exact).  Half the accumulator registers of the two-accumulator form above, which is what lets a
+// workgroup own a 128-pixel x 512-row output tile and halves the weight bytes fetched per MFMA.
+//   * gfx950's v_mfma_f32_32x32x16_f16 keeps fp16 SUBNORMAL inputs (scripts/ubench/mfma_denorm.hip, measured on MI355X), so a
+//     small lo loses nothing but what fp16's fixed 2^-24 spacing cannot hold: |V - hi - lo| <= max(2^-22 |V|, 2^-25).
+//   * weights: per output row o the exponent e[o] puts max_k |w'[o][k]| into [2^12, 2^13): the absolute floor 2^-25 is
+//     2^-37 of the row's largest weight.  The row factor 2^-e[o] is undone in the epilogue (exact).
+//   * activations (z1 window, h1, h2): fixed factor SH2_ACT_SCALE = 2^4: range |v| < 4094 (larger -> inf -> non-finite nll,
+//     picked up by the sticky flag / exact-fp32 fall-back), floor 2^-29 = 1.9e-9 below |v| = 2^-7.
+constexpr float SH2_ACT_SCALE = 16.0f;
+constexpr float SH2_ACT_INV = 1.0f / 16.0f;
+__device__ __forceinline__ void sh2_split(float V, _Float16& hi, _Float16& lo) {
+    hi = (_Float16)V;
+    lo = (_Float16)(V - (float)hi);
+}
+// Weight image of one convolution as the A operand: half [plane][Kp/8][M][8] (as above), then M floats rowscale, then M floats
+// bias:  out_scaled[o] = acc * rowscale[o] + bias[o]  is the layer output times SH2_ACT_SCALE (f.0, f.2: rowscale = 2^-e,
+// bias = b' * 16) or the plain value (f.4 rows: rowscale = 2^-e / 16, no bias).
+__host__ __device__ static inline size_t sh2_image_bytes(int Kp, int M) { return (size_t)2 * Kp * M * sizeof(_Float16) + (size_t)2 * M * sizeof(float); }
+__host__ __device__ static inline size_t sh2_rowscale_off(int Kp, int M) { return (size_t)2 * Kp * M * sizeof(_Float16); }
+
+// ---- the whole coupling network f() = f.0 -> f.2 -> f.4 as ONE kernel + a light finishing kernel (cnet_sh.hip) --------
+bool cnet_supported(int Cin, int H, int W, int hidden, int Cout);
+int cnet_g0(int Cin);                 // 8-wide k groups of the f.0 image (even count)
+int cnet_mpad4(int Cout);             // rows of the taps-as-rows f.4 image (multiple of 32)
+size_t cnet_scratch_floats(int N, int H, int W, int Cout);   // partial-sum scratch (floats) for batch N; <= N * the per-sample bound
+size_t cnet_scratch_floats_per_sample(int H, int W, int Cout);
+struct CnetArgs {
+    const float* x; long x_bs;                   // z1: channels [0, Cin) of (N, *, H, W), batch stride x_bs
+    const void* w0; const void* w2; const void* w4;   // SH2 images (REPACK_SH2_FIRST / _GEMM / _TAIL)
+    int N, Cin, H, W, hidden, Cout;
+    float* scratch;                              // cnet_scratch_floats(N, ...) floats
+    _Float16* y_sh;                              // testing: write h2 as an (old-format) SH tensor and stop before f.4
+    // ---- finishing kernel: coupling + log-det + channel mixer
+    const float* bias; const float* scale;       // f.4 bias (Cout), exp(3 logs) (Cout)
+    int mode;                                    // TailMode: the four coupling modes
+    const float* z_in; long z_in_bs;             // (N, C, H, W): z1 = channels [0, C/2), z2 = [C/2, C)
+    float* z_out; long z_out_bs;                 // result (may be z_in: a workgroup reads all of its own pixels before it writes)
+    unsigned long long* acc;
+    // channel mixer applied to the updated z before it is written (C = 0: none; only z2 is written then)
+    //   forward: the NEXT step's  y = M ((z + mix_bias) * mix_scale);   reverse: THIS step's  x = (M z) * mix_scale - mix_bias
+    int mix_C; int mix_reverse;
+    const float* mix_bias; const float* mix_scale; const float* mix_matrix; const int32_t* mix_gather;
+};
+int launch_cnet(const CnetArgs& a, hipStream_t s);
+void cnet_force(int ms, int flags);   // testing hook: ms in {0 (automatic), 1, 2, 4}
+
 }  // namespace glowhip

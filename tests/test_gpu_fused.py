@@ -14,6 +14,20 @@ from test_gpu_parity import close, dev, make_glow
 
 pytestmark = pytest.mark.gpu
 
+CNET_OFF = 0x100000      # glowhip_debug_force_tail_tile: the one-kernel coupling network off -> the round-1 kernel pairs run
+
+
+@pytest.fixture(params=["cnet", "pairs"])
+def path(request):
+    """Both kernel families behind the same tests: the product default (k_cnet: f.0 + f.2 + f.4 in one kernel + finishing
+    kernel) and the kernel pairs it replaced (k_f02_sh / k_first_sh + k_gemm_sh, then k_tail_sh), which stay as the fall-back
+    for shapes cnet does not take."""
+    G.lib().glowhip_debug_force_tail_tile(CNET_OFF if request.param == "pairs" else 0)
+    try:
+        yield request.param
+    finally:
+        G.lib().glowhip_debug_force_tail_tile(0)
+
 
 def _case(image, L, K, hidden, batch, seed=5, coup="affine", perm="invconv"):
     cfg = O.default_cfg(image_shape=(image, image, 3), hidden_channels=hidden, K=K, L=L, flow_coupling=coup,
@@ -44,11 +58,17 @@ def _case(image, L, K, hidden, batch, seed=5, coup="affine", perm="invconv"):
     return plan, fwd, rev
 
 
-def test_fused_f02_runs_and_matches_oracle_config_b_geometry():
-    """Config-B geometry at batch 48: levels 1 (768 workgroups) and 2 (192) take the fused kernel, forward and inverse; level 3
-    (48 workgroups) the separate pair.  Full z / nll / decode vs the oracle at 1e-4."""
+def test_fused_f02_runs_and_matches_oracle_config_b_geometry(path):
+    """Config-B geometry at batch 48, full z / nll / decode vs the oracle at 1e-4.  cnet: every FlowStep is one k_cnet launch
+    (+ finishing kernel), forward and inverse.  pairs: levels 1 (768 workgroups) and 2 (192) take the fused f.0 + f.2 kernel,
+    level 3 (48 workgroups) the separate pair."""
     K = 4
     plan, fwd, rev = _case(64, 3, K, 512, 48)
+    if path == "cnet":
+        assert fwd.get("k_cnet", 0) + fwd.get("k_cnet+mixer", 0) == 3 * K and rev.get("k_cnet+mixer", 0) == 3 * K, (fwd, rev)
+        assert not any(k in fwd for k in ("k_f02_sh", "k_gemm_sh", "k_tail_sh", "k_conv_direct", "k_gemm_f32")), fwd
+        assert sum("cnet-sh2" in l for l in plan.describe(48).splitlines()) == 3 * K
+        return
     assert fwd.get("k_f02_sh", 0) == 2 * K, fwd          # levels 1 and 2, every step
     assert fwd.get("k_first_sh", 0) == K and fwd.get("k_gemm_sh", 0) == K, fwd   # level 3
     assert rev.get("k_f02_sh", 0) == 2 * K, rev
@@ -59,31 +79,54 @@ def test_fused_f02_runs_and_matches_oracle_config_b_geometry():
     assert sum("-sh-fused" in l for l in d4.splitlines()) == 0
 
 
-def test_fused_f02_level1_only_batch16():
-    """Batch 16: only level 1 (256 workgroups) reaches the fused kernel."""
+def test_fused_f02_level1_only_batch16(path):
+    """Batch 16: in the pairs family only level 1 (256 workgroups) reaches the fused kernel; cnet splits the h2 rows over 2 / 4
+    workgroups per tile at the levels whose pixel tiles alone would leave CUs idle."""
     K = 3
     plan, fwd, rev = _case(64, 3, K, 512, 16, seed=6)
-    assert fwd.get("k_f02_sh", 0) == K and fwd.get("k_gemm_sh", 0) == 2 * K, fwd
+    if path == "cnet":
+        assert fwd.get("k_cnet", 0) + fwd.get("k_cnet+mixer", 0) == 3 * K, fwd
+    else:
+        assert fwd.get("k_f02_sh", 0) == K and fwd.get("k_gemm_sh", 0) == 2 * K, fwd
 
 
-def test_fused_f02_w64_level():
+def test_fused_f02_w64_level(path):
     """The 64-pixel-wide level (config D level 1, 128x128 input): a 64-pixel tile is one image row (wshift = 6).  Batch 3 ->
     192 workgroups."""
     K = 2
     plan, fwd, rev = _case(128, 2, K, 256, 3, seed=7)
-    assert fwd.get("k_f02_sh", 0) >= K, fwd              # the W=64 level is fused at this batch
-    assert rev.get("k_f02_sh", 0) >= K, rev
+    if path == "cnet":
+        assert fwd.get("k_cnet", 0) + fwd.get("k_cnet+mixer", 0) == 2 * K and rev.get("k_cnet+mixer", 0) == 2 * K, (fwd, rev)
+    else:
+        assert fwd.get("k_f02_sh", 0) >= K and rev.get("k_f02_sh", 0) >= K, (fwd, rev)   # the W=64 level is fused at this batch
 
 
-def test_fused_f02_additive_and_shuffle():
+def test_fused_f02_additive_and_shuffle(path):
     """Additive coupling (Cout = C/2 tail rows) and a gather permutation behind the fused kernel."""
     K = 2
     plan, fwd, rev = _case(64, 2, K, 512, 16, seed=8, coup="additive", perm="reverse")
-    assert fwd.get("k_f02_sh", 0) >= K, fwd
+    if path == "cnet":
+        assert fwd.get("k_cnet", 0) + fwd.get("k_cnet+mixer", 0) == 2 * K, fwd
+    else:
+        assert fwd.get("k_f02_sh", 0) >= K, fwd
+
+
+@pytest.mark.parametrize("ms", [1, 2, 4])
+@pytest.mark.parametrize("image,L,hidden,batch", [(64, 3, 512, 5), (64, 3, 256, 3), (32, 2, 128, 3), (128, 2, 512, 2)])
+def test_cnet_every_row_split(ms, image, L, hidden, batch):
+    """k_cnet with the h2 rows forced onto 1, 2 and 4 workgroups per pixel tile (the launch heuristic picks by grid size): odd
+    batches (a half-filled last tile at the 8x8 level), three hidden widths, tile rows from 16 (8-wide level: two images per
+    tile) down to 2 (64-wide level), halo rows between tiles summed by the finishing kernel."""
+    G.lib().glowhip_debug_force_tail_tile(ms << 22)
+    try:
+        plan, fwd, rev = _case(image, L, 2, hidden, batch, seed=30 + ms)
+    finally:
+        G.lib().glowhip_debug_force_tail_tile(0)
+    assert fwd.get("k_cnet", 0) + fwd.get("k_cnet+mixer", 0) == 2 * L, fwd
 
 
 @pytest.mark.parametrize("case", range(14))
-def test_fuzz_parity_seeded(case):
+def test_fuzz_parity_seeded(case, path):
     """tests/fuzz_parity.py's randomised sweep (image 16..128, L, K, hidden 64..512, coupling, permutation, batch 1..48) as
     seeded regression cases, BIG shapes included."""
     import fuzz_parity

@@ -280,7 +280,7 @@ def _full_tensor_check(expect_sh):
           f"(fp32 oracle itself {d(o['z32'], o['z64']):.2e})")
     line = o["describe"].splitlines()[1]
     print(line)
-    assert ("f2=mfma-sh" in line) == expect_sh and ("f0=mfma-halo-sh" in line) == expect_sh and ("f4=mfma-sh" in line) == expect_sh
+    assert ("cnet-sh2" in line) == expect_sh and ("f2=mfma " in line) == (not expect_sh), line
     # no further from an fp64 evaluation than twice the fp32 reference's own rounding noise
     assert d(o["z"], o["z64"]) <= 2.0 * d(o["z32"], o["z64"]) + 2e-6
 
@@ -308,7 +308,7 @@ def test_split_half_survives_large_and_tiny_activations():
                 st.f[0].weight.mul_(wmul); st.f[2].weight.mul_(wmul)
             sd = {k: v.detach().cpu().clone() for k, v in st.state_dict().items()}
         x = torch.randn(2, 12, 32, 32, generator=torch.Generator().manual_seed(6)) * scale
-        assert "f2=mfma-sh" in st._plan(dev(x)).describe()
+        assert "cnet-sh2" in st._plan(dev(x)).describe() or "f2=mfma-sh" in st._plan(dev(x)).describe()
         z, ld = st(dev(x), 0.)
         zr, ldr = O.flowstep(x, torch.zeros(2), sd, "", "invconv", "affine")
         tol = 2e-5 * max(1.0, zr.abs().max().item())
@@ -443,7 +443,7 @@ def test_mfma_flowstep_vs_oracle(c, h, w, hidden, coup, n):
     x = torch.randn(n, c, h, w, generator=torch.Generator().manual_seed(1))
     ld = torch.randn(n, generator=torch.Generator().manual_seed(2))
     desc = st._plan(dev(x)).describe()
-    assert "f0=mfma" in desc and "f2=mfma" in desc and "f4=mfma" in desc, desc
+    assert "cnet-sh2" in desc or ("f0=mfma" in desc and "f2=mfma" in desc and "f4=mfma" in desc), desc
     z, ldz = st(dev(x), dev(ld))
     zr, ldr = O.flowstep(x, ld, sd, "", "invconv", coup)
     close(z, zr, 2e-5, what="fwd z"); ld_close(ldz, ldr)
@@ -578,12 +578,11 @@ def test_split_half_stack_every_coupling_and_permutation(coup, perm):
     plan = glow.flow.plan_for(dev(x))
     desc = plan.describe(batch)
     steps = [l for l in desc.splitlines() if "flowstep" in l]
-    assert all("f2=mfma-sh" in l and "f4=mfma-sh" in l for l in steps), desc
+    assert all("cnet-sh2" in l for l in steps), desc
     plan.launch_counts(reset=True)
     z, nll, _ = glow.normal_flow(dev(x), None, noise=dev(noise))
     counts = plan.launch_counts(reset=True)
-    assert counts.get("k_f02_sh", 0) == 3 and counts.get("k_gemm_sh", 0) == 6, counts     # level 1 fused, levels 2-3 separate
-    assert counts.get("k_tail_sh+mixer", 0) >= 4 and counts.get("k_conv_direct", 0) == 0, counts
+    assert counts.get("k_cnet+mixer", 0) >= 4 and counts.get("k_conv_direct", 0) == 0, counts
     close(z, z_ref, 1e-4, what="z"); close(nll, nll_ref, 1e-4, what="nll")
     G.lib().glowhip_debug_force_tail_tile(0x8000)      # the same without the mixer fused into the tails
     try:
