@@ -22,6 +22,8 @@
 
 #include "conv_mfma.h"
 
+GH_STAMPS_DEFINE(cnet)
+
 namespace glowhip {
 
 constexpr int CN_PX = 128;                   // pixels per workgroup tile
@@ -32,6 +34,7 @@ struct CnetGeo {
     int wshift, lsub, NI, R, WP, Wpx, nchunk, G, steps0, Mpad4, Mrow, NRT4, KS, npass, tiles;
     int winplane;     // halfs per window plane
     int HW;
+    int lpp;          // log2(pixels per staging pass)
 };
 
 __host__ __device__ inline int cnet_trow(int M9) {   // T row stride (floats): multiple of 4, an odd multiple (bank spread)
@@ -51,14 +54,25 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
     static_assert(TP1 >= 1 && TP2 >= 1, "hidden / MS too small for 8 waves");
     constexpr int RT2 = TP2 >= 4 ? TP2 / 4 : 1;      // row tiles x pixel tiles of a wave's h2 block
     constexpr int PT2 = TP2 >= 4 ? 4 : TP2;
-    constexpr int P1SUB = (TP2 == 8 && TP1 == 4) ? 2 : 1;   // P1 in two pixel sub-passes while 128 accumulator registers are live
+    constexpr int P1SUB = (TP1 == 4 && TP2 == 8) ? 2 : 1;   // P1 in two pixel sub-passes while 128 accumulator registers are live;
+                                                            // otherwise all of a wave's tiles per k-step (12 MFMAs cover the L2 latency of the A sets)
     constexpr int PTS = TP1 / P1SUB;                 // pixel tiles per P1 sub-pass
     constexpr int NL = MR > 256 ? 2 : 1;             // loads of h2 into the LDS buffer for P3
     constexpr int LK = MR / NL;                      // channels per load
+    constexpr int LCH = LK / 8;                      // chunks per load
+    constexpr int NS = HK / 16;                      // k-steps of P2 per half
+    static_assert(NS % 3 == 1 || NH == 1, "the set rotation of P2 must end on set 0 for the second half to restart there");
 
     extern __shared__ __attribute__((aligned(16))) _Float16 smem_c[];
     _Float16* hbuf = smem_c;
     _Float16* win = smem_c + CN_HBUF / 2;
+    // small tables behind the window: row scale / bias of f.0 and f.2 (this workgroup's rows), row scale of the f.4 rows -- read
+    // from LDS in the epilogues instead of from global memory
+    float* t_rs0 = reinterpret_cast<float*>(win + 2 * g.winplane);
+    float* t_b0 = t_rs0 + HID;
+    float* t_rs2 = t_b0 + HID;
+    float* t_b2 = t_rs2 + MR;
+    float* t_rs4 = t_b2 + MR;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -76,11 +90,12 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
     const _Float16* W0 = (const _Float16*)a.w0;
     const long w0_plane = (long)g.G * HID * 8;
     const float* rs0 = (const float*)((const char*)a.w0 + sh2_rowscale_off(g.G * 8, HID));
-    const float* b0 = rs0 + HID;
     const _Float16* W2 = (const _Float16*)a.w2;
     constexpr long w2_plane = (long)HID * HID;
     const float* rs2 = (const float*)((const char*)a.w2 + sh2_rowscale_off(HID, HID));
-    const float* b2 = rs2 + HID;
+    const _Float16* W4 = (const _Float16*)a.w4;
+    const long w4_plane = (long)HID * g.Mpad4;
+    const float* rs4 = (const float*)((const char*)a.w4 + sh2_rowscale_off(HID, g.Mpad4));
 
     // ---- wave's h2 block: row tiles [rt2, rt2 + RT2), pixel tiles [pt2, pt2 + PT2)
     const int rt2 = (wid * TP2) >> 2, pt2 = (wid * TP2) & 3;
@@ -94,11 +109,29 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
             dst[RT2 + i] = *reinterpret_cast<const h8*>(p + i * 256 + w2_plane);
         }
     };
-    // requested before the window is built: the first two A sets of P2 (their L2 round trips overlap P0 and P1)
-    loadA2(0, A2[0]);
-    loadA2(1, A2[1]);
+    // ---- wave's h1 tiles per half: row tile rt1, pixel tiles [pt1, pt1 + TP1)
+    const int rt1 = (wid * TP1) >> 2, pt1 = (wid * TP1) & 3;
+    const _Float16* a1p = W0 + ((long)kl * HID + rt1 * 32 + ml) * 8;               // + half * HK*8 ; + st * 2*HID*8 ; lo: + w0_plane
+    h8 A1[3][2];           // [set]{hi, lo}
+    auto loadA1 = [&](int hh, int st, h8 (&dst)[2]) {
+        const _Float16* p = a1p + (long)hh * (HK * 8) + (long)st * (2 * HID * 8);
+        dst[0] = *reinterpret_cast<const h8*>(p);
+        dst[1] = *reinterpret_cast<const h8*>(p + w0_plane);
+    };
+    GH_STAMP(0);
+    // requested before the window is built (their L2 round trips overlap P0): the first two A sets of P1 and of P2
+    loadA1(0, 0, A1[0]);
+    loadA1(0, g.steps0 > 1 ? 1 : 0, A1[1]);
+    constexpr bool A2_LATE = TP2 == 8;    // 128 accumulator registers live across P1: P2's first A sets are requested after P1
+    if (!A2_LATE) {
+        loadA2(0, A2[0]);
+        loadA2(1, A2[1]);
+    }
 
-    // ---- P0: window -> (hi, lo) halves in LDS; slot e = (chunk, sub-tile, window pixel), 8 channels each
+    // ---- P0: tables, then the window -> (hi, lo) halves in LDS; slot e = (chunk, sub-tile, window pixel), 8 channels each
+    for (int e = tid; e < 2 * HID; e += 512) t_rs0[e] = rs0[e];                               // rs0 | b0 are adjacent in the image
+    for (int e = tid; e < MR; e += 512) { t_rs2[e] = rs2[ms_row0 + e]; t_b2[e] = rs2[HID + ms_row0 + e]; }
+    for (int e = tid; e < g.Mpad4; e += 512) t_rs4[e] = rs4[e];
     {
         const int nslots = g.nchunk * g.NI * g.Wpx;
         for (int e = tid; e < nslots; e += 512) {
@@ -109,14 +142,18 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
             const int yy = y0 - 1 + r, xx = c - 1;
             const long n = n0 + sub;
             const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W && n < a.N;
-            const float* xin = a.x + n * a.x_bs;
+            // every load is issued unconditionally from a clamped (valid) address and masked afterwards: eight independent loads
+            // in flight per slot instead of eight round trips behind one another
+            const float* xin = a.x + (n < a.N ? n : (long)a.N - 1) * a.x_bs + min(max(yy, 0), H - 1) * W + min(max(xx, 0), W - 1);
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = xin[(long)min(ch * 8 + q, a.Cin - 1) * HW];
             h8 hi, lo;
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                const int ci = ch * 8 + q;
-                const float v = (in && ci < a.Cin) ? xin[(long)ci * HW + yy * W + xx] * SH2_ACT_SCALE : 0.f;
+                const float vv = (in && ch * 8 + q < a.Cin) ? v[q] * SH2_ACT_SCALE : 0.f;
                 _Float16 x0, x1;
-                sh2_split(v, x0, x1);
+                sh2_split(vv, x0, x1);
                 hi[q] = x0; lo[q] = x1;
             }
             *reinterpret_cast<h8*>(win + (long)e * 8) = hi;
@@ -124,6 +161,7 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
         }
     }
     __syncthreads();
+    GH_STAMP(1);
 
     // window offset (halfs) of tile pixel q for tap (0,0), chunk 0
     auto pix_base = [&](int q) {
@@ -141,84 +179,107 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
 
 #pragma unroll 1
     for (int hh = 0; hh < NH; ++hh) {
-        // ---- P1: h1 channels [hh*HK, hh*HK + HK) of all 128 pixels -> hbuf
-        {
-            const int t0 = wid * TP1;
-            const int rt1 = t0 >> 2, pt1 = t0 & 3;
-            const int o0 = hh * HK + rt1 * 32;
-            const _Float16* a0p = W0 + ((long)kl * HID + o0 + ml) * 8;     // + st * 2*HID*8 ; lo: + w0_plane
+        // ---- P1: h1 channels [hh*HK, hh*HK + HK) of all 128 pixels -> hbuf.  Its first two A sets are already in flight.
 #pragma unroll 1
-            for (int sp = 0; sp < P1SUB; ++sp) {
-                int pb[PTS];
+        for (int sp = 0; sp < P1SUB; ++sp) {
+            int pb[PTS];
 #pragma unroll
-                for (int j = 0; j < PTS; ++j) pb[j] = pix_base((pt1 + sp * PTS + j) * 32 + ml);
-                f32x16_t acc1[PTS];
+            for (int j = 0; j < PTS; ++j) pb[j] = pix_base((pt1 + sp * PTS + j) * 32 + ml);
+            f32x16_t acc1[PTS];
 #pragma unroll
-                for (int j = 0; j < PTS; ++j)
+            for (int j = 0; j < PTS; ++j)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc1[j][r] = 0.f;
-                h8 Ah0 = *reinterpret_cast<const h8*>(a0p), Al0 = *reinterpret_cast<const h8*>(a0p + w0_plane);
-                h8 Ah1 = Ah0, Al1 = Al0;
-                if (g.steps0 > 1) {
-                    Ah1 = *reinterpret_cast<const h8*>(a0p + 2 * HID * 8);
-                    Al1 = *reinterpret_cast<const h8*>(a0p + 2 * HID * 8 + w0_plane);
+                for (int r = 0; r < 16; ++r) acc1[j][r] = 0.f;
+            // k groups of f.0 are ordered (8-channel chunk, tap), tap fastest: group gk -> chunk gk / 9, tap gk % 9 (divisions by
+            // constants); groups past 9 * nchunk carry zero weights and read window offset 0.  The B fragments of step st + 1 --
+            // tap-shifted window addresses -- are requested while the MFMAs of step st issue.  The A sets rotate by NAME (loop
+            // unrolled by three): a rotation by register copies makes the compiler wait for the newest global load at the end
+            // of every step (vmcnt(0)).
+            int gk = kl;
+            auto cur_goff = [&]() {
+                const int ch = gk / 9, tap = gk - ch * 9;
+                const int dy = tap / 3, dx = tap - dy * 3;
+                return ch < g.nchunk ? (ch * g.NI * g.Wpx + dy * g.WP + dx) * 8 : 0;
+            };
+            auto advance = [&]() { gk += 2; };
+            constexpr bool BPRE = PTS <= 2;    // B fragments one step ahead (register budget: only with at most two tiles)
+            h8 Bc[2 * PTS], Bn[BPRE ? 2 * PTS : 1];     // [j] hi, [PTS + j] lo
+            auto loadB = [&](h8* dst) {
+                const int goff = cur_goff();
+#pragma unroll
+                for (int j = 0; j < PTS; ++j) {
+                    dst[j] = *reinterpret_cast<const h8*>(win + goff + pb[j]);
+                    dst[PTS + j] = *reinterpret_cast<const h8*>(win + g.winplane + goff + pb[j]);
                 }
+            };
+            if (BPRE) loadB(Bc);
+            auto step1 = [&](int st, const h8 (&use)[2], h8 (&fill)[2]) {
+                loadA1(hh, min(st + 2, g.steps0 - 1), fill);     // unconditional (clamped): no branch, counted waits
+                if (BPRE) { advance(); loadB(Bn); } else { loadB(Bc); advance(); }
+                // three sweeps over the tiles: consecutive MFMAs never share an accumulator
+#pragma unroll
+                for (int j = 0; j < PTS; ++j) acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(use[0], Bc[j], acc1[j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < PTS; ++j) acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(use[0], Bc[PTS + j], acc1[j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < PTS; ++j) acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(use[1], Bc[j], acc1[j], 0, 0, 0);
+                if (BPRE) {
+#pragma unroll
+                    for (int j = 0; j < 2 * PTS; ++j) Bc[j] = Bn[j];
+                }
+            };
 #pragma unroll 1
-                for (int st = 0; st < g.steps0; ++st) {
-                    h8 Ah2 = Ah1, Al2 = Al1;
-                    if (st + 2 < g.steps0) {
-                        Ah2 = *reinterpret_cast<const h8*>(a0p + (long)(st + 2) * (2 * HID * 8));
-                        Al2 = *reinterpret_cast<const h8*>(a0p + (long)(st + 2) * (2 * HID * 8) + w0_plane);
-                    }
-                    int gk = 2 * st + kl;
-                    gk = gk < 9 * g.nchunk ? gk : 0;           // padded groups carry zero weights
-                    const int tap = gk / g.nchunk, ch = gk - tap * g.nchunk;
-                    const int dy = tap / 3, dx = tap - dy * 3;
-                    const int goff = (ch * g.NI * g.Wpx + dy * g.WP + dx) * 8;
-#pragma unroll
-                    for (int j = 0; j < PTS; ++j) {
-                        const h8 bh = *reinterpret_cast<const h8*>(win + goff + pb[j]);
-                        const h8 bl = *reinterpret_cast<const h8*>(win + g.winplane + goff + pb[j]);
-                        acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah0, bh, acc1[j], 0, 0, 0);
-                        acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah0, bl, acc1[j], 0, 0, 0);
-                        acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al0, bh, acc1[j], 0, 0, 0);
-                    }
-                    Ah0 = Ah1; Al0 = Al1; Ah1 = Ah2; Al1 = Al2;
+            for (int st = 0; st < g.steps0; st += 3) {     // steps0 is a multiple of 3 (zero-weight groups pad the image)
+                step1(st, A1[0], A1[2]);
+                step1(st + 1, A1[1], A1[0]);
+                step1(st + 2, A1[2], A1[1]);
+            }
+            // A sets of the next P1 pass (next pixel sub-pass of this half, or the other half): in flight during the epilogue,
+            // the barrier and P2
+            {
+                const int nh = sp + 1 < P1SUB ? hh : hh + 1;
+                if (nh < NH) {
+                    loadA1(nh, 0, A1[0]);
+                    loadA1(nh, g.steps0 > 1 ? 1 : 0, A1[1]);
                 }
-                // relu, split, store into the B-operand image: a lane's 4 consecutive channels = 8 bytes per plane
+            }
+            // relu, split, store into the B-operand image: a lane's 4 consecutive channels = 8 bytes per plane
 #pragma unroll
-                for (int gq = 0; gq < 4; ++gq) {
-                    const int o = o0 + 8 * gq + 4 * kl;
-                    const f32x4_t rs = *reinterpret_cast<const f32x4_t*>(rs0 + o);
-                    const f32x4_t bb = *reinterpret_cast<const f32x4_t*>(b0 + o);
-                    const int chunk = rt1 * 4 + gq;
+            for (int gq = 0; gq < 4; ++gq) {
+                const int o = hh * HK + rt1 * 32 + 8 * gq + 4 * kl;
+                const f32x4_t rs = *reinterpret_cast<const f32x4_t*>(t_rs0 + o);
+                const f32x4_t bb = *reinterpret_cast<const f32x4_t*>(t_b0 + o);
+                const int chunk = rt1 * 4 + gq;
 #pragma unroll
-                    for (int j = 0; j < PTS; ++j) {
-                        h4 hi, lo;
+                for (int j = 0; j < PTS; ++j) {
+                    h4 hi, lo;
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) {
-                            const float v = fmaxf(acc1[j][4 * gq + t] * rs[t] + bb[t], 0.f);
-                            _Float16 x0, x1;
-                            sh2_split(v, x0, x1);
-                            hi[t] = x0; lo[t] = x1;
-                        }
-                        _Float16* dst = hbuf + ((long)chunk * CN_PX + (pt1 + sp * PTS + j) * 32 + ml) * 8 + 4 * kl;
-                        *reinterpret_cast<h4*>(dst) = hi;
-                        *reinterpret_cast<h4*>(dst + (long)NCH * CN_PX * 8) = lo;
+                    for (int t = 0; t < 4; ++t) {
+                        const float v = fmaxf(fmaf(acc1[j][4 * gq + t], rs[t], bb[t]), 0.f);
+                        _Float16 x0, x1;
+                        sh2_split(v, x0, x1);
+                        hi[t] = x0; lo[t] = x1;
                     }
+                    _Float16* dst = hbuf + ((long)chunk * CN_PX + (pt1 + sp * PTS + j) * 32 + ml) * 8 + 4 * kl;
+                    *reinterpret_cast<h4*>(dst) = hi;
+                    *reinterpret_cast<h4*>(dst + (long)NCH * CN_PX * 8) = lo;
                 }
             }
         }
+        if (A2_LATE) {
+            loadA2(hh * NS, A2[0]);
+            loadA2(hh * NS + 1, A2[1]);
+        }
+        GH_STAMP(2 + 4 * hh);
         __syncthreads();
+        GH_STAMP(3 + 4 * hh);
 
         // ---- P2: acc2 += W2'[rows, half hh] h1[half hh]; B from LDS, A two k-steps ahead from L2
         {
-            constexpr int NS = HK / 16;
             const int ks0 = hh * NS;
             const _Float16* bp = hbuf + ((long)kl * CN_PX + pt2 * 32 + ml) * 8;
-#pragma unroll 1
-            for (int s = 0; s < NS; ++s) {
-                if (ks0 + s + 2 < HID / 16) loadA2(ks0 + s + 2, A2[2]);
+            auto kstep = [&](int s, const h8 (&use)[2 * RT2], h8 (&fill)[2 * RT2]) {
+                loadA2(ks0 + min(s + 2, NS - 1), fill);          // unconditional (clamped)
                 const _Float16* bs = bp + (long)s * (2 * CN_PX * 8);
                 h8 bh[PT2], bl[PT2];
 #pragma unroll
@@ -230,22 +291,53 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
                 for (int i = 0; i < RT2; ++i)
 #pragma unroll
                     for (int j = 0; j < PT2; ++j)
-                        acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A2[0][i], bh[j], acc2[i][j], 0, 0, 0);
+                        acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(use[i], bh[j], acc2[i][j], 0, 0, 0);
 #pragma unroll
                 for (int i = 0; i < RT2; ++i)
 #pragma unroll
                     for (int j = 0; j < PT2; ++j)
-                        acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A2[0][i], bl[j], acc2[i][j], 0, 0, 0);
+                        acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(use[i], bl[j], acc2[i][j], 0, 0, 0);
 #pragma unroll
                 for (int i = 0; i < RT2; ++i)
 #pragma unroll
                     for (int j = 0; j < PT2; ++j)
-                        acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A2[0][RT2 + i], bh[j], acc2[i][j], 0, 0, 0);
-#pragma unroll
-                for (int t = 0; t < 2 * RT2; ++t) { A2[0][t] = A2[1][t]; A2[1][t] = A2[2][t]; }
+                        acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(use[RT2 + i], bh[j], acc2[i][j], 0, 0, 0);
+            };
+#pragma unroll 1
+            for (int s = 0; s + 3 <= NS; s += 3) {
+                kstep(s, A2[0], A2[2]);
+                kstep(s + 1, A2[1], A2[0]);
+                kstep(s + 2, A2[2], A2[1]);
+            }
+            if (NS % 3 >= 1) kstep(NS - NS % 3, A2[0], A2[2]);
+            if (NS % 3 == 2) kstep(NS - 1, A2[1], A2[0]);
+            if (!A2_LATE && hh + 1 < NH) {   // A sets of the other half's first two k-steps: in flight while P1 rebuilds the LDS buffer
+                loadA2((hh + 1) * NS, A2[0]);
+                loadA2((hh + 1) * NS + 1, A2[1]);
             }
         }
+        GH_STAMP(4 + 4 * hh);
         __syncthreads();     // every wave is done reading this half of h1
+        GH_STAMP(5 + 4 * hh);
+    }
+
+    // ---- P3 set-up: T units of this wave.  unit u = (row tile rt4 = u % NRT4, k part u / NRT4) x all 4 pixel tiles; wave w
+    // takes units w (and w + 8 when UPW = 2).  The first two A sets of the first unit are requested NOW.
+    const int nunits = g.NRT4 * g.KS;
+    const int nsl = (LK / 16) / g.KS;                        // k-steps of one h2 load per k part
+    h8 A4[3][2];
+    auto a4_base = [&](int unit, int l) {
+        const int rt4 = unit % g.NRT4, kp = unit / g.NRT4;
+        return W4 + ((long)((ms_row0 + l * LK) / 8 + 2 * kp * nsl + kl) * g.Mpad4 + rt4 * 32 + ml) * 8;
+    };
+    auto loadA4 = [&](const _Float16* ap, int st, h8 (&dst)[2]) {
+        dst[0] = *reinterpret_cast<const h8*>(ap + (long)st * (2 * g.Mpad4 * 8));
+        dst[1] = *reinterpret_cast<const h8*>(ap + (long)st * (2 * g.Mpad4 * 8) + w4_plane);
+    };
+    if (!a.y_sh && wid < nunits) {
+        const _Float16* ap = a4_base(wid, 0);
+        loadA4(ap, 0, A4[0]);
+        loadA4(ap, nsl > 1 ? 1 : 0, A4[1]);
     }
 
     // ---- h2 = relu(acc2 * rowscale + bias) (times SH2_ACT_SCALE), in place
@@ -253,14 +345,15 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
     for (int i = 0; i < RT2; ++i)
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
-            const int o = ms_row0 + (rt2 + i) * 32 + 8 * gq + 4 * kl;
-            const f32x4_t rs = *reinterpret_cast<const f32x4_t*>(rs2 + o);
-            const f32x4_t bb = *reinterpret_cast<const f32x4_t*>(b2 + o);
+            const int o = (rt2 + i) * 32 + 8 * gq + 4 * kl;           // workgroup-local row
+            const f32x4_t rs = *reinterpret_cast<const f32x4_t*>(t_rs2 + o);
+            const f32x4_t bb = *reinterpret_cast<const f32x4_t*>(t_b2 + o);
 #pragma unroll
             for (int j = 0; j < PT2; ++j)
 #pragma unroll
-                for (int t = 0; t < 4; ++t) acc2[i][j][4 * gq + t] = fmaxf(acc2[i][j][4 * gq + t] * rs[t] + bb[t], 0.f);
+                for (int t = 0; t < 4; ++t) acc2[i][j][4 * gq + t] = fmaxf(fmaf(acc2[i][j][4 * gq + t], rs[t], bb[t]), 0.f);
         }
+    GH_STAMP(10);
 
     if (a.y_sh) {   // testing: h2 as an (old-format) SH tensor, f.4 left to k_tail_sh
 #pragma unroll
@@ -288,11 +381,6 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
     }
 
     // ---- P3: T[m][px] = sum_k W4t[m][k] h2[k][px] over this workgroup's h2 rows (= k range [ms_row0, ms_row0 + MR))
-    // unit u = (row tile rt4 = u % NRT4, k part u / NRT4) x all 4 pixel tiles; wave w takes units w (and w + 8 when UPW = 2)
-    const _Float16* W4 = (const _Float16*)a.w4;
-    const long w4_plane = (long)HID * g.Mpad4;
-    const float* rs4 = (const float*)((const char*)a.w4 + sh2_rowscale_off(HID, g.Mpad4));
-    const int nunits = g.NRT4 * g.KS;
     f32x16_t accT[UPW][4];
 #pragma unroll
     for (int u = 0; u < UPW; ++u)
@@ -300,7 +388,6 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) accT[u][j][r] = 0.f;
-    constexpr int LCH = LK / 8;        // chunks per load
 #pragma unroll 1
     for (int l = 0; l < NL; ++l) {
         // the owners of rows [l*LK, (l+1)*LK) pass their h2 to the B side through hbuf
@@ -326,102 +413,109 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
                 }
             }
         }
+        GH_STAMP(11 + 4 * l);
         __syncthreads();
-        const int nsl = (LK / 16) / g.KS;                    // k-steps of this load per k part
+        GH_STAMP(12 + 4 * l);
 #pragma unroll
         for (int u = 0; u < UPW; ++u) {
             const int unit = wid + 8 * u;
             if (unit >= nunits) continue;
-            const int rt4 = unit % g.NRT4, kp = unit / g.NRT4;
-            const int s0 = kp * nsl;
-            const _Float16* ap = W4 + ((long)((ms_row0 + l * LK) / 8 + 2 * s0 + kl) * g.Mpad4 + rt4 * 32 + ml) * 8;
-            const _Float16* bp = hbuf + ((long)(2 * s0 + kl) * CN_PX + ml) * 8;
-            h8 ah0 = *reinterpret_cast<const h8*>(ap), al0 = *reinterpret_cast<const h8*>(ap + w4_plane);
-            h8 ah1 = ah0, al1 = al0;
-            if (nsl > 1) {
-                ah1 = *reinterpret_cast<const h8*>(ap + (long)2 * g.Mpad4 * 8);
-                al1 = *reinterpret_cast<const h8*>(ap + (long)2 * g.Mpad4 * 8 + w4_plane);
-            }
-#pragma unroll 1
-            for (int s = 0; s < nsl; ++s) {
-                h8 ah2 = ah1, al2 = al1;
-                if (s + 2 < nsl) {
-                    ah2 = *reinterpret_cast<const h8*>(ap + (long)(s + 2) * (2 * g.Mpad4 * 8));
-                    al2 = *reinterpret_cast<const h8*>(ap + (long)(s + 2) * (2 * g.Mpad4 * 8) + w4_plane);
-                }
-                const _Float16* bs = bp + (long)s * (2 * CN_PX * 8);
+            const int kp = unit / g.NRT4;
+            const _Float16* ap = a4_base(unit, l);
+            const _Float16* bp = hbuf + ((long)(2 * kp * nsl + kl) * CN_PX + ml) * 8;
+            auto step4 = [&](int st, const h8 (&use)[2], h8 (&fill)[2]) {
+                loadA4(ap, min(st + 2, nsl - 1), fill);          // unconditional (clamped)
+                const _Float16* bs = bp + (long)st * (2 * CN_PX * 8);
+                // all four pixel tiles per k-step when the h2 accumulators are small (12 MFMAs behind one round of LDS reads),
+                // two at a time while 128 of them are still live
+                constexpr int JW = TP2 == 8 ? 2 : 4;
 #pragma unroll
-                for (int jp = 0; jp < 2; ++jp) {
-                    h8 bh[2], bl[2];
+                for (int jp = 0; jp < 4 / JW; ++jp) {
+                    h8 bh[JW], bl[JW];
 #pragma unroll
-                    for (int jj = 0; jj < 2; ++jj) {
-                        bh[jj] = *reinterpret_cast<const h8*>(bs + (2 * jp + jj) * 256);
-                        bl[jj] = *reinterpret_cast<const h8*>(bs + (2 * jp + jj) * 256 + (long)LCH * CN_PX * 8);
+                    for (int jj = 0; jj < JW; ++jj) {
+                        bh[jj] = *reinterpret_cast<const h8*>(bs + (JW * jp + jj) * 256);
+                        bl[jj] = *reinterpret_cast<const h8*>(bs + (JW * jp + jj) * 256 + (long)LCH * CN_PX * 8);
                     }
 #pragma unroll
-                    for (int jj = 0; jj < 2; ++jj)
-                        accT[u][2 * jp + jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bh[jj], accT[u][2 * jp + jj], 0, 0, 0);
+                    for (int jj = 0; jj < JW; ++jj)
+                        accT[u][JW * jp + jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(use[0], bh[jj], accT[u][JW * jp + jj], 0, 0, 0);
 #pragma unroll
-                    for (int jj = 0; jj < 2; ++jj)
-                        accT[u][2 * jp + jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bl[jj], accT[u][2 * jp + jj], 0, 0, 0);
+                    for (int jj = 0; jj < JW; ++jj)
+                        accT[u][JW * jp + jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(use[0], bl[jj], accT[u][JW * jp + jj], 0, 0, 0);
 #pragma unroll
-                    for (int jj = 0; jj < 2; ++jj)
-                        accT[u][2 * jp + jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, bh[jj], accT[u][2 * jp + jj], 0, 0, 0);
+                    for (int jj = 0; jj < JW; ++jj)
+                        accT[u][JW * jp + jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(use[1], bh[jj], accT[u][JW * jp + jj], 0, 0, 0);
                 }
-                ah0 = ah1; al0 = al1; ah1 = ah2; al1 = al2;
+            };
+            int st = 0;
+#pragma unroll 1
+            for (; st + 3 <= nsl; st += 3) {
+                step4(st, A4[0], A4[2]);
+                step4(st + 1, A4[1], A4[0]);
+                step4(st + 2, A4[2], A4[1]);
+            }
+            if (st < nsl) step4(st, A4[0], A4[2]);
+            if (st + 1 < nsl) step4(st + 1, A4[1], A4[0]);
+            // first two A sets of the wave's next (unit, load)
+            {
+                int nu = unit + 8, nl = l;
+                if (u + 1 >= UPW || nu >= nunits) { nu = wid; nl = l + 1; }
+                if (nl < NL && nu < nunits) {
+                    const _Float16* np = a4_base(nu, nl);
+                    loadA4(np, 0, A4[0]);
+                    loadA4(np, nsl > 1 ? 1 : 0, A4[1]);
+                }
             }
         }
+        GH_STAMP(13 + 4 * l);
         __syncthreads();     // hbuf free again (next load / T staging)
+        GH_STAMP(14 + 4 * l);
     }
 
-    // ---- P4: T -> LDS [pixel][Mrow] (fp32, row scale applied), k parts summed in a fixed order, then the 9-tap sums
+    // ---- P4: T -> LDS as fp32 [row m][pixel] (row scale applied; lanes = consecutive pixels: conflict-free stores and tap
+    // reads), k parts summed in a fixed order, then the 9-tap sums
     float* T = reinterpret_cast<float*>(hbuf);
-    const int Mrow = g.Mrow, Cout = a.Cout;
+    const int Cout = a.Cout, M9 = 9 * Cout;
     const bool paired = a.mode == TAIL_AFFINE_FWD || a.mode == TAIL_AFFINE_REV;
     const int nch = paired ? Cout / 2 : Cout;
-    const int ppx = CN_PX / g.npass;                         // pixels per staging pass (whole sub-tiles when npass = 2)
+    const int ppx = 1 << g.lpp;                              // pixels per staging pass (whole sub-tiles when npass = 2)
     const long msN = (long)blockIdx.y * a.N;
     float* hpart = a.scratch;
     float* hup = a.scratch + (long)MS * a.N * Cout * HW;
     float* hdn = hup + (long)MS * g.tiles * Cout * W;
 #pragma unroll 1
     for (int pass = 0; pass < g.npass; ++pass) {
-#pragma unroll 1
-        for (int kp = 0; kp < g.KS; ++kp) {
+        {
 #pragma unroll
             for (int u = 0; u < UPW; ++u) {
                 const int unit = wid + 8 * u;
-                if (unit >= nunits || unit / g.NRT4 != kp) continue;
-                const int rt4 = unit % g.NRT4;
+                if (unit >= nunits) continue;
+                const int rt4 = unit % g.NRT4, kp = unit / g.NRT4;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int q = j * 32 + ml;
-                    if (q / ppx != pass) continue;
+                    if ((q >> g.lpp) != pass) continue;
 #pragma unroll
                     for (int gq = 0; gq < 4; ++gq) {
                         const int m = rt4 * 32 + 8 * gq + 4 * kl;
-                        if (m >= Mrow) continue;
-                        const f32x4_t rs = *reinterpret_cast<const f32x4_t*>(rs4 + m);
-                        f32x4_t* dst = reinterpret_cast<f32x4_t*>(T + (long)(q - pass * ppx) * Mrow + m);
-                        f32x4_t v;
+                        if (m >= M9) continue;                 // 9 * Cout is a multiple of... m + 3 < M9 checked per row below
+                        const f32x4_t rs = *reinterpret_cast<const f32x4_t*>(t_rs4 + m);
+                        float* dst = T + ((long)(kp * M9 + m) << g.lpp) + (q - (pass << g.lpp));   // slab kp: no read-modify-write
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) v[t] = accT[u][j][4 * gq + t] * rs[t];
-                        if (kp > 0) {
-                            const f32x4_t o = *dst;
-#pragma unroll
-                            for (int t = 0; t < 4; ++t) v[t] += o[t];
-                        }
-                        *dst = v;
+                        for (int t = 0; t < 4; ++t)
+                            if (m + t < M9) dst[(long)t << g.lpp] = accT[u][j][4 * gq + t] * rs[t];
                     }
                 }
             }
             __syncthreads();
         }
+        GH_STAMP(20);
         // own rows: out[c][r][x] = sum over taps whose source row r + dy - 1 lies inside the sub-tile
-        const int items = nch * ppx;
+        const int items = nch << g.lpp;
         for (int e = tid; e < items; e += 512) {
-            const int c = e / ppx, ql = e - c * ppx;
-            const int q = pass * ppx + ql;
+            const int c = e >> g.lpp, ql = e & (ppx - 1);
+            const int q = (pass << g.lpp) + ql;
             const int sub = q >> g.lsub, qq = q & submask;
             const int r = qq >> g.wshift, x = qq & (W - 1);
             const long n = n0 + sub;
@@ -437,9 +531,11 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
                     const int xs = x + dx - 1;
                     if (xs < 0 || xs >= W) continue;
                     const int tap = dy * 3 + dx;              // out(r, x) += T[tap (dy, dx)][source (r + dy - 1, x + dx - 1)]
-                    const float* tp = T + (long)(ql + (dy - 1) * W + (dx - 1)) * Mrow + tap * Cout + ce;
-                    se += tp[0];
-                    if (paired) so += tp[1];
+                    const float* tp = T + ((long)(tap * Cout + ce) << g.lpp) + ql + (dy - 1) * W + (dx - 1);
+                    for (int kp = 0; kp < g.KS; ++kp) {        // k parts of the reduction, fixed order
+                        se += tp[(long)(kp * M9) << g.lpp];
+                        if (paired) so += tp[((long)(kp * M9) << g.lpp) + ppx];
+                    }
                 }
             }
             const long base = ((msN + n) * Cout + ce) * HW + (long)(y0 + r) * W + x;
@@ -450,9 +546,9 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
         if (g.NI == 1 && g.R < H) {
             const int hitems = 2 * Cout * W;
             for (int e = tid; e < hitems; e += 512) {
-                const int dn = e / (Cout * W);
+                const int dn = e >= Cout * W;
                 const int rem = e - dn * (Cout * W);
-                const int co = rem / W, x = rem - co * W;
+                const int co = rem >> g.wshift, x = rem & (W - 1);
                 if (dn ? (y0 + g.R >= H) : (y0 == 0)) continue;
                 const int rsrc = dn ? g.R - 1 : 0;
                 const int dyt = dn ? 0 : 2;                 // filter row applied by the outside pixel to this source row
@@ -461,13 +557,15 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
                 for (int dx = 0; dx < 3; ++dx) {
                     const int xs = x + dx - 1;
                     if (xs < 0 || xs >= W) continue;
-                    sacc += T[(long)(rsrc * W + xs) * Mrow + (dyt * 3 + dx) * Cout + co];
+                    for (int kp = 0; kp < g.KS; ++kp)
+                        sacc += T[((long)(kp * M9 + (dyt * 3 + dx) * Cout + co) << g.lpp) + rsrc * W + xs];
                 }
                 (dn ? hdn : hup)[(((long)blockIdx.y * g.tiles + tb) * Cout + co) * W + x] = sacc;
             }
         }
         if (pass + 1 < g.npass) __syncthreads();
     }
+    GH_STAMP(21);
 }
 
 // ------------------------------------------------------------------------------------------------ finishing kernel
@@ -478,20 +576,21 @@ struct CfinArgs {
     int MS, tiles, R, NI, wshift, HW;
 };
 
+template <int PXB>
 __global__ void __launch_bounds__(256) k_cfinish(CfinArgs f) {
-    extern __shared__ __attribute__((aligned(16))) float fsm[];   // [C][64] values, then [C*C] matrix
+    extern __shared__ __attribute__((aligned(16))) float fsm[];   // [C][PXB] values, then [C*C] matrix
     __shared__ double red[4];
     const CnetArgs& a = f.a;
     const int tid = threadIdx.x;
     const int HW = f.HW, W = a.W, H = a.H, Cout = a.Cout;
-    const long gp0 = (long)blockIdx.x * 64;
+    const long gp0 = (long)blockIdx.x * PXB;
     const long n = gp0 / HW;
     const int p0 = (int)(gp0 - n * HW);
     const bool paired = a.mode == TAIL_AFFINE_FWD || a.mode == TAIL_AFFINE_REV;
     const int Ch = paired ? Cout / 2 : Cout;         // channels of z2 (= C/2)
     const int C = 2 * Ch;
     float* mixv = fsm;
-    float* mixm = fsm + C * 64;
+    float* mixm = fsm + C * PXB;
     if (a.mix_C && a.mix_matrix)
         for (int e = tid; e < C * C; e += 256) mixm[e] = a.mix_matrix[e];
     const float* hpart = a.scratch;
@@ -499,35 +598,35 @@ __global__ void __launch_bounds__(256) k_cfinish(CfinArgs f) {
     const float* hdn = hup + (long)f.MS * f.tiles * Cout * W;
     const float* zi = a.z_in + n * a.z_in_bs;
     float* zn = a.z_out + n * a.z_out_bs;
+    const bool halos = f.NI == 1 && f.R < H;
     double ld = 0.0;
-    for (int e = tid; e < Ch * 64; e += 256) {
-        const int c = e >> 6, q = e & 63;
+    for (int e = tid; e < Ch * PXB; e += 256) {
+        const int c = e / PXB, q = e - c * PXB;
         const int p = p0 + q;
         const int y = p >> f.wshift, x = p & (W - 1);
         const int ce = paired ? 2 * c : c;
+        // every load below is unconditional (clamped index, masked value): all of them are in flight together
+        const float zin = zi[(long)(Ch + c) * HW + p];
+        const float z1v = zi[(long)c * HW + p];
         float se = 0.f, so = 0.f;
         for (int m = 0; m < f.MS; ++m) {
             const long base = (((long)m * a.N + n) * Cout + ce) * HW + p;
             se += hpart[base];
-            if (paired) so += hpart[base + HW];
+            so += hpart[base + (paired ? HW : 0)];
         }
-        if (f.NI == 1 && f.R < H) {
+        if (halos) {
             const int r = y & (f.R - 1);
             const long tile = (n * HW + (long)(y - r) * W) >> 7;       // 128-pixel tile holding row y
-            if (r == 0 && y > 0)
-                for (int m = 0; m < f.MS; ++m) {
-                    const long hb = (((long)m * f.tiles + tile - 1) * Cout + ce) * W + x;
-                    se += hdn[hb];
-                    if (paired) so += hdn[hb + W];
-                }
-            if (r == f.R - 1 && y < H - 1)
-                for (int m = 0; m < f.MS; ++m) {
-                    const long hb = (((long)m * f.tiles + tile + 1) * Cout + ce) * W + x;
-                    se += hup[hb];
-                    if (paired) so += hup[hb + W];
-                }
+            const float wd = (r == 0 && y > 0) ? 1.f : 0.f;            // row below the previous tile: its `hdn`
+            const float wu = (r == f.R - 1 && y < H - 1) ? 1.f : 0.f;  // row above the next tile: its `hup`
+            const long td = tile > 0 ? tile - 1 : 0, tu = tile + 1 < f.tiles ? tile + 1 : tile;
+            for (int m = 0; m < f.MS; ++m) {
+                const long hd = (((long)m * f.tiles + td) * Cout + ce) * W + x;
+                const long hu = (((long)m * f.tiles + tu) * Cout + ce) * W + x;
+                se += wd * hdn[hd] + wu * hup[hu];
+                so += wd * hdn[hd + (paired ? W : 0)] + wu * hup[hu + (paired ? W : 0)];
+            }
         }
-        const float zin = zi[(long)(Ch + c) * HW + p];
         const float A_ = (se + a.bias[ce]) * a.scale[ce];
         float zres;
         if (paired) {
@@ -544,13 +643,12 @@ __global__ void __launch_bounds__(256) k_cfinish(CfinArgs f) {
             zres = a.mode == TAIL_ADD_FWD ? zin + A_ : zin - A_;
         }
         if (a.mix_C) {
-            const float z1v = zi[(long)c * HW + p];
             if (!a.mix_reverse) {     // ActNorm of the next step on both halves, staged for its matrix / gather
-                mixv[c * 64 + q] = (z1v + a.mix_bias[c]) * a.mix_scale[c];
-                mixv[(Ch + c) * 64 + q] = (zres + a.mix_bias[Ch + c]) * a.mix_scale[Ch + c];
+                mixv[c * PXB + q] = (z1v + a.mix_bias[c]) * a.mix_scale[c];
+                mixv[(Ch + c) * PXB + q] = (zres + a.mix_bias[Ch + c]) * a.mix_scale[Ch + c];
             } else {
-                mixv[c * 64 + q] = z1v;
-                mixv[(Ch + c) * 64 + q] = zres;
+                mixv[c * PXB + q] = z1v;
+                mixv[(Ch + c) * PXB + q] = zres;
             }
         } else {
             zn[(long)(Ch + c) * HW + p] = zres;
@@ -558,18 +656,38 @@ __global__ void __launch_bounds__(256) k_cfinish(CfinArgs f) {
     }
     if (a.mix_C) {
         __syncthreads();
-        for (int e = tid; e < C * 64; e += 256) {
-            const int o = e >> 6, q = e & 63;
-            float r;
+        // thread = (output group og, pixel q): outputs o = og, og + OG, ... four at a time (the staged value v[i][q] is read once
+        // for four outputs; the matrix rows are wave-uniform LDS broadcasts)
+        constexpr int OG = 256 / PXB;
+        const int q = tid & (PXB - 1), og = tid / PXB;
+        for (int ob = og; ob < C; ob += 4 * OG) {
+            float r[4];
             if (a.mix_matrix) {   // same operation order as k_chanmix: r = fma(m[o][i], v[i], r), i ascending
-                r = 0.f;
-                const float* m = mixm + o * C;
-                for (int i = 0; i < C; ++i) r = fmaf(m[i], mixv[i * 64 + q], r);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) r[j] = 0.f;
+                for (int i = 0; i < C; ++i) {
+                    const float vi = mixv[i * PXB + q];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int o = ob + j * OG;
+                        r[j] = fmaf(mixm[(o < C ? o : 0) * C + i], vi, r[j]);
+                    }
+                }
             } else {
-                r = mixv[(a.mix_gather ? a.mix_gather[o] : o) * 64 + q];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int o = ob + j * OG;
+                    r[j] = mixv[(o < C ? (a.mix_gather ? a.mix_gather[o] : o) : 0) * PXB + q];
+                }
             }
-            if (a.mix_reverse) r = r * a.mix_scale[o] - a.mix_bias[o];
-            zn[(long)o * HW + p0 + q] = r;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int o = ob + j * OG;
+                if (o >= C) continue;
+                float v = r[j];
+                if (a.mix_reverse) v = v * a.mix_scale[o] - a.mix_bias[o];
+                zn[(long)o * HW + p0 + q] = v;
+            }
         }
     }
     if (paired) {
@@ -582,10 +700,15 @@ __global__ void __launch_bounds__(256) k_cfinish(CfinArgs f) {
 static int g_cnet_ms = 0;
 void cnet_force(int ms, int flags) { g_cnet_ms = ms; (void)flags; }
 
-int cnet_g0(int Cin) { return (9 * ((Cin + 7) / 8) + 1) & ~1; }
+int cnet_g0(int Cin) { return (9 * ((Cin + 7) / 8) + 5) / 6 * 6; }   // 8-wide k groups of f.0, padded to whole triples of k-steps
 int cnet_mpad4(int Cout) { return (9 * Cout + 31) / 32 * 32; }
 
 static bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+// LDS: activation buffer + window planes + tables (rs0 | b0 | rs2 | b2 (at most hidden rows) | rs4 | goff)
+static size_t cnet_lds_bytes(const CnetGeo& g, int hidden) {
+    return (size_t)CN_HBUF + (size_t)2 * g.winplane * sizeof(_Float16) + ((size_t)4 * hidden + g.Mpad4 + g.G + 4) * sizeof(float);
+}
 
 static bool cnet_geo(int Cin, int H, int W, int hidden, int Cout, int N, CnetGeo* out) {
     if (!(hidden == 64 || hidden == 128 || hidden == 256 || hidden == 512)) return false;
@@ -609,10 +732,11 @@ static bool cnet_geo(int Cin, int H, int W, int hidden, int Cout, int N, CnetGeo
     g.NRT4 = g.Mpad4 / 32;
     if (g.NRT4 > 16) return false;
     g.KS = g.NRT4 <= 2 ? 4 : (g.NRT4 <= 4 ? 2 : 1);
-    g.npass = (size_t)CN_PX * g.Mrow * sizeof(float) > (size_t)CN_HBUF ? 2 : 1;
-    if (g.npass == 2 && (g.NI != 2 || (size_t)(CN_PX / 2) * g.Mrow * sizeof(float) > (size_t)CN_HBUF)) return false;
+    g.npass = (size_t)CN_PX * 9 * Cout * g.KS * sizeof(float) > (size_t)CN_HBUF ? 2 : 1;     // T staging [k part][9 Cout][pixels] fp32
+    if (g.npass == 2 && (g.NI != 2 || (size_t)(CN_PX / 2) * 9 * Cout * g.KS * sizeof(float) > (size_t)CN_HBUF)) return false;
     g.winplane = g.nchunk * g.NI * g.Wpx * 8;
-    if ((size_t)CN_HBUF + (size_t)2 * g.winplane * sizeof(_Float16) > 160 * 1024) return false;
+    g.lpp = g.npass == 2 ? 6 : 7;
+    if (cnet_lds_bytes(g, hidden) > 160 * 1024) return false;
     g.tiles = N > 0 ? (int)(((long)N * HW + CN_PX - 1) / CN_PX) : 0;
     if (out) *out = g;
     return true;
@@ -632,7 +756,7 @@ size_t cnet_scratch_floats_per_sample(int H, int W, int Cout) {
 
 template <int HID, int MS, int UPW>
 static int launch_cnet_inst(const CnetArgs& a, const CnetGeo& g, hipStream_t s) {
-    const size_t lds = (size_t)CN_HBUF + (size_t)2 * g.winplane * sizeof(_Float16);
+    const size_t lds = cnet_lds_bytes(g, HID);
     (void)hipFuncSetAttribute((const void*)k_cnet<HID, MS, UPW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((k_cnet<HID, MS, UPW>), dim3(g.tiles, MS), dim3(512), lds, s, a, g);
     GH_LAUNCH_CHECK("k_cnet");
@@ -668,10 +792,17 @@ int launch_cnet(const CnetArgs& a, hipStream_t s) {
     const bool paired = a.mode == TAIL_AFFINE_FWD || a.mode == TAIL_AFFINE_REV;
     const int C = 2 * (paired ? a.Cout / 2 : a.Cout);
     GH_REQUIRE(a.mix_C == 0 || a.mix_C == C, "cnet: mixer channel count %d != %d", a.mix_C, C);
-    const size_t flds = ((size_t)C * 64 + (a.mix_C && a.mix_matrix ? (size_t)C * C : 0)) * sizeof(float);
+    const long total_px = (long)a.N * g.HW;
+    const int pxb = total_px < 32768 ? 16 : 64;      // small levels: 16 pixels per workgroup, so that the launch still covers the chip
+    const size_t flds = ((size_t)C * pxb + (a.mix_C && a.mix_matrix ? (size_t)C * C : 0)) * sizeof(float);
     GH_REQUIRE(flds <= 64 * 1024, "cnet: finishing kernel LDS");
-    if (flds > 32 * 1024) (void)hipFuncSetAttribute((const void*)k_cfinish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds);
-    hipLaunchKernelGGL(k_cfinish, dim3((unsigned)((long)a.N * g.HW / 64)), dim3(256), flds, s, f);
+    if (pxb == 16) {
+        if (flds > 32 * 1024) (void)hipFuncSetAttribute((const void*)k_cfinish<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds);
+        hipLaunchKernelGGL(k_cfinish<16>, dim3((unsigned)(total_px / 16)), dim3(256), flds, s, f);
+    } else {
+        if (flds > 32 * 1024) (void)hipFuncSetAttribute((const void*)k_cfinish<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds);
+        hipLaunchKernelGGL(k_cfinish<64>, dim3((unsigned)(total_px / 64)), dim3(256), flds, s, f);
+    }
     GH_LAUNCH_CHECK("k_cfinish");
     return GLOWHIP_OK;
 }

@@ -125,7 +125,7 @@ __global__ void __launch_bounds__(256) k_repack_batched(const RepackJob* __restr
 // SH2 images (sh.h): half [plane][Kp/8][M][8] of w'[r][k] * 2^e[r], then M floats row scale, then M floats bias.  ONE WAVE PER
 // OUTPUT ROW: the row's largest |w'| fixes its exponent e (largest value in [2^12, 2^13)), which needs the whole row first.
 //   SH2_GEMM  (f.2): row o, k = input channel;           w' = w[o][k] exp(3 logs[o]);  rowscale = 2^-e, bias = b' * 16
-//   SH2_FIRST (f.0): row o, k = (tap, chunk, 8 channels); same folding; j.K = G groups
+//   SH2_FIRST (f.0): row o, k = (8-channel chunk, tap, 8 channels), tap fastest; same folding; j.K = G groups
 //   SH2_TAIL  (f.4): row m = tap * Cout + co (< j.Kpad = Mpad4 rows, zero beyond 9 Cout), k = input channel;
 //                    rowscale = 2^-e / 16 (undoes the activation scale as well), no bias
 __global__ void __launch_bounds__(256) k_repack_sh2_batched(const RepackJob* __restrict__ jobs, char* packed) {
@@ -146,8 +146,8 @@ __global__ void __launch_bounds__(256) k_repack_sh2_batched(const RepackJob* __r
             if (j.kind == REPACK_SH2_GEMM) return j.w[(long)r * j.Cin + k] * fold;
             if (j.kind == REPACK_SH2_FIRST) {
                 const int gi = k >> 3, k8 = k & 7;
-                const int tap = gi / nchunk, ci = (gi - tap * nchunk) * 8 + k8;
-                return (gi < 9 * nchunk && ci < j.Cin) ? j.w[((long)r * j.Cin + ci) * 9 + tap] * fold : 0.f;
+                const int ch = gi / 9, tap = gi - ch * 9, ci = ch * 8 + k8;
+                return (ch < nchunk && ci < j.Cin) ? j.w[((long)r * j.Cin + ci) * 9 + tap] * fold : 0.f;
             }
             const int tap = r / j.Cout, co = r - tap * j.Cout;
             return r < 9 * j.Cout ? j.w[((long)co * j.Cin + k) * 9 + tap] : 0.f;
