@@ -242,7 +242,8 @@ int glowhip_plan_timing_read(glowhip_plan* plan, glowhip_timing_record* out, int
  * (split-half f16 path off), | 0x1000 = fp32 tail behind the split-half GEMM, | 0x2000 = fp32-MFMA f.0 writing the
  * split-half tensor, | 0x4000 = f.0 and f.2 as separate kernels, | 0x8000 = k_chanmix instead of the mixer fused into the
  * previous tail; bits 16..19 = 4 or 8: only that wave count of the split-half tail; | 0x100000 = the one-kernel coupling
- * network (cnet) off; | 0x200000 = cnet computes f.0 + f.2 only; bits 22..24 = 1, 2 or 4: that many row splits of cnet.
+ * network (cnet) off; | 0x200000 = cnet computes f.0 + f.2 only; bits 22..24 = 1, 2 or 4: that many row splits of cnet;
+ * | 0x2000000 = cnet with 128-pixel tiles only, | 0x4000000 = 64-pixel tiles wherever supported.
  * 0 restores automatic selection.
  * Process-wide, not thread safe: a testing hook, not part of the operator surface. */
 void glowhip_debug_force_tail_tile(int pixels_and_flags);

@@ -31,10 +31,11 @@ constexpr int CN_HBUF = 128 * 1024;          // bytes of the h1 / h2 / T region
 constexpr int CN_MAXMS = 4;
 
 struct CnetGeo {
-    int wshift, lsub, NI, R, WP, Wpx, nchunk, G, steps0, Mpad4, Mrow, NRT4, KS, npass, tiles;
+    int wshift, lsub, NI, R, WP, Wpx, nchunk, G, steps0, Mpad4, NRT4, NU4, KS, npass, tiles;
     int winplane;     // halfs per window plane
     int HW;
     int lpp;          // log2(pixels per staging pass)
+    int pxt, lpxt;    // pixels per workgroup tile (128 or 64) and its log2
 };
 
 __host__ __device__ inline int cnet_trow(int M9) {   // T row stride (floats): multiple of 4, an odd multiple (bank spread)
@@ -43,25 +44,27 @@ __host__ __device__ inline int cnet_trow(int M9) {   // T row stride (floats): m
     return r * 4;
 }
 
-template <int HID, int MS, int UPW>
+template <int HID, int MS, int UPW, int PXT>
 __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
-    constexpr int NH = HID > 256 ? 2 : 1;            // channel halves of h1 (the LDS buffer holds 256 channels x 128 px)
-    constexpr int HK = HID / NH;                     // channels per half
-    constexpr int NCH = HK / 8;                      // 8-channel chunks per half
+    constexpr int NPT = PXT / 32;                    // pixel tiles of the workgroup: 4 (128 pixels) or 2 (64 pixels)
+    constexpr int CAP = CN_HBUF / (PXT * 4);         // activation channels the LDS buffer holds as (hi, lo) halves: 256 / 512
+    constexpr int NH = HID > CAP ? HID / CAP : 1;    // passes over h1
+    constexpr int HK = HID / NH;                     // channels per pass
+    constexpr int NCH = HK / 8;                      // 8-channel chunks per pass
     constexpr int MR = HID / MS;                     // h2 rows of this workgroup
-    constexpr int TP1 = (HK / 32) * 4 / 8;           // P1 tiles per wave and half: 4 / 2 / 1
-    constexpr int TP2 = (MR / 32) * 4 / 8;           // P2 tiles per wave: 8 / 4 / 2 / 1
+    constexpr int TP1 = (HK / 32) * NPT / 8;         // P1 tiles per wave and pass
+    constexpr int TP2 = (MR / 32) * NPT / 8;         // P2 tiles per wave
     static_assert(TP1 >= 1 && TP2 >= 1, "hidden / MS too small for 8 waves");
-    constexpr int RT2 = TP2 >= 4 ? TP2 / 4 : 1;      // row tiles x pixel tiles of a wave's h2 block
-    constexpr int PT2 = TP2 >= 4 ? 4 : TP2;
-    constexpr int P1SUB = (TP1 == 4 && TP2 == 8) ? 2 : 1;   // P1 in two pixel sub-passes while 128 accumulator registers are live;
-                                                            // otherwise all of a wave's tiles per k-step (12 MFMAs cover the L2 latency of the A sets)
-    constexpr int PTS = TP1 / P1SUB;                 // pixel tiles per P1 sub-pass
-    constexpr int NL = MR > 256 ? 2 : 1;             // loads of h2 into the LDS buffer for P3
+    constexpr int PT1 = TP1 < NPT ? TP1 : NPT, RT1 = TP1 / PT1;   // a wave's h1 block: RT1 row tiles x PT1 pixel tiles
+    constexpr int PT2 = TP2 < NPT ? TP2 : NPT, RT2 = TP2 / PT2;   // a wave's h2 block
+    constexpr int P1SUB = (TP2 == 8 && PT1 == 4) ? 2 : 1;   // P1 in two pixel sub-passes while 128 accumulator registers are live
+    constexpr int PTS = PT1 / P1SUB;                 // pixel tiles per P1 sub-pass
+    constexpr int NL = MR > CAP ? MR / CAP : 1;      // loads of h2 into the LDS buffer for P3
     constexpr int LK = MR / NL;                      // channels per load
     constexpr int LCH = LK / 8;                      // chunks per load
-    constexpr int NS = HK / 16;                      // k-steps of P2 per half
-    static_assert(NS % 3 == 1 || NH == 1, "the set rotation of P2 must end on set 0 for the second half to restart there");
+    constexpr int NS = HK / 16;                      // k-steps of P2 per pass
+    constexpr int RTU = 4 / NPT;                     // row tiles of a T unit (a unit = 4 MFMA tiles: RTU row tiles x all pixel tiles)
+    static_assert(NS % 3 == 1 || NH == 1, "the set rotation of P2 must end on set 0 for the second pass to restart there");
 
     extern __shared__ __attribute__((aligned(16))) _Float16 smem_c[];
     _Float16* hbuf = smem_c;
@@ -80,7 +83,7 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
     const int W = a.W, H = a.H, HW = g.HW;
     const int tb = blockIdx.x;
     const int ms_row0 = blockIdx.y * MR;
-    const long gp0 = (long)tb * CN_PX;
+    const long gp0 = (long)tb * PXT;
     // tile origin: one image (NI = 1: R rows from y0) or NI whole images
     const long n0 = g.NI == 1 ? gp0 / HW : (long)tb * g.NI;
     const int y0 = g.NI == 1 ? (int)((gp0 - n0 * HW) >> g.wshift) : 0;
@@ -98,7 +101,7 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
     const float* rs4 = (const float*)((const char*)a.w4 + sh2_rowscale_off(HID, g.Mpad4));
 
     // ---- wave's h2 block: row tiles [rt2, rt2 + RT2), pixel tiles [pt2, pt2 + PT2)
-    const int rt2 = (wid * TP2) >> 2, pt2 = (wid * TP2) & 3;
+    const int rt2 = (wid * TP2) / NPT, pt2 = (wid * TP2) % NPT;
     const _Float16* a2p = W2 + ((long)kl * HID + ms_row0 + rt2 * 32 + ml) * 8;      // + ks * 2*HID*8 ; + i*256 ; lo: + w2_plane
     h8 A2[3][2 * RT2];     // three k-steps of A fragments in flight: [set][i] hi, [set][RT2 + i] lo
     auto loadA2 = [&](int ks, h8 (&dst)[2 * RT2]) {
@@ -109,14 +112,17 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
             dst[RT2 + i] = *reinterpret_cast<const h8*>(p + i * 256 + w2_plane);
         }
     };
-    // ---- wave's h1 tiles per half: row tile rt1, pixel tiles [pt1, pt1 + TP1)
-    const int rt1 = (wid * TP1) >> 2, pt1 = (wid * TP1) & 3;
-    const _Float16* a1p = W0 + ((long)kl * HID + rt1 * 32 + ml) * 8;               // + half * HK*8 ; + st * 2*HID*8 ; lo: + w0_plane
-    h8 A1[3][2];           // [set]{hi, lo}
-    auto loadA1 = [&](int hh, int st, h8 (&dst)[2]) {
+    // ---- wave's h1 block per pass: row tiles [rt1, rt1 + RT1), pixel tiles [pt1, pt1 + PT1)
+    const int rt1 = (wid * TP1) / NPT, pt1 = (wid * TP1) % NPT;
+    const _Float16* a1p = W0 + ((long)kl * HID + rt1 * 32 + ml) * 8;               // + pass * HK*8 ; + st * 2*HID*8 ; lo: + w0_plane
+    h8 A1[3][2 * RT1];     // [set][i] hi, [set][RT1 + i] lo
+    auto loadA1 = [&](int hh, int st, h8 (&dst)[2 * RT1]) {
         const _Float16* p = a1p + (long)hh * (HK * 8) + (long)st * (2 * HID * 8);
-        dst[0] = *reinterpret_cast<const h8*>(p);
-        dst[1] = *reinterpret_cast<const h8*>(p + w0_plane);
+#pragma unroll
+        for (int i = 0; i < RT1; ++i) {
+            dst[i] = *reinterpret_cast<const h8*>(p + i * 256);
+            dst[RT1 + i] = *reinterpret_cast<const h8*>(p + i * 256 + w0_plane);
+        }
     };
     GH_STAMP(0);
     // requested before the window is built (their L2 round trips overlap P0): the first two A sets of P1 and of P2
@@ -179,29 +185,30 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
 
 #pragma unroll 1
     for (int hh = 0; hh < NH; ++hh) {
-        // ---- P1: h1 channels [hh*HK, hh*HK + HK) of all 128 pixels -> hbuf.  Its first two A sets are already in flight.
+        // ---- P1: h1 channels [hh*HK, hh*HK + HK) of all pixels -> hbuf.  Its first two A sets are already in flight.
 #pragma unroll 1
         for (int sp = 0; sp < P1SUB; ++sp) {
             int pb[PTS];
 #pragma unroll
             for (int j = 0; j < PTS; ++j) pb[j] = pix_base((pt1 + sp * PTS + j) * 32 + ml);
-            f32x16_t acc1[PTS];
+            f32x16_t acc1[RT1][PTS];
 #pragma unroll
-            for (int j = 0; j < PTS; ++j)
+            for (int i = 0; i < RT1; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc1[j][r] = 0.f;
+                for (int j = 0; j < PTS; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc1[i][j][r] = 0.f;
             // k groups of f.0 are ordered (8-channel chunk, tap), tap fastest: group gk -> chunk gk / 9, tap gk % 9 (divisions by
-            // constants); groups past 9 * nchunk carry zero weights and read window offset 0.  The B fragments of step st + 1 --
-            // tap-shifted window addresses -- are requested while the MFMAs of step st issue.  The A sets rotate by NAME (loop
-            // unrolled by three): a rotation by register copies makes the compiler wait for the newest global load at the end
-            // of every step (vmcnt(0)).
+            // constants); groups past 9 * nchunk carry zero weights and read window offset 0.  With at most two pixel tiles the B
+            // fragments of step st + 1 -- tap-shifted window addresses -- are requested while the MFMAs of step st issue.  The A
+            // sets rotate by NAME (loop unrolled by three): a rotation by register copies makes the compiler wait for the newest
+            // global load at the end of every step (vmcnt(0)).
             int gk = kl;
             auto cur_goff = [&]() {
                 const int ch = gk / 9, tap = gk - ch * 9;
                 const int dy = tap / 3, dx = tap - dy * 3;
                 return ch < g.nchunk ? (ch * g.NI * g.Wpx + dy * g.WP + dx) * 8 : 0;
             };
-            auto advance = [&]() { gk += 2; };
             constexpr bool BPRE = PTS <= 2;    // B fragments one step ahead (register budget: only with at most two tiles)
             h8 Bc[2 * PTS], Bn[BPRE ? 2 * PTS : 1];     // [j] hi, [PTS + j] lo
             auto loadB = [&](h8* dst) {
@@ -213,16 +220,22 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
                 }
             };
             if (BPRE) loadB(Bc);
-            auto step1 = [&](int st, const h8 (&use)[2], h8 (&fill)[2]) {
+            auto step1 = [&](int st, const h8 (&use)[2 * RT1], h8 (&fill)[2 * RT1]) {
                 loadA1(hh, min(st + 2, g.steps0 - 1), fill);     // unconditional (clamped): no branch, counted waits
-                if (BPRE) { advance(); loadB(Bn); } else { loadB(Bc); advance(); }
+                if (BPRE) { gk += 2; loadB(Bn); } else { loadB(Bc); gk += 2; }
                 // three sweeps over the tiles: consecutive MFMAs never share an accumulator
 #pragma unroll
-                for (int j = 0; j < PTS; ++j) acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(use[0], Bc[j], acc1[j], 0, 0, 0);
+                for (int i = 0; i < RT1; ++i)
 #pragma unroll
-                for (int j = 0; j < PTS; ++j) acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(use[0], Bc[PTS + j], acc1[j], 0, 0, 0);
+                    for (int j = 0; j < PTS; ++j) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(use[i], Bc[j], acc1[i][j], 0, 0, 0);
 #pragma unroll
-                for (int j = 0; j < PTS; ++j) acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(use[1], Bc[j], acc1[j], 0, 0, 0);
+                for (int i = 0; i < RT1; ++i)
+#pragma unroll
+                    for (int j = 0; j < PTS; ++j) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(use[i], Bc[PTS + j], acc1[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < RT1; ++i)
+#pragma unroll
+                    for (int j = 0; j < PTS; ++j) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(use[RT1 + i], Bc[j], acc1[i][j], 0, 0, 0);
                 if (BPRE) {
 #pragma unroll
                     for (int j = 0; j < 2 * PTS; ++j) Bc[j] = Bn[j];
@@ -234,8 +247,8 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
                 step1(st + 1, A1[1], A1[0]);
                 step1(st + 2, A1[2], A1[1]);
             }
-            // A sets of the next P1 pass (next pixel sub-pass of this half, or the other half): in flight during the epilogue,
-            // the barrier and P2
+            // A sets of the next P1 pass (next pixel sub-pass of this channel pass, or the next channel pass): in flight during
+            // the epilogue, the barrier and P2
             {
                 const int nh = sp + 1 < P1SUB ? hh : hh + 1;
                 if (nh < NH) {
@@ -245,26 +258,28 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
             }
             // relu, split, store into the B-operand image: a lane's 4 consecutive channels = 8 bytes per plane
 #pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                const int o = hh * HK + rt1 * 32 + 8 * gq + 4 * kl;
-                const f32x4_t rs = *reinterpret_cast<const f32x4_t*>(t_rs0 + o);
-                const f32x4_t bb = *reinterpret_cast<const f32x4_t*>(t_b0 + o);
-                const int chunk = rt1 * 4 + gq;
+            for (int i = 0; i < RT1; ++i)
 #pragma unroll
-                for (int j = 0; j < PTS; ++j) {
-                    h4 hi, lo;
+                for (int gq = 0; gq < 4; ++gq) {
+                    const int o = hh * HK + (rt1 + i) * 32 + 8 * gq + 4 * kl;
+                    const f32x4_t rs = *reinterpret_cast<const f32x4_t*>(t_rs0 + o);
+                    const f32x4_t bb = *reinterpret_cast<const f32x4_t*>(t_b0 + o);
+                    const int chunk = (rt1 + i) * 4 + gq;
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const float v = fmaxf(fmaf(acc1[j][4 * gq + t], rs[t], bb[t]), 0.f);
-                        _Float16 x0, x1;
-                        sh2_split(v, x0, x1);
-                        hi[t] = x0; lo[t] = x1;
+                    for (int j = 0; j < PTS; ++j) {
+                        h4 hi, lo;
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            const float v = fmaxf(fmaf(acc1[i][j][4 * gq + t], rs[t], bb[t]), 0.f);
+                            _Float16 x0, x1;
+                            sh2_split(v, x0, x1);
+                            hi[t] = x0; lo[t] = x1;
+                        }
+                        _Float16* dst = hbuf + ((long)chunk * PXT + (pt1 + sp * PTS + j) * 32 + ml) * 8 + 4 * kl;
+                        *reinterpret_cast<h4*>(dst) = hi;
+                        *reinterpret_cast<h4*>(dst + (long)NCH * PXT * 8) = lo;
                     }
-                    _Float16* dst = hbuf + ((long)chunk * CN_PX + (pt1 + sp * PTS + j) * 32 + ml) * 8 + 4 * kl;
-                    *reinterpret_cast<h4*>(dst) = hi;
-                    *reinterpret_cast<h4*>(dst + (long)NCH * CN_PX * 8) = lo;
                 }
-            }
         }
         if (A2_LATE) {
             loadA2(hh * NS, A2[0]);
@@ -274,18 +289,18 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
         __syncthreads();
         GH_STAMP(3 + 4 * hh);
 
-        // ---- P2: acc2 += W2'[rows, half hh] h1[half hh]; B from LDS, A two k-steps ahead from L2
+        // ---- P2: acc2 += W2'[rows, pass hh] h1[pass hh]; B from LDS, A two k-steps ahead from L2
         {
             const int ks0 = hh * NS;
-            const _Float16* bp = hbuf + ((long)kl * CN_PX + pt2 * 32 + ml) * 8;
+            const _Float16* bp = hbuf + ((long)kl * PXT + pt2 * 32 + ml) * 8;
             auto kstep = [&](int s, const h8 (&use)[2 * RT2], h8 (&fill)[2 * RT2]) {
                 loadA2(ks0 + min(s + 2, NS - 1), fill);          // unconditional (clamped)
-                const _Float16* bs = bp + (long)s * (2 * CN_PX * 8);
+                const _Float16* bs = bp + (long)s * (2 * PXT * 8);
                 h8 bh[PT2], bl[PT2];
 #pragma unroll
                 for (int j = 0; j < PT2; ++j) {
                     bh[j] = *reinterpret_cast<const h8*>(bs + j * 256);
-                    bl[j] = *reinterpret_cast<const h8*>(bs + j * 256 + (long)NCH * CN_PX * 8);
+                    bl[j] = *reinterpret_cast<const h8*>(bs + j * 256 + (long)NCH * PXT * 8);
                 }
 #pragma unroll
                 for (int i = 0; i < RT2; ++i)
@@ -311,33 +326,37 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
             }
             if (NS % 3 >= 1) kstep(NS - NS % 3, A2[0], A2[2]);
             if (NS % 3 == 2) kstep(NS - 1, A2[1], A2[0]);
-            if (!A2_LATE && hh + 1 < NH) {   // A sets of the other half's first two k-steps: in flight while P1 rebuilds the LDS buffer
+            if (!A2_LATE && hh + 1 < NH) {   // A sets of the next pass' first two k-steps: in flight while P1 rebuilds the LDS buffer
                 loadA2((hh + 1) * NS, A2[0]);
                 loadA2((hh + 1) * NS + 1, A2[1]);
             }
         }
         GH_STAMP(4 + 4 * hh);
-        __syncthreads();     // every wave is done reading this half of h1
+        __syncthreads();     // every wave is done reading this pass of h1
         GH_STAMP(5 + 4 * hh);
     }
 
-    // ---- P3 set-up: T units of this wave.  unit u = (row tile rt4 = u % NRT4, k part u / NRT4) x all 4 pixel tiles; wave w
+    // ---- P3 set-up: T units of this wave.  unit = (RTU row tiles ru of T, k part kp) x all pixel tiles = 4 MFMA tiles; wave w
     // takes units w (and w + 8 when UPW = 2).  The first two A sets of the first unit are requested NOW.
-    const int nunits = g.NRT4 * g.KS;
+    const int nunits = g.NU4 * g.KS;
     const int nsl = (LK / 16) / g.KS;                        // k-steps of one h2 load per k part
-    h8 A4[3][2];
+    h8 A4[3][2 * RTU];
     auto a4_base = [&](int unit, int l) {
-        const int rt4 = unit % g.NRT4, kp = unit / g.NRT4;
-        return W4 + ((long)((ms_row0 + l * LK) / 8 + 2 * kp * nsl + kl) * g.Mpad4 + rt4 * 32 + ml) * 8;
+        const int kp = unit / g.NU4;
+        return W4 + ((long)((ms_row0 + l * LK) / 8 + 2 * kp * nsl + kl) * g.Mpad4 + ml) * 8;
     };
-    auto loadA4 = [&](const _Float16* ap, int st, h8 (&dst)[2]) {
-        dst[0] = *reinterpret_cast<const h8*>(ap + (long)st * (2 * g.Mpad4 * 8));
-        dst[1] = *reinterpret_cast<const h8*>(ap + (long)st * (2 * g.Mpad4 * 8) + w4_plane);
+    auto loadA4 = [&](const _Float16* ap, int ru, int st, h8 (&dst)[2 * RTU]) {
+#pragma unroll
+        for (int i = 0; i < RTU; ++i) {
+            const int rt4 = min(ru * RTU + i, g.NRT4 - 1);       // a unit's surplus row tile re-reads the last one (never staged)
+            dst[i] = *reinterpret_cast<const h8*>(ap + (long)st * (2 * g.Mpad4 * 8) + rt4 * 256);
+            dst[RTU + i] = *reinterpret_cast<const h8*>(ap + (long)st * (2 * g.Mpad4 * 8) + rt4 * 256 + w4_plane);
+        }
     };
     if (!a.y_sh && wid < nunits) {
         const _Float16* ap = a4_base(wid, 0);
-        loadA4(ap, 0, A4[0]);
-        loadA4(ap, nsl > 1 ? 1 : 0, A4[1]);
+        loadA4(ap, wid % g.NU4, 0, A4[0]);
+        loadA4(ap, wid % g.NU4, nsl > 1 ? 1 : 0, A4[1]);
     }
 
     // ---- h2 = relu(acc2 * rowscale + bias) (times SH2_ACT_SCALE), in place
@@ -381,7 +400,7 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
     }
 
     // ---- P3: T[m][px] = sum_k W4t[m][k] h2[k][px] over this workgroup's h2 rows (= k range [ms_row0, ms_row0 + MR))
-    f32x16_t accT[UPW][4];
+    f32x16_t accT[UPW][4];     // tile 4-index = (row tile within the unit) * NPT + pixel tile
 #pragma unroll
     for (int u = 0; u < UPW; ++u)
 #pragma unroll
@@ -407,9 +426,9 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
                         sh2_split(acc2[i][j][4 * gq + t], x0, x1);
                         hi[t] = x0; lo[t] = x1;
                     }
-                    _Float16* dst = hbuf + ((long)chunk * CN_PX + (pt2 + j) * 32 + ml) * 8 + 4 * kl;
+                    _Float16* dst = hbuf + ((long)chunk * PXT + (pt2 + j) * 32 + ml) * 8 + 4 * kl;
                     *reinterpret_cast<h4*>(dst) = hi;
-                    *reinterpret_cast<h4*>(dst + (long)LCH * CN_PX * 8) = lo;
+                    *reinterpret_cast<h4*>(dst + (long)LCH * PXT * 8) = lo;
                 }
             }
         }
@@ -420,32 +439,41 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
         for (int u = 0; u < UPW; ++u) {
             const int unit = wid + 8 * u;
             if (unit >= nunits) continue;
-            const int kp = unit / g.NRT4;
+            const int kp = unit / g.NU4, ru = unit - kp * g.NU4;
             const _Float16* ap = a4_base(unit, l);
-            const _Float16* bp = hbuf + ((long)(2 * kp * nsl + kl) * CN_PX + ml) * 8;
-            auto step4 = [&](int st, const h8 (&use)[2], h8 (&fill)[2]) {
-                loadA4(ap, min(st + 2, nsl - 1), fill);          // unconditional (clamped)
-                const _Float16* bs = bp + (long)st * (2 * CN_PX * 8);
-                // all four pixel tiles per k-step when the h2 accumulators are small (12 MFMAs behind one round of LDS reads),
-                // two at a time while 128 of them are still live
-                constexpr int JW = TP2 == 8 ? 2 : 4;
+            const _Float16* bp = hbuf + ((long)(2 * kp * nsl + kl) * PXT + ml) * 8;
+            auto step4 = [&](int st, const h8 (&use)[2 * RTU], h8 (&fill)[2 * RTU]) {
+                loadA4(ap, ru, min(st + 2, nsl - 1), fill);      // unconditional (clamped)
+                const _Float16* bs = bp + (long)st * (2 * PXT * 8);
+                // all pixel tiles per k-step when the h2 accumulators are small (12 MFMAs behind one round of LDS reads), two at
+                // a time while 128 of them are still live
+                constexpr int JW = TP2 == 8 ? 2 : NPT;
 #pragma unroll
-                for (int jp = 0; jp < 4 / JW; ++jp) {
+                for (int jp = 0; jp < NPT / JW; ++jp) {
                     h8 bh[JW], bl[JW];
 #pragma unroll
                     for (int jj = 0; jj < JW; ++jj) {
                         bh[jj] = *reinterpret_cast<const h8*>(bs + (JW * jp + jj) * 256);
-                        bl[jj] = *reinterpret_cast<const h8*>(bs + (JW * jp + jj) * 256 + (long)LCH * CN_PX * 8);
+                        bl[jj] = *reinterpret_cast<const h8*>(bs + (JW * jp + jj) * 256 + (long)LCH * PXT * 8);
                     }
 #pragma unroll
-                    for (int jj = 0; jj < JW; ++jj)
-                        accT[u][JW * jp + jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(use[0], bh[jj], accT[u][JW * jp + jj], 0, 0, 0);
+                    for (int i = 0; i < RTU; ++i)
 #pragma unroll
-                    for (int jj = 0; jj < JW; ++jj)
-                        accT[u][JW * jp + jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(use[0], bl[jj], accT[u][JW * jp + jj], 0, 0, 0);
+                        for (int jj = 0; jj < JW; ++jj)
+                            accT[u][i * NPT + JW * jp + jj] =
+                                __builtin_amdgcn_mfma_f32_32x32x16_f16(use[i], bh[jj], accT[u][i * NPT + JW * jp + jj], 0, 0, 0);
 #pragma unroll
-                    for (int jj = 0; jj < JW; ++jj)
-                        accT[u][JW * jp + jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(use[1], bh[jj], accT[u][JW * jp + jj], 0, 0, 0);
+                    for (int i = 0; i < RTU; ++i)
+#pragma unroll
+                        for (int jj = 0; jj < JW; ++jj)
+                            accT[u][i * NPT + JW * jp + jj] =
+                                __builtin_amdgcn_mfma_f32_32x32x16_f16(use[i], bl[jj], accT[u][i * NPT + JW * jp + jj], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < RTU; ++i)
+#pragma unroll
+                        for (int jj = 0; jj < JW; ++jj)
+                            accT[u][i * NPT + JW * jp + jj] =
+                                __builtin_amdgcn_mfma_f32_32x32x16_f16(use[RTU + i], bh[jj], accT[u][i * NPT + JW * jp + jj], 0, 0, 0);
                 }
             };
             int st = 0;
@@ -463,8 +491,8 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
                 if (u + 1 >= UPW || nu >= nunits) { nu = wid; nl = l + 1; }
                 if (nl < NL && nu < nunits) {
                     const _Float16* np = a4_base(nu, nl);
-                    loadA4(np, 0, A4[0]);
-                    loadA4(np, nsl > 1 ? 1 : 0, A4[1]);
+                    loadA4(np, nu % g.NU4, 0, A4[0]);
+                    loadA4(np, nu % g.NU4, nsl > 1 ? 1 : 0, A4[1]);
                 }
             }
         }
@@ -473,8 +501,8 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
         GH_STAMP(14 + 4 * l);
     }
 
-    // ---- P4: T -> LDS as fp32 [row m][pixel] (row scale applied; lanes = consecutive pixels: conflict-free stores and tap
-    // reads), k parts summed in a fixed order, then the 9-tap sums
+    // ---- P4: T -> LDS as fp32 [k part][row m][pixel] (row scale applied; lanes = consecutive pixels: conflict-free stores and
+    // tap reads; one slab per k part, summed in a fixed order by the readers), then the 9-tap sums
     float* T = reinterpret_cast<float*>(hbuf);
     const int Cout = a.Cout, M9 = 9 * Cout;
     const bool paired = a.mode == TAIL_AFFINE_FWD || a.mode == TAIL_AFFINE_REV;
@@ -486,30 +514,28 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
     float* hdn = hup + (long)MS * g.tiles * Cout * W;
 #pragma unroll 1
     for (int pass = 0; pass < g.npass; ++pass) {
-        {
 #pragma unroll
-            for (int u = 0; u < UPW; ++u) {
-                const int unit = wid + 8 * u;
-                if (unit >= nunits) continue;
-                const int rt4 = unit % g.NRT4, kp = unit / g.NRT4;
+        for (int u = 0; u < UPW; ++u) {
+            const int unit = wid + 8 * u;
+            if (unit >= nunits) continue;
+            const int kp = unit / g.NU4, ru = unit - kp * g.NU4;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int q = j * 32 + ml;
-                    if ((q >> g.lpp) != pass) continue;
+            for (int j = 0; j < 4; ++j) {
+                const int q = (j % NPT) * 32 + ml;
+                if ((q >> g.lpp) != pass) continue;
 #pragma unroll
-                    for (int gq = 0; gq < 4; ++gq) {
-                        const int m = rt4 * 32 + 8 * gq + 4 * kl;
-                        if (m >= M9) continue;                 // 9 * Cout is a multiple of... m + 3 < M9 checked per row below
-                        const f32x4_t rs = *reinterpret_cast<const f32x4_t*>(t_rs4 + m);
-                        float* dst = T + ((long)(kp * M9 + m) << g.lpp) + (q - (pass << g.lpp));   // slab kp: no read-modify-write
+                for (int gq = 0; gq < 4; ++gq) {
+                    const int m = (ru * RTU + j / NPT) * 32 + 8 * gq + 4 * kl;
+                    if (m >= M9) continue;
+                    const f32x4_t rs = *reinterpret_cast<const f32x4_t*>(t_rs4 + m);
+                    float* dst = T + ((long)(kp * M9 + m) << g.lpp) + (q - (pass << g.lpp));
 #pragma unroll
-                        for (int t = 0; t < 4; ++t)
-                            if (m + t < M9) dst[(long)t << g.lpp] = accT[u][j][4 * gq + t] * rs[t];
-                    }
+                    for (int t = 0; t < 4; ++t)
+                        if (m + t < M9) dst[(long)t << g.lpp] = accT[u][j][4 * gq + t] * rs[t];
                 }
             }
-            __syncthreads();
         }
+        __syncthreads();
         GH_STAMP(20);
         // own rows: out[c][r][x] = sum over taps whose source row r + dy - 1 lies inside the sub-tile
         const int items = nch << g.lpp;
@@ -531,10 +557,10 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
                     const int xs = x + dx - 1;
                     if (xs < 0 || xs >= W) continue;
                     const int tap = dy * 3 + dx;              // out(r, x) += T[tap (dy, dx)][source (r + dy - 1, x + dx - 1)]
-                    const float* tp = T + ((long)(tap * Cout + ce) << g.lpp) + ql + (dy - 1) * W + (dx - 1);
+                    const float* tp = T + ((tap * Cout + ce) << g.lpp) + ql + (dy - 1) * W + (dx - 1);
                     for (int kp = 0; kp < g.KS; ++kp) {        // k parts of the reduction, fixed order
-                        se += tp[(long)(kp * M9) << g.lpp];
-                        if (paired) so += tp[((long)(kp * M9) << g.lpp) + ppx];
+                        se += tp[(kp * M9) << g.lpp];
+                        if (paired) so += tp[((kp * M9) << g.lpp) + ppx];
                     }
                 }
             }
@@ -558,7 +584,7 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
                     const int xs = x + dx - 1;
                     if (xs < 0 || xs >= W) continue;
                     for (int kp = 0; kp < g.KS; ++kp)
-                        sacc += T[((long)(kp * M9 + (dyt * 3 + dx) * Cout + co) << g.lpp) + rsrc * W + xs];
+                        sacc += T[((kp * M9 + (dyt * 3 + dx) * Cout + co) << g.lpp) + rsrc * W + xs];
                 }
                 (dn ? hdn : hup)[(((long)blockIdx.y * g.tiles + tb) * Cout + co) * W + x] = sacc;
             }
@@ -573,7 +599,7 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
 // (h + bias) * exp(3 logs), coupling, per-sample log-det, then the channel mixer on the finished pixels.
 struct CfinArgs {
     CnetArgs a;
-    int MS, tiles, R, NI, wshift, HW;
+    int MS, tiles, R, NI, wshift, HW, lpxt;
 };
 
 template <int PXB>
@@ -616,7 +642,7 @@ __global__ void __launch_bounds__(256) k_cfinish(CfinArgs f) {
         }
         if (halos) {
             const int r = y & (f.R - 1);
-            const long tile = (n * HW + (long)(y - r) * W) >> 7;       // 128-pixel tile holding row y
+            const long tile = (n * HW + (long)(y - r) * W) >> f.lpxt;  // tile holding row y
             const float wd = (r == 0 && y > 0) ? 1.f : 0.f;            // row below the previous tile: its `hdn`
             const float wu = (r == f.R - 1 && y < H - 1) ? 1.f : 0.f;  // row above the next tile: its `hup`
             const long td = tile > 0 ? tile - 1 : 0, tu = tile + 1 < f.tiles ? tile + 1 : tile;
@@ -697,8 +723,8 @@ __global__ void __launch_bounds__(256) k_cfinish(CfinArgs f) {
 }
 
 // ------------------------------------------------------------------------------------------------ host side
-static int g_cnet_ms = 0;
-void cnet_force(int ms, int flags) { g_cnet_ms = ms; (void)flags; }
+static int g_cnet_ms = 0, g_cnet_flags = 0;
+void cnet_force(int ms, int flags) { g_cnet_ms = ms; g_cnet_flags = flags; }
 
 int cnet_g0(int Cin) { return (9 * ((Cin + 7) / 8) + 5) / 6 * 6; }   // 8-wide k groups of f.0, padded to whole triples of k-steps
 int cnet_mpad4(int Cout) { return (9 * Cout + 31) / 32 * 32; }
@@ -710,17 +736,19 @@ static size_t cnet_lds_bytes(const CnetGeo& g, int hidden) {
     return (size_t)CN_HBUF + (size_t)2 * g.winplane * sizeof(_Float16) + ((size_t)4 * hidden + g.Mpad4 + g.G + 4) * sizeof(float);
 }
 
-static bool cnet_geo(int Cin, int H, int W, int hidden, int Cout, int N, CnetGeo* out) {
+static bool cnet_geo(int Cin, int H, int W, int hidden, int Cout, int N, int pxt, CnetGeo* out) {
     if (!(hidden == 64 || hidden == 128 || hidden == 256 || hidden == 512)) return false;
-    if (!pow2(W) || !pow2(H) || W < 4 || W > 128) return false;
+    if (pxt == 64 && hidden < 128) return false;
+    if (!pow2(W) || !pow2(H) || W < 4 || W > pxt) return false;
     const int HW = H * W;
     if (HW < 64) return false;
     if (Cin < 1 || Cout < 1 || Cout > 56) return false;
     CnetGeo g{};
     g.HW = HW;
+    g.pxt = pxt; g.lpxt = __builtin_ctz(pxt);
     g.wshift = __builtin_ctz(W);
-    if (HW >= CN_PX) { g.NI = 1; g.R = CN_PX / W; g.lsub = 7; }
-    else { g.NI = CN_PX / HW; g.R = H; g.lsub = __builtin_ctz(HW); }
+    if (HW >= pxt) { g.NI = 1; g.R = pxt / W; g.lsub = g.lpxt; }
+    else { g.NI = pxt / HW; g.R = H; g.lsub = __builtin_ctz(HW); }
     if (g.NI > 2) return false;
     g.WP = W + 2;
     g.Wpx = (g.R + 2) * g.WP;
@@ -728,67 +756,85 @@ static bool cnet_geo(int Cin, int H, int W, int hidden, int Cout, int N, CnetGeo
     g.G = cnet_g0(Cin);
     g.steps0 = g.G / 2;
     g.Mpad4 = cnet_mpad4(Cout);
-    g.Mrow = cnet_trow(9 * Cout);
     g.NRT4 = g.Mpad4 / 32;
     if (g.NRT4 > 16) return false;
-    g.KS = g.NRT4 <= 2 ? 4 : (g.NRT4 <= 4 ? 2 : 1);
-    g.npass = (size_t)CN_PX * 9 * Cout * g.KS * sizeof(float) > (size_t)CN_HBUF ? 2 : 1;     // T staging [k part][9 Cout][pixels] fp32
-    if (g.npass == 2 && (g.NI != 2 || (size_t)(CN_PX / 2) * 9 * Cout * g.KS * sizeof(float) > (size_t)CN_HBUF)) return false;
+    const int rtu = 4 / (pxt / 32);                     // row tiles of T per unit
+    g.NU4 = (g.NRT4 + rtu - 1) / rtu;
+    g.KS = g.NU4 <= 2 ? 4 : (g.NU4 <= 4 ? 2 : 1);
+    if ((hidden / CN_MAXMS / 16) / g.KS < 1 && g.KS > 1) g.KS = 1;      // (at least one k-step per part at the largest row split)
+    g.npass = (size_t)pxt * 9 * Cout * g.KS * sizeof(float) > (size_t)CN_HBUF ? 2 : 1;     // T staging [k part][9 Cout][pixels] fp32
+    if (g.npass == 2 && (g.NI != 2 || (size_t)(pxt / 2) * 9 * Cout * g.KS * sizeof(float) > (size_t)CN_HBUF)) return false;
     g.winplane = g.nchunk * g.NI * g.Wpx * 8;
-    g.lpp = g.npass == 2 ? 6 : 7;
+    g.lpp = g.lpxt - (g.npass - 1);
     if (cnet_lds_bytes(g, hidden) > 160 * 1024) return false;
-    g.tiles = N > 0 ? (int)(((long)N * HW + CN_PX - 1) / CN_PX) : 0;
+    g.tiles = N > 0 ? (int)(((long)N * HW + pxt - 1) / pxt) : 0;
     if (out) *out = g;
     return true;
 }
 
-bool cnet_supported(int Cin, int H, int W, int hidden, int Cout) { return cnet_geo(Cin, H, W, hidden, Cout, 0, nullptr); }
+bool cnet_supported(int Cin, int H, int W, int hidden, int Cout) {
+    return cnet_geo(Cin, H, W, hidden, Cout, 0, 128, nullptr) || cnet_geo(Cin, H, W, hidden, Cout, 0, 64, nullptr);
+}
 
+// scratch: MS partial copies of the f.4 output + the halo rows of every tile (bounded with the smaller tile, the larger split)
 size_t cnet_scratch_floats(int N, int H, int W, int Cout) {
-    const long tiles = ((long)N * H * W + CN_PX - 1) / CN_PX;
+    const long tiles = ((long)N * H * W + 63) / 64;
     return (size_t)CN_MAXMS * ((size_t)N * Cout * H * W + (size_t)2 * tiles * Cout * W);
 }
 
 size_t cnet_scratch_floats_per_sample(int H, int W, int Cout) {
-    const long tiles = ((long)H * W + CN_PX - 1) / CN_PX;
+    const long tiles = ((long)H * W + 63) / 64;
     return (size_t)CN_MAXMS * ((size_t)Cout * H * W + (size_t)2 * tiles * Cout * W);
 }
 
-template <int HID, int MS, int UPW>
+template <int HID, int MS, int UPW, int PXT>
 static int launch_cnet_inst(const CnetArgs& a, const CnetGeo& g, hipStream_t s) {
     const size_t lds = cnet_lds_bytes(g, HID);
-    (void)hipFuncSetAttribute((const void*)k_cnet<HID, MS, UPW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((k_cnet<HID, MS, UPW>), dim3(g.tiles, MS), dim3(512), lds, s, a, g);
+    (void)hipFuncSetAttribute((const void*)k_cnet<HID, MS, UPW, PXT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((k_cnet<HID, MS, UPW, PXT>), dim3(g.tiles, MS), dim3(512), lds, s, a, g);
     GH_LAUNCH_CHECK("k_cnet");
     return GLOWHIP_OK;
 }
 
 int launch_cnet(const CnetArgs& a, hipStream_t s) {
-    CnetGeo g;
-    GH_REQUIRE(cnet_geo(a.Cin, a.H, a.W, a.hidden, a.Cout, a.N, &g), "cnet: unsupported shape");
     GH_REQUIRE(a.mode == TAIL_AFFINE_FWD || a.mode == TAIL_AFFINE_REV || a.mode == TAIL_ADD_FWD || a.mode == TAIL_ADD_REV,
                "cnet: coupling modes only");
     if (a.N == 0) return GLOWHIP_OK;
-    // rows of h2 per workgroup: split them over MS workgroups when the pixel tiles alone leave most CUs idle
+    // Tile size and row split.  128-pixel tiles halve the weight bytes per MFMA and are taken whenever they alone give every CU a
+    // workgroup.  Below that, 64-pixel tiles double the workgroup count without recomputing anything; splitting the h2 rows over
+    // MS workgroups per tile (each recomputing h1) comes last.
+    CnetGeo g128, g64, g;
+    const bool ok128 = cnet_geo(a.Cin, a.H, a.W, a.hidden, a.Cout, a.N, 128, &g128);
+    const bool ok64 = cnet_geo(a.Cin, a.H, a.W, a.hidden, a.Cout, a.N, 64, &g64);
+    GH_REQUIRE(ok128 || ok64, "cnet: unsupported shape");
+    bool use64 = !ok128 || (ok64 && g128.tiles < 224);
+    if (g_cnet_flags & 1) use64 = !ok128;      // testing: 128-pixel tiles wherever they exist
+    if (g_cnet_flags & 2) use64 = ok64;        // testing: 64-pixel tiles wherever they exist
+    if (a.y_sh && ok128) use64 = false;
+    g = use64 ? g64 : g128;
     int ms = 1;
-    const int ms_max = std::min(CN_MAXMS, a.hidden / 64);
+    const int ms_max = std::min(CN_MAXMS, a.hidden / (use64 ? 128 : 64));
     while (ms < ms_max && g.tiles * ms < 160) ms *= 2;
     if (g_cnet_ms) ms = std::min(g_cnet_ms, ms_max);
     if (a.y_sh) ms = 1;
-    // T units per wave: (row tiles of T) x (k parts) over 8 waves.  Two units per wave next to the 128 accumulator registers of
-    // a 512-row h2 block would spill: that combination runs with the rows split in two
-    const int upw = g.NRT4 * g.KS > 8 ? 2 : 1;
-    if (upw == 2 && a.hidden == 512 && ms == 1 && !a.y_sh) ms = 2;
+    // T units per wave: (unit rows of T) x (k parts) over 8 waves.  Two units per wave next to the 128 accumulator registers of
+    // a 512-row x 128-pixel h2 block would spill: that combination runs with the rows split in two
+    const int upw = g.NU4 * g.KS > 8 ? 2 : 1;
+    if (upw == 2 && a.hidden == 512 && ms == 1 && !use64 && !a.y_sh) ms = 2;
+    while ((a.hidden / ms / 16) / g.KS < 1 && ms > 1) ms /= 2;
     int rc = GLOWHIP_EINVAL;
-#define GH_CN(hid, m, u) if (a.hidden == hid && ms == m && upw == u) rc = launch_cnet_inst<hid, m, u>(a, g, s);
-    GH_CN(512, 1, 1) GH_CN(512, 2, 1) GH_CN(512, 4, 1) GH_CN(256, 1, 1) GH_CN(256, 2, 1) GH_CN(256, 4, 1) GH_CN(128, 1, 1)
-    GH_CN(128, 2, 1) GH_CN(64, 1, 1)
-    GH_CN(512, 2, 2) GH_CN(512, 4, 2) GH_CN(256, 1, 2) GH_CN(256, 2, 2) GH_CN(256, 4, 2) GH_CN(128, 1, 2) GH_CN(128, 2, 2)
-    GH_CN(64, 1, 2)
+#define GH_CN(hid, m, u, px) if (a.hidden == hid && ms == m && upw == u && g.pxt == px) rc = launch_cnet_inst<hid, m, u, px>(a, g, s);
+    GH_CN(512, 1, 1, 128) GH_CN(512, 2, 1, 128) GH_CN(512, 4, 1, 128) GH_CN(256, 1, 1, 128) GH_CN(256, 2, 1, 128) GH_CN(256, 4, 1, 128)
+    GH_CN(128, 1, 1, 128) GH_CN(128, 2, 1, 128) GH_CN(64, 1, 1, 128)
+    GH_CN(512, 2, 2, 128) GH_CN(512, 4, 2, 128) GH_CN(256, 1, 2, 128) GH_CN(256, 2, 2, 128) GH_CN(256, 4, 2, 128) GH_CN(128, 1, 2, 128)
+    GH_CN(128, 2, 2, 128) GH_CN(64, 1, 2, 128)
+    GH_CN(512, 1, 1, 64) GH_CN(512, 2, 1, 64) GH_CN(512, 4, 1, 64) GH_CN(256, 1, 1, 64) GH_CN(256, 2, 1, 64) GH_CN(128, 1, 1, 64)
+    GH_CN(512, 1, 2, 64) GH_CN(512, 2, 2, 64) GH_CN(512, 4, 2, 64) GH_CN(256, 1, 2, 64) GH_CN(256, 2, 2, 64) GH_CN(128, 1, 2, 64)
 #undef GH_CN
+    if (rc == GLOWHIP_EINVAL) set_error("cnet: no kernel instance for hidden=%d ms=%d upw=%d tile=%d", a.hidden, ms, upw, g.pxt);
     GH_TRY(rc);
     if (a.y_sh) return GLOWHIP_OK;
-    CfinArgs f{a, ms, g.tiles, g.R, g.NI, g.wshift, g.HW};
+    CfinArgs f{a, ms, g.tiles, g.R, g.NI, g.wshift, g.HW, g.lpxt};
     const bool paired = a.mode == TAIL_AFFINE_FWD || a.mode == TAIL_AFFINE_REV;
     const int C = 2 * (paired ? a.Cout / 2 : a.Cout);
     GH_REQUIRE(a.mix_C == 0 || a.mix_C == C, "cnet: mixer channel count %d != %d", a.mix_C, C);
