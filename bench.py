@@ -345,9 +345,10 @@ def main():
         recs = plan.timing_read()
         plan.timing(False)
         hid = hps.model.hidden_channels
-        kinds = {0: "chanmix", 1: "conv_f0_3x3", 2: "conv_f2_1x1", 3: "conv_f4_3x3_tail"}
+        kinds = {0: "chanmix", 1: "conv_f0_3x3", 2: "conv_f2_1x1", 3: "conv_f4_3x3_tail", 5: "cnet_f0+f2+f4", 6: "cnet_finish"}
         desc = plan.describe(B)
-        sh_path = "f2=mfma-sh" in desc
+        cnet_path = "cnet-sh2" in desc
+        sh_path = "f2=mfma-sh" in desc or cnet_path
         fused = {int(l.split()[0]) for l in desc.splitlines() if "-sh-fused" in l}   # layers whose f.0 + f.2 run as k_f02_sh at this N
         bd = {}
         dom_ms, dom_flop, dom_bytes, dom_n = 0.0, 0.0, 0.0, 0
@@ -361,7 +362,16 @@ def main():
             bd[key][1] += 1
             total_px = B * d.H * d.W
             uses_128 = (hid // 128) * ((total_px + 127) // 128) >= 512
-            if sh_path:
+            cout = d.C if hps.ablation.flow_coupling == "affine" else d.C // 2
+            if cnet_path:
+                # dominant kernel = k_cnet: the whole coupling network of a FlowStep (f.0 3x3, f.2 1x1, f.4 3x3) in one launch;
+                # h1 and h2 never reach HBM: algorithmic bytes = read z1 + write the f.4 partial sums (+ halo rows, ignored)
+                if kind == 5:
+                    dom_ms += ms
+                    dom_flop += 2.0 * (9 * (d.C // 2) * hid + hid * hid + 9 * hid * cout) * total_px
+                    dom_bytes += 4.0 * (d.C // 2) * total_px + 4.0 * cout * total_px
+                    dom_n += 1
+            elif sh_path:
                 # dominant kernel = k_f02_sh: f.0 (3x3, C/2 -> hidden) + f.2 (1x1, hidden -> hidden) fused, h1 never in HBM
                 if key.startswith("conv_f0+f2_fused"):
                     dom_ms += ms
@@ -378,12 +388,16 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath) and args.config == "B" and B == 64 and args.mode == "forward":
             tj = json.load(open(tpath))
-            traffic = tj.get("k_f02_sh_hbm_bytes_per_launch" if sh_path else "k_gemm_glds_hbm_bytes_per_launch")
+            traffic = tj.get("k_cnet_hbm_bytes_per_launch" if cnet_path else ("k_f02_sh_hbm_bytes_per_launch" if sh_path else "k_gemm_glds_hbm_bytes_per_launch"))
             traffic_src = {"file": "profiles/pmc_traffic.json", "collected_at_commit": tj.get("commit"),
                            "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (scripts/prof_pmc.sh), not re-measured by this run"}
         peak = PEAK_SPLIT_TFLOPS if sh_path else PEAK_FP32_MFMA_TFLOPS
         out["roofline"] = {"bound": "mfma",
-                           "kernel": ("k_f02_sh (f.0 3x3 conv C/2->512 + f.2 1x1 conv 512->512, both with ActNorm + ReLU, fused; "
+                           "kernel": ("k_cnet (the coupling network of a FlowStep in ONE launch: f.0 3x3 conv C/2->512 + ActNorm + ReLU, f.2 "
+                                      "1x1 conv 512->512 + ActNorm + ReLU, f.4 3x3 conv 512->C as taps-as-rows GEMM + tap sums; h1, h2 stay in "
+                                      "LDS / registers; fp32-accurate products as 3 f16 MFMAs, peak = 2500/3 TFLOP/s algorithmic; all three "
+                                      "levels' launches)") if cnet_path else
+                                     ("k_f02_sh (f.0 3x3 conv C/2->512 + f.2 1x1 conv 512->512, both with ActNorm + ReLU, fused; "
                                       "fp32-accurate products as 3 f16 MFMAs, peak = 2500/3 TFLOP/s algorithmic)") if sh_path else
                                      "k_gemm_glds (f.2: 1x1 conv 512->512 + ActNorm + ReLU, fp32-input MFMA, 128x128 tiles)",
                            "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",

@@ -225,7 +225,7 @@ int glowhip_glow_backward(glowhip_plan* plan, const void* packed, const float* x
  * every encode/decode appends records.  glowhip_plan_timing_read synchronises with the recorded events,
  * copies up to `max` records (launch order) and clears the list. */
 enum { GLOWHIP_K_CHANMIX = 0, GLOWHIP_K_CONV_F0 = 1, GLOWHIP_K_CONV_F2 = 2, GLOWHIP_K_CONV_F4 = 3, GLOWHIP_K_OTHER = 4,
-       GLOWHIP_K_CNET = 5 /* whole coupling network + finishing kernel */ };
+       GLOWHIP_K_CNET = 5 /* k_cnet: f.0 + f.2 + f.4 of a FlowStep */, GLOWHIP_K_CFINISH = 6 /* its finishing kernel */ };
 typedef struct glowhip_timing_record {
     int32_t kind;   /* GLOWHIP_K_* */
     int32_t layer;  /* index into the plan's layer list */
@@ -243,7 +243,8 @@ int glowhip_plan_timing_read(glowhip_plan* plan, glowhip_timing_record* out, int
  * split-half tensor, | 0x4000 = f.0 and f.2 as separate kernels, | 0x8000 = k_chanmix instead of the mixer fused into the
  * previous tail; bits 16..19 = 4 or 8: only that wave count of the split-half tail; | 0x100000 = the one-kernel coupling
  * network (cnet) off; | 0x200000 = cnet computes f.0 + f.2 only; bits 22..24 = 1, 2 or 4: that many row splits of cnet;
- * | 0x2000000 = cnet with 128-pixel tiles only, | 0x4000000 = 64-pixel tiles wherever supported.
+ * | 0x2000000 = cnet with 128-pixel tiles only, | 0x4000000 = 64-pixel tiles wherever supported,
+ * | 0x8000000 = the finishing step of a FlowStep runs inside the next FlowStep's k_cnet (off by default: measured slower).
  * 0 restores automatic selection.
  * Process-wide, not thread safe: a testing hook, not part of the operator surface. */
 void glowhip_debug_force_tail_tile(int pixels_and_flags);

@@ -44,6 +44,77 @@ __host__ __device__ inline int cnet_trow(int M9) {   // T row stride (floats): m
     return r * 4;
 }
 
+// ------------------------------------------------------------------------------------------------ finishing arithmetic
+// Shared by the finishing kernel and by k_cnet's window-time finishing of the previous step: the two must agree bit for bit.
+struct FinSrc {
+    const float* hpart; const float* hup; const float* hdn;      // partial sums of h = f(z1): own rows, halo rows up / down
+    const float* bias; const float* scale;                       // f.4 bias, exp(3 logs)
+    int MS, tiles, R, lpxt, N, Cout, HW, W, H, wshift, mode;
+    bool halos, paired;
+};
+
+__device__ __forceinline__ FinSrc fin_src(const CnetPending& p, int N, int H, int W, int HW, int wshift) {
+    FinSrc f;
+    f.hpart = p.scratch;
+    f.hup = p.scratch + (long)p.MS * N * p.Cout * HW;
+    f.hdn = f.hup + (long)p.MS * p.tiles * p.Cout * W;
+    f.bias = p.bias; f.scale = p.scale;
+    f.MS = p.MS; f.tiles = p.tiles; f.R = p.R; f.lpxt = p.lpxt; f.N = N; f.Cout = p.Cout; f.HW = HW; f.W = W; f.H = H;
+    f.wshift = wshift; f.mode = p.mode;
+    f.halos = p.NI == 1 && p.R < H;
+    f.paired = p.mode == TAIL_AFFINE_FWD || p.mode == TAIL_AFFINE_REV;
+    return f;
+}
+
+// Updated z2 value of coupling channel c at pixel p of image n, given its current value zin; the log-det term of the element is
+// added to ldq as Q31.32 fixed point (integer sums are exact: the per-sample total does not depend on how elements are grouped
+// into workgroups, so both users produce the same bits).  Every load is unconditional (clamped index, masked value).
+__device__ __forceinline__ float fin_couple(const FinSrc& f, long n, int c, int p, float zin, long long& ldq) {
+    const int y = p >> f.wshift, x = p & (f.W - 1);
+    const int ce = f.paired ? 2 * c : c;
+    float se = 0.f, so = 0.f;
+    for (int m = 0; m < f.MS; ++m) {
+        const long base = (((long)m * f.N + n) * f.Cout + ce) * f.HW + p;
+        se += f.hpart[base];
+        so += f.hpart[base + (f.paired ? f.HW : 0)];
+    }
+    if (f.halos) {
+        const int r = y & (f.R - 1);
+        const long tile = (n * f.HW + (long)(y - r) * f.W) >> f.lpxt;    // tile holding row y
+        const float wd = (r == 0 && y > 0) ? 1.f : 0.f;                   // row below the previous tile: its `hdn`
+        const float wu = (r == f.R - 1 && y < f.H - 1) ? 1.f : 0.f;       // row above the next tile: its `hup`
+        const long td = tile > 0 ? tile - 1 : 0, tu = tile + 1 < f.tiles ? tile + 1 : tile;
+        for (int m = 0; m < f.MS; ++m) {
+            const long hd = (((long)m * f.tiles + td) * f.Cout + ce) * f.W + x;
+            const long hu = (((long)m * f.tiles + tu) * f.Cout + ce) * f.W + x;
+            se += wd * f.hdn[hd] + wu * f.hup[hu];
+            so += wd * f.hdn[hd + (f.paired ? f.W : 0)] + wu * f.hup[hu + (f.paired ? f.W : 0)];
+        }
+    }
+    const float A_ = (se + f.bias[ce]) * f.scale[ce];
+    if (!f.paired) return f.mode == TAIL_ADD_FWD ? zin + A_ : zin - A_;
+    const float B_ = (so + f.bias[ce + 1]) * f.scale[ce + 1];
+    const float sc = sigmoidf_(B_ + 2.0f);
+    const long long lq = __double2ll_rn((double)logf(sc) * FIX_SCALE);
+    if (f.mode == TAIL_AFFINE_FWD) { ldq += lq; return (zin + A_) * sc; }
+    ldq -= lq;
+    return zin / sc - A_;
+}
+
+// sum of a Q31.32 term over a workgroup of NT threads (valid in thread 0); red: NT / 64 slots of LDS
+template <int NT>
+__device__ __forceinline__ long long block_sum_ll(long long v, long long* red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    long long t = 0;
+    if (threadIdx.x == 0)
+        for (int i = 0; i < NT / 64; ++i) t += red[i];
+    __syncthreads();
+    return t;
+}
+
 template <int HID, int MS, int UPW, int PXT>
 __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
     constexpr int NPT = PXT / 32;                    // pixel tiles of the workgroup: 4 (128 pixels) or 2 (64 pixels)
@@ -138,22 +209,95 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
     for (int e = tid; e < 2 * HID; e += 512) t_rs0[e] = rs0[e];                               // rs0 | b0 are adjacent in the image
     for (int e = tid; e < MR; e += 512) { t_rs2[e] = rs2[ms_row0 + e]; t_b2[e] = rs2[HID + ms_row0 + e]; }
     for (int e = tid; e < g.Mpad4; e += 512) t_rs4[e] = rs4[e];
+    const int nwin = g.NI * g.Wpx;
+    float* nz = nullptr;     // with `pre`: z1 of the freshly finished state at every window pixel, fp32 [Cin][nwin] in LDS
+    if (a.pre_on) {
+        // ---- finish the PREVIOUS step on every window pixel: coupling (+ log-det for the tile's own pixels), then the channel
+        // mixer; the result of the own pixels goes to pre_z_new, z1 of all window pixels to `nz` (hbuf is free at this point)
+        const FinSrc f = fin_src(a.pre, a.N, H, W, HW, g.wshift);
+        const int Ch = f.paired ? f.Cout / 2 : f.Cout, C = 2 * Ch;
+        float* pv = reinterpret_cast<float*>(hbuf);          // [C][nwin] staged values
+        float* pm = pv + C * nwin;                           // [C][C] mixer matrix
+        nz = pm + C * C;
+        long long* red = reinterpret_cast<long long*>(nz + a.Cin * nwin + (((size_t)(nz + a.Cin * nwin) & 4) ? 1 : 0));
+        if (a.pre_mix.matrix)
+            for (int e = tid; e < C * C; e += 512) pm[e] = a.pre_mix.matrix[e];
+        long long ldq[2] = {0, 0};
+        for (int e = tid; e < Ch * nwin; e += 512) {
+            const int c = e / nwin, w = e - c * nwin;
+            const int sub = w / g.Wpx, wp = w - sub * g.Wpx;
+            const int r = wp / g.WP, col = wp - r * g.WP;
+            const int yy = y0 - 1 + r, xx = col - 1;
+            const long n = n0 + sub;
+            const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W && n < a.N;
+            float v1 = 0.f, v2 = 0.f;
+            if (in) {
+                const int p = yy * W + xx;
+                const float* zp = a.pre.z + n * a.pre.z_bs;
+                const float z1v = zp[(long)c * HW + p];
+                const float zin = zp[(long)(Ch + c) * HW + p];
+                long long lq = 0;
+                const float zres = fin_couple(f, n, c, p, zin, lq);
+                if (r >= 1 && r <= g.R && blockIdx.y == 0) ldq[sub & 1] += lq;   // own pixel (not a halo row), once per tile: counts for the log-det
+                if (!a.pre_mix.reverse && a.pre_mix.C) {             // ActNorm of the mixer on both halves, staged for its matrix / gather
+                    v1 = (z1v + a.pre_mix.bias[c]) * a.pre_mix.scale[c];
+                    v2 = (zres + a.pre_mix.bias[Ch + c]) * a.pre_mix.scale[Ch + c];
+                } else { v1 = z1v; v2 = zres; }
+            }
+            pv[c * nwin + w] = v1;
+            pv[(Ch + c) * nwin + w] = v2;
+        }
+        __syncthreads();
+        for (int e = tid; e < C * nwin; e += 512) {
+            const int o = e / nwin, w = e - o * nwin;
+            const int sub = w / g.Wpx, wp = w - sub * g.Wpx;
+            const int r = wp / g.WP, col = wp - r * g.WP;
+            const int yy = y0 - 1 + r, xx = col - 1;
+            const long n = n0 + sub;
+            const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W && n < a.N;
+            float rr = 0.f;
+            if (in) {
+                if (a.pre_mix.matrix) {   // same operation order as k_chanmix / k_cfinish: r = fma(m[o][i], v[i], r), i ascending
+                    const float* m = pm + o * C;
+                    for (int i = 0; i < C; ++i) rr = fmaf(m[i], pv[i * nwin + w], rr);
+                } else {
+                    rr = pv[(a.pre_mix.gather ? a.pre_mix.gather[o] : o) * nwin + w];
+                }
+                if (a.pre_mix.reverse && a.pre_mix.C) rr = rr * a.pre_mix.scale[o] - a.pre_mix.bias[o];
+                if (r >= 1 && r <= g.R && blockIdx.y == 0) a.pre_z_new[n * a.pre_z_new_bs + (long)o * HW + yy * W + xx] = rr;
+            }
+            if (o < a.Cin) nz[o * nwin + w] = rr;
+        }
+        if (f.paired) {
+            for (int sb = 0; sb < g.NI; ++sb) {
+                const long long tot = block_sum_ll<512>(ldq[sb], red);
+                if (tid == 0 && n0 + sb < a.N) atomicAdd(a.acc + (n0 + sb), (unsigned long long)tot);
+            }
+        } else {
+            __syncthreads();
+        }
+    }
     {
-        const int nslots = g.nchunk * g.NI * g.Wpx;
+        const int nslots = g.nchunk * nwin;
         for (int e = tid; e < nslots; e += 512) {
-            const int ch = e / (g.NI * g.Wpx);
-            const int rem = e - ch * (g.NI * g.Wpx);
+            const int ch = e / nwin;
+            const int rem = e - ch * nwin;
             const int sub = rem / g.Wpx, wp = rem - sub * g.Wpx;
             const int r = wp / g.WP, c = wp - r * g.WP;
             const int yy = y0 - 1 + r, xx = c - 1;
             const long n = n0 + sub;
             const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W && n < a.N;
-            // every load is issued unconditionally from a clamped (valid) address and masked afterwards: eight independent loads
-            // in flight per slot instead of eight round trips behind one another
-            const float* xin = a.x + (n < a.N ? n : (long)a.N - 1) * a.x_bs + min(max(yy, 0), H - 1) * W + min(max(xx, 0), W - 1);
             float v[8];
+            if (nz) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = xin[(long)min(ch * 8 + q, a.Cin - 1) * HW];
+                for (int q = 0; q < 8; ++q) v[q] = nz[min(ch * 8 + q, a.Cin - 1) * nwin + rem];
+            } else {
+                // every load is issued unconditionally from a clamped (valid) address and masked afterwards: eight independent
+                // loads in flight per slot instead of eight round trips behind one another
+                const float* xin = a.x + (n < a.N ? n : (long)a.N - 1) * a.x_bs + min(max(yy, 0), H - 1) * W + min(max(xx, 0), W - 1);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = xin[(long)min(ch * 8 + q, a.Cin - 1) * HW];
+            }
             h8 hi, lo;
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
@@ -598,89 +742,52 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
 // One workgroup = 64 consecutive pixels of one image x all channels: sums the MS partials and the neighbour tiles' halo rows,
 // (h + bias) * exp(3 logs), coupling, per-sample log-det, then the channel mixer on the finished pixels.
 struct CfinArgs {
-    CnetArgs a;
-    int MS, tiles, R, NI, wshift, HW, lpxt;
+    CnetPending p;            // partial sums + coupling of the step being finished
+    CnetMixer mix;
+    float* z_out; long z_out_bs;
+    unsigned long long* acc;
+    int N, H, W, HW, wshift;
 };
 
 template <int PXB>
-__global__ void __launch_bounds__(256) k_cfinish(CfinArgs f) {
+__global__ void __launch_bounds__(256) k_cfinish(CfinArgs a) {
     extern __shared__ __attribute__((aligned(16))) float fsm[];   // [C][PXB] values, then [C*C] matrix
-    __shared__ double red[4];
-    const CnetArgs& a = f.a;
+    __shared__ long long red[4];
     const int tid = threadIdx.x;
-    const int HW = f.HW, W = a.W, H = a.H, Cout = a.Cout;
+    const int HW = a.HW, W = a.W;
+    const FinSrc f = fin_src(a.p, a.N, a.H, W, HW, a.wshift);
     const long gp0 = (long)blockIdx.x * PXB;
     const long n = gp0 / HW;
     const int p0 = (int)(gp0 - n * HW);
-    const bool paired = a.mode == TAIL_AFFINE_FWD || a.mode == TAIL_AFFINE_REV;
-    const int Ch = paired ? Cout / 2 : Cout;         // channels of z2 (= C/2)
+    const int Ch = f.paired ? f.Cout / 2 : f.Cout;         // channels of z2 (= C/2)
     const int C = 2 * Ch;
     float* mixv = fsm;
     float* mixm = fsm + C * PXB;
-    if (a.mix_C && a.mix_matrix)
-        for (int e = tid; e < C * C; e += 256) mixm[e] = a.mix_matrix[e];
-    const float* hpart = a.scratch;
-    const float* hup = a.scratch + (long)f.MS * a.N * Cout * HW;
-    const float* hdn = hup + (long)f.MS * f.tiles * Cout * W;
-    const float* zi = a.z_in + n * a.z_in_bs;
+    if (a.mix.C && a.mix.matrix)
+        for (int e = tid; e < C * C; e += 256) mixm[e] = a.mix.matrix[e];
+    const float* zi = a.p.z + n * a.p.z_bs;
     float* zn = a.z_out + n * a.z_out_bs;
-    const bool halos = f.NI == 1 && f.R < H;
-    double ld = 0.0;
+    long long ldq = 0;
     for (int e = tid; e < Ch * PXB; e += 256) {
         const int c = e / PXB, q = e - c * PXB;
         const int p = p0 + q;
-        const int y = p >> f.wshift, x = p & (W - 1);
-        const int ce = paired ? 2 * c : c;
-        // every load below is unconditional (clamped index, masked value): all of them are in flight together
         const float zin = zi[(long)(Ch + c) * HW + p];
         const float z1v = zi[(long)c * HW + p];
-        float se = 0.f, so = 0.f;
-        for (int m = 0; m < f.MS; ++m) {
-            const long base = (((long)m * a.N + n) * Cout + ce) * HW + p;
-            se += hpart[base];
-            so += hpart[base + (paired ? HW : 0)];
-        }
-        if (halos) {
-            const int r = y & (f.R - 1);
-            const long tile = (n * HW + (long)(y - r) * W) >> f.lpxt;  // tile holding row y
-            const float wd = (r == 0 && y > 0) ? 1.f : 0.f;            // row below the previous tile: its `hdn`
-            const float wu = (r == f.R - 1 && y < H - 1) ? 1.f : 0.f;  // row above the next tile: its `hup`
-            const long td = tile > 0 ? tile - 1 : 0, tu = tile + 1 < f.tiles ? tile + 1 : tile;
-            for (int m = 0; m < f.MS; ++m) {
-                const long hd = (((long)m * f.tiles + td) * Cout + ce) * W + x;
-                const long hu = (((long)m * f.tiles + tu) * Cout + ce) * W + x;
-                se += wd * hdn[hd] + wu * hup[hu];
-                so += wd * hdn[hd + (paired ? W : 0)] + wu * hup[hu + (paired ? W : 0)];
-            }
-        }
-        const float A_ = (se + a.bias[ce]) * a.scale[ce];
-        float zres;
-        if (paired) {
-            const float B_ = (so + a.bias[ce + 1]) * a.scale[ce + 1];
-            const float sc = sigmoidf_(B_ + 2.0f);
-            if (a.mode == TAIL_AFFINE_FWD) {
-                zres = (zin + A_) * sc;
-                ld += (double)logf(sc);
-            } else {
-                zres = zin / sc - A_;
-                ld -= (double)logf(sc);
-            }
-        } else {
-            zres = a.mode == TAIL_ADD_FWD ? zin + A_ : zin - A_;
-        }
-        if (a.mix_C) {
-            if (!a.mix_reverse) {     // ActNorm of the next step on both halves, staged for its matrix / gather
-                mixv[c * PXB + q] = (z1v + a.mix_bias[c]) * a.mix_scale[c];
-                mixv[(Ch + c) * PXB + q] = (zres + a.mix_bias[Ch + c]) * a.mix_scale[Ch + c];
+        const float zres = fin_couple(f, n, c, p, zin, ldq);
+        if (a.mix.C) {
+            if (!a.mix.reverse) {     // ActNorm of the next step on both halves, staged for its matrix / gather
+                mixv[c * PXB + q] = (z1v + a.mix.bias[c]) * a.mix.scale[c];
+                mixv[(Ch + c) * PXB + q] = (zres + a.mix.bias[Ch + c]) * a.mix.scale[Ch + c];
             } else {
                 mixv[c * PXB + q] = z1v;
                 mixv[(Ch + c) * PXB + q] = zres;
             }
         } else {
             zn[(long)(Ch + c) * HW + p] = zres;
+            if (zn != zi) zn[(long)c * HW + p] = z1v;       // out of place: z1 travels along
         }
     }
-    if (a.mix_C) {
+    if (a.mix.C) {
         __syncthreads();
         // thread = (output group og, pixel q): outputs o = og, og + OG, ... four at a time (the staged value v[i][q] is read once
         // for four outputs; the matrix rows are wave-uniform LDS broadcasts)
@@ -688,7 +795,7 @@ __global__ void __launch_bounds__(256) k_cfinish(CfinArgs f) {
         const int q = tid & (PXB - 1), og = tid / PXB;
         for (int ob = og; ob < C; ob += 4 * OG) {
             float r[4];
-            if (a.mix_matrix) {   // same operation order as k_chanmix: r = fma(m[o][i], v[i], r), i ascending
+            if (a.mix.matrix) {   // same operation order as k_chanmix: r = fma(m[o][i], v[i], r), i ascending
 #pragma unroll
                 for (int j = 0; j < 4; ++j) r[j] = 0.f;
                 for (int i = 0; i < C; ++i) {
@@ -703,7 +810,7 @@ __global__ void __launch_bounds__(256) k_cfinish(CfinArgs f) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int o = ob + j * OG;
-                    r[j] = mixv[(o < C ? (a.mix_gather ? a.mix_gather[o] : o) : 0) * PXB + q];
+                    r[j] = mixv[(o < C ? (a.mix.gather ? a.mix.gather[o] : o) : 0) * PXB + q];
                 }
             }
 #pragma unroll
@@ -711,19 +818,20 @@ __global__ void __launch_bounds__(256) k_cfinish(CfinArgs f) {
                 const int o = ob + j * OG;
                 if (o >= C) continue;
                 float v = r[j];
-                if (a.mix_reverse) v = v * a.mix_scale[o] - a.mix_bias[o];
+                if (a.mix.reverse) v = v * a.mix.scale[o] - a.mix.bias[o];
                 zn[(long)o * HW + p0 + q] = v;
             }
         }
     }
-    if (paired) {
-        const double tot = block_sum<256>(ld, red);
-        if (tid == 0) fix_atomic_add(a.acc + n, tot);
+    if (f.paired) {
+        const long long tot = block_sum_ll<256>(ldq, red);
+        if (tid == 0) atomicAdd(a.acc + n, (unsigned long long)tot);
     }
 }
 
 // ------------------------------------------------------------------------------------------------ host side
 static int g_cnet_ms = 0, g_cnet_flags = 0;
+bool cnet_chain_enabled() { return (g_cnet_flags & 4) != 0; }
 void cnet_force(int ms, int flags) { g_cnet_ms = ms; g_cnet_flags = flags; }
 
 int cnet_g0(int Cin) { return (9 * ((Cin + 7) / 8) + 5) / 6 * 6; }   // 8-wide k groups of f.0, padded to whole triples of k-steps
@@ -796,7 +904,7 @@ static int launch_cnet_inst(const CnetArgs& a, const CnetGeo& g, hipStream_t s) 
     return GLOWHIP_OK;
 }
 
-int launch_cnet(const CnetArgs& a, hipStream_t s) {
+int launch_cnet_main(const CnetArgs& a, hipStream_t s, CnetPending* out) {
     GH_REQUIRE(a.mode == TAIL_AFFINE_FWD || a.mode == TAIL_AFFINE_REV || a.mode == TAIL_ADD_FWD || a.mode == TAIL_ADD_REV,
                "cnet: coupling modes only");
     if (a.N == 0) return GLOWHIP_OK;
@@ -833,14 +941,25 @@ int launch_cnet(const CnetArgs& a, hipStream_t s) {
 #undef GH_CN
     if (rc == GLOWHIP_EINVAL) set_error("cnet: no kernel instance for hidden=%d ms=%d upw=%d tile=%d", a.hidden, ms, upw, g.pxt);
     GH_TRY(rc);
-    if (a.y_sh) return GLOWHIP_OK;
-    CfinArgs f{a, ms, g.tiles, g.R, g.NI, g.wshift, g.HW, g.lpxt};
-    const bool paired = a.mode == TAIL_AFFINE_FWD || a.mode == TAIL_AFFINE_REV;
-    const int C = 2 * (paired ? a.Cout / 2 : a.Cout);
-    GH_REQUIRE(a.mix_C == 0 || a.mix_C == C, "cnet: mixer channel count %d != %d", a.mix_C, C);
-    const long total_px = (long)a.N * g.HW;
+    if (out) {
+        out->scratch = a.scratch; out->MS = ms; out->tiles = g.tiles; out->R = g.R; out->NI = g.NI; out->lpxt = g.lpxt;
+        out->bias = a.bias; out->scale = a.scale; out->mode = a.mode; out->Cout = a.Cout;
+        out->z = a.pre_on ? a.pre_z_new : a.z_in;
+        out->z_bs = a.pre_on ? a.pre_z_new_bs : a.z_in_bs;
+    }
+    return GLOWHIP_OK;
+}
+
+int launch_cnet_finish(const CnetArgs& a, const CnetPending& p, hipStream_t s) {
+    if (a.N == 0) return GLOWHIP_OK;
+    const int HW = a.H * a.W;
+    CfinArgs f{p, a.mix, a.z_out, a.z_out_bs, a.acc, a.N, a.H, a.W, HW, __builtin_ctz(a.W)};
+    const bool paired = p.mode == TAIL_AFFINE_FWD || p.mode == TAIL_AFFINE_REV;
+    const int C = 2 * (paired ? p.Cout / 2 : p.Cout);
+    GH_REQUIRE(a.mix.C == 0 || a.mix.C == C, "cnet: mixer channel count %d != %d", a.mix.C, C);
+    const long total_px = (long)a.N * HW;
     const int pxb = total_px < 32768 ? 16 : 64;      // small levels: 16 pixels per workgroup, so that the launch still covers the chip
-    const size_t flds = ((size_t)C * pxb + (a.mix_C && a.mix_matrix ? (size_t)C * C : 0)) * sizeof(float);
+    const size_t flds = ((size_t)C * pxb + (a.mix.C && a.mix.matrix ? (size_t)C * C : 0)) * sizeof(float);
     GH_REQUIRE(flds <= 64 * 1024, "cnet: finishing kernel LDS");
     if (pxb == 16) {
         if (flds > 32 * 1024) (void)hipFuncSetAttribute((const void*)k_cfinish<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds);
@@ -851,6 +970,25 @@ int launch_cnet(const CnetArgs& a, hipStream_t s) {
     }
     GH_LAUNCH_CHECK("k_cfinish");
     return GLOWHIP_OK;
+}
+
+int launch_cnet(const CnetArgs& a, hipStream_t s) {
+    CnetPending p{};
+    GH_TRY(launch_cnet_main(a, s, &p));
+    if (a.y_sh || a.N == 0) return GLOWHIP_OK;
+    return launch_cnet_finish(a, p, s);
+}
+
+// window-time finishing stages [C][window] + [C][C] + [Cin][window] floats in the (then idle) activation buffer
+bool cnet_pre_supported(int Cin, int H, int W, int hidden, int Cout, int C) {
+    if (C > 96) return false;
+    for (int pxt : {128, 64}) {
+        CnetGeo g;
+        if (!cnet_geo(Cin, H, W, hidden, Cout, 0, pxt, &g)) continue;
+        const size_t nwin = (size_t)g.NI * g.Wpx;
+        if (((size_t)C * nwin + (size_t)C * C + (size_t)Cin * nwin + 32) * sizeof(float) > (size_t)CN_HBUF) return false;
+    }
+    return true;
 }
 
 }  // namespace glowhip

@@ -98,28 +98,40 @@ static bool f02_runs_at(int N, int HW) { return N <= 0 || (long)N * HW / 64 >= 1
 static bool tail_runs_sh(const LayerPlan& L) { return L.sh_mid && L.sh_tail && !g_sh_disabled && !g_sh_tail_disabled; }
 static bool cnet_runs(const LayerPlan& L) { return L.cnet && !g_sh_disabled && !g_cnet_disabled; }
 
-// Channel mixer a coupling kernel applies to the finished pixels: forward = the NEXT step's ActNorm + permutation, reverse
-// (cnet only) = THIS step's inverse permutation + inverse ActNorm
-struct CnetIo { const float* z_in; long z_in_bs; float* z_out; long z_out_bs; int mix_C, mix_reverse;
-                const float* mix_bias; const float* mix_scale; const float* mix_matrix; const int32_t* mix_gather; };
-
-static int run_cnet(glowhip_plan* P, const LayerPlan& L, const void* packed, const CnetIo& io, int N, int reverse,
-                    const Workspace& w, hipStream_t s) {
+// ---- the one-kernel coupling network (cnet_sh.hip).  A FlowStep is k_cnet (partial sums of h = f(z1)) + a finishing step
+// (coupling, log-det, channel mixer); the finishing step of step k runs either as its own kernel or inside step k+1's k_cnet
+// while that builds its window ("pending").
+static CnetArgs cnet_base(const LayerPlan& L, const void* packed, int N, int reverse, float* scratch, const Workspace& w) {
     const glowhip_layer_desc& d = L.d;
     CnetArgs c{};
-    c.x = io.z_in; c.x_bs = io.z_in_bs;
     c.w0 = at<char>(packed, L.cn_w0); c.w2 = at<char>(packed, L.cn_w2); c.w4 = at<char>(packed, L.cn_w4);
     c.N = N; c.Cin = d.C / 2; c.H = d.H; c.W = d.W; c.hidden = d.hidden; c.Cout = L.Cout;
-    c.scratch = w.h1;
+    c.scratch = scratch;
     c.bias = d.f4_bias; c.scale = at<float>(packed, L.f4_scale);
     c.mode = d.coupling == GLOWHIP_COUPLING_AFFINE ? (reverse ? TAIL_AFFINE_REV : TAIL_AFFINE_FWD)
                                                    : (reverse ? TAIL_ADD_REV : TAIL_ADD_FWD);
-    c.z_in = io.z_in; c.z_in_bs = io.z_in_bs; c.z_out = io.z_out; c.z_out_bs = io.z_out_bs; c.acc = w.acc;
-    c.mix_C = io.mix_C; c.mix_reverse = io.mix_reverse; c.mix_bias = io.mix_bias; c.mix_scale = io.mix_scale;
-    c.mix_matrix = io.mix_matrix; c.mix_gather = io.mix_gather;
-    ScopedTimer t(P, GLOWHIP_K_CNET, 1, s);
-    count_launch(P, io.mix_C ? "k_cnet+mixer" : "k_cnet");
-    return launch_cnet(c, s);
+    c.acc = w.acc;
+    return c;
+}
+static CnetMixer mixer_fwd(const LayerPlan& L, const void* packed) {      // ActNorm + permutation of step L, forward
+    const glowhip_layer_desc& d = L.d;
+    return CnetMixer{d.C, 0, d.an_bias, at<float>(packed, L.an_scale), d.permutation == GLOWHIP_PERM_INVCONV ? d.invconv_w : nullptr,
+                     d.permutation == GLOWHIP_PERM_GATHER ? d.perm_idx : nullptr};
+}
+static CnetMixer mixer_rev(const LayerPlan& L, const void* packed) {      // permutation^-1 + ActNorm^-1 of step L
+    const glowhip_layer_desc& d = L.d;
+    return CnetMixer{d.C, 1, d.an_bias, at<float>(packed, L.an_inv_scale),
+                     d.permutation == GLOWHIP_PERM_INVCONV ? at<float>(packed, L.winv) : nullptr,
+                     d.permutation == GLOWHIP_PERM_GATHER ? d.perm_idx_inv : nullptr};
+}
+// may the finishing step of layer A run inside layer B's k_cnet?  (Off by default: the window-time finishing costs a workgroup
+// ~25 k cycles of dependent global round trips with 8 waves, more than the ~10 us finishing kernel it saves; kept behind
+// glowhip_debug_force_tail_tile(0x8000000) with its bitwise-equality test.)
+static bool cnet_chain(const LayerPlan& A, const LayerPlan& B) {
+    const glowhip_layer_desc& a = A.d; const glowhip_layer_desc& b = B.d;
+    return cnet_chain_enabled() && !g_sh_mix_disabled && !g_cnet_h2_only && a.kind == GLOWHIP_LAYER_FLOWSTEP && b.kind == GLOWHIP_LAYER_FLOWSTEP &&
+           cnet_runs(A) && cnet_runs(B) && a.C == b.C && a.H == b.H && a.W == b.W && a.coupling == b.coupling &&
+           cnet_pre_supported(b.C / 2, b.H, b.W, b.hidden, B.Cout, b.C);
 }
 
 static int run_coupling(glowhip_plan* P, const LayerPlan& L, const void* packed, const float* x1, long x1_bs, const float* z2_in,
@@ -259,6 +271,9 @@ static int run_forward(glowhip_plan* p, const void* packed, const float* x, cons
     const float* cur = x;
     const int nl = (int)p->layers.size();
     bool premixed = false;   // `cur` already holds this step's ActNorm + permutation output (applied by the previous tail)
+    bool pending = false;    // the previous FlowStep's k_cnet has run, its finishing step has not (cnet_chain)
+    CnetPending pend{};
+    int scr_i = 0;
     for (int li = first_layer; li < nl; ++li) {
         const LayerPlan& L = p->layers[li];
         const glowhip_layer_desc& d = L.d;
@@ -278,6 +293,57 @@ static int run_forward(glowhip_plan* p, const void* packed, const float* x, cons
                 if (li != nl - 1) dst = w.bufB;
             }
             const int Ch = d.C / 2;
+            if (d.kind == GLOWHIP_LAYER_FLOWSTEP && cnet_runs(L) && !g_cnet_h2_only) {
+                // ---- k_cnet path.  `cur` holds the input of this step's mixer, or -- `premixed` -- its output, or -- `pending` --
+                // the state the PREVIOUS step's k_cnet read, whose finishing (coupling + this step's mixer) this launch does itself
+                float* scratch = (scr_i ^= 1) ? w.h1 : w.h2;
+                CnetArgs c = cnet_base(L, packed, N, 0, scratch, w);
+                if (pending) {
+                    float* nxt = other_buf(w, cur);
+                    c.pre_on = 1; c.pre = pend; c.pre_mix = mixer_fwd(L, packed); c.pre_z_new = nxt; c.pre_z_new_bs = chw;
+                    cur = nxt;
+                } else {
+                    if (!premixed) {
+                        ChanMixArgs m{};
+                        m.in_a = cur; m.in_a_bs = chw; m.in_b = cur + (long)Ch * HW; m.in_b_bs = chw; m.Ca = Ch;
+                        m.out = dst; m.out_bs = chw;
+                        m.bias = d.an_bias; m.scale = at<float>(packed, L.an_scale);
+                        m.matrix = d.permutation == GLOWHIP_PERM_INVCONV ? d.invconv_w : nullptr;
+                        m.gather = d.permutation == GLOWHIP_PERM_GATHER ? d.perm_idx : nullptr;
+                        m.reverse = 0; m.N = N; m.C = d.C; m.HW = HW;
+                        ScopedTimer tm(p, GLOWHIP_K_CHANMIX, 0, s);
+                        count_launch(p, "k_chanmix");
+                        GH_TRY(launch_chanmix(m, s));
+                        cur = dst;
+                    }
+                    c.x = cur; c.x_bs = chw; c.z_in = cur; c.z_in_bs = chw;
+                }
+                premixed = false;
+                const bool chain = li + 1 < nl && cnet_chain(L, p->layers[li + 1]);
+                {
+                    ScopedTimer t(p, GLOWHIP_K_CNET, 1, s);
+                    count_launch(p, pending ? "k_cnet+prev_finish" : "k_cnet");
+                    GH_TRY(launch_cnet_main(c, s, &pend));
+                }
+                pending = chain;
+                if (!chain) {   // finish now; with the NEXT step's mixer when that is a same-shape FlowStep on another kernel family
+                    float* out = (li == nl - 1) ? z_out : const_cast<float*>(cur);
+                    c.z_out = out; c.z_out_bs = chw;
+                    if (li + 1 < nl - 1 && !g_sh_mix_disabled && d.C <= 96) {
+                        const LayerPlan& Ln = p->layers[li + 1];
+                        const glowhip_layer_desc& dn = Ln.d;
+                        if (dn.kind == GLOWHIP_LAYER_FLOWSTEP && dn.C == d.C && dn.H == d.H && dn.W == d.W) {
+                            c.mix = mixer_fwd(Ln, packed);
+                            premixed = true;
+                        }
+                    }
+                    ScopedTimer t(p, GLOWHIP_K_CFINISH, 0, s);
+                    count_launch(p, c.mix.C ? "k_cfinish+mixer" : "k_cfinish");
+                    GH_TRY(launch_cnet_finish(c, pend, s));
+                    cur = out;
+                }
+                continue;
+            }
             if (d.kind == GLOWHIP_LAYER_FLOWSTEP) {
                 if (premixed) {
                     dst = const_cast<float*>(cur);   // the step runs in place on the already mixed buffer
@@ -296,12 +362,11 @@ static int run_forward(glowhip_plan* p, const void* packed, const float* x, cons
                 // Let this step's tail apply the NEXT step's channel mixer (one launch less per step) when the next layer is
                 // a FlowStep of the same shape that may run in place (i.e. is not the one writing z_out)
                 NextMix nm{};
-                const bool by_cnet = cnet_runs(L) && !g_cnet_h2_only;
-                if (li + 1 < nl - 1 && !g_sh_mix_disabled && (by_cnet || tail_runs_sh(L))) {
+                if (li + 1 < nl - 1 && !g_sh_mix_disabled && tail_runs_sh(L)) {
                     const LayerPlan& Ln = p->layers[li + 1];
                     const glowhip_layer_desc& dn = Ln.d;
                     if (dn.kind == GLOWHIP_LAYER_FLOWSTEP && dn.C == d.C && dn.H == d.H && dn.W == d.W &&
-                        (by_cnet ? d.C <= 96 : tail_sh_mix_supported(d.hidden, d.H, d.W, L.Cout, d.C))) {
+                        tail_sh_mix_supported(d.hidden, d.H, d.W, L.Cout, d.C)) {
                         nm.C = d.C; nm.out = dst; nm.out_bs = chw;
                         nm.bias = dn.an_bias; nm.scale = at<float>(packed, Ln.an_scale);
                         nm.matrix = dn.permutation == GLOWHIP_PERM_INVCONV ? dn.invconv_w : nullptr;
@@ -309,12 +374,7 @@ static int run_forward(glowhip_plan* p, const void* packed, const float* x, cons
                     }
                 }
                 float* z2 = dst + (long)Ch * HW;
-                if (by_cnet) {
-                    CnetIo io{dst, chw, dst, chw, nm.C, 0, nm.bias, nm.scale, nm.matrix, nm.gather};
-                    GH_TRY(run_cnet(p, L, packed, io, N, 0, w, s));
-                } else {
-                    GH_TRY(run_coupling(p, L, packed, dst, chw, z2, chw, z2, chw, N, 0, w, s, &nm));
-                }
+                GH_TRY(run_coupling(p, L, packed, dst, chw, z2, chw, z2, chw, N, 0, w, s, &nm));
                 premixed = nm.C != 0;
             } else {  // SPLIT2D: score z2 under the prior predicted from z1, keep z1
                 GH_TRY(run_split(L, packed, cur, chw, cur + (long)Ch * HW, chw, nullptr, nullptr, 0, N, 0, w, s));
@@ -332,6 +392,9 @@ static int run_reverse(glowhip_plan* p, const void* packed, const float* z, cons
     const float* cur = z;
     const int nl = (int)p->layers.size();
     int ke = 0;
+    bool pending = false;    // as in run_forward
+    CnetPending pend{};
+    int scr_i = 0;
     for (int li = nl - 1; li >= 0; --li) {
         const LayerPlan& L = p->layers[li];
         const glowhip_layer_desc& d = L.d;
@@ -344,12 +407,33 @@ static int run_reverse(glowhip_plan* p, const void* packed, const float* z, cons
             GH_TRY(launch_squeeze(cur, nullptr, dst, N, d.C * 4, d.H / 2, d.W / 2, 2, 1, s));
         } else if (d.kind == GLOWHIP_LAYER_FLOWSTEP) {
             float* z2 = dst + (long)Ch * HW;
-            if (cnet_runs(L) && !g_cnet_h2_only && d.C <= 96) {   // coupling^-1, permutation^-1 and ActNorm^-1 by the finishing kernel
-                CnetIo io{cur, chw, dst, chw, d.C, 1, d.an_bias, at<float>(packed, L.an_inv_scale),
-                          d.permutation == GLOWHIP_PERM_INVCONV ? at<float>(packed, L.winv) : nullptr,
-                          d.permutation == GLOWHIP_PERM_GATHER ? d.perm_idx_inv : nullptr};
-                GH_TRY(run_cnet(p, L, packed, io, N, 1, w, s));
-                cur = dst;
+            if (cnet_runs(L) && !g_cnet_h2_only && d.C <= 96) {
+                // coupling^-1, permutation^-1 and ActNorm^-1 by the finishing step -- run by the next-executed step's k_cnet where
+                // the two chain, by the finishing kernel otherwise
+                float* scratch = (scr_i ^= 1) ? w.h1 : w.h2;
+                CnetArgs c = cnet_base(L, packed, N, 1, scratch, w);
+                if (pending) {
+                    float* nxt = other_buf(w, cur);
+                    c.pre_on = 1; c.pre = pend; c.pre_mix = mixer_rev(p->layers[li + 1], packed); c.pre_z_new = nxt; c.pre_z_new_bs = chw;
+                    cur = nxt;
+                } else {
+                    c.x = cur; c.x_bs = chw; c.z_in = cur; c.z_in_bs = chw;
+                }
+                const bool chain = li - 1 >= 0 && cnet_chain(L, p->layers[li - 1]) && p->layers[li - 1].d.C <= 96;
+                {
+                    ScopedTimer t(p, GLOWHIP_K_CNET, 1, s);
+                    count_launch(p, pending ? "k_cnet+prev_finish" : "k_cnet");
+                    GH_TRY(launch_cnet_main(c, s, &pend));
+                }
+                pending = chain;
+                if (!chain) {
+                    float* out = (li == 0) ? x_out : other_buf(w, cur);
+                    c.z_out = out; c.z_out_bs = chw; c.mix = mixer_rev(L, packed);
+                    ScopedTimer t(p, GLOWHIP_K_CFINISH, 0, s);
+                    count_launch(p, "k_cfinish+mixer");
+                    GH_TRY(launch_cnet_finish(c, pend, s));
+                    cur = out;
+                }
                 continue;
             }
             GH_TRY(run_coupling(p, L, packed, cur, chw, cur + (long)Ch * HW, chw, z2, chw, N, 1, w, s));

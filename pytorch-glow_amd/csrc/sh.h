@@ -132,24 +132,40 @@ int cnet_g0(int Cin);                 // 8-wide k groups of the f.0 image (even 
 int cnet_mpad4(int Cout);             // rows of the taps-as-rows f.4 image (multiple of 32)
 size_t cnet_scratch_floats(int N, int H, int W, int Cout);   // partial-sum scratch (floats) for batch N; <= N * the per-sample bound
 size_t cnet_scratch_floats_per_sample(int H, int W, int Cout);
+// What a k_cnet launch leaves behind for whoever finishes the step -- the finishing kernel, or the NEXT step's k_cnet while it
+// builds its window: the partial sums of h = f(z1) in `scratch`, how they are tiled, and the coupling they feed.
+struct CnetPending {
+    const float* scratch; int MS, tiles, R, NI, lpxt;
+    const float* bias; const float* scale;       // f.4 bias (Cout), exp(3 logs) (Cout) of that step
+    int mode, Cout;                              // TailMode of that step's coupling
+    const float* z; long z_bs;                   // the state that step read: z1 = channels [0, C/2), z2 = [C/2, C)
+};
+// channel mixer applied to a finished state (C = 0: none)
+//   forward: the NEXT step's  y = M ((z + bias) * scale);   reverse: THIS step's  x = (M z) * scale - bias
+struct CnetMixer { int C, reverse; const float* bias; const float* scale; const float* matrix; const int32_t* gather; };
 struct CnetArgs {
-    const float* x; long x_bs;                   // z1: channels [0, Cin) of (N, *, H, W), batch stride x_bs
+    const float* x; long x_bs;                   // z1: channels [0, Cin) of (N, *, H, W), batch stride x_bs (unused with `pre`)
     const void* w0; const void* w2; const void* w4;   // SH2 images (REPACK_SH2_FIRST / _GEMM / _TAIL)
     int N, Cin, H, W, hidden, Cout;
     float* scratch;                              // cnet_scratch_floats(N, ...) floats
     _Float16* y_sh;                              // testing: write h2 as an (old-format) SH tensor and stop before f.4
-    // ---- finishing kernel: coupling + log-det + channel mixer
+    // ---- finishing kernel of THIS step: coupling + log-det + channel mixer
     const float* bias; const float* scale;       // f.4 bias (Cout), exp(3 logs) (Cout)
     int mode;                                    // TailMode: the four coupling modes
     const float* z_in; long z_in_bs;             // (N, C, H, W): z1 = channels [0, C/2), z2 = [C/2, C)
     float* z_out; long z_out_bs;                 // result (may be z_in: a workgroup reads all of its own pixels before it writes)
     unsigned long long* acc;
-    // channel mixer applied to the updated z before it is written (C = 0: none; only z2 is written then)
-    //   forward: the NEXT step's  y = M ((z + mix_bias) * mix_scale);   reverse: THIS step's  x = (M z) * mix_scale - mix_bias
-    int mix_C; int mix_reverse;
-    const float* mix_bias; const float* mix_scale; const float* mix_matrix; const int32_t* mix_gather;
+    CnetMixer mix;                               // applied by this step's finishing kernel (mix.C = 0: only z2 is updated)
+    // ---- optional: finish the PREVIOUS step while the window is built (one launch per FlowStep instead of two).  The
+    // workgroup applies `pre`'s coupling and `pre_mix` to every window pixel (its own and the halo), takes z1 of the result as its
+    // f.0 input and writes the result of its OWN pixels to pre_z_new (a buffer other than pre.z: neighbours still read that).
+    int pre_on; CnetPending pre; CnetMixer pre_mix; float* pre_z_new; long pre_z_new_bs;
 };
-int launch_cnet(const CnetArgs& a, hipStream_t s);
+int launch_cnet_main(const CnetArgs& a, hipStream_t s, CnetPending* out);            // k_cnet only; *out describes its partial sums
+int launch_cnet_finish(const CnetArgs& a, const CnetPending& p, hipStream_t s);     // the finishing kernel for those sums
+int launch_cnet(const CnetArgs& a, hipStream_t s);                                   // both
+bool cnet_chain_enabled();   // testing hook (off by default: measured slower)
+bool cnet_pre_supported(int Cin, int H, int W, int hidden, int Cout, int C);         // window-time finishing fits the LDS
 void cnet_force(int ms, int flags);   // testing hook: ms in {0 (automatic), 1, 2, 4}
 
 }  // namespace glowhip

@@ -29,6 +29,14 @@ def path(request):
         G.lib().glowhip_debug_force_tail_tile(0)
 
 
+def ncnet(counts):
+    return counts.get("k_cnet", 0) + counts.get("k_cnet+prev_finish", 0)
+
+
+def nfinish(counts):
+    return counts.get("k_cfinish", 0) + counts.get("k_cfinish+mixer", 0)
+
+
 def _case(image, L, K, hidden, batch, seed=5, coup="affine", perm="invconv"):
     cfg = O.default_cfg(image_shape=(image, image, 3), hidden_channels=hidden, K=K, L=L, flow_coupling=coup,
                         flow_permutation=perm, batch=batch)
@@ -65,7 +73,9 @@ def test_fused_f02_runs_and_matches_oracle_config_b_geometry(path):
     K = 4
     plan, fwd, rev = _case(64, 3, K, 512, 48)
     if path == "cnet":
-        assert fwd.get("k_cnet", 0) + fwd.get("k_cnet+mixer", 0) == 3 * K and rev.get("k_cnet+mixer", 0) == 3 * K, (fwd, rev)
+        # one k_cnet + one finishing kernel per FlowStep
+        assert ncnet(fwd) == 3 * K and ncnet(rev) == 3 * K, (fwd, rev)
+        assert nfinish(fwd) == 3 * K and nfinish(rev) == 3 * K, (fwd, rev)
         assert not any(k in fwd for k in ("k_f02_sh", "k_gemm_sh", "k_tail_sh", "k_conv_direct", "k_gemm_f32")), fwd
         assert sum("cnet-sh2" in l for l in plan.describe(48).splitlines()) == 3 * K
         return
@@ -85,7 +95,7 @@ def test_fused_f02_level1_only_batch16(path):
     K = 3
     plan, fwd, rev = _case(64, 3, K, 512, 16, seed=6)
     if path == "cnet":
-        assert fwd.get("k_cnet", 0) + fwd.get("k_cnet+mixer", 0) == 3 * K, fwd
+        assert ncnet(fwd) == 3 * K, fwd
     else:
         assert fwd.get("k_f02_sh", 0) == K and fwd.get("k_gemm_sh", 0) == 2 * K, fwd
 
@@ -96,7 +106,7 @@ def test_fused_f02_w64_level(path):
     K = 2
     plan, fwd, rev = _case(128, 2, K, 256, 3, seed=7)
     if path == "cnet":
-        assert fwd.get("k_cnet", 0) + fwd.get("k_cnet+mixer", 0) == 2 * K and rev.get("k_cnet+mixer", 0) == 2 * K, (fwd, rev)
+        assert ncnet(fwd) == 2 * K and ncnet(rev) == 2 * K, (fwd, rev)
     else:
         assert fwd.get("k_f02_sh", 0) >= K and rev.get("k_f02_sh", 0) >= K, (fwd, rev)   # the W=64 level is fused at this batch
 
@@ -106,7 +116,7 @@ def test_fused_f02_additive_and_shuffle(path):
     K = 2
     plan, fwd, rev = _case(64, 2, K, 512, 16, seed=8, coup="additive", perm="reverse")
     if path == "cnet":
-        assert fwd.get("k_cnet", 0) + fwd.get("k_cnet+mixer", 0) == 2 * K, fwd
+        assert ncnet(fwd) == 2 * K, fwd
     else:
         assert fwd.get("k_f02_sh", 0) >= K, fwd
 
@@ -122,7 +132,37 @@ def test_cnet_every_row_split(ms, image, L, hidden, batch):
         plan, fwd, rev = _case(image, L, 2, hidden, batch, seed=30 + ms)
     finally:
         G.lib().glowhip_debug_force_tail_tile(0)
-    assert fwd.get("k_cnet", 0) + fwd.get("k_cnet+mixer", 0) == 2 * L, fwd
+    assert ncnet(fwd) == 2 * L, fwd
+
+
+@pytest.mark.parametrize("tile", [0x2000000, 0x4000000])
+@pytest.mark.parametrize("chained", [True, False])
+def test_cnet_tile_sizes_and_chaining(tile, chained):
+    """128- and 64-pixel tiles forced (the heuristic picks by grid size), each with the finishing step as its own kernel (the
+    default) and chained into the next FlowStep's launch (0x8000000): the two orders of evaluation must agree BIT FOR BIT -- same arithmetic, log-det terms
+    summed as fixed point -- and both match the oracle."""
+    outs = []
+    CHAIN = 0x8000000
+    for flags in [tile | (CHAIN if chained else 0), tile | (0 if chained else CHAIN)]:
+        G.lib().glowhip_debug_force_tail_tile(flags)
+        try:
+            cfg = O.default_cfg(image_shape=(32, 32, 3), hidden_channels=128, K=3, L=2, batch=5)
+            sd = O.seeded_state_dict(cfg, seed=77, invconv_perturb=0.02)
+            g = torch.Generator().manual_seed(77)
+            x = torch.rand(5, 3, 32, 32, generator=g); noise = torch.rand(5, 3, 32, 32, generator=g) / 256
+            glow = make_glow(cfg, sd, 5)
+            plan = glow.flow.plan_for(dev(x)); plan.launch_counts(reset=True)
+            z, nll, _ = glow.normal_flow(dev(x), None, noise=dev(noise))
+            counts = plan.launch_counts(reset=True)
+            xr = glow.reverse_flow(z, None, eps=[torch.zeros(5, 6, 16, 16, device=z.device)])
+            outs.append((z.clone(), nll.clone(), xr.clone(), counts))
+        finally:
+            G.lib().glowhip_debug_force_tail_tile(0)
+    (z0, n0, x0, c0), (z1, n1, x1, c1) = outs
+    assert ("k_cnet+prev_finish" in c0) != ("k_cnet+prev_finish" in c1), (c0, c1)
+    assert torch.equal(z0, z1) and torch.equal(n0, n1) and torch.equal(x0, x1)
+    z_ref, nll_ref, _ = O.glow_forward(x, noise, sd, cfg)
+    close(z0, z_ref, 1e-4, what="z"); close(n0, nll_ref, 1e-4, what="nll")
 
 
 @pytest.mark.parametrize("case", range(14))

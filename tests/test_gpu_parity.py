@@ -582,7 +582,7 @@ def test_split_half_stack_every_coupling_and_permutation(coup, perm):
     plan.launch_counts(reset=True)
     z, nll, _ = glow.normal_flow(dev(x), None, noise=dev(noise))
     counts = plan.launch_counts(reset=True)
-    assert counts.get("k_cnet+mixer", 0) >= 4 and counts.get("k_conv_direct", 0) == 0, counts
+    assert counts.get("k_cfinish+mixer", 0) >= 4 and counts.get("k_conv_direct", 0) == 0, counts
     close(z, z_ref, 1e-4, what="z"); close(nll, nll_ref, 1e-4, what="nll")
     G.lib().glowhip_debug_force_tail_tile(0x8000)      # the same without the mixer fused into the tails
     try:
