@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GLOWHIP_VERSION 100 /* 0.1.0 */
+#define GLOWHIP_VERSION 101 /* 0.1.1 */
 
 #define GLOWHIP_OK 0
 #define GLOWHIP_EINVAL (-1)    /* bad argument (shape, null pointer, unsupported value) */
@@ -91,9 +91,10 @@ int glowhip_conv2d(const float* x, long x_batch_stride, const float* w, const fl
 
 /* GaussianDiag.logp, network/module.py:453-467: out[n] = (in ? in[n] : 0) +
  * sum_{c,p} -0.5*(log(2pi) + 2*logs + (x-mean)^2/exp(2*logs)).  mean/logs may be NULL (= 0).
- * Element (n,c,p) of x/mean/logs at base[n*stride + c*HW + p]. */
+ * Element (n,c,p) of x/mean/logs at base[n*stride + c*HW + p].  scratch16N: 16*N bytes (per-sample fixed-point accumulator +
+ * sticky non-finite flag: a NaN / inf term makes out[n] NaN, it is never dropped). */
 int glowhip_gaussian_logp(const float* x, long x_stride, const float* mean, const float* logs, long ml_stride,
-                          int N, int C, int HW, const float* in, float* out, void* scratch8N,
+                          int N, int C, int HW, const float* in, float* out, void* scratch16N,
                           glowhip_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------

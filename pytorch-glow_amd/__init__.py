@@ -17,4 +17,4 @@ from . import misc, network  # noqa: F401
 from .network import (ActNorm, Conv2d, Conv2dZeros, FlowModel, FlowStep, GaussianDiag, Glow,  # noqa: F401
                       Invertible1x1Conv, LinearZeros, Permutation2d, Split2d, Squeeze2d, f)
 
-__version__ = "0.1.0"
+__version__ = "0.1.1"

@@ -107,10 +107,10 @@ int glowhip_conv2d(const float* x, long x_batch_stride, const float* w, const fl
 }
 
 int glowhip_gaussian_logp(const float* x, long x_stride, const float* mean, const float* logs, long ml_stride, int N,
-                          int C, int HW, const float* in, float* out, void* scratch8N, glowhip_stream_t stream) {
-    GH_REQUIRE(x && out && scratch8N, "gaussian_logp: null argument");
+                          int C, int HW, const float* in, float* out, void* scratch16N, glowhip_stream_t stream) {
+    GH_REQUIRE(x && out && scratch16N, "gaussian_logp: null argument");
     hipStream_t s = (hipStream_t)stream;
-    unsigned long long* acc = (unsigned long long*)scratch8N;
+    unsigned long long* acc = (unsigned long long*)scratch16N;
     GH_TRY(launch_zero_acc(acc, N, s));
     GH_TRY(launch_gaussian_logp(x, x_stride, mean, logs, ml_stride, N, C, HW, acc, s));
     return launch_finalize(in, acc, nullptr, 1.0, 0.0, 1.0, out, nullptr, N, s);

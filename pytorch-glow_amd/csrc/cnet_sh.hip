@@ -69,7 +69,7 @@ __device__ __forceinline__ FinSrc fin_src(const CnetPending& p, int N, int H, in
 // Updated z2 value of coupling channel c at pixel p of image n, given its current value zin; the log-det term of the element is
 // added to ldq as Q31.32 fixed point (integer sums are exact: the per-sample total does not depend on how elements are grouped
 // into workgroups, so both users produce the same bits).  Every load is unconditional (clamped index, masked value).
-__device__ __forceinline__ float fin_couple(const FinSrc& f, long n, int c, int p, float zin, long long& ldq) {
+__device__ __forceinline__ float fin_couple(const FinSrc& f, long n, int c, int p, float zin, long long& ldq, float& bad) {
     const int y = p >> f.wshift, x = p & (f.W - 1);
     const int ce = f.paired ? 2 * c : c;
     float se = 0.f, so = 0.f;
@@ -95,10 +95,15 @@ __device__ __forceinline__ float fin_couple(const FinSrc& f, long n, int c, int 
     if (!f.paired) return f.mode == TAIL_ADD_FWD ? zin + A_ : zin - A_;
     const float B_ = (so + f.bias[ce + 1]) * f.scale[ce + 1];
     const float sc = sigmoidf_(B_ + 2.0f);
-    const long long lq = __double2ll_rn((double)logf(sc) * FIX_SCALE);
-    if (f.mode == TAIL_AFFINE_FWD) { ldq += lq; return (zin + A_) * sc; }
-    ldq -= lq;
-    return zin / sc - A_;
+    const float lg = logf(sc);
+    const float zr = f.mode == TAIL_AFFINE_FWD ? (zin + A_) * sc : zin / sc - A_;
+    // a non-finite log-det term (fp16-range overflow upstream, diverged weights, a saturated sigmoid) cannot go into the
+    // fixed-point sum: `bad` returns it and the caller raises the sample's sticky flag (common.h).  A non-finite z needs no flag
+    // of its own: it reaches a prior's logp, which is then non-finite.
+    const float term = f.mode == TAIL_AFFINE_FWD ? lg : -lg;
+    if (isfinite(term)) ldq += __double2ll_rn((double)term * FIX_SCALE);
+    else bad = term;
+    return zr;
 }
 
 // sum of a Q31.32 term over a workgroup of NT threads (valid in thread 0); red: NT / 64 slots of LDS
@@ -237,7 +242,9 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
                 const float z1v = zp[(long)c * HW + p];
                 const float zin = zp[(long)(Ch + c) * HW + p];
                 long long lq = 0;
-                const float zres = fin_couple(f, n, c, p, zin, lq);
+                float bad = 0.f;
+                const float zres = fin_couple(f, n, c, p, zin, lq, bad);
+                if (bad != 0.f && r >= 1 && r <= g.R && blockIdx.y == 0) fix_flag_nonfinite(a.acc, n, a.N, bad);
                 if (r >= 1 && r <= g.R && blockIdx.y == 0) ldq[sub & 1] += lq;   // own pixel (not a halo row), once per tile: counts for the log-det
                 if (!a.pre_mix.reverse && a.pre_mix.C) {             // ActNorm of the mixer on both halves, staged for its matrix / gather
                     v1 = (z1v + a.pre_mix.bias[c]) * a.pre_mix.scale[c];
@@ -414,7 +421,7 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
                         h4 hi, lo;
 #pragma unroll
                         for (int t = 0; t < 4; ++t) {
-                            const float v = fmaxf(fmaf(acc1[i][j][4 * gq + t], rs[t], bb[t]), 0.f);
+                            const float v = relu_(fmaf(acc1[i][j][4 * gq + t], rs[t], bb[t]));
                             _Float16 x0, x1;
                             sh2_split(v, x0, x1);
                             hi[t] = x0; lo[t] = x1;
@@ -514,7 +521,7 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
 #pragma unroll
             for (int j = 0; j < PT2; ++j)
 #pragma unroll
-                for (int t = 0; t < 4; ++t) acc2[i][j][4 * gq + t] = fmaxf(fmaf(acc2[i][j][4 * gq + t], rs[t], bb[t]), 0.f);
+                for (int t = 0; t < 4; ++t) acc2[i][j][4 * gq + t] = relu_(fmaf(acc2[i][j][4 * gq + t], rs[t], bb[t]));
         }
     GH_STAMP(10);
 
@@ -773,7 +780,9 @@ __global__ void __launch_bounds__(256) k_cfinish(CfinArgs a) {
         const int p = p0 + q;
         const float zin = zi[(long)(Ch + c) * HW + p];
         const float z1v = zi[(long)c * HW + p];
-        const float zres = fin_couple(f, n, c, p, zin, ldq);
+        float bad = 0.f;
+        const float zres = fin_couple(f, n, c, p, zin, ldq, bad);
+        if (bad != 0.f) fix_flag_nonfinite(a.acc, n, a.N, bad);
         if (a.mix.C) {
             if (!a.mix.reverse) {     // ActNorm of the next step on both halves, staged for its matrix / gather
                 mixv[c * PXB + q] = (z1v + a.mix.bias[c]) * a.mix.scale[c];

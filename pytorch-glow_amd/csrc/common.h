@@ -40,9 +40,19 @@ constexpr float LOGSCALE = 3.0f;  // network/module.py:10 logscale_factor
 // Kept as signed Q31.32 fixed point in a u64 so that atomic accumulation from many workgroups is
 // order-independent (bitwise reproducible), unlike float atomics.
 constexpr double FIX_SCALE = 4294967296.0;
-__device__ __forceinline__ void fix_atomic_add(unsigned long long* acc, double v) {
+// acc: 2 N words -- acc[n] the accumulator of sample n, acc[N + n] its STICKY NON-FINITE FLAG.  A NaN / inf partial sum cannot
+// be represented in fixed point (the conversion would silently turn NaN into 0): it raises the flag instead, and k_finalize
+// reports NaN / +inf / -inf for a flagged sample -- an fp16-range overflow in the split-half kernels, diverged weights or out-of-distribution
+// input surface as a non-finite nll exactly as in the reference, never as a finite wrong one.
+// flag bits: 1 = a NaN term, 2 = a +inf term, 4 = a -inf term (k_finalize: NaN wins, +inf and -inf together give NaN, as in the
+// reference's floating-point sum)
+__device__ __forceinline__ void fix_flag_nonfinite(unsigned long long* acc, long n, int N, double v) {
+    atomicOr(acc + N + n, isnan(v) ? 1ull : (v > 0 ? 2ull : 4ull));
+}
+__device__ __forceinline__ void fix_atomic_add(unsigned long long* acc, long n, int N, double v) {
+    if (!isfinite(v)) { fix_flag_nonfinite(acc, n, N, v); return; }
     long long q = __double2ll_rn(v * FIX_SCALE);
-    atomicAdd(acc, (unsigned long long)q);
+    atomicAdd(acc + n, (unsigned long long)q);
 }
 __device__ __forceinline__ double fix_to_double(unsigned long long a) {
     return (double)(long long)a * (1.0 / FIX_SCALE);
@@ -83,6 +93,9 @@ __device__ __forceinline__ int xcd_remap(int b, int nblk) {
 }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// ReLU that PROPAGATES NaN like the reference's (torch.relu(NaN) = NaN); fmaxf(NaN, 0) = 0 would turn an fp16-range overflow
+// (inf - inf = NaN in a split-half operand) into a finite wrong activation
+__device__ __forceinline__ float relu_(float v) { return v < 0.f ? 0.f : v; }
 
 // ---- debug build only (-DGLOWHIP_DEBUG_STAMPS): s_memtime stamps of workgroup 0 / wave 0, read back by scripts/stamps.py
 #ifdef GLOWHIP_DEBUG_STAMPS

@@ -51,7 +51,7 @@ __global__ void __launch_bounds__(256) k_conv_direct(ConvArgs a) {
             if (a.post_bias) v += a.post_bias[o];
             if (a.post_scale) v *= a.post_scale[o];
             else if (a.post_logs) v *= expf(a.post_logs[o] * LOGSCALE);
-            if (a.relu) v = fmaxf(v, 0.f);
+            if (a.relu) v = relu_(v);
             a.y[(n * a.Cout + o) * HW + p] = v;
         }
     }

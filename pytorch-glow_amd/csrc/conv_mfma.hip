@@ -170,7 +170,7 @@ k_conv_wide(const float* __restrict__ X, long x_bs, const float* __restrict__ Wt
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const float v = (acc[i][j][r] + bo) * so;
-                stage[row * WN + j * 32 + ml] = relu ? fmaxf(v, 0.f) : v;
+                stage[row * WN + j * 32 + ml] = relu ? relu_(v) : v;
             }
         }
     }
@@ -330,7 +330,7 @@ k_gemm_glds(const float* __restrict__ X, long x_bs, const float* __restrict__ Wt
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const float v = (acc[i][j][r] + bo) * so;
-                stage[row * WN + j * 32 + ml] = relu ? fmaxf(v, 0.f) : v;
+                stage[row * WN + j * 32 + ml] = relu ? relu_(v) : v;
             }
         }
     }

@@ -180,7 +180,7 @@ k_conv_first(const float* __restrict__ X, long x_bs, const float* __restrict__ W
                             h4 hi, lo;
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
-                                const float v = relu ? fmaxf(acc[i][j][4 * gq + q], 0.f) : acc[i][j][4 * gq + q];
+                                const float v = relu ? relu_(acc[i][j][4 * gq + q]) : acc[i][j][4 * gq + q];
                                 _Float16 a, b;
                                 sh_split(v, a, b);
                                 hi[q] = a; lo[q] = b;
@@ -202,7 +202,7 @@ k_conv_first(const float* __restrict__ X, long x_bs, const float* __restrict__ W
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int o = mt * BM + wr * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl;
-                        yn[(long)o * HW] = relu ? fmaxf(acc[i][j][r], 0.f) : acc[i][j][r];
+                        yn[(long)o * HW] = relu ? relu_(acc[i][j][r]) : acc[i][j][r];
                     }
                 }
             }

@@ -287,7 +287,7 @@ __global__ void __launch_bounds__(256) k_conv_tail(TailConvArgs a, TailGeom gr, 
     if (wk == 0) ld = tail_epilogue<MT, NTW>(a, acc, n, p0, HW, wn, mt0, paired, lane);
     if (a.acc && (a.mode == TAIL_AFFINE_FWD || a.mode == TAIL_AFFINE_REV || a.mode == TAIL_SPLIT_FWD)) {
         const double tot = block_sum<256>(ld, red);
-        if (tid == 0) fix_atomic_add(a.acc + n, tot);
+        if (tid == 0) fix_atomic_add(a.acc, n, a.N, tot);
     }
 }
 

@@ -157,7 +157,7 @@ k_f02_sh(const float* __restrict__ X, long x_bs, const _Float16* __restrict__ W0
                         h4 hi, lo;
 #pragma unroll
                         for (int t = 0; t < 4; ++t) {
-                            const float v = fmaxf(am[i][u][4 * gq + t] + ax[i][u][4 * gq + t] * SH_LO_INV, 0.f);
+                            const float v = relu_(am[i][u][4 * gq + t] + ax[i][u][4 * gq + t] * SH_LO_INV);
                             _Float16 a, b;
                             sh_split(v, a, b);
                             hi[t] = a; lo[t] = b;
@@ -235,7 +235,7 @@ k_f02_sh(const float* __restrict__ X, long x_bs, const _Float16* __restrict__ W0
                     h4 hi, lo;
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
-                        const float v = fmaxf(accm[i][jn][4 * gq + t] + accx[i][jn][4 * gq + t] * SH_LO_INV, 0.f);
+                        const float v = relu_(accm[i][jn][4 * gq + t] + accx[i][jn][4 * gq + t] * SH_LO_INV);
                         _Float16 a, b;
                         sh_split(v, a, b);
                         hi[t] = a; lo[t] = b;

@@ -114,7 +114,7 @@ k_first_sh(const float* __restrict__ X, long x_bs, const _Float16* __restrict__ 
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const float t = accm[u][4 * gq + q] + accx[u][4 * gq + q] * SH_LO_INV;
-                    const float v = relu ? fmaxf(t, 0.f) : t;
+                    const float v = relu ? relu_(t) : t;
                     _Float16 a, b;
                     sh_split(v, a, b);
                     hi[q] = a; lo[q] = b;

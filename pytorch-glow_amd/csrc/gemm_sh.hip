@@ -43,7 +43,7 @@ __device__ __forceinline__ void gemm_sh_epilogue(const f32x16_t (&accm)[2][2], c
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const float t = accm[i][j][4 * g + q] + accx[i][j][4 * g + q] * SH_LO_INV;
-                    v[q] = relu ? fmaxf(t, 0.f) : t;
+                    v[q] = relu ? relu_(t) : t;
                 }
                 if (OUT_SH) {
                     h4 hi, lo;

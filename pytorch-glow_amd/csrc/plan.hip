@@ -53,7 +53,7 @@ struct Workspace {
 
 static size_t workspace_bytes(const glowhip_plan* p, int N) {
     size_t off = 0;
-    take(off, (size_t)N * 8);
+    take(off, (size_t)N * 16);
     take(off, (size_t)N * p->max_chw * 4);
     take(off, (size_t)N * p->max_chw * 4);
     take(off, (size_t)N * p->max_hidden * 4);
@@ -67,7 +67,7 @@ static int carve(const glowhip_plan* p, int N, void* ws, size_t bytes, Workspace
         return GLOWHIP_EWORKSPACE;
     }
     size_t off = 0;
-    w.acc = at<unsigned long long>(ws, take(off, (size_t)N * 8));
+    w.acc = at<unsigned long long>(ws, take(off, (size_t)N * 16));
     w.bufA = at<float>(ws, take(off, (size_t)N * p->max_chw * 4));
     w.bufB = at<float>(ws, take(off, (size_t)N * p->max_chw * 4));
     w.h1 = at<float>(ws, take(off, (size_t)N * p->max_hidden * 4));

@@ -108,7 +108,7 @@ static void wgrad_scratch_floats(const glowhip_plan* p, int N, size_t* col, size
 
 static size_t train_ws_layout(const glowhip_plan* p, int N, void* base, TrainWs* w) {
     size_t off = 0;
-    const size_t o_acc = take(off, (size_t)N * 8), o_gld = take(off, (size_t)N * 4), o_gsum = take(off, 64);
+    const size_t o_acc = take(off, (size_t)N * 16), o_gld = take(off, (size_t)N * 4), o_gsum = take(off, 64);
     const size_t o_gA = take(off, (size_t)N * p->max_chw * 4), o_gB = take(off, (size_t)N * p->max_chw * 4);
     const size_t o_h1 = take(off, (size_t)N * p->max_hidden * 4), o_h2 = take(off, (size_t)N * p->max_hidden * 4);
     const size_t o_gpre = take(off, (size_t)N * p->max_chw * 4);

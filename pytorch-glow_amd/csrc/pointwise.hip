@@ -300,7 +300,7 @@ __global__ void __launch_bounds__(256) k_coupling_tail(CouplingTailArgs a) {
     }
     if (a.affine && a.acc) {
         double tot = block_sum<256>(ld, red);
-        if (threadIdx.x == 0) fix_atomic_add(a.acc + n, a.reverse ? -tot : tot);
+        if (threadIdx.x == 0) fix_atomic_add(a.acc, n, a.N, a.reverse ? -tot : tot);
     }
 }
 
@@ -340,7 +340,7 @@ __global__ void __launch_bounds__(256) k_split_tail(SplitTailArgs a) {
     }
     if (!a.reverse && a.acc) {
         double tot = block_sum<256>(lp, red);
-        if (threadIdx.x == 0) fix_atomic_add(a.acc + n, tot);
+        if (threadIdx.x == 0) fix_atomic_add(a.acc, n, a.N, tot);
     }
 }
 
@@ -366,7 +366,7 @@ __global__ void __launch_bounds__(256) k_gaussian_logp(const float* __restrict__
         lp = (double)gauss_logp1(m, l, x[n * xbs + e]);
     }
     double tot = block_sum<256>(lp, red);
-    if (threadIdx.x == 0) fix_atomic_add(acc + n, tot);
+    if (threadIdx.x == 0) fix_atomic_add(acc, n, gridDim.y, tot);
 }
 
 int launch_gaussian_logp(const float* x, long xbs, const float* mean, const float* logs, long mlbs, int N, int C,
@@ -380,12 +380,12 @@ int launch_gaussian_logp(const float* x, long xbs, const float* mean, const floa
 
 __global__ void __launch_bounds__(256) k_zero_acc(unsigned long long* acc, int N) {
     int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < N) acc[i] = 0ull;
+    if (i < 2 * N) acc[i] = 0ull;      // accumulators and non-finite flags
 }
 
 int launch_zero_acc(unsigned long long* acc, int N, hipStream_t s) {
     if (N == 0) return GLOWHIP_OK;
-    hipLaunchKernelGGL(k_zero_acc, dim3(cdiv(N, 256)), dim3(256), 0, s, acc, N);
+    hipLaunchKernelGGL(k_zero_acc, dim3(cdiv(2 * N, 256)), dim3(256), 0, s, acc, N);
     GH_LAUNCH_CHECK("k_zero_acc");
     return GLOWHIP_OK;
 }
@@ -398,6 +398,10 @@ __global__ void __launch_bounds__(256) k_finalize(const float* __restrict__ in,
     int n = blockIdx.x * 256 + threadIdx.x;
     if (n >= N) return;
     double v = (in ? (double)in[n] : 0.0) + offset + (konst ? sign * konst[0] : 0.0) + (acc ? fix_to_double(acc[n]) : 0.0);
+    if (acc && acc[N + n] != 0ull) {      // partial sums of this sample that were NaN / +inf / -inf (common.h)
+        const unsigned long long fl = acc[N + n];
+        v = ((fl & 1ull) || (fl & 6ull) == 6ull) ? __builtin_nan("") : ((fl & 2ull) ? __builtin_inf() : -__builtin_inf());
+    }
     if (out_unscaled) out_unscaled[n] = (float)v;
     if (out) out[n] = (float)(v * scale);
 }

@@ -265,7 +265,7 @@ __global__ void __launch_bounds__(64 * NWV) k_tail_sh(TailShArgs a, int WGM, int
     GH_STAMP(5);
     if (paired) {
         const double tot = block_sum<NTHR>(ld, red);
-        if (tid == 0) fix_atomic_add(a.acc + n, tot);
+        if (tid == 0) fix_atomic_add(a.acc, n, a.N, tot);
     }
 }
 

@@ -248,9 +248,15 @@ class Glow(nn.Module):
         nc = h.shape[1]
         return h[:, :nc // 2, ...], h[:, nc // 2:, ...]
 
-    def normal_flow(self, x, y_onehot=None, noise=None, repack=False):
+    def normal_flow(self, x, y_onehot=None, noise=None, repack=False, safe=False):
         """z = x + U(0, 1/2^n_bits); objective = -ln(n_bins)*CHW + logdet + logp(z); nll = -objective/(ln2*CHW).
-        ``noise`` (optional, beyond the reference signature) injects the dequantisation draw."""
+        ``noise`` (optional, beyond the reference signature) injects the dequantisation draw.
+
+        Range: the product kernels carry the coupling networks' activations as fp16 pairs (csrc/sh.h): a hidden activation
+        beyond 4094 becomes inf there where the fp32 reference stays finite.  That never yields a finite wrong answer -- a
+        sticky per-sample flag makes the nll NaN -- and ``safe=True`` (inference path; costs one host sync) re-runs such a batch
+        on the exact-fp32 MFMA kernels, so the result is the reference's up to fp32 rounding for any input the reference
+        handles."""
         x = require_device_tensor(x, "Glow input", allow_uint8=True)   # uint8 = pixels as loaded, scaled by 1/255 in-kernel
         if x.dtype == torch.uint8 and (self.training or torch.is_grad_enabled()):
             x = x.float() / 255.0   # the ActNorm init pass and the training step take fp32; inference reads the bytes itself
@@ -276,7 +282,23 @@ class Glow(nn.Module):
             z, nll = _GlowTrainFn.apply(plan, x, noise, n_bits, *params)
             return z, nll, None
         z, nll, _ = plan.glow_forward(x, noise, mean, logs, stride, n_bits, repack=repack)
+        if safe and not bool(torch.isfinite(nll).all()):
+            z, nll = self._forward_exact_fp32(plan, x, noise, mean, logs, stride, n_bits)
         return z, nll, None
+
+    _RANGE_FALLBACKS = 0   # how often safe=True had to re-run on the exact-fp32 kernels (diagnostics / tests)
+
+    def _forward_exact_fp32(self, plan, x, noise, mean, logs, stride, n_bits):
+        """The same forward on the exact-fp32 MFMA kernels (v_mfma_f32_32x32x2_f32): no fp16 range limit.  Process-wide kernel
+        switch (glowhip_debug_force_tail_tile), so not for concurrent use from several threads."""
+        Glow._RANGE_FALLBACKS += 1
+        _lib.lib().glowhip_debug_force_tail_tile(0x800)
+        try:
+            z, nll, _ = plan.glow_forward(x, noise, mean, logs, stride, n_bits, repack=True)
+        finally:
+            _lib.lib().glowhip_debug_force_tail_tile(0)
+            plan.invalidate()          # the next call re-derives the product kernels' weight images
+        return z, nll
 
     def reverse_flow(self, z, y_onehot=None, eps_std=None, eps=None):
         with torch.no_grad():

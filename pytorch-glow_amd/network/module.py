@@ -288,7 +288,7 @@ class GaussianDiag:
         mean = None if mean is None else require_device_tensor(mean.expand_as(x), "mean")
         logs = None if logs is None else require_device_tensor(logs.expand_as(x), "logs")
         out = torch.empty(n, dtype=torch.float32, device=x.device)
-        scratch = torch.empty(n, dtype=torch.int64, device=x.device)
+        scratch = torch.empty(2 * n, dtype=torch.int64, device=x.device)   # accumulator + sticky non-finite flag per sample
         check(lib().glowhip_gaussian_logp(ptr(x), c * h * w, ptr(mean), ptr(logs), c * h * w, n, c, h * w, None, ptr(out),
                                           ptr(scratch), stream_ptr(x.device)))
         return out

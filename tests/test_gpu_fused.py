@@ -173,3 +173,69 @@ def test_fuzz_parity_seeded(case, path):
     line, worst, counts = fuzz_parity.run_case(case, big=True)
     print(line)
     assert worst < 1e-4
+
+
+# ------------------------------------------------------------------------------------------------ range / non-finite handling
+def _range_case(scale_h):
+    """One FlowStep-deep Glow whose f.0 ActNorm scale is blown up so that h1 reaches ~scale_h (the fp16 pairs of the split-half
+    kernels hold |v| < 4094 with the activation pre-scale 16)."""
+    cfg = O.default_cfg(image_shape=(16, 16, 3), hidden_channels=64, K=1, L=1, batch=4)
+    sd = O.seeded_state_dict(cfg, seed=3, zeros_std=1e-6)
+    sd["flow.layers.1.f.0.actnorm.logs"] = sd["flow.layers.1.f.0.actnorm.logs"] + float(np.log(scale_h)) / 3.0
+    sd["flow.layers.1.f.2.actnorm.logs"] = sd["flow.layers.1.f.2.actnorm.logs"] - float(np.log(scale_h)) / 3.0   # keep h2 modest
+    g = torch.Generator().manual_seed(9)
+    x = torch.rand(4, 3, 16, 16, generator=g); noise = torch.rand(4, 3, 16, 16, generator=g) / 256
+    z_ref, nll_ref, _ = O.glow_forward(x, noise, sd, cfg)
+    return cfg, sd, x, noise, z_ref, nll_ref
+
+
+@pytest.mark.parametrize("flags", [0, 0x100000, 0x800])
+def test_range_overflow_is_never_a_finite_wrong_answer(flags):
+    """Hidden activations of ~1e5 overflow the fp16 pairs (product kernels: cnet; 0x100000: the kernel pairs) but not fp32 (0x800:
+    exact-fp32 kernels).  The reference stays finite.  Overflowing paths must report a NON-FINITE nll (sticky per-sample flag:
+    a NaN partial sum cannot hide in the fixed-point accumulator), never a finite wrong one; the fp32 kernels must match the
+    oracle; and safe=True must recover the reference's answer through the exact-fp32 re-run."""
+    cfg, sd, x, noise, z_ref, nll_ref = _range_case(3e5)
+    assert torch.isfinite(nll_ref).all()
+    G.lib().glowhip_debug_force_tail_tile(flags)
+    try:
+        glow = make_glow(cfg, sd, 4)
+        z, nll, _ = glow.normal_flow(dev(x), None, noise=dev(noise))
+        if flags == 0x800:
+            close(nll, nll_ref, 1e-4, what="nll (exact fp32 kernels)")
+            return
+        ok = torch.isfinite(nll).cpu()
+        assert not ok.any() or (nll.cpu()[ok] - nll_ref[ok]).abs().max() < 1e-4, "finite AND wrong nll after an fp16-range overflow"
+        if flags == 0:     # (the kernel pairs fall back to exact-fp32 kernels at this small hidden width: no overflow there)
+            assert (~ok).any(), "this input is meant to overflow the split-half range"
+    finally:
+        G.lib().glowhip_debug_force_tail_tile(0)
+    if flags != 0:
+        return
+    n0 = G.Glow._RANGE_FALLBACKS
+    z2, nll2, _ = glow.normal_flow(dev(x), None, noise=dev(noise), safe=True)
+    assert G.Glow._RANGE_FALLBACKS == n0 + 1
+    close(nll2, nll_ref, 1e-4, what="nll after the exact-fp32 re-run"); close(z2, z_ref, 1e-4, what="z after the re-run")
+    # and the product path is back afterwards
+    cfgm, sdm, xm, noisem, zm_ref, nllm_ref = _range_case(1.0)
+    glow_m = make_glow(cfgm, sdm, 4)
+    zq, nllq, _ = glow_m.normal_flow(dev(xm), None, noise=dev(noisem), safe=True)
+    assert G.Glow._RANGE_FALLBACKS == n0 + 1
+    close(nllq, nllm_ref, 1e-4, what="nll (in range)")
+
+
+def test_nan_input_gives_nan_nll_on_every_path():
+    """A NaN pixel must give a NaN nll for that sample (and only that sample) -- the fixed-point accumulators cannot hold it, the
+    sticky flag does."""
+    cfg, sd, x, noise, _, nll_ref = _range_case(1.0)
+    x = x.clone(); x[2, 1, 5, 5] = float("nan")
+    for flags in (0, 0x100000, 0x800):
+        G.lib().glowhip_debug_force_tail_tile(flags)
+        try:
+            glow = make_glow(cfg, sd, 4)
+            _, nll, _ = glow.normal_flow(dev(x), None, noise=dev(noise))
+        finally:
+            G.lib().glowhip_debug_force_tail_tile(0)
+        nll = nll.cpu()
+        assert torch.isnan(nll[2]) and torch.isfinite(nll[[0, 1, 3]]).all(), (flags, nll)
+        assert (nll[[0, 1, 3]] - nll_ref[[0, 1, 3]]).abs().max() < 1e-4
