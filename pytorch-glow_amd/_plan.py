@@ -123,14 +123,20 @@ class FlowPlan:
     def pack(self, use: int = 3) -> None:
         """Refresh what is derived from the parameters (exp(3 logs), LU, and the weight images `use` asks for: the inference
         kernels' and/or the training kernels')."""
+        version = self._version_signature()
+        if version == self._packed_version:
+            use |= getattr(self, "_packed_use", 0)       # same parameters: the images packed earlier stay valid, add to them
         check(lib().glowhip_plan_pack_for(self._h, ptr(self.packed), self.packed.numel(), use, stream_ptr(self.device)))
-        self._packed_version = self._version_signature()
+        self._packed_version = version
         self._packed_use = use
 
     def ensure_packed(self, force: bool = False, use: int = 1) -> None:
+        """Re-derive the packed data when the parameters changed since the last pack (or `force`), or when images `use` asks
+        for have not been packed for the current parameter version."""
         have = getattr(self, "_packed_use", 0)
-        if force or self._packed_version != self._version_signature() or (use & ~have):
-            self.pack(use)
+        stale = self._packed_version != self._version_signature()
+        if force or stale or (use & ~have):
+            self.pack(use if (force or stale) else (use & ~have))
 
     def invalidate(self) -> None:
         self._packed_version = None
@@ -234,7 +240,7 @@ class FlowPlan:
     def glow_forward_train(self, x, noise, prior_mean, prior_logs, prior_stride, n_bits):
         """Forward that records the activation tape; returns (z, nll, tape)."""
         n = x.shape[0]
-        self.ensure_packed(True, use=self.PACK_TRAINING)   # weights are expected to have just been updated
+        self.ensure_packed(False, use=self.PACK_TRAINING)   # re-packs when the weights changed since the last pack (optimizer step)
         z = torch.empty((n,) + self.out_chw, dtype=torch.float32, device=self.device)
         nll = torch.empty(n, dtype=torch.float32, device=self.device)
         tape = torch.empty(int(lib().glowhip_plan_tape_bytes(self._h, n)), dtype=torch.uint8, device=self.device)
@@ -242,6 +248,7 @@ class FlowPlan:
         check(lib().glowhip_glow_forward_train(self._h, ptr(self.packed), ptr(x), ptr(noise), ptr(prior_mean),
                                                ptr(prior_logs), prior_stride, n_bits, ptr(z), ptr(nll), None, n, ptr(tape),
                                                tape.numel(), ptr(ws), ws.numel(), stream_ptr(self.device)))
+        self._tape_version = self._packed_version           # glow_backward must see the same weights (and their images)
         return z, nll, tape
 
     def _train_workspace(self, n):
@@ -255,6 +262,10 @@ class FlowPlan:
     def glow_backward(self, x, tape, nll_grad, z_grad, prior_mean, prior_logs, prior_stride, want_grad_x=False):
         """Parameter gradients (list aligned with trainable_parameters()) and optionally dL/dx."""
         n = x.shape[0]
+        if (self._version_signature() != getattr(self, "_tape_version", None) or self._packed_version != self._tape_version
+                or not (getattr(self, "_packed_use", 0) & self.PACK_TRAINING)):
+            raise _lib.GlowHipError("glow_backward: the parameters (or their packed images) changed between the training forward "
+                                    "and its backward -- an in-place update or optimizer step in between would mix weight versions")
         fields = self._grad_fields()
         grads = [torch.empty_like(p) for _, _, p in fields]
         arr = (_lib.LayerGrads * len(self.layers))()

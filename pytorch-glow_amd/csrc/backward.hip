@@ -162,7 +162,7 @@ __global__ void __launch_bounds__(256) k_act_bwd(float* __restrict__ g, const fl
 // per-channel sums are plain wave reductions.
 __global__ void __launch_bounds__(256) k_act_bwd_sh(float* __restrict__ g, const float* __restrict__ h,
                                                     const float* __restrict__ e, int Cm, int HW, double* __restrict__ acc_b,
-                                                    double* __restrict__ acc_l, _Float16* __restrict__ gsh) {
+                                                    double* __restrict__ acc_l, _Float16* __restrict__ gsh, float sh_scale) {
     __shared__ __attribute__((aligned(16))) _Float16 st[2][64][8];
     const int px = threadIdx.x & 63, cq = threadIdx.x >> 6;
     const int chunk = blockIdx.y;
@@ -175,8 +175,12 @@ __global__ void __launch_bounds__(256) k_act_bwd_sh(float* __restrict__ g, const
         const float hv = h[idx], gh = g[idx];
         const float gu = hv > 0.f ? gh * e[c] : 0.f;
         g[idx] = gu;
+        // The split-half copy carries gu * 2^k (exact): with loss = mean(nll), dL/d(objective) = 1 / (B ln2 CHW) ~ 1e-6 and the
+        // gradients behind the near-zero Conv2dZeros weights are ~1e-8 .. 1e-10 -- below fp16's normal range (6.1e-5), where
+        // the pair is only absolutely accurate (2.9e-11).  2^k = B ln2 CHW rounded to a power of two brings them back to
+        // O(1)-relative magnitudes; the GEMM that consumes the tensor multiplies its result by 2^-k.
         _Float16 a, b;
-        sh_split(gu, a, b);
+        sh_split(gu * sh_scale, a, b);
         st[0][px][cq * 2 + k] = a;
         st[1][px][cq * 2 + k] = b;
         const double tb = wave_sum((double)gu), tl = wave_sum((double)(gh * hv) * 3.0);
@@ -194,11 +198,11 @@ __global__ void __launch_bounds__(256) k_act_bwd_sh(float* __restrict__ g, const
 }
 
 int launch_act_bwd(float* g, const float* h, const float* e, int N, int Cm, int HW, double* acc_b, double* acc_l,
-                   hipStream_t s, _Float16* g_sh) {
+                   hipStream_t s, _Float16* g_sh, float sh_scale) {
     if (N == 0) return GLOWHIP_OK;
     if (g_sh) {
         GH_REQUIRE(HW % 64 == 0 && Cm % 8 == 0, "act_bwd: split-half copy needs HW %% 64 == 0 and channels %% 8 == 0");
-        hipLaunchKernelGGL(k_act_bwd_sh, dim3(HW / 64, Cm / 8, N), dim3(256), 0, s, g, h, e, Cm, HW, acc_b, acc_l, g_sh);
+        hipLaunchKernelGGL(k_act_bwd_sh, dim3(HW / 64, Cm / 8, N), dim3(256), 0, s, g, h, e, Cm, HW, acc_b, acc_l, g_sh, sh_scale);
         GH_LAUNCH_CHECK("k_act_bwd_sh");
         return GLOWHIP_OK;
     }

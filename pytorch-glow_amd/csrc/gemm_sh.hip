@@ -26,7 +26,7 @@ constexpr int SH_STAGE_HALFS = 2 * SH_A_HALFS;                    // A + B: 16 K
 template <bool OUT_SH>
 __device__ __forceinline__ void gemm_sh_epilogue(const f32x16_t (&accm)[2][2], const f32x16_t (&accx)[2][2],
                                                  const float* __restrict__ bias, float* __restrict__ Yf,
-                                                 _Float16* __restrict__ Ysh, long P, int M, int HW, int relu, int tile_m,
+                                                 _Float16* __restrict__ Ysh, long P, int M, int HW, int relu, float out_scale, int tile_m,
                                                  int tile_n, int wr, int wc, int kl, int ml) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -42,7 +42,7 @@ __device__ __forceinline__ void gemm_sh_epilogue(const f32x16_t (&accm)[2][2], c
                 float v[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float t = accm[i][j][4 * g + q] + accx[i][j][4 * g + q] * SH_LO_INV;
+                    const float t = (accm[i][j][4 * g + q] + accx[i][j][4 * g + q] * SH_LO_INV) * out_scale;   // power of two: exact
                     v[q] = relu ? relu_(t) : t;
                 }
                 if (OUT_SH) {
@@ -71,7 +71,7 @@ __device__ __forceinline__ void gemm_sh_epilogue(const f32x16_t (&accm)[2][2], c
 template <bool OUT_SH>
 __global__ void __launch_bounds__(256, 2)
 k_gemm_sh(const _Float16* __restrict__ X, long P, const _Float16* __restrict__ Wsh, const float* __restrict__ bias,
-          float* __restrict__ Yf, _Float16* __restrict__ Ysh, int K, int M, int HW, int relu) {
+          float* __restrict__ Yf, _Float16* __restrict__ Ysh, int K, int M, int HW, int relu, float out_scale) {
     extern __shared__ __attribute__((aligned(16))) _Float16 smem_h[];   // SH_ST stages
     GH_STAMP(16);
     const int tiles_m = M / SH_BM;
@@ -165,7 +165,7 @@ k_gemm_sh(const _Float16* __restrict__ X, long P, const _Float16* __restrict__ W
     }
 
     GH_STAMP(18);
-    gemm_sh_epilogue<OUT_SH>(accm, accx, bias, Yf, Ysh, P, M, HW, relu, tile_m, tile_n, wr, wc, kl, ml);
+    gemm_sh_epilogue<OUT_SH>(accm, accx, bias, Yf, Ysh, P, M, HW, relu, out_scale, tile_m, tile_n, wr, wc, kl, ml);
     GH_STAMP(19);
 }
 
@@ -178,7 +178,7 @@ size_t gemm_sh_packed_bytes(int K, int M) {
 }
 
 int launch_gemm_sh(const _Float16* x_sh, const void* wsh, float* y_f32, _Float16* y_sh, int N, int K, int HW, int M, int relu,
-                   hipStream_t s) {
+                   hipStream_t s, float out_scale) {
     GH_REQUIRE(gemm_sh_supported(K, M, HW, 1), "gemm_sh: unsupported shape K=%d M=%d HW=%d", K, M, HW);
     GH_REQUIRE((y_f32 != nullptr) != (y_sh != nullptr), "gemm_sh: exactly one output");
     if (N == 0) return GLOWHIP_OK;
@@ -189,10 +189,10 @@ int launch_gemm_sh(const _Float16* x_sh, const void* wsh, float* y_f32, _Float16
     const unsigned grid = (unsigned)((M / SH_BM) * ((P + SH_BN - 1) / SH_BN));
     if (y_sh) {
         (void)hipFuncSetAttribute((const void*)k_gemm_sh<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k_gemm_sh<true>, dim3(grid), dim3(256), lds, s, x_sh, P, w, bias, nullptr, y_sh, K, M, HW, relu);
+        hipLaunchKernelGGL(k_gemm_sh<true>, dim3(grid), dim3(256), lds, s, x_sh, P, w, bias, nullptr, y_sh, K, M, HW, relu, out_scale);
     } else {
         (void)hipFuncSetAttribute((const void*)k_gemm_sh<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k_gemm_sh<false>, dim3(grid), dim3(256), lds, s, x_sh, P, w, bias, y_f32, nullptr, K, M, HW, relu);
+        hipLaunchKernelGGL(k_gemm_sh<false>, dim3(grid), dim3(256), lds, s, x_sh, P, w, bias, y_f32, nullptr, K, M, HW, relu, out_scale);
     }
     GH_LAUNCH_CHECK("k_gemm_sh");
     return GLOWHIP_OK;

@@ -259,6 +259,9 @@ static int backward_sweep(glowhip_plan* p, const void* packed, const float* x_in
                           TrainWs& w, float* g_top, hipStream_t s) {
     // g: gradient w.r.t. the current layer's OUTPUT (contiguous (N, C_out, H, W)), held in gA/gB
     float* g = g_top;
+    // power-of-two pre-scale of the gradients that travel as fp16 pairs (k_act_bwd_sh): 2^round(log2(B ln2 CHW)), the inverse
+    // of dL/d(objective) for loss = mean(nll) (network/model.py:448-450, 496-506)
+    const float sh_grad_scale = exp2f(rintf(log2f((float)N * 0.6931472f * (float)p->in_shape[0] * p->in_shape[1] * p->in_shape[2])));
     const int nl = (int)p->layers.size();
     std::vector<GradJob>& jobs = p->grad_jobs;
     jobs.clear();
@@ -317,7 +320,7 @@ static int backward_sweep(glowhip_plan* p, const void* packed, const float* x_in
             }
             const bool shd = L.sh_mid && train_sh_enabled() && HW % 64 == 0;   // f.2's input gradient on the f16 pipe
             GH_TRY(launch_act_bwd(w.gh2, h2, at<float>(packed, L.f2_scale), N, hid, HW, a2b, a2l, s,
-                                  shd ? (_Float16*)w.gsh : nullptr));
+                                  shd ? (_Float16*)w.gsh : nullptr, sh_grad_scale));
             // (c) f.2 (1x1)
             if (fastw) {
                 GH_TRY(launch_wgrad_mfma(w.gh2, (long)hid * HW, h1, (long)hid * HW, w.partial, G.f2_w, N, HW, hid, hid, hid, hid,
@@ -326,7 +329,8 @@ static int backward_sweep(glowhip_plan* p, const void* packed, const float* x_in
                 GH_TRY(launch_wgrad_direct(w.gh2, h1, (long)hid * HW, G.f2_w, N, hid, d.H, d.W, hid, 1, s));
             }
             if (shd) {
-                GH_TRY(launch_gemm_sh((const _Float16*)w.gsh, at<char>(packed, L.f2T_sh), w.gh1, nullptr, N, hid, HW, hid, 0, s));
+                GH_TRY(launch_gemm_sh((const _Float16*)w.gsh, at<char>(packed, L.f2T_sh), w.gh1, nullptr, N, hid, HW, hid, 0, s,
+                                      1.0f / sh_grad_scale));
             } else if (L.mfma_mid) {   // W2 in its reference layout [o][i] is already the K-major image of the transposed GEMM
                 GH_TRY(launch_conv_mfma_wide(w.gh2, (long)hid * HW, d.f2_w, nullptr, nullptr, w.gh1, N, hid, d.H, d.W, hid, 1,
                                              s, 0));

@@ -56,7 +56,7 @@ bool gemm_sh_supported(int K, int M, int H, int W);
 size_t gemm_sh_packed_bytes(int K, int M);
 // exactly one of y_f32 (N,M,H,W fp32) / y_sh (SH tensor, P = N*HW) is written
 int launch_gemm_sh(const _Float16* x_sh, const void* wsh, float* y_f32, _Float16* y_sh, int N, int K, int HW, int M, int relu,
-                   hipStream_t s);
+                   hipStream_t s, float out_scale = 1.0f);   // out_scale: exact power of two applied to the result
 
 // ---- f.0 on SH operands (first_sh.hip): fp32 z in, SH h1 out -----------------------------------------
 // wsh: half [2][G][Cout][8] (k group g = tap * nchunk + chunk, 8 channels each; ActNorm scale folded), then Cout floats b'

@@ -35,7 +35,8 @@ def build_scheduler(hps):
     if name not in lr_scheduler.SCHEDULES:
         raise KeyError(f"unknown lr_scheduler {name!r}; the reference knows {sorted(lr_scheduler.SCHEDULES)}")
     args = dict(hps.optim.lr_scheduler_args)
-    return partial(lr_scheduler.SCHEDULES[name], base_lr=hps.optim.optimizer_args["lr"], **args)
+    args.setdefault("base_lr", hps.optim.optimizer_args["lr"])     # builder.py:118-119: only when the profile does not set it
+    return partial(lr_scheduler.SCHEDULES[name], **args)
 
 
 class TrainLoop:
