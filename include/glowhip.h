@@ -221,6 +221,20 @@ int glowhip_glow_backward(glowhip_plan* plan, const void* packed, const float* x
                           const float* prior_logs, long prior_stride, const glowhip_layer_grads* grads,
                           float* grad_x, int N, void* workspace, size_t workspace_bytes, glowhip_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Optimiser step (reference network/trainer.py:142-150: clip_grad_value_, clip_grad_norm_, optimizer.step() with the
+ * torch.optim.Adam / Adamax of network/builder.py:10-13,108-113) over ALL parameters as two launches.
+ * A chunk is at most 2^16 consecutive elements of one parameter with its gradient and optimiser state (m = exp_avg,
+ * v = exp_avg_sq for Adam / exp_inf for Adamax).  partial_dev: n_chunks doubles of scratch.  kind: 0 = Adam (amsgrad off),
+ * 1 = Adamax; step: 1-based count of this update (bias corrections); clip_value / max_norm <= 0: that clipping off.
+ * grad_norm_out (1 float, may be NULL) <- total gradient norm after the value clipping, before the norm clipping, as
+ * clip_grad_norm_ returns it.  Gradients are clipped IN PLACE as the reference's utilities do.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct glowhip_optim_chunk { float* param; float* grad; float* m; float* v; int32_t n; int32_t pad; } glowhip_optim_chunk;
+int glowhip_optim_step(const glowhip_optim_chunk* chunks_dev, int n_chunks, int kind, float lr, double beta1, double beta2,
+                       float eps, float weight_decay, int step, float clip_value, float max_norm, double* partial_dev,
+                       float* grad_norm_out, glowhip_stream_t stream);
+
 /* Per-launch timing for benchmarks (HIP events recorded on the execution stream around every kernel of
  * the coupling path).  enable=1 creates an event pool (host resource), enable=0 destroys it; while enabled
  * every encode/decode appends records.  glowhip_plan_timing_read synchronises with the recorded events,

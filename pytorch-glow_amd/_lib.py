@@ -48,6 +48,11 @@ class LayerGrads(ctypes.Structure):
                                         "f2_w", "f2_an_bias", "f2_an_logs", "f4_w", "f4_bias", "f4_logs")]
 
 
+class OptimChunk(ctypes.Structure):
+    """Mirror of ``glowhip_optim_chunk``."""
+    _fields_ = [("param", c_void_p), ("grad", c_void_p), ("m", c_void_p), ("v", c_void_p), ("n", c_int32), ("pad", c_int32)]
+
+
 class TimingRecord(ctypes.Structure):
     """Mirror of ``glowhip_timing_record``."""
     _fields_ = [("kind", c_int32), ("layer", c_int32), ("mfma", c_int32), ("ms", c_float)]
@@ -91,6 +96,7 @@ SIGNATURES = {
                                            c_size_t, _P]),
     "glowhip_glow_backward": (c_int, [_P, _P, _P, _P, c_size_t, _P, _P, _P, _P, c_long, POINTER(LayerGrads), _P, c_int,
                                       _P, c_size_t, _P]),
+    "glowhip_optim_step": (c_int, [_P, c_int, c_int, c_float, ctypes.c_double, ctypes.c_double, c_float, c_float, c_int, c_float, c_float, _P, _P, _P]),
     "glowhip_plan_timing_enable": (c_int, [_P, c_int]),
     "glowhip_plan_timing_read": (c_int, [_P, POINTER(TimingRecord), c_int, POINTER(c_int)]),
 }

@@ -119,14 +119,17 @@ def train_step(glow, optimizer, x_local: torch.Tensor, world: int = 1, max_grad_
         loss = glow.generative_loss(nll)
         loss.backward()
     allreduce_gradients(glow, world)
-    params = [p for p in glow.parameters() if p.grad is not None]
-    if max_grad_clip and max_grad_clip > 0:
-        torch.nn.utils.clip_grad_value_(params, max_grad_clip)
-    if max_grad_norm and max_grad_norm > 0:
-        grad_norm = torch.nn.utils.clip_grad_norm_(params, max_grad_norm)
+    if hasattr(optimizer, "fused_step"):     # training.HipAdam / HipAdamax: both clippings + the update in two HIP launches
+        grad_norm = optimizer.fused_step(max_grad_clip, max_grad_norm)
     else:
-        grad_norm = torch.zeros((), device=x_local.device)
-    optimizer.step()
+        params = [p for p in glow.parameters() if p.grad is not None]
+        if max_grad_clip and max_grad_clip > 0:
+            torch.nn.utils.clip_grad_value_(params, max_grad_clip)
+        if max_grad_norm and max_grad_norm > 0:
+            grad_norm = torch.nn.utils.clip_grad_norm_(params, max_grad_norm)
+        else:
+            grad_norm = torch.zeros((), device=x_local.device)
+        optimizer.step()
     loss = loss.detach()
     if world > 1:
         dist.all_reduce(loss, op=dist.ReduceOp.SUM)

@@ -14,7 +14,134 @@ import torch
 from . import parallel
 from .misc import lr_scheduler
 
-OPTIMIZERS = {"adam": torch.optim.Adam, "adamax": torch.optim.Adamax}
+import ctypes
+
+from . import _lib
+
+
+class _HipOptimizer(torch.optim.Optimizer):
+    """torch.optim.Adam / Adamax with the whole step -- and the reference loop's two gradient clippings in front of it
+    (network/trainer.py:142-150) -- as TWO HIP launches over all parameter tensors (csrc/optim.hip) instead of several foreach
+    kernels per operation over ~1 060 tensors.  Same hyper-parameters, same per-parameter state names (``step``, ``exp_avg``,
+    ``exp_avg_sq`` / ``exp_inf``), so ``state_dict()`` round-trips with torch's classes and the optimiser state of a
+    reference snapshot (misc/util.py:309-322) loads.  The state tensors are views into two flat buffers.
+
+    ``step()`` alone is torch's semantics; ``fused_step(max_grad_clip, max_grad_norm)`` also clips (in place, like
+    ``clip_grad_value_`` / ``clip_grad_norm_``) and returns the total gradient norm as a device tensor -- no host sync."""
+
+    KIND = 0
+    SECOND = "exp_avg_sq"
+    CHUNK = 1 << 16
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, **unsupported):
+        for k, v in unsupported.items():
+            if v not in (False, None, 0):
+                raise ValueError(f"{type(self).__name__}: option {k}={v!r} is not supported on the HIP optimiser")
+        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
+        self._flat = None
+        self._steps = 0
+
+    def _ensure_state(self):
+        if self._flat is not None:
+            return
+        ps = [p for g in self.param_groups for p in g["params"]]
+        if not ps:
+            return
+        dev = ps[0].device
+        if dev.type != "cuda" or any(p.device != dev or p.dtype != torch.float32 or not p.is_contiguous() for p in ps):
+            raise _lib.GlowHipError("the HIP optimiser needs contiguous fp32 parameters on one HIP device")
+        total = sum(p.numel() for p in ps)
+        m, v = torch.zeros(total, device=dev), torch.zeros(total, device=dev)
+        off = 0
+        for p in ps:
+            n = p.numel()
+            st = self.state[p]
+            for name, buf in (("exp_avg", m), (self.SECOND, v)):
+                view = buf[off:off + n].view_as(p)
+                if name in st:                      # state loaded before the first step (load_state_dict)
+                    view.copy_(st[name])
+                st[name] = view
+            st.setdefault("step", torch.tensor(float(self._steps)))
+            off += n
+        self._flat = (m, v)
+        self._partial = None
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        steps = [float(s["step"]) for s in self.state.values() if "step" in s]
+        self._steps = int(max(steps)) if steps else 0
+        self._flat = None            # re-home the loaded tensors in the flat buffers at the next step
+        self._ensure_state()
+
+    @torch.no_grad()
+    def fused_step(self, max_grad_clip=0.0, max_grad_norm=0.0):
+        self._ensure_state()
+        group0 = self.param_groups[0]
+        dev = group0["params"][0].device
+        chunks = []
+        for g in self.param_groups:
+            if (g["betas"], g["eps"], g["weight_decay"]) != (group0["betas"], group0["eps"], group0["weight_decay"]) or g["lr"] != group0["lr"]:
+                raise _lib.GlowHipError("the HIP optimiser takes one set of hyper-parameters for all parameter groups")
+            for p in g["params"]:
+                if p.grad is None:
+                    continue
+                gr = p.grad
+                if not gr.is_contiguous() or gr.dtype != torch.float32:
+                    raise _lib.GlowHipError("gradients must be contiguous fp32")
+                st = self.state[p]
+                n, base = p.numel(), (p.data_ptr(), gr.data_ptr(), st["exp_avg"].data_ptr(), st[self.SECOND].data_ptr())
+                for o in range(0, n, self.CHUNK):
+                    chunks.append((base[0] + 4 * o, base[1] + 4 * o, base[2] + 4 * o, base[3] + 4 * o, min(self.CHUNK, n - o)))
+        self._steps += 1
+        for st in self.state.values():
+            if "step" in st:
+                st["step"] = torch.tensor(float(self._steps))
+        norm = torch.zeros(1, device=dev)
+        if not chunks:
+            return norm[0]
+        key = hash(tuple(c[1] for c in chunks))       # the caching allocator usually hands the gradients the same addresses again
+        if getattr(self, "_table_key", None) == (key, len(chunks)):
+            table = self._keep
+        else:
+            arr = (_lib.OptimChunk * len(chunks))(*[_lib.OptimChunk(*c, 0) for c in chunks])
+            host = torch.frombuffer(bytearray(ctypes.string_at(arr, ctypes.sizeof(arr))), dtype=torch.uint8)
+            table = host.to(dev, non_blocking=False)
+            self._table_key = (key, len(chunks))
+        if self._partial is None or self._partial.numel() < len(chunks):
+            self._partial = torch.empty(len(chunks), dtype=torch.float64, device=dev)
+        _lib.check(_lib.lib().glowhip_optim_step(
+            _lib.ptr(table), len(chunks), self.KIND, float(group0["lr"]), float(group0["betas"][0]), float(group0["betas"][1]),
+            float(group0["eps"]), float(group0["weight_decay"]), self._steps, float(max_grad_clip or 0.0), float(max_grad_norm or 0.0),
+            _lib.ptr(self._partial), _lib.ptr(norm), _lib.stream_ptr(dev)))
+        self._keep = table      # alive until the stream has consumed it (the next step replaces it)
+        for g in self.param_groups:            # the kernel wrote the parameters behind torch's back: bump their version counters,
+            for p in g["params"]:              # which is what tells the flow plans to re-derive their packed weight images
+                if p.grad is not None:
+                    torch.autograd.graph.increment_version(p)
+        return norm[0]
+
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        self.fused_step(0.0, 0.0)
+        return loss
+
+
+class HipAdam(_HipOptimizer):
+    KIND, SECOND = 0, "exp_avg_sq"
+
+
+class HipAdamax(_HipOptimizer):
+    KIND, SECOND = 1, "exp_inf"
+
+    def __init__(self, params, lr=2e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, **kw):
+        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, **kw)
+
+
+# hps.optim.optimizer -> class (builder.py:10-13).  The HIP classes are drop-in for torch.optim.Adam / Adamax (same arguments,
+# same state_dict); GLOWHIP_TORCH_OPTIM=1 selects torch's own for A/B comparisons.
+import os as _os
+OPTIMIZERS = ({"adam": torch.optim.Adam, "adamax": torch.optim.Adamax} if _os.environ.get("GLOWHIP_TORCH_OPTIM") == "1"
+              else {"adam": HipAdam, "adamax": HipAdamax})
 
 
 def build_optimizer(hps, params: Iterable[torch.nn.Parameter]) -> torch.optim.Optimizer:

@@ -273,3 +273,46 @@ def test_tiny_gradients_behind_near_zero_tail_weights_purely_relative():
         assert err.max().item() <= 0.05 * scale, f"{name}: max err {err.max().item():.3e}, max|g| {scale:.3e}"
         checked += 1
     assert checked == 3 * K * 6
+
+
+@pytest.mark.parametrize("kind", ["adam", "adamax"])
+def test_hip_optimizer_matches_torch_optim(kind):
+    """csrc/optim.hip against torch.optim.Adam / Adamax + clip_grad_value_ + clip_grad_norm_ (network/trainer.py:142-150) over
+    five steps on tensors of awkward sizes (one longer than a 2^16 chunk): parameters, both state tensors and the returned
+    gradient norm at 1e-6 relative; state_dict interchange both ways."""
+    from pytorch_glow_amd import training
+    g = torch.Generator().manual_seed(3)
+    shapes = [(512, 24, 3, 3), (1, 512, 1, 1), (48, 48), (7,), (70001,)]
+    p_ref = [torch.nn.Parameter((torch.randn(s, generator=g) * 0.1).to(DEV)) for s in shapes]
+    p_hip = [torch.nn.Parameter(p.detach().clone()) for p in p_ref]
+    args = dict(lr=1e-3, betas=(0.9, 0.9999), eps=1e-8, weight_decay=0)
+    o_ref = (torch.optim.Adam if kind == "adam" else torch.optim.Adamax)(p_ref, **args)
+    o_hip = (training.HipAdam if kind == "adam" else training.HipAdamax)(p_hip, **args)
+    rel = lambda a, b: ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+    for step in range(5):
+        grads = [torch.randn(s, generator=g).to(DEV) * (10.0 if step == 2 else 0.5) for s in shapes]
+        for p, q, gr in zip(p_ref, p_hip, grads):
+            p.grad, q.grad = gr.clone(), gr.clone()
+        torch.nn.utils.clip_grad_value_(p_ref, 5.0)
+        n_ref = torch.nn.utils.clip_grad_norm_(p_ref, 100.0)
+        o_ref.step()
+        n_hip = o_hip.fused_step(5.0, 100.0)
+        assert abs(n_hip.item() - n_ref.item()) <= 1e-5 * n_ref.item()
+        for p, q in zip(p_ref, p_hip):
+            assert rel(q.detach(), p.detach()) < 1e-6 and rel(q.grad, p.grad) < 1e-6
+    second = "exp_avg_sq" if kind == "adam" else "exp_inf"
+    for p, q in zip(p_ref, p_hip):
+        assert rel(o_hip.state[q]["exp_avg"], o_ref.state[p]["exp_avg"]) < 1e-6
+        assert rel(o_hip.state[q][second], o_ref.state[p][second]) < 1e-6
+    # state_dict interchange: torch -> hip and hip -> torch, then one more identical step
+    o_hip2 = (training.HipAdam if kind == "adam" else training.HipAdamax)([torch.nn.Parameter(p.detach().clone()) for p in p_ref], **args)
+    o_hip2.load_state_dict(o_ref.state_dict())
+    o_ref2 = (torch.optim.Adam if kind == "adam" else torch.optim.Adamax)([torch.nn.Parameter(p.detach().clone()) for p in p_ref], **args)
+    o_ref2.load_state_dict(o_hip.state_dict())
+    grads = [torch.randn(s, generator=g).to(DEV) for s in shapes]
+    for o in (o_ref, o_hip2, o_ref2):
+        for p, gr in zip(o.param_groups[0]["params"], grads):
+            p.grad = gr.clone()
+        o.step()
+    for a, b, c in zip(o_ref.param_groups[0]["params"], o_hip2.param_groups[0]["params"], o_ref2.param_groups[0]["params"]):
+        assert rel(b.detach(), a.detach()) < 1e-6 and rel(c.detach(), a.detach()) < 1e-6

@@ -45,7 +45,8 @@ def test_builder_training_state(built, tmp_path):
     hps2.general.pre_trained = hps.general.pre_trained
     hps2.general.result_dir = str(tmp_path)
     st = Builder(hps2).build(training=True)
-    assert isinstance(st["optimizer"], torch.optim.Adam) and len(st["optimizer"].state) > 0     # Adam state of the snapshot
+    from pytorch_glow_amd import training
+    assert isinstance(st["optimizer"], (torch.optim.Adam, training.HipAdam)) and len(st["optimizer"].state) > 0   # Adam state of the snapshot
     assert st["scheduler"](global_step=0) == pytest.approx(1e-4 / 10)
     assert os.path.basename(st["result_subdir"]) == "000-g9"
     hps3 = _g9_hps()
@@ -96,3 +97,50 @@ def test_inferer_decode_sample_and_attribute_manipulation(built):
     assert (out - want).abs().max().item() < 1e-5
     with pytest.raises(AssertionError):
         inf.apply_attribute_delta(g["xs"][0], deltaz, [0.5])
+
+
+def test_trainer_runs_train_py_as_written(tmp_path):
+    """train.py:36-49 of the reference, verbatim but for the dataset: ``state = Builder(hps).build()``,
+    ``Trainer(hps=hps, dataset=dataset, **state).train()``.  Synthetic dataset of the reference's ``{'x', 'y_onehot'}`` items;
+    8 steps: the loss falls, a snapshot in the reference's format appears (and loads back through the Builder with its
+    optimiser state), the reconstruction / sampling hooks run, scalars are exported."""
+    from pytorch_glow_amd.network import Trainer
+
+    class Synthetic(torch.utils.data.Dataset):
+        def __init__(self):
+            g = torch.Generator().manual_seed(0)
+            base = torch.rand(1, 3, 16, 16, generator=g)
+            self.x = (base + 0.05 * torch.rand(32, 3, 16, 16, generator=g)).clamp(0, 1)
+        def __len__(self):
+            return self.x.shape[0]
+        def __getitem__(self, i):
+            return {"x": self.x[i], "y_onehot": torch.zeros(3)}
+
+    hps = _g9_hps()
+    hps.general.warm_start = False
+    hps.general.result_dir = str(tmp_path)
+    hps.optim.update(num_batch_train=8, num_epochs=8, interval_scalar=1, interval_snapshot=4, interval_valid=3, interval_sample=5,
+                     num_sample=2, optimizer="adam", optimizer_args=dict(lr=1e-3, betas=[0.9, 0.9999], eps=1e-8),
+                     lr_scheduler="noam", lr_scheduler_args=dict(warmup_steps=20, min_lr=1e-5))
+    hps.dataset.num_workers = 0
+    util.manual_seed(3)
+    state = Builder(hps).build()
+    trainer = Trainer(hps=hps, dataset=Synthetic(), **state)
+    assert trainer.num_epochs == 2 and trainer.batch_size == 8
+    first = []
+    orig = trainer.loop.step
+    trainer.loop.step = lambda x: (lambda r: (first.append(r[0].item()), r)[1])(orig(x))
+    trainer.train()
+    assert trainer.step == 8 and len(first) == 8 and all(np.isfinite(first))
+    assert min(first[-2:]) < first[0], first
+    sub = state["result_subdir"]
+    assert os.path.exists(os.path.join(sub, "network-snapshot-000004.pth")) and os.path.exists(os.path.join(sub, "all_scalars.json"))
+    snap = torch.load(os.path.join(sub, "network-snapshot-000004.pth"), map_location="cpu", weights_only=False)
+    assert set(snap) == {"step", "graph", "optimizer", "criterion", "seconds"} and snap["step"] == 4
+    assert set(snap["graph"]) == set(state["graph"].state_dict()) and len(snap["optimizer"]["state"]) > 0
+    # the snapshot warm-starts a new run through the Builder (reference builder.py:66-104)
+    hps2 = _g9_hps()
+    hps2.general.update(warm_start=True, result_dir=str(tmp_path), resume_run_id=0, resume_step=4, pre_trained="")
+    hps2.optim.update(hps.optim)
+    st2 = Builder(hps2).build()
+    assert st2["step"] == 4 and len(st2["optimizer"].state) > 0

@@ -132,10 +132,10 @@ def test_optimizer_and_scheduler_are_built_from_the_profile():
     hps = util.load_profile("celeba")
     w = torch.nn.Parameter(torch.zeros(3))
     opt = training.build_optimizer(hps, [w])
-    assert isinstance(opt, torch.optim.Adam) and opt.defaults["betas"] == (0.9, 0.9999) and opt.defaults["lr"] == 1e-3
+    assert isinstance(opt, (torch.optim.Adam, training.HipAdam)) and opt.defaults["betas"] == (0.9, 0.9999) and opt.defaults["lr"] == 1e-3
     sched = training.build_scheduler(hps)
     assert sched(global_step=0) == pytest.approx(1e-3 / 4000) and sched(global_step=3999) == pytest.approx(1e-3)
-    assert isinstance(training.build_optimizer(util.load_profile("test"), [w]), torch.optim.Adamax)
+    assert isinstance(training.build_optimizer(util.load_profile("test"), [w]), (torch.optim.Adamax, training.HipAdamax))
     hps.optim.optimizer = "sgd"
     with pytest.raises(KeyError):
         training.build_optimizer(hps, [w])
