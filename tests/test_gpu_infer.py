@@ -144,3 +144,42 @@ def test_trainer_runs_train_py_as_written(tmp_path):
     hps2.optim.update(hps.optim)
     st2 = Builder(hps2).build()
     assert st2["step"] == 4 and len(st2["optimizer"].state) > 0
+
+
+def test_hip_path_under_a_one_rank_rccl_process_group(tmp_path):
+    """The data-parallel helpers on DEVICE tensors under a real RCCL ("nccl") process group of one rank -- rendezvous on
+    127.0.0.1, data-dependent init + flat parameter broadcast, scalar loss all-reduce, gradient all-reduce, one training step --
+    in a child process (a process group per pytest process would leak into the other tests)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", RANK="0", WORLD_SIZE="1")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+import pytorch_glow_amd as G
+from pytorch_glow_amd import parallel, training
+from test_host import _g9_hps
+hps = _g9_hps(); hps.optim.num_batch_train = 4
+glow = G.Glow(hps).to("cuda:0")
+x = torch.rand(4, 3, 16, 16, device="cuda:0")
+glow.train(); parallel.data_dependent_init(glow, x, rank=0, world=dist.get_world_size())
+glow.eval()
+with torch.no_grad():
+    z, nll, _ = glow.normal_flow(x, None)
+    total = parallel.reduce_loss(nll, 2)          # world > 1 branch: the all-reduce really runs (sum over one rank)
+    gathered = parallel.gather_nll(nll, 2) if False else nll
+assert torch.isfinite(total) and abs(total.item() - nll.sum().item()) < 1e-4
+loop = training.TrainLoop(glow, hps, rank=0, world=1)
+l0, _ = loop.step(x)
+parallel.allreduce_gradients(glow, world=2, average=False)      # flat-buffer all-reduce on device gradients
+l1, _ = loop.step(x)
+assert torch.isfinite(l0) and torch.isfinite(l1)
+print("RCCL_OK", dist.get_backend(), dist.get_world_size(), float(total))
+dist.destroy_process_group()
+''' % (root, root)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert out.returncode == 0 and "RCCL_OK nccl 1" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
