@@ -207,6 +207,8 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="images per GPU (default: the config's: 64 / 32 / 16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-repack", action="store_true", help="inference mode: keep derived parameter data across steps")
+    ap.add_argument("--repack", action="store_true", help="inverse mode: re-derive the parameter data (W^-1, weight images) every step "
+                    "as well (default there: once -- sampling from a trained model)")
     ap.add_argument("--mode", choices=["forward", "inverse", "train"], default="forward",
                     help="forward = the headline metric (Glow.normal_flow); inverse = Glow.reverse_flow sampling throughput; "
                          "train = full training step (fwd with tape + HIP backward + RCCL gradient all-reduce + clip + Adam)")
@@ -254,7 +256,7 @@ def main():
     parallel.data_dependent_init(glow, x, rank=rank, world=world)
     glow.eval()
     plan = glow.flow.plan_for(x)
-    repack = not args.no_repack
+    repack = args.repack if args.mode == "inverse" else not args.no_repack
 
     if args.mode == "inverse":
         z_top = torch.randn((B,) + tuple(plan.out_chw), device=device) * 0.7
@@ -270,7 +272,7 @@ def main():
             loss, _ = loop.step(x)
             return loss * (world * B)
         if args.mode == "inverse":   # secondary metric: sampling (eps drawn on device, W^-1 from the in-kernel LU)
-            plan.ensure_packed(repack)
+            plan.ensure_packed(repack, use=plan.PACK_INFERENCE | plan.PACK_INVERSE)
             xs = glow.reverse_flow(z_top, None, eps_std=0.7)
             return xs.sum()
         z, nll, _ = glow.normal_flow(x, None, repack=repack)

@@ -118,13 +118,13 @@ class FlowPlan:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._ws
 
-    PACK_INFERENCE, PACK_TRAINING = 1, 2   # glowhip.h GLOWHIP_PACK_*
+    PACK_INFERENCE, PACK_TRAINING, PACK_INVERSE = 1, 2, 4   # glowhip.h GLOWHIP_PACK_*
 
-    def pack(self, use: int = 3) -> None:
+    def pack(self, use: int = 7, merge: bool = True) -> None:
         """Refresh what is derived from the parameters (exp(3 logs), LU, and the weight images `use` asks for: the inference
         kernels' and/or the training kernels')."""
         version = self._version_signature()
-        if version == self._packed_version:
+        if merge and version == self._packed_version:
             use |= getattr(self, "_packed_use", 0)       # same parameters: the images packed earlier stay valid, add to them
         check(lib().glowhip_plan_pack_for(self._h, ptr(self.packed), self.packed.numel(), use, stream_ptr(self.device)))
         self._packed_version = version
@@ -136,7 +136,8 @@ class FlowPlan:
         have = getattr(self, "_packed_use", 0)
         stale = self._packed_version != self._version_signature()
         if force or stale or (use & ~have):
-            self.pack(use if (force or stale) else (use & ~have))
+            # forced = the caller declares the parameters changed (behind the version counters' back): nothing packed earlier counts
+            self.pack(use if (force or stale) else (use & ~have), merge=not force)
 
     def invalidate(self) -> None:
         self._packed_version = None
@@ -182,7 +183,7 @@ class FlowPlan:
         n = z.shape[0]
         assert tuple(z.shape[1:]) == self.out_chw, (z.shape, self.out_chw)
         assert len(eps) >= self.n_split
-        self.ensure_packed(repack)
+        self.ensure_packed(repack, use=self.PACK_INFERENCE | self.PACK_INVERSE)
         x = torch.empty((n,) + self.in_chw, dtype=torch.float32, device=self.device)
         ld_out = torch.empty(n, dtype=torch.float32, device=self.device) if want_logdet else None
         if n == 0:
@@ -285,7 +286,7 @@ class FlowPlan:
         check(lib().glowhip_plan_actnorm_init(self._h, ptr(self.packed), self.packed.numel(), ptr(x), ptr(noise),
                                               float(actnorm_scale), n, ptr(ws), ws.numel(), stream_ptr(self.device)))
         self._packed_version = self._version_signature()   # the init pass ends with a full glowhip_plan_pack
-        self._packed_use = 3
+        self._packed_use = 7
 
 
 class PlanCache:

@@ -2,6 +2,8 @@
 // Tensor.inverse at network/module.py:357,365).  One workgroup per matrix runs Gauss-Jordan
 // elimination with partial pivoting in fp64 on the augmented matrix [W | I] held in LDS (C <= 64)
 // or in an L2-resident scratch buffer (larger C): log|det W| = sum log|pivot|, W^-1 = right half.
+#include <algorithm>
+
 #include "kernels.h"
 
 namespace glowhip {
@@ -9,6 +11,7 @@ namespace glowhip {
 size_t invconv_scratch_bytes(int C) { return (size_t)C * 2 * C * sizeof(double); }
 
 constexpr int LU_LDS_MAX_C = 64;  // 64 * 128 * 8 B = 64 KiB
+constexpr int LU_LDS_ONLY_MAX_C = 128;   // log-det only: 128 * 128 * 8 B = 128 KiB
 
 // Workgroup-wide Gauss-Jordan on A = [W | I] (C x 2C doubles, LDS or global).  Returns log|det W| (thread 192).
 // Three barriers per pivot: (1) pivot row and value published by wave 0; (2) rows k and p swapped with the pivot row scaled
@@ -81,6 +84,66 @@ __device__ double lu_gauss_jordan(const float* __restrict__ w, int C, float* __r
     return s_logdet;
 }
 
+// log|det W| ONLY (what encode / glow_forward need; W^-1 is for decode and the backward pass): LU with partial pivoting on the
+// C x C matrix alone, the rank-1 update restricted to the trailing (C-k-1)^2 block -- C^3/3 element updates instead of
+// Gauss-Jordan's 2 C^3 on the augmented matrix.  For C = 384 (config E's last level) that is the difference between 150 ms
+// and a few ms per pack.  A: C*C doubles (LDS for C <= 128, global scratch above).
+__device__ double lu_logdet_only(const float* __restrict__ w, int C, double* A) {
+    __shared__ int s_piv2;
+    __shared__ double s_pivval2;
+    const int tid = threadIdx.x;
+    __syncthreads();
+    for (int e = tid; e < C * C; e += 256) A[e] = (double)w[e];
+    double logdet = 0.0;   // meaningful in thread 192
+    __syncthreads();
+    for (int k = 0; k < C; ++k) {
+        if (tid < 64) {
+            double best = -1.0;
+            int bi = k;
+            for (int r = k + tid; r < C; r += 64) {
+                double v = fabs(A[r * C + k]);
+                if (v > best) { best = v; bi = r; }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                double ov = __shfl_down(best, o, 64);
+                int oi = __shfl_down(bi, o, 64);
+                if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+            }
+            if (tid == 0) { s_piv2 = bi; s_pivval2 = A[bi * C + k]; }
+        }
+        __syncthreads();
+        const int pr = s_piv2;
+        const double piv = s_pivval2;
+        if (tid == 192) logdet += log(fabs(piv));
+        const int rem = C - k - 1;
+        if (rem == 0) break;
+        // swap the trailing parts of rows k and pr (columns > k), and turn column k below the diagonal into multipliers
+        if (pr != k)
+            for (int c = k + 1 + tid; c < C; c += 256) {
+                const double t = A[pr * C + c];
+                A[pr * C + c] = A[k * C + c];
+                A[k * C + c] = t;
+            }
+        for (int r = k + 1 + tid; r < C; r += 256) {
+            const double akk = (r == pr && pr != k) ? A[k * C + k] : A[r * C + k];   // row pr now holds old row k
+            A[r * C + k] = akk / piv;
+        }
+        __syncthreads();
+        // trailing update: A[r][c] -= l[r] * A[k][c], r, c > k; a thread walks one row segment with stride 256 over (r, c)
+        const long nel = (long)rem * rem;
+        for (long e = tid; e < nel; e += 256) {
+            const int r = k + 1 + (int)(e / rem), c = k + 1 + (int)(e - (long)(e / rem) * rem);
+            A[r * C + c] = fma(-A[r * C + k], A[k * C + c], A[r * C + c]);
+        }
+        __syncthreads();
+    }
+    __shared__ double s_logdet2;
+    if (tid == 192) s_logdet2 = logdet;
+    __syncthreads();
+    return s_logdet2;
+}
+
 template <bool USE_LDS>
 __global__ void __launch_bounds__(256) k_invconv_prepare(const float* __restrict__ w, int C, float* __restrict__ winv,
                                                          float* __restrict__ logabsdet, double* __restrict__ scratch) {
@@ -91,14 +154,19 @@ __global__ void __launch_bounds__(256) k_invconv_prepare(const float* __restrict
 
 // Batched form used by glowhip_plan_pack: one workgroup per FlowStep; also produces the step's
 // data-independent log-det term  konst = 3*sum(actnorm.logs)*HW + log|det W|*HW  (network/module.py:76-82,356-357).
-__global__ void __launch_bounds__(256) k_step_prepare_batched(const StepPrepJob* __restrict__ jobs, char* packed) {
+__global__ void __launch_bounds__(256) k_step_prepare_batched(const StepPrepJob* __restrict__ jobs, char* packed, int want_inverse) {
     extern __shared__ __attribute__((aligned(16))) double lds_aug[];
     __shared__ double red[4];
     const StepPrepJob j = jobs[blockIdx.x];
     double lad = 0.0;
     if (j.w) {
-        double* A = j.C <= LU_LDS_MAX_C ? lds_aug : (double*)(packed + j.scratch_off);
-        lad = lu_gauss_jordan(j.w, j.C, (float*)(packed + j.winv_off), A);
+        if (j.C <= LU_LDS_MAX_C || want_inverse) {
+            double* A = j.C <= LU_LDS_MAX_C ? lds_aug : (double*)(packed + j.scratch_off);
+            lad = lu_gauss_jordan(j.w, j.C, (float*)(packed + j.winv_off), A);
+        } else {      // wide level, forward only: log|det W| without the inverse
+            double* A = j.C <= LU_LDS_ONLY_MAX_C ? lds_aug : (double*)(packed + j.scratch_off);
+            lad = lu_logdet_only(j.w, j.C, A);
+        }
     }
     double acc = 0.0;
     for (int k = threadIdx.x; k < j.C; k += 256) acc += (double)(j.an_logs[k] * LOGSCALE);
@@ -124,15 +192,18 @@ __global__ void __launch_bounds__(256) k_sum_konst(const StepPrepJob* __restrict
     if (threadIdx.x == 0) *(double*)packed = t;
 }
 
-int launch_step_prepare_batched(const StepPrepJob* jobs_dev, int n, int max_lds_c, void* packed, hipStream_t s) {
+int launch_step_prepare_batched(const StepPrepJob* jobs_dev, int n, int max_lds_c, void* packed, hipStream_t s, int want_inverse,
+                                int max_c) {
     if (n == 0) {
         (void)hipMemsetAsync(packed, 0, sizeof(double), s);
         return GLOWHIP_OK;
     }
-    const size_t lds = invconv_scratch_bytes(max_lds_c > 0 ? max_lds_c : 1);
+    size_t lds = invconv_scratch_bytes(max_lds_c > 0 ? max_lds_c : 1);
+    if (!want_inverse && max_c > LU_LDS_MAX_C)      // the log-det-only factorisation of matrices up to 128 x 128 runs in LDS
+        lds = std::max(lds, (size_t)std::min(max_c, LU_LDS_ONLY_MAX_C) * std::min(max_c, LU_LDS_ONLY_MAX_C) * sizeof(double));
     if (lds > 32 * 1024)
         (void)hipFuncSetAttribute((const void*)k_step_prepare_batched, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_step_prepare_batched, dim3(n), dim3(256), lds, s, jobs_dev, (char*)packed);
+    hipLaunchKernelGGL(k_step_prepare_batched, dim3(n), dim3(256), lds, s, jobs_dev, (char*)packed, want_inverse);
     GH_LAUNCH_CHECK("k_step_prepare_batched");
     hipLaunchKernelGGL(k_sum_konst, dim3(1), dim3(256), 0, s, jobs_dev, n, (char*)packed);
     GH_LAUNCH_CHECK("k_sum_konst");

@@ -226,10 +226,16 @@ static int run_coupling(glowhip_plan* P, const LayerPlan& L, const void* packed,
         count_launch(P, "k_conv_tail_f32");
         GH_TRY(launch_conv_mfma_tail(t, s));
     } else {
-        ConvArgs c{w.h2, (long)hid * HW, d.f4_w, d.f4_bias, nullptr, nullptr, at<float>(packed, L.f4_scale), 0, w.h1,
-                   N, hid, d.H, d.W, L.Cout, 3};
-        count_launch(P, "k_conv_direct");
-        GH_TRY(launch_conv_direct(c, s));
+        if (L.wide_last && !use_sh_tail) {     // (conv + bias) * exp(3 logs) on the fp32 MFMA implicit-GEMM kernel
+            count_launch(P, "k_conv_wide_f32");
+            GH_TRY(launch_conv_mfma_wide(w.h2, (long)hid * HW, at<float>(packed, L.f4_wt), d.f4_bias, at<float>(packed, L.f4_scale),
+                                         w.h1, N, hid, d.H, d.W, L.Cout, 3, s, 0));
+        } else {
+            ConvArgs c{w.h2, (long)hid * HW, d.f4_w, d.f4_bias, nullptr, nullptr, at<float>(packed, L.f4_scale), 0, w.h1,
+                       N, hid, d.H, d.W, L.Cout, 3};
+            count_launch(P, "k_conv_direct");
+            GH_TRY(launch_conv_direct(c, s));
+        }
         CouplingTailArgs t{w.h1, z2_in, z2_in_bs, z2_out, z2_out_bs, N, Ch, HW,
                            d.coupling == GLOWHIP_COUPLING_AFFINE, reverse, w.acc};
         GH_TRY(launch_coupling_tail(t, s));
@@ -540,6 +546,8 @@ glowhip_plan* glowhip_plan_create(const glowhip_layer_desc* layers, int n_layers
                 p->max_hidden = std::max(p->max_hidden, (long)cnet_scratch_floats_per_sample(H, W, L.Cout));
             }
             if (L.mfma_last) L.f4_wp = take(off, conv_mfma_tail_packed_bytes(d.hidden, L.Cout));
+            L.wide_last = !L.mfma_last && conv_mfma_wide_supported(d.hidden, H, W, L.Cout, 3);
+            if (L.wide_last) L.f4_wt = take(off, conv_mfma_wide_packed_bytes(d.hidden, L.Cout, 3));
             L.dg4_first = conv_mfma_first_supported(L.Cout, H, W, d.hidden);
             if (L.dg4_first) L.f4T_wf = take(off, conv_mfma_first_packed_bytes(L.Cout, d.hidden));
             L.dg0_tail = conv_mfma_tail_supported(d.hidden, H, W, C / 2);
@@ -572,6 +580,7 @@ glowhip_plan* glowhip_plan_create(const glowhip_layer_desc* layers, int n_layers
             j.winv_off = L.winv; j.logabsdet_off = L.logabsdet; j.konst_off = L.konst; j.scratch_off = L.lu_scratch;
             p->prep_jobs.push_back(j);
             if (j.w && d.C <= 64) p->max_lds_c = std::max(p->max_lds_c, d.C);
+            if (j.w) p->max_c = std::max(p->max_c, d.C);
             p->scale_jobs.push_back(ScaleJob{d.an_logs, L.an_scale, L.an_inv_scale, d.C, 1});
             p->scale_jobs.push_back(ScaleJob{d.f0_an_logs, L.f0_scale, 0, d.hidden, 0});
             p->scale_jobs.push_back(ScaleJob{d.f2_an_logs, L.f2_scale, 0, d.hidden, 0});
@@ -618,6 +627,10 @@ glowhip_plan* glowhip_plan_create(const glowhip_layer_desc* layers, int n_layers
                 r.paired = d.coupling == GLOWHIP_COUPLING_AFFINE; r.MT = tail_mt(L.Cout, r.paired);
                 r.use = 2 | (L.sh_tail ? 0 : 1);
                 r.total = (long)tail_chunks(r.Cin) * (TAIL_CK / 4) * 9 * r.MT * 64; p->repack_jobs.push_back(r);
+            }
+            if (L.wide_last) {
+                RepackJob r{}; r.w = d.f4_w; r.out_off = L.f4_wt; r.kind = REPACK_WIDE; r.Cin = d.hidden; r.Cout = L.Cout;
+                r.K = r.Cin * 9; r.Kpad = wide_kpad(r.Cin, 3); r.use = 3; p->repack_jobs.push_back(r);
             }
             if (L.dg4_first) {   // input gradient of f.4 = 3x3 conv Cout -> hidden with w[ci][o][8-tap]
                 RepackJob r{}; r.w = d.f4_w; r.out_off = L.f4T_wf; r.kind = REPACK_FIRST; r.Cin = L.Cout; r.Cout = d.hidden;
@@ -738,12 +751,13 @@ int glowhip_plan_describe_for(const glowhip_plan* plan, int N, char* buf, size_t
 }
 
 int glowhip_plan_pack(glowhip_plan* plan, void* packed, size_t packed_bytes, glowhip_stream_t stream) {
-    return glowhip_plan_pack_for(plan, packed, packed_bytes, GLOWHIP_PACK_INFERENCE | GLOWHIP_PACK_TRAINING, stream);
+    return glowhip_plan_pack_for(plan, packed, packed_bytes, GLOWHIP_PACK_INFERENCE | GLOWHIP_PACK_TRAINING | GLOWHIP_PACK_INVERSE, stream);
 }
 
 int glowhip_plan_pack_for(glowhip_plan* plan, void* packed, size_t packed_bytes, int use, glowhip_stream_t stream) {
     GH_REQUIRE(plan && packed, "plan_pack: null argument");
     GH_REQUIRE(use & (GLOWHIP_PACK_INFERENCE | GLOWHIP_PACK_TRAINING), "plan_pack: empty use mask");
+    const int orig_use = use;
     // with a kernel family switched off through the debug hook the other family's images are needed after all
     if (g_sh_disabled || g_sh_tail_disabled || g_sh_first_disabled || g_cnet_disabled) use = GLOWHIP_PACK_INFERENCE | GLOWHIP_PACK_TRAINING;
     plan->repack_sel.clear();
@@ -769,7 +783,8 @@ int glowhip_plan_pack_for(glowhip_plan* plan, void* packed, size_t packed_bytes,
     GH_TRY(launch_pack_batched(at<ScaleJob>(packed, plan->scale_off), (int)plan->scale_jobs.size(),
                                at<RepackJob>(packed, plan->repack_off), (int)plan->repack_sel.size(), packed, s));
     GH_TRY(launch_step_prepare_batched(at<StepPrepJob>(packed, plan->prep_off), (int)plan->prep_jobs.size(),
-                                       plan->max_lds_c, packed, s));
+                                       plan->max_lds_c, packed, s, (orig_use & (GLOWHIP_PACK_INVERSE | GLOWHIP_PACK_TRAINING)) != 0,
+                                       plan->max_c));
     return GLOWHIP_OK;
 }
 

@@ -29,6 +29,7 @@ struct LayerPlan {
     bool sh_f02 = false;                       // f.0 + f.2 as one kernel (f02_sh.hip), h1 never written
     bool sh_tail = false; size_t f4_sh = 0;   // f.2 writes h2 as an SH tensor, f.4 + coupling on tail_sh.hip
     bool cnet = false; size_t cn_w0 = 0, cn_w2 = 0, cn_w4 = 0;   // whole coupling network as one kernel (cnet_sh.hip), SH2 images
+    bool wide_last = false; size_t f4_wt = 0;   // f.4 on k_conv_wide<3> (+ separate coupling tail): levels no tail kernel takes (4x4 pixels)
     bool first_halo = false;  // f.0 on k_conv_first (stationary pixel window) instead of k_conv_wide<3>
 };
 
@@ -50,7 +51,7 @@ struct glowhip_plan {
     std::vector<RepackJob> repack_jobs;
     std::vector<RepackJob> repack_sel;    // the subset selected by the last glowhip_plan_pack_for (kept alive for the async copy)
     size_t prep_off = 0, scale_off = 0, repack_off = 0;
-    int max_lds_c = 0;
+    int max_lds_c = 0, max_c = 0;
     size_t packed_bytes = 0;
     int in_shape[3] = {0, 0, 0}, out_shape[3] = {0, 0, 0};
     long max_chw = 0;      // max over layer inputs/outputs of C*H*W

@@ -233,10 +233,72 @@ __global__ void __launch_bounds__(256) k_chanmix(ChanMixArgs a, int stage_matrix
     }
 }
 
+// Wide levels (C > 110: the C x C matrix no longer fits beside the pixel tile; 8x8 / 4x4 pixels per image, so a launch has
+// few pixels): workgroup = 16 pixels x 32 OUTPUT channels, grid = (pixel tiles, C / 32).  The 16 x C input tile and the 32
+// matrix rows are staged in LDS; same operation order per output as k_chanmix (r = fma(m[o][i], v[i], r), i ascending).
+__global__ void __launch_bounds__(256) k_chanmix_wide(ChanMixArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float wsm[];   // v [C][16], then m [32][C]
+    const int C = a.C, px = threadIdx.x & 15, og = threadIdx.x >> 4;      // og: 0..15, two outputs each
+    float* v = wsm;
+    float* m = wsm + C * 16;
+    const long gp = (long)blockIdx.x * 16 + px;
+    const long total = (long)a.N * a.HW;
+    const bool valid = gp < total;
+    const long n = valid ? gp / a.HW : 0;
+    const int p = valid ? (int)(gp - n * a.HW) : 0;
+    const float* pa = a.in_a + n * a.in_a_bs + p;
+    const float* pb = a.in_b + n * a.in_b_bs + p;
+    const bool an = a.bias != nullptr;
+    for (int c = og; c < C; c += 16) {
+        float xv = 0.f;
+        if (valid) xv = (c < a.Ca) ? pa[(long)c * a.HW] : pb[(long)(c - a.Ca) * a.HW];
+        if (!a.reverse && an) xv = (xv + a.bias[c]) * a.scale[c];
+        v[c * 16 + px] = xv;
+    }
+    float* po = a.out + n * a.out_bs + p;
+    // gridDim.y == 1 (output aliases an input: in place): this workgroup walks all output slices itself, its pixels already in LDS
+    const int nsl = gridDim.y == 1 ? (C + 31) / 32 : 1;
+    for (int sl = 0; sl < nsl; ++sl) {
+        const int o0 = (gridDim.y == 1 ? sl : (int)blockIdx.y) * 32;
+        __syncthreads();
+        if (a.matrix)
+            for (int e = threadIdx.x; e < 32 * C; e += 256) {
+                const int r = e / C;
+                m[e] = o0 + r < C ? a.matrix[(long)(o0 + r) * C + (e - r * C)] : 0.f;
+            }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int ol = og * 2 + j, o = o0 + ol;
+            if (o >= C) continue;
+            float r;
+            if (a.matrix) {
+                r = 0.f;
+                const float* mr = m + ol * C;
+                for (int i = 0; i < C; ++i) r = fmaf(mr[i], v[i * 16 + px], r);
+            } else {
+                r = v[(a.gather ? a.gather[o] : o) * 16 + px];
+            }
+            if (a.reverse && an) r = r * a.scale[o] - a.bias[o];
+            if (valid) po[(long)o * a.HW] = r;
+        }
+    }
+}
+
 int launch_chanmix(const ChanMixArgs& a, hipStream_t s) {
     GH_REQUIRE(a.C > 0 && a.C <= 512, "channel mixer: C=%d unsupported (1..512)", a.C);
     const long total = (long)a.N * a.HW;
     if (total == 0) return GLOWHIP_OK;
+    if ((size_t)a.C * a.C * sizeof(float) > 48 * 1024) {
+        // output slices over gridDim.y only when the output does not alias an input (other workgroups read the same pixels)
+        const float* o_lo = a.out; const float* o_hi = a.out + (long)a.N * a.out_bs;
+        const bool alias = (a.in_a >= o_lo && a.in_a < o_hi) || (a.in_b >= o_lo && a.in_b < o_hi);
+        const size_t lds = ((size_t)a.C * 16 + (size_t)32 * a.C) * sizeof(float);
+        if (lds > 32 * 1024) (void)hipFuncSetAttribute((const void*)k_chanmix_wide, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_chanmix_wide, dim3(cdiv(total, 16), alias ? 1 : cdiv(a.C, 32)), dim3(256), lds, s, a);
+        GH_LAUNCH_CHECK("k_chanmix_wide");
+        return GLOWHIP_OK;
+    }
     const int stage = (size_t)a.C * a.C * sizeof(float) <= 48 * 1024;   // C <= 110: the matrix fits next to the pixel tile
     const size_t mbytes = stage ? (size_t)a.C * a.C * sizeof(float) : 0;
     if (total < 16384 && a.C >= 16 && stage) {   // deep levels: 16 pixels x 16 output groups per workgroup
