@@ -690,6 +690,7 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
         GH_STAMP(20);
         // own rows: out[c][r][x] = sum over taps whose source row r + dy - 1 lies inside the sub-tile
         const int items = nch << g.lpp;
+        const int slab = M9 << g.lpp;                         // floats per k part
         for (int e = tid; e < items; e += 512) {
             const int c = e >> g.lpp, ql = e & (ppx - 1);
             const int q = (pass << g.lpp) + ql;
@@ -709,9 +710,9 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
                     if (xs < 0 || xs >= W) continue;
                     const int tap = dy * 3 + dx;              // out(r, x) += T[tap (dy, dx)][source (r + dy - 1, x + dx - 1)]
                     const float* tp = T + ((tap * Cout + ce) << g.lpp) + ql + (dy - 1) * W + (dx - 1);
-                    for (int kp = 0; kp < g.KS; ++kp) {        // k parts of the reduction, fixed order
-                        se += tp[(kp * M9) << g.lpp];
-                        if (paired) so += tp[((kp * M9) << g.lpp) + ppx];
+                    for (int kp = 0; kp < g.KS; ++kp, tp += slab) {   // k parts of the reduction, fixed order
+                        se += tp[0];
+                        if (paired) so += tp[ppx];
                     }
                 }
             }
@@ -796,8 +797,13 @@ __global__ void __launch_bounds__(256) k_cfinish(CfinArgs a) {
             if (zn != zi) zn[(long)c * HW + p] = z1v;       // out of place: z1 travels along
         }
     }
-    if (a.mix.C) {
+    if (f.paired) {     // per-sample log-det: issued before the mixer phase, whose time hides the atomic's round trip
+        const long long tot = block_sum_ll<256>(ldq, red);
+        if (tid == 0) atomicAdd(a.acc + n, (unsigned long long)tot);
+    } else if (a.mix.C) {
         __syncthreads();
+    }
+    if (a.mix.C) {
         // thread = (output group og, pixel q): outputs o = og, og + OG, ... four at a time (the staged value v[i][q] is read once
         // for four outputs; the matrix rows are wave-uniform LDS broadcasts)
         constexpr int OG = 256 / PXB;
@@ -831,10 +837,6 @@ __global__ void __launch_bounds__(256) k_cfinish(CfinArgs a) {
                 zn[(long)o * HW + p0 + q] = v;
             }
         }
-    }
-    if (f.paired) {
-        const long long tot = block_sum_ll<256>(ldq, red);
-        if (tid == 0) atomicAdd(a.acc + n, (unsigned long long)tot);
     }
 }
 
