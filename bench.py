@@ -39,7 +39,7 @@ PEAK_SPLIT_TFLOPS = PEAK_F16_MFMA_TFLOPS / 3.0
 
 # BASELINE.json configs (per-GPU batches: SURVEY.md section 8 "B B=64; C 64/GPU; D 32/GPU; E 16/GPU")
 CONFIGS = {
-    "B": dict(image=64, L=3, K=32, hidden=512, batch=64, cpu_sample=64,
+    "B": dict(image=64, L=3, K=32, hidden=512, batch=64, cpu_sample=32,
               label="CelebA 64x64x3 Glow L=3 K=32 hidden=512 affine+invconv", ref="BASELINE configs[1]"),
     "D": dict(image=128, L=4, K=48, hidden=512, batch=32, cpu_sample=4,
               label="CelebA 128x128x3 Glow L=4 K=48 hidden=512 affine+invconv", ref="BASELINE configs[3]"),
@@ -96,9 +96,11 @@ def usable_cores(cap=32):
     return max(1, min(n, cap))
 
 
-def cpu_baseline(glow, x_cpu, cfg, budget_s=25.0):
+def cpu_baseline(glow, x_cpu, cfg, budget_s=30.0):
     """Time the CPU oracle (a port of the reference's eager op sequence) on this box's host cores: one warm-up forward, then
-    up to 3 timed forwards of the same batch (median), bounded by `budget_s` of CPU work."""
+    up to 3 timed forwards of the same batch (median), bounded by `budget_s` of CPU work (SURVEY.md section 8d asks for B = 64 and
+    a median of 3; at ~12 s per 64-image forward on the box's 16 usable cores that is 50 s, so the sample is HALF a batch --
+    images are independent units, the rate per image is the same -- which fits warm-up + 3 forwards into the budget)."""
     import torch
     from oracle import glow_oracle as O
     cores = usable_cores()
@@ -338,6 +340,7 @@ def main():
                 dist.destroy_process_group()
             return
         # ---- roofline of the dominant kernel: instrumented pass of the same step, HIP events per launch
+        plan.launch_counts(reset=True)
         plan.timing(True)
         for _ in range(3):   # rank-local pass: NO collective here (the other ranks are already past the timed loop)
             if args.mode == "inverse":
@@ -346,6 +349,7 @@ def main():
                 glow.normal_flow(x, None, repack=repack)
         recs = plan.timing_read()
         plan.timing(False)
+        launches = {k: v // 3 for k, v in plan.launch_counts(reset=True).items()}     # run-time counters of the 3 instrumented passes
         hid = hps.model.hidden_channels
         kinds = {0: "chanmix", 1: "conv_f0_3x3", 2: "conv_f2_1x1", 3: "conv_f4_3x3_tail", 5: "cnet_f0+f2+f4", 6: "cnet_finish"}
         desc = plan.describe(B)
@@ -428,7 +432,7 @@ def main():
                                               "note": "one GPU, same step with v_mfma_f32_32x32x2_f32 kernels only"}
         out["breakdown_ms_per_step"] = {k: round(v[0] / 3, 4) for k, v in sorted(bd.items())}
         out["breakdown_sum_ms"] = round(sum(v[0] for v in bd.values()) / 3, 3)
-        out["kernel_launches_per_step"] = plan.launch_counts(reset=True) if hasattr(plan, "launch_counts") else None
+        out["kernel_launches_per_step"] = launches
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(glow, x[:min(B, cfg["cpu_sample"])].cpu(), cfg)
         print(json.dumps(out), flush=True)

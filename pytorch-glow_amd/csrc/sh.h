@@ -1,13 +1,17 @@
 // sh.h -- "split-half" (SH) operands: fp32 values carried as TWO fp16 numbers so the coupling network's contractions run
 // on the f16 matrix pipe (v_mfma_f32_32x32x16_f16, 16x the rate of the fp32-input MFMA) at fp32 accuracy.
 //
-//   hi = fp16(v)                       |v - hi|            <= 2^-12 |v|   (round to nearest, 11-bit significand)
-//   lo = fp16((v - hi) * 2^11)         |v - hi - lo/2^11|  <= 2^-24 |v|   -- the same half-ulp bound as fp32 itself
+//   hi = fp16(v)                       |v - hi|            <= 2^-11 |v|   (round to nearest, 11-bit significand: half an ulp)
+//   lo = fp16((v - hi) * 2^11)         |v - hi - lo/2^11|  <= 2^-22 |v|   worst case (lo keeps 11 bits of a residual that is itself
+//                                                                          <= 2^-11 |v|); fp32's own half ulp is 2^-24 |v|.  The residual
+//                                                                          is usually well below its bound: the measured distance to fp64
+//                                                                          below equals the fp32 reference's
 //
 // (v - hi is exact in fp32; the 2^11 pre-scale keeps lo a NORMAL fp16 number.)  A product is evaluated as
 //   a*b ~= a.hi*b.hi + (a.hi*b.lo + a.lo*b.hi) / 2^11            (the dropped lo*lo term is <= 2^-24 |a b|)
 // with every fp16 x fp16 product exact in the fp32 accumulator (11+11 bits), two accumulators (main, cross) and
-// fp32 accumulation as in the fp32 MFMA.  Three f16 MFMAs per k-step instead of one fp32 MFMA of 1/16 the rate.
+// fp32 accumulation as in the fp32 MFMA.  (This two-accumulator form serves the round-1 kernel pairs and the training GEMMs; the
+// product path, cnet_sh.hip, uses the single-accumulator SH2 form at the end of this file.)  Three f16 MFMAs per k-step instead of one fp32 MFMA of 1/16 the rate.
 // Range: |v| < 65504 (fp16 max; larger values become inf and surface as a non-finite nll, they are never clipped
 // silently); below 6.1e-5 the representation is absolute, 2.9e-11.  tests/diag_split_precision.py: on the celeba64
 // model the deviation from an fp64 evaluation is 5.8e-6 (z), the fp32 reference's own is 5.4e-6.

@@ -10,7 +10,7 @@ run_trace() {  # name, bench args...
   local name=$1; shift
   mkdir -p $O/$name
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/$name -o t -- python3 $R/bench.py --no-cpu-baseline "$@" > $O/$name/log.txt 2>&1
-  tail -1 $O/$name/log.txt > $O/$name/bench_line.json
+  grep '^{' $O/$name/log.txt | tail -1 > $O/$name/bench_line.json
   rm -f $O/$name/t_kernel_trace.csv      # large; the stats summary is what gets committed
   echo "$name: $(cut -c1-160 $O/$name/bench_line.json)"
 }
