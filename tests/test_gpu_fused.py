@@ -239,3 +239,40 @@ def test_nan_input_gives_nan_nll_on_every_path():
         nll = nll.cpu()
         assert torch.isnan(nll[2]) and torch.isfinite(nll[[0, 1, 3]]).all(), (flags, nll)
         assert (nll[[0, 1, 3]] - nll_ref[[0, 1, 3]]).abs().max() < 1e-4
+
+
+# ------------------------------------------------------------------------------------------------ configs D and E at full size
+@pytest.mark.parametrize("name,image,L,K,batch", [("D", 128, 4, 48, 32), ("E", 256, 6, 32, 16)])
+def test_full_size_properties_configs_d_e(name, image, L, K, batch):
+    """BASELINE configs[3] / [4] at their TRUE K, hidden width and per-GPU batch (no CPU oracle finishes these: D is 2e11, E
+    5e11 FLOP per image) through size-independent properties: finite outputs; bitwise reproducible run to run; rows of the
+    full batch equal the rows of a 2-image sub-batch (other tile / row-split choices: to rounding); encode -> decode with the
+    dropped halves re-derived by a second encode returns the input; kernel selection from the run-time counters (the
+    product kernel k_cnet on every level with C <= 48, W up to 128)."""
+    import bench
+    cfg = bench.CONFIGS[name]
+    glow, hps = bench.build_model(G, G.misc.util, torch.device("cuda:0"), cfg, batch)
+    g = torch.Generator().manual_seed(21)
+    x = torch.rand(batch, 3, image, image, generator=g).to("cuda:0")
+    noise = (torch.rand(batch, 3, image, image, generator=g) / 256).to("cuda:0")
+    glow.train()
+    glow.normal_flow(x, None, noise=noise)          # data-dependent ActNorm init on the full batch
+    glow.eval()
+    plan = glow.flow.plan_for(x)
+    plan.launch_counts(reset=True)
+    z, nll, _ = glow.normal_flow(x, None, noise=noise)
+    counts = plan.launch_counts(reset=True)
+    assert torch.isfinite(z).all() and torch.isfinite(nll).all()
+    assert counts.get("k_cnet", 0) == 3 * K and counts.get("k_conv_direct", 0) == 0, counts       # levels 1-3: C = 12, 24, 48
+    for rep in range(2):
+        z2, nll2, _ = glow.normal_flow(x, None, noise=noise, repack=(rep == 1))
+        assert torch.equal(z, z2) and torch.equal(nll, nll2), "not bitwise reproducible"
+    zs, ns, _ = glow.normal_flow(x[:2].contiguous(), None, noise=noise[:2].contiguous())
+    close(zs, z[:2], 5e-5, what=f"{name} batch slice z"); close(ns, nll[:2], 2e-5, what=f"{name} batch slice nll")
+    # inverse: decode(z, eps = 0) = the mode of the dropped halves; re-encoding it must give back z (the flow is a bijection on
+    # the kept half) and a log-det consistent with the forward's
+    eps0 = [torch.zeros((batch,) + s, device="cuda:0") for s in glow.flow.split_shapes((3, image, image))]
+    xm = glow.reverse_flow(z, None, eps=eps0)
+    assert torch.isfinite(xm).all()
+    zb, _ = glow.flow.encode(xm, 0.)
+    close(zb, z, 2e-3 if name == "E" else 5e-4, what=f"{name} encode(decode(z)) vs z")
