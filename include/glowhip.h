@@ -181,6 +181,15 @@ int glowhip_glow_forward_u8(glowhip_plan* plan, const void* packed, const uint8_
                             float* nll_out, float* objective_out, int N, void* workspace, size_t workspace_bytes,
                             glowhip_stream_t stream);
 
+/* Dequantisation noise drawn INSIDE the leading squeeze (network/model.py:421): with enable != 0, every later
+ * glowhip_glow_forward / _u8 call whose `noise` is NULL adds U(0, 2^-n_bits) from the counter-based generator
+ * Philox4x32-10(key = seed; counter = element index, call number) -- no noise tensor, no RNG launch.  The call number starts at
+ * 0 when the seed is (re)set and advances by one per such call; *next_call (HOST, may be NULL) receives its next value
+ * (enable < 0: query only).  glowhip_dequant_noise writes the draw of a given call as a tensor (n elements in the order of x):
+ * a forward with that tensor as `noise` is bitwise equal to the in-kernel draw. */
+int glowhip_plan_set_dequant_rng(glowhip_plan* plan, unsigned long long seed, int enable, unsigned long long* next_call);
+int glowhip_dequant_noise(float* out, long n, unsigned long long seed, unsigned long long call, int n_bits, glowhip_stream_t stream);
+
 /* Data-dependent ActNorm initialisation pass over a whole plan (first training-mode forward,
  * network/trainer.py:112-115 + network/module.py:45-46,66-67): runs encode on x and writes every
  * ActNorm's bias/logs THROUGH the parameter pointers of the layer descs (which must be writable). */

@@ -84,6 +84,8 @@ SIGNATURES = {
     "glowhip_plan_decode": (c_int, [_P, _P, _P, POINTER(c_void_p), c_int, _P, _P, _P, c_int, _P, c_size_t, _P]),
     "glowhip_glow_forward": (c_int, [_P, _P, _P, _P, _P, _P, c_long, c_int, _P, _P, _P, c_int, _P, c_size_t, _P]),
     "glowhip_glow_forward_u8": (c_int, [_P, _P, _P, c_float, _P, _P, _P, c_long, c_int, _P, _P, _P, c_int, _P, c_size_t, _P]),
+    "glowhip_plan_set_dequant_rng": (c_int, [_P, ctypes.c_ulonglong, c_int, POINTER(ctypes.c_ulonglong)]),
+    "glowhip_dequant_noise": (c_int, [_P, c_long, ctypes.c_ulonglong, ctypes.c_ulonglong, c_int, _P]),
     "glowhip_plan_actnorm_init": (c_int, [_P, _P, c_size_t, _P, _P, c_float, c_int, _P, c_size_t, _P]),
     "glowhip_plan_output_shape": (c_int, [_P, c_int, POINTER(c_int32)]),
     "glowhip_plan_describe": (c_int, [_P, c_char_p, c_size_t]),

@@ -153,6 +153,18 @@ class FlowPlan:
         check(lib().glowhip_plan_timing_read(self._h, buf, max_records, ctypes.byref(n)))
         return [(buf[i].kind, buf[i].layer, buf[i].mfma, buf[i].ms) for i in range(n.value)]
 
+    def set_dequant_rng(self, seed, enable: bool = True) -> int:
+        """In-kernel dequantisation noise for glow_forward calls without a noise tensor; returns the next call number."""
+        nxt = ctypes.c_ulonglong(0)
+        check(lib().glowhip_plan_set_dequant_rng(self._h, int(seed) & (2 ** 64 - 1), -1 if enable is None else int(bool(enable)), ctypes.byref(nxt)))
+        return int(nxt.value)
+
+    def dequant_noise(self, shape, seed, call, n_bits) -> torch.Tensor:
+        """The draw the kernel makes for call number `call` under `seed`, as a tensor shaped like x."""
+        out = torch.empty(tuple(shape), dtype=torch.float32, device=self.device)
+        check(lib().glowhip_dequant_noise(ptr(out), out.numel(), int(seed) & (2 ** 64 - 1), int(call), int(n_bits), stream_ptr(self.device)))
+        return out
+
     def describe(self, n: int = 0) -> str:
         """Kernel selection per layer; with a batch size ``n`` the choices that depend on the grid size are resolved as a
         call with that batch resolves them (n = 0: what the shapes support)."""

@@ -5,10 +5,13 @@
 namespace glowhip {
 
 // ---------------------------------------------------------------- pointwise.hip
+// in-kernel dequantisation noise (pointwise.hip): U(0, scale) from Philox4x32-10(seed; element index, call number)
+struct RngSpec { int on; unsigned long long seed, call; float scale; };
 int launch_squeeze(const float* x, const float* noise, float* y, int N, int C, int H, int W, int f, int reverse,
-                   hipStream_t s);
+                   hipStream_t s, const RngSpec* rng = nullptr);
 int launch_squeeze_u8(const uint8_t* x, const float* noise, float* y, int N, int C, int H, int W, int f, float divisor,
-                      hipStream_t s);
+                      hipStream_t s, const RngSpec* rng = nullptr);
+int launch_dequant_noise(float* out, long n, unsigned long long seed, unsigned long long call, float scale, hipStream_t s);
 int launch_copy_strided(const float* x, long xbs, float* y, long ybs, int N, long per_sample, hipStream_t s);
 int launch_actnorm_init(const float* x, long xbs, int N, int C, int HW, float scale, float* bias, float* logs,
                         hipStream_t s);

@@ -273,7 +273,7 @@ static float* other_buf(const Workspace& w, const float* cur) { return cur == w.
 
 // ---------------------------------------------------------------- encode (network/model.py:263-276)
 static int run_forward(glowhip_plan* p, const void* packed, const float* x, const float* noise, float* z_out, int N,
-                       const Workspace& w, hipStream_t s, int first_layer = 0) {
+                       const Workspace& w, hipStream_t s, int first_layer = 0, const RngSpec* rng = nullptr) {
     const float* cur = x;
     const int nl = (int)p->layers.size();
     bool premixed = false;   // `cur` already holds this step's ActNorm + permutation output (applied by the previous tail)
@@ -288,14 +288,14 @@ static int run_forward(glowhip_plan* p, const void* packed, const float* x, cons
         const int HW = d.H * d.W;
         const long chw = (long)d.C * HW;
         if (d.kind == GLOWHIP_LAYER_SQUEEZE) {
-            GH_TRY(launch_squeeze(cur, noise, dst, N, d.C, d.H, d.W, 2, 0, s));
-            noise = nullptr;
+            GH_TRY(launch_squeeze(cur, noise, dst, N, d.C, d.H, d.W, 2, 0, s, li == 0 ? rng : nullptr));
+            noise = nullptr; rng = nullptr;
         } else {
-            if (noise) {  // dequantisation noise with no leading squeeze (only possible at layer 0, cur == x):
+            if (noise || (rng && li == 0)) {  // dequantisation noise with no leading squeeze (only possible at layer 0, cur == x):
                           // the identity "squeeze" (factor 1) adds it into a workspace buffer
-                GH_TRY(launch_squeeze(cur, noise, w.bufA, N, d.C, d.H, d.W, 1, 0, s));
+                GH_TRY(launch_squeeze(cur, noise, w.bufA, N, d.C, d.H, d.W, 1, 0, s, rng));
                 cur = w.bufA;
-                noise = nullptr;
+                noise = nullptr; rng = nullptr;
                 if (li != nl - 1) dst = w.bufB;
             }
             const int Ch = d.C / 2;
@@ -704,6 +704,23 @@ int glowhip_plan_output_shape(const glowhip_plan* plan, int reverse, int32_t out
     return GLOWHIP_OK;
 }
 
+int glowhip_plan_set_dequant_rng(glowhip_plan* plan, unsigned long long seed, int enable, unsigned long long* next_call) {
+    GH_REQUIRE(plan, "plan_set_dequant_rng: null plan");
+    if (enable > 0) {
+        if (plan->rng_seed != seed) plan->rng_calls = 0;      // a new seed restarts the stream; switching off and on again does not
+        plan->rng_on = true; plan->rng_seed = seed;
+    } else if (enable == 0) {
+        plan->rng_on = false;
+    }
+    if (next_call) *next_call = plan->rng_calls;
+    return GLOWHIP_OK;
+}
+
+int glowhip_dequant_noise(float* out, long n, unsigned long long seed, unsigned long long call, int n_bits, glowhip_stream_t stream) {
+    GH_REQUIRE(out && n >= 0 && n_bits > 0 && n_bits <= 30, "dequant_noise: bad argument");
+    return launch_dequant_noise(out, n, seed, call, (float)(1.0 / pow(2.0, n_bits)), (hipStream_t)stream);
+}
+
 int glowhip_plan_describe(const glowhip_plan* plan, char* buf, size_t buf_bytes) {
     return glowhip_plan_describe_for(plan, 0, buf, buf_bytes);
 }
@@ -834,7 +851,9 @@ int glowhip_glow_forward(glowhip_plan* plan, const void* packed, const float* x,
     Workspace w;
     GH_TRY(carve(plan, N, workspace, workspace_bytes, w));
     GH_TRY(launch_zero_acc(w.acc, N, s));
-    GH_TRY(run_forward(plan, packed, x, noise, z, N, w, s));
+    RngSpec rng{plan->rng_on && !noise, plan->rng_seed, plan->rng_calls, (float)(1.0 / pow(2.0, n_bits))};
+    if (rng.on) ++plan->rng_calls;
+    GH_TRY(run_forward(plan, packed, x, noise, z, N, w, s, 0, rng.on ? &rng : nullptr));
     const int* o = plan->out_shape;
     GH_TRY(launch_gaussian_logp(z, (long)o[0] * o[1] * o[2], prior_mean, prior_logs, prior_stride, N, o[0], o[1] * o[2],
                                 w.acc, s));
@@ -864,7 +883,9 @@ int glowhip_glow_forward_u8(glowhip_plan* plan, const void* packed, const uint8_
     GH_TRY(launch_zero_acc(w.acc, N, s));
     const glowhip_layer_desc& d0 = plan->layers[0].d;
     plan->cur_layer = 0;
-    GH_TRY(launch_squeeze_u8(x_u8, noise, w.bufA, N, d0.C, d0.H, d0.W, 2, divisor, s));
+    RngSpec rng{plan->rng_on && !noise, plan->rng_seed, plan->rng_calls, (float)(1.0 / pow(2.0, n_bits))};
+    if (rng.on) ++plan->rng_calls;
+    GH_TRY(launch_squeeze_u8(x_u8, noise, w.bufA, N, d0.C, d0.H, d0.W, 2, divisor, s, rng.on ? &rng : nullptr));
     GH_TRY(run_forward(plan, packed, w.bufA, nullptr, z, N, w, s, 1));
     const int* o = plan->out_shape;
     GH_TRY(launch_gaussian_logp(z, (long)o[0] * o[1] * o[2], prior_mean, prior_logs, prior_stride, N, o[0], o[1] * o[2],

@@ -13,9 +13,39 @@ namespace glowhip {
 // Squeeze2d / unsqueeze (network/module.py:551-592), optional dequantisation-noise add on the input
 // (network/model.py:421).  One thread per OUTPUT element (gather form) => coalesced stores.
 // ------------------------------------------------------------------------------------------------
+// Dequantisation noise drawn in the kernel (network/model.py:421: x + U(0, 1/2^n_bits)): counter-based Philox4x32-10, key =
+// the caller's seed, counter = (element index / 4, call number); element i takes word i % 4.  No noise tensor in HBM, no
+// separate RNG launch; the same stream is available as a tensor through glowhip_dequant_noise (parity tests).
+__device__ __forceinline__ float dequant_noise(unsigned long long seed, unsigned long long call, unsigned long long i, float scale) {
+    unsigned int c0 = (unsigned int)(i >> 2), c1 = (unsigned int)(i >> 34), c2 = (unsigned int)call, c3 = (unsigned int)(call >> 32);
+    unsigned int k0 = (unsigned int)seed, k1 = (unsigned int)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+        const unsigned int n0 = (unsigned int)(p1 >> 32) ^ c1 ^ k0, n2 = (unsigned int)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (unsigned int)p1; c3 = (unsigned int)p0; c0 = n0; c2 = n2;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    const unsigned int w = (i & 3) == 0 ? c0 : ((i & 3) == 1 ? c1 : ((i & 3) == 2 ? c2 : c3));
+    return (float)(w >> 8) * (1.0f / 16777216.0f) * scale;          // 24 uniform bits in [0, 1), exact in fp32
+}
+
+__global__ void __launch_bounds__(256) k_dequant_noise(float* __restrict__ out, long n, unsigned long long seed,
+                                                       unsigned long long call, float scale) {
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = dequant_noise(seed, call, (unsigned long long)i, scale);
+}
+
+int launch_dequant_noise(float* out, long n, unsigned long long seed, unsigned long long call, float scale, hipStream_t s) {
+    if (n == 0) return GLOWHIP_OK;
+    hipLaunchKernelGGL(k_dequant_noise, dim3(cdiv(n, 256)), dim3(256), 0, s, out, n, seed, call, scale);
+    GH_LAUNCH_CHECK("k_dequant_noise");
+    return GLOWHIP_OK;
+}
+
 __global__ void __launch_bounds__(256) k_squeeze(const float* __restrict__ x, const float* __restrict__ noise,
                                                  float* __restrict__ y, long total, int C, int H, int W, int f,
-                                                 int reverse) {
+                                                 int reverse, RngSpec rng) {
     long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= total) return;
     long src;
@@ -42,6 +72,7 @@ __global__ void __launch_bounds__(256) k_squeeze(const float* __restrict__ x, co
     }
     float v = x[src];
     if (noise) v += noise[src];
+    else if (rng.on) v += dequant_noise(rng.seed, rng.call, (unsigned long long)src, rng.scale);
     y[idx] = v;
 }
 
@@ -49,7 +80,7 @@ __global__ void __launch_bounds__(256) k_squeeze(const float* __restrict__ x, co
 // the dequantisation noise (network/model.py:421) and the first squeeze in one pass over a quarter of the bytes.
 __global__ void __launch_bounds__(256) k_squeeze_u8(const uint8_t* __restrict__ x, const float* __restrict__ noise,
                                                     float* __restrict__ y, long total, int C, int H, int W, int f,
-                                                    float divisor) {
+                                                    float divisor, RngSpec rng) {
     long idx = (long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= total) return;
     const int Ho = H / f, Wo = W / f, Co = C * f * f;
@@ -63,27 +94,28 @@ __global__ void __launch_bounds__(256) k_squeeze_u8(const uint8_t* __restrict__ 
     const long src = ((n * C + c) * H + (h * f + i)) * (long)W + (w * f + j);
     float v = (float)x[src] / divisor;
     if (noise) v += noise[src];
+    else if (rng.on) v += dequant_noise(rng.seed, rng.call, (unsigned long long)src, rng.scale);
     y[idx] = v;
 }
 
 int launch_squeeze_u8(const uint8_t* x, const float* noise, float* y, int N, int C, int H, int W, int f, float divisor,
-                      hipStream_t s) {
+                      hipStream_t s, const RngSpec* rng) {
     GH_REQUIRE(f >= 1 && H % f == 0 && W % f == 0, "squeeze2d(u8): H,W must be divisible by the factor");
     long total = (long)N * C * H * W;
     if (total == 0) return GLOWHIP_OK;
-    hipLaunchKernelGGL(k_squeeze_u8, dim3(cdiv(total, 256)), dim3(256), 0, s, x, noise, y, total, C, H, W, f, divisor);
+    hipLaunchKernelGGL(k_squeeze_u8, dim3(cdiv(total, 256)), dim3(256), 0, s, x, noise, y, total, C, H, W, f, divisor, rng ? *rng : RngSpec{});
     GH_LAUNCH_CHECK("k_squeeze_u8");
     return GLOWHIP_OK;
 }
 
 int launch_squeeze(const float* x, const float* noise, float* y, int N, int C, int H, int W, int f, int reverse,
-                   hipStream_t s) {
+                   hipStream_t s, const RngSpec* rng) {
     GH_REQUIRE(f >= 1, "squeeze2d: factor must be >= 1");
     if (!reverse) GH_REQUIRE(H % f == 0 && W % f == 0, "squeeze2d: H,W must be divisible by factor");
     else GH_REQUIRE(C >= f * f && C % (f * f) == 0, "unsqueeze2d: C must be a multiple of factor^2");
     long total = (long)N * C * H * W;
     if (total == 0) return GLOWHIP_OK;
-    hipLaunchKernelGGL(k_squeeze, dim3(cdiv(total, 256)), dim3(256), 0, s, x, noise, y, total, C, H, W, f, reverse);
+    hipLaunchKernelGGL(k_squeeze, dim3(cdiv(total, 256)), dim3(256), 0, s, x, noise, y, total, C, H, W, f, reverse, rng ? *rng : RngSpec{});
     GH_LAUNCH_CHECK("k_squeeze");
     return GLOWHIP_OK;
 }

@@ -261,12 +261,19 @@ class Glow(nn.Module):
         if x.dtype == torch.uint8 and (self.training or torch.is_grad_enabled()):
             x = x.float() / 255.0   # the ActNorm init pass and the training step take fp32; inference reads the bytes itself
         n_bits = self.hps.model.n_bits_x
+        plan = self.flow.plan_for(x)
+        in_kernel_rng = False
         if noise is None:
-            noise = torch.empty(x.shape, dtype=torch.float32, device=x.device).uniform_(0, 1. / 2 ** n_bits)
+            if self.training or torch.is_grad_enabled():
+                noise = torch.empty(x.shape, dtype=torch.float32, device=x.device).uniform_(0, 1. / 2 ** n_bits)
+            else:     # inference: the leading squeeze draws it (Philox keyed by torch's seed; no noise tensor, no RNG launch)
+                in_kernel_rng = True
+                plan.set_dequant_rng(torch.initial_seed(), True)
         else:
             noise = require_device_tensor(noise, "noise")
             assert noise.shape == x.shape
-        plan = self.flow.plan_for(x)
+        if not in_kernel_rng:
+            plan.set_dequant_rng(0, False)
         _maybe_data_dependent_init(self.flow, plan, x, noise, self.flow.actnorm_scale)
         mean, logs = self.prior(y_onehot)
         stride = 0

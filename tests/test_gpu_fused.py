@@ -276,3 +276,40 @@ def test_full_size_properties_configs_d_e(name, image, L, K, batch):
     assert torch.isfinite(xm).all()
     zb, _ = glow.flow.encode(xm, 0.)
     close(zb, z, 2e-3 if name == "E" else 5e-4, what=f"{name} encode(decode(z)) vs z")
+
+
+def test_in_kernel_dequantisation_noise():
+    """Inference without a noise tensor: the leading squeeze draws U(0, 1/2^n_bits) itself (Philox4x32-10 keyed by torch's seed).
+    (1) the draw, exported as a tensor, has the right range and moments; (2) a forward with that tensor injected is BITWISE equal
+    to the in-kernel draw (fp32 and uint8 inputs); (3) consecutive calls use consecutive streams; (4) torch.manual_seed replays."""
+    cfg = O.default_cfg(image_shape=(32, 32, 3), hidden_channels=64, K=2, L=2, batch=8)
+    sd = O.seeded_state_dict(cfg, seed=5)
+    glow = make_glow(cfg, sd, 8)
+    x = torch.rand(8, 3, 32, 32, generator=torch.Generator().manual_seed(1)).to("cuda:0")
+    plan = glow.flow.plan_for(x)
+    torch.manual_seed(1234)
+    call0 = plan.set_dequant_rng(torch.initial_seed(), None)
+    z_a, nll_a, _ = glow.normal_flow(x, None)                      # call number call0
+    z_b, nll_b, _ = glow.normal_flow(x, None)                      # call0 + 1
+    assert not torch.equal(z_a, z_b)
+    n0 = plan.dequant_noise(x.shape, 1234, call0, 8)
+    n1 = plan.dequant_noise(x.shape, 1234, call0 + 1, 8)
+    assert n0.min().item() >= 0.0 and n0.max().item() < 1.0 / 256 and not torch.equal(n0, n1)
+    assert abs(n0.mean().item() * 512 - 1.0) < 0.02 and abs(n0.var().item() * 12 * 256 * 256 - 1.0) < 0.05
+    z_i, nll_i, _ = glow.normal_flow(x, None, noise=n0)
+    assert torch.equal(z_i, z_a) and torch.equal(nll_i, nll_a)
+    z_j, nll_j, _ = glow.normal_flow(x, None, noise=n1)
+    assert torch.equal(z_j, z_b) and torch.equal(nll_j, nll_b)
+    # 8-bit input path
+    xu = (x * 255).round().to(torch.uint8)
+    c = plan.set_dequant_rng(1234, None)
+    z_u, nll_u, _ = glow.normal_flow(xu, None)
+    z_v, nll_v, _ = glow.normal_flow(xu, None, noise=plan.dequant_noise(x.shape, 1234, c, 8))
+    assert torch.equal(z_u, z_v) and torch.equal(nll_u, nll_v)
+    # a new seed restarts the stream
+    torch.manual_seed(99)
+    z_c, _, _ = glow.normal_flow(x, None)
+    torch.manual_seed(99)
+    plan.set_dequant_rng(7, True)         # (a different seed in between, so that seed 99 restarts at call 0)
+    z_d, _, _ = glow.normal_flow(x, None)
+    assert torch.equal(z_c, z_d)
