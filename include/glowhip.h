@@ -143,11 +143,11 @@ int glowhip_plan_pack(glowhip_plan* plan, void* packed, size_t packed_bytes, glo
 /* The same, restricted to the weight images a caller is going to use: GLOWHIP_PACK_INFERENCE = what encode / decode /
  * glow_forward read (the split-half images where those kernels apply), GLOWHIP_PACK_TRAINING = what glow_forward_train /
  * glow_backward read (exact-fp32 images + the flipped/transposed input-gradient images).  glowhip_plan_pack = both.
- * Scale tables and log|det W| are always refreshed, W^-1 with GLOWHIP_PACK_INVERSE or GLOWHIP_PACK_TRAINING (always for C <= 64). */
+ * Scale tables and log|det W| are always refreshed, W^-1 with GLOWHIP_PACK_INVERSE or GLOWHIP_PACK_TRAINING. */
 #define GLOWHIP_PACK_INFERENCE 1
 #define GLOWHIP_PACK_TRAINING 2
-#define GLOWHIP_PACK_INVERSE 4   /* W^-1 of the invertible 1x1 convolutions (decode; implied by TRAINING): without it levels wider than
-                                    64 channels get log|det W| from an LU of the matrix alone (C^3/3 instead of 2 C^3 updates) */
+#define GLOWHIP_PACK_INVERSE 4   /* W^-1 of the invertible 1x1 convolutions (decode; implied by TRAINING): without it
+                                    log|det W| comes from an LU of the matrix alone (C^3/3 instead of 2 C^3 updates) and W^-1 is stale */
 int glowhip_plan_pack_for(glowhip_plan* plan, void* packed, size_t packed_bytes, int use, glowhip_stream_t stream);
 
 /* FlowModel.encode: x (N, C0,H0,W0 of layer 0) -> z (output shape of the last layer),

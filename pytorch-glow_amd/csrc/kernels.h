@@ -74,7 +74,7 @@ struct StepPrepJob {
     size_t winv_off, logabsdet_off, konst_off, scratch_off;
 };
 int launch_step_prepare_batched(const StepPrepJob* jobs_dev, int n, int max_lds_c, void* packed, hipStream_t s, int want_inverse = 1,
-                                int max_c = 0);   // want_inverse = 0: log|det W| only (W^-1 of levels wider than 64 channels is left stale)
+                                int max_c = 0);   // want_inverse = 0: log|det W| only (W^-1 is left stale)
 
 struct ScaleJob { const float* logs; size_t scale_off, inv_off; int n; int has_inv; };
 enum { REPACK_WIDE = 0, REPACK_TAIL = 1, REPACK_FIRST = 2, REPACK_SH_GEMM = 3, REPACK_SH_TAIL = 4, REPACK_SH_FIRST = 5,

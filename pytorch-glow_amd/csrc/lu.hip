@@ -160,10 +160,10 @@ __global__ void __launch_bounds__(256) k_step_prepare_batched(const StepPrepJob*
     const StepPrepJob j = jobs[blockIdx.x];
     double lad = 0.0;
     if (j.w) {
-        if (j.C <= LU_LDS_MAX_C || want_inverse) {
+        if (want_inverse) {
             double* A = j.C <= LU_LDS_MAX_C ? lds_aug : (double*)(packed + j.scratch_off);
             lad = lu_gauss_jordan(j.w, j.C, (float*)(packed + j.winv_off), A);
-        } else {      // wide level, forward only: log|det W| without the inverse
+        } else {      // forward only: log|det W| without the inverse (C^3/3 instead of 2 C^3 element updates)
             double* A = j.C <= LU_LDS_ONLY_MAX_C ? lds_aug : (double*)(packed + j.scratch_off);
             lad = lu_logdet_only(j.w, j.C, A);
         }

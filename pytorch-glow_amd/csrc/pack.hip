@@ -131,7 +131,9 @@ __global__ void __launch_bounds__(256) k_repack_batched(const RepackJob* __restr
 __global__ void __launch_bounds__(256) k_repack_sh2_batched(const RepackJob* __restrict__ jobs, char* packed) {
     const RepackJob j = jobs[blockIdx.y];
     if (j.kind < REPACK_SH2_GEMM) return;
-    const int lane = threadIdx.x & 63;
+    // a wave takes EIGHT consecutive rows: lane = (k group within the pass) * 8 + row, so the eight 16-byte groups of one k group
+    // are 128 contiguous bytes of the image (a single row per wave wrote 16 bytes every M * 16)
+    const int lane = threadIdx.x & 63, r8 = lane & 7, gl = lane >> 3;
     const int M = j.kind == REPACK_SH2_TAIL ? j.Kpad : j.Cout;
     const int Kp = j.kind == REPACK_SH2_FIRST ? j.K * 8 : j.Cin;
     const int ngroups = Kp / 8;
@@ -139,10 +141,13 @@ __global__ void __launch_bounds__(256) k_repack_sh2_batched(const RepackJob* __r
     float* rowscale = (float*)(packed + j.out_off + (size_t)2 * Kp * M * sizeof(_Float16));
     float* rbias = rowscale + M;
     const int nchunk = (j.Cin + 7) / 8;
-    for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < M; r += gridDim.x * 4) {
+    for (int r0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 8; r0 < M; r0 += gridDim.x * 32) {
+        const int r = r0 + r8;
+        const bool rv = r < M;
         float fold = 1.f;
-        if (j.kind != REPACK_SH2_TAIL && j.fold_logs) fold = expf(j.fold_logs[r] * LOGSCALE);
+        if (rv && j.kind != REPACK_SH2_TAIL && j.fold_logs) fold = expf(j.fold_logs[r] * LOGSCALE);
         auto value = [&](int k) -> float {
+            if (!rv) return 0.f;
             if (j.kind == REPACK_SH2_GEMM) return j.w[(long)r * j.Cin + k] * fold;
             if (j.kind == REPACK_SH2_FIRST) {
                 const int gi = k >> 3, k8 = k & 7;
@@ -152,12 +157,25 @@ __global__ void __launch_bounds__(256) k_repack_sh2_batched(const RepackJob* __r
             const int tap = r / j.Cout, co = r - tap * j.Cout;
             return r < 9 * j.Cout ? j.w[((long)co * j.Cin + k) * 9 + tap] : 0.f;
         };
+        constexpr int KEEP = 8;               // passes whose values stay in registers (Kp <= 512); beyond that they are re-read
+        float keep[KEEP][8];
         float mx = 0.f;
-        for (int gi = lane; gi < ngroups; gi += 64)
+#pragma unroll
+        for (int it = 0; it < KEEP; ++it) {           // compile-time indices: `keep` stays in registers
+            const int gi = gl + 8 * it;
+#pragma unroll
+            for (int k8 = 0; k8 < 8; ++k8) {
+                const float v = gi < ngroups ? value(gi * 8 + k8) : 0.f;
+                keep[it][k8] = v;
+                mx = fmaxf(mx, fabsf(v));
+            }
+        }
+        for (int gi = gl + 8 * KEEP; gi < ngroups; gi += 8)
 #pragma unroll
             for (int k8 = 0; k8 < 8; ++k8) mx = fmaxf(mx, fabsf(value(gi * 8 + k8)));
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 8, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         int e = 0;
         if (mx > 0.f && mx < 3.0e38f) {
             int ex;
@@ -166,18 +184,29 @@ __global__ void __launch_bounds__(256) k_repack_sh2_batched(const RepackJob* __r
             e = e > 100 ? 100 : (e < -100 ? -100 : e);
         }
         const float up = ldexpf(1.f, e);
-        for (int gi = lane; gi < ngroups; gi += 64) {
+        auto emit = [&](int gi, const float (&v)[8]) {
             h8 hi, lo;
 #pragma unroll
             for (int k8 = 0; k8 < 8; ++k8) {
                 _Float16 a, b;
-                sh2_split(value(gi * 8 + k8) * up, a, b);
+                sh2_split(v[k8] * up, a, b);
                 hi[k8] = a; lo[k8] = b;
             }
-            *reinterpret_cast<h8*>(oh + ((long)gi * M + r) * 8) = hi;
-            *reinterpret_cast<h8*>(oh + ((long)(ngroups + gi) * M + r) * 8) = lo;
+            if (rv) {
+                *reinterpret_cast<h8*>(oh + ((long)gi * M + r) * 8) = hi;
+                *reinterpret_cast<h8*>(oh + ((long)(ngroups + gi) * M + r) * 8) = lo;
+            }
+        };
+#pragma unroll
+        for (int it = 0; it < KEEP; ++it)
+            if (gl + 8 * it < ngroups) emit(gl + 8 * it, keep[it]);
+        for (int gi = gl + 8 * KEEP; gi < ngroups; gi += 8) {
+            float v[8];
+#pragma unroll
+            for (int k8 = 0; k8 < 8; ++k8) v[k8] = value(gi * 8 + k8);
+            emit(gi, v);
         }
-        if (lane == 0) {
+        if (gl == 0 && rv) {
             if (j.kind == REPACK_SH2_TAIL) {
                 rowscale[r] = ldexpf(1.f, -e) * SH2_ACT_INV;
                 rbias[r] = 0.f;
@@ -198,7 +227,7 @@ int launch_pack_batched(const ScaleJob* sj_dev, int n_scale, const RepackJob* rj
     if (n_repack > 0) {
         hipLaunchKernelGGL(k_repack_batched, dim3(64, n_repack), dim3(256), 0, s, rj_dev, (char*)packed);
         GH_LAUNCH_CHECK("k_repack_batched");
-        hipLaunchKernelGGL(k_repack_sh2_batched, dim3(128, n_repack), dim3(256), 0, s, rj_dev, (char*)packed);
+        hipLaunchKernelGGL(k_repack_sh2_batched, dim3(16, n_repack), dim3(256), 0, s, rj_dev, (char*)packed);
         GH_LAUNCH_CHECK("k_repack_sh2_batched");
     }
     return GLOWHIP_OK;

@@ -599,14 +599,14 @@ glowhip_plan* glowhip_plan_create(const glowhip_layer_desc* layers, int n_layers
             }
             if (L.sh_mid) {
                 RepackJob r{}; r.w = d.f2_w; r.out_off = L.f2_sh; r.kind = REPACK_SH_GEMM; r.Cin = d.hidden; r.Cout = d.hidden;
-                r.K = d.hidden; r.fold_bias = d.f2_an_bias; r.fold_logs = d.f2_an_logs; r.use = 3; p->repack_jobs.push_back(r);
+                r.K = d.hidden; r.fold_bias = d.f2_an_bias; r.fold_logs = d.f2_an_logs; r.use = 2 | (L.cnet ? 8 : 1); p->repack_jobs.push_back(r);
                 // input gradient of f.2 on the same kernel: W2^T, nothing folded (training only)
                 RepackJob t{}; t.w = d.f2_w; t.out_off = L.f2T_sh; t.kind = REPACK_SH_GEMM; t.Cin = d.hidden; t.Cout = d.hidden;
                 t.K = d.hidden; t.transposed = 1; t.use = 2; p->repack_jobs.push_back(t);
             }
             if (L.sh_first) {
                 RepackJob r{}; r.w = d.f0_w; r.out_off = L.f0_sh; r.kind = REPACK_SH_FIRST; r.Cin = d.C / 2; r.Cout = d.hidden;
-                r.K = (9 * ((r.Cin + 7) / 8) + 1) & ~1; r.fold_bias = d.f0_an_bias; r.fold_logs = d.f0_an_logs; r.use = 1;
+                r.K = (9 * ((r.Cin + 7) / 8) + 1) & ~1; r.fold_bias = d.f0_an_bias; r.fold_logs = d.f0_an_logs; r.use = L.cnet ? 8 : 1;
                 p->repack_jobs.push_back(r);
             }
             if (L.cnet) {
@@ -620,7 +620,7 @@ glowhip_plan* glowhip_plan_create(const glowhip_layer_desc* layers, int n_layers
             }
             if (L.sh_tail) {
                 RepackJob r{}; r.w = d.f4_w; r.out_off = L.f4_sh; r.kind = REPACK_SH_TAIL; r.Cin = d.hidden; r.Cout = L.Cout;
-                r.Kpad = tail_sh_mpad(d.hidden, d.H, d.W, L.Cout, &r.MT); r.use = 1; p->repack_jobs.push_back(r);
+                r.Kpad = tail_sh_mpad(d.hidden, d.H, d.W, L.Cout, &r.MT); r.use = L.cnet ? 8 : 1; p->repack_jobs.push_back(r);
             }
             if (L.mfma_last) {
                 RepackJob r{}; r.w = d.f4_w; r.out_off = L.f4_wp; r.kind = REPACK_TAIL; r.Cin = d.hidden; r.Cout = L.Cout;
@@ -776,7 +776,9 @@ int glowhip_plan_pack_for(glowhip_plan* plan, void* packed, size_t packed_bytes,
     GH_REQUIRE(use & (GLOWHIP_PACK_INFERENCE | GLOWHIP_PACK_TRAINING), "plan_pack: empty use mask");
     const int orig_use = use;
     // with a kernel family switched off through the debug hook the other family's images are needed after all
-    if (g_sh_disabled || g_sh_tail_disabled || g_sh_first_disabled || g_cnet_disabled) use = GLOWHIP_PACK_INFERENCE | GLOWHIP_PACK_TRAINING;
+    // use bit 8 (internal): the round-1 split-half images of layers that normally run k_cnet -- needed only with cnet switched off
+    if (g_sh_disabled || g_sh_tail_disabled || g_sh_first_disabled) use = GLOWHIP_PACK_INFERENCE | GLOWHIP_PACK_TRAINING | 8;
+    if ((use & GLOWHIP_PACK_INFERENCE) && (g_cnet_disabled || g_cnet_h2_only)) use |= 8;
     plan->repack_sel.clear();
     for (const RepackJob& r : plan->repack_jobs)
         if (r.use & use) plan->repack_sel.push_back(r);
@@ -800,7 +802,7 @@ int glowhip_plan_pack_for(glowhip_plan* plan, void* packed, size_t packed_bytes,
     GH_TRY(launch_pack_batched(at<ScaleJob>(packed, plan->scale_off), (int)plan->scale_jobs.size(),
                                at<RepackJob>(packed, plan->repack_off), (int)plan->repack_sel.size(), packed, s));
     GH_TRY(launch_step_prepare_batched(at<StepPrepJob>(packed, plan->prep_off), (int)plan->prep_jobs.size(),
-                                       plan->max_lds_c, packed, s, (orig_use & (GLOWHIP_PACK_INVERSE | GLOWHIP_PACK_TRAINING)) != 0,
+                                       plan->max_lds_c, packed, s, (use & (GLOWHIP_PACK_INVERSE | GLOWHIP_PACK_TRAINING)) != 0,
                                        plan->max_c));
     return GLOWHIP_OK;
 }
