@@ -19,6 +19,7 @@
 // pixel count alone cannot fill 256 CUs.  The finishing kernel sums the MS partials and the neighbours' halo rows.
 #include "sh.h"
 #include <algorithm>
+#include <type_traits>
 
 #include "conv_mfma.h"
 
@@ -327,26 +328,21 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
     };
 
     f32x16_t acc2[RT2][PT2];
-#pragma unroll
-    for (int i = 0; i < RT2; ++i)
-#pragma unroll
-        for (int j = 0; j < PT2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc2[i][j][r] = 0.f;
-
-#pragma unroll 1
-    for (int hh = 0; hh < NH; ++hh) {
+    // P1 of one channel pass; PTSV = pixel tiles per sub-pass (fewer while the h2 accumulators are live)
+    auto p1_pass = [&](int hh, auto ptsc) {
+        constexpr int PTSV = decltype(ptsc)::value;
+        constexpr int SUBV = PT1 / PTSV;
         // ---- P1: h1 channels [hh*HK, hh*HK + HK) of all pixels -> hbuf.  Its first two A sets are already in flight.
 #pragma unroll 1
-        for (int sp = 0; sp < P1SUB; ++sp) {
-            int pb[PTS];
+        for (int sp = 0; sp < SUBV; ++sp) {
+            int pb[PTSV];
 #pragma unroll
-            for (int j = 0; j < PTS; ++j) pb[j] = pix_base((pt1 + sp * PTS + j) * 32 + ml);
-            f32x16_t acc1[RT1][PTS];
+            for (int j = 0; j < PTSV; ++j) pb[j] = pix_base((pt1 + sp * PTSV + j) * 32 + ml);
+            f32x16_t acc1[RT1][PTSV];
 #pragma unroll
             for (int i = 0; i < RT1; ++i)
 #pragma unroll
-                for (int j = 0; j < PTS; ++j)
+                for (int j = 0; j < PTSV; ++j)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc1[i][j][r] = 0.f;
             // k groups of f.0 are ordered (8-channel chunk, tap), tap fastest: group gk -> chunk gk / 9, tap gk % 9 (divisions by
@@ -360,14 +356,14 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
                 const int dy = tap / 3, dx = tap - dy * 3;
                 return ch < g.nchunk ? (ch * g.NI * g.Wpx + dy * g.WP + dx) * 8 : 0;
             };
-            constexpr bool BPRE = PTS <= 2;    // B fragments one step ahead (register budget: only with at most two tiles)
-            h8 Bc[2 * PTS], Bn[BPRE ? 2 * PTS : 1];     // [j] hi, [PTS + j] lo
+            constexpr bool BPRE = PTSV <= 2;    // B fragments one step ahead (register budget: only with at most two tiles)
+            h8 Bc[2 * PTSV], Bn[BPRE ? 2 * PTSV : 1];     // [j] hi, [PTSV + j] lo
             auto loadB = [&](h8* dst) {
                 const int goff = cur_goff();
 #pragma unroll
-                for (int j = 0; j < PTS; ++j) {
+                for (int j = 0; j < PTSV; ++j) {
                     dst[j] = *reinterpret_cast<const h8*>(win + goff + pb[j]);
-                    dst[PTS + j] = *reinterpret_cast<const h8*>(win + g.winplane + goff + pb[j]);
+                    dst[PTSV + j] = *reinterpret_cast<const h8*>(win + g.winplane + goff + pb[j]);
                 }
             };
             if (BPRE) loadB(Bc);
@@ -378,18 +374,18 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
 #pragma unroll
                 for (int i = 0; i < RT1; ++i)
 #pragma unroll
-                    for (int j = 0; j < PTS; ++j) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(use[i], Bc[j], acc1[i][j], 0, 0, 0);
+                    for (int j = 0; j < PTSV; ++j) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(use[i], Bc[j], acc1[i][j], 0, 0, 0);
 #pragma unroll
                 for (int i = 0; i < RT1; ++i)
 #pragma unroll
-                    for (int j = 0; j < PTS; ++j) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(use[i], Bc[PTS + j], acc1[i][j], 0, 0, 0);
+                    for (int j = 0; j < PTSV; ++j) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(use[i], Bc[PTSV + j], acc1[i][j], 0, 0, 0);
 #pragma unroll
                 for (int i = 0; i < RT1; ++i)
 #pragma unroll
-                    for (int j = 0; j < PTS; ++j) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(use[RT1 + i], Bc[j], acc1[i][j], 0, 0, 0);
+                    for (int j = 0; j < PTSV; ++j) acc1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(use[RT1 + i], Bc[j], acc1[i][j], 0, 0, 0);
                 if (BPRE) {
 #pragma unroll
-                    for (int j = 0; j < 2 * PTS; ++j) Bc[j] = Bn[j];
+                    for (int j = 0; j < 2 * PTSV; ++j) Bc[j] = Bn[j];
                 }
             };
 #pragma unroll 1
@@ -401,7 +397,7 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
             // A sets of the next P1 pass (next pixel sub-pass of this channel pass, or the next channel pass): in flight during
             // the epilogue, the barrier and P2
             {
-                const int nh = sp + 1 < P1SUB ? hh : hh + 1;
+                const int nh = sp + 1 < SUBV ? hh : hh + 1;
                 if (nh < NH) {
                     loadA1(nh, 0, A1[0]);
                     loadA1(nh, g.steps0 > 1 ? 1 : 0, A1[1]);
@@ -417,7 +413,7 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
                     const f32x4_t bb = *reinterpret_cast<const f32x4_t*>(t_b0 + o);
                     const int chunk = (rt1 + i) * 4 + gq;
 #pragma unroll
-                    for (int j = 0; j < PTS; ++j) {
+                    for (int j = 0; j < PTSV; ++j) {
                         h4 hi, lo;
 #pragma unroll
                         for (int t = 0; t < 4; ++t) {
@@ -426,20 +422,14 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
                             sh2_split(v, x0, x1);
                             hi[t] = x0; lo[t] = x1;
                         }
-                        _Float16* dst = hbuf + ((long)chunk * PXT + (pt1 + sp * PTS + j) * 32 + ml) * 8 + 4 * kl;
+                        _Float16* dst = hbuf + ((long)chunk * PXT + (pt1 + sp * PTSV + j) * 32 + ml) * 8 + 4 * kl;
                         *reinterpret_cast<h4*>(dst) = hi;
                         *reinterpret_cast<h4*>(dst + (long)NCH * PXT * 8) = lo;
                     }
                 }
         }
-        if (A2_LATE) {
-            loadA2(hh * NS, A2[0]);
-            loadA2(hh * NS + 1, A2[1]);
-        }
-        GH_STAMP(2 + 4 * hh);
-        __syncthreads();
-        GH_STAMP(3 + 4 * hh);
-
+    };
+    auto p2_pass = [&](int hh) {
         // ---- P2: acc2 += W2'[rows, pass hh] h1[pass hh]; B from LDS, A two k-steps ahead from L2
         {
             const int ks0 = hh * NS;
@@ -482,6 +472,30 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
                 loadA2((hh + 1) * NS + 1, A2[1]);
             }
         }
+    };
+    // With a 512-row x 128-pixel h2 block (128 accumulator registers) the FIRST channel pass of P1 still runs before those
+    // accumulators exist: all four pixel tiles per k-step there (12 MFMAs behind each A set), two at a time afterwards.
+    constexpr bool PEEL = TP2 == 8 && PT1 == 4 && NH == 2;
+#pragma unroll
+    for (int hh = 0; hh < NH; ++hh) {
+        if (PEEL && hh == 0) p1_pass(hh, std::integral_constant<int, PT1>{});
+        else p1_pass(hh, std::integral_constant<int, PTS>{});
+        if (hh == 0) {
+#pragma unroll
+            for (int i = 0; i < RT2; ++i)
+#pragma unroll
+                for (int j = 0; j < PT2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc2[i][j][r] = 0.f;
+        }
+        if (A2_LATE) {
+            loadA2(hh * NS, A2[0]);
+            loadA2(hh * NS + 1, A2[1]);
+        }
+        GH_STAMP(2 + 4 * hh);
+        __syncthreads();
+        GH_STAMP(3 + 4 * hh);
+        p2_pass(hh);
         GH_STAMP(4 + 4 * hh);
         __syncthreads();     // every wave is done reading this pass of h1
         GH_STAMP(5 + 4 * hh);
