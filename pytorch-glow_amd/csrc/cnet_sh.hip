@@ -82,14 +82,17 @@ __device__ __forceinline__ float fin_couple(const FinSrc& f, long n, int c, int 
     if (f.halos) {
         const int r = y & (f.R - 1);
         const long tile = (n * f.HW + (long)(y - r) * f.W) >> f.lpxt;    // tile holding row y
-        const float wd = (r == 0 && y > 0) ? 1.f : 0.f;                   // row below the previous tile: its `hdn`
-        const float wu = (r == f.R - 1 && y < f.H - 1) ? 1.f : 0.f;       // row above the next tile: its `hup`
+        const bool wd = r == 0 && y > 0;                   // row below the previous tile: its `hdn`
+        const bool wu = r == f.R - 1 && y < f.H - 1;       // row above the next tile: its `hup`
         const long td = tile > 0 ? tile - 1 : 0, tu = tile + 1 < f.tiles ? tile + 1 : tile;
         for (int m = 0; m < f.MS; ++m) {
             const long hd = (((long)m * f.tiles + td) * f.Cout + ce) * f.W + x;
             const long hu = (((long)m * f.tiles + tu) * f.Cout + ce) * f.W + x;
-            se += wd * f.hdn[hd] + wu * f.hup[hu];
-            so += wd * f.hdn[hd + (f.paired ? f.W : 0)] + wu * f.hup[hu + (f.paired ? f.W : 0)];
+            // loaded unconditionally, SELECTED (never multiplied by a 0/1 mask: an unused slot of the scratch buffer may hold
+            // NaN or inf bit patterns, and 0 * NaN is NaN)
+            const float d0 = f.hdn[hd], u0 = f.hup[hu], d1 = f.hdn[hd + (f.paired ? f.W : 0)], u1 = f.hup[hu + (f.paired ? f.W : 0)];
+            se += (wd ? d0 : 0.f) + (wu ? u0 : 0.f);
+            so += (wd ? d1 : 0.f) + (wu ? u1 : 0.f);
         }
     }
     const float A_ = (se + f.bias[ce]) * f.scale[ce];
@@ -785,8 +788,15 @@ __global__ void __launch_bounds__(256) k_cfinish(CfinArgs a) {
     const int C = 2 * Ch;
     float* mixv = fsm;
     float* mixm = fsm + C * PXB;
-    if (a.mix.C && a.mix.matrix)
-        for (int e = tid; e < C * C; e += 256) mixm[e] = a.mix.matrix[e];
+    // the mixer matrix is REQUESTED now and stored to LDS only after the coupling phase has issued its own loads: one round
+    // trip to memory for both instead of two behind one another (the launch is latency-bound: a few KB per workgroup)
+    constexpr int MREG = 10;                     // C <= 48: 2304 / 256 = 9 values per thread; wider mixers use the loop below
+    float mreg[MREG];
+    const bool mfast = a.mix.C && a.mix.matrix && C * C <= MREG * 256;
+    if (mfast) {
+#pragma unroll
+        for (int k = 0; k < MREG; ++k) mreg[k] = tid + 256 * k < C * C ? a.mix.matrix[tid + 256 * k] : 0.f;
+    }
     const float* zi = a.p.z + n * a.p.z_bs;
     float* zn = a.z_out + n * a.z_out_bs;
     long long ldq = 0;
@@ -810,6 +820,13 @@ __global__ void __launch_bounds__(256) k_cfinish(CfinArgs a) {
             zn[(long)(Ch + c) * HW + p] = zres;
             if (zn != zi) zn[(long)c * HW + p] = z1v;       // out of place: z1 travels along
         }
+    }
+    if (mfast) {
+#pragma unroll
+        for (int k = 0; k < MREG; ++k)
+            if (tid + 256 * k < C * C) mixm[tid + 256 * k] = mreg[k];
+    } else if (a.mix.C && a.mix.matrix) {
+        for (int e = tid; e < C * C; e += 256) mixm[e] = a.mix.matrix[e];
     }
     if (f.paired) {     // per-sample log-det: issued before the mixer phase, whose time hides the atomic's round trip
         const long long tot = block_sum_ll<256>(ldq, red);

@@ -160,15 +160,25 @@ __global__ void __launch_bounds__(256) k_repack_sh2_batched(const RepackJob* __r
         constexpr int KEEP = 8;               // passes whose values stay in registers (Kp <= 512); beyond that they are re-read
         float keep[KEEP][8];
         float mx = 0.f;
+        // f.2 rows are contiguous in memory: a lane's 8 values are two 16-byte loads (the other kinds gather with stride 9)
+        const bool vec = j.kind == REPACK_SH2_GEMM && (j.Cin & 7) == 0;
 #pragma unroll
         for (int it = 0; it < KEEP; ++it) {           // compile-time indices: `keep` stays in registers
             const int gi = gl + 8 * it;
+            if (vec) {
+                f32x4_t lo4 = {0.f, 0.f, 0.f, 0.f}, hi4 = lo4;
+                if (rv && gi < ngroups) {
+                    const f32x4_t* src = reinterpret_cast<const f32x4_t*>(j.w + (long)r * j.Cin + gi * 8);
+                    lo4 = src[0]; hi4 = src[1];
+                }
 #pragma unroll
-            for (int k8 = 0; k8 < 8; ++k8) {
-                const float v = gi < ngroups ? value(gi * 8 + k8) : 0.f;
-                keep[it][k8] = v;
-                mx = fmaxf(mx, fabsf(v));
+                for (int k8 = 0; k8 < 4; ++k8) { keep[it][k8] = lo4[k8] * fold; keep[it][4 + k8] = hi4[k8] * fold; }
+            } else {
+#pragma unroll
+                for (int k8 = 0; k8 < 8; ++k8) keep[it][k8] = gi < ngroups ? value(gi * 8 + k8) : 0.f;
             }
+#pragma unroll
+            for (int k8 = 0; k8 < 8; ++k8) mx = fmaxf(mx, fabsf(keep[it][k8]));
         }
         for (int gi = gl + 8 * KEEP; gi < ngroups; gi += 8)
 #pragma unroll

@@ -313,3 +313,26 @@ def test_in_kernel_dequantisation_noise():
     plan.set_dequant_rng(7, True)         # (a different seed in between, so that seed 99 restarts at call 0)
     z_d, _, _ = glow.normal_flow(x, None)
     assert torch.equal(z_c, z_d)
+
+
+def test_unused_scratch_slots_may_hold_nan():
+    """The finishing step reads the neighbour tiles' halo rows with unconditional loads and discards what does not apply.  The
+    workspace is uninitialised memory: poison it with NaN before every call -- a 0/1-mask multiply would leak them (0 * NaN)."""
+    cfg = O.default_cfg(image_shape=(64, 64, 3), hidden_channels=128, K=2, L=3, batch=3)
+    sd = O.seeded_state_dict(cfg, seed=8, zeros_std=0.02)
+    glow = make_glow(cfg, sd, 3)
+    g = torch.Generator().manual_seed(2)
+    x = torch.rand(3, 3, 64, 64, generator=g); noise = torch.rand(3, 3, 64, 64, generator=g) / 256
+    z_ref, nll_ref, _ = O.glow_forward(x, noise, sd, cfg)
+    plan = glow.flow.plan_for(dev(x))
+    z0, nll0, _ = glow.normal_flow(dev(x), None, noise=dev(noise))
+    for fill in (float("nan"), float("inf"), -1e30):
+        plan._ws.view(torch.float32).fill_(fill)
+        z, nll, _ = glow.normal_flow(dev(x), None, noise=dev(noise))
+        assert torch.equal(z, z0) and torch.equal(nll, nll0), fill
+    close(z0, z_ref, 1e-4, what="z"); close(nll0, nll_ref, 1e-4, what="nll")
+    eps = [torch.randn(3, *s, generator=g) * 0.7 for s in glow.flow.split_shapes((3, 64, 64))]
+    x_ref = O.glow_reverse(z_ref, sd, cfg, eps)
+    plan._ws.view(torch.float32).fill_(float("nan"))
+    xr = glow.reverse_flow(dev(z_ref), None, eps=[dev(e) for e in eps])
+    close(xr, x_ref, 1e-4, what="decode")
