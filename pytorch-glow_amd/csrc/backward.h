@@ -53,7 +53,7 @@ int launch_shift_expand(const float* src, long src_bs, float* out, int N, int C,
 bool wgrad_mfma_supported(int HW, int Mpad, int Npad);
 size_t wgrad_mfma_partial_floats(int Mpad, int Npad, int N, int HW);
 int launch_wgrad_mfma(const float* A, long a_bs, const float* B, long b_bs, float* partial, float* dw, int N, int HW,
-                      int Mpad, int Npad, int Mreal, int Nreal, int mode, hipStream_t s);
+                      int Mpad, int Npad, int Mreal, int Nreal, int mode, hipStream_t s, float sh_scale = 0.f);   // sh_scale > 0: f16-pipe kernel, gradient operand A pre-scaled by it
 
 // one launch for all reduction-type parameter gradients of a backward sweep
 struct GradJob {

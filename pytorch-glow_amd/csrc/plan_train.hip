@@ -307,7 +307,7 @@ static int backward_sweep(glowhip_plan* p, const void* packed, const float* x_in
                 const int m4 = round_up(L.Cout * 9, 128);
                 GH_TRY(launch_shift_expand(w.gpre, (long)L.Cout * HW, w.col, N, L.Cout, d.H, d.W, m4, -1, s));
                 GH_TRY(launch_wgrad_mfma(w.col, (long)m4 * HW, h2, (long)hid * HW, w.partial, G.f4_w, N, HW, m4, hid,
-                                         L.Cout * 9, hid, 1, s));
+                                         L.Cout * 9, hid, 1, s, train_sh_enabled() ? sh_grad_scale : 0.f));
             } else {
                 GH_TRY(launch_wgrad_direct(w.gpre, h2, (long)hid * HW, G.f4_w, N, hid, d.H, d.W, L.Cout, 3, s));
             }
@@ -324,7 +324,7 @@ static int backward_sweep(glowhip_plan* p, const void* packed, const float* x_in
             // (c) f.2 (1x1)
             if (fastw) {
                 GH_TRY(launch_wgrad_mfma(w.gh2, (long)hid * HW, h1, (long)hid * HW, w.partial, G.f2_w, N, HW, hid, hid, hid, hid,
-                                         0, s));
+                                         0, s, train_sh_enabled() ? sh_grad_scale : 0.f));
             } else {
                 GH_TRY(launch_wgrad_direct(w.gh2, h1, (long)hid * HW, G.f2_w, N, hid, d.H, d.W, hid, 1, s));
             }
@@ -343,7 +343,7 @@ static int backward_sweep(glowhip_plan* p, const void* packed, const float* x_in
                 const int n0 = round_up(Ch * 9, 64);
                 GH_TRY(launch_shift_expand(out, chw, w.col, N, Ch, d.H, d.W, n0, +1, s));
                 GH_TRY(launch_wgrad_mfma(w.gh1, (long)hid * HW, w.col, (long)n0 * HW, w.partial, G.f0_w, N, HW, hid, n0, hid,
-                                         Ch * 9, 0, s));
+                                         Ch * 9, 0, s, train_sh_enabled() ? sh_grad_scale : 0.f));
             } else {
                 GH_TRY(launch_wgrad_direct(w.gh1, out, chw, G.f0_w, N, Ch, d.H, d.W, hid, 3, s));
             }

@@ -10,6 +10,7 @@
 // the pixel axis is split over workgroups (split-K), partial tiles go to a scratch buffer and a second kernel adds
 // them in a fixed order (deterministic) while scattering into the reference weight layout.
 #include "backward.h"
+#include "sh.h"
 
 namespace glowhip {
 
@@ -141,6 +142,130 @@ k_wgrad_gemm(const float* __restrict__ A, long a_bs, const float* __restrict__ B
             }
 }
 
+
+// The same GEMM on the f16 matrix pipe (sh.h, two-accumulator split-half form): both operands are converted to (hi, lo * 2^11)
+// fp16 pairs on their way into LDS -- a thread's 8 consecutive pixels of a row are exactly one 16-byte MFMA fragment group, so
+// the "transposing" store of the fp32 kernel (16 scalar LDS stores per thread and tile) becomes 4 vector stores -- and every
+// product is three v_mfma_f32_32x32x16_f16.  24 MFMAs of 32 cycles per 32-pixel k-tile instead of 64 of 64 cycles: the kernel
+// goes from MFMA-bound to operand-delivery-bound.  The gradient operand (A) is multiplied by a_scale = 2^k on the way in (it is
+// ~1e-6 .. 1e-10 early in training, below fp16's normal range) and the partial sums by 2^-k on the way out (exact).
+template <int BN>
+__global__ void __launch_bounds__(256)
+k_wgrad_gemm_sh(const float* __restrict__ A, long a_bs, const float* __restrict__ B, long b_bs, float* __restrict__ partial,
+                int HW, int Mpad, int Npad, int ktiles_total, int ktiles_per_split, float a_scale) {
+    constexpr int BM = 128, BK = 32;
+    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+    constexpr int A_F4 = BM * BK / 4 / 256, B_F4 = BN * BK / 4 / 256;   // float4 per thread per K-tile (4, 4|2)
+    __shared__ __attribute__((aligned(16))) _Float16 As[2][2][BK / 8][BM][8];    // [buffer][plane][k group][row][8]
+    __shared__ __attribute__((aligned(16))) _Float16 Bs[2][2][BK / 8][BN][8];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wr = wid >> 1, wc = wid & 1, kl = lane >> 5, ml = lane & 31;
+    const int tiles_n = Npad / BN;
+    const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x % tiles_n;
+    const int split = blockIdx.y;
+    const int kt0 = split * ktiles_per_split;
+    const int kt1 = min(ktiles_total, kt0 + ktiles_per_split);
+    const int tiles_per_img = HW / BK;
+    const int a_row = tid & (BM - 1), a_q = tid / BM;
+    const int b_row = tid & (BN - 1), b_q = tid / BN;
+    f32x4 ra[A_F4], rb[B_F4];
+    auto load_tile = [&](int kt) {
+        const int img = kt / tiles_per_img, p0 = (kt - img * tiles_per_img) * BK;
+        const float* ap = A + (long)img * a_bs + (long)(tile_m * BM + a_row) * HW + p0 + a_q * (A_F4 * 4);
+        const float* bp = B + (long)img * b_bs + (long)(tile_n * BN + b_row) * HW + p0 + b_q * (B_F4 * 4);
+#pragma unroll
+        for (int j = 0; j < A_F4; ++j) ra[j] = *reinterpret_cast<const f32x4*>(ap + j * 4);
+#pragma unroll
+        for (int j = 0; j < B_F4; ++j) rb[j] = *reinterpret_cast<const f32x4*>(bp + j * 4);
+    };
+    auto store_tile = [&](int buf) {   // 8 consecutive pixels of a row = one fragment group; lanes = consecutive rows: conflict-free
+#pragma unroll
+        for (int g2 = 0; g2 < A_F4 / 2; ++g2) {
+            h8 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                _Float16 x0, x1;
+                sh_split(ra[2 * g2 + (e >> 2)][e & 3] * a_scale, x0, x1);
+                hi[e] = x0; lo[e] = x1;
+            }
+            const int grp = a_q * (A_F4 / 2) + g2;
+            *reinterpret_cast<h8*>(&As[buf][0][grp][a_row][0]) = hi;
+            *reinterpret_cast<h8*>(&As[buf][1][grp][a_row][0]) = lo;
+        }
+#pragma unroll
+        for (int g2 = 0; g2 < B_F4 / 2; ++g2) {
+            h8 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                _Float16 x0, x1;
+                sh_split(rb[2 * g2 + (e >> 2)][e & 3], x0, x1);
+                hi[e] = x0; lo[e] = x1;
+            }
+            const int grp = b_q * (B_F4 / 2) + g2;
+            *reinterpret_cast<h8*>(&Bs[buf][0][grp][b_row][0]) = hi;
+            *reinterpret_cast<h8*>(&Bs[buf][1][grp][b_row][0]) = lo;
+        }
+    };
+
+    f32x16_t accm[TM][TN], accx[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { accm[i][j][r] = 0.f; accx[i][j][r] = 0.f; }
+
+    if (kt0 < kt1) {
+        load_tile(kt0);
+        store_tile(0);
+        __syncthreads();
+        for (int kt = kt0; kt < kt1; ++kt) {
+            const int buf = (kt - kt0) & 1;
+            if (kt + 1 < kt1) load_tile(kt + 1);
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                const int grp = 2 * ks + kl;
+                h8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    ah[i] = *reinterpret_cast<const h8*>(&As[buf][0][grp][wr * WM + i * 32 + ml][0]);
+                    al[i] = *reinterpret_cast<const h8*>(&As[buf][1][grp][wr * WM + i * 32 + ml][0]);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    bh[j] = *reinterpret_cast<const h8*>(&Bs[buf][0][grp][wc * WN + j * 32 + ml][0]);
+                    bl[j] = *reinterpret_cast<const h8*>(&Bs[buf][1][grp][wc * WN + j * 32 + ml][0]);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) accm[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], accm[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], accx[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], accx[i][j], 0, 0, 0);
+            }
+            if (kt + 1 < kt1) store_tile(buf ^ 1);
+            __syncthreads();
+        }
+    }
+    const float inv = 1.0f / a_scale;
+    float* out = partial + ((long)split * Mpad + tile_m * BM) * Npad + tile_n * BN;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wr * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl;
+                out[(long)row * Npad + wc * WN + j * 32 + ml] = (accm[i][j][r] + accx[i][j][r] * SH_LO_INV) * inv;
+            }
+}
+
 // dW[f(m, n)] = sum_split partial[split][m][n], splits added in order.
 //   mode 0: dW[m*Nreal + n]                      (f.2: [512][512];  f.0: [512][Ch*9] = dW0[o][i][tap] flat)
 //   mode 1: m = o*9 + tap, n = i: dW[(o*Nreal + i)*9 + tap]      (f.4: dW4[o][i][tap])
@@ -168,7 +293,7 @@ size_t wgrad_mfma_partial_floats(int Mpad, int Npad, int N, int HW) {
 }
 
 int launch_wgrad_mfma(const float* A, long a_bs, const float* B, long b_bs, float* partial, float* dw, int N, int HW,
-                      int Mpad, int Npad, int Mreal, int Nreal, int mode, hipStream_t s) {
+                      int Mpad, int Npad, int Mreal, int Nreal, int mode, hipStream_t s, float sh_scale) {
     GH_REQUIRE(wgrad_mfma_supported(HW, Mpad, Npad), "wgrad_mfma: unsupported shape");
     if (N == 0) return GLOWHIP_OK;
     const bool bn128 = Npad % 128 == 0;
@@ -177,7 +302,13 @@ int launch_wgrad_mfma(const float* A, long a_bs, const float* B, long b_bs, floa
     int splits = std::max(1, std::min(total, (384 + tiles - 1) / tiles));   // ~1.5 workgroups per CU
     const int per = (total + splits - 1) / splits;
     splits = (total + per - 1) / per;
-    if (bn128)
+    if (sh_scale > 0.f && bn128)       // f16 matrix pipe, split-half operands (sh_scale = power-of-two pre-scale of the gradient operand)
+        hipLaunchKernelGGL(k_wgrad_gemm_sh<128>, dim3(tiles, splits), dim3(256), 0, s, A, a_bs, B, b_bs, partial, HW, Mpad, Npad,
+                           total, per, sh_scale);
+    else if (sh_scale > 0.f)
+        hipLaunchKernelGGL(k_wgrad_gemm_sh<64>, dim3(tiles, splits), dim3(256), 0, s, A, a_bs, B, b_bs, partial, HW, Mpad, Npad,
+                           total, per, sh_scale);
+    else if (bn128)
         hipLaunchKernelGGL(k_wgrad_gemm<128>, dim3(tiles, splits), dim3(256), 0, s, A, a_bs, B, b_bs, partial, HW, Mpad, Npad,
                            total, per);
     else
