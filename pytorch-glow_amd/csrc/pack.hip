@@ -128,14 +128,13 @@ __global__ void __launch_bounds__(256) k_repack_batched(const RepackJob* __restr
 //   SH2_FIRST (f.0): row o, k = (8-channel chunk, tap, 8 channels), tap fastest; same folding; j.K = G groups
 //   SH2_TAIL  (f.4): row m = tap * Cout + co (< j.Kpad = Mpad4 rows, zero beyond 9 Cout), k = input channel;
 //                    rowscale = 2^-e / 16 (undoes the activation scale as well), no bias
-__global__ void __launch_bounds__(256) k_repack_sh2_batched(const RepackJob* __restrict__ jobs, char* packed) {
-    const RepackJob j = jobs[blockIdx.y];
-    if (j.kind < REPACK_SH2_GEMM) return;
+template <int KIND>
+__device__ __forceinline__ void repack_sh2_rows(const RepackJob& j, char* packed) {
     // a wave takes EIGHT consecutive rows: lane = (k group within the pass) * 8 + row, so the eight 16-byte groups of one k group
     // are 128 contiguous bytes of the image (a single row per wave wrote 16 bytes every M * 16)
     const int lane = threadIdx.x & 63, r8 = lane & 7, gl = lane >> 3;
-    const int M = j.kind == REPACK_SH2_TAIL ? j.Kpad : j.Cout;
-    const int Kp = j.kind == REPACK_SH2_FIRST ? j.K * 8 : j.Cin;
+    const int M = KIND == REPACK_SH2_TAIL ? j.Kpad : j.Cout;
+    const int Kp = KIND == REPACK_SH2_FIRST ? j.K * 8 : j.Cin;
     const int ngroups = Kp / 8;
     _Float16* oh = (_Float16*)(packed + j.out_off);
     float* rowscale = (float*)(packed + j.out_off + (size_t)2 * Kp * M * sizeof(_Float16));
@@ -145,44 +144,44 @@ __global__ void __launch_bounds__(256) k_repack_sh2_batched(const RepackJob* __r
         const int r = r0 + r8;
         const bool rv = r < M;
         float fold = 1.f;
-        if (rv && j.kind != REPACK_SH2_TAIL && j.fold_logs) fold = expf(j.fold_logs[r] * LOGSCALE);
-        auto value = [&](int k) -> float {
-            if (!rv) return 0.f;
-            if (j.kind == REPACK_SH2_GEMM) return j.w[(long)r * j.Cin + k] * fold;
-            if (j.kind == REPACK_SH2_FIRST) {
-                const int gi = k >> 3, k8 = k & 7;
-                const int ch = gi / 9, tap = gi - ch * 9, ci = ch * 8 + k8;
-                return (ch < nchunk && ci < j.Cin) ? j.w[((long)r * j.Cin + ci) * 9 + tap] * fold : 0.f;
-            }
-            const int tap = r / j.Cout, co = r - tap * j.Cout;
-            return r < 9 * j.Cout ? j.w[((long)co * j.Cin + k) * 9 + tap] : 0.f;
-        };
-        constexpr int KEEP = 8;               // passes whose values stay in registers (Kp <= 512); beyond that they are re-read
-        float keep[KEEP][8];
-        float mx = 0.f;
-        // f.2 rows are contiguous in memory: a lane's 8 values are two 16-byte loads (the other kinds gather with stride 9)
-        const bool vec = j.kind == REPACK_SH2_GEMM && (j.Cin & 7) == 0;
+        if (rv && KIND != REPACK_SH2_TAIL && j.fold_logs) fold = expf(j.fold_logs[r] * LOGSCALE);
+        // the 8 values of k group gi of this lane's row
+        auto group = [&](int gi, float (&v)[8]) {
 #pragma unroll
-        for (int it = 0; it < KEEP; ++it) {           // compile-time indices: `keep` stays in registers
-            const int gi = gl + 8 * it;
-            if (vec) {
-                f32x4_t lo4 = {0.f, 0.f, 0.f, 0.f}, hi4 = lo4;
-                if (rv && gi < ngroups) {
-                    const f32x4_t* src = reinterpret_cast<const f32x4_t*>(j.w + (long)r * j.Cin + gi * 8);
-                    lo4 = src[0]; hi4 = src[1];
+            for (int k8 = 0; k8 < 8; ++k8) v[k8] = 0.f;
+            if (!rv || gi >= ngroups) return;
+            if (KIND == REPACK_SH2_GEMM) {          // contiguous in memory: two 16-byte loads when the row length allows
+                const float* src = j.w + (long)r * j.Cin + gi * 8;
+                if ((j.Cin & 3) == 0) {
+                    const f32x4_t a = *reinterpret_cast<const f32x4_t*>(src), b = *reinterpret_cast<const f32x4_t*>(src + 4);
+#pragma unroll
+                    for (int k8 = 0; k8 < 4; ++k8) { v[k8] = a[k8] * fold; v[4 + k8] = b[k8] * fold; }
+                } else {
+#pragma unroll
+                    for (int k8 = 0; k8 < 8; ++k8) v[k8] = src[k8] * fold;
                 }
+            } else if (KIND == REPACK_SH2_FIRST) {
+                const int ch = gi / 9, tap = gi - ch * 9;
+                if (ch < nchunk) {
 #pragma unroll
-                for (int k8 = 0; k8 < 4; ++k8) { keep[it][k8] = lo4[k8] * fold; keep[it][4 + k8] = hi4[k8] * fold; }
-            } else {
+                    for (int k8 = 0; k8 < 8; ++k8)
+                        if (ch * 8 + k8 < j.Cin) v[k8] = j.w[((long)r * j.Cin + ch * 8 + k8) * 9 + tap] * fold;
+                }
+            } else if (r < 9 * j.Cout) {
+                const int tap = r / j.Cout, co = r - tap * j.Cout;
 #pragma unroll
-                for (int k8 = 0; k8 < 8; ++k8) keep[it][k8] = gi < ngroups ? value(gi * 8 + k8) : 0.f;
+                for (int k8 = 0; k8 < 8; ++k8) v[k8] = j.w[((long)co * j.Cin + gi * 8 + k8) * 9 + tap];
             }
+        };
+        // pass 1: the row's largest magnitude (the values are re-read in pass 2: they come from L2, and holding them would cost
+        // 64+ registers per lane -- an earlier version did and ran at one wave per SIMD)
+        float mx = 0.f;
+        for (int gi = gl; gi < ngroups; gi += 8) {
+            float v[8];
+            group(gi, v);
 #pragma unroll
-            for (int k8 = 0; k8 < 8; ++k8) mx = fmaxf(mx, fabsf(keep[it][k8]));
+            for (int k8 = 0; k8 < 8; ++k8) mx = fmaxf(mx, fabsf(v[k8]));
         }
-        for (int gi = gl + 8 * KEEP; gi < ngroups; gi += 8)
-#pragma unroll
-            for (int k8 = 0; k8 < 8; ++k8) mx = fmaxf(mx, fabsf(value(gi * 8 + k8)));
         mx = fmaxf(mx, __shfl_xor(mx, 8, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
@@ -194,7 +193,9 @@ __global__ void __launch_bounds__(256) k_repack_sh2_batched(const RepackJob* __r
             e = e > 100 ? 100 : (e < -100 ? -100 : e);
         }
         const float up = ldexpf(1.f, e);
-        auto emit = [&](int gi, const float (&v)[8]) {
+        for (int gi = gl; gi < ngroups; gi += 8) {
+            float v[8];
+            group(gi, v);
             h8 hi, lo;
 #pragma unroll
             for (int k8 = 0; k8 < 8; ++k8) {
@@ -206,18 +207,9 @@ __global__ void __launch_bounds__(256) k_repack_sh2_batched(const RepackJob* __r
                 *reinterpret_cast<h8*>(oh + ((long)gi * M + r) * 8) = hi;
                 *reinterpret_cast<h8*>(oh + ((long)(ngroups + gi) * M + r) * 8) = lo;
             }
-        };
-#pragma unroll
-        for (int it = 0; it < KEEP; ++it)
-            if (gl + 8 * it < ngroups) emit(gl + 8 * it, keep[it]);
-        for (int gi = gl + 8 * KEEP; gi < ngroups; gi += 8) {
-            float v[8];
-#pragma unroll
-            for (int k8 = 0; k8 < 8; ++k8) v[k8] = value(gi * 8 + k8);
-            emit(gi, v);
         }
         if (gl == 0 && rv) {
-            if (j.kind == REPACK_SH2_TAIL) {
+            if (KIND == REPACK_SH2_TAIL) {
                 rowscale[r] = ldexpf(1.f, -e) * SH2_ACT_INV;
                 rbias[r] = 0.f;
             } else {
@@ -226,6 +218,183 @@ __global__ void __launch_bounds__(256) k_repack_sh2_batched(const RepackJob* __r
             }
         }
     }
+}
+
+// f.0 and f.4 weights are [o][i][3][3]: one (8 input channels) x (9 taps) BRICK of a row is 72 contiguous floats.  A lane loads
+// whole bricks (wide loads where the alignment allows) and emits their nine k groups; gathering tap by tap instead fetched a
+// 128-byte line per 4-byte load and ran at the L2 -> L1 rate (169 us per pack for the f.4 images alone).
+__device__ __forceinline__ void load_brick(const float* src, int nk, bool valid, float (&b)[72]) {
+#pragma unroll
+    for (int i = 0; i < 72; ++i) b[i] = 0.f;
+    if (!valid) return;
+    const int count = nk * 9;
+    if (nk == 8 && ((size_t)src & 15) == 0) {
+#pragma unroll
+        for (int i = 0; i < 18; ++i) {
+            const f32x4_t v = reinterpret_cast<const f32x4_t*>(src)[i];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) b[i * 4 + q] = v[q];
+        }
+    } else if ((count & 1) == 0 && ((size_t)src & 7) == 0) {
+#pragma unroll
+        for (int i = 0; i < 36; ++i)
+            if (2 * i < count) {
+                const f32x2_t v = reinterpret_cast<const f32x2_t*>(src)[i];
+                b[2 * i] = v[0]; b[2 * i + 1] = v[1];
+            }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 72; ++i)
+            if (i < count) b[i] = src[i];
+    }
+}
+
+__device__ __forceinline__ int sh2_row_exponent(float mx) {
+    int e = 0;
+    if (mx > 0.f && mx < 3.0e38f) {
+        int ex;
+        (void)frexpf(mx, &ex);
+        e = 13 - ex;
+        e = e > 100 ? 100 : (e < -100 ? -100 : e);
+    }
+    return e;
+}
+
+// group tap of a brick -> the (hi, lo) pair of 16-byte groups
+__device__ __forceinline__ void brick_emit(const float (&b)[72], int tap, float mul, h8& hi, h8& lo) {
+#pragma unroll
+    for (int k8 = 0; k8 < 8; ++k8) {
+        _Float16 x, y;
+        sh2_split(b[k8 * 9 + tap] * mul, x, y);
+        hi[k8] = x; lo[k8] = y;
+    }
+}
+
+// SH2_FIRST: one lane per output row, a loop over the row's bricks (two passes: row maximum, then the split)
+__device__ __forceinline__ void repack_sh2_first(const RepackJob& j, char* packed) {
+    const int M = j.Cout, G = j.K, Kp = G * 8;
+    _Float16* oh = (_Float16*)(packed + j.out_off);
+    float* rowscale = (float*)(packed + j.out_off + (size_t)2 * Kp * M * sizeof(_Float16));
+    float* rbias = rowscale + M;
+    const int nchunk = (j.Cin + 7) / 8;
+    for (int r = blockIdx.x * 256 + threadIdx.x; r < M; r += gridDim.x * 256) {
+        const float fold = j.fold_logs ? expf(j.fold_logs[r] * LOGSCALE) : 1.f;
+        const float* row = j.w + (long)r * j.Cin * 9;
+        float mx = 0.f;
+        for (int ch = 0; ch < nchunk; ++ch) {
+            float b[72];
+            load_brick(row + ch * 72, min(8, j.Cin - ch * 8), true, b);
+#pragma unroll
+            for (int i = 0; i < 72; ++i) mx = fmaxf(mx, fabsf(b[i] * fold));
+        }
+        const int e = sh2_row_exponent(mx);
+        const float up = ldexpf(1.f, e);
+        for (int ch = 0; ch < nchunk; ++ch) {
+            float b[72];
+            load_brick(row + ch * 72, min(8, j.Cin - ch * 8), true, b);
+#pragma unroll
+            for (int i = 0; i < 72; ++i) b[i] *= fold;      // same rounding order as the row maximum: (w * fold) * 2^e
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                h8 hi, lo;
+                brick_emit(b, tap, up, hi, lo);
+                const int gi = ch * 9 + tap;
+                *reinterpret_cast<h8*>(oh + ((long)gi * M + r) * 8) = hi;
+                *reinterpret_cast<h8*>(oh + ((long)(G + gi) * M + r) * 8) = lo;
+            }
+        }
+        h8 z;
+#pragma unroll
+        for (int k8 = 0; k8 < 8; ++k8) z[k8] = (_Float16)0.f;
+        for (int gi = nchunk * 9; gi < G; ++gi) {           // the k padding up to a whole number of pipeline steps
+            *reinterpret_cast<h8*>(oh + ((long)gi * M + r) * 8) = z;
+            *reinterpret_cast<h8*>(oh + ((long)(G + gi) * M + r) * 8) = z;
+        }
+        rowscale[r] = ldexpf(1.f, -e);
+        rbias[r] = (j.fold_bias ? j.fold_bias[r] * fold : 0.f) * SH2_ACT_SCALE;
+    }
+}
+
+// SH2_TAIL: a block takes EIGHT output channels (lane = brick-in-pass * 8 + channel, the four waves split the bricks) and emits
+// their 9 x 8 rows; row maxima go through LDS.  Rows beyond 9 Cout (the padding to whole row tiles) are zero-filled.
+__device__ __forceinline__ void repack_sh2_tail(const RepackJob& j, char* packed) {
+    __shared__ float s_mx[4][9][8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r8 = lane & 7, gl = lane >> 3;
+    const int M = j.Kpad, Kp = j.Cin, ngroups = Kp / 8, rows = 9 * j.Cout;
+    _Float16* oh = (_Float16*)(packed + j.out_off);
+    float* rowscale = (float*)(packed + j.out_off + (size_t)2 * Kp * M * sizeof(_Float16));
+    float* rbias = rowscale + M;
+    for (int co0 = blockIdx.x * 8; co0 < j.Cout; co0 += gridDim.x * 8) {
+        const int co = co0 + r8;
+        const bool rv = co < j.Cout;
+        const float* row = j.w + (long)(rv ? co : 0) * j.Cin * 9;
+        float mx[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) mx[t] = 0.f;
+        for (int gi = wave * 8 + gl; gi < ngroups; gi += 32) {
+            float b[72];
+            load_brick(row + gi * 72, 8, rv, b);
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int k8 = 0; k8 < 8; ++k8) mx[t] = fmaxf(mx[t], fabsf(b[k8 * 9 + t]));
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            mx[t] = fmaxf(mx[t], __shfl_xor(mx[t], 8, 64));
+            mx[t] = fmaxf(mx[t], __shfl_xor(mx[t], 16, 64));
+            mx[t] = fmaxf(mx[t], __shfl_xor(mx[t], 32, 64));
+            if (gl == 0) s_mx[wave][t][r8] = mx[t];
+        }
+        __syncthreads();
+        int e[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+            e[t] = sh2_row_exponent(fmaxf(fmaxf(s_mx[0][t][r8], s_mx[1][t][r8]), fmaxf(s_mx[2][t][r8], s_mx[3][t][r8])));
+        __syncthreads();
+        for (int gi = wave * 8 + gl; gi < ngroups; gi += 32) {
+            float b[72];
+            load_brick(row + gi * 72, 8, rv, b);
+            if (rv) {
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    h8 hi, lo;
+                    brick_emit(b, t, ldexpf(1.f, e[t]), hi, lo);
+                    const int r = t * j.Cout + co;
+                    *reinterpret_cast<h8*>(oh + ((long)gi * M + r) * 8) = hi;
+                    *reinterpret_cast<h8*>(oh + ((long)(ngroups + gi) * M + r) * 8) = lo;
+                }
+            }
+        }
+        if (wave == 0 && gl == 0 && rv) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                rowscale[t * j.Cout + co] = ldexpf(1.f, -e[t]) * SH2_ACT_INV;
+                rbias[t * j.Cout + co] = 0.f;
+            }
+        }
+    }
+    const int pad = M - rows;
+    h8 z;
+#pragma unroll
+    for (int k8 = 0; k8 < 8; ++k8) z[k8] = (_Float16)0.f;
+    for (int el = blockIdx.x * 256 + threadIdx.x; el < pad * 2 * ngroups; el += gridDim.x * 256) {
+        const int g2 = el / pad, r = rows + (el - g2 * pad);
+        *reinterpret_cast<h8*>(oh + ((long)g2 * M + r) * 8) = z;
+    }
+    for (int r = rows + blockIdx.x * 256 + threadIdx.x; r < M; r += gridDim.x * 256) {
+        rowscale[r] = SH2_ACT_INV;
+        rbias[r] = 0.f;
+    }
+}
+
+template <int KIND>
+__global__ void __launch_bounds__(256) k_repack_sh2_batched(const RepackJob* __restrict__ jobs, char* packed) {
+    const RepackJob j = jobs[blockIdx.y];
+    if (j.kind != KIND) return;
+    if (KIND == REPACK_SH2_GEMM) repack_sh2_rows<REPACK_SH2_GEMM>(j, packed);
+    else if (KIND == REPACK_SH2_FIRST) repack_sh2_first(j, packed);
+    else repack_sh2_tail(j, packed);
 }
 
 int launch_pack_batched(const ScaleJob* sj_dev, int n_scale, const RepackJob* rj_dev, int n_repack, void* packed,
@@ -237,7 +406,9 @@ int launch_pack_batched(const ScaleJob* sj_dev, int n_scale, const RepackJob* rj
     if (n_repack > 0) {
         hipLaunchKernelGGL(k_repack_batched, dim3(64, n_repack), dim3(256), 0, s, rj_dev, (char*)packed);
         GH_LAUNCH_CHECK("k_repack_batched");
-        hipLaunchKernelGGL(k_repack_sh2_batched, dim3(16, n_repack), dim3(256), 0, s, rj_dev, (char*)packed);
+        hipLaunchKernelGGL(k_repack_sh2_batched<REPACK_SH2_GEMM>, dim3(16, n_repack), dim3(256), 0, s, rj_dev, (char*)packed);
+        hipLaunchKernelGGL(k_repack_sh2_batched<REPACK_SH2_FIRST>, dim3(2, n_repack), dim3(256), 0, s, rj_dev, (char*)packed);
+        hipLaunchKernelGGL(k_repack_sh2_batched<REPACK_SH2_TAIL>, dim3(16, n_repack), dim3(256), 0, s, rj_dev, (char*)packed);
         GH_LAUNCH_CHECK("k_repack_sh2_batched");
     }
     return GLOWHIP_OK;
