@@ -27,7 +27,6 @@ GH_STAMPS_DEFINE(cnet)
 
 namespace glowhip {
 
-constexpr int CN_PX = 128;                   // pixels per workgroup tile
 constexpr int CN_HBUF = 128 * 1024;          // bytes of the h1 / h2 / T region
 constexpr int CN_MAXMS = 4;
 
@@ -215,10 +214,30 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
     }
 
     // ---- P0: tables, then the window -> (hi, lo) halves in LDS; slot e = (chunk, sub-tile, window pixel), 8 channels each
+    const int nwin = g.NI * g.Wpx;
+    const int nslots = g.nchunk * nwin;
+    // window slot e -> (inside the image?, address of its first channel); the address is always valid (clamped)
+    auto slot_src = [&](int e, bool& in, int& ch) {
+        ch = e / nwin;
+        const int rem = e - ch * nwin;
+        const int sub = rem / g.Wpx, wp = rem - sub * g.Wpx;
+        const int r = wp / g.WP, c = wp - r * g.WP;
+        const int yy = y0 - 1 + r, xx = c - 1;
+        const long n = n0 + sub;
+        in = yy >= 0 && yy < H && xx >= 0 && xx < W && n < a.N;
+        return a.x + (n < a.N ? n : (long)a.N - 1) * a.x_bs + min(max(yy, 0), H - 1) * W + min(max(xx, 0), W - 1);
+    };
+    // the first round of window values is REQUESTED before the tables are copied: one trip to memory for both
+    float v0[8];
+    if (!a.pre_on) {     // (chained launches build the window from the state they finish themselves)
+        bool in; int ch;
+        const float* xin = slot_src(min(tid, nslots - 1), in, ch);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v0[q] = xin[(long)min(ch * 8 + q, a.Cin - 1) * HW];
+    }
     for (int e = tid; e < 2 * HID; e += 512) t_rs0[e] = rs0[e];                               // rs0 | b0 are adjacent in the image
     for (int e = tid; e < MR; e += 512) { t_rs2[e] = rs2[ms_row0 + e]; t_b2[e] = rs2[HID + ms_row0 + e]; }
     for (int e = tid; e < g.Mpad4; e += 512) t_rs4[e] = rs4[e];
-    const int nwin = g.NI * g.Wpx;
     float* nz = nullptr;     // with `pre`: z1 of the freshly finished state at every window pixel, fp32 [Cin][nwin] in LDS
     if (a.pre_on) {
         // ---- finish the PREVIOUS step on every window pixel: coupling (+ log-det for the tile's own pixels), then the channel
@@ -288,38 +307,33 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
             __syncthreads();
         }
     }
-    {
-        const int nslots = g.nchunk * nwin;
-        for (int e = tid; e < nslots; e += 512) {
-            const int ch = e / nwin;
+    for (int e = tid; e < nslots; e += 512) {
+        bool in; int ch;
+        const float* xin = slot_src(e, in, ch);
+        float v[8];
+        if (nz) {
             const int rem = e - ch * nwin;
-            const int sub = rem / g.Wpx, wp = rem - sub * g.Wpx;
-            const int r = wp / g.WP, c = wp - r * g.WP;
-            const int yy = y0 - 1 + r, xx = c - 1;
-            const long n = n0 + sub;
-            const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W && n < a.N;
-            float v[8];
-            if (nz) {
 #pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] = nz[min(ch * 8 + q, a.Cin - 1) * nwin + rem];
-            } else {
-                // every load is issued unconditionally from a clamped (valid) address and masked afterwards: eight independent
-                // loads in flight per slot instead of eight round trips behind one another
-                const float* xin = a.x + (n < a.N ? n : (long)a.N - 1) * a.x_bs + min(max(yy, 0), H - 1) * W + min(max(xx, 0), W - 1);
+            for (int q = 0; q < 8; ++q) v[q] = nz[min(ch * 8 + q, a.Cin - 1) * nwin + rem];
+        } else if (e == tid) {      // (nz == nullptr <=> !a.pre_on: v0 was loaded)
 #pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] = xin[(long)min(ch * 8 + q, a.Cin - 1) * HW];
-            }
-            h8 hi, lo;
+            for (int q = 0; q < 8; ++q) v[q] = v0[q];
+        } else {
+            // every load is issued unconditionally from a clamped (valid) address and masked afterwards: eight independent
+            // loads in flight per slot instead of eight round trips behind one another
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const float vv = (in && ch * 8 + q < a.Cin) ? v[q] * SH2_ACT_SCALE : 0.f;
-                _Float16 x0, x1;
-                sh2_split(vv, x0, x1);
-                hi[q] = x0; lo[q] = x1;
-            }
-            *reinterpret_cast<h8*>(win + (long)e * 8) = hi;
-            *reinterpret_cast<h8*>(win + g.winplane + (long)e * 8) = lo;
+            for (int q = 0; q < 8; ++q) v[q] = xin[(long)min(ch * 8 + q, a.Cin - 1) * HW];
         }
+        h8 hi, lo;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float vv = (in && ch * 8 + q < a.Cin) ? v[q] * SH2_ACT_SCALE : 0.f;
+            _Float16 x0, x1;
+            sh2_split(vv, x0, x1);
+            hi[q] = x0; lo[q] = x1;
+        }
+        *reinterpret_cast<h8*>(win + (long)e * 8) = hi;
+        *reinterpret_cast<h8*>(win + g.winplane + (long)e * 8) = lo;
     }
     __syncthreads();
     GH_STAMP(1);
@@ -672,14 +686,26 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
     // ---- P4: T -> LDS as fp32 [k part][row m][pixel] (row scale applied; lanes = consecutive pixels: conflict-free stores and
     // tap reads; one slab per k part, summed in a fixed order by the readers), then the 9-tap sums
     float* T = reinterpret_cast<float*>(hbuf);
-    const int Cout = a.Cout, M9 = 9 * Cout;
-    const bool paired = a.mode == TAIL_AFFINE_FWD || a.mode == TAIL_AFFINE_REV;
-    const int nch = paired ? Cout / 2 : Cout;
+    const int Cout = a.Cout;
     const int ppx = 1 << g.lpp;                              // pixels per staging pass (whole sub-tiles when npass = 2)
     const long msN = (long)blockIdx.y * a.N;
     float* hpart = a.scratch;
     float* hup = a.scratch + (long)MS * a.N * Cout * HW;
     float* hdn = hup + (long)MS * g.tiles * Cout * W;
+    // row scales of this wave's T rows, fetched before the loop (one LDS round trip instead of one per group of four rows)
+    f32x4_t rs4v[UPW][RTU][4];
+#pragma unroll
+    for (int u = 0; u < UPW; ++u)
+#pragma unroll
+        for (int i = 0; i < RTU; ++i)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int unit = wid + 8 * u;
+                const int ru = unit < nunits ? unit % g.NU4 : 0;
+                rs4v[u][i][gq] = *reinterpret_cast<const f32x4_t*>(t_rs4 + min(ru * RTU + i, g.NRT4 - 1) * 32 + 8 * gq + 4 * kl);
+            }
+    const int slab = g.Mpad4 << g.lpp;                        // floats per k part: every row of the padded image has a slot, so
+                                                              // the stores below need no per-row predicate
 #pragma unroll 1
     for (int pass = 0; pass < g.npass; ++pass) {
 #pragma unroll
@@ -689,53 +715,51 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
             const int kp = unit / g.NU4, ru = unit - kp * g.NU4;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
+                const int rtile = ru * RTU + j / NPT;
+                if (rtile >= g.NRT4) continue;                              // (wave-uniform) a unit's surplus row tile
+                if ((((j % NPT) * 32) >> g.lpp) != pass) continue;          // (wave-uniform) pixel tile of the other pass
                 const int q = (j % NPT) * 32 + ml;
-                if ((q >> g.lpp) != pass) continue;
+                float* dst = T + kp * slab + ((rtile * 32 + 4 * kl) << g.lpp) + (q - (pass << g.lpp));
 #pragma unroll
-                for (int gq = 0; gq < 4; ++gq) {
-                    const int m = (ru * RTU + j / NPT) * 32 + 8 * gq + 4 * kl;
-                    if (m >= M9) continue;
-                    const f32x4_t rs = *reinterpret_cast<const f32x4_t*>(t_rs4 + m);
-                    float* dst = T + ((long)(kp * M9 + m) << g.lpp) + (q - (pass << g.lpp));
+                for (int gq = 0; gq < 4; ++gq)
 #pragma unroll
                     for (int t = 0; t < 4; ++t)
-                        if (m + t < M9) dst[(long)t << g.lpp] = accT[u][j][4 * gq + t] * rs[t];
-                }
+                        dst[(8 * gq + t) << g.lpp] = accT[u][j][4 * gq + t] * rs4v[u][j / NPT][gq][t];
             }
         }
         __syncthreads();
         GH_STAMP(20);
-        // own rows: out[c][r][x] = sum over taps whose source row r + dy - 1 lies inside the sub-tile
-        const int items = nch << g.lpp;
-        const int slab = M9 << g.lpp;                         // floats per k part
+        // own rows: out[c][r][x] = sum over taps whose source row r + dy - 1 lies inside the sub-tile.  One item = one output
+        // channel of one pixel; every LDS read is unconditional (the tile's own pixel when the tap falls outside) and SELECTED,
+        // so the nine reads of a k part are in flight together.
+        const int items = Cout << g.lpp;
         for (int e = tid; e < items; e += 512) {
-            const int c = e >> g.lpp, ql = e & (ppx - 1);
+            const int ce = e >> g.lpp, ql = e & (ppx - 1);
             const int q = (pass << g.lpp) + ql;
             const int sub = q >> g.lsub, qq = q & submask;
             const int r = qq >> g.wshift, x = qq & (W - 1);
             const long n = n0 + sub;
             if (n >= a.N) continue;
-            const int ce = paired ? 2 * c : c;
-            float se = 0.f, so = 0.f;
+            int off[9];
+            bool ok[9];
 #pragma unroll
-            for (int dy = 0; dy < 3; ++dy) {
-                const int rs_ = r + dy - 1;
-                if (rs_ < 0 || rs_ >= g.R) continue;
+            for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
                 for (int dx = 0; dx < 3; ++dx) {
-                    const int xs = x + dx - 1;
-                    if (xs < 0 || xs >= W) continue;
                     const int tap = dy * 3 + dx;              // out(r, x) += T[tap (dy, dx)][source (r + dy - 1, x + dx - 1)]
-                    const float* tp = T + ((tap * Cout + ce) << g.lpp) + ql + (dy - 1) * W + (dx - 1);
-                    for (int kp = 0; kp < g.KS; ++kp, tp += slab) {   // k parts of the reduction, fixed order
-                        se += tp[0];
-                        if (paired) so += tp[ppx];
-                    }
+                    ok[tap] = r + dy - 1 >= 0 && r + dy - 1 < g.R && x + dx - 1 >= 0 && x + dx - 1 < W;
+                    off[tap] = ((tap * Cout + ce) << g.lpp) + ql + (ok[tap] ? (dy - 1) * W + (dx - 1) : 0);
                 }
+            float sum = 0.f;
+            const float* tp = T;
+            for (int kp = 0; kp < g.KS; ++kp, tp += slab) {   // k parts of the reduction, fixed order
+                float v[9];
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) v[tap] = tp[off[tap]];
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) sum += ok[tap] ? v[tap] : 0.f;
             }
-            const long base = ((msN + n) * Cout + ce) * HW + (long)(y0 + r) * W + x;
-            hpart[base] = se;
-            if (paired) hpart[base + HW] = so;
+            hpart[((msN + n) * Cout + ce) * HW + (long)(y0 + r) * W + x] = sum;
         }
         // halo rows (NI = 1 only): what the tile's first row gives to image row y0 - 1, its last row to row y0 + R
         if (g.NI == 1 && g.R < H) {
@@ -747,13 +771,18 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
                 if (dn ? (y0 + g.R >= H) : (y0 == 0)) continue;
                 const int rsrc = dn ? g.R - 1 : 0;
                 const int dyt = dn ? 0 : 2;                 // filter row applied by the outside pixel to this source row
-                float sacc = 0.f;
+                int off[3];
+                bool ok[3];
 #pragma unroll
                 for (int dx = 0; dx < 3; ++dx) {
-                    const int xs = x + dx - 1;
-                    if (xs < 0 || xs >= W) continue;
-                    for (int kp = 0; kp < g.KS; ++kp)
-                        sacc += T[((kp * M9 + (dyt * 3 + dx) * Cout + co) << g.lpp) + rsrc * W + xs];
+                    ok[dx] = x + dx - 1 >= 0 && x + dx - 1 < W;
+                    off[dx] = (((dyt * 3 + dx) * Cout + co) << g.lpp) + rsrc * W + (ok[dx] ? x + dx - 1 : x);
+                }
+                float sacc = 0.f;
+                const float* tp = T;
+                for (int kp = 0; kp < g.KS; ++kp, tp += slab) {
+                    const float v0 = tp[off[0]], v1 = tp[off[1]], v2 = tp[off[2]];
+                    sacc += (ok[0] ? v0 : 0.f) + (ok[1] ? v1 : 0.f) + (ok[2] ? v2 : 0.f);
                 }
                 (dn ? hdn : hup)[(((long)blockIdx.y * g.tiles + tb) * Cout + co) * W + x] = sacc;
             }
