@@ -19,11 +19,19 @@
 // pixel count alone cannot fill 256 CUs.  The finishing kernel sums the MS partials and the neighbours' halo rows.
 #include "sh.h"
 #include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 
 #include "conv_mfma.h"
 
 GH_STAMPS_DEFINE(cnet)
+
+#ifndef CN_SB_P1
+#define CN_SB_P1 0
+#endif
+#ifndef CN_SB_P3
+#define CN_SB_P3 0
+#endif
 
 namespace glowhip {
 
@@ -36,6 +44,7 @@ struct CnetGeo {
     int HW;
     int lpp;          // log2(pixels per staging pass)
     int pxt, lpxt;    // pixels per workgroup tile (128 or 64) and its log2
+    int exp;          // experiment selector (env GLOWHIP_EXP; 0 in production)
 };
 
 __host__ __device__ inline int cnet_trow(int M9) {   // T row stride (floats): multiple of 4, an odd multiple (bank spread)
@@ -386,6 +395,9 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
             if (BPRE) loadB(Bc);
             auto step1 = [&](int st, const h8 (&use)[2 * RT1], h8 (&fill)[2 * RT1]) {
                 loadA1(hh, min(st + 2, g.steps0 - 1), fill);     // unconditional (clamped): no branch, counted waits
+#if CN_SB_P1
+                __builtin_amdgcn_sched_barrier(0);               // (as in P2: keep the request here)
+#endif
                 if (BPRE) { gk += 2; loadB(Bn); } else { loadB(Bc); gk += 2; }
                 // three sweeps over the tiles: consecutive MFMAs never share an accumulator
 #pragma unroll
@@ -453,6 +465,9 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
             const _Float16* bp = hbuf + ((long)kl * PXT + pt2 * 32 + ml) * 8;
             auto kstep = [&](int s, const h8 (&use)[2 * RT2], h8 (&fill)[2 * RT2]) {
                 loadA2(ks0 + min(s + 2, NS - 1), fill);          // unconditional (clamped)
+                // the scheduler must not sink these loads towards their use two k-steps later (it does, to save registers, and
+                // the wave then waits a full L2 round trip per k-step: measured 57% of the MFMA rate for a wave on its own)
+                __builtin_amdgcn_sched_barrier(0);
                 const _Float16* bs = bp + (long)s * (2 * PXT * 8);
                 h8 bh[PT2], bl[PT2];
 #pragma unroll
@@ -626,6 +641,9 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
             const _Float16* bp = hbuf + ((long)(2 * kp * nsl + kl) * PXT + ml) * 8;
             auto step4 = [&](int st, const h8 (&use)[2 * RTU], h8 (&fill)[2 * RTU]) {
                 loadA4(ap, ru, min(st + 2, nsl - 1), fill);      // unconditional (clamped)
+#if CN_SB_P3
+                __builtin_amdgcn_sched_barrier(0);
+#endif
                 const _Float16* bs = bp + (long)st * (2 * PXT * 8);
                 // all pixel tiles per k-step when the h2 accumulators are small (12 MFMAs behind one round of LDS reads), two at
                 // a time while 128 of them are still live
@@ -991,6 +1009,7 @@ int launch_cnet_main(const CnetArgs& a, hipStream_t s, CnetPending* out) {
     if (g_cnet_flags & 2) use64 = ok64;        // testing: 64-pixel tiles wherever they exist
     if (a.y_sh && ok128) use64 = false;
     g = use64 ? g64 : g128;
+    { static const int e = getenv("GLOWHIP_EXP") ? atoi(getenv("GLOWHIP_EXP")) : 0; g.exp = e; }
     int ms = 1;
     const int ms_max = std::min(CN_MAXMS, a.hidden / (use64 ? 128 : 64));
     while (ms < ms_max && g.tiles * ms < 160) ms *= 2;

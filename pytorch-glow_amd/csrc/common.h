@@ -108,7 +108,10 @@ __device__ __forceinline__ float relu_(float v) { return v < 0.f ? 0.f : v; }
 #ifndef GH_STAMP_BLOCK
 #define GH_STAMP_BLOCK 0
 #endif
-#define GH_STAMP(i) do { if (blockIdx.x == GH_STAMP_BLOCK && blockIdx.y == 0 && threadIdx.x == 0) g_stamps_local[i] = __builtin_readcyclecounter(); } while (0)
+#ifndef GH_STAMP_THREAD
+#define GH_STAMP_THREAD 0
+#endif
+#define GH_STAMP(i) do { if (blockIdx.x == GH_STAMP_BLOCK && blockIdx.y == 0 && threadIdx.x == GH_STAMP_THREAD) g_stamps_local[i] = __builtin_readcyclecounter(); } while (0)
 #else
 #define GH_STAMPS_DEFINE(name)
 #define GH_STAMP(i) do { } while (0)
