@@ -75,25 +75,30 @@ __device__ __forceinline__ FinSrc fin_src(const CnetPending& p, int N, int H, in
     return f;
 }
 
-// Updated z2 value of coupling channel c at pixel p of image n, given its current value zin; the log-det term of the element is
-// added to ldq as Q31.32 fixed point (integer sums are exact: the per-sample total does not depend on how elements are grouped
-// into workgroups, so both users produce the same bits).  Every load is unconditional (clamped index, masked value).
-__device__ __forceinline__ float fin_couple(const FinSrc& f, long n, int c, int p, float zin, long long& ldq, float& bad) {
+// Partial sums of h = f(z1) for coupling channel c at pixel p of image n: (se, so) = the shift (and, affine, the scale logit) before
+// bias and exp(3 logs).  Every load is unconditional (clamped index, selected value), so a caller that gathers several elements
+// before using any has all of their loads in flight together.
+template <int MSV, bool HALO = true>      // MSV > 0: f.MS known at compile time (loops unrolled: every load of the element in
+                                          // flight at once); HALO = false: the caller knows f.halos is false
+__device__ __forceinline__ void fin_gather_t(const FinSrc& f, long n, int c, int p, float& se, float& so) {
+    const int ms = MSV > 0 ? MSV : f.MS;
     const int y = p >> f.wshift, x = p & (f.W - 1);
     const int ce = f.paired ? 2 * c : c;
-    float se = 0.f, so = 0.f;
-    for (int m = 0; m < f.MS; ++m) {
+    se = 0.f; so = 0.f;
+#pragma unroll
+    for (int m = 0; m < ms; ++m) {
         const long base = (((long)m * f.N + n) * f.Cout + ce) * f.HW + p;
         se += f.hpart[base];
         so += f.hpart[base + (f.paired ? f.HW : 0)];
     }
-    if (f.halos) {
+    if (HALO) {   // halo rows: no branch either (without halos the selects below drop a valid but unused slot of the scratch buffer)
         const int r = y & (f.R - 1);
         const long tile = (n * f.HW + (long)(y - r) * f.W) >> f.lpxt;    // tile holding row y
-        const bool wd = r == 0 && y > 0;                   // row below the previous tile: its `hdn`
-        const bool wu = r == f.R - 1 && y < f.H - 1;       // row above the next tile: its `hup`
+        const bool wd = f.halos && r == 0 && y > 0;                   // row below the previous tile: its `hdn`
+        const bool wu = f.halos && r == f.R - 1 && y < f.H - 1;       // row above the next tile: its `hup`
         const long td = tile > 0 ? tile - 1 : 0, tu = tile + 1 < f.tiles ? tile + 1 : tile;
-        for (int m = 0; m < f.MS; ++m) {
+#pragma unroll
+        for (int m = 0; m < ms; ++m) {
             const long hd = (((long)m * f.tiles + td) * f.Cout + ce) * f.W + x;
             const long hu = (((long)m * f.tiles + tu) * f.Cout + ce) * f.W + x;
             // loaded unconditionally, SELECTED (never multiplied by a 0/1 mask: an unused slot of the scratch buffer may hold
@@ -103,9 +108,17 @@ __device__ __forceinline__ float fin_couple(const FinSrc& f, long n, int c, int 
             so += (wd ? d1 : 0.f) + (wu ? u1 : 0.f);
         }
     }
-    const float A_ = (se + f.bias[ce]) * f.scale[ce];
+}
+__device__ __forceinline__ void fin_gather(const FinSrc& f, long n, int c, int p, float& se, float& so) { fin_gather_t<0>(f, n, c, p, se, so); }
+
+// Updated z2 value of coupling channel c given its current value zin and the gathered sums; the log-det term of the element is
+// added to ldq as Q31.32 fixed point (integer sums are exact: the per-sample total does not depend on how elements are grouped
+// into workgroups, so every user produces the same bits).
+__device__ __forceinline__ float fin_apply_k(const FinSrc& f, float se, float so, float zin, float bias_e, float scale_e, float bias_o,
+                                             float scale_o, long long& ldq, float& bad) {
+    const float A_ = (se + bias_e) * scale_e;
     if (!f.paired) return f.mode == TAIL_ADD_FWD ? zin + A_ : zin - A_;
-    const float B_ = (so + f.bias[ce + 1]) * f.scale[ce + 1];
+    const float B_ = (so + bias_o) * scale_o;
     const float sc = sigmoidf_(B_ + 2.0f);
     const float lg = logf(sc);
     const float zr = f.mode == TAIL_AFFINE_FWD ? (zin + A_) * sc : zin / sc - A_;
@@ -116,6 +129,16 @@ __device__ __forceinline__ float fin_couple(const FinSrc& f, long n, int c, int 
     if (isfinite(term)) ldq += __double2ll_rn((double)term * FIX_SCALE);
     else bad = term;
     return zr;
+}
+__device__ __forceinline__ float fin_apply(const FinSrc& f, int c, float se, float so, float zin, long long& ldq, float& bad) {
+    const int ce = f.paired ? 2 * c : c;
+    return fin_apply_k(f, se, so, zin, f.bias[ce], f.scale[ce], f.bias[ce + (f.paired ? 1 : 0)], f.scale[ce + (f.paired ? 1 : 0)], ldq, bad);
+}
+
+__device__ __forceinline__ float fin_couple(const FinSrc& f, long n, int c, int p, float zin, long long& ldq, float& bad) {
+    float se, so;
+    fin_gather(f, n, c, p, se, so);
+    return fin_apply(f, c, se, so, zin, ldq, bad);
 }
 
 // sum of a Q31.32 term over a workgroup of NT threads (valid in thread 0); red: NT / 64 slots of LDS
@@ -132,8 +155,10 @@ __device__ __forceinline__ long long block_sum_ll(long long v, long long* red) {
     return t;
 }
 
-template <int HID, int MS, int UPW, int PXT>
+// PRE: the launch may finish the previous step while it builds its window (a.pre_on); without it none of that code is compiled in
+template <int HID, int MS, int UPW, int PXT, bool PRE>
 __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
+    const bool pre_on = PRE && a.pre_on;
     constexpr int NPT = PXT / 32;                    // pixel tiles of the workgroup: 4 (128 pixels) or 2 (64 pixels)
     constexpr int CAP = CN_HBUF / (PXT * 4);         // activation channels the LDS buffer holds as (hi, lo) halves: 256 / 512
     constexpr int NH = HID > CAP ? HID / CAP : 1;    // passes over h1
@@ -164,6 +189,7 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
     float* t_rs2 = t_b0 + HID;
     float* t_b2 = t_rs2 + MR;
     float* t_rs4 = t_b2 + MR;
+    long long* ld_slot = reinterpret_cast<long long*>((reinterpret_cast<size_t>(t_rs4 + g.Mpad4) + 7) & ~(size_t)7);   // [8 waves][2]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -226,105 +252,212 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
     const int nwin = g.NI * g.Wpx;
     const int nslots = g.nchunk * nwin;
     // window slot e -> (inside the image?, address of its first channel); the address is always valid (clamped)
+    int slot_r, slot_c, slot_sub;      // window row / column / sub-image of the slot slot_src was last asked about
     auto slot_src = [&](int e, bool& in, int& ch) {
         ch = e / nwin;
         const int rem = e - ch * nwin;
         const int sub = rem / g.Wpx, wp = rem - sub * g.Wpx;
         const int r = wp / g.WP, c = wp - r * g.WP;
+        slot_r = r; slot_c = c; slot_sub = sub;
         const int yy = y0 - 1 + r, xx = c - 1;
         const long n = n0 + sub;
         in = yy >= 0 && yy < H && xx >= 0 && xx < W && n < a.N;
         return a.x + (n < a.N ? n : (long)a.N - 1) * a.x_bs + min(max(yy, 0), H - 1) * W + min(max(xx, 0), W - 1);
     };
-    // the first round of window values is REQUESTED before the tables are copied: one trip to memory for both
+    // With `pre`: the window pixels that lie inside an image, as a compact list k = (sub-image * nrows + row) * W + x over the window
+    // rows [rlo, rlo + nrows); KP = that count rounded up to whole waves.
+    const int rlo = y0 == 0 ? 1 : 0;
+    const int nrows = min(g.R + 2, H - y0 + 1) - rlo;
+    const int nin = g.NI * nrows * W;
+    const int KP = (nin + 63) & ~63;
+    const int per_sub = nrows << g.wshift;
+    // pixel k of the list -> image n, pixel index p, own pixel of this tile?
+    auto pix = [&](int k, long& n, int& p, bool& own, int& sub) {
+        sub = k >= per_sub ? 1 : 0;
+        const int kk = k - sub * per_sub;
+        const int r = rlo + (kk >> g.wshift);                     // window row
+        n = n0 + sub;
+        p = (y0 - 1 + r) * W + (kk & (W - 1));
+        own = r >= 1 && r <= g.R;
+        return k < nin && n < a.N;
+    };
+    // ---- the first round of global loads is REQUESTED before the tables are copied (one trip to memory for both): the window
+    // values, or -- chained launch -- everything the finishing of the previous step reads
+    constexpr int PU = 3;      // elements per thread and round of the finishing
+    const FinSrc pf = pre_on ? fin_src(a.pre, a.N, H, W, HW, g.wshift) : FinSrc{};
+    const int pCh = pf.paired ? pf.Cout / 2 : pf.Cout, pC = 2 * pCh;
+    const int ptotal = pCh * KP;
+    float pse[PU], pso[PU], pzin[PU], pz1[PU], pkb[PU][4], pkm[PU][4];      // pkb: f.4 bias / scale (even, odd); pkm: mixer bias / scale
+    int pcc[PU], pkq[PU];
+    auto pre_gather = [&](int e0, auto halo_c) {
+        constexpr bool HALO = decltype(halo_c)::value;
+#pragma unroll
+        for (int u = 0; u < PU; ++u) {
+            const int e = min(e0 + 512 * u, ptotal - 1);
+            const int c = __builtin_amdgcn_readfirstlane(e / KP);           // (a wave's 64 elements share the channel: 64 | KP)
+            const int k = e - c * KP;
+            long n; int p, sub; bool own;
+            const bool ok = pix(k, n, p, own, sub);
+            const long nc = ok ? n : n0;
+            const int pc = ok ? p : (y0 - 1 + rlo) * W;                     // (clamped: a pixel of the list's first row)
+            const float* zp = a.pre.z + nc * a.pre.z_bs;
+            pz1[u] = zp[(long)c * HW + pc];
+            pzin[u] = zp[(long)(pCh + c) * HW + pc];
+            fin_gather_t<MS, HALO>(pf, nc, c, pc, pse[u], pso[u]);       // (pre.MS == MS: checked by the launcher)
+            pcc[u] = c; pkq[u] = k;
+            const int ce = pf.paired ? 2 * c : c, co = ce + (pf.paired ? 1 : 0);
+            pkb[u][0] = pf.bias[ce]; pkb[u][1] = pf.scale[ce]; pkb[u][2] = pf.bias[co]; pkb[u][3] = pf.scale[co];
+            const bool an = !a.pre_mix.reverse && a.pre_mix.C;
+            pkm[u][0] = an ? a.pre_mix.bias[c] : 0.f; pkm[u][1] = an ? a.pre_mix.scale[c] : 1.f;
+            pkm[u][2] = an ? a.pre_mix.bias[pCh + c] : 0.f; pkm[u][3] = an ? a.pre_mix.scale[pCh + c] : 1.f;
+        }
+    };
     float v0[8];
-    if (!a.pre_on) {     // (chained launches build the window from the state they finish themselves)
+    if (!pre_on) {     // (chained launches build the window from the state they finish themselves)
         bool in; int ch;
         const float* xin = slot_src(min(tid, nslots - 1), in, ch);
 #pragma unroll
         for (int q = 0; q < 8; ++q) v0[q] = xin[(long)min(ch * 8 + q, a.Cin - 1) * HW];
+    } else if (pf.halos) {
+        pre_gather(tid, std::true_type{});
+    } else {
+        pre_gather(tid, std::false_type{});
     }
     for (int e = tid; e < 2 * HID; e += 512) t_rs0[e] = rs0[e];                               // rs0 | b0 are adjacent in the image
     for (int e = tid; e < MR; e += 512) { t_rs2[e] = rs2[ms_row0 + e]; t_b2[e] = rs2[HID + ms_row0 + e]; }
     for (int e = tid; e < g.Mpad4; e += 512) t_rs4[e] = rs4[e];
-    float* nz = nullptr;     // with `pre`: z1 of the freshly finished state at every window pixel, fp32 [Cin][nwin] in LDS
-    if (a.pre_on) {
-        // ---- finish the PREVIOUS step on every window pixel: coupling (+ log-det for the tile's own pixels), then the channel
-        // mixer; the result of the own pixels goes to pre_z_new, z1 of all window pixels to `nz` (hbuf is free at this point)
-        const FinSrc f = fin_src(a.pre, a.N, H, W, HW, g.wshift);
-        const int Ch = f.paired ? f.Cout / 2 : f.Cout, C = 2 * Ch;
-        float* pv = reinterpret_cast<float*>(hbuf);          // [C][nwin] staged values
-        float* pm = pv + C * nwin;                           // [C][C] mixer matrix
-        nz = pm + C * C;
-        long long* red = reinterpret_cast<long long*>(nz + a.Cin * nwin + (((size_t)(nz + a.Cin * nwin) & 4) ? 1 : 0));
+    float* nz = nullptr;     // with `pre`: z1 of the freshly finished state, fp32 [Cin][KP]
+    if (pre_on) {
+        // ---- finish the PREVIOUS step on the window pixels: coupling (+ log-det for the tile's own pixels), then the channel mixer;
+        // the result of the own pixels goes to pre_z_new, z1 of all of them to `nz` (hbuf is free at this point).  Same arithmetic
+        // as k_cfinish, bit for bit.  Built for latency: ONE round of global loads (requested above), the mixer's matrix staged in
+        // LDS meanwhile and read as wave-uniform 16-byte broadcasts, log-det terms summed per wave (fixed point: any grouping
+        // gives the same bits).
+        const FinSrc& f = pf;
+        const int Ch = pCh, C = pC;
+        float* pv = reinterpret_cast<float*>(hbuf);          // [C][KP] staged values
+        nz = pv + C * KP;
+        const int CP = (C + 3) & ~3;                          // matrix row stride (16-byte aligned rows)
+        float* pm = nz + a.Cin * KP;                          // [C][CP]
         if (a.pre_mix.matrix)
-            for (int e = tid; e < C * C; e += 512) pm[e] = a.pre_mix.matrix[e];
+            for (int e = tid; e < C * C; e += 512) { const int o = e / C; pm[o * CP + (e - o * C)] = a.pre_mix.matrix[e]; }
+        GH_STAMP(22);
         long long ldq[2] = {0, 0};
-        for (int e = tid; e < Ch * nwin; e += 512) {
-            const int c = e / nwin, w = e - c * nwin;
-            const int sub = w / g.Wpx, wp = w - sub * g.Wpx;
-            const int r = wp / g.WP, col = wp - r * g.WP;
-            const int yy = y0 - 1 + r, xx = col - 1;
-            const long n = n0 + sub;
-            const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W && n < a.N;
-            float v1 = 0.f, v2 = 0.f;
-            if (in) {
-                const int p = yy * W + xx;
-                const float* zp = a.pre.z + n * a.pre.z_bs;
-                const float z1v = zp[(long)c * HW + p];
-                const float zin = zp[(long)(Ch + c) * HW + p];
-                long long lq = 0;
-                float bad = 0.f;
-                const float zres = fin_couple(f, n, c, p, zin, lq, bad);
-                if (bad != 0.f && r >= 1 && r <= g.R && blockIdx.y == 0) fix_flag_nonfinite(a.acc, n, a.N, bad);
-                if (r >= 1 && r <= g.R && blockIdx.y == 0) ldq[sub & 1] += lq;   // own pixel (not a halo row), once per tile: counts for the log-det
-                if (!a.pre_mix.reverse && a.pre_mix.C) {             // ActNorm of the mixer on both halves, staged for its matrix / gather
-                    v1 = (z1v + a.pre_mix.bias[c]) * a.pre_mix.scale[c];
-                    v2 = (zres + a.pre_mix.bias[Ch + c]) * a.pre_mix.scale[Ch + c];
-                } else { v1 = z1v; v2 = zres; }
+        for (int e0 = tid; e0 < ptotal; e0 += 512 * PU) {
+            if (e0 != tid) {                                  // (a second round only for shapes beyond the product's)
+                if (f.halos) pre_gather(e0, std::true_type{}); else pre_gather(e0, std::false_type{});
             }
-            pv[c * nwin + w] = v1;
-            pv[(Ch + c) * nwin + w] = v2;
-        }
-        __syncthreads();
-        for (int e = tid; e < C * nwin; e += 512) {
-            const int o = e / nwin, w = e - o * nwin;
-            const int sub = w / g.Wpx, wp = w - sub * g.Wpx;
-            const int r = wp / g.WP, col = wp - r * g.WP;
-            const int yy = y0 - 1 + r, xx = col - 1;
-            const long n = n0 + sub;
-            const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W && n < a.N;
-            float rr = 0.f;
-            if (in) {
-                if (a.pre_mix.matrix) {   // same operation order as k_chanmix / k_cfinish: r = fma(m[o][i], v[i], r), i ascending
-                    const float* m = pm + o * C;
-                    for (int i = 0; i < C; ++i) rr = fmaf(m[i], pv[i * nwin + w], rr);
-                } else {
-                    rr = pv[(a.pre_mix.gather ? a.pre_mix.gather[o] : o) * nwin + w];
+#pragma unroll
+            for (int u = 0; u < PU; ++u) {
+                if (e0 + 512 * u >= ptotal) continue;
+                const int c = pcc[u], k = pkq[u];
+                long n; int p, sub; bool own;
+                const bool ok = pix(k, n, p, own, sub);
+                float v1 = 0.f, v2 = 0.f;
+                if (ok) {
+                    long long lq = 0;
+                    float bad = 0.f;
+                    const float zres = fin_apply_k(f, pse[u], pso[u], pzin[u], pkb[u][0], pkb[u][1], pkb[u][2], pkb[u][3], lq, bad);
+                    if (own && blockIdx.y == 0) {            // own pixel (not a halo row), once per tile: counts for the log-det
+                        if (bad != 0.f) fix_flag_nonfinite(a.acc, n, a.N, bad);
+                        ldq[sub] += lq;
+                    }
+                    if (!a.pre_mix.reverse && a.pre_mix.C) {             // ActNorm of the mixer on both halves, staged for its matrix / gather
+                        v1 = (pz1[u] + pkm[u][0]) * pkm[u][1];
+                        v2 = (zres + pkm[u][2]) * pkm[u][3];
+                    } else { v1 = pz1[u]; v2 = zres; }
                 }
-                if (a.pre_mix.reverse && a.pre_mix.C) rr = rr * a.pre_mix.scale[o] - a.pre_mix.bias[o];
-                if (r >= 1 && r <= g.R && blockIdx.y == 0) a.pre_z_new[n * a.pre_z_new_bs + (long)o * HW + yy * W + xx] = rr;
+                pv[c * KP + k] = v1;
+                pv[(Ch + c) * KP + k] = v2;
             }
-            if (o < a.Cin) nz[o * nwin + w] = rr;
         }
-        if (f.paired) {
-            for (int sb = 0; sb < g.NI; ++sb) {
-                const long long tot = block_sum_ll<512>(ldq[sb], red);
-                if (tid == 0 && n0 + sb < a.N) atomicAdd(a.acc + (n0 + sb), (unsigned long long)tot);
+        if (f.paired && blockIdx.y == 0) {                    // per-wave sums of the fixed-point terms, one atomic per wave and image
+#pragma unroll
+            for (int sb = 0; sb < 2; ++sb) {
+                if (sb >= g.NI) continue;
+                long long v = ldq[sb];
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+                if (lane == 0) ld_slot[wid * 2 + sb] = v;     // added to the sample's accumulator at the END of the kernel: an
+                                                              // atomic in flight here would sit in front of every later wait
             }
-        } else {
-            __syncthreads();
         }
+        GH_STAMP(23);
+        __syncthreads();
+        GH_STAMP(24);
+        // mixer: item = (group of OB output channels, 64 pixels); the matrix rows of a wave's output channels are wave-uniform
+        constexpr int OB = 6;
+        const int npb = KP >> 6, nog = (C + OB - 1) / OB;
+        for (int it = wid; it < nog * npb; it += 8) {
+            const int og = it / npb, pb = it - og * npb;
+            const int k = pb * 64 + lane;
+            float r[OB], osc[OB], obi[OB];
+            const bool rev = a.pre_mix.reverse && a.pre_mix.C;
+#pragma unroll
+            for (int j = 0; j < OB; ++j) {        // inverse ActNorm of the outputs (reverse flow): requested before the products
+                const int o = min(og * OB + j, C - 1);
+                osc[j] = rev ? a.pre_mix.scale[o] : 1.f;
+                obi[j] = rev ? a.pre_mix.bias[o] : 0.f;
+            }
+            if (a.pre_mix.matrix) {   // same operation order as k_chanmix / k_cfinish: r = fma(m[o][i], v[i], r), i ascending
+#pragma unroll
+                for (int j = 0; j < OB; ++j) r[j] = 0.f;
+                const float* mrow[OB];
+#pragma unroll
+                for (int j = 0; j < OB; ++j) mrow[j] = pm + min(og * OB + j, C - 1) * CP;
+                int i = 0;
+                for (; i + 4 <= C; i += 4) {
+                    float vi[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) vi[t] = pv[(i + t) * KP + k];
+#pragma unroll
+                    for (int j = 0; j < OB; ++j) {
+                        const f32x4_t m4 = *reinterpret_cast<const f32x4_t*>(mrow[j] + i);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) r[j] = fmaf(m4[t], vi[t], r[j]);
+                    }
+                }
+                for (; i < C; ++i) {
+                    const float vi = pv[i * KP + k];
+#pragma unroll
+                    for (int j = 0; j < OB; ++j) r[j] = fmaf(mrow[j][i], vi, r[j]);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < OB; ++j) {
+                    const int o = min(og * OB + j, C - 1);
+                    r[j] = pv[(a.pre_mix.gather ? a.pre_mix.gather[o] : o) * KP + k];
+                }
+            }
+            long n; int p, sub; bool own;
+            const bool ok = pix(k, n, p, own, sub);
+            const bool wr = ok && own && blockIdx.y == 0;
+            float* zo = a.pre_z_new + (wr ? n : n0) * a.pre_z_new_bs + (wr ? p : 0);
+#pragma unroll
+            for (int j = 0; j < OB; ++j) {
+                const int o = og * OB + j;
+                if (rev) r[j] = r[j] * osc[j] - obi[j];
+                if (o < C && wr) zo[(long)o * HW] = r[j];
+            }
+#pragma unroll
+            for (int j = 0; j < OB; ++j) {
+                const int o = og * OB + j;
+                if (o < a.Cin && o < C) nz[o * KP + k] = ok ? r[j] : 0.f;
+            }
+        }
+        GH_STAMP(25);
+        __syncthreads();
     }
+    GH_STAMP(26);
     for (int e = tid; e < nslots; e += 512) {
         bool in; int ch;
         const float* xin = slot_src(e, in, ch);
         float v[8];
         if (nz) {
-            const int rem = e - ch * nwin;
+            const int k = in ? ((slot_sub * nrows + slot_r - rlo) << g.wshift) + slot_c - 1 : 0;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = nz[min(ch * 8 + q, a.Cin - 1) * nwin + rem];
-        } else if (e == tid) {      // (nz == nullptr <=> !a.pre_on: v0 was loaded)
+            for (int q = 0; q < 8; ++q) v[q] = nz[min(ch * 8 + q, a.Cin - 1) * KP + k];
+        } else if (e == tid) {      // (nz == nullptr <=> !pre_on: v0 was loaded)
 #pragma unroll
             for (int q = 0; q < 8; ++q) v[q] = v0[q];
         } else {
@@ -807,6 +940,10 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
         }
         if (pass + 1 < g.npass) __syncthreads();
     }
+    if (pre_on && blockIdx.y == 0 && lane < g.NI && (a.pre.mode == TAIL_AFFINE_FWD || a.pre.mode == TAIL_AFFINE_REV)) {
+        const long long v = ld_slot[wid * 2 + lane];         // (written by this wave's lane 0 in the window phase)
+        if (v != 0 && n0 + lane < a.N) atomicAdd(a.acc + (n0 + lane), (unsigned long long)v);
+    }
     GH_STAMP(21);
 }
 
@@ -821,7 +958,7 @@ struct CfinArgs {
     int N, H, W, HW, wshift;
 };
 
-template <int PXB>
+template <int PXB, int MSV, bool HALO>
 __global__ void __launch_bounds__(256) k_cfinish(CfinArgs a) {
     extern __shared__ __attribute__((aligned(16))) float fsm[];   // [C][PXB] values, then [C*C] matrix
     __shared__ long long red[4];
@@ -835,8 +972,9 @@ __global__ void __launch_bounds__(256) k_cfinish(CfinArgs a) {
     const int C = 2 * Ch;
     float* mixv = fsm;
     float* mixm = fsm + C * PXB;
-    // the mixer matrix is REQUESTED now and stored to LDS only after the coupling phase has issued its own loads: one round
-    // trip to memory for both instead of two behind one another (the launch is latency-bound: a few KB per workgroup)
+    // The launch is latency-bound (a few KB per workgroup): EVERYTHING it reads from memory -- the mixer matrix, the state, the
+    // MS partial sums and halo rows, the per-channel constants -- is requested in one round, branch-free (fin_gather_t), before the
+    // first value is used.
     constexpr int MREG = 10;                     // C <= 48: 2304 / 256 = 9 values per thread; wider mixers use the loop below
     float mreg[MREG];
     const bool mfast = a.mix.C && a.mix.matrix && C * C <= MREG * 256;
@@ -847,25 +985,44 @@ __global__ void __launch_bounds__(256) k_cfinish(CfinArgs a) {
     const float* zi = a.p.z + n * a.p.z_bs;
     float* zn = a.z_out + n * a.z_out_bs;
     long long ldq = 0;
-    for (int e = tid; e < Ch * PXB; e += 256) {
-        const int c = e / PXB, q = e - c * PXB;
-        const int p = p0 + q;
-        const float zin = zi[(long)(Ch + c) * HW + p];
-        const float z1v = zi[(long)c * HW + p];
-        float bad = 0.f;
-        const float zres = fin_couple(f, n, c, p, zin, ldq, bad);
-        if (bad != 0.f) fix_flag_nonfinite(a.acc, n, a.N, bad);
-        if (a.mix.C) {
-            if (!a.mix.reverse) {     // ActNorm of the next step on both halves, staged for its matrix / gather
-                mixv[c * PXB + q] = (z1v + a.mix.bias[c]) * a.mix.scale[c];
-                mixv[(Ch + c) * PXB + q] = (zres + a.mix.bias[Ch + c]) * a.mix.scale[Ch + c];
+    constexpr int U = 2;
+    const int total = Ch * PXB;
+    const bool an = a.mix.C && !a.mix.reverse;
+    for (int e0 = tid; e0 < total; e0 += 256 * U) {
+        float se[U], so[U], zin[U], z1v[U], kb[U][4], km[U][4];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = min(e0 + 256 * u, total - 1);
+            const int c = e / PXB, q = e - c * PXB;
+            zin[u] = zi[(long)(Ch + c) * HW + p0 + q];
+            z1v[u] = zi[(long)c * HW + p0 + q];
+            fin_gather_t<MSV, HALO>(f, n, c, p0 + q, se[u], so[u]);
+            const int ce = f.paired ? 2 * c : c, co = ce + (f.paired ? 1 : 0);
+            kb[u][0] = f.bias[ce]; kb[u][1] = f.scale[ce]; kb[u][2] = f.bias[co]; kb[u][3] = f.scale[co];
+            km[u][0] = an ? a.mix.bias[c] : 0.f; km[u][1] = an ? a.mix.scale[c] : 1.f;
+            km[u][2] = an ? a.mix.bias[Ch + c] : 0.f; km[u][3] = an ? a.mix.scale[Ch + c] : 1.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = e0 + 256 * u;
+            if (e >= total) continue;
+            const int c = e / PXB, q = e - c * PXB;
+            const int p = p0 + q;
+            float bad = 0.f;
+            const float zres = fin_apply_k(f, se[u], so[u], zin[u], kb[u][0], kb[u][1], kb[u][2], kb[u][3], ldq, bad);
+            if (bad != 0.f) fix_flag_nonfinite(a.acc, n, a.N, bad);
+            if (a.mix.C) {
+                if (!a.mix.reverse) {     // ActNorm of the next step on both halves, staged for its matrix / gather
+                    mixv[c * PXB + q] = (z1v[u] + km[u][0]) * km[u][1];
+                    mixv[(Ch + c) * PXB + q] = (zres + km[u][2]) * km[u][3];
+                } else {
+                    mixv[c * PXB + q] = z1v[u];
+                    mixv[(Ch + c) * PXB + q] = zres;
+                }
             } else {
-                mixv[c * PXB + q] = z1v;
-                mixv[(Ch + c) * PXB + q] = zres;
+                zn[(long)(Ch + c) * HW + p] = zres;
+                if (zn != zi) zn[(long)c * HW + p] = z1v[u];       // out of place: z1 travels along
             }
-        } else {
-            zn[(long)(Ch + c) * HW + p] = zres;
-            if (zn != zi) zn[(long)c * HW + p] = z1v;       // out of place: z1 travels along
         }
     }
     if (mfast) {
@@ -875,9 +1032,11 @@ __global__ void __launch_bounds__(256) k_cfinish(CfinArgs a) {
     } else if (a.mix.C && a.mix.matrix) {
         for (int e = tid; e < C * C; e += 256) mixm[e] = a.mix.matrix[e];
     }
-    if (f.paired) {     // per-sample log-det: issued before the mixer phase, whose time hides the atomic's round trip
+    if (f.paired) {     // per-sample log-det: ONE atomic per workgroup (64 workgroups and more share a sample's accumulator: per-wave
+                        // atomics queued up behind one another and doubled the launch time), issued before the mixer phase,
+                        // whose time hides its round trip
         const long long tot = block_sum_ll<256>(ldq, red);
-        if (tid == 0) atomicAdd(a.acc + n, (unsigned long long)tot);
+        if (tid == 0 && tot != 0) atomicAdd(a.acc + n, (unsigned long long)tot);
     } else if (a.mix.C) {
         __syncthreads();
     }
@@ -930,7 +1089,7 @@ static bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
 // LDS: activation buffer + window planes + tables (rs0 | b0 | rs2 | b2 (at most hidden rows) | rs4 | goff)
 static size_t cnet_lds_bytes(const CnetGeo& g, int hidden) {
-    return (size_t)CN_HBUF + (size_t)2 * g.winplane * sizeof(_Float16) + ((size_t)4 * hidden + g.Mpad4 + g.G + 4) * sizeof(float);
+    return (size_t)CN_HBUF + (size_t)2 * g.winplane * sizeof(_Float16) + ((size_t)4 * hidden + g.Mpad4 + g.G + 4 + 36) * sizeof(float);
 }
 
 static bool cnet_geo(int Cin, int H, int W, int hidden, int Cout, int N, int pxt, CnetGeo* out) {
@@ -987,8 +1146,13 @@ size_t cnet_scratch_floats_per_sample(int H, int W, int Cout) {
 template <int HID, int MS, int UPW, int PXT>
 static int launch_cnet_inst(const CnetArgs& a, const CnetGeo& g, hipStream_t s) {
     const size_t lds = cnet_lds_bytes(g, HID);
-    (void)hipFuncSetAttribute((const void*)k_cnet<HID, MS, UPW, PXT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((k_cnet<HID, MS, UPW, PXT>), dim3(g.tiles, MS), dim3(512), lds, s, a, g);
+    if (a.pre_on) {
+        (void)hipFuncSetAttribute((const void*)k_cnet<HID, MS, UPW, PXT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((k_cnet<HID, MS, UPW, PXT, true>), dim3(g.tiles, MS), dim3(512), lds, s, a, g);
+    } else {
+        (void)hipFuncSetAttribute((const void*)k_cnet<HID, MS, UPW, PXT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((k_cnet<HID, MS, UPW, PXT, false>), dim3(g.tiles, MS), dim3(512), lds, s, a, g);
+    }
     GH_LAUNCH_CHECK("k_cnet");
     return GLOWHIP_OK;
 }
@@ -1020,6 +1184,7 @@ int launch_cnet_main(const CnetArgs& a, hipStream_t s, CnetPending* out) {
     const int upw = g.NU4 * g.KS > 8 ? 2 : 1;
     if (upw == 2 && a.hidden == 512 && ms == 1 && !use64 && !a.y_sh) ms = 2;
     while ((a.hidden / ms / 16) / g.KS < 1 && ms > 1) ms /= 2;
+    GH_REQUIRE(!a.pre_on || a.pre.MS == ms, "cnet: a chained launch needs the previous step's row split");
     int rc = GLOWHIP_EINVAL;
 #define GH_CN(hid, m, u, px) if (a.hidden == hid && ms == m && upw == u && g.pxt == px) rc = launch_cnet_inst<hid, m, u, px>(a, g, s);
     GH_CN(512, 1, 1, 128) GH_CN(512, 2, 1, 128) GH_CN(512, 4, 1, 128) GH_CN(256, 1, 1, 128) GH_CN(256, 2, 1, 128) GH_CN(256, 4, 1, 128)
@@ -1051,13 +1216,19 @@ int launch_cnet_finish(const CnetArgs& a, const CnetPending& p, hipStream_t s) {
     const int pxb = total_px < 32768 ? 16 : 64;      // small levels: 16 pixels per workgroup, so that the launch still covers the chip
     const size_t flds = ((size_t)C * pxb + (a.mix.C && a.mix.matrix ? (size_t)C * C : 0)) * sizeof(float);
     GH_REQUIRE(flds <= 64 * 1024, "cnet: finishing kernel LDS");
-    if (pxb == 16) {
-        if (flds > 32 * 1024) (void)hipFuncSetAttribute((const void*)k_cfinish<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds);
-        hipLaunchKernelGGL(k_cfinish<16>, dim3((unsigned)(total_px / 16)), dim3(256), flds, s, f);
-    } else {
-        if (flds > 32 * 1024) (void)hipFuncSetAttribute((const void*)k_cfinish<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds);
-        hipLaunchKernelGGL(k_cfinish<64>, dim3((unsigned)(total_px / 64)), dim3(256), flds, s, f);
+    const bool halos = p.NI == 1 && p.R < a.H;
+    bool launched = false;
+#define GH_CF(px, m, h)                                                                                                       \
+    if (!launched && pxb == px && p.MS == m && halos == h) {                                                                  \
+        if (flds > 32 * 1024)                                                                                                 \
+            (void)hipFuncSetAttribute((const void*)k_cfinish<px, m, h>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds); \
+        hipLaunchKernelGGL((k_cfinish<px, m, h>), dim3((unsigned)(total_px / px)), dim3(256), flds, s, f);                    \
+        launched = true;                                                                                                      \
     }
+    GH_CF(16, 1, false) GH_CF(16, 1, true) GH_CF(16, 2, false) GH_CF(16, 2, true) GH_CF(16, 4, false) GH_CF(16, 4, true)
+    GH_CF(64, 1, false) GH_CF(64, 1, true) GH_CF(64, 2, false) GH_CF(64, 2, true) GH_CF(64, 4, false) GH_CF(64, 4, true)
+#undef GH_CF
+    GH_REQUIRE(launched, "cnet: no finishing kernel for row split %d", p.MS);
     GH_LAUNCH_CHECK("k_cfinish");
     return GLOWHIP_OK;
 }
@@ -1075,8 +1246,8 @@ bool cnet_pre_supported(int Cin, int H, int W, int hidden, int Cout, int C) {
     for (int pxt : {128, 64}) {
         CnetGeo g;
         if (!cnet_geo(Cin, H, W, hidden, Cout, 0, pxt, &g)) continue;
-        const size_t nwin = (size_t)g.NI * g.Wpx;
-        if (((size_t)C * nwin + (size_t)C * C + (size_t)Cin * nwin + 32) * sizeof(float) > (size_t)CN_HBUF) return false;
+        const size_t kp = ((size_t)g.NI * (g.R + 2) * W + 63) / 64 * 64;      // upper bound of the in-image window pixels
+        if (((size_t)C * kp + (size_t)Cin * kp + (size_t)C * (C + 3) + 32) * sizeof(float) > (size_t)CN_HBUF) return false;
     }
     return true;
 }

@@ -23,11 +23,11 @@ torch.cuda.synchronize()
 buf = (ctypes.c_ulonglong * 64)()
 G.lib().glowhip_debug_read_stamps_cnet(buf)
 t = list(buf)
-names = {0: "start", 1: "window built", 2: "P1a done", 3: "barrier", 4: "P2a done", 5: "barrier", 6: "P1b done", 7: "barrier", 8: "P2b done",
+names = {0: "start", 22: "pre: set up", 23: "pre: coupled", 24: "pre: barrier", 25: "pre: mixed", 26: "pre: log-det summed", 1: "window built", 2: "P1a done", 3: "barrier", 4: "P2a done", 5: "barrier", 6: "P1b done", 7: "barrier", 8: "P2b done",
          9: "barrier", 10: "h2 epilogue", 11: "h2 load0 written", 12: "barrier", 13: "P3 load0 done", 14: "barrier", 15: "h2 load1 written",
          16: "barrier", 17: "P3 load1 done", 18: "barrier", 20: "T staged", 21: "end"}
 prev = t[0]
-for i in sorted(names):
+for i in sorted(names, key=lambda i: (t[i] if t[i] >= t[0] else 0, i)):
     if t[i] >= t[0] and t[i] != 0:
         print(f"{names[i]:20s} +{t[i] - prev:7d}   (t = {t[i] - t[0]:7d})")
         prev = t[i]

@@ -7,7 +7,7 @@
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f16v __attribute__((ext_vector_type(16)));
 
-template <bool GL, bool DS, int WAVES, int AHEAD = 2, bool DUMMY = false>
+template <bool GL, bool DS, int WAVES, int AHEAD = 2, bool DUMMY = false, bool SPREAD = false>
 __global__ void __launch_bounds__(WAVES * 64) k(const char* img, float* out, int ksteps, int reps, unsigned long long* cyc) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, kl = lane >> 5, ml = lane & 31;
@@ -34,7 +34,8 @@ __global__ void __launch_bounds__(WAVES * 64) k(const char* img, float* out, int
     for (int j = 0; j < 4; ++j) K0[j] = A[2][j];
     for (int j = 0; j < 4; ++j) { bh[j] = A[0][j]; bl[j] = A[1][j]; }
     auto kstep = [&](int s, const h8 (&use)[4], h8 (&fill)[4]) {
-        if (GL) { loadA(min(s + AHEAD, ksteps - 1), fill); __builtin_amdgcn_sched_barrier(0); }
+        const char* lp = ap + (long)min(s + AHEAD, ksteps - 1) * (2 * 512 * 16);
+        if (GL && !SPREAD) { loadA(min(s + AHEAD, ksteps - 1), fill); __builtin_amdgcn_sched_barrier(0); }
         if (DS) {
             const char* bs = bp + (long)(s & 15) * (2 * 128 * 16);
 #pragma unroll
@@ -43,22 +44,22 @@ __global__ void __launch_bounds__(WAVES * 64) k(const char* img, float* out, int
                 bl[j] = *reinterpret_cast<const h8*>(bs + j * 512 + 65536);
             }
         }
+        if (GL && SPREAD) { fill[0] = *reinterpret_cast<const h8*>(lp); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(use[0], bh[j], acc[j], 0, 0, 0);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i * 4 + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(DUMMY ? K0[i] : use[i], bh[j], acc[i * 4 + j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) acc[4 + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(use[1], bh[j], acc[4 + j], 0, 0, 0);
+        if (GL && SPREAD) { __builtin_amdgcn_sched_barrier(0); fill[1] = *reinterpret_cast<const h8*>(lp + 512); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(use[0], bl[j], acc[j], 0, 0, 0);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i * 4 + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(DUMMY ? K0[i] : use[i], bl[j], acc[i * 4 + j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) acc[4 + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(use[1], bl[j], acc[4 + j], 0, 0, 0);
+        if (GL && SPREAD) { __builtin_amdgcn_sched_barrier(0); fill[2] = *reinterpret_cast<const h8*>(lp + plane); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(use[2], bh[j], acc[j], 0, 0, 0);
+        if (GL && SPREAD) { __builtin_amdgcn_sched_barrier(0); fill[3] = *reinterpret_cast<const h8*>(lp + 512 + plane); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i * 4 + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(DUMMY ? K0[2 + i] : use[2 + i], bh[j], acc[i * 4 + j], 0, 0, 0);
-        if (DUMMY) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) sink = __builtin_bit_cast(h8, (us8)(__builtin_bit_cast(us8, sink) ^ __builtin_bit_cast(us8, use[i])));
-        }
+        for (int j = 0; j < 4; ++j) acc[4 + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(use[3], bh[j], acc[4 + j], 0, 0, 0);
     };
     unsigned long long t0 = __builtin_readcyclecounter();
     for (int r = 0; r < reps; ++r) {
@@ -97,25 +98,25 @@ __global__ void __launch_bounds__(WAVES * 64) k(const char* img, float* out, int
     if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) cyc[wid] = t1 - t0;
 }
 
-template <bool GL, bool DS, int WAVES, int AHEAD = 2, bool DUMMY = false>
+template <bool GL, bool DS, int WAVES, int AHEAD = 2, bool DUMMY = false, bool SPREAD = false>
 void run(const char* img) {
     float* out; unsigned long long* cyc;
     const int blocks = 256;
     hipMalloc(&out, 4 * blocks * WAVES * 64); hipMalloc(&cyc, 64);
     const int ksteps = 30, reps = 20;
-    hipFuncSetAttribute((const void*)k<GL, DS, WAVES, AHEAD, DUMMY>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    hipFuncSetAttribute((const void*)k<GL, DS, WAVES, AHEAD, DUMMY, SPREAD>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    k<GL, DS, WAVES, AHEAD, DUMMY><<<blocks, WAVES * 64, 128 * 1024>>>(img, out, ksteps, 2, cyc);
+    k<GL, DS, WAVES, AHEAD, DUMMY, SPREAD><<<blocks, WAVES * 64, 128 * 1024>>>(img, out, ksteps, 2, cyc);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    k<GL, DS, WAVES, AHEAD, DUMMY><<<blocks, WAVES * 64, 128 * 1024>>>(img, out, ksteps, reps, cyc);
+    k<GL, DS, WAVES, AHEAD, DUMMY, SPREAD><<<blocks, WAVES * 64, 128 * 1024>>>(img, out, ksteps, reps, cyc);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     unsigned long long c[8]; hipMemcpy(c, cyc, 64, hipMemcpyDeviceToHost);
     const double nm = 24.0 * ksteps * reps;       // MFMAs per wave
     const double ideal = nm * 32 * (WAVES / 4);   // cycles if the pipe never idles
     unsigned long long cmax = 0; for (int i = 0; i < WAVES; ++i) cmax = c[i] > cmax ? c[i] : cmax;
-    printf("dummy %d ahead %d global %d lds %d waves %d: %.3f ms, %.0f TFLOP/s, MFMA pipe busy %.2f (slowest wave), first wave %.1f / last %.1f ticks per own MFMA\n", (int)DUMMY, AHEAD, GL, DS, WAVES, ms,
+    printf("spread %d dummy %d ahead %d global %d lds %d waves %d: %.3f ms, %.0f TFLOP/s, MFMA pipe busy %.2f (slowest wave), first wave %.1f / last %.1f ticks per own MFMA\n", (int)SPREAD, (int)DUMMY, AHEAD, GL, DS, WAVES, ms,
            nm * 32768.0 * blocks * WAVES / ms / 1e9, ideal / cmax, c[0] / nm, c[WAVES - 1] / nm);
     hipFree(out); hipFree(cyc);
 }
@@ -130,9 +131,9 @@ int main() {
     run<true, false, 4>(img);
     run<false, true, 4>(img);
     run<true, true, 4>(img);
-    run<true, false, 8, 4>(img);
-    run<true, true, 8, 4>(img);
-    run<true, true, 4, 4>(img);
+    run<true, false, 8, 2, false, true>(img);
+    run<true, true, 8, 2, false, true>(img);
+    run<true, true, 4, 2, false, true>(img);
     run<true, false, 8, 1>(img);
     run<true, true, 8, 1>(img);
     run<true, true, 4, 1>(img);
