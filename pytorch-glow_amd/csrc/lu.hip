@@ -144,6 +144,150 @@ __device__ double lu_logdet_only(const float* __restrict__ w, int C, double* A) 
     return s_logdet2;
 }
 
+// log|det W| for matrices too large for LDS (128 < C): BLOCKED right-looking LU with partial pivoting, one workgroup per matrix.
+// A (C x C doubles) lives in an L2-resident scratch buffer; per panel of NB columns
+//   (a) the panel (all rows below the diagonal block, NB columns) is copied to LDS and factored there (pivot search, row swap,
+//       scale + rank-1 update: three barriers per column, LDS only),
+//   (b) its row swaps are applied to the columns right of the panel (a thread owns whole columns: no barrier),
+//   (c) column block by column block (CB columns): U12 = L11^-1 A12 by forward substitution (a thread per column, the result kept
+//       in LDS), then the trailing update A22 -= L21 U12 with 4 x 4 register tiles (L21 and U12 both read from LDS).
+// The unblocked version above walks the trailing matrix in global memory once per COLUMN with a 64-bit division per element:
+// 33 ms for config E's C = 384 matrices, half of that config's forward step.  This one reads / writes it once per PANEL.
+constexpr int LU_NB = 32, LU_CB = 64;
+__host__ __device__ inline size_t lu_blocked_lds_bytes(int C) {
+    return ((size_t)C * (LU_NB + 1) + (size_t)LU_NB * (LU_CB + 1)) * sizeof(double) + (LU_NB + 4) * sizeof(int);
+}
+constexpr int LU_BLOCKED_MAX_C = 448;    // panel of 448 rows: 118 KiB + 16.6 KiB U block
+
+__device__ double lu_logdet_blocked(const float* __restrict__ w, int C, double* __restrict__ A, double* lds) {
+    constexpr int NB = LU_NB, CB = LU_CB, PS = NB + 1, US = CB + 1;    // padded LDS row strides (doubles)
+    double* P = lds;                             // panel: [rows below k0][PS]
+    double* U = lds + (size_t)C * PS;            // U12 column block: [NB][US]
+    int* piv = reinterpret_cast<int*>(U + NB * US);   // [NB] pivot rows (relative to k0), then [1] scratch
+    __shared__ int s_p;
+    __shared__ double s_pv;
+    const int tid = threadIdx.x;
+    __syncthreads();
+    for (int e = tid; e < C * C; e += 256) A[e] = (double)w[e];
+    double logdet = 0.0;   // meaningful in thread 192
+    __syncthreads();
+    for (int k0 = 0; k0 < C; k0 += NB) {
+        const int nb = min(NB, C - k0), m = C - k0;
+        // (a) panel -> LDS, factor
+        for (int e = tid; e < m * nb; e += 256) {
+            const int i = e / nb, j = e - i * nb;
+            P[i * PS + j] = A[(long)(k0 + i) * C + k0 + j];
+        }
+        __syncthreads();
+        for (int j = 0; j < nb; ++j) {
+            if (tid < 64) {
+                double best = -1.0;
+                int bi = j;
+                for (int r = j + tid; r < m; r += 64) {
+                    const double v = fabs(P[r * PS + j]);
+                    if (v > best) { best = v; bi = r; }
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    const double ov = __shfl_down(best, o, 64);
+                    const int oi = __shfl_down(bi, o, 64);
+                    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+                }
+                if (tid == 0) { s_p = bi; s_pv = P[bi * PS + j]; piv[j] = bi; }
+            }
+            __syncthreads();
+            const int pr = s_p;
+            const double pv = s_pv;
+            if (tid == 192) logdet += log(fabs(pv));
+            if (pr != j && tid < nb) {           // swap rows j and pr of the panel (all nb columns: the left ones are the L part)
+                const double t = P[pr * PS + tid];
+                P[pr * PS + tid] = P[j * PS + tid];
+                P[j * PS + tid] = t;
+            }
+            __syncthreads();
+            // rows below the diagonal: multiplier, then the rank-1 update of the panel's remaining columns (a thread owns a row)
+            for (int r = j + 1 + tid; r < m; r += 256) {
+                const double l = P[r * PS + j] / pv;
+                P[r * PS + j] = l;
+                for (int c = j + 1; c < nb; ++c) P[r * PS + c] = fma(-l, P[j * PS + c], P[r * PS + c]);
+            }
+            __syncthreads();
+        }
+        const int n2 = C - k0 - nb;              // columns right of the panel
+        if (n2 <= 0) break;
+        // (b) the panel's row swaps on the right part, in order; a thread owns its columns
+        for (int c = k0 + nb + tid; c < C; c += 256) {
+            for (int j = 0; j < nb; ++j) {
+                const int pr = piv[j];
+                if (pr != j) {
+                    const double t = A[(long)(k0 + pr) * C + c];
+                    A[(long)(k0 + pr) * C + c] = A[(long)(k0 + j) * C + c];
+                    A[(long)(k0 + j) * C + c] = t;
+                }
+            }
+        }
+        __syncthreads();
+        // (c) column blocks of the right part
+        const int m2 = m - nb;                   // rows below the diagonal block
+        for (int c0 = k0 + nb; c0 < C; c0 += CB) {
+            const int cb = min(CB, C - c0);
+            // U12 block: forward substitution with the unit lower triangle L11 (panel rows 0..nb-1)
+            if (tid < cb) {
+                double x[NB];
+#pragma unroll
+                for (int i = 0; i < NB; ++i) x[i] = i < nb ? A[(long)(k0 + i) * C + c0 + tid] : 0.0;
+#pragma unroll
+                for (int i = 1; i < NB; ++i) {
+                    if (i < nb) {
+                        double v = x[i];
+#pragma unroll
+                        for (int t = 0; t < i; ++t) v = fma(-P[i * PS + t], x[t], v);
+                        x[i] = v;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < NB; ++i) U[i * US + tid] = x[i];
+            }
+            __syncthreads();
+            // trailing update of this column block: 4 x 4 register tiles
+            const int tr = (m2 + 3) / 4, tc = (cb + 3) / 4;
+            for (int tix = tid; tix < tr * tc; tix += 256) {
+                const int ti = tix / tc, tj = tix - ti * tc;
+                const int r0 = nb + ti * 4, cc0 = tj * 4;           // panel-relative row, block-relative column
+                double acc[4][4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+                for (int t = 0; t < nb; ++t) {
+                    double l[4], u[4];
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) l[a] = P[min(r0 + a, m - 1) * PS + t];
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) u[b] = U[t * US + min(cc0 + b, cb - 1)];
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) acc[a][b] = fma(l[a], u[b], acc[a][b]);
+                }
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+                        if (r0 + a < m && cc0 + b < cb) {
+                            const long idx = (long)(k0 + r0 + a) * C + c0 + cc0 + b;
+                            A[idx] -= acc[a][b];
+                        }
+            }
+            __syncthreads();
+        }
+    }
+    __shared__ double s_logdet3;
+    if (tid == 192) s_logdet3 = logdet;
+    __syncthreads();
+    return s_logdet3;
+}
+
 template <bool USE_LDS>
 __global__ void __launch_bounds__(256) k_invconv_prepare(const float* __restrict__ w, int C, float* __restrict__ winv,
                                                          float* __restrict__ logabsdet, double* __restrict__ scratch) {
@@ -163,6 +307,8 @@ __global__ void __launch_bounds__(256) k_step_prepare_batched(const StepPrepJob*
         if (want_inverse) {
             double* A = j.C <= LU_LDS_MAX_C ? lds_aug : (double*)(packed + j.scratch_off);
             lad = lu_gauss_jordan(j.w, j.C, (float*)(packed + j.winv_off), A);
+        } else if (j.C > LU_LDS_ONLY_MAX_C && j.C <= LU_BLOCKED_MAX_C) {   // forward only, too large for LDS: blocked LU
+            lad = lu_logdet_blocked(j.w, j.C, (double*)(packed + j.scratch_off), lds_aug);
         } else {      // forward only: log|det W| without the inverse (C^3/3 instead of 2 C^3 element updates)
             double* A = j.C <= LU_LDS_ONLY_MAX_C ? lds_aug : (double*)(packed + j.scratch_off);
             lad = lu_logdet_only(j.w, j.C, A);
@@ -199,8 +345,11 @@ int launch_step_prepare_batched(const StepPrepJob* jobs_dev, int n, int max_lds_
         return GLOWHIP_OK;
     }
     size_t lds = invconv_scratch_bytes(max_lds_c > 0 ? max_lds_c : 1);
-    if (!want_inverse && max_c > LU_LDS_MAX_C)      // the log-det-only factorisation of matrices up to 128 x 128 runs in LDS
+    if (!want_inverse && max_c > LU_LDS_MAX_C) {    // the log-det-only factorisation of matrices up to 128 x 128 runs in LDS,
+                                                    // the blocked one above that keeps a panel + a U block there
         lds = std::max(lds, (size_t)std::min(max_c, LU_LDS_ONLY_MAX_C) * std::min(max_c, LU_LDS_ONLY_MAX_C) * sizeof(double));
+        if (max_c > LU_LDS_ONLY_MAX_C) lds = std::max(lds, lu_blocked_lds_bytes(std::min(max_c, LU_BLOCKED_MAX_C)));
+    }
     if (lds > 32 * 1024)
         (void)hipFuncSetAttribute((const void*)k_step_prepare_batched, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k_step_prepare_batched, dim3(n), dim3(256), lds, s, jobs_dev, (char*)packed, want_inverse);
