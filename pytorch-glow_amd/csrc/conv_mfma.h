@@ -10,8 +10,11 @@ bool conv_mfma_wide_supported(int Cin, int H, int W, int Cout, int ksize);
 size_t conv_mfma_wide_packed_bytes(int Cin, int Cout, int ksize);
 int conv_mfma_wide_pack(const float* w, int Cin, int Cout, int ksize, float* wt, hipStream_t s);
 // post_bias / post_scale may be NULL (0 / 1) and relu = 0 for a plain GEMM (input-gradient use) -- 1x1 LDS-DMA path only
+// splitk_scratch (optional, splitk_floats floats, must not overlap x or y): lets a launch with few output tiles and a long
+// reduction split the reduction over workgroups (partial sums there, summed in a fixed order by a second small kernel)
 int launch_conv_mfma_wide(const float* x, long x_bs, const float* wt, const float* post_bias, const float* post_scale,
-                          float* y, int N, int Cin, int H, int W, int Cout, int ksize, hipStream_t s, int relu = 1);
+                          float* y, int N, int Cin, int H, int W, int Cout, int ksize, hipStream_t s, int relu = 1,
+                          float* splitk_scratch = nullptr, size_t splitk_floats = 0);
 
 void conv_mfma_wide_disable_glds(int off);  // testing hook: 1 = use the register-staged k_conv_wide for 1x1 too
 

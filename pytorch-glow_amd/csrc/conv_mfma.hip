@@ -29,7 +29,10 @@ template <int KS, int BM, int BN, int BK>
 __global__ void __launch_bounds__(256)
 k_conv_wide(const float* __restrict__ X, long x_bs, const float* __restrict__ Wt, const float* __restrict__ bias,
             const float* __restrict__ scale, float* __restrict__ Y, int N, int Cin, int H, int W, int M, int K,
-            int Kpad, int relu) {
+            int Kpad, int relu, float* __restrict__ Ypart) {
+    // gridDim.y > 1: split-K -- workgroup (x, y) reduces k-tiles [y, y+1) * nkt / gridDim.y and writes its RAW partial sums to
+    // Ypart[y] (k_splitk_finish adds them up in a fixed order and applies the epilogue).  For the deep levels of the large
+    // configurations: 16 images x 4 x 4 pixels x 384 channels is 24 output tiles for a reduction of 4 608.
     constexpr int WM = BM / 2, WN = BN / 2;      // per-wave tile
     constexpr int TM = WM / 32, TN = WN / 32;    // 32x32 MFMA tiles per wave
     constexpr int A_F4 = BM / 4, B_F4 = BN / 4;  // float4 per tile row
@@ -106,13 +109,14 @@ k_conv_wide(const float* __restrict__ X, long x_bs, const float* __restrict__ Wt
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nkt = Kpad / BK;
-    load_tile(0);
+    const int nkt_all = Kpad / BK;
+    const int kt0 = (int)((long)blockIdx.y * nkt_all / gridDim.y), nkt = (int)((long)(blockIdx.y + 1) * nkt_all / gridDim.y);
+    load_tile(kt0);
     store_tile(0);
     __syncthreads();
     const int kl = lane >> 5, ml = lane & 31;
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int buf = kt & 1;
+    for (int kt = kt0; kt < nkt; ++kt) {
+        const int buf = (kt - kt0) & 1;
         if (kt + 1 < nkt) load_tile(kt + 1);  // HBM/L2 latency hidden under this tile's MFMAs
         // fragment reads are software-pipelined one k-step ahead of the MFMAs that consume them
         float a[2][TM], b[2][TN];
@@ -166,11 +170,12 @@ k_conv_wide(const float* __restrict__ X, long x_bs, const float* __restrict__ Wt
         for (int r = 0; r < 16; ++r) {
             const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl;
             const int o = tile_m * BM + wr * WM + row;
-            const float bo = bias ? bias[o] : 0.f, so = scale ? scale[o] : 1.f;
+            const bool part = gridDim.y > 1;
+            const float bo = (bias && !part) ? bias[o] : 0.f, so = (scale && !part) ? scale[o] : 1.f;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                const float v = (acc[i][j][r] + bo) * so;
-                stage[row * WN + j * 32 + ml] = relu ? relu_(v) : v;
+                const float v = part ? acc[i][j][r] : (acc[i][j][r] + bo) * so;
+                stage[row * WN + j * 32 + ml] = (relu && !part) ? relu_(v) : v;
             }
         }
     }
@@ -181,7 +186,7 @@ k_conv_wide(const float* __restrict__ X, long x_bs, const float* __restrict__ Wt
     if (gp < total_px) {
         const long n = gp / HW;
         const int p = (int)(gp - n * HW);
-        float* yn = Y + n * (long)M * HW + p;
+        float* yn = (gridDim.y > 1 ? Ypart + (long)blockIdx.y * N * M * HW : Y) + n * (long)M * HW + p;
 #pragma unroll
         for (int it = 0; it < WM / ROWS_PER_IT; ++it) {
             const int row = it * ROWS_PER_IT + rrow;
@@ -326,11 +331,12 @@ k_gemm_glds(const float* __restrict__ X, long x_bs, const float* __restrict__ Wt
         for (int r = 0; r < 16; ++r) {
             const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl;
             const int o = tile_m * BM + wr * WM + row;
-            const float bo = bias ? bias[o] : 0.f, so = scale ? scale[o] : 1.f;
+            const bool part = gridDim.y > 1;
+            const float bo = (bias && !part) ? bias[o] : 0.f, so = (scale && !part) ? scale[o] : 1.f;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                const float v = (acc[i][j][r] + bo) * so;
-                stage[row * WN + j * 32 + ml] = relu ? relu_(v) : v;
+                const float v = part ? acc[i][j][r] : (acc[i][j][r] + bo) * so;
+                stage[row * WN + j * 32 + ml] = (relu && !part) ? relu_(v) : v;
             }
         }
     }
@@ -391,20 +397,50 @@ int conv_mfma_wide_pack(const float* w, int Cin, int Cout, int ksize, float* wt,
     return GLOWHIP_OK;
 }
 
+// y[n][o][p] = act((sum_s part[s][n][o][p] + bias[o]) * scale[o]), s ascending (deterministic)
+__global__ void __launch_bounds__(256) k_splitk_finish(const float* __restrict__ part, int S, long per, const float* __restrict__ bias,
+                                                       const float* __restrict__ scale, int relu, float* __restrict__ Y, int M, int HW) {
+    const long i4 = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i4 >= per) return;
+    f32x4 v = *reinterpret_cast<const f32x4*>(part + i4);
+    for (int sidx = 1; sidx < S; ++sidx) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(part + (long)sidx * per + i4);
+        v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
+    }
+    const int o = (int)((i4 / HW) % M);                    // HW % 4 == 0: the four values share the channel
+    const float bo = bias ? bias[o] : 0.f, so = scale ? scale[o] : 1.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { v[q] = (v[q] + bo) * so; if (relu) v[q] = relu_(v[q]); }
+    *reinterpret_cast<f32x4*>(Y + i4) = v;
+}
+
 template <int KS, int BMN>
 static int launch_wide_cfg(const float* x, long x_bs, const float* wt, const float* bias, const float* scale, float* y,
-                           int N, int Cin, int H, int W, int Cout, hipStream_t s, int relu) {
+                           int N, int Cin, int H, int W, int Cout, hipStream_t s, int relu, float* scratch, size_t scratch_floats) {
     const long total_px = (long)N * H * W;
     const int tiles = (Cout / BMN) * (int)((total_px + BMN - 1) / BMN);
     const int K = Cin * KS * KS;
-    hipLaunchKernelGGL((k_conv_wide<KS, BMN, BMN, 32>), dim3(tiles), dim3(256), 0, s, x, x_bs, wt, bias, scale, y, N,
-                       Cin, H, W, Cout, K, wide_kpad(Cin, KS), relu);
+    const int nkt = wide_kpad(Cin, KS) / 32;
+    // split-K when the output tiles alone leave most of the chip idle and the reduction is long enough to share
+    int S = 1;
+    const long per = (long)N * Cout * H * W;
+    if (scratch && tiles < 96 && nkt >= 16) {
+        S = std::min(std::min(16, 320 / tiles), nkt / 4);
+        while (S > 1 && (size_t)S * per > scratch_floats) --S;
+    }
+    hipLaunchKernelGGL((k_conv_wide<KS, BMN, BMN, 32>), dim3(tiles, S), dim3(256), 0, s, x, x_bs, wt, bias, scale, y, N,
+                       Cin, H, W, Cout, K, wide_kpad(Cin, KS), relu, scratch);
     GH_LAUNCH_CHECK("k_conv_wide");
+    if (S > 1) {
+        hipLaunchKernelGGL(k_splitk_finish, dim3(cdiv(per / 4, 256)), dim3(256), 0, s, scratch, S, per, bias, scale, relu, y, Cout, H * W);
+        GH_LAUNCH_CHECK("k_splitk_finish");
+    }
     return GLOWHIP_OK;
 }
 
 int launch_conv_mfma_wide(const float* x, long x_bs, const float* wt, const float* post_bias, const float* post_scale,
-                          float* y, int N, int Cin, int H, int W, int Cout, int ksize, hipStream_t s, int relu) {
+                          float* y, int N, int Cin, int H, int W, int Cout, int ksize, hipStream_t s, int relu,
+                          float* splitk_scratch, size_t splitk_floats) {
     GH_REQUIRE(conv_mfma_wide_supported(Cin, H, W, Cout, ksize), "conv_mfma_wide: unsupported shape");
     if (N == 0) return GLOWHIP_OK;
     const int t = pick_wide_tile(Cout, (long)N * H * W);
@@ -421,11 +457,11 @@ int launch_conv_mfma_wide(const float* x, long x_bs, const float* wt, const floa
         return GLOWHIP_OK;
     }
     if (ksize == 1) {
-        if (t == 128) return launch_wide_cfg<1, 128>(x, x_bs, wt, post_bias, post_scale, y, N, Cin, H, W, Cout, s, relu);
-        return launch_wide_cfg<1, 64>(x, x_bs, wt, post_bias, post_scale, y, N, Cin, H, W, Cout, s, relu);
+        if (t == 128) return launch_wide_cfg<1, 128>(x, x_bs, wt, post_bias, post_scale, y, N, Cin, H, W, Cout, s, relu, splitk_scratch, splitk_floats);
+        return launch_wide_cfg<1, 64>(x, x_bs, wt, post_bias, post_scale, y, N, Cin, H, W, Cout, s, relu, splitk_scratch, splitk_floats);
     }
-    if (t == 128) return launch_wide_cfg<3, 128>(x, x_bs, wt, post_bias, post_scale, y, N, Cin, H, W, Cout, s, relu);
-    return launch_wide_cfg<3, 64>(x, x_bs, wt, post_bias, post_scale, y, N, Cin, H, W, Cout, s, relu);
+    if (t == 128) return launch_wide_cfg<3, 128>(x, x_bs, wt, post_bias, post_scale, y, N, Cin, H, W, Cout, s, relu, splitk_scratch, splitk_floats);
+    return launch_wide_cfg<3, 64>(x, x_bs, wt, post_bias, post_scale, y, N, Cin, H, W, Cout, s, relu, splitk_scratch, splitk_floats);
 }
 
 // ================================================================================================

@@ -171,7 +171,7 @@ static int run_coupling(glowhip_plan* P, const LayerPlan& L, const void* packed,
     } else if (L.mfma_first) {
         count_launch(P, "k_conv_wide_f32");
         GH_TRY(launch_conv_mfma_wide(x1, x1_bs, at<float>(packed, L.f0_wt), d.f0_an_bias, at<float>(packed, L.f0_scale),
-                                     w.h1, N, Ch, d.H, d.W, hid, 3, s));
+                                     w.h1, N, Ch, d.H, d.W, hid, 3, s, 1, w.h2, (size_t)N * P->max_hidden));
     } else {
         ConvArgs c{x1, x1_bs, d.f0_w, nullptr, d.f0_an_bias, nullptr, at<float>(packed, L.f0_scale), 1, w.h1,
                    N, Ch, d.H, d.W, hid, 3};
@@ -228,8 +228,11 @@ static int run_coupling(glowhip_plan* P, const LayerPlan& L, const void* packed,
     } else {
         if (L.wide_last && !use_sh_tail) {     // (conv + bias) * exp(3 logs) on the fp32 MFMA implicit-GEMM kernel
             count_launch(P, "k_conv_wide_f32");
+            // split-K partial sums go behind the output in the same (level-1 sized) buffer
+            const size_t out_f = (size_t)N * L.Cout * HW, h1_f = (size_t)N * P->max_hidden;
             GH_TRY(launch_conv_mfma_wide(w.h2, (long)hid * HW, at<float>(packed, L.f4_wt), d.f4_bias, at<float>(packed, L.f4_scale),
-                                         w.h1, N, hid, d.H, d.W, L.Cout, 3, s, 0));
+                                         w.h1, N, hid, d.H, d.W, L.Cout, 3, s, 0, h1_f > out_f ? w.h1 + out_f : nullptr,
+                                         h1_f > out_f ? h1_f - out_f : 0));
         } else {
             ConvArgs c{w.h2, (long)hid * HW, d.f4_w, d.f4_bias, nullptr, nullptr, at<float>(packed, L.f4_scale), 0, w.h1,
                        N, hid, d.H, d.W, L.Cout, 3};
@@ -774,7 +777,6 @@ int glowhip_plan_pack(glowhip_plan* plan, void* packed, size_t packed_bytes, glo
 int glowhip_plan_pack_for(glowhip_plan* plan, void* packed, size_t packed_bytes, int use, glowhip_stream_t stream) {
     GH_REQUIRE(plan && packed, "plan_pack: null argument");
     GH_REQUIRE(use & (GLOWHIP_PACK_INFERENCE | GLOWHIP_PACK_TRAINING), "plan_pack: empty use mask");
-    const int orig_use = use;
     // with a kernel family switched off through the debug hook the other family's images are needed after all
     // use bit 8 (internal): the round-1 split-half images of layers that normally run k_cnet -- needed only with cnet switched off
     if (g_sh_disabled || g_sh_tail_disabled || g_sh_first_disabled) use = GLOWHIP_PACK_INFERENCE | GLOWHIP_PACK_TRAINING | 8;
