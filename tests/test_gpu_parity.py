@@ -452,6 +452,19 @@ def test_mfma_flowstep_vs_oracle(c, h, w, hidden, coup, n):
     close(xi, xr, 5e-5, what="rev x"); ld_close(ldi, ldxr)
 
 
+@pytest.mark.parametrize("c", [132, 200, 448, 452])
+def test_invconv_logdet_blocked_lu(c):
+    """log|det W| of invconv matrices too large for LDS: the blocked LU (32-column panels; csrc/lu.hip lu_logdet_blocked) takes
+    128 < C <= 448 on the forward-only pack -- C = 132 and 200 end on a partial panel, 448 is the largest it takes, 452 falls to
+    the unblocked factorisation -- checked against the oracle's FlowStep (network/module.py:356-357) on a 4x4 map."""
+    st, sd = _rand_step(c, 64, "additive", seed=c)
+    x = torch.randn(2, c, 4, 4, generator=torch.Generator().manual_seed(1))
+    ld = torch.zeros(2)
+    z, ldz = st(dev(x), dev(ld))                       # encode: packs for inference only -> log-det-only factorisation
+    zr, ldr = O.flowstep(x, ld, sd, "", "invconv", "additive")
+    close(z, zr, 5e-5, what="fwd z"); ld_close(ldz, ldr)
+
+
 @pytest.mark.parametrize("c,h,w,n", [(12, 32, 32, 3), (24, 16, 16, 2), (48, 8, 8, 5)])
 def test_mfma_split2d_vs_oracle(c, h, w, n):
     g = torch.Generator().manual_seed(c)
