@@ -130,11 +130,14 @@ __device__ double lu_logdet_only(const float* __restrict__ w, int C, double* A) 
             A[r * C + k] = akk / piv;
         }
         __syncthreads();
-        // trailing update: A[r][c] -= l[r] * A[k][c], r, c > k; a thread walks one row segment with stride 256 over (r, c)
-        const long nel = (long)rem * rem;
-        for (long e = tid; e < nel; e += 256) {
-            const int r = k + 1 + (int)(e / rem), c = k + 1 + (int)(e - (long)(e / rem) * rem);
-            A[r * C + c] = fma(-A[r * C + k], A[k * C + c], A[r * C + c]);
+        // trailing update: A[r][c] -= l[r] * A[k][c], r, c > k; threads as a 16 x 16 grid over (r, c) -- no index division (a
+        // flat index cost a 64-bit division per element, more than the update itself)
+        {
+            const int tx = tid & 15, ty = tid >> 4;
+            for (int r = k + 1 + ty; r < C; r += 16) {
+                const double l = A[r * C + k];
+                for (int c = k + 1 + tx; c < C; c += 16) A[r * C + c] = fma(-l, A[k * C + c], A[r * C + c]);
+            }
         }
         __syncthreads();
     }

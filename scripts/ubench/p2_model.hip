@@ -7,9 +7,10 @@
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f16v __attribute__((ext_vector_type(16)));
 
-template <bool GL, bool DS, int WAVES, int AHEAD = 2, bool DUMMY = false, bool SPREAD = false>
+template <bool GL, bool DS, int WAVES, int AHEAD = 2, bool DUMMY = false, bool SPREAD = false, bool DMA = false>
 __global__ void __launch_bounds__(WAVES * 64) k(const char* img, float* out, int ksteps, int reps, unsigned long long* cyc) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
+    char* dma = lds + 32768 + (threadIdx.x >> 6) * 12288;   // per-wave ring of three 4 KB slots (overlaps the B area: timing only)
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, kl = lane >> 5, ml = lane & 31;
     for (int e = threadIdx.x; e < 128 * 1024 / 4; e += WAVES * 64) reinterpret_cast<float*>(lds)[e] = 0.001f * e;
     __syncthreads();
@@ -35,7 +36,22 @@ __global__ void __launch_bounds__(WAVES * 64) k(const char* img, float* out, int
     for (int j = 0; j < 4; ++j) { bh[j] = A[0][j]; bl[j] = A[1][j]; }
     auto kstep = [&](int s, const h8 (&use)[4], h8 (&fill)[4]) {
         const char* lp = ap + (long)min(s + AHEAD, ksteps - 1) * (2 * 512 * 16);
-        if (GL && !SPREAD) { loadA(min(s + AHEAD, ksteps - 1), fill); __builtin_amdgcn_sched_barrier(0); }
+        if (GL && DMA) {
+            // request k-step s + 2 into ring slot (s + 2) % 3 of this wave's private LDS area, then wait for k-step s and read it
+            const char* lp2 = ap - ((long)kl * 512 + ml) * 16 + (long)min(s + 2, ksteps - 1) * (2 * 512 * 16);   // wave base (lane offset added by the DMA)
+            char* slot = dma + ((s + 2) % 3) * 4096;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const char* src = lp2 + (q & 1) * 512 + (q >> 1) * plane + ((long)kl * 512 + ml) * 16;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(slot + q * 1024), 16, 0, 0);
+            }
+            __builtin_amdgcn_s_waitcnt(0x0f70 | 8);      // vmcnt(8): the four loads of k-step s have landed (two younger groups in flight)
+            const char* rs = dma + (s % 3) * 4096 + lane * 16;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) fill[q] = *reinterpret_cast<const h8*>(rs + q * 1024);
+        }
+        if (GL && !SPREAD && !DMA) { loadA(min(s + AHEAD, ksteps - 1), fill); __builtin_amdgcn_sched_barrier(0); }
         if (DS) {
             const char* bs = bp + (long)(s & 15) * (2 * 128 * 16);
 #pragma unroll
@@ -46,25 +62,32 @@ __global__ void __launch_bounds__(WAVES * 64) k(const char* img, float* out, int
         }
         if (GL && SPREAD) { fill[0] = *reinterpret_cast<const h8*>(lp); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(use[0], bh[j], acc[j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(DMA ? fill[0] : use[0], bh[j], acc[j], 0, 0, 0);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[4 + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(use[1], bh[j], acc[4 + j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) acc[4 + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(DMA ? fill[1] : use[1], bh[j], acc[4 + j], 0, 0, 0);
         if (GL && SPREAD) { __builtin_amdgcn_sched_barrier(0); fill[1] = *reinterpret_cast<const h8*>(lp + 512); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(use[0], bl[j], acc[j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(DMA ? fill[0] : use[0], bl[j], acc[j], 0, 0, 0);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[4 + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(use[1], bl[j], acc[4 + j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) acc[4 + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(DMA ? fill[1] : use[1], bl[j], acc[4 + j], 0, 0, 0);
         if (GL && SPREAD) { __builtin_amdgcn_sched_barrier(0); fill[2] = *reinterpret_cast<const h8*>(lp + plane); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(use[2], bh[j], acc[j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(DMA ? fill[2] : use[2], bh[j], acc[j], 0, 0, 0);
         if (GL && SPREAD) { __builtin_amdgcn_sched_barrier(0); fill[3] = *reinterpret_cast<const h8*>(lp + 512 + plane); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[4 + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(use[3], bh[j], acc[4 + j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) acc[4 + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(DMA ? fill[3] : use[3], bh[j], acc[4 + j], 0, 0, 0);
     };
     unsigned long long t0 = __builtin_readcyclecounter();
     for (int r = 0; r < reps; ++r) {
         if (AHEAD == 2) {
-            if (GL) { loadA(0, A[0]); loadA(1, A[1]); }
+            if (GL && !DMA) { loadA(0, A[0]); loadA(1, A[1]); }
+            if (GL && DMA) {
+                for (int g2 = 0; g2 < 2; ++g2)
+                    for (int q = 0; q < 4; ++q) {
+                        const char* src = ap + (long)g2 * (2 * 512 * 16) + (q & 1) * 512 + (q >> 1) * plane;
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(dma + g2 * 4096 + q * 1024), 16, 0, 0);
+                    }
+            }
 #pragma unroll 1
             for (int s = 0; s + 3 <= ksteps; s += 3) {
                 kstep(s, A[0], A[2]);
@@ -98,25 +121,25 @@ __global__ void __launch_bounds__(WAVES * 64) k(const char* img, float* out, int
     if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) cyc[wid] = t1 - t0;
 }
 
-template <bool GL, bool DS, int WAVES, int AHEAD = 2, bool DUMMY = false, bool SPREAD = false>
+template <bool GL, bool DS, int WAVES, int AHEAD = 2, bool DUMMY = false, bool SPREAD = false, bool DMA = false>
 void run(const char* img) {
     float* out; unsigned long long* cyc;
     const int blocks = 256;
     hipMalloc(&out, 4 * blocks * WAVES * 64); hipMalloc(&cyc, 64);
     const int ksteps = 30, reps = 20;
-    hipFuncSetAttribute((const void*)k<GL, DS, WAVES, AHEAD, DUMMY, SPREAD>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    hipFuncSetAttribute((const void*)k<GL, DS, WAVES, AHEAD, DUMMY, SPREAD, DMA>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    k<GL, DS, WAVES, AHEAD, DUMMY, SPREAD><<<blocks, WAVES * 64, 128 * 1024>>>(img, out, ksteps, 2, cyc);
+    k<GL, DS, WAVES, AHEAD, DUMMY, SPREAD, DMA><<<blocks, WAVES * 64, 128 * 1024>>>(img, out, ksteps, 2, cyc);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    k<GL, DS, WAVES, AHEAD, DUMMY, SPREAD><<<blocks, WAVES * 64, 128 * 1024>>>(img, out, ksteps, reps, cyc);
+    k<GL, DS, WAVES, AHEAD, DUMMY, SPREAD, DMA><<<blocks, WAVES * 64, 128 * 1024>>>(img, out, ksteps, reps, cyc);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     unsigned long long c[8]; hipMemcpy(c, cyc, 64, hipMemcpyDeviceToHost);
     const double nm = 24.0 * ksteps * reps;       // MFMAs per wave
     const double ideal = nm * 32 * (WAVES / 4);   // cycles if the pipe never idles
     unsigned long long cmax = 0; for (int i = 0; i < WAVES; ++i) cmax = c[i] > cmax ? c[i] : cmax;
-    printf("spread %d dummy %d ahead %d global %d lds %d waves %d: %.3f ms, %.0f TFLOP/s, MFMA pipe busy %.2f (slowest wave), first wave %.1f / last %.1f ticks per own MFMA\n", (int)SPREAD, (int)DUMMY, AHEAD, GL, DS, WAVES, ms,
+    printf("dma %d spread %d dummy %d ahead %d global %d lds %d waves %d: %.3f ms, %.0f TFLOP/s, MFMA pipe busy %.2f (slowest wave), first wave %.1f / last %.1f ticks per own MFMA\n", (int)DMA, (int)SPREAD, (int)DUMMY, AHEAD, GL, DS, WAVES, ms,
            nm * 32768.0 * blocks * WAVES / ms / 1e9, ideal / cmax, c[0] / nm, c[WAVES - 1] / nm);
     hipFree(out); hipFree(cyc);
 }
@@ -131,9 +154,9 @@ int main() {
     run<true, false, 4>(img);
     run<false, true, 4>(img);
     run<true, true, 4>(img);
-    run<true, false, 8, 2, false, true>(img);
-    run<true, true, 8, 2, false, true>(img);
-    run<true, true, 4, 2, false, true>(img);
+    run<true, false, 8, 2, false, false, true>(img);
+    run<true, true, 8, 2, false, false, true>(img);
+    run<true, true, 4, 2, false, false, true>(img);
     run<true, false, 8, 1>(img);
     run<true, true, 8, 1>(img);
     run<true, true, 4, 1>(img);
