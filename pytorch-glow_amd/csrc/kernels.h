@@ -88,7 +88,9 @@ struct RepackJob {
     int transposed;              // source is the FORWARD weight (Cin,Cout,3,3) of which this is the input-gradient conv:
                                  // element (o, ci, tap) = w[ci][o][8 - tap]
 };
-int launch_pack_batched(const ScaleJob* sj_dev, int n_scale, const RepackJob* rj_dev, int n_repack, void* packed,
+// rj_dev: the repack jobs SORTED by kind group (legacy kinds | SH2_GEMM | SH2_FIRST | SH2_TAIL), n_kind[4] their counts;
+// tail_blocks: workgroups per SH2_TAIL job (8 output channels each)
+int launch_pack_batched(const ScaleJob* sj_dev, int n_scale, const RepackJob* rj_dev, const int* n_kind, int tail_blocks, void* packed,
                         hipStream_t s);
 
 // ---------------------------------------------------------------- conv_direct.hip

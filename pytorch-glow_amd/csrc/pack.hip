@@ -397,20 +397,27 @@ __global__ void __launch_bounds__(256) k_repack_sh2_batched(const RepackJob* __r
     else repack_sh2_tail(j, packed);
 }
 
-int launch_pack_batched(const ScaleJob* sj_dev, int n_scale, const RepackJob* rj_dev, int n_repack, void* packed,
+int launch_pack_batched(const ScaleJob* sj_dev, int n_scale, const RepackJob* rj_dev, const int* n_kind, int tail_blocks, void* packed,
                         hipStream_t s) {
     if (n_scale > 0) {
         hipLaunchKernelGGL(k_pack_scales_batched, dim3(2, n_scale), dim3(256), 0, s, sj_dev, (char*)packed);
         GH_LAUNCH_CHECK("k_pack_scales_batched");
     }
-    if (n_repack > 0) {
-        hipLaunchKernelGGL(k_repack_batched, dim3(64, n_repack), dim3(256), 0, s, rj_dev, (char*)packed);
+    // the jobs are sorted by kind (legacy | SH2 GEMM | SH2 FIRST | SH2 TAIL): every kernel gets exactly its own jobs -- a grid over
+    // ALL jobs with an early exit per foreign job cost the f.4 image kernel 4 300 empty workgroups at two per CU (its registers)
+    const RepackJob* rj = rj_dev;
+    if (n_kind[0] > 0) {
+        hipLaunchKernelGGL(k_repack_batched, dim3(64, n_kind[0]), dim3(256), 0, s, rj, (char*)packed);
         GH_LAUNCH_CHECK("k_repack_batched");
-        hipLaunchKernelGGL(k_repack_sh2_batched<REPACK_SH2_GEMM>, dim3(16, n_repack), dim3(256), 0, s, rj_dev, (char*)packed);
-        hipLaunchKernelGGL(k_repack_sh2_batched<REPACK_SH2_FIRST>, dim3(2, n_repack), dim3(256), 0, s, rj_dev, (char*)packed);
-        hipLaunchKernelGGL(k_repack_sh2_batched<REPACK_SH2_TAIL>, dim3(16, n_repack), dim3(256), 0, s, rj_dev, (char*)packed);
-        GH_LAUNCH_CHECK("k_repack_sh2_batched");
     }
+    rj += n_kind[0];
+    if (n_kind[1] > 0) hipLaunchKernelGGL(k_repack_sh2_batched<REPACK_SH2_GEMM>, dim3(16, n_kind[1]), dim3(256), 0, s, rj, (char*)packed);
+    rj += n_kind[1];
+    if (n_kind[2] > 0) hipLaunchKernelGGL(k_repack_sh2_batched<REPACK_SH2_FIRST>, dim3(2, n_kind[2]), dim3(256), 0, s, rj, (char*)packed);
+    rj += n_kind[2];
+    if (n_kind[3] > 0)
+        hipLaunchKernelGGL(k_repack_sh2_batched<REPACK_SH2_TAIL>, dim3(tail_blocks > 0 ? tail_blocks : 1, n_kind[3]), dim3(256), 0, s, rj, (char*)packed);
+    GH_LAUNCH_CHECK("k_repack_sh2_batched");
     return GLOWHIP_OK;
 }
 

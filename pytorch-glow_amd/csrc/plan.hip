@@ -782,8 +782,15 @@ int glowhip_plan_pack_for(glowhip_plan* plan, void* packed, size_t packed_bytes,
     if (g_sh_disabled || g_sh_tail_disabled || g_sh_first_disabled) use = GLOWHIP_PACK_INFERENCE | GLOWHIP_PACK_TRAINING | 8;
     if ((use & GLOWHIP_PACK_INFERENCE) && (g_cnet_disabled || g_cnet_h2_only)) use |= 8;
     plan->repack_sel.clear();
-    for (const RepackJob& r : plan->repack_jobs)
-        if (r.use & use) plan->repack_sel.push_back(r);
+    int n_kind[4] = {0, 0, 0, 0}, tail_blocks = 1;
+    auto group = [](const RepackJob& r) { return r.kind < REPACK_SH2_GEMM ? 0 : r.kind - REPACK_SH2_GEMM + 1; };
+    for (int gk = 0; gk < 4; ++gk)            // sorted by kind group: each image kernel is launched over its own jobs only
+        for (const RepackJob& r : plan->repack_jobs)
+            if ((r.use & use) && group(r) == gk) {
+                plan->repack_sel.push_back(r);
+                ++n_kind[gk];
+                if (gk == 3) tail_blocks = std::max(tail_blocks, (r.Cout + 7) / 8);
+            }
     GH_REQUIRE(packed_bytes >= plan->packed_bytes, "plan_pack: packed buffer too small (%zu < %zu)", packed_bytes,
                plan->packed_bytes);
     hipStream_t s = (hipStream_t)stream;
@@ -802,7 +809,7 @@ int glowhip_plan_pack_for(glowhip_plan* plan, void* packed, size_t packed_bytes,
         return GLOWHIP_ELAUNCH;
     }
     GH_TRY(launch_pack_batched(at<ScaleJob>(packed, plan->scale_off), (int)plan->scale_jobs.size(),
-                               at<RepackJob>(packed, plan->repack_off), (int)plan->repack_sel.size(), packed, s));
+                               at<RepackJob>(packed, plan->repack_off), n_kind, tail_blocks, packed, s));
     GH_TRY(launch_step_prepare_batched(at<StepPrepJob>(packed, plan->prep_off), (int)plan->prep_jobs.size(),
                                        plan->max_lds_c, packed, s, (use & (GLOWHIP_PACK_INVERSE | GLOWHIP_PACK_TRAINING)) != 0,
                                        plan->max_c));
