@@ -19,7 +19,6 @@
 // pixel count alone cannot fill 256 CUs.  The finishing kernel sums the MS partials and the neighbours' halo rows.
 #include "sh.h"
 #include <algorithm>
-#include <cstdlib>
 #include <type_traits>
 
 #include "conv_mfma.h"
@@ -44,7 +43,6 @@ struct CnetGeo {
     int HW;
     int lpp;          // log2(pixels per staging pass)
     int pxt, lpxt;    // pixels per workgroup tile (128 or 64) and its log2
-    int exp;          // experiment selector (env GLOWHIP_EXP; 0 in production)
 };
 
 __host__ __device__ inline int cnet_trow(int M9) {   // T row stride (floats): multiple of 4, an odd multiple (bank spread)
@@ -1173,7 +1171,6 @@ int launch_cnet_main(const CnetArgs& a, hipStream_t s, CnetPending* out) {
     if (g_cnet_flags & 2) use64 = ok64;        // testing: 64-pixel tiles wherever they exist
     if (a.y_sh && ok128) use64 = false;
     g = use64 ? g64 : g128;
-    { static const int e = getenv("GLOWHIP_EXP") ? atoi(getenv("GLOWHIP_EXP")) : 0; g.exp = e; }
     int ms = 1;
     const int ms_max = std::min(CN_MAXMS, a.hidden / (use64 ? 128 : 64));
     while (ms < ms_max && g.tiles * ms < 160) ms *= 2;
