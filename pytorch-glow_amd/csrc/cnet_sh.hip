@@ -548,12 +548,17 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
                     for (int j = 0; j < 2 * PTSV; ++j) Bc[j] = Bn[j];
                 }
             };
+            int st = 0;
 #pragma unroll 1
-            for (int st = 0; st < g.steps0; st += 3) {     // steps0 is a multiple of 3 (zero-weight groups pad the image)
+            for (; st + 3 <= g.steps0; st += 3) {
                 step1(st, A1[0], A1[2]);
                 step1(st + 1, A1[1], A1[0]);
                 step1(st + 2, A1[2], A1[1]);
             }
+            // the one or two k-steps left over (the reduction is padded to whole k-steps only, not to whole triples: level 1
+            // has 5 k-steps for its 54 real k values, a sixth would be a sixth of the phase's MFMAs for nothing)
+            if (st < g.steps0) step1(st, A1[0], A1[2]);
+            if (st + 1 < g.steps0) step1(st + 1, A1[1], A1[0]);
             // A sets of the next P1 pass (next pixel sub-pass of this channel pass, or the next channel pass): in flight during
             // the epilogue, the barrier and P2
             {
@@ -1080,7 +1085,7 @@ static int g_cnet_ms = 0, g_cnet_flags = 0;
 bool cnet_chain_enabled() { return (g_cnet_flags & 4) != 0; }
 void cnet_force(int ms, int flags) { g_cnet_ms = ms; g_cnet_flags = flags; }
 
-int cnet_g0(int Cin) { return (9 * ((Cin + 7) / 8) + 5) / 6 * 6; }   // 8-wide k groups of f.0, padded to whole triples of k-steps
+int cnet_g0(int Cin) { return (9 * ((Cin + 7) / 8) + 1) / 2 * 2; }   // 8-wide k groups of f.0, padded to whole k-steps (two groups each)
 int cnet_mpad4(int Cout) { return (9 * Cout + 31) / 32 * 32; }
 
 static bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
