@@ -486,8 +486,12 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
 
     f32x16_t acc2[RT2][PT2];
     // P1 of one channel pass; PTSV = pixel tiles per sub-pass (fewer while the h2 accumulators are live)
-    auto p1_pass = [&](int hh, auto ptsc) {
+    // syncc: the barrier "every wave is done reading the previous pass of h1" sits INSIDE this pass, between the MFMAs of its first
+    // pixel sub-pass (which only read the window) and the first store into the h1 buffer -- a wave that is done with P2 early
+    // (the older wave of each SIMD, ~8 k cycles) issues those MFMAs into the gaps of its partner's P2 instead of waiting
+    auto p1_pass = [&](int hh, auto ptsc, auto syncc) {
         constexpr int PTSV = decltype(ptsc)::value;
+        constexpr bool SYNC = decltype(syncc)::value;
         constexpr int SUBV = PT1 / PTSV;
         // ---- P1: h1 channels [hh*HK, hh*HK + HK) of all pixels -> hbuf.  Its first two A sets are already in flight.
 #pragma unroll 1
@@ -568,6 +572,11 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
                     loadA1(nh, g.steps0 > 1 ? 1 : 0, A1[1]);
                 }
             }
+            if (SYNC && sp == 0) {
+                GH_STAMP(4 + 4 * (hh - 1));
+                __syncthreads();     // every wave is done reading the previous pass of h1
+                GH_STAMP(5 + 4 * (hh - 1));
+            }
             // relu, split, store into the B-operand image: a lane's 4 consecutive channels = 8 bytes per plane
 #pragma unroll
             for (int i = 0; i < RT1; ++i)
@@ -646,8 +655,9 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
     constexpr bool PEEL = TP2 == 8 && PT1 == 4 && NH == 2;
 #pragma unroll
     for (int hh = 0; hh < NH; ++hh) {
-        if (PEEL && hh == 0) p1_pass(hh, std::integral_constant<int, PT1>{});
-        else p1_pass(hh, std::integral_constant<int, PTS>{});
+        if (PEEL && hh == 0) p1_pass(hh, std::integral_constant<int, PT1>{}, std::false_type{});
+        else if (hh == 0) p1_pass(hh, std::integral_constant<int, PTS>{}, std::false_type{});
+        else p1_pass(hh, std::integral_constant<int, PTS>{}, std::true_type{});
         if (hh == 0) {
 #pragma unroll
             for (int i = 0; i < RT2; ++i)
@@ -664,9 +674,11 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
         __syncthreads();
         GH_STAMP(3 + 4 * hh);
         p2_pass(hh);
-        GH_STAMP(4 + 4 * hh);
-        __syncthreads();     // every wave is done reading this pass of h1
-        GH_STAMP(5 + 4 * hh);
+        if (hh == NH - 1) {  // (between passes that barrier is inside the next P1 pass)
+            GH_STAMP(4 + 4 * hh);
+            __syncthreads();     // every wave is done reading this pass of h1
+            GH_STAMP(5 + 4 * hh);
+        }
     }
 
     // ---- P3 set-up: T units of this wave.  unit = (RTU row tiles ru of T, k part kp) x all pixel tiles = 4 MFMA tiles; wave w
