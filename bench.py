@@ -202,8 +202,8 @@ def dry_run_cpu(args, rank, world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="B", help="BASELINE.json workload: B = configs[1] (headline), "
                     "D = configs[3] (128x128 L=4 K=48), E = configs[4] (256x256 L=6 K=32)")
     ap.add_argument("--batch", type=int, default=0, help="images per GPU (default: the config's: 64 / 32 / 16)")
