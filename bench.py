@@ -296,6 +296,7 @@ def main():
     for i in range(args.steps):
         loss = step()
         marks[i + 1].record()
+    dt_host = time.perf_counter() - t0      # host time to ENQUEUE the steps (how far the CPU runs ahead of the GPU)
     sync()
     dt = time.perf_counter() - t0
     per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
@@ -320,7 +321,7 @@ def main():
             "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "ms_per_step_min": round(per_step[0], 4), "ms_per_step_median": round(per_step[len(per_step) // 2], 4),
-            "ms_per_step_max": round(per_step[-1], 4),
+            "ms_per_step_max": round(per_step[-1], 4), "host_enqueue_ms_per_step": round(1e3 * dt_host / args.steps, 4),
             "rccl_world_size": dist.get_world_size() if world > 1 else 1,
             "arithmetic": "fp32 values carried as 2 x f16 (hi, lo), exact f16 products, fp32 accumulate (csrc/sh.h); "
                           "max-abs vs CPU reference 7e-6 (z), same as the exact-fp32 kernels",

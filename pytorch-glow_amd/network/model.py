@@ -281,7 +281,7 @@ class Glow(nn.Module):
             assert mean.shape[0] == x.shape[0], "batch must equal h_top's batch when learn_top is on"
             stride = mean.stride(0)
             assert mean[0].is_contiguous() and logs[0].is_contiguous() and logs.stride(0) == stride
-        params = plan.trainable_parameters()
+        params = plan.trainable_parameters() if torch.is_grad_enabled() else ()     # (a walk over ~1 060 tensors: skipped on the inference path)
         if torch.is_grad_enabled() and any(p.requires_grad for p in params):
             # training step: one autograd node over the whole flow (HIP forward with tape + HIP backward)
             if mean is not None:
