@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GLOWHIP_VERSION 101 /* 0.1.1 */
+#define GLOWHIP_VERSION 102 /* 0.1.2 */
 
 #define GLOWHIP_OK 0
 #define GLOWHIP_EINVAL (-1)    /* bad argument (shape, null pointer, unsupported value) */
@@ -181,6 +181,26 @@ int glowhip_glow_forward_u8(glowhip_plan* plan, const void* packed, const uint8_
                             float* nll_out, float* objective_out, int N, void* workspace, size_t workspace_bytes,
                             glowhip_stream_t stream);
 
+/* Kernel family of a plan's coupling networks (network/module.py:300-319) -- a property of the PLAN, not of the process:
+ *   GLOWHIP_FAMILY_AUTO        the split-half f16 matrix-pipe kernels wherever the shape allows (default; hidden activations
+ *                              |v| < 4094, beyond that the result is non-finite and flagged, never a finite wrong value);
+ *   GLOWHIP_FAMILY_EXACT_FP32  v_mfma_f32_32x32x2_f32 kernels only: the reference's full fp32 range at 1/3 of the speed.
+ * Takes effect at the next glowhip_plan_pack_for (the family's weight images are packed on demand) + encode / decode /
+ * glow_forward.  HOST bookkeeping; the caller serialises it with the plan's own calls as for any other plan call. */
+#define GLOWHIP_FAMILY_AUTO 0
+#define GLOWHIP_FAMILY_EXACT_FP32 1
+int glowhip_plan_set_family(glowhip_plan* plan, int family);
+int glowhip_plan_get_family(const glowhip_plan* plan);
+
+/* Range / non-finite status of the encode / decode / glow_forward call that last ran with `workspace` for batch N (enqueue it
+ * on the same stream right after that call): status_out[n] (DEVICE, N int32) = bit 0: a NaN term, bit 1: a +inf term, bit 2: a
+ * -inf term entered sample n's log-det sum (the sticky flags the nll reports as NaN / inf) | bit 3: an element of
+ * result[n*elems_per_sample ..) (the call's output tensor: x of a decode, z of an encode; may be NULL) is not finite.
+ * Non-zero means: out of the product kernels' range (or genuinely diverged) -- re-run on GLOWHIP_FAMILY_EXACT_FP32 to get
+ * the reference's answer (Glow.reverse_flow network/model.py:454-471 has no nll that would show it).  No host sync. */
+int glowhip_plan_status(const glowhip_plan* plan, const void* workspace, size_t workspace_bytes, int N, const float* result,
+                        long elems_per_sample, int32_t* status_out, glowhip_stream_t stream);
+
 /* Dequantisation noise drawn INSIDE the leading squeeze (network/model.py:421): with enable != 0, every later
  * glowhip_glow_forward / _u8 call whose `noise` is NULL adds U(0, 2^-n_bits) from the counter-based generator
  * Philox4x32-10(key = seed; counter = element index, call number) -- no noise tensor, no RNG launch.  The call number starts at
@@ -240,11 +260,14 @@ int glowhip_glow_backward(glowhip_plan* plan, const void* packed, const float* x
  * 1 = Adamax; step: 1-based count of this update (bias corrections); clip_value / max_norm <= 0: that clipping off.
  * grad_norm_out (1 float, may be NULL) <- total gradient norm after the value clipping, before the norm clipping, as
  * clip_grad_norm_ returns it.  Gradients are clipped IN PLACE as the reference's utilities do.
+ * skip_if_nonfinite != 0: when that norm is NaN / inf the update launch leaves parameters, state and gradients untouched (the
+ * device-side "found inf" of a loss scaler: no host sync) -- the caller reads grad_norm_out at its next natural sync and re-runs
+ * the batch on GLOWHIP_FAMILY_EXACT_FP32 (training.TrainLoop).  0 = torch's semantics (NaN gradients give NaN parameters).
  * ---------------------------------------------------------------------------------------------- */
 typedef struct glowhip_optim_chunk { float* param; float* grad; float* m; float* v; int32_t n; int32_t pad; } glowhip_optim_chunk;
 int glowhip_optim_step(const glowhip_optim_chunk* chunks_dev, int n_chunks, int kind, float lr, double beta1, double beta2,
                        float eps, float weight_decay, int step, float clip_value, float max_norm, double* partial_dev,
-                       float* grad_norm_out, glowhip_stream_t stream);
+                       float* grad_norm_out, int skip_if_nonfinite, glowhip_stream_t stream);
 
 /* Per-launch timing for benchmarks (HIP events recorded on the execution stream around every kernel of
  * the coupling path).  enable=1 creates an event pool (host resource), enable=0 destroys it; while enabled

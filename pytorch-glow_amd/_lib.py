@@ -84,6 +84,9 @@ SIGNATURES = {
     "glowhip_plan_decode": (c_int, [_P, _P, _P, POINTER(c_void_p), c_int, _P, _P, _P, c_int, _P, c_size_t, _P]),
     "glowhip_glow_forward": (c_int, [_P, _P, _P, _P, _P, _P, c_long, c_int, _P, _P, _P, c_int, _P, c_size_t, _P]),
     "glowhip_glow_forward_u8": (c_int, [_P, _P, _P, c_float, _P, _P, _P, c_long, c_int, _P, _P, _P, c_int, _P, c_size_t, _P]),
+    "glowhip_plan_set_family": (c_int, [_P, c_int]),
+    "glowhip_plan_get_family": (c_int, [_P]),
+    "glowhip_plan_status": (c_int, [_P, _P, c_size_t, c_int, _P, c_long, _P, _P]),
     "glowhip_plan_set_dequant_rng": (c_int, [_P, ctypes.c_ulonglong, c_int, POINTER(ctypes.c_ulonglong)]),
     "glowhip_dequant_noise": (c_int, [_P, c_long, ctypes.c_ulonglong, ctypes.c_ulonglong, c_int, _P]),
     "glowhip_plan_actnorm_init": (c_int, [_P, _P, c_size_t, _P, _P, c_float, c_int, _P, c_size_t, _P]),
@@ -98,7 +101,7 @@ SIGNATURES = {
                                            c_size_t, _P]),
     "glowhip_glow_backward": (c_int, [_P, _P, _P, _P, c_size_t, _P, _P, _P, _P, c_long, POINTER(LayerGrads), _P, c_int,
                                       _P, c_size_t, _P]),
-    "glowhip_optim_step": (c_int, [_P, c_int, c_int, c_float, ctypes.c_double, ctypes.c_double, c_float, c_float, c_int, c_float, c_float, _P, _P, _P]),
+    "glowhip_optim_step": (c_int, [_P, c_int, c_int, c_float, ctypes.c_double, ctypes.c_double, c_float, c_float, c_int, c_float, c_float, _P, _P, c_int, _P]),
     "glowhip_plan_timing_enable": (c_int, [_P, c_int]),
     "glowhip_plan_timing_read": (c_int, [_P, POINTER(TimingRecord), c_int, POINTER(c_int)]),
 }

@@ -119,6 +119,29 @@ class FlowPlan:
         return self._ws
 
     PACK_INFERENCE, PACK_TRAINING, PACK_INVERSE = 1, 2, 4   # glowhip.h GLOWHIP_PACK_*
+    FAMILY_AUTO, FAMILY_EXACT_FP32 = 0, 1                   # glowhip.h GLOWHIP_FAMILY_*
+
+    @property
+    def family(self) -> int:
+        return int(lib().glowhip_plan_get_family(self._h))
+
+    def set_family(self, family: int) -> None:
+        """Kernel family of this plan's coupling networks (glowhip_plan_set_family): per plan, no process-wide state.  The
+        exact-fp32 family reads the fp32 MFMA weight images; they are packed on demand by the next call (ensure_packed)."""
+        check(lib().glowhip_plan_set_family(self._h, int(family)))
+
+    def _family_use(self, use: int) -> int:
+        return use | (self.PACK_TRAINING if self.family == self.FAMILY_EXACT_FP32 else 0)
+
+    def status(self, n: int, result: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """(n,) int32 device tensor: sticky non-finite flags of the call that last used this plan's workspace (bits 0-2) |
+        8 where `result` (that call's output tensor) holds a non-finite element.  Asynchronous: no host sync."""
+        st = torch.empty(n, dtype=torch.int32, device=self.device)
+        if n:
+            ws = self._workspace(n)
+            elems = 0 if result is None else result[0].numel()
+            check(lib().glowhip_plan_status(self._h, ptr(ws), ws.numel(), n, ptr(result), elems, ptr(st), stream_ptr(self.device)))
+        return st
 
     def pack(self, use: int = 7, merge: bool = True) -> None:
         """Refresh what is derived from the parameters (exp(3 logs), LU, and the weight images `use` asks for: the inference
@@ -133,6 +156,7 @@ class FlowPlan:
     def ensure_packed(self, force: bool = False, use: int = 1) -> None:
         """Re-derive the packed data when the parameters changed since the last pack (or `force`), or when images `use` asks
         for have not been packed for the current parameter version."""
+        use = self._family_use(use)
         have = getattr(self, "_packed_use", 0)
         stale = self._packed_version != self._version_signature()
         if force or stale or (use & ~have):

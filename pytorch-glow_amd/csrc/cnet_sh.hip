@@ -321,9 +321,13 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
     } else {
         pre_gather(tid, std::false_type{});
     }
-    for (int e = tid; e < 2 * HID; e += 512) t_rs0[e] = rs0[e];                               // rs0 | b0 are adjacent in the image
-    for (int e = tid; e < MR; e += 512) { t_rs2[e] = rs2[ms_row0 + e]; t_b2[e] = rs2[HID + ms_row0 + e]; }
-    for (int e = tid; e < g.Mpad4; e += 512) t_rs4[e] = rs4[e];
+    // The activations travel NEGATED from the first epilogue on (sh.h nrelu_bits): h1 and h2 sit in LDS as -h1, -h2, the h2 and T
+    // accumulators hold the negated sums.  So the tables carry the signs: f.0 (-rs0, -b0) turns the true accumulator into -t;
+    // f.2 (rs2, -b2) turns the negated accumulator into -t; f.4's row scale -rs4 turns the negated T back.  canon_nan: a NaN
+    // from memory gets the sign bit the hardware's own NaNs have.
+    for (int e = tid; e < 2 * HID; e += 512) t_rs0[e] = canon_nan(-rs0[e]);                   // rs0 | b0 are adjacent in the image
+    for (int e = tid; e < MR; e += 512) { t_rs2[e] = canon_nan(rs2[ms_row0 + e]); t_b2[e] = canon_nan(-rs2[HID + ms_row0 + e]); }
+    for (int e = tid; e < g.Mpad4; e += 512) t_rs4[e] = canon_nan(-rs4[e]);
     float* nz = nullptr;     // with `pre`: z1 of the freshly finished state, fp32 [Cin][KP]
     if (pre_on) {
         // ---- finish the PREVIOUS step on the window pixels: coupling (+ log-det for the tile's own pixels), then the channel mixer;
@@ -467,7 +471,7 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
         h8 hi, lo;
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            const float vv = (in && ch * 8 + q < a.Cin) ? v[q] * SH2_ACT_SCALE : 0.f;
+            const float vv = (in && ch * 8 + q < a.Cin) ? canon_nan(v[q] * SH2_ACT_SCALE) : 0.f;
             _Float16 x0, x1;
             sh2_split(vv, x0, x1);
             hi[q] = x0; lo[q] = x1;
@@ -577,7 +581,7 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
                 __syncthreads();     // every wave is done reading the previous pass of h1
                 GH_STAMP(5 + 4 * (hh - 1));
             }
-            // relu, split, store into the B-operand image: a lane's 4 consecutive channels = 8 bytes per plane
+            // -relu (sh.h nrelu_bits), split, store into the B-operand image: a lane's 4 consecutive channels = 8 bytes per plane
 #pragma unroll
             for (int i = 0; i < RT1; ++i)
 #pragma unroll
@@ -589,13 +593,10 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
 #pragma unroll
                     for (int j = 0; j < PTSV; ++j) {
                         h4 hi, lo;
+                        f32x4_t v;
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) {
-                            const float v = relu_(fmaf(acc1[i][j][4 * gq + t], rs[t], bb[t]));
-                            _Float16 x0, x1;
-                            sh2_split(v, x0, x1);
-                            hi[t] = x0; lo[t] = x1;
-                        }
+                        for (int t = 0; t < 4; ++t) v[t] = nrelu_bits(fmaf(acc1[i][j][4 * gq + t], rs[t], bb[t]));
+                        sh2_split4(v, hi, lo);
                         _Float16* dst = hbuf + ((long)chunk * PXT + (pt1 + sp * PTSV + j) * 32 + ml) * 8 + 4 * kl;
                         *reinterpret_cast<h4*>(dst) = hi;
                         *reinterpret_cast<h4*>(dst + (long)NCH * PXT * 8) = lo;
@@ -704,7 +705,7 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
         loadA4(ap, wid % g.NU4, nsl > 1 ? 1 : 0, A4[1]);
     }
 
-    // ---- h2 = relu(acc2 * rowscale + bias) (times SH2_ACT_SCALE), in place
+    // ---- -h2 = -relu(t2), t2 = true sum * rowscale + bias (times SH2_ACT_SCALE), in place (the accumulators hold the negated sum)
 #pragma unroll
     for (int i = 0; i < RT2; ++i)
 #pragma unroll
@@ -715,7 +716,7 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
 #pragma unroll
             for (int j = 0; j < PT2; ++j)
 #pragma unroll
-                for (int t = 0; t < 4; ++t) acc2[i][j][4 * gq + t] = relu_(fmaf(acc2[i][j][4 * gq + t], rs[t], bb[t]));
+                for (int t = 0; t < 4; ++t) acc2[i][j][4 * gq + t] = nrelu_bits(fmaf(acc2[i][j][4 * gq + t], rs[t], bb[t]));
         }
     GH_STAMP(10);
 
@@ -733,7 +734,7 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
                         _Float16 x0, x1;
-                        sh_split(acc2[i][j][4 * gq + t] * SH2_ACT_INV, x0, x1);
+                        sh_split(-acc2[i][j][4 * gq + t] * SH2_ACT_INV, x0, x1);
                         hi[t] = x0; lo[t] = x1;
                     }
                     _Float16* dst = a.y_sh + sh_off(HID / 8, 0, o >> 3, px) + (o & 7);
@@ -765,12 +766,8 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
 #pragma unroll
                 for (int j = 0; j < PT2; ++j) {
                     h4 hi, lo;
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        _Float16 x0, x1;
-                        sh2_split(acc2[i][j][4 * gq + t], x0, x1);
-                        hi[t] = x0; lo[t] = x1;
-                    }
+                    const f32x4_t v = {acc2[i][j][4 * gq], acc2[i][j][4 * gq + 1], acc2[i][j][4 * gq + 2], acc2[i][j][4 * gq + 3]};
+                    sh2_split4(v, hi, lo);
                     _Float16* dst = hbuf + ((long)chunk * PXT + (pt2 + j) * 32 + ml) * 8 + 4 * kl;
                     *reinterpret_cast<h4*>(dst) = hi;
                     *reinterpret_cast<h4*>(dst + (long)LCH * PXT * 8) = lo;

@@ -62,6 +62,9 @@ int launch_zero_acc(unsigned long long* acc, int N, hipStream_t s);
 int launch_finalize(const float* in, const unsigned long long* acc, const double* konst, double sign, double offset,
                     double scale, float* out, float* out_unscaled, int N, hipStream_t s);
 
+// status[n] = sticky non-finite flags of sample n (acc[N + n], common.h) | 8 if any of result[n*elems .. +elems) is not finite
+int launch_status(const unsigned long long* acc, int N, const float* result, long elems, int32_t* status, hipStream_t s);
+
 // ---------------------------------------------------------------- lu.hip
 size_t invconv_scratch_bytes(int C);
 int launch_invconv_prepare(const float* w, int C, float* winv, float* logabsdet, void* scratch, hipStream_t s);

@@ -30,8 +30,9 @@ __global__ void __launch_bounds__(256) k_optim_clip_sumsq(const glowhip_optim_ch
 __global__ void __launch_bounds__(256) k_optim_update(const glowhip_optim_chunk* __restrict__ chunks, int n_chunks,
                                                       const double* __restrict__ partial, int kind, float lr, float beta1,
                                                       float beta2, float omb1, float omb2, float eps, float weight_decay, double bc1, double bc2,
-                                                      float max_norm, float* __restrict__ grad_norm_out) {
+                                                      float max_norm, float* __restrict__ grad_norm_out, int skip_if_nonfinite) {
     __shared__ float s_coef;
+    __shared__ int s_skip;
     if (threadIdx.x < 64) {       // total gradient norm: the chunk sums in a fixed order (wave 0), then clip_grad_norm_'s coefficient
         double t = 0.0;
         for (int i = threadIdx.x; i < n_chunks; i += 64) t += partial[i];
@@ -44,11 +45,14 @@ __global__ void __launch_bounds__(256) k_optim_update(const glowhip_optim_chunk*
                 coef = coef > 1.f ? 1.f : coef;
             }
             s_coef = coef;
+            s_skip = skip_if_nonfinite && !isfinite(norm);
             if (blockIdx.x == 0 && grad_norm_out) grad_norm_out[0] = norm;
         }
     }
     __syncthreads();
     const float coef = s_coef;
+    if (s_skip) return;      // a non-finite gradient somewhere: parameters, state and gradients stay as they are (the caller
+                             // reads grad_norm_out later and decides -- no host sync here)
     const glowhip_optim_chunk c = chunks[blockIdx.x];
     const float step_size = (float)((double)lr / bc1);
     const float bc2_sqrt = (float)sqrt(bc2);
@@ -86,7 +90,7 @@ using namespace glowhip;
 
 extern "C" int glowhip_optim_step(const glowhip_optim_chunk* chunks_dev, int n_chunks, int kind, float lr, double beta1_d,
                                   double beta2_d, float eps, float weight_decay, int step, float clip_value, float max_norm,
-                                  double* partial_dev, float* grad_norm_out, glowhip_stream_t stream) {
+                                  double* partial_dev, float* grad_norm_out, int skip_if_nonfinite, glowhip_stream_t stream) {
     GH_REQUIRE(chunks_dev && partial_dev, "optim_step: null argument");
     GH_REQUIRE(kind == 0 || kind == 1, "optim_step: kind %d (0 = adam, 1 = adamax)", kind);
     GH_REQUIRE(step >= 1, "optim_step: step must be >= 1");
@@ -97,7 +101,7 @@ extern "C" int glowhip_optim_step(const glowhip_optim_chunk* chunks_dev, int n_c
     const float beta1 = (float)beta1_d, beta2 = (float)beta2_d;
     const double bc1 = 1.0 - pow(beta1_d, (double)step), bc2 = 1.0 - pow(beta2_d, (double)step);     // python-double arithmetic, as torch
     hipLaunchKernelGGL(k_optim_update, dim3(n_chunks), dim3(256), 0, s, chunks_dev, n_chunks, partial_dev, kind, lr, beta1, beta2,
-                       (float)(1.0 - (double)beta1_d), (float)(1.0 - (double)beta2_d), eps, weight_decay, bc1, bc2, max_norm, grad_norm_out);
+                       (float)(1.0 - (double)beta1_d), (float)(1.0 - (double)beta2_d), eps, weight_decay, bc1, bc2, max_norm, grad_norm_out, skip_if_nonfinite);
     GH_LAUNCH_CHECK("k_optim_update");
     return GLOWHIP_OK;
 }

@@ -95,8 +95,10 @@ struct NextMix { int C; float* out; long out_bs; const float* bias; const float*
 // workgroups at the 8x8 level of a 64-image batch the two separate kernels are faster).  N = 0: batch unknown (plan time)
 static bool f02_runs_at(int N, int HW) { return N <= 0 || (long)N * HW / 64 >= 192; }
 
-static bool tail_runs_sh(const LayerPlan& L) { return L.sh_mid && L.sh_tail && !g_sh_disabled && !g_sh_tail_disabled; }
-static bool cnet_runs(const LayerPlan& L) { return L.cnet && !g_sh_disabled && !g_cnet_disabled; }
+// split-half f16 kernels off for this plan: its own family (glowhip_plan_set_family) or the process-wide testing hook
+static bool sh_off(const glowhip_plan* p) { return g_sh_disabled || (p && p->family == GLOWHIP_FAMILY_EXACT_FP32); }
+static bool tail_runs_sh(const glowhip_plan* p, const LayerPlan& L) { return L.sh_mid && L.sh_tail && !sh_off(p) && !g_sh_tail_disabled; }
+static bool cnet_runs(const glowhip_plan* p, const LayerPlan& L) { return L.cnet && !sh_off(p) && !g_cnet_disabled; }
 
 // ---- the one-kernel coupling network (cnet_sh.hip).  A FlowStep is k_cnet (partial sums of h = f(z1)) + a finishing step
 // (coupling, log-det, channel mixer); the finishing step of step k runs either as its own kernel or inside step k+1's k_cnet
@@ -127,10 +129,10 @@ static CnetMixer mixer_rev(const LayerPlan& L, const void* packed) {      // per
 // may the finishing step of layer A run inside layer B's k_cnet?  (Off by default: the window-time finishing costs a workgroup
 // ~25 k cycles of dependent global round trips with 8 waves, more than the ~10 us finishing kernel it saves; kept behind
 // glowhip_debug_force_tail_tile(0x8000000) with its bitwise-equality test.)
-static bool cnet_chain(const LayerPlan& A, const LayerPlan& B) {
+static bool cnet_chain(const glowhip_plan* p, const LayerPlan& A, const LayerPlan& B) {
     const glowhip_layer_desc& a = A.d; const glowhip_layer_desc& b = B.d;
     return cnet_chain_enabled() && !g_sh_mix_disabled && !g_cnet_h2_only && a.kind == GLOWHIP_LAYER_FLOWSTEP && b.kind == GLOWHIP_LAYER_FLOWSTEP &&
-           cnet_runs(A) && cnet_runs(B) && a.C == b.C && a.H == b.H && a.W == b.W && a.coupling == b.coupling &&
+           cnet_runs(p, A) && cnet_runs(p, B) && a.C == b.C && a.H == b.H && a.W == b.W && a.coupling == b.coupling &&
            cnet_pre_supported(b.C / 2, b.H, b.W, b.hidden, B.Cout, b.C);
 }
 
@@ -139,7 +141,7 @@ static int run_coupling(glowhip_plan* P, const LayerPlan& L, const void* packed,
                         hipStream_t s, const NextMix* mix = nullptr) {
     const glowhip_layer_desc& d = L.d;
     const int Ch = d.C / 2, HW = d.H * d.W, hid = d.hidden;
-    const bool use_sh = L.sh_mid && !g_sh_disabled;
+    const bool use_sh = L.sh_mid && !sh_off(P);
     const bool use_sh_tail = use_sh && L.sh_tail && !g_sh_tail_disabled;
     const bool use_f02 = use_sh_tail && L.sh_f02 && !g_sh_f02_disabled && f02_runs_at(N, HW);
     const bool cnet_h2 = use_sh_tail && L.cnet && g_cnet_h2_only && !g_cnet_disabled;
@@ -302,7 +304,7 @@ static int run_forward(glowhip_plan* p, const void* packed, const float* x, cons
                 if (li != nl - 1) dst = w.bufB;
             }
             const int Ch = d.C / 2;
-            if (d.kind == GLOWHIP_LAYER_FLOWSTEP && cnet_runs(L) && !g_cnet_h2_only) {
+            if (d.kind == GLOWHIP_LAYER_FLOWSTEP && cnet_runs(p, L) && !g_cnet_h2_only) {
                 // ---- k_cnet path.  `cur` holds the input of this step's mixer, or -- `premixed` -- its output, or -- `pending` --
                 // the state the PREVIOUS step's k_cnet read, whose finishing (coupling + this step's mixer) this launch does itself
                 float* scratch = (scr_i ^= 1) ? w.h1 : w.h2;
@@ -328,7 +330,7 @@ static int run_forward(glowhip_plan* p, const void* packed, const float* x, cons
                     c.x = cur; c.x_bs = chw; c.z_in = cur; c.z_in_bs = chw;
                 }
                 premixed = false;
-                const bool chain = li + 1 < nl && cnet_chain(L, p->layers[li + 1]);
+                const bool chain = li + 1 < nl && cnet_chain(p, L, p->layers[li + 1]);
                 {
                     ScopedTimer t(p, GLOWHIP_K_CNET, 1, s);
                     count_launch(p, pending ? "k_cnet+prev_finish" : "k_cnet");
@@ -371,7 +373,7 @@ static int run_forward(glowhip_plan* p, const void* packed, const float* x, cons
                 // Let this step's tail apply the NEXT step's channel mixer (one launch less per step) when the next layer is
                 // a FlowStep of the same shape that may run in place (i.e. is not the one writing z_out)
                 NextMix nm{};
-                if (li + 1 < nl - 1 && !g_sh_mix_disabled && tail_runs_sh(L)) {
+                if (li + 1 < nl - 1 && !g_sh_mix_disabled && tail_runs_sh(p, L)) {
                     const LayerPlan& Ln = p->layers[li + 1];
                     const glowhip_layer_desc& dn = Ln.d;
                     if (dn.kind == GLOWHIP_LAYER_FLOWSTEP && dn.C == d.C && dn.H == d.H && dn.W == d.W &&
@@ -416,7 +418,7 @@ static int run_reverse(glowhip_plan* p, const void* packed, const float* z, cons
             GH_TRY(launch_squeeze(cur, nullptr, dst, N, d.C * 4, d.H / 2, d.W / 2, 2, 1, s));
         } else if (d.kind == GLOWHIP_LAYER_FLOWSTEP) {
             float* z2 = dst + (long)Ch * HW;
-            if (cnet_runs(L) && !g_cnet_h2_only && d.C <= 96) {
+            if (cnet_runs(p, L) && !g_cnet_h2_only) {
                 // coupling^-1, permutation^-1 and ActNorm^-1 by the finishing step -- run by the next-executed step's k_cnet where
                 // the two chain, by the finishing kernel otherwise
                 float* scratch = (scr_i ^= 1) ? w.h1 : w.h2;
@@ -428,19 +430,41 @@ static int run_reverse(glowhip_plan* p, const void* packed, const float* z, cons
                 } else {
                     c.x = cur; c.x_bs = chw; c.z_in = cur; c.z_in_bs = chw;
                 }
-                const bool chain = li - 1 >= 0 && cnet_chain(L, p->layers[li - 1]) && p->layers[li - 1].d.C <= 96;
+                const bool chain = d.C <= 96 && li - 1 >= 0 && cnet_chain(p, L, p->layers[li - 1]) && p->layers[li - 1].d.C <= 96;
                 {
                     ScopedTimer t(p, GLOWHIP_K_CNET, 1, s);
                     count_launch(p, pending ? "k_cnet+prev_finish" : "k_cnet");
                     GH_TRY(launch_cnet_main(c, s, &pend));
                 }
                 pending = chain;
-                if (!chain) {
+                if (!chain && d.C <= 96) {
                     float* out = (li == 0) ? x_out : other_buf(w, cur);
                     c.z_out = out; c.z_out_bs = chw; c.mix = mixer_rev(L, packed);
                     ScopedTimer t(p, GLOWHIP_K_CFINISH, 0, s);
                     count_launch(p, "k_cfinish+mixer");
                     GH_TRY(launch_cnet_finish(c, pend, s));
+                    cur = out;
+                } else if (!chain) {
+                    // wider than the finishing kernel's mixer (additive coupling, 96 < C <= 112: L.cnet holds, the fused mixer
+                    // does not): coupling^-1 alone by the finishing kernel, then permutation^-1 + ActNorm^-1 by k_chanmix
+                    float* mid = other_buf(w, cur);
+                    c.z_out = mid; c.z_out_bs = chw;
+                    {
+                        ScopedTimer t(p, GLOWHIP_K_CFINISH, 0, s);
+                        count_launch(p, "k_cfinish");
+                        GH_TRY(launch_cnet_finish(c, pend, s));
+                    }
+                    float* out = (li == 0) ? x_out : other_buf(w, mid);
+                    ChanMixArgs m{};
+                    m.in_a = mid; m.in_a_bs = chw; m.in_b = mid + (long)Ch * HW; m.in_b_bs = chw; m.Ca = Ch;
+                    m.out = out; m.out_bs = chw;
+                    m.bias = d.an_bias; m.scale = at<float>(packed, L.an_inv_scale);
+                    m.matrix = d.permutation == GLOWHIP_PERM_INVCONV ? at<float>(packed, L.winv) : nullptr;
+                    m.gather = d.permutation == GLOWHIP_PERM_GATHER ? d.perm_idx_inv : nullptr;
+                    m.reverse = 1; m.N = N; m.C = d.C; m.HW = HW;
+                    ScopedTimer tm(p, GLOWHIP_K_CHANMIX, 0, s);
+                    count_launch(p, "k_chanmix");
+                    GH_TRY(launch_chanmix(m, s));
                     cur = out;
                 }
                 continue;
@@ -750,8 +774,8 @@ int glowhip_plan_describe_for(const glowhip_plan* plan, int N, char* buf, size_t
         {
             // "-sh": split-half f16 matrix-pipe kernels (sh.h) are selected for this convolution (unless disabled by the
             // debug switch); the name before it is the exact-fp32 kernel that would run otherwise
-            const bool sh = L.sh_mid && !g_sh_disabled;
-            if (cnet_runs(L) && !g_cnet_h2_only)
+            const bool sh = L.sh_mid && !sh_off(plan);
+            if (cnet_runs(plan, L) && !g_cnet_h2_only)
                 snprintf(line, sizeof line, "%d flowstep C=%d H=%d W=%d hidden=%d f=cnet-sh2 (f.0+f.2+f.4 one kernel + finish)\n", li, d.C, d.H,
                          d.W, d.hidden);
             else
@@ -780,6 +804,8 @@ int glowhip_plan_pack_for(glowhip_plan* plan, void* packed, size_t packed_bytes,
     // with a kernel family switched off through the debug hook the other family's images are needed after all
     // use bit 8 (internal): the round-1 split-half images of layers that normally run k_cnet -- needed only with cnet switched off
     if (g_sh_disabled || g_sh_tail_disabled || g_sh_first_disabled) use = GLOWHIP_PACK_INFERENCE | GLOWHIP_PACK_TRAINING | 8;
+    // a plan on the exact-fp32 family reads the fp32 MFMA images, which are the training path's
+    if (plan->family == GLOWHIP_FAMILY_EXACT_FP32) use |= GLOWHIP_PACK_TRAINING;
     if ((use & GLOWHIP_PACK_INFERENCE) && (g_cnet_disabled || g_cnet_h2_only)) use |= 8;
     plan->repack_sel.clear();
     int n_kind[4] = {0, 0, 0, 0}, tail_blocks = 1;
@@ -814,6 +840,25 @@ int glowhip_plan_pack_for(glowhip_plan* plan, void* packed, size_t packed_bytes,
                                        plan->max_lds_c, packed, s, (use & (GLOWHIP_PACK_INVERSE | GLOWHIP_PACK_TRAINING)) != 0,
                                        plan->max_c));
     return GLOWHIP_OK;
+}
+
+int glowhip_plan_set_family(glowhip_plan* plan, int family) {
+    GH_REQUIRE(plan, "plan_set_family: null plan");
+    GH_REQUIRE(family == GLOWHIP_FAMILY_AUTO || family == GLOWHIP_FAMILY_EXACT_FP32, "plan_set_family: unknown family %d", family);
+    plan->family = family;
+    return GLOWHIP_OK;
+}
+
+int glowhip_plan_get_family(const glowhip_plan* plan) { return plan ? plan->family : GLOWHIP_EINVAL; }
+
+int glowhip_plan_status(const glowhip_plan* plan, const void* workspace, size_t workspace_bytes, int N, const float* result,
+                        long elems_per_sample, int32_t* status_out, glowhip_stream_t stream) {
+    GH_REQUIRE(plan && status_out, "plan_status: null argument");
+    GH_REQUIRE(N >= 0 && N <= 65535, "batch size %d out of range", N);
+    if (N == 0) return GLOWHIP_OK;
+    Workspace w;
+    GH_TRY(carve(plan, N, const_cast<void*>(workspace), workspace_bytes, w));
+    return launch_status(w.acc, N, result, elems_per_sample, status_out, (hipStream_t)stream);
 }
 
 int glowhip_plan_encode(glowhip_plan* plan, const void* packed, const float* x, const float* noise,

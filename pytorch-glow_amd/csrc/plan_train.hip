@@ -84,7 +84,8 @@ static size_t max_acc_doubles(const glowhip_plan* p) {
 static int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 static bool g_train_sh = true;   // testing hook: 0 = exact-fp32 kernels for f.2 in the training step too
-static bool train_sh_enabled() { return g_train_sh; }
+// (the plan's own family, glowhip_plan_set_family, decides first: GLOWHIP_FAMILY_EXACT_FP32 keeps the f16 pipe out of the training step)
+static bool train_sh_enabled(const glowhip_plan* p) { return g_train_sh && !(p && p->family == GLOWHIP_FAMILY_EXACT_FP32); }
 void plan_train_disable_sh(int off) { g_train_sh = off == 0; }
 
 static bool wgrad_fast(const LayerPlan& L) {
@@ -161,7 +162,7 @@ static int forward_train(glowhip_plan* p, const void* packed, const float* x, co
             // f.0
             // f.2 on the f16 matrix pipe (gemm_sh.hip) when f.0 can hand it h1 as a split-half tensor next to the fp32 copy
             // the tape keeps; the tape itself stays fp32 (the weight-gradient GEMMs read it)
-            const bool sh2 = L.first_halo && L.sh_mid && train_sh_enabled();
+            const bool sh2 = L.first_halo && L.sh_mid && train_sh_enabled(p);
             if (L.first_halo) {
                 const float* wf = at<float>(packed, L.f0_wt);
                 GH_TRY(launch_conv_mfma_first(dst, chw, wf, wf + (size_t)9 * Ch * hid, h1, N, Ch, d.H, d.W, hid, s, 1,
@@ -307,7 +308,7 @@ static int backward_sweep(glowhip_plan* p, const void* packed, const float* x_in
                 const int m4 = round_up(L.Cout * 9, 128);
                 GH_TRY(launch_shift_expand(w.gpre, (long)L.Cout * HW, w.col, N, L.Cout, d.H, d.W, m4, -1, s));
                 GH_TRY(launch_wgrad_mfma(w.col, (long)m4 * HW, h2, (long)hid * HW, w.partial, G.f4_w, N, HW, m4, hid,
-                                         L.Cout * 9, hid, 1, s, train_sh_enabled() ? sh_grad_scale : 0.f));
+                                         L.Cout * 9, hid, 1, s, train_sh_enabled(p) ? sh_grad_scale : 0.f));
             } else {
                 GH_TRY(launch_wgrad_direct(w.gpre, h2, (long)hid * HW, G.f4_w, N, hid, d.H, d.W, L.Cout, 3, s));
             }
@@ -318,13 +319,13 @@ static int backward_sweep(glowhip_plan* p, const void* packed, const float* x_in
             } else {
                 GH_TRY(dgrad_direct(w.gpre, d.f4_w, w.wT, w.gh2, N, hid, d.H, d.W, L.Cout, 3, s));
             }
-            const bool shd = L.sh_mid && train_sh_enabled() && HW % 64 == 0;   // f.2's input gradient on the f16 pipe
+            const bool shd = L.sh_mid && train_sh_enabled(p) && HW % 64 == 0;   // f.2's input gradient on the f16 pipe
             GH_TRY(launch_act_bwd(w.gh2, h2, at<float>(packed, L.f2_scale), N, hid, HW, a2b, a2l, s,
                                   shd ? (_Float16*)w.gsh : nullptr, sh_grad_scale));
             // (c) f.2 (1x1)
             if (fastw) {
                 GH_TRY(launch_wgrad_mfma(w.gh2, (long)hid * HW, h1, (long)hid * HW, w.partial, G.f2_w, N, HW, hid, hid, hid, hid,
-                                         0, s, train_sh_enabled() ? sh_grad_scale : 0.f));
+                                         0, s, train_sh_enabled(p) ? sh_grad_scale : 0.f));
             } else {
                 GH_TRY(launch_wgrad_direct(w.gh2, h1, (long)hid * HW, G.f2_w, N, hid, d.H, d.W, hid, 1, s));
             }
@@ -343,7 +344,7 @@ static int backward_sweep(glowhip_plan* p, const void* packed, const float* x_in
                 const int n0 = round_up(Ch * 9, 64);
                 GH_TRY(launch_shift_expand(out, chw, w.col, N, Ch, d.H, d.W, n0, +1, s));
                 GH_TRY(launch_wgrad_mfma(w.gh1, (long)hid * HW, w.col, (long)n0 * HW, w.partial, G.f0_w, N, HW, hid, n0, hid,
-                                         Ch * 9, 0, s, train_sh_enabled() ? sh_grad_scale : 0.f));
+                                         Ch * 9, 0, s, train_sh_enabled(p) ? sh_grad_scale : 0.f));
             } else {
                 GH_TRY(launch_wgrad_direct(w.gh1, out, chw, G.f0_w, N, Ch, d.H, d.W, hid, 3, s));
             }

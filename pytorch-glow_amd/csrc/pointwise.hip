@@ -509,4 +509,28 @@ int launch_finalize(const float* in, const unsigned long long* acc, const double
     return GLOWHIP_OK;
 }
 
+// Range / non-finite status of a finished call (glowhip_plan_status): one workgroup per sample
+__global__ void __launch_bounds__(256) k_status(const unsigned long long* __restrict__ acc, int N, const float* __restrict__ result,
+                                                long elems, int32_t* __restrict__ status) {
+    __shared__ int any;
+    const int n = blockIdx.x;
+    if (threadIdx.x == 0) any = 0;
+    __syncthreads();
+    int bad = 0;
+    if (result) {
+        const float* r = result + (long)n * elems;
+        for (long e = threadIdx.x; e < elems; e += 256) bad |= !isfinite(r[e]);
+    }
+    if (bad) any = 1;      // (benign race: every writer stores 1)
+    __syncthreads();
+    if (threadIdx.x == 0) status[n] = (int32_t)(acc[N + n] & 7ull) | (any ? 8 : 0);
+}
+
+int launch_status(const unsigned long long* acc, int N, const float* result, long elems, int32_t* status, hipStream_t s) {
+    if (N == 0) return GLOWHIP_OK;
+    hipLaunchKernelGGL(k_status, dim3(N), dim3(256), 0, s, acc, N, result, elems, status);
+    GH_LAUNCH_CHECK("k_status");
+    return GLOWHIP_OK;
+}
+
 }  // namespace glowhip

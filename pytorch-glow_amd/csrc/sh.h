@@ -125,6 +125,36 @@ __device__ __forceinline__ void sh2_split(float V, _Float16& hi, _Float16& lo) {
     hi = (_Float16)V;
     lo = (_Float16)(V - (float)hi);
 }
+// Four values at once with the packed conversion (v_cvt_pk_f16_f32: two values per instruction, round to nearest even like the
+// scalar conversion -- same bits as four sh2_split calls)
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void sh2_split4(const f32x4_t& V, h4& hi, h4& lo) {
+#pragma unroll
+    for (int t = 0; t < 4; t += 2) {
+        const f32x2_t vv = {V[t], V[t + 1]};
+        const h2 x = __builtin_convertvector(vv, h2);
+        // (v_fma_mix_f32 would fold the conversion back and the subtraction into one instruction -- 29.3 -> 23.8 cycles per
+        // value-wave in scripts/ubench/epi_split.hip -- but as inline asm it costs the level-1 instance of k_cnet, which sits at
+        // the 256-register limit, its allocation: the h2 hand-over went from 5 k to 32 k cycles.  Left to the compiler.)
+        const float r0 = V[t] - (float)x[0], r1 = V[t + 1] - (float)x[1];
+        const f32x2_t rr = {r0, r1};
+        const h2 y = __builtin_convertvector(rr, h2);
+        hi[t] = x[0]; hi[t + 1] = x[1]; lo[t] = y[0]; lo[t + 1] = y[1];
+    }
+}
+// ReLU on the BIT PATTERN of the NEGATED value (one v_min_i32 instead of compare + select), NaN-propagating like torch.relu
+// (common.h relu_).  k_cnet carries its activations negated: u = -t comes out of the epilogue's fma for free (negated row scale
+// and bias tables), and as signed integers
+//     u = -t with t > 0, t = +inf, or any NaN with its sign bit SET   ->  negative integer  ->  kept        (= -relu(t))
+//     u = -t with t < 0 (incl. t = -inf)                              ->  positive integer  ->  +0
+// so nrelu_bits(u) = -relu(t).  The negation then rides along for free: -h1 on the B side gives -(W2 h1) in the next
+// accumulator, whose epilogue again wants the negated value; the last stage multiplies by a negated row scale.  Every step is
+// an exact sign flip of what the positive chain computes (round-to-nearest is symmetric), so the results are the same bits.
+// NaNs: gfx950 GENERATES 0xffc00000 -- sign bit set -- on both the matrix pipe and the VALU (inf - inf, inf * 0, and NaN
+// operands in; scripts/ubench/epi_split.hip, measured), and NaNs that come in from memory are canonicalised to that pattern on
+// the way in (canon_nan), so every NaN inside the kernel has its sign bit set and survives.
+__device__ __forceinline__ float nrelu_bits(float u) { return __int_as_float(min(__float_as_int(u), 0)); }
+__device__ __forceinline__ float canon_nan(float v) { return v != v ? __uint_as_float(0xffc00000u) : v; }
 // Weight image of one convolution as the A operand: half [plane][Kp/8][M][8] (as above), then M floats rowscale, then M floats
 // bias:  out_scaled[o] = acc * rowscale[o] + bias[o]  is the layer output times SH2_ACT_SCALE (f.0, f.2: rowscale = 2^-e,
 // bias = b' * 16) or the plain value (f.4 rows: rowscale = 2^-e / 16, no bias).

@@ -51,9 +51,13 @@ class Inferer:
                 z = util.make_batch(z, self.batch_size)
             return self.graph(z=z.to(self.device), y_onehot=None, reverse=True)[0, :, :, :]
 
-    def compute_attribute_delta(self, dataset, samples_per_batch=None, shuffle=True, num_workers=None, world=1):
+    def compute_attribute_delta(self, dataset, samples_per_batch=None, shuffle=True, num_workers=None, world=1, _exact=False):
         """deltaz[c] = mean latent of the images with attribute c - mean latent of those without (inferer.py:104-153).
-        `dataset` yields dicts with 'x' (C,H,W) and 'y_onehot' (classes,)."""
+        `dataset` yields dicts with 'x' (C,H,W) and 'y_onehot' (classes,).
+
+        Range check without a host sync per batch: the encodes run unchecked on the product kernels, a device flag collects
+        "some nll was not finite", and it is read once with the sums at the end -- only then (an input beyond the fp16 pairs'
+        range) the pass is repeated with the plans on the exact-fp32 family."""
         from torch.utils.data import DataLoader
         shape = tuple(self.graph.flow.output_shapes[-1][1:])
         dim = int(np.prod(shape))
@@ -61,6 +65,7 @@ class Inferer:
         neg = torch.zeros_like(pos)
         n_pos = torch.zeros(self.num_classes, dtype=torch.float64, device=self.device)
         n_neg = torch.zeros_like(n_pos)
+        bad = torch.zeros((), dtype=torch.bool, device=self.device)
         loader = DataLoader(dataset, batch_size=self.batch_size, shuffle=shuffle, drop_last=True,
                             num_workers=self.hps.dataset.num_workers if num_workers is None else num_workers)
         with torch.no_grad():
@@ -68,7 +73,18 @@ class Inferer:
                 assert 'y_onehot' in batch.keys(), 'Compute attribute deltaz needs "y_onehot" in batch data'
                 x = batch['x'].to(self.device)
                 y = batch['y_onehot'].to(self.device)
-                z, _, _ = self.graph(x)
+                if hasattr(self.graph.flow, "plan_for"):
+                    plan = self.graph.flow.plan_for(x)
+                    fam = plan.family
+                    if _exact:
+                        plan.set_family(plan.FAMILY_EXACT_FP32)
+                    try:
+                        z, nll, _ = self.graph.normal_flow(x, None, safe=False)
+                    finally:
+                        plan.set_family(fam)
+                    bad |= ~torch.isfinite(nll).all()
+                else:                                               # (a graph without flow plans: the bookkeeping tests' stand-in)
+                    z, _, _ = self.graph(x)
                 take = len(batch) if samples_per_batch == "reference" else (samples_per_batch or x.shape[0])
                 zf = z[:take].reshape(take, dim).double()
                 has = (y[:take] > 0).double()                       # (take, classes)
@@ -77,11 +93,14 @@ class Inferer:
                 n_pos += has.sum(0)
                 n_neg += (1.0 - has).sum(0)
         if world > 1:                                               # ranks saw different batches: one exchange at the end
-            flat = torch.cat([pos.reshape(-1), neg.reshape(-1), n_pos, n_neg])
+            flat = torch.cat([pos.reshape(-1), neg.reshape(-1), n_pos, n_neg, bad.double().reshape(1)])
             dist.all_reduce(flat, op=dist.ReduceOp.SUM)
             k = self.num_classes * dim
             pos, neg = flat[:k].view(self.num_classes, dim), flat[k:2 * k].view(self.num_classes, dim)
-            n_pos, n_neg = flat[2 * k:2 * k + self.num_classes], flat[2 * k + self.num_classes:]
+            n_pos, n_neg = flat[2 * k:2 * k + self.num_classes], flat[2 * k + self.num_classes:2 * k + 2 * self.num_classes]
+            bad = flat[-1] > 0
+        if getattr(self.graph, "range_check", True) and not _exact and bool(bad):
+            return self.compute_attribute_delta(dataset, samples_per_batch, shuffle, num_workers, world, _exact=True)
         delta = pos / n_pos.clamp(min=1.0)[:, None] - neg / n_neg.clamp(min=1.0)[:, None]
         return delta.view(self.num_classes, *shape).cpu().numpy()
 

@@ -142,8 +142,11 @@ class FlowModel(nn.Module):
         ld = _logdet_arg(logdet, z.shape[0], z.device)
         return plan.encode(z, None, ld, want_logdet=ld is not None)
 
-    def decode(self, z, eps_std=None, eps=None):
-        """``eps``: optional list of injected draws, one per Split2d in decode order (deepest first)."""
+    _RANGE_FALLBACKS = 0
+
+    def decode(self, z, eps_std=None, eps=None, safe=False):
+        """``eps``: optional list of injected draws, one per Split2d in decode order (deepest first).  ``safe``: see
+        Glow.reverse_flow."""
         z = require_device_tensor(z, "FlowModel latent")
         n = z.shape[0]
         c, h, w = z.shape[1:]
@@ -151,7 +154,16 @@ class FlowModel(nn.Module):
         plan = self._plans.get(list(self.layers), self._input_chw_for_latent((c, h, w)), z.device)
         if eps is None:
             eps = self.draw_eps(n, plan, eps_std, z.device)
-        x, _ = plan.decode(z, [require_device_tensor(e, "eps") for e in eps], None, want_logdet=False)
+        eps = [require_device_tensor(e, "eps") for e in eps]
+        x, _ = plan.decode(z, eps, None, want_logdet=False)
+        if safe and bool(plan.status(n, x).any()):       # out of the fp16 pairs' range somewhere: the exact-fp32 kernels, same draws
+            FlowModel._RANGE_FALLBACKS += 1
+            prev = plan.family
+            plan.set_family(plan.FAMILY_EXACT_FP32)
+            try:
+                x, _ = plan.decode(z, eps, None, want_logdet=False)
+            finally:
+                plan.set_family(prev)
         return x
 
     def _input_chw_for_latent(self, chw):
@@ -268,7 +280,7 @@ class Glow(nn.Module):
                 noise = torch.empty(x.shape, dtype=torch.float32, device=x.device).uniform_(0, 1. / 2 ** n_bits)
             else:     # inference: the leading squeeze draws it (Philox keyed by torch's seed; no noise tensor, no RNG launch)
                 in_kernel_rng = True
-                plan.set_dequant_rng(torch.initial_seed(), True)
+                rng_call = plan.set_dequant_rng(torch.initial_seed(), True)     # the call number this forward will draw with
         else:
             noise = require_device_tensor(noise, "noise")
             assert noise.shape == x.shape
@@ -290,24 +302,29 @@ class Glow(nn.Module):
             return z, nll, None
         z, nll, _ = plan.glow_forward(x, noise, mean, logs, stride, n_bits, repack=repack)
         if safe and not bool(torch.isfinite(nll).all()):
-            z, nll = self._forward_exact_fp32(plan, x, noise, mean, logs, stride, n_bits)
+            if in_kernel_rng:     # the re-run sees the same dequantisation draw as the flagged run
+                noise = plan.dequant_noise(x.shape, torch.initial_seed(), rng_call, n_bits)
+            z, nll = self._forward_exact_fp32(plan, x.float() / 255.0 if x.dtype == torch.uint8 else x, noise, mean, logs, stride, n_bits)
         return z, nll, None
 
     _RANGE_FALLBACKS = 0   # how often safe=True had to re-run on the exact-fp32 kernels (diagnostics / tests)
 
     def _forward_exact_fp32(self, plan, x, noise, mean, logs, stride, n_bits):
-        """The same forward on the exact-fp32 MFMA kernels (v_mfma_f32_32x32x2_f32): no fp16 range limit.  Process-wide kernel
-        switch (glowhip_debug_force_tail_tile), so not for concurrent use from several threads."""
+        """The same forward on the exact-fp32 MFMA kernels (v_mfma_f32_32x32x2_f32): no fp16 range limit.  The kernel family is
+        a property of the plan (glowhip_plan_set_family), set for this one call: nothing process-wide is touched, the product
+        kernels' weight images stay valid for the next call."""
         Glow._RANGE_FALLBACKS += 1
-        _lib.lib().glowhip_debug_force_tail_tile(0x800)
+        prev = plan.family
+        plan.set_family(plan.FAMILY_EXACT_FP32)
         try:
-            z, nll, _ = plan.glow_forward(x, noise, mean, logs, stride, n_bits, repack=True)
+            z, nll, _ = plan.glow_forward(x, noise, mean, logs, stride, n_bits)
         finally:
-            _lib.lib().glowhip_debug_force_tail_tile(0)
-            plan.invalidate()          # the next call re-derives the product kernels' weight images
+            plan.set_family(prev)
         return z, nll
 
-    def reverse_flow(self, z, y_onehot=None, eps_std=None, eps=None):
+    def reverse_flow(self, z, y_onehot=None, eps_std=None, eps=None, safe=False):
+        """``safe=True``: the decode's range status (glowhip_plan_status: sticky log-det flags | a non-finite pixel) is read back
+        -- one host sync -- and a flagged batch is decoded again on the exact-fp32 kernels with the same eps draws."""
         with torch.no_grad():
             if z is None:
                 mean, logs = self.prior(y_onehot)
@@ -315,12 +332,20 @@ class Glow(nn.Module):
                     c2, h, w = self.h_top.shape[1:]
                     mean = logs = torch.zeros((self.batch_h_top, c2 // 2, h, w), device=self.h_top.device)
                 z = module.GaussianDiag.sample(mean, logs, eps_std)
-            return self.flow.decode(z, eps_std=eps_std, eps=eps)
+            return self.flow.decode(z, eps_std=eps_std, eps=eps, safe=safe)
+
+    # Range policy of ``forward`` -- the call the reference's Trainer / Inferer make (network/trainer.py:113,123,163,171,
+    # inferer.py:55,81,98,133).  Under torch.no_grad() in eval mode (validation, sampling, Inferer) the checked path is the default:
+    # the result is the reference's for every input the reference handles, at the price of one host sync per call -- which those
+    # callers pay anyway when they take the result to the host.  ``Glow.range_check = False`` (class or instance) switches it off;
+    # benchmarks call normal_flow / reverse_flow directly (safe=False).  Training steps are checked by training.TrainLoop.
+    range_check = True
 
     def forward(self, x=None, y_onehot=None, z=None, eps_std=None, reverse=False):
+        safe = bool(self.range_check) and not self.training and not torch.is_grad_enabled()
         if not reverse:
-            return self.normal_flow(x, y_onehot)
-        return self.reverse_flow(z, y_onehot, eps_std)
+            return self.normal_flow(x, y_onehot, safe=safe)
+        return self.reverse_flow(z, y_onehot, eps_std, safe=safe)
 
     @staticmethod
     def generative_loss(nll):

@@ -51,12 +51,29 @@ def _writer(log_dir):
         return _ScalarLog(log_dir)
 
 
-class Trainer:
-    criterion_dict = {
-        'single_class': lambda y_logits, y: Glow.single_class_loss(y_logits, y),
-        'multi_class': lambda y_logits, y_onehot: Glow.single_class_loss(y_logits, y_onehot)
-    }
+class _ShardSampler(torch.utils.data.Sampler):
+    """Indices of rank `rank`'s shard of every global batch: one seeded permutation per epoch (the same on every rank), cut
+    into global batches of `global_batch`, of which this rank yields positions [rank*per, (rank+1)*per)."""
 
+    def __init__(self, dataset, global_batch, rank, world, seed=0):
+        assert global_batch % world == 0, f"global batch {global_batch} not divisible by {world} ranks"
+        self.n, self.gb, self.rank, self.world, self.seed, self.epoch = len(dataset), global_batch, rank, world, seed, 0
+        self.per = global_batch // world
+
+    def __len__(self):
+        return (self.n // self.gb) * self.per
+
+    def __iter__(self):
+        g = torch.Generator()
+        g.manual_seed(self.seed * 1000003 + self.epoch)
+        self.epoch += 1
+        perm = torch.randperm(self.n, generator=g)
+        nb = self.n // self.gb
+        shard = perm[:nb * self.gb].view(nb, self.gb)[:, self.rank * self.per:(self.rank + 1) * self.per]
+        return iter(shard.reshape(-1).tolist())
+
+
+class Trainer:
     def __init__(self, hps, result_subdir, step, graph, optimizer, scheduler, devices, dataset, data_device,
                  rank=0, world=1):
         self.hps = hps
@@ -71,15 +88,20 @@ class Trainer:
         self.data_device = data_device
         self.batch_size = self.hps.optim.num_batch_train
         self.num_classes = self.hps.dataset.num_classes
-        self.data_loader = DataLoader(dataset, batch_size=self.batch_size, num_workers=self.hps.dataset.num_workers,
-                                      shuffle=True, drop_last=True)
+        # One process per GPU: every rank loads ONLY its shard of each global batch.  All ranks shuffle with the same seeded
+        # generator (profile seed), so the global batch of a step is the same set of samples on every rank and rank r keeps
+        # positions [r*B/G, (r+1)*B/G) of it -- no overlap, no omission, no G-fold loading.
+        self.data_loader = DataLoader(dataset, batch_size=self.batch_size // world, num_workers=self.hps.dataset.num_workers,
+                                      sampler=_ShardSampler(dataset, self.batch_size, rank, world,
+                                                            seed=int(getattr(self.hps.ablation, "seed", 0) or 0)),
+                                      drop_last=True)
         self.num_epochs = (self.hps.optim.num_epochs + len(self.data_loader) - 1) // len(self.data_loader)
         self.y_condition = self.hps.ablation.y_condition
         if self.y_condition:
             raise NotImplementedError("class-conditional training (y_condition) is outside the flow hot path")
         self.max_grad_clip = self.hps.ablation.max_grad_clip
         self.max_grad_norm = self.hps.ablation.max_grad_norm
-        self.writer = _writer(self.result_subdir)
+        self.writer = _writer(self.result_subdir) if rank == 0 else _ScalarLog(self.result_subdir)   # rank 0 alone writes logs
         self.interval_scalar = self.hps.optim.interval_scalar
         self.interval_snapshot = self.hps.optim.interval_snapshot
         self.interval_valid = self.hps.optim.interval_valid
@@ -107,7 +129,7 @@ class Trainer:
             for idx, batch in enumerate(tqdm(self.data_loader)):
                 for i in batch:
                     batch[i] = batch[i].to(self._device())       # the flow runs on this rank's GPU only
-                x = parallel.shard_batch(batch['x'], self.world, self.rank) if self.world > 1 else batch['x']
+                x = batch['x']                                   # already this rank's shard (_ShardSampler)
                 loss, grad_norm = self.loop.step(x.float().contiguous())
                 lr = self.loop.lr
                 self.last_loss = loss
@@ -117,6 +139,8 @@ class Trainer:
                     self.writer.add_scalar('loss/generative_loss', loss, self.step)
                     if self.max_grad_norm is not None and self.max_grad_norm > 0:
                         self.writer.add_scalar("grad_norm/grad_norm", grad_norm, self.step)
+                if self.step % self.interval_snapshot == 0 and self.step > 0:
+                    self.loop.flush()                            # (collective when it re-runs a step: every rank, not just 0)
                 if self.step % self.interval_snapshot == 0 and self.step > 0 and self.rank == 0:
                     util.save_model(result_subdir=self.result_subdir, step=self.step, graph=self.graph, optimizer=self.optimizer,
                                     seconds=time.time() - self.start_time, is_best=True)
@@ -141,6 +165,7 @@ class Trainer:
                     break
             if max_steps is not None and done >= max_steps:
                 break
+        self.loop.flush()
         if self.rank == 0:
             self.writer.export_scalars_to_json(os.path.join(self.result_subdir, "all_scalars.json"))
         self.writer.close()

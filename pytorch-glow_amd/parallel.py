@@ -108,10 +108,11 @@ def allreduce_gradients(module: torch.nn.Module, world: Optional[int] = None, av
 
 
 def train_step(glow, optimizer, x_local: torch.Tensor, world: int = 1, max_grad_clip: float = 0.0,
-               max_grad_norm: float = 0.0) -> Tuple[torch.Tensor, torch.Tensor]:
+               max_grad_norm: float = 0.0, skip_nonfinite: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
     """One data-parallel training step of the reference's loop (network/trainer.py:123-150) on this rank's shard:
     forward (HIP, with tape) -> loss = mean(nll) -> backward (HIP reverse sweep) -> gradient all-reduce (RCCL) ->
     clip_grad_value_ / clip_grad_norm_ -> optimizer.step().  Returns (global mean loss, gradient norm).
+    ``skip_nonfinite`` (HIP optimisers): a NaN / inf gradient norm skips the update on the device (training.TrainLoop's range check).
     The local loss is mean over the LOCAL shard; averaging the gradients over ranks makes it the global mean."""
     optimizer.zero_grad(set_to_none=True)
     with torch.enable_grad():
@@ -120,7 +121,7 @@ def train_step(glow, optimizer, x_local: torch.Tensor, world: int = 1, max_grad_
         loss.backward()
     allreduce_gradients(glow, world)
     if hasattr(optimizer, "fused_step"):     # training.HipAdam / HipAdamax: both clippings + the update in two HIP launches
-        grad_norm = optimizer.fused_step(max_grad_clip, max_grad_norm)
+        grad_norm = optimizer.fused_step(max_grad_clip, max_grad_norm, skip_nonfinite=skip_nonfinite)
     else:
         params = [p for p in glow.parameters() if p.grad is not None]
         if max_grad_clip and max_grad_clip > 0:

@@ -65,6 +65,8 @@ class _HipOptimizer(torch.optim.Optimizer):
             off += n
         self._flat = (m, v)
         self._partial = None
+        self._table_key = None       # the cached chunk table points into the previous state buffers
+        self._keep = None
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
@@ -74,7 +76,9 @@ class _HipOptimizer(torch.optim.Optimizer):
         self._ensure_state()
 
     @torch.no_grad()
-    def fused_step(self, max_grad_clip=0.0, max_grad_norm=0.0):
+    def fused_step(self, max_grad_clip=0.0, max_grad_norm=0.0, skip_nonfinite=False):
+        """``skip_nonfinite``: a NaN / inf total gradient norm leaves parameters and state untouched ON THE DEVICE (no host sync);
+        the caller finds out from the returned norm when it next looks (``undo_step`` then takes the step count back)."""
         self._ensure_state()
         group0 = self.param_groups[0]
         dev = group0["params"][0].device
@@ -99,7 +103,9 @@ class _HipOptimizer(torch.optim.Optimizer):
         norm = torch.zeros(1, device=dev)
         if not chunks:
             return norm[0]
-        key = hash(tuple(c[1] for c in chunks))       # the caching allocator usually hands the gradients the same addresses again
+        # the caching allocator usually hands the gradients the same addresses again; the table also holds the parameter and the
+        # two state addresses, so ALL of them key the cache (a reloaded state or a re-allocated parameter must not reuse it)
+        key = hash(tuple(chunks))
         if getattr(self, "_table_key", None) == (key, len(chunks)):
             table = self._keep
         else:
@@ -112,7 +118,7 @@ class _HipOptimizer(torch.optim.Optimizer):
         _lib.check(_lib.lib().glowhip_optim_step(
             _lib.ptr(table), len(chunks), self.KIND, float(group0["lr"]), float(group0["betas"][0]), float(group0["betas"][1]),
             float(group0["eps"]), float(group0["weight_decay"]), self._steps, float(max_grad_clip or 0.0), float(max_grad_norm or 0.0),
-            _lib.ptr(self._partial), _lib.ptr(norm), _lib.stream_ptr(dev)))
+            _lib.ptr(self._partial), _lib.ptr(norm), int(bool(skip_nonfinite)), _lib.stream_ptr(dev)))
         self._keep = table      # alive until the stream has consumed it (the next step replaces it)
         for g in self.param_groups:            # the kernel wrote the parameters behind torch's back: bump their version counters,
             for p in g["params"]:              # which is what tells the flow plans to re-derive their packed weight images
@@ -124,6 +130,13 @@ class _HipOptimizer(torch.optim.Optimizer):
         loss = closure() if closure is not None else None
         self.fused_step(0.0, 0.0)
         return loss
+
+    def undo_step(self):
+        """Take back the count of a step the device skipped (fused_step(skip_nonfinite=True) with a non-finite norm)."""
+        self._steps = max(self._steps - 1, 0)
+        for st in self.state.values():
+            if "step" in st:
+                st["step"] = torch.tensor(float(self._steps))
 
 
 class HipAdam(_HipOptimizer):
@@ -170,8 +183,20 @@ class TrainLoop:
     """The state the reference's ``Trainer`` carries from step to step, minus its I/O: model, optimiser, schedule, step
     counter, clipping thresholds (trainer.py:44-60).  ``step(x_local)`` runs one iteration on this rank's shard."""
 
-    def __init__(self, glow, hps, rank: int = 0, world: int = 1, optimizer: Optional[torch.optim.Optimizer] = None):
+    def __init__(self, glow, hps, rank: int = 0, world: int = 1, optimizer: Optional[torch.optim.Optimizer] = None,
+                 range_check: bool = True):
+        """``range_check``: the training forward carries h1 as fp16 pairs through f.2 (|v| < 65504; the reference's fp32 has no
+        such limit).  With the check on, a step whose gradient norm comes out non-finite is SKIPPED on the device (csrc/optim.hip:
+        parameters and optimiser state untouched, no host sync); the host looks at the norm one step later -- when that step's
+        work is already queued, so nothing stalls -- and runs the skipped batch again with the plan on the exact-fp32 family
+        (the batch order changes by one; a norm that is non-finite there too is the model's own divergence and is left to the
+        caller, counted in ``diverged_steps``)."""
         self.glow, self.hps, self.rank, self.world = glow, hps, rank, world
+        self.range_check = range_check
+        self.range_fallbacks = 0
+        self.diverged_steps = 0
+        self._pending = None
+        self._host = None
         self.optimizer = optimizer or build_optimizer(hps, glow.parameters())
         self.scheduler = build_scheduler(hps)
         self.max_grad_clip = hps.ablation.get("max_grad_clip", 0)      # trainer.py:58-59
@@ -188,7 +213,51 @@ class TrainLoop:
         self.lr = self.scheduler(global_step=self.global_step)
         for group in self.optimizer.param_groups:           # trainer.py:89-91
             group["lr"] = self.lr
+        checked = self.range_check and hasattr(self.optimizer, "undo_step") and x_local.is_cuda
         loss, grad_norm = parallel.train_step(self.glow, self.optimizer, x_local, world=self.world,
-                                              max_grad_clip=self.max_grad_clip, max_grad_norm=self.max_grad_norm)
+                                              max_grad_clip=self.max_grad_clip, max_grad_norm=self.max_grad_norm,
+                                              skip_nonfinite=checked)
         self.global_step += 1
+        if checked:
+            prev, self._pending = self._pending, self._stash(x_local, grad_norm)
+            if prev is not None:
+                self._resolve(prev)
         return loss, grad_norm
+
+    # ---- deferred range check (no host sync on the step's own work)
+    def _stash(self, x_local, grad_norm):
+        if self._host is None:       # two pinned words, used alternately
+            self._host = [torch.zeros(1, pin_memory=True), torch.zeros(1, pin_memory=True)]
+        host = self._host[self.global_step & 1]
+        host.copy_(grad_norm.detach().reshape(1), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return x_local, host, ev
+
+    def _resolve(self, pending):
+        x_local, host, ev = pending
+        ev.synchronize()                        # that step's norm has landed (its successor is already queued behind it)
+        if bool(torch.isfinite(host).all()):
+            return
+        # the device skipped that update: take the count back and run the batch again on the exact-fp32 kernels
+        self.optimizer.undo_step()
+        self.range_fallbacks += 1
+        plan = self.glow.flow.plan_for(x_local)
+        prev = plan.family
+        plan.set_family(plan.FAMILY_EXACT_FP32)
+        try:
+            loss, grad_norm = parallel.train_step(self.glow, self.optimizer, x_local, world=self.world,
+                                                  max_grad_clip=self.max_grad_clip, max_grad_norm=self.max_grad_norm,
+                                                  skip_nonfinite=True)
+        finally:
+            plan.set_family(prev)
+        if not bool(torch.isfinite(grad_norm).all()):      # (a sync, on a path that only runs after an overflow)
+            self.optimizer.undo_step()
+            self.diverged_steps += 1
+        self.last_rerun = (loss, grad_norm)
+
+    def flush(self):
+        """Resolve the check of the last step (call before reading parameters for a snapshot, and at the end of training)."""
+        pending, self._pending = self._pending, None
+        if pending is not None:
+            self._resolve(pending)

@@ -28,7 +28,7 @@ def test_header_cites_reference_for_every_entry_point():
 def test_library_builds_and_loads():
     assert os.path.exists(_lib.build()), "libglowhip.so missing after build"
     lib = G.lib()
-    assert lib.glowhip_version() == 101
+    assert lib.glowhip_version() == 102
     assert lib.glowhip_last_error() is not None
 
 

@@ -241,6 +241,79 @@ def test_nan_input_gives_nan_nll_on_every_path():
         assert (nll[[0, 1, 3]] - nll_ref[[0, 1, 3]]).abs().max() < 1e-4
 
 
+def test_nan_of_either_sign_survives_the_integer_relu():
+    """k_cnet's ReLU is one integer min on the negated value (sh.h nrelu_bits), which keeps NaNs whose sign bit is set -- what gfx950
+    generates; NaNs from memory are canonicalised on the way in.  A NaN pixel of EITHER sign, placed in z1 and in z2, must still give
+    a NaN nll for its sample only."""
+    cfg, sd, x, noise, _, nll_ref = _range_case(1.0)
+    for bits in (0x7fc00000, 0xffc00000, 0x7f800001):
+        for ch in (0, 1, 2):
+            xx = x.clone()
+            xx.view(torch.int32)[1, ch, 3, 4] = torch.tensor(bits - (1 << 32) if bits >= 1 << 31 else bits, dtype=torch.int32)
+            glow = make_glow(cfg, sd, 4)
+            _, nll, _ = glow.normal_flow(dev(xx), None, noise=dev(noise))
+            nll = nll.cpu()
+            assert torch.isnan(nll[1]) and torch.isfinite(nll[[0, 2, 3]]).all(), (hex(bits), ch, nll)
+
+
+def test_kernel_family_is_a_property_of_the_plan():
+    """glowhip_plan_set_family: two plans in one process on different families, no process-wide switch.  The
+    exact-fp32 plan launches no split-half kernel and handles the overflowing input; the other plan keeps running k_cnet; switching a
+    plan back needs no re-pack of the product images."""
+    cfg, sd, x, noise, z_ref, nll_ref = _range_case(3e5)
+    ga, gb = make_glow(cfg, sd, 4), make_glow(cfg, sd, 4)
+    pa, pb = ga.flow.plan_for(dev(x)), gb.flow.plan_for(dev(x))
+    pb.set_family(pb.FAMILY_EXACT_FP32)
+    assert pa.family == pa.FAMILY_AUTO and pb.family == pb.FAMILY_EXACT_FP32
+    pa.launch_counts(reset=True); pb.launch_counts(reset=True)
+    _, nll_a, _ = ga.normal_flow(dev(x), None, noise=dev(noise))
+    zb, nll_b, _ = gb.normal_flow(dev(x), None, noise=dev(noise))
+    ca, cb = pa.launch_counts(), pb.launch_counts()
+    assert ca.get("k_cnet", 0) == 1 and "k_cnet" not in cb and not any(k.endswith("_sh") or "_sh+" in k for k in cb), (ca, cb)
+    assert not torch.isfinite(nll_a).all()
+    close(nll_b, nll_ref, 1e-4, what="nll (exact-fp32 plan)"); close(zb, z_ref, 1e-4, what="z (exact-fp32 plan)")
+    # back to the product family: same bits as a plan that never left it
+    cfgm, sdm, xm, noisem, zm_ref, nllm_ref = _range_case(1.0)
+    g1, g2 = make_glow(cfgm, sdm, 4), make_glow(cfgm, sdm, 4)
+    p2 = g2.flow.plan_for(dev(xm))
+    p2.set_family(p2.FAMILY_EXACT_FP32); g2.normal_flow(dev(xm), None, noise=dev(noisem)); p2.set_family(p2.FAMILY_AUTO)
+    z1, n1, _ = g1.normal_flow(dev(xm), None, noise=dev(noisem))
+    z2, n2, _ = g2.normal_flow(dev(xm), None, noise=dev(noisem))
+    assert torch.equal(z1, z2) and torch.equal(n1, n2)
+    close(n1, nllm_ref, 1e-4, what="nll (in range)")
+
+
+def test_decode_overflow_is_flagged_and_the_checked_path_recovers():
+    """Glow.reverse_flow has no nll that would show an fp16-range overflow: glowhip_plan_status returns a per-sample flag word with
+    x (sticky log-det flags | a non-finite pixel).  A decode through hidden activations of ~3e5: the product path's x is flagged
+    for every sample (and is non-finite there, never finite and wrong); safe=True -- what Glow.forward(reverse=True) does in eval --
+    decodes again on the exact-fp32 kernels and returns the oracle's x."""
+    cfg, sd, x, noise, z_ref, nll_ref = _range_case(3e5)
+    x_ref = O.glow_reverse(z_ref, sd, cfg, [])
+    glow = make_glow(cfg, sd, 4)
+    plan = glow.flow.plan_for(dev(x))
+    xd = glow.reverse_flow(dev(z_ref), None, None, eps=[])
+    st = plan.status(4, xd).cpu()
+    assert (st != 0).all(), st
+    bad = ~torch.isfinite(xd).cpu().flatten(1).all(1)
+    fin = torch.isfinite(xd).cpu()
+    assert bad.all() and ((xd.cpu() - x_ref).abs()[fin] < 1e-4).all(), "a flagged sample may hold non-finite pixels, never finite wrong ones"
+    n0 = G.FlowModel._RANGE_FALLBACKS
+    glow.eval()
+    with torch.no_grad():
+        xs = glow(z=dev(z_ref), y_onehot=None, eps_std=None, reverse=True)        # the reference's call: checked by default
+    assert G.FlowModel._RANGE_FALLBACKS == n0 + 1 and plan.family == plan.FAMILY_AUTO
+    close(xs, x_ref, 1e-4, what="x after the exact-fp32 re-run")
+    # in range: status 0, no fall-back, same bits with and without the check
+    cfgm, sdm, xm, noisem, zm_ref, _ = _range_case(1.0)
+    gm = make_glow(cfgm, sdm, 4)
+    xa = gm.reverse_flow(dev(zm_ref), None, None, eps=[])
+    assert int(gm.flow.plan_for(dev(xm)).status(4, xa).abs().sum()) == 0
+    xb = gm.reverse_flow(dev(zm_ref), None, None, eps=[], safe=True)
+    assert G.FlowModel._RANGE_FALLBACKS == n0 + 1 and torch.equal(xa, xb)
+    close(xa, O.glow_reverse(zm_ref, sdm, cfgm, []), 1e-4, what="x (in range)")
+
+
 # ------------------------------------------------------------------------------------------------ configs D and E at full size
 @pytest.mark.parametrize("name,image,L,K,batch", [("D", 128, 4, 48, 32), ("E", 256, 6, 32, 16)])
 def test_full_size_properties_configs_d_e(name, image, L, K, batch):

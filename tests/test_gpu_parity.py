@@ -46,7 +46,7 @@ def load_sd(mod, sd, strict=True):
 
 
 def test_library_loaded_and_no_cpu_fallback():
-    assert G.lib().glowhip_version() == 101
+    assert G.lib().glowhip_version() == 102
     with pytest.raises(G.GlowHipError):
         G.ActNorm(4)(torch.zeros(1, 4, 2, 2))  # CPU tensor: must raise, not fall back
 
@@ -449,6 +449,28 @@ def test_mfma_flowstep_vs_oracle(c, h, w, hidden, coup, n):
     close(z, zr, 2e-5, what="fwd z"); ld_close(ldz, ldr)
     xi, ldi = st(dev(x), dev(ld), reverse=True)
     xr, ldxr = O.flowstep(x, ld, sd, "", "invconv", coup, reverse=True)
+    close(xi, xr, 5e-5, what="rev x"); ld_close(ldi, ldxr)
+
+
+@pytest.mark.parametrize("c", [100, 104, 112])
+def test_additive_step_wider_than_the_fused_mixer_both_directions(c):
+    """additive coupling with 96 < C <= 112 still runs k_cnet (Cout = C/2 <= 56) but is wider than the finishing kernel's
+    fused mixer.  Forward and reverse must take the SAME kernel family (the reverse used to fall back to the round-1 pairs, whose
+    weight images the decode pack does not write): both checked against the oracle, k_cnet asserted from the launch counters."""
+    st, sd = _rand_step(c, 128, "additive", seed=c)
+    x = torch.randn(3, c, 8, 8, generator=torch.Generator().manual_seed(1))
+    ld = torch.randn(3, generator=torch.Generator().manual_seed(2))
+    plan = st._plan(dev(x))
+    plan.launch_counts(reset=True)
+    z, ldz = st(dev(x), dev(ld))
+    cf = plan.launch_counts(reset=True)
+    xi, ldi = st(dev(x), dev(ld), reverse=True)
+    cr = plan.launch_counts(reset=True)
+    assert cf.get("k_cnet") == 1 and cr.get("k_cnet") == 1 and cr.get("k_chanmix") == 1, (cf, cr)
+    assert not any(k.endswith("_sh") or k.endswith("_f32") for k in list(cf) + list(cr)), (cf, cr)
+    zr, ldr = O.flowstep(x, ld, sd, "", "invconv", "additive")
+    close(z, zr, 2e-5, what="fwd z"); ld_close(ldz, ldr)
+    xr, ldxr = O.flowstep(x, ld, sd, "", "invconv", "additive", reverse=True)
     close(xi, xr, 5e-5, what="rev x"); ld_close(ldi, ldxr)
 
 
