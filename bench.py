@@ -126,6 +126,109 @@ def cpu_baseline(glow, x_cpu, cfg, budget_s=30.0):
                       f"model/weights as the GPU run, fp32, torch CPU threads={cores}; oracle/glow_oracle.py"}
 
 
+# ------------------------------------------------------------------------------------------------ workloads
+def setup_workload(G, util, parallel, device, cfg_name, mode, B, rank, world, repack, graph=False):
+    """Model + synthetic batch + one-step closure of a (config, mode) workload; sets torch's grad mode for it."""
+    import torch
+    cfg = CONFIGS[cfg_name]
+    glow, hps = build_model(G, util, device, cfg, B)
+    x = torch.rand(B, 3, cfg["image"], cfg["image"], generator=torch.Generator().manual_seed(2384 + rank)).to(device)
+    # data-dependent ActNorm init on rank 0's first batch, then broadcast (reference trainer.py:112-115)
+    glow.train()
+    with torch.no_grad():       # (the init pass needs no activation tape)
+        parallel.data_dependent_init(glow, x, rank=rank, world=world)
+    glow.eval()
+    plan = glow.flow.plan_for(x)
+    wl = dict(glow=glow, hps=hps, plan=plan, x=x, cfg=cfg)
+    if mode == "inverse":
+        wl["z_top"] = z_top = torch.randn((B,) + tuple(plan.out_chw), device=device) * 0.7
+    if mode == "train":
+        from pytorch_glow_amd import training
+        loop = training.TrainLoop(glow, hps, rank=rank, world=world)   # Adam + noam warm-up + clip 5/100 (celeba profile)
+        wl["loop"] = loop
+        torch.set_grad_enabled(True)
+    else:
+        torch.set_grad_enabled(False)   # forward+logdet metric: inference path (no activation tape)
+
+    def step():
+        if mode == "train":     # secondary metric: the reference's training step (trainer.py:123-150)
+            loss, _ = loop.step(x)
+            return loss * (world * B)
+        if mode == "inverse":   # secondary metric: sampling (eps drawn on device, W^-1 from the in-kernel LU)
+            plan.ensure_packed(repack, use=plan.PACK_INFERENCE | plan.PACK_INVERSE)
+            xs = glow.reverse_flow(z_top, None, eps_std=0.7)
+            return xs.sum()
+        if wl["graph"] is not None:   # the whole forward (noise draw + pack + launch list) as ONE hipGraph launch
+            z, nll = wl["graph"]()
+        else:
+            z, nll, _ = glow.normal_flow(x, None, repack=repack)
+        return parallel.reduce_loss(nll, world)
+    wl["step"] = step
+    wl["graph"], wl["launch"] = None, "eager (one C call per forward issuing the kernel list)"
+    if graph and mode == "forward":
+        try:
+            wl["graph"] = glow.capture_forward(x, repack=repack)
+            wl["launch"] = "hipGraph (forward captured once, one graph launch per step)"
+        except Exception as e:     # capture is an optimisation of the host side only: the eager launch list is the same work
+            wl["launch"] += f"; hipGraph capture failed: {type(e).__name__}: {str(e)[:200]}"
+    return wl
+
+
+SECONDARY = [("D", ["forward"]), ("E", ["forward", "inverse"]), ("B", ["train"])]
+
+
+def secondary_workloads(G, util, parallel, device, steps=3, warmup=2):
+    """The other BASELINE configurations under the SAME process and clock as the headline line, AFTER its timed region (nothing
+    of this is in `value` / `ms_per_step`): a few timed steps each of configs[3] (D) and configs[4] (E) forward, E sampling
+    (reverse_flow, derived data kept across steps as when sampling from a trained model) and the config-B training step.  One
+    GPU, per-GPU batches of SURVEY.md section 8; rates are images/sec of this one GPU."""
+    import gc
+    import torch
+    out = {}
+    for cfg_name, modes in SECONDARY:
+        cfg = CONFIGS[cfg_name]
+        B = cfg["batch"]
+        wl = None
+        for mode in modes:
+            t_wall = time.perf_counter()
+            if wl is None or mode == "train":
+                wl = setup_workload(G, util, parallel, device, cfg_name, mode, B, 0, 1, repack=(mode == "forward"))
+                step = wl["step"]
+            else:       # the same model and batch in another mode (config E: forward, then sampling)
+                plan, glow = wl["plan"], wl["glow"]
+                z_top = torch.randn((B,) + tuple(plan.out_chw), device=device) * 0.7
+
+                def step():
+                    plan.ensure_packed(False, use=plan.PACK_INFERENCE | plan.PACK_INVERSE)
+                    return glow.reverse_flow(z_top, None, eps_std=0.7).sum()
+            for _ in range(warmup):
+                step()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0 = time.perf_counter()
+            e0.record()
+            for _ in range(steps):
+                last = step()
+            e1.record()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            if "loop" in wl:
+                wl["loop"].flush()
+            name = f"{cfg_name}_{mode}"
+            out[name] = {"value": round(B * steps / dt, 2), "unit": "images/sec", "ms_per_step": round(1e3 * dt / steps, 3),
+                         "ms_per_step_gpu_events": round(e0.elapsed_time(e1) / steps, 3), "steps": steps, "warmup": warmup, "batch": B,
+                         "workload": f"{cfg['label']}, {mode}, batch {B} ({cfg['ref']})",
+                         "finite": bool(torch.isfinite(last).all()),
+                         "kernel_families": sorted(wl["plan"].launch_counts(reset=True)),
+                         "wall_s_incl_setup": round(time.perf_counter() - t_wall, 1)}
+            del last
+        del wl, step
+        gc.collect()
+        torch.cuda.empty_cache()
+    torch.set_grad_enabled(False)
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ rank launcher
 def free_port():
     s = socket.socket()
@@ -143,6 +246,10 @@ def spawn_ranks(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=port,
                    GLOWHIP_BENCH_CHILD="1")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # N ranks share this host's cores: each child gets its share for OpenMP / torch's intra-op pool instead of every child
+        # sizing its pool to the whole machine (8 x 256 threads in a 16-core cgroup would turn the enqueue loop host-bound)
+        env.setdefault("OMP_NUM_THREADS", str(max(1, usable_cores(cap=256) // n)))
+        env.setdefault("MKL_NUM_THREADS", env["OMP_NUM_THREADS"])
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     rc = 0
     pending = dict(enumerate(procs))
@@ -208,6 +315,10 @@ def main():
                     "D = configs[3] (128x128 L=4 K=48), E = configs[4] (256x256 L=6 K=32)")
     ap.add_argument("--batch", type=int, default=0, help="images per GPU (default: the config's: 64 / 32 / 16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="forward mode: issue the kernel list eagerly every step instead of "
+                    "replaying the captured hipGraph")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the `secondary` workloads (configs D / E, sampling, training "
+                    "step) that the default one-GPU headline run appends to its JSON line")
     ap.add_argument("--no-repack", action="store_true", help="inference mode: keep derived parameter data across steps")
     ap.add_argument("--repack", action="store_true", help="inverse mode: re-derive the parameter data (W^-1, weight images) every step "
                     "as well (default there: once -- sampling from a trained model)")
@@ -226,6 +337,8 @@ def main():
 
     import torch
     import torch.distributed as dist
+    if env_world > 1 and os.environ.get("OMP_NUM_THREADS"):
+        torch.set_num_threads(int(os.environ["OMP_NUM_THREADS"]))
 
     rank = int(os.environ.get("RANK", "0"))
     world = env_world
@@ -250,35 +363,10 @@ def main():
         G.lib().glowhip_debug_force_tail_tile(dbg)
     cfg = CONFIGS[args.config]
     B = args.batch or cfg["batch"]
-    glow, hps = build_model(G, util, device, cfg, B)
-    x = torch.rand(B, 3, cfg["image"], cfg["image"], generator=torch.Generator().manual_seed(2384 + rank)).to(device)
-
-    # data-dependent ActNorm init on rank 0's first batch, then broadcast (reference trainer.py:112-115)
-    glow.train()
-    parallel.data_dependent_init(glow, x, rank=rank, world=world)
-    glow.eval()
-    plan = glow.flow.plan_for(x)
     repack = args.repack if args.mode == "inverse" else not args.no_repack
-
-    if args.mode == "inverse":
-        z_top = torch.randn((B,) + tuple(plan.out_chw), device=device) * 0.7
-
-    if args.mode == "train":
-        from pytorch_glow_amd import training
-        loop = training.TrainLoop(glow, hps, rank=rank, world=world)   # Adam + noam warm-up + clip 5/100 (celeba profile)
-    else:
-        torch.set_grad_enabled(False)   # forward+logdet metric: inference path (no activation tape)
-
-    def step():
-        if args.mode == "train":     # secondary metric: the reference's training step (trainer.py:123-150)
-            loss, _ = loop.step(x)
-            return loss * (world * B)
-        if args.mode == "inverse":   # secondary metric: sampling (eps drawn on device, W^-1 from the in-kernel LU)
-            plan.ensure_packed(repack, use=plan.PACK_INFERENCE | plan.PACK_INVERSE)
-            xs = glow.reverse_flow(z_top, None, eps_std=0.7)
-            return xs.sum()
-        z, nll, _ = glow.normal_flow(x, None, repack=repack)
-        return parallel.reduce_loss(nll, world)
+    wl = setup_workload(G, util, parallel, device, args.config, args.mode, B, rank, world, repack, graph=not args.no_graph and not dbg)
+    glow, hps, plan, x, step = wl["glow"], wl["hps"], wl["plan"], wl["x"], wl["step"]
+    z_top = wl.get("z_top")
 
     def sync():
         if world > 1:
@@ -322,7 +410,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "ms_per_step_min": round(per_step[0], 4), "ms_per_step_median": round(per_step[len(per_step) // 2], 4),
             "ms_per_step_max": round(per_step[-1], 4), "host_enqueue_ms_per_step": round(1e3 * dt_host / args.steps, 4),
-            "rccl_world_size": dist.get_world_size() if world > 1 else 1,
+            "rccl_world_size": dist.get_world_size() if world > 1 else 1, "launch": wl["launch"],
             "arithmetic": "fp32 values carried as 2 x f16 (hi, lo), exact f16 products, fp32 accumulate (csrc/sh.h); "
                           "max-abs vs CPU reference 7e-6 (z), same as the exact-fp32 kernels",
             "config": {"workload": f"{cfg['label']}, {what}, batch {B}/GPU ({cfg['ref']})", "global_batch": world * B,
@@ -417,7 +505,7 @@ def main():
                            "hbm_frac_of_8TBps": round(dom_bytes / (dom_ms * 1e-3) / 8e12, 4) if dom_ms > 0 else 0.0}
         if args.mode == "forward" and sh_path and args.config == "B":
             # the same step on the exact-fp32 MFMA kernels (split-half path switched off), for the record; rank-local
-            G.lib().glowhip_debug_force_tail_tile(0x800)
+            plan.set_family(plan.FAMILY_EXACT_FP32)       # a property of this plan (glowhip_plan_set_family), nothing process-wide
             try:
                 for _ in range(2):
                     glow.normal_flow(x, None, repack=repack)
@@ -428,7 +516,7 @@ def main():
                 torch.cuda.synchronize()
                 dt1 = (time.perf_counter() - t1) / 5
             finally:
-                G.lib().glowhip_debug_force_tail_tile(0)
+                plan.set_family(plan.FAMILY_AUTO)
             out["exact_fp32_mfma_kernels"] = {"value": round(B / dt1, 2), "unit": "images/sec", "ms_per_step": round(1e3 * dt1, 4),
                                               "note": "one GPU, same step with v_mfma_f32_32x32x2_f32 kernels only"}
         out["breakdown_ms_per_step"] = {k: round(v[0] / 3, 4) for k, v in sorted(bd.items())}
@@ -436,6 +524,10 @@ def main():
         out["kernel_launches_per_step"] = launches
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(glow, x[:min(B, cfg["cpu_sample"])].cpu(), cfg)
+        if world == 1 and args.mode == "forward" and args.config == "B" and not args.no_secondary and not dbg:
+            del glow, plan, wl, step
+            torch.cuda.empty_cache()
+            out["secondary"] = secondary_workloads(G, util, parallel, device)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

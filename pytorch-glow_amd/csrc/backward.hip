@@ -133,9 +133,64 @@ int launch_split_bwd(const SplitBwdArgs& a, hipStream_t s) {
 //   g_u = g_h * (h > 0) * e;   g_b = sum g_u;   g_logs = 3 * sum g_h*h   (h = (u+b)*e wherever the mask is 1)
 // In place on g (g_h -> g_u).  Grid (pixel blocks, channels, N).
 // ------------------------------------------------------------------------------------------------
+// One workgroup = 1024 consecutive elements of one image (= 1024 / HW whole channels, or a slice of one), four per thread as one
+// 16-byte access; per-channel sums in fp32 inside the segment (<= 1024 terms), one fp64 atomic pair per channel segment.
+// (The first version had one element per thread and two fp64 block reductions per 256 elements: 2.8 TB/s.)
 __global__ void __launch_bounds__(256) k_act_bwd(float* __restrict__ g, const float* __restrict__ h,
-                                                 const float* __restrict__ e, int Cm, int HW,
+                                                 const float* __restrict__ e, int Cm, int HW, long per_img,
                                                  double* __restrict__ acc_b, double* __restrict__ acc_l) {
+    __shared__ float red[2][4];
+    const long n = blockIdx.y;
+    const long off = (long)blockIdx.x * 1024 + threadIdx.x * 4;          // element offset inside the image
+    const int tpc = HW >> 2;                                             // threads per channel (HW % 4 == 0)
+    float sb = 0.f, sl = 0.f;
+    int c = 0;
+    if (off < per_img) {
+        c = (int)(off / HW);
+        const long idx = n * per_img + off;
+        const float4 hv = *reinterpret_cast<const float4*>(h + idx);
+        float4 gh = *reinterpret_cast<const float4*>(g + idx);
+        const float ec = e[c];
+        sl = (gh.x * hv.x + gh.y * hv.y) + (gh.z * hv.z + gh.w * hv.w);
+        gh.x = hv.x > 0.f ? gh.x * ec : 0.f; gh.y = hv.y > 0.f ? gh.y * ec : 0.f;
+        gh.z = hv.z > 0.f ? gh.z * ec : 0.f; gh.w = hv.w > 0.f ? gh.w * ec : 0.f;
+        *reinterpret_cast<float4*>(g + idx) = gh;
+        sb = (gh.x + gh.y) + (gh.z + gh.w);
+    }
+    if (tpc >= 256) {            // the whole workgroup sits inside one channel
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { sb += __shfl_down(sb, o, 64); sl += __shfl_down(sl, o, 64); }
+        if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = sb; red[1][threadIdx.x >> 6] = sl; }
+        __syncthreads();
+        if (threadIdx.x == 0 && off < per_img) {
+            atomic_add_f64(acc_b + c, (double)((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])));
+            atomic_add_f64(acc_l + c, 3.0 * (double)((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])));
+        }
+        return;
+    }
+    // tpc in {1, 2, 4, ..., 128}: segments of tpc consecutive threads
+    const int w = tpc < 64 ? tpc : 64;
+    for (int o = w >> 1; o > 0; o >>= 1) { sb += __shfl_down(sb, o, 64); sl += __shfl_down(sl, o, 64); }
+    if (tpc == 128) {            // two waves per channel
+        if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = sb; red[1][threadIdx.x >> 6] = sl; }
+        __syncthreads();
+        if ((threadIdx.x & 127) == 0 && off < per_img) {
+            const int wv = threadIdx.x >> 6;
+            atomic_add_f64(acc_b + c, (double)(red[0][wv] + red[0][wv + 1]));
+            atomic_add_f64(acc_l + c, 3.0 * (double)(red[1][wv] + red[1][wv + 1]));
+        }
+        return;
+    }
+    if ((threadIdx.x & (tpc - 1)) == 0 && off < per_img) {
+        atomic_add_f64(acc_b + c, (double)sb);
+        atomic_add_f64(acc_l + c, 3.0 * (double)sl);
+    }
+}
+
+// element-per-thread fall-back for shapes the vector kernel does not take (HW not a power of two >= 4)
+__global__ void __launch_bounds__(256) k_act_bwd1(float* __restrict__ g, const float* __restrict__ h,
+                                                  const float* __restrict__ e, int Cm, int HW,
+                                                  double* __restrict__ acc_b, double* __restrict__ acc_l) {
     __shared__ double red[4];
     const int c = blockIdx.y;
     const long n = blockIdx.z;
@@ -183,10 +238,10 @@ __global__ void __launch_bounds__(256) k_act_bwd_sh(float* __restrict__ g, const
         sh_split(gu * sh_scale, a, b);
         st[0][px][cq * 2 + k] = a;
         st[1][px][cq * 2 + k] = b;
-        const double tb = wave_sum((double)gu), tl = wave_sum((double)(gh * hv) * 3.0);
+        const float tb = wave_sum(gu), tl = wave_sum(gh * hv);       // 64 terms in fp32, then one fp64 atomic pair per wave and channel
         if (px == 0) {
-            atomic_add_f64(acc_b + c, tb);
-            atomic_add_f64(acc_l + c, tl);
+            atomic_add_f64(acc_b + c, (double)tb);
+            atomic_add_f64(acc_l + c, 3.0 * (double)tl);
         }
     }
     __syncthreads();
@@ -206,7 +261,13 @@ int launch_act_bwd(float* g, const float* h, const float* e, int N, int Cm, int 
         GH_LAUNCH_CHECK("k_act_bwd_sh");
         return GLOWHIP_OK;
     }
-    hipLaunchKernelGGL(k_act_bwd, dim3(cdiv(HW, 256), Cm, N), dim3(256), 0, s, g, h, e, Cm, HW, acc_b, acc_l);
+    const bool pow2 = HW >= 4 && (HW & (HW - 1)) == 0;
+    if (pow2) {
+        const long per_img = (long)Cm * HW;
+        hipLaunchKernelGGL(k_act_bwd, dim3((unsigned)((per_img + 1023) / 1024), N), dim3(256), 0, s, g, h, e, Cm, HW, per_img, acc_b, acc_l);
+    } else {
+        hipLaunchKernelGGL(k_act_bwd1, dim3(cdiv(HW, 256), Cm, N), dim3(256), 0, s, g, h, e, Cm, HW, acc_b, acc_l);
+    }
     GH_LAUNCH_CHECK("k_act_bwd");
     return GLOWHIP_OK;
 }

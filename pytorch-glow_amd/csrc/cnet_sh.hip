@@ -968,7 +968,19 @@ struct CfinArgs {
     float* z_out; long z_out_bs;
     unsigned long long* acc;
     int N, H, W, HW, wshift;
+    int xcd_affine;
 };
+
+// XCD affinity (speed only; any block-to-chunk permutation is correct).  The hardware places block b on XCD b % 8, and each XCD
+// has its own L2.  k_cnet's tile t -- whose partial sums this kernel reads, and whose successor in the next FlowStep reads the
+// state this kernel writes -- runs on XCD t % 8.  So block b = 8 s + x takes a pixel chunk of a tile t with t % 8 == x: partial
+// sums and state then travel between kernels through ONE XCD's L2 instead of through memory (halo rows excepted).
+// lr = log2(chunks per k_cnet tile).
+__device__ __forceinline__ int cfin_chunk(int b, int nblk, int lr) {
+    if (nblk & ((8 << lr) - 1)) return b;                 // not whole groups of 8 tiles: identity
+    const int x = b & 7, s = b >> 3;
+    return ((((s >> lr) << 3) + x) << lr) + (s & ((1 << lr) - 1));
+}
 
 template <int PXB, int MSV, bool HALO>
 __global__ void __launch_bounds__(256) k_cfinish(CfinArgs a) {
@@ -977,7 +989,9 @@ __global__ void __launch_bounds__(256) k_cfinish(CfinArgs a) {
     const int tid = threadIdx.x;
     const int HW = a.HW, W = a.W;
     const FinSrc f = fin_src(a.p, a.N, a.H, W, HW, a.wshift);
-    const long gp0 = (long)blockIdx.x * PXB;
+    constexpr int LPXB = PXB == 64 ? 6 : 4;
+    const int chunk = a.xcd_affine && f.lpxt >= LPXB ? cfin_chunk(blockIdx.x, gridDim.x, f.lpxt - LPXB) : (int)blockIdx.x;
+    const long gp0 = (long)chunk * PXB;
     const long n = gp0 / HW;
     const int p0 = (int)(gp0 - n * HW);
     const int Ch = f.paired ? f.Cout / 2 : f.Cout;         // channels of z2 (= C/2)
@@ -1219,7 +1233,7 @@ int launch_cnet_main(const CnetArgs& a, hipStream_t s, CnetPending* out) {
 int launch_cnet_finish(const CnetArgs& a, const CnetPending& p, hipStream_t s) {
     if (a.N == 0) return GLOWHIP_OK;
     const int HW = a.H * a.W;
-    CfinArgs f{p, a.mix, a.z_out, a.z_out_bs, a.acc, a.N, a.H, a.W, HW, __builtin_ctz(a.W)};
+    CfinArgs f{p, a.mix, a.z_out, a.z_out_bs, a.acc, a.N, a.H, a.W, HW, __builtin_ctz(a.W), (g_cnet_flags & 8) ? 0 : 1};
     const bool paired = p.mode == TAIL_AFFINE_FWD || p.mode == TAIL_AFFINE_REV;
     const int C = 2 * (paired ? p.Cout / 2 : p.Cout);
     GH_REQUIRE(a.mix.C == 0 || a.mix.C == C, "cnet: mixer channel count %d != %d", a.mix.C, C);

@@ -350,7 +350,7 @@ void conv_mfma_tail_force_tile(int v) {
     // 0x8000 next-step mixer inside the tail; bits 16..19: 4 / 8 = only those wave counts of k_tail_sh
     plan_disable_sh(((v & 0x800) ? 1 : 0) | ((v & 0x1000) ? 2 : 0) | ((v & 0x2000) ? 4 : 0) | ((v & 0x4000) ? 8 : 0) |
                     ((v & 0x8000) ? 16 : 0) | ((v & 0x100000) ? 32 : 0) | ((v & 0x200000) ? 64 : 0));
-    cnet_force((v >> 22) & 7, (v >> 25) & 7);    // bits 22..24: row splits; bit 25: 128-pixel tiles only, bit 26: 64-pixel tiles, bit 27: finishing chained into the next k_cnet
+    cnet_force((v >> 22) & 7, (v >> 25) & 15);   // bits 22..24: row splits; bit 25: 128-pixel tiles only, bit 26: 64-pixel tiles, bit 27: finishing chained into the next k_cnet, bit 28: finishing kernel without the XCD-affine chunk order
     tail_sh_force_waves((v >> 16) & 0xf);
     plan_train_disable_sh((v & 0x800) ? 1 : 0);
 }

@@ -62,6 +62,8 @@ int launch_zero_acc(unsigned long long* acc, int N, hipStream_t s);
 int launch_finalize(const float* in, const unsigned long long* acc, const double* konst, double sign, double offset,
                     double scale, float* out, float* out_unscaled, int N, hipStream_t s);
 
+// in place: h[n][c][p] = relu((h + bias[c]) * scale[c])  (Conv2d's ActNorm + ReLU after the data-dependent init set them)
+int launch_bias_scale_relu(float* h, int N, int C, int HW, const float* bias, const float* scale, hipStream_t s);
 // status[n] = sticky non-finite flags of sample n (acc[N + n], common.h) | 8 if any of result[n*elems .. +elems) is not finite
 int launch_status(const unsigned long long* acc, int N, const float* result, long elems, int32_t* status, hipStream_t s);
 

@@ -558,6 +558,8 @@ glowhip_plan* glowhip_plan_create(const glowhip_layer_desc* layers, int n_layers
             if (L.first_halo) L.f0_wt = take(off, conv_mfma_first_packed_bytes(C / 2, d.hidden));
             else if (L.mfma_first) L.f0_wt = take(off, conv_mfma_wide_packed_bytes(C / 2, d.hidden, 3));
             if (L.mfma_mid) L.f2_wt = take(off, conv_mfma_wide_packed_bytes(d.hidden, d.hidden, 1));
+            if (L.first_halo && L.mfma_first) L.f0_init = take(off, conv_mfma_wide_packed_bytes(C / 2, d.hidden, 3));
+            else if (L.mfma_first) L.f0_init = L.f0_wt;      // already the plain K-major image
             L.sh_mid = L.first_halo && gemm_sh_supported(d.hidden, d.hidden, H, W);
             if (L.sh_mid) { L.f2_sh = take(off, gemm_sh_packed_bytes(d.hidden, d.hidden)); L.f2T_sh = take(off, gemm_sh_packed_bytes(d.hidden, d.hidden)); }
             L.sh_first = L.sh_mid && first_sh_supported(C / 2, H, W, d.hidden);
@@ -619,6 +621,10 @@ glowhip_plan* glowhip_plan_create(const glowhip_layer_desc* layers, int n_layers
             } else if (L.mfma_first) {
                 RepackJob r{}; r.w = d.f0_w; r.out_off = L.f0_wt; r.kind = REPACK_WIDE; r.Cin = d.C / 2; r.Cout = d.hidden;
                 r.K = r.Cin * 9; r.Kpad = wide_kpad(r.Cin, 3); r.use = 3; p->repack_jobs.push_back(r);
+            }
+            if (L.first_halo && L.f0_init) {   // use bit 16 (internal): read by the data-dependent init pass only
+                RepackJob r{}; r.w = d.f0_w; r.out_off = L.f0_init; r.kind = REPACK_WIDE; r.Cin = d.C / 2; r.Cout = d.hidden;
+                r.K = r.Cin * 9; r.Kpad = wide_kpad(r.Cin, 3); r.use = 16; p->repack_jobs.push_back(r);
             }
             if (L.mfma_mid) {
                 RepackJob r{}; r.w = d.f2_w; r.out_off = L.f2_wt; r.kind = REPACK_WIDE; r.Cin = d.hidden; r.Cout = d.hidden;
@@ -828,11 +834,16 @@ int glowhip_plan_pack_for(glowhip_plan* plan, void* packed, size_t packed_bytes,
     auto upload = [&](size_t off, const void* src, size_t bytes) {
         return bytes == 0 || hipMemcpyAsync((char*)packed + off, src, bytes, hipMemcpyHostToDevice, s) == hipSuccess;
     };
-    if (!upload(plan->prep_off, plan->prep_jobs.data(), plan->prep_jobs.size() * sizeof(StepPrepJob)) ||
-        !upload(plan->scale_off, plan->scale_jobs.data(), plan->scale_jobs.size() * sizeof(ScaleJob)) ||
-        !upload(plan->repack_off, plan->repack_sel.data(), plan->repack_sel.size() * sizeof(RepackJob))) {
-        set_error("plan_pack: hipMemcpyAsync of the job tables failed");
-        return GLOWHIP_ELAUNCH;
+    // The job tables are plan constants: they travel once per (buffer, use mask) and stay in `packed` -- a re-pack of the same
+    // buffer is then kernel launches only (no host-to-device copy per step, and the sequence can be captured in a hipGraph)
+    if (plan->tables_in != packed || plan->tables_use != use) {
+        if (!upload(plan->prep_off, plan->prep_jobs.data(), plan->prep_jobs.size() * sizeof(StepPrepJob)) ||
+            !upload(plan->scale_off, plan->scale_jobs.data(), plan->scale_jobs.size() * sizeof(ScaleJob)) ||
+            !upload(plan->repack_off, plan->repack_sel.data(), plan->repack_sel.size() * sizeof(RepackJob))) {
+            set_error("plan_pack: hipMemcpyAsync of the job tables failed");
+            return GLOWHIP_ELAUNCH;
+        }
+        plan->tables_in = packed; plan->tables_use = use;
     }
     GH_TRY(launch_pack_batched(at<ScaleJob>(packed, plan->scale_off), (int)plan->scale_jobs.size(),
                                at<RepackJob>(packed, plan->repack_off), n_kind, tail_blocks, packed, s));
@@ -960,6 +971,8 @@ int glowhip_plan_actnorm_init(glowhip_plan* plan, void* packed, size_t packed_by
     Workspace w;
     GH_TRY(carve(plan, N, workspace, workspace_bytes, w));
     GH_TRY(launch_zero_acc(w.acc, N, s));
+    // plain (ActNorm-free) fp32 MFMA weight images of every convolution: the training family's + the init pass's own f.0 image
+    GH_TRY(glowhip_plan_pack_for(plan, packed, packed_bytes, GLOWHIP_PACK_TRAINING | 16, stream));
     // Layer by layer: set the ActNorm statistics from the activations that reach it, refresh the packed
     // data of that layer, then run the layer forward with the fresh parameters (first training-mode
     // forward of the reference: network/module.py:45-46,66-67).
@@ -992,26 +1005,57 @@ int glowhip_plan_actnorm_init(glowhip_plan* plan, void* packed, size_t packed_by
             m.gather = d.permutation == GLOWHIP_PERM_GATHER ? d.perm_idx : nullptr;
             m.reverse = 0; m.N = N; m.C = d.C; m.HW = HW;
             GH_TRY(launch_chanmix(m, s));
-            // f.0: raw conv -> statistics (Conv2d's ActNorm uses scale 1, network/module.py:239)
-            ConvArgs c0{dst, chw, d.f0_w, nullptr, nullptr, nullptr, nullptr, 0, w.h1, N, Ch, d.H, d.W, hid, 3};
-            GH_TRY(launch_conv_direct(c0, s));
+            // The statistics of a Conv2d's ActNorm are taken BETWEEN the convolution and the ActNorm (network/module.py:258-259,
+            // 86-120), so the init pass needs the un-fused form -- not the slow one: raw convolution on the exact-fp32 MFMA kernels
+            // (plain weight images packed above), statistics, then ActNorm + ReLU as one in-place pass.  The generic direct kernel
+            // (two launches per convolution before) runs only for shapes no MFMA kernel takes.
+            // f.0 (Conv2d's ActNorm uses scale 1, network/module.py:239)
+            if (L.f0_init) {
+                GH_TRY(launch_conv_mfma_wide(dst, chw, at<float>(packed, L.f0_init), nullptr, nullptr, w.h1, N, Ch, d.H, d.W, hid, 3, s, 0));
+            } else {
+                ConvArgs c0{dst, chw, d.f0_w, nullptr, nullptr, nullptr, nullptr, 0, w.h1, N, Ch, d.H, d.W, hid, 3};
+                GH_TRY(launch_conv_direct(c0, s));
+            }
             GH_TRY(launch_actnorm_init(w.h1, (long)hid * HW, N, hid, HW, 1.0f, (float*)d.f0_an_bias, (float*)d.f0_an_logs, s));
             GH_TRY(pack_scales(d.f0_an_logs, hid, at<float>(packed, L.f0_scale), nullptr, s));
-            c0.post_bias = d.f0_an_bias; c0.post_scale = at<float>(packed, L.f0_scale); c0.relu = 1;
-            GH_TRY(launch_conv_direct(c0, s));
-            ConvArgs c2{w.h1, (long)hid * HW, d.f2_w, nullptr, nullptr, nullptr, nullptr, 0, w.h2, N, hid, d.H, d.W, hid, 1};
-            GH_TRY(launch_conv_direct(c2, s));
+            GH_TRY(launch_bias_scale_relu(w.h1, N, hid, HW, d.f0_an_bias, at<float>(packed, L.f0_scale), s));
+            // f.2
+            if (L.mfma_mid) {
+                GH_TRY(launch_conv_mfma_wide(w.h1, (long)hid * HW, at<float>(packed, L.f2_wt), nullptr, nullptr, w.h2, N, hid, d.H, d.W,
+                                             hid, 1, s, 0));
+            } else {
+                ConvArgs c2{w.h1, (long)hid * HW, d.f2_w, nullptr, nullptr, nullptr, nullptr, 0, w.h2, N, hid, d.H, d.W, hid, 1};
+                GH_TRY(launch_conv_direct(c2, s));
+            }
             GH_TRY(launch_actnorm_init(w.h2, (long)hid * HW, N, hid, HW, 1.0f, (float*)d.f2_an_bias, (float*)d.f2_an_logs, s));
             GH_TRY(pack_scales(d.f2_an_logs, hid, at<float>(packed, L.f2_scale), nullptr, s));
-            c2.post_bias = d.f2_an_bias; c2.post_scale = at<float>(packed, L.f2_scale); c2.relu = 1;
-            GH_TRY(launch_conv_direct(c2, s));
+            GH_TRY(launch_bias_scale_relu(w.h2, N, hid, HW, d.f2_an_bias, at<float>(packed, L.f2_scale), s));
+            // f.4 + coupling
             GH_TRY(pack_scales(d.f4_logs, L.Cout, at<float>(packed, L.f4_scale), nullptr, s));
-            ConvArgs c4{w.h2, (long)hid * HW, d.f4_w, d.f4_bias, nullptr, nullptr, at<float>(packed, L.f4_scale), 0, w.h1,
-                        N, hid, d.H, d.W, L.Cout, 3};
-            GH_TRY(launch_conv_direct(c4, s));
             float* z2 = dst + (long)Ch * HW;
-            CouplingTailArgs t{w.h1, z2, chw, z2, chw, N, Ch, HW, d.coupling == GLOWHIP_COUPLING_AFFINE, 0, nullptr};
-            GH_TRY(launch_coupling_tail(t, s));
+            if (L.mfma_last) {
+                TailConvArgs t{};
+                t.x = w.h2; t.x_bs = (long)hid * HW; t.wp = at<float>(packed, L.f4_wp); t.bias = d.f4_bias;
+                t.scale = at<float>(packed, L.f4_scale);
+                t.N = N; t.Cin = hid; t.H = d.H; t.W = d.W; t.Cout = L.Cout;
+                t.mode = d.coupling == GLOWHIP_COUPLING_AFFINE ? TAIL_AFFINE_FWD : TAIL_ADD_FWD;
+                t.z2_in = z2; t.z2_in_bs = chw; t.z2_out = z2; t.z2_out_bs = chw; t.acc = w.acc;     // (the log-det sums are not used)
+                t.zeros = at<float>(packed, 64);
+                GH_TRY(launch_conv_mfma_tail(t, s));
+            } else {
+                if (L.wide_last) {
+                    const size_t out_f = (size_t)N * L.Cout * HW, h1_f = (size_t)N * plan->max_hidden;
+                    GH_TRY(launch_conv_mfma_wide(w.h2, (long)hid * HW, at<float>(packed, L.f4_wt), d.f4_bias, at<float>(packed, L.f4_scale),
+                                                 w.h1, N, hid, d.H, d.W, L.Cout, 3, s, 0, h1_f > out_f ? w.h1 + out_f : nullptr,
+                                                 h1_f > out_f ? h1_f - out_f : 0));
+                } else {
+                    ConvArgs c4{w.h2, (long)hid * HW, d.f4_w, d.f4_bias, nullptr, nullptr, at<float>(packed, L.f4_scale), 0, w.h1,
+                                N, hid, d.H, d.W, L.Cout, 3};
+                    GH_TRY(launch_conv_direct(c4, s));
+                }
+                CouplingTailArgs t{w.h1, z2, chw, z2, chw, N, Ch, HW, d.coupling == GLOWHIP_COUPLING_AFFINE, 0, nullptr};
+                GH_TRY(launch_coupling_tail(t, s));
+            }
         }
         cur = dst;
     }

@@ -31,6 +31,8 @@ struct LayerPlan {
     bool cnet = false; size_t cn_w0 = 0, cn_w2 = 0, cn_w4 = 0;   // whole coupling network as one kernel (cnet_sh.hip), SH2 images
     bool wide_last = false; size_t f4_wt = 0;   // f.4 on k_conv_wide<3> (+ separate coupling tail): levels no tail kernel takes (4x4 pixels)
     bool first_halo = false;  // f.0 on k_conv_first (stationary pixel window) instead of k_conv_wide<3>
+    size_t f0_init = 0;       // data-dependent init pass: PLAIN K-major image of f.0 for k_conv_wide<3> (the k_conv_first image has
+                              // the ActNorm being initialised folded in); 0 = none (the direct kernel runs)
 };
 
 }  // namespace glowhip
@@ -51,6 +53,7 @@ struct glowhip_plan {
     std::vector<RepackJob> repack_jobs;
     std::vector<RepackJob> repack_sel;    // the subset selected by the last glowhip_plan_pack_for (kept alive for the async copy)
     size_t prep_off = 0, scale_off = 0, repack_off = 0;
+    const void* tables_in = nullptr; int tables_use = 0;   // the `packed` buffer that already holds the job tables of that use mask
     int max_lds_c = 0, max_c = 0;
     size_t packed_bytes = 0;
     int in_shape[3] = {0, 0, 0}, out_shape[3] = {0, 0, 0};

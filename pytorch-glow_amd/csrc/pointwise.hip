@@ -509,6 +509,38 @@ int launch_finalize(const float* in, const unsigned long long* acc, const double
     return GLOWHIP_OK;
 }
 
+// Conv2d's ActNorm + ReLU as a separate in-place pass (network/module.py:258-259 + :310): only the data-dependent init pass
+// needs the un-fused form (the statistics are taken between the convolution and its ActNorm)
+__global__ void __launch_bounds__(256) k_bias_scale_relu(float* __restrict__ h, long total4, int HW4, int C, const float* __restrict__ bias,
+                                                         const float* __restrict__ scale) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total4) return;
+    const int c = (int)((i / HW4) % C);
+    const float b = bias[c], sc = scale[c];
+    float4 v = reinterpret_cast<float4*>(h)[i];
+    v.x = relu_((v.x + b) * sc); v.y = relu_((v.y + b) * sc); v.z = relu_((v.z + b) * sc); v.w = relu_((v.w + b) * sc);
+    reinterpret_cast<float4*>(h)[i] = v;
+}
+__global__ void __launch_bounds__(256) k_bias_scale_relu1(float* __restrict__ h, long total, int HW, int C, const float* __restrict__ bias,
+                                                          const float* __restrict__ scale) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)((i / HW) % C);
+    h[i] = relu_((h[i] + bias[c]) * scale[c]);
+}
+
+int launch_bias_scale_relu(float* h, int N, int C, int HW, const float* bias, const float* scale, hipStream_t s) {
+    const long total = (long)N * C * HW;
+    if (total == 0) return GLOWHIP_OK;
+    if (HW % 4 == 0) {
+        hipLaunchKernelGGL(k_bias_scale_relu, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, s, h, total / 4, HW / 4, C, bias, scale);
+    } else {
+        hipLaunchKernelGGL(k_bias_scale_relu1, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, h, total, HW, C, bias, scale);
+    }
+    GH_LAUNCH_CHECK("k_bias_scale_relu");
+    return GLOWHIP_OK;
+}
+
 // Range / non-finite status of a finished call (glowhip_plan_status): one workgroup per sample
 __global__ void __launch_bounds__(256) k_status(const unsigned long long* __restrict__ acc, int N, const float* __restrict__ result,
                                                 long elems, int32_t* __restrict__ status) {

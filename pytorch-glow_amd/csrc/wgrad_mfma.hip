@@ -57,9 +57,15 @@ k_wgrad_gemm(const float* __restrict__ A, long a_bs, const float* __restrict__ B
     __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wr = wid >> 1, wc = wid & 1, kl = lane >> 5, ml = lane & 31;
+    // XCD-aware order (8 XCDs with private L2s, block b lands on XCD b % 8): the tiles of ONE pixel slice share their operand
+    // panels -- every A panel is read by all tile_n, every B panel by all tile_m -- so they go to the same XCD back to back and
+    // the panels travel from HBM once per slice instead of once per tile (the tile-major grid spread a slice over all 8 L2s:
+    // 4x the operand bytes from memory at 512 x 512).
     const int tiles_n = Npad / BN;
-    const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x % tiles_n;
-    const int split = blockIdx.y;
+    const int ntiles = (Mpad / BM) * tiles_n;
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = logical / ntiles, tile = logical - split * ntiles;
+    const int tile_m = tile / tiles_n, tile_n = tile % tiles_n;
     const int kt0 = split * ktiles_per_split;
     const int kt1 = min(ktiles_total, kt0 + ktiles_per_split);
     const int tiles_per_img = HW / BK;
@@ -160,9 +166,15 @@ k_wgrad_gemm_sh(const float* __restrict__ A, long a_bs, const float* __restrict_
     __shared__ __attribute__((aligned(16))) _Float16 Bs[2][2][BK / 8][BN][8];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wr = wid >> 1, wc = wid & 1, kl = lane >> 5, ml = lane & 31;
+    // XCD-aware order (8 XCDs with private L2s, block b lands on XCD b % 8): the tiles of ONE pixel slice share their operand
+    // panels -- every A panel is read by all tile_n, every B panel by all tile_m -- so they go to the same XCD back to back and
+    // the panels travel from HBM once per slice instead of once per tile (the tile-major grid spread a slice over all 8 L2s:
+    // 4x the operand bytes from memory at 512 x 512).
     const int tiles_n = Npad / BN;
-    const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x % tiles_n;
-    const int split = blockIdx.y;
+    const int ntiles = (Mpad / BM) * tiles_n;
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = logical / ntiles, tile = logical - split * ntiles;
+    const int tile_m = tile / tiles_n, tile_n = tile % tiles_n;
     const int kt0 = split * ktiles_per_split;
     const int kt1 = min(ktiles_total, kt0 + ktiles_per_split);
     const int tiles_per_img = HW / BK;
@@ -303,16 +315,16 @@ int launch_wgrad_mfma(const float* A, long a_bs, const float* B, long b_bs, floa
     const int per = (total + splits - 1) / splits;
     splits = (total + per - 1) / per;
     if (sh_scale > 0.f && bn128)       // f16 matrix pipe, split-half operands (sh_scale = power-of-two pre-scale of the gradient operand)
-        hipLaunchKernelGGL(k_wgrad_gemm_sh<128>, dim3(tiles, splits), dim3(256), 0, s, A, a_bs, B, b_bs, partial, HW, Mpad, Npad,
+        hipLaunchKernelGGL(k_wgrad_gemm_sh<128>, dim3(tiles * splits), dim3(256), 0, s, A, a_bs, B, b_bs, partial, HW, Mpad, Npad,
                            total, per, sh_scale);
     else if (sh_scale > 0.f)
-        hipLaunchKernelGGL(k_wgrad_gemm_sh<64>, dim3(tiles, splits), dim3(256), 0, s, A, a_bs, B, b_bs, partial, HW, Mpad, Npad,
+        hipLaunchKernelGGL(k_wgrad_gemm_sh<64>, dim3(tiles * splits), dim3(256), 0, s, A, a_bs, B, b_bs, partial, HW, Mpad, Npad,
                            total, per, sh_scale);
     else if (bn128)
-        hipLaunchKernelGGL(k_wgrad_gemm<128>, dim3(tiles, splits), dim3(256), 0, s, A, a_bs, B, b_bs, partial, HW, Mpad, Npad,
+        hipLaunchKernelGGL(k_wgrad_gemm<128>, dim3(tiles * splits), dim3(256), 0, s, A, a_bs, B, b_bs, partial, HW, Mpad, Npad,
                            total, per);
     else
-        hipLaunchKernelGGL(k_wgrad_gemm<64>, dim3(tiles, splits), dim3(256), 0, s, A, a_bs, B, b_bs, partial, HW, Mpad, Npad,
+        hipLaunchKernelGGL(k_wgrad_gemm<64>, dim3(tiles * splits), dim3(256), 0, s, A, a_bs, B, b_bs, partial, HW, Mpad, Npad,
                            total, per);
     GH_LAUNCH_CHECK("k_wgrad_gemm");
     hipLaunchKernelGGL(k_wgrad_reduce, dim3(cdiv((long)Mreal * Nreal, 256)), dim3(256), 0, s, partial, dw, splits, Mpad, Npad,

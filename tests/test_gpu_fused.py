@@ -314,6 +314,38 @@ def test_decode_overflow_is_flagged_and_the_checked_path_recovers():
     close(xa, O.glow_reverse(zm_ref, sdm, cfgm, []), 1e-4, what="x (in range)")
 
 
+def test_forward_captured_in_a_hip_graph_equals_the_eager_forward():
+    """Glow.capture_forward: the plan's static launch list (noise draw + glowhip_plan_pack + ~kernels) as ONE hipGraph launch.  Every
+    replay must equal the eager forward on the noise it drew, bit for bit; successive replays draw different noise; an in-place
+    parameter update between replays is seen (the pack is inside the graph)."""
+    cfg = O.default_cfg(image_shape=(32, 32, 3), hidden_channels=128, K=3, L=2, batch=6)
+    sd = O.seeded_state_dict(cfg, seed=4)
+    glow = make_glow(cfg, sd, 6).eval()
+    g = torch.Generator().manual_seed(2)
+    x = dev(torch.rand(6, 3, 32, 32, generator=g))
+    with torch.no_grad():
+        gf = glow.capture_forward(x, repack=True)
+        z1, n1 = (t.clone() for t in gf())
+        noise1 = gf.noise.clone()
+        ze, ne, _ = glow.normal_flow(x, None, noise=noise1)
+        assert torch.equal(z1, ze) and torch.equal(n1, ne)
+        z2, n2 = (t.clone() for t in gf())
+        assert not torch.equal(gf.noise, noise1) and not torch.equal(n2, n1), "every replay draws fresh dequantisation noise"
+        z_ref, nll_ref, _ = O.glow_forward(x.cpu(), gf.noise.cpu(), sd, cfg)
+        close(z2, z_ref, 1e-4, what="z (graph replay)"); close(n2, nll_ref, 1e-4, what="nll (graph replay)")
+        # an optimiser-style in-place update: the next replay packs the new weights
+        w = glow.flow.layers[1].f[2].weight
+        w.mul_(1.25)
+        z3, n3 = (t.clone() for t in gf())
+        ze3, ne3, _ = glow.normal_flow(x, None, noise=gf.noise.clone())
+        assert torch.equal(z3, ze3) and torch.equal(n3, ne3) and not torch.equal(n3, n2)
+        # another batch through the same graph
+        xb = dev(torch.rand(6, 3, 32, 32, generator=g))
+        z4, n4 = gf(xb)
+        ze4, ne4, _ = glow.normal_flow(xb, None, noise=gf.noise.clone())
+        assert torch.equal(z4, ze4) and torch.equal(n4, ne4)
+
+
 # ------------------------------------------------------------------------------------------------ configs D and E at full size
 @pytest.mark.parametrize("name,image,L,K,batch", [("D", 128, 4, 48, 32), ("E", 256, 6, 32, 16)])
 def test_full_size_properties_configs_d_e(name, image, L, K, batch):

@@ -183,3 +183,44 @@ dist.destroy_process_group()
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
                          env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
     assert out.returncode == 0 and "RCCL_OK nccl 1" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+def _run_bench(extra, timeout=900):
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    proc = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + extra, capture_output=True, text=True, timeout=timeout,
+                          cwd=root)
+    assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-4000:]
+    lines = [l for l in proc.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, proc.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_over_rccl_when_two_gpus_are_there():
+    """The first box with >= 2 GPUs validates the N > 1 path in the test log (VERDICT r2 #4c): `bench.py --gpus 2` spawns two
+    ranks (children started before anything touches a GPU), they join ONE RCCL group, the line reports the aggregate rate, and the
+    training mode runs its flat gradient all-reduce over RCCL.  Skipped on a one-GPU box (the launcher / protocol is then
+    covered by the gloo dry run in tests/test_dist_gloo.py)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    d = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "2", "--no-cpu-baseline"])
+    assert d["n_gpus"] == 2 and d["rccl_world_size"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 128
+    assert d["value"] > 0 and np.isfinite(d["config"]["loss_mean_nll_bits_per_dim"])
+    t = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "2", "--mode", "train"])
+    assert t["n_gpus"] == 2 and t["rccl_world_size"] == 2 and np.isfinite(t["config"]["loss_mean_nll_bits_per_dim"])
+
+
+def test_bench_line_carries_the_contract_fields_and_the_secondary_workloads():
+    """One short default-shaped run: the ONE JSON line has the contract's fields, `roofline` (k_cnet, live HIP events), and the
+    `secondary` dict -- configs D / E forward, E sampling and the config-B training step measured in the same process after the
+    headline's timed region -- each finite, each on the product kernel family."""
+    d = _run_bench(["--steps", "5", "--warmup", "3", "--no-cpu-baseline"])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["steps"] == 5 and d["n_gpus"] == 1 and d["roofline"]["bound"] == "mfma" and 0 < d["roofline"]["frac"] < 1
+    sec = d["secondary"]
+    assert set(sec) == {"D_forward", "E_forward", "E_inverse", "B_train"}
+    for name, r in sec.items():
+        assert r["finite"] and r["value"] > 0 and r["steps"] == 3, (name, r)
+    assert "k_cnet" in sec["D_forward"]["kernel_families"] and "k_cnet" in sec["E_forward"]["kernel_families"]

@@ -1,0 +1,136 @@
+"""Precision of the product kernels at TRAINED scale (-m gpu; SURVEY.md section 7 "hard parts").
+
+Every other oracle comparison runs near-init weights (Conv2dZeros ~ N(0, 0.002..0.02), ActNorm logs ~ 0.1).  The split-half
+arithmetic (csrc/sh.h) is relative per operand but its activation floor and its range are absolute, so it is re-validated here
+where activations and weights have grown:
+  * a mid-size model after 250 optimiser steps of the HIP training loop on structured images;
+  * config-B geometry (C = 12/24/48, hidden 512) with ActNorm logs ~ N(0, 0.5) and the Conv2dZeros weights at the largest scale
+    the fp32 oracle itself keeps finite.
+Bars: max-abs deviation from the fp32 oracle <= 1e-4 (north star) -- or, where the fp32 oracle's own distance to an fp64
+evaluation is larger than that, 3x that distance -- and never further from fp64 than twice the fp32 oracle is."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import pytorch_glow_amd as G  # noqa: E402
+from oracle import glow_oracle as O  # noqa: E402
+from test_gpu_grad import hps_for  # noqa: E402
+from test_gpu_parity import dev, make_glow  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def _structured_images(n, size, seed):
+    """Smooth low-frequency fields + a few blobs, quantised to 8 bits like real pixels: data a flow can actually learn."""
+    g = torch.Generator().manual_seed(seed)
+    yy, xx = torch.meshgrid(torch.linspace(0, 1, size), torch.linspace(0, 1, size), indexing="ij")
+    out = torch.empty(n, 3, size, size)
+    for i in range(n):
+        f = torch.rand(3, 4, generator=g) * 6.0
+        ph = torch.rand(3, 2, generator=g) * 6.28
+        img = 0.5 + 0.25 * torch.sin(f[:, 0, None, None] * xx + ph[:, 0, None, None]) * torch.cos(f[:, 1, None, None] * yy + ph[:, 1, None, None])
+        cx, cy, r = torch.rand(3, generator=g)
+        img = img + 0.3 * torch.exp(-((xx - cx) ** 2 + (yy - cy) ** 2) / (0.02 + 0.05 * r))[None]
+        out[i] = img.clamp(0, 1)
+    return torch.floor(out * 255.0) / 256.0
+
+
+def _dist(a, b):
+    return (a.double().cpu() - b.double().cpu()).abs().max().item()
+
+
+def _compare_with_oracles(glow, sd, cfg, x, noise, eps, what):
+    """HIP forward + decode against the fp32 oracle and an fp64 evaluation of the same weights; returns the table of distances."""
+    plan = glow.flow.plan_for(dev(x))
+    plan.launch_counts(reset=True)
+    with torch.no_grad():
+        z, nll, _ = glow.normal_flow(dev(x), None, noise=dev(noise))
+        z32, nll32, _ = O.glow_forward(x, noise, sd, cfg)
+        sd64 = {k: v.double() for k, v in sd.items()}
+        z64, nll64, _ = O.glow_forward(x.double(), noise.double(), sd64, cfg)
+        xr = glow.reverse_flow(dev(z32), None, eps=[dev(e) for e in eps])
+        x32 = O.glow_reverse(z32, sd, cfg, eps)
+        x64 = O.glow_reverse(z32.double(), sd64, cfg, [e.double() for e in eps])
+    counts = plan.launch_counts(reset=True)
+    assert counts.get("k_cnet", 0) > 0 and not any(k.endswith("_sh") or k.endswith("_f32") for k in counts), counts
+    assert torch.isfinite(nll32).all() and torch.isfinite(x32).all(), "the fp32 oracle itself must be finite for this case"
+    rows = {}
+    for name, hip, o32, o64 in (("z", z, z32, z64), ("nll", nll, nll32, nll64), ("decode", xr, x32, x64)):
+        rows[name] = dict(vs32=_dist(hip, o32), vs64=_dist(hip, o64), ref=_dist(o32, o64), scale=o64.abs().max().item())
+    print(f"\n{what}: " + "; ".join(f"{k}: |hip-fp32| {v['vs32']:.2e}, |hip-fp64| {v['vs64']:.2e}, |fp32-fp64| {v['ref']:.2e}, max|.| {v['scale']:.1f}"
+                                     for k, v in rows.items()))
+    for name, v in rows.items():
+        assert v["vs32"] <= max(1e-4, 3.0 * v["ref"]), (what, name, v)
+        assert v["vs64"] <= 2.0 * v["ref"] + 2e-6, (what, name, v)
+    return rows
+
+
+def test_forward_and_decode_after_250_training_steps():
+    """250 steps of the HIP training loop (ActNorm init, tape forward, HIP backward, clip 5 / 100, Adam with noam warm-up) on
+    structured images: the loss must have fallen by more than 2 bits/dim and the Conv2dZeros weights must have left zero --
+    then forward / nll / decode of the RESULTING weights on held-out images against the oracles."""
+    from pytorch_glow_amd import training
+    torch.manual_seed(0)
+    np.random.seed(0)
+    cfg = O.default_cfg(image_shape=(32, 32, 3), hidden_channels=128, K=4, L=2, flow_coupling="affine", batch=16)
+    hps = hps_for(cfg, 16)
+    hps.optim.update(optimizer="adam", optimizer_args=dict(lr=1e-3, betas=[0.9, 0.9999], eps=1e-8),
+                     lr_scheduler="noam", lr_scheduler_args=dict(warmup_steps=50, min_lr=1e-4))
+    hps.ablation.update(max_grad_clip=5, max_grad_norm=100)
+    glow = G.Glow(hps).to(DEV)
+    loop = training.TrainLoop(glow, hps)
+    data = _structured_images(64, 32, seed=1).to(DEV)
+    losses = []
+    for step in range(250):
+        xb = data[(step * 16) % 64:(step * 16) % 64 + 16]
+        loss, _ = loop.step(xb)
+        if step % 25 == 0 or step == 249:
+            losses.append(loss.item())
+    loop.flush()
+    assert loop.range_fallbacks == 0 and loop.diverged_steps == 0
+    assert losses[-1] < losses[0] - 2.0, losses
+    sd = {k: v.detach().cpu().clone() for k, v in glow.state_dict().items()}
+    tails = torch.cat([v.flatten() for k, v in sd.items() if k.endswith("f.4.weight")])
+    assert tails.abs().max() > 0.02 and tails.std() > 2e-3, (tails.abs().max(), tails.std())     # (zero at initialisation)
+    glow.eval()
+    x = _structured_images(16, 32, seed=7)
+    noise = torch.rand(16, 3, 32, 32, generator=torch.Generator().manual_seed(3)) / 256
+    eps = [torch.randn(16, *s, generator=torch.Generator().manual_seed(5 + i)) * 0.7
+           for i, s in enumerate(glow.flow.split_shapes((3, 32, 32)))]
+    print("loss (bits/dim) every 25 steps:", [round(v, 3) for v in losses])
+    _compare_with_oracles(glow, sd, cfg, x, noise, eps, "after 250 training steps")
+
+
+@pytest.mark.parametrize("logs_std", [0.5])
+def test_config_b_geometry_with_wide_logs_and_the_largest_finite_tails(logs_std):
+    """Config-B channel geometry (64x64x3, L=3, hidden 512; K = 4 so that the fp64 oracle finishes in seconds) with every
+    ActNorm / Conv2dZeros `logs` ~ N(0, 0.5) -- scales exp(3 logs) between ~0.05 and ~20 -- and the Conv2dZeros weights at the
+    largest sigma of a fixed ladder for which the fp32 oracle's forward AND decode stay finite with |z| < 1e3."""
+    batch = 4
+    cfg = O.default_cfg(K=4, batch=batch)
+    g = torch.Generator().manual_seed(17)
+    x = torch.rand(batch, 3, 64, 64, generator=g)
+    noise = torch.rand(batch, 3, 64, 64, generator=g) / 256
+    chosen = None
+    for zeros_std in (0.05, 0.02, 0.01, 0.005, 0.002):
+        sd = O.seeded_state_dict(cfg, seed=23, zeros_std=zeros_std, invconv_perturb=0.05)
+        with torch.no_grad():
+            sd = O.glow_init_actnorm(x, noise, sd, cfg)
+            gl = torch.Generator().manual_seed(29)
+            for k in sd:
+                if k.endswith("logs"):
+                    sd[k] = sd[k] + torch.randn(sd[k].shape, generator=gl) * logs_std
+            z32, nll32, _ = O.glow_forward(x, noise, sd, cfg)
+            if not (torch.isfinite(z32).all() and torch.isfinite(nll32).all() and z32.abs().max() < 1e3):
+                continue
+            glow = make_glow(cfg, sd, batch)
+            eps = [torch.randn(batch, *s, generator=torch.Generator().manual_seed(31 + i)) * 0.7
+                   for i, s in enumerate(glow.flow.split_shapes((3, 64, 64)))]
+            if torch.isfinite(O.glow_reverse(z32, sd, cfg, eps)).all():
+                chosen = zeros_std
+                break
+    assert chosen is not None, "no rung of the ladder keeps the fp32 oracle finite"
+    print(f"Conv2dZeros sigma = {chosen}")
+    _compare_with_oracles(glow.eval(), sd, cfg, x, noise, eps, f"config-B geometry, logs sigma {logs_std}, tails sigma {chosen}")
