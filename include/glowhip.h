@@ -252,6 +252,14 @@ int glowhip_glow_backward(glowhip_plan* plan, const void* packed, const float* x
                           const float* prior_logs, long prior_stride, const glowhip_layer_grads* grads,
                           float* grad_x, int N, void* workspace, size_t workspace_bytes, glowhip_stream_t stream);
 
+/* Gradient-ready marks: lets the caller overlap the gradient all-reduce of one process per GPU (the replacement of
+ * nn.DataParallel's reduce-to-GPU-0, network/trainer.py:117-123) with the rest of the backward sweep.  The sweep runs from the
+ * last layer to the first; glowhip_glow_backward records events[i] (hipEvent_t handles owned by the caller) on its stream as
+ * soon as every kernel writing the convolution WEIGHT gradients (f0_w, f2_w, f4_w -- 99.8 % of the gradient bytes) of all layers
+ * with index >= after_layer[i] has been enqueued.  after_layer must decrease.  The reduction-type gradients (biases, logs,
+ * invconv matrices of ALL layers) are final only after the call's last kernel.  n = 0 clears the marks.  HOST bookkeeping. */
+int glowhip_plan_backward_marks(glowhip_plan* plan, const int32_t* after_layer, void* const* events, int n);
+
 /* ------------------------------------------------------------------------------------------------
  * Optimiser step (reference network/trainer.py:142-150: clip_grad_value_, clip_grad_norm_, optimizer.step() with the
  * torch.optim.Adam / Adamax of network/builder.py:10-13,108-113) over ALL parameters as two launches.

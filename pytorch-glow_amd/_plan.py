@@ -304,16 +304,57 @@ class FlowPlan:
             raise _lib.GlowHipError("glow_backward: the parameters (or their packed images) changed between the training forward "
                                     "and its backward -- an in-place update or optimizer step in between would mix weight versions")
         fields = self._grad_fields()
-        grads = [torch.empty_like(p) for _, _, p in fields]
+        layout = self._bucket_layout()
+        # Gradients live in one flat buffer per bucket (the convolution weights of one LEVEL; everything small in a last one):
+        # a data-parallel run all-reduces each bucket in place -- no concatenation, no copy back -- and starts with a level's
+        # bucket as soon as the sweep has left that level (gradient-ready marks), while the lower levels are still being swept.
+        flats = [torch.empty(nel, dtype=torch.float32, device=self.device) for nel in layout["sizes"]]
+        grads = [flats[b][off:off + p.numel()].view_as(p) for (_, _, p), (b, off) in zip(fields, layout["slots"])]
         arr = (_lib.LayerGrads * len(self.layers))()
         for (i, name, _), gt in zip(fields, grads):
             setattr(arr[i], name, gt.data_ptr())
         gx = torch.empty_like(x) if want_grad_x else None
         ws = self._train_workspace(n)
-        check(lib().glowhip_glow_backward(self._h, ptr(self.packed), ptr(x), ptr(tape), tape.numel(), ptr(nll_grad),
-                                          ptr(z_grad), ptr(prior_mean), ptr(prior_logs), prior_stride, arr, ptr(gx), n,
-                                          ptr(ws), ws.numel(), stream_ptr(self.device)))
+        events = [torch.cuda.Event() for _ in layout["marks"]]
+        for ev in events:
+            ev.record()                  # (creates the handle; the C sweep records it again where it belongs)
+        marks = (ctypes.c_int32 * max(len(events), 1))(*layout["marks"])
+        handles = (ctypes.c_void_p * max(len(events), 1))(*[ev.cuda_event for ev in events])
+        check(lib().glowhip_plan_backward_marks(self._h, marks, handles, len(events)))
+        try:
+            check(lib().glowhip_glow_backward(self._h, ptr(self.packed), ptr(x), ptr(tape), tape.numel(), ptr(nll_grad),
+                                              ptr(z_grad), ptr(prior_mean), ptr(prior_logs), prior_stride, arr, ptr(gx), n,
+                                              ptr(ws), ws.numel(), stream_ptr(self.device)))
+        finally:
+            check(lib().glowhip_plan_backward_marks(self._h, None, None, 0))
+        done = torch.cuda.Event()
+        done.record()
+        # in sweep order: (flat bucket, event after which it is final); the small bucket is final at the end of the call
+        self.last_grad_buckets = [(flats[b], events[k]) for k, b in enumerate(layout["mark_bucket"])] + [(flats[-1], done)]
         return grads, gx
+
+    def _bucket_layout(self):
+        lay = getattr(self, "_bucket_lay", None)
+        if lay is not None:
+            return lay
+        fields = self._grad_fields()
+        level_of, starts, cur = [], [], -1
+        for i, layer in enumerate(self.layers):
+            if layer.glowhip_kind == _lib.LAYER_SQUEEZE or cur < 0:
+                cur += 1
+                starts.append(i)
+            level_of.append(cur)
+        nlev = cur + 1
+        sizes = [0] * (nlev + 1)                                   # one bucket per level + the small one (last)
+        slots = []
+        for i, name, p in fields:
+            b = level_of[i] if name in ("f0_w", "f2_w", "f4_w") else nlev
+            slots.append((b, sizes[b]))
+            sizes[b] += (p.numel() + 63) // 64 * 64                # 256-byte aligned slots
+        order = [l for l in range(nlev - 1, -1, -1) if sizes[l] > 0]   # sweep order: deepest level first
+        lay = dict(sizes=[max(v, 64) for v in sizes], slots=slots, marks=[starts[l] for l in order], mark_bucket=order)
+        self._bucket_lay = lay
+        return lay
 
     def actnorm_init(self, x, noise, actnorm_scale: float) -> None:
         """Data-dependent init of every ActNorm in the plan from batch x (writes the parameters in place)."""

@@ -43,6 +43,8 @@ struct CnetGeo {
     int HW;
     int lpp;          // log2(pixels per staging pass)
     int pxt, lpxt;    // pixels per workgroup tile (128 or 64) and its log2
+    int ng, Cg;       // f.4 in ng groups of Cg output channels (Mpad4, NRT4, NU4, KS, npass describe ONE group): wide steps
+                      // (C = 96: Cout = 96 = 2 x 48) run P3 + P4 once per group, h2 handed over again from the registers
 };
 
 __host__ __device__ inline int cnet_trow(int M9) {   // T row stride (floats): multiple of 4, an odd multiple (bank spread)
@@ -154,7 +156,9 @@ __device__ __forceinline__ long long block_sum_ll(long long v, long long* red) {
 }
 
 // PRE: the launch may finish the previous step while it builds its window (a.pre_on); without it none of that code is compiled in
-template <int HID, int MS, int UPW, int PXT, bool PRE>
+// NG: f.4 output-channel groups (compile time: with one group nothing of the group loop survives -- as a run-time count it kept
+// the h2 accumulators alive through P4 and cost the level-1 instance 88 bytes of spills)
+template <int HID, int MS, int UPW, int PXT, bool PRE, int NG = 1>
 __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
     const bool pre_on = PRE && a.pre_on;
     constexpr int NPT = PXT / 32;                    // pixel tiles of the workgroup: 4 (128 pixels) or 2 (64 pixels)
@@ -237,6 +241,7 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
         }
     };
     GH_STAMP(0);
+    GH_STAMP_VAL(63, __builtin_amdgcn_s_getreg((31 << 11) | 4));      // HW_REG_HW_ID: wave slot [3:0], SIMD [5:4], CU [11:8]
     // requested before the window is built (their L2 round trips overlap P0): the first two A sets of P1 and of P2
     loadA1(0, 0, A1[0]);
     loadA1(0, g.steps0 > 1 ? 1 : 0, A1[1]);
@@ -327,7 +332,7 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
     // from memory gets the sign bit the hardware's own NaNs have.
     for (int e = tid; e < 2 * HID; e += 512) t_rs0[e] = canon_nan(-rs0[e]);                   // rs0 | b0 are adjacent in the image
     for (int e = tid; e < MR; e += 512) { t_rs2[e] = canon_nan(rs2[ms_row0 + e]); t_b2[e] = canon_nan(-rs2[HID + ms_row0 + e]); }
-    for (int e = tid; e < g.Mpad4; e += 512) t_rs4[e] = canon_nan(-rs4[e]);
+    for (int e = tid; e < g.Mpad4; e += 512) t_rs4[e] = canon_nan(-rs4[e]);      // (group 0; the others are loaded in the group loop)
     float* nz = nullptr;     // with `pre`: z1 of the freshly finished state, fp32 [Cin][KP]
     if (pre_on) {
         // ---- finish the PREVIOUS step on the window pixels: coupling (+ log-det for the tile's own pixels), then the channel mixer;
@@ -605,22 +610,36 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
         }
     };
     auto p2_pass = [&](int hh) {
-        // ---- P2: acc2 += W2'[rows, pass hh] h1[pass hh]; B from LDS, A two k-steps ahead from L2
+        // ---- P2: acc2 += W2'[rows, pass hh] h1[pass hh]; B from LDS, A two k-steps ahead from L2.
+        // Operand timing inside a k-step (per-wave stamps: every k-step used to open with the full LDS round trip of its eight B
+        // reads in front of its first MFMA -- nothing hides that for the wave that has a SIMD to itself, ~20 % of P2):
+        //   * the hi-plane B fragments of step s + 1 are requested before the THIRD sweep of step s (which still multiplies step
+        //     s' own hi plane: the next ones go to the other half of a two-deep, named register pair);
+        //   * the lo-plane B fragments of step s are requested at its start and first used by the SECOND sweep, 8 MFMAs later.
+        // The k-loop is fully unrolled: A set (s % 3) and B pair (s & 1) are register NAMES.
         {
             const int ks0 = hh * NS;
             const _Float16* bp = hbuf + ((long)kl * PXT + pt2 * 32 + ml) * 8;
-            auto kstep = [&](int s, const h8 (&use)[2 * RT2], h8 (&fill)[2 * RT2]) {
+            h8 bhq[2][PT2];
+            auto load_bh = [&](int s, h8 (&dst)[PT2]) {
+                const _Float16* bs = bp + (long)s * (2 * PXT * 8);
+#pragma unroll
+                for (int j = 0; j < PT2; ++j) dst[j] = *reinterpret_cast<const h8*>(bs + j * 256);
+            };
+            load_bh(0, bhq[0]);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                h8 (&use)[2 * RT2] = A2[s % 3];
+                h8 (&fill)[2 * RT2] = A2[(s + 2) % 3];
+                h8 (&bh)[PT2] = bhq[s & 1];
                 loadA2(ks0 + min(s + 2, NS - 1), fill);          // unconditional (clamped)
                 // the scheduler must not sink these loads towards their use two k-steps later (it does, to save registers, and
                 // the wave then waits a full L2 round trip per k-step: measured 57% of the MFMA rate for a wave on its own)
                 __builtin_amdgcn_sched_barrier(0);
                 const _Float16* bs = bp + (long)s * (2 * PXT * 8);
-                h8 bh[PT2], bl[PT2];
+                h8 bl[PT2];
 #pragma unroll
-                for (int j = 0; j < PT2; ++j) {
-                    bh[j] = *reinterpret_cast<const h8*>(bs + j * 256);
-                    bl[j] = *reinterpret_cast<const h8*>(bs + j * 256 + (long)NCH * PXT * 8);
-                }
+                for (int j = 0; j < PT2; ++j) bl[j] = *reinterpret_cast<const h8*>(bs + j * 256 + (long)NCH * PXT * 8);
 #pragma unroll
                 for (int i = 0; i < RT2; ++i)
 #pragma unroll
@@ -631,20 +650,15 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
 #pragma unroll
                     for (int j = 0; j < PT2; ++j)
                         acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(use[i], bl[j], acc2[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (s + 1 < NS) load_bh(s + 1, bhq[(s + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < RT2; ++i)
 #pragma unroll
                     for (int j = 0; j < PT2; ++j)
                         acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(use[RT2 + i], bh[j], acc2[i][j], 0, 0, 0);
-            };
-#pragma unroll 1
-            for (int s = 0; s + 3 <= NS; s += 3) {
-                kstep(s, A2[0], A2[2]);
-                kstep(s + 1, A2[1], A2[0]);
-                kstep(s + 2, A2[2], A2[1]);
             }
-            if (NS % 3 >= 1) kstep(NS - NS % 3, A2[0], A2[2]);
-            if (NS % 3 == 2) kstep(NS - 1, A2[1], A2[0]);
             if (!A2_LATE && hh + 1 < NH) {   // A sets of the next pass' first two k-steps: in flight while P1 rebuilds the LDS buffer
                 loadA2((hh + 1) * NS, A2[0]);
                 loadA2((hh + 1) * NS + 1, A2[1]);
@@ -687,9 +701,11 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
     const int nunits = g.NU4 * g.KS;
     const int nsl = (LK / 16) / g.KS;                        // k-steps of one h2 load per k part
     h8 A4[3][2 * RTU];
+    const long w4_grp = (long)(sh2_image_bytes(HID, g.Mpad4) / sizeof(_Float16));     // halfs from one group's image to the next
+    int grp = 0;                                             // output-channel group of f.4 being computed
     auto a4_base = [&](int unit, int l) {
         const int kp = unit / g.NU4;
-        return W4 + ((long)((ms_row0 + l * LK) / 8 + 2 * kp * nsl + kl) * g.Mpad4 + ml) * 8;
+        return W4 + (NG > 1 ? grp * w4_grp : 0) + ((long)((ms_row0 + l * LK) / 8 + 2 * kp * nsl + kl) * g.Mpad4 + ml) * 8;
     };
     auto loadA4 = [&](const _Float16* ap, int ru, int st, h8 (&dst)[2 * RTU]) {
 #pragma unroll
@@ -747,6 +763,19 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
 
     // ---- P3: T[m][px] = sum_k W4t[m][k] h2[k][px] over this workgroup's h2 rows (= k range [ms_row0, ms_row0 + MR))
     f32x16_t accT[UPW][4];     // tile 4-index = (row tile within the unit) * NPT + pixel tile
+#pragma unroll 1
+    for (grp = 0; grp < NG; ++grp) {
+    if (NG > 1 && grp > 0) {     // next group of output channels: its row scales and first A sets (the tap sums of the previous group are done
+                       // with T = hbuf after this barrier; h2 is still in the accumulator registers and is handed over again)
+        __syncthreads();
+        const float* rs4g = (const float*)((const char*)a.w4 + (size_t)grp * sh2_image_bytes(HID, g.Mpad4) + sh2_rowscale_off(HID, g.Mpad4));
+        for (int e = tid; e < g.Mpad4; e += 512) t_rs4[e] = canon_nan(-rs4g[e]);
+        if (wid < nunits) {
+            const _Float16* ap = a4_base(wid, 0);
+            loadA4(ap, wid % g.NU4, 0, A4[0]);
+            loadA4(ap, wid % g.NU4, nsl > 1 ? 1 : 0, A4[1]);
+        }
+    }
 #pragma unroll
     for (int u = 0; u < UPW; ++u)
 #pragma unroll
@@ -849,12 +878,13 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
     // ---- P4: T -> LDS as fp32 [k part][row m][pixel] (row scale applied; lanes = consecutive pixels: conflict-free stores and
     // tap reads; one slab per k part, summed in a fixed order by the readers), then the 9-tap sums
     float* T = reinterpret_cast<float*>(hbuf);
-    const int Cout = a.Cout;
+    const int Cout = g.Cg;                                   // T rows of THIS group: row m = tap * Cg + (channel within the group)
+    const int CoutT = a.Cout, c0 = NG > 1 ? grp * g.Cg : 0;               // all output channels (strides of the partial sums), first of the group
     const int ppx = 1 << g.lpp;                              // pixels per staging pass (whole sub-tiles when npass = 2)
     const long msN = (long)blockIdx.y * a.N;
     float* hpart = a.scratch;
-    float* hup = a.scratch + (long)MS * a.N * Cout * HW;
-    float* hdn = hup + (long)MS * g.tiles * Cout * W;
+    float* hup = a.scratch + (long)MS * a.N * CoutT * HW;
+    float* hdn = hup + (long)MS * g.tiles * CoutT * W;
     // row scales of this wave's T rows, fetched before the loop (one LDS round trip instead of one per group of four rows)
     f32x4_t rs4v[UPW][RTU][4];
 #pragma unroll
@@ -922,7 +952,7 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
 #pragma unroll
                 for (int tap = 0; tap < 9; ++tap) sum += ok[tap] ? v[tap] : 0.f;
             }
-            hpart[((msN + n) * Cout + ce) * HW + (long)(y0 + r) * W + x] = sum;
+            hpart[((msN + n) * CoutT + c0 + ce) * HW + (long)(y0 + r) * W + x] = sum;
         }
         // halo rows (NI = 1 only): what the tile's first row gives to image row y0 - 1, its last row to row y0 + R
         if (g.NI == 1 && g.R < H) {
@@ -947,11 +977,12 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
                     const float v0 = tp[off[0]], v1 = tp[off[1]], v2 = tp[off[2]];
                     sacc += (ok[0] ? v0 : 0.f) + (ok[1] ? v1 : 0.f) + (ok[2] ? v2 : 0.f);
                 }
-                (dn ? hdn : hup)[(((long)blockIdx.y * g.tiles + tb) * Cout + co) * W + x] = sacc;
+                (dn ? hdn : hup)[(((long)blockIdx.y * g.tiles + tb) * CoutT + c0 + co) * W + x] = sacc;
             }
         }
         if (pass + 1 < g.npass) __syncthreads();
     }
+    }      // output-channel groups
     if (pre_on && blockIdx.y == 0 && lane < g.NI && (a.pre.mode == TAIL_AFFINE_FWD || a.pre.mode == TAIL_AFFINE_REV)) {
         const long long v = ld_slot[wid * 2 + lane];         // (written by this wave's lane 0 in the window phase)
         if (v != 0 && n0 + lane < a.N) atomicAdd(a.acc + (n0 + lane), (unsigned long long)v);
@@ -1118,14 +1149,30 @@ static size_t cnet_lds_bytes(const CnetGeo& g, int hidden) {
     return (size_t)CN_HBUF + (size_t)2 * g.winplane * sizeof(_Float16) + ((size_t)4 * hidden + g.Mpad4 + g.G + 4 + 36) * sizeof(float);
 }
 
+// f.4 output-channel groups: one up to 56 channels, else the fewest (2..4) equal even-sized groups of at most 56 (0: unsupported)
+int cnet_groups(int Cout) {
+    if (Cout <= 56) return 1;
+    for (int ng = 2; ng <= 4; ++ng)
+        if (Cout % ng == 0 && Cout / ng <= 56 && (Cout / ng) % 2 == 0) return ng;
+    return 0;
+}
+size_t cnet_w4_bytes(int hidden, int Cout) {
+    const int ng = cnet_groups(Cout);
+    return ng ? (size_t)ng * sh2_image_bytes(hidden, cnet_mpad4(Cout / ng)) : 0;
+}
+
 static bool cnet_geo(int Cin, int H, int W, int hidden, int Cout, int N, int pxt, CnetGeo* out) {
     if (!(hidden == 64 || hidden == 128 || hidden == 256 || hidden == 512)) return false;
     if (pxt == 64 && hidden < 128) return false;
     if (!pow2(W) || !pow2(H) || W < 4 || W > pxt) return false;
     const int HW = H * W;
     if (HW < 64) return false;
-    if (Cin < 1 || Cout < 1 || Cout > 56) return false;
+    if (Cin < 1 || Cout < 1) return false;
+    const int ng = cnet_groups(Cout);
+    if (ng == 0 || ng > 2 || (ng == 2 && pxt != 64)) return false;      // (instantiated: one group; two groups at 64-pixel tiles)
     CnetGeo g{};
+    g.ng = ng; g.Cg = Cout / ng;
+    Cout = g.Cg;      // everything below describes ONE group of f.4 output channels
     g.HW = HW;
     g.pxt = pxt; g.lpxt = __builtin_ctz(pxt);
     g.wshift = __builtin_ctz(W);
@@ -1170,6 +1217,16 @@ size_t cnet_scratch_floats_per_sample(int H, int W, int Cout) {
 }
 
 template <int HID, int MS, int UPW, int PXT>
+static int launch_cnet_inst2(const CnetArgs& a, const CnetGeo& g, hipStream_t s) {     // two groups of f.4 output channels (C = 96)
+    const size_t lds = cnet_lds_bytes(g, HID);
+    GH_REQUIRE(!a.pre_on, "cnet: no chained launch with output-channel groups");
+    (void)hipFuncSetAttribute((const void*)k_cnet<HID, MS, UPW, PXT, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((k_cnet<HID, MS, UPW, PXT, false, 2>), dim3(g.tiles, MS), dim3(512), lds, s, a, g);
+    GH_LAUNCH_CHECK("k_cnet");
+    return GLOWHIP_OK;
+}
+
+template <int HID, int MS, int UPW, int PXT>
 static int launch_cnet_inst(const CnetArgs& a, const CnetGeo& g, hipStream_t s) {
     const size_t lds = cnet_lds_bytes(g, HID);
     if (a.pre_on) {
@@ -1211,7 +1268,10 @@ int launch_cnet_main(const CnetArgs& a, hipStream_t s, CnetPending* out) {
     while ((a.hidden / ms / 16) / g.KS < 1 && ms > 1) ms /= 2;
     GH_REQUIRE(!a.pre_on || a.pre.MS == ms, "cnet: a chained launch needs the previous step's row split");
     int rc = GLOWHIP_EINVAL;
-#define GH_CN(hid, m, u, px) if (a.hidden == hid && ms == m && upw == u && g.pxt == px) rc = launch_cnet_inst<hid, m, u, px>(a, g, s);
+#define GH_CN(hid, m, u, px) if (g.ng == 1 && a.hidden == hid && ms == m && upw == u && g.pxt == px) rc = launch_cnet_inst<hid, m, u, px>(a, g, s);
+#define GH_CN2(hid, m, u, px) if (g.ng == 2 && a.hidden == hid && ms == m && upw == u && g.pxt == px) rc = launch_cnet_inst2<hid, m, u, px>(a, g, s);
+    GH_CN2(512, 1, 1, 64) GH_CN2(512, 2, 1, 64) GH_CN2(512, 4, 1, 64) GH_CN2(256, 1, 1, 64) GH_CN2(256, 2, 1, 64) GH_CN2(128, 1, 1, 64)
+#undef GH_CN2
     GH_CN(512, 1, 1, 128) GH_CN(512, 2, 1, 128) GH_CN(512, 4, 1, 128) GH_CN(256, 1, 1, 128) GH_CN(256, 2, 1, 128) GH_CN(256, 4, 1, 128)
     GH_CN(128, 1, 1, 128) GH_CN(128, 2, 1, 128) GH_CN(64, 1, 1, 128)
     GH_CN(512, 2, 2, 128) GH_CN(512, 4, 2, 128) GH_CN(256, 1, 2, 128) GH_CN(256, 2, 2, 128) GH_CN(256, 4, 2, 128) GH_CN(128, 1, 2, 128)
@@ -1267,7 +1327,7 @@ int launch_cnet(const CnetArgs& a, hipStream_t s) {
 
 // window-time finishing stages [C][window] + [C][C] + [Cin][window] floats in the (then idle) activation buffer
 bool cnet_pre_supported(int Cin, int H, int W, int hidden, int Cout, int C) {
-    if (C > 96) return false;
+    if (C > 96 || cnet_groups(Cout) != 1) return false;
     for (int pxt : {128, 64}) {
         CnetGeo g;
         if (!cnet_geo(Cin, H, W, hidden, Cout, 0, pxt, &g)) continue;

@@ -101,20 +101,23 @@ __device__ __forceinline__ float relu_(float v) { return v < 0.f ? 0.f : v; }
 #ifdef GLOWHIP_DEBUG_STAMPS
 // (one array + one extern "C" reader per translation unit: no relocatable device code in this build)
 #define GH_STAMPS_DEFINE(name)                                                                                  \
-    namespace glowhip { __device__ unsigned long long g_stamps_local[64]; }                                     \
+    namespace glowhip { __device__ unsigned long long g_stamps_local[8 * 64]; }                                 \
     extern "C" int glowhip_debug_read_stamps_##name(unsigned long long* dst) {                                  \
         return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(glowhip::g_stamps_local), sizeof(unsigned long long) * 64); \
+    }                                                                                                           \
+    extern "C" int glowhip_debug_read_stamps_all_##name(unsigned long long* dst) {   /* [wave][stamp] */        \
+        return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(glowhip::g_stamps_local), sizeof(unsigned long long) * 8 * 64); \
     }
 #ifndef GH_STAMP_BLOCK
 #define GH_STAMP_BLOCK 0
 #endif
-#ifndef GH_STAMP_THREAD
-#define GH_STAMP_THREAD 0
-#endif
-#define GH_STAMP(i) do { if (blockIdx.x == GH_STAMP_BLOCK && blockIdx.y == 0 && threadIdx.x == GH_STAMP_THREAD) g_stamps_local[i] = __builtin_readcyclecounter(); } while (0)
+// lane 0 of EVERY wave of the stamped workgroup records: [wave][stamp] (wave 0's row is what the one-wave readers see)
+#define GH_STAMP(i) do { if (blockIdx.x == GH_STAMP_BLOCK && blockIdx.y == 0 && (threadIdx.x & 63) == 0) g_stamps_local[(threadIdx.x >> 6) * 64 + (i)] = __builtin_readcyclecounter(); } while (0)
+#define GH_STAMP_VAL(i, v) do { if (blockIdx.x == GH_STAMP_BLOCK && blockIdx.y == 0 && (threadIdx.x & 63) == 0) g_stamps_local[(threadIdx.x >> 6) * 64 + (i)] = (unsigned long long)(v); } while (0)
 #else
 #define GH_STAMPS_DEFINE(name)
 #define GH_STAMP(i) do { } while (0)
+#define GH_STAMP_VAL(i, v) do { } while (0)
 #endif
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

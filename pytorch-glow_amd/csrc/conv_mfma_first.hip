@@ -47,7 +47,7 @@ size_t conv_mfma_first_packed_bytes(int Cin, int Cout) { return ((size_t)9 * Cin
 // that every tap/channel LDS offset of the unrolled k-loop is an instruction immediate (with a runtime width the
 // 27 offsets lived in VGPRs: 253 VGPRs + spills into AGPRs, one wave per SIMD).
 template <int BN, int WF>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)     // (at 193 + 64 = 257 registers the BN = 128 instances ran one wave per SIMD)
 k_conv_first(const float* __restrict__ X, long x_bs, const float* __restrict__ Wf, const float* __restrict__ bs,
              float* __restrict__ Y, int N, int Cin, int H, int W, int M, FirstGeom gr, int relu,
              _Float16* __restrict__ Ysh) {

@@ -571,7 +571,7 @@ glowhip_plan* glowhip_plan_create(const glowhip_layer_desc* layers, int n_layers
             if (L.cnet) {
                 L.cn_w0 = take(off, sh2_image_bytes(cnet_g0(C / 2) * 8, d.hidden));
                 L.cn_w2 = take(off, sh2_image_bytes(d.hidden, d.hidden));
-                L.cn_w4 = take(off, sh2_image_bytes(d.hidden, cnet_mpad4(L.Cout)));
+                L.cn_w4 = take(off, cnet_w4_bytes(d.hidden, L.Cout));
                 p->max_hidden = std::max(p->max_hidden, (long)cnet_scratch_floats_per_sample(H, W, L.Cout));
             }
             if (L.mfma_last) L.f4_wp = take(off, conv_mfma_tail_packed_bytes(d.hidden, L.Cout));
@@ -648,8 +648,12 @@ glowhip_plan* glowhip_plan_create(const glowhip_layer_desc* layers, int n_layers
                 p->repack_jobs.push_back(r0);
                 RepackJob r2{}; r2.w = d.f2_w; r2.out_off = L.cn_w2; r2.kind = REPACK_SH2_GEMM; r2.Cin = d.hidden; r2.Cout = d.hidden;
                 r2.K = d.hidden; r2.fold_bias = d.f2_an_bias; r2.fold_logs = d.f2_an_logs; r2.use = 1; p->repack_jobs.push_back(r2);
-                RepackJob r4{}; r4.w = d.f4_w; r4.out_off = L.cn_w4; r4.kind = REPACK_SH2_TAIL; r4.Cin = d.hidden; r4.Cout = L.Cout;
-                r4.Kpad = cnet_mpad4(L.Cout); r4.use = 1; p->repack_jobs.push_back(r4);
+                const int ng = cnet_groups(L.Cout), cg = L.Cout / ng;       // one image per group of f.4 output channels
+                for (int gi = 0; gi < ng; ++gi) {
+                    RepackJob r4{}; r4.w = d.f4_w + (size_t)gi * cg * d.hidden * 9; r4.out_off = L.cn_w4 + gi * sh2_image_bytes(d.hidden, cnet_mpad4(cg));
+                    r4.kind = REPACK_SH2_TAIL; r4.Cin = d.hidden; r4.Cout = cg;
+                    r4.Kpad = cnet_mpad4(cg); r4.use = 1; p->repack_jobs.push_back(r4);
+                }
             }
             if (L.sh_tail) {
                 RepackJob r{}; r.w = d.f4_w; r.out_off = L.f4_sh; r.kind = REPACK_SH_TAIL; r.Cin = d.hidden; r.Cout = L.Cout;

@@ -62,6 +62,7 @@ struct glowhip_plan {
     int n_split = 0;
     std::vector<glowhip::GradJob> grad_jobs;   // host copy of the last backward's finalize table (kept alive for the async copy)
     bool rng_on = false; unsigned long long rng_seed = 0, rng_calls = 0;   // in-kernel dequantisation noise (glowhip_plan_set_dequant_rng)
+    std::vector<std::pair<int, hipEvent_t>> bwd_marks;   // (layer index, event): glowhip_plan_backward_marks
     int family = GLOWHIP_FAMILY_AUTO;          // kernel family of the coupling networks (glowhip_plan_set_family): a property of the plan
     std::map<std::string, long> launch_counts; // run-time record of which kernel families this plan launched (glowhip_plan_launch_counts)
 };

@@ -275,7 +275,16 @@ static int backward_sweep(glowhip_plan* p, const void* packed, const float* x_in
     auto fin = [&](const double* acc, float* out, int n, double add_mul, const float* winv = nullptr, int C = 0) {
         if (out) jobs.push_back(GradJob{acc, out, n, add_mul, winv, C});
     };
+    size_t mark_i = 0;      // gradient-ready marks (glowhip_plan_backward_marks), in sweep order
+    auto marks_down_to = [&](int li) {
+        while (mark_i < p->bwd_marks.size() && p->bwd_marks[mark_i].first >= li) {
+            if (hipEventRecord(p->bwd_marks[mark_i].second, s) != hipSuccess) { set_error("backward: hipEventRecord of a mark failed"); return GLOWHIP_ELAUNCH; }
+            ++mark_i;
+        }
+        return GLOWHIP_OK;
+    };
     for (int li = nl - 1; li >= 0; --li) {
+        GH_TRY(marks_down_to(li + 1));      // every layer above li has been swept
         const LayerPlan& L = p->layers[li];
         const glowhip_layer_desc& d = L.d;
         const glowhip_layer_grads& G = grads[li];
@@ -391,6 +400,7 @@ static int backward_sweep(glowhip_plan* p, const void* packed, const float* x_in
             g = gnext;
         }
     }
+    GH_TRY(marks_down_to(0));
     if (!jobs.empty()) {
         if (hipMemcpyAsync(w.jobs, jobs.data(), jobs.size() * sizeof(GradJob), hipMemcpyHostToDevice, s) != hipSuccess) {
             set_error("backward: hipMemcpyAsync of the finalize job table failed");
@@ -434,6 +444,18 @@ int glowhip_glow_forward_train(glowhip_plan* plan, const void* packed, const flo
     const double offset = -log(pow(2.0, n_bits)) * chw;
     const double scale = -1.0 / (log(2.0) * chw);
     return launch_finalize(nullptr, w.acc, at<double>(packed, 0), 1.0, offset, scale, nll_out, objective_out, N, s);
+}
+
+int glowhip_plan_backward_marks(glowhip_plan* plan, const int32_t* after_layer, void* const* events, int n) {
+    GH_REQUIRE(plan && n >= 0 && (n == 0 || (after_layer && events)), "plan_backward_marks: bad argument");
+    plan->bwd_marks.clear();
+    for (int i = 0; i < n; ++i) {
+        GH_REQUIRE(events[i] != nullptr, "plan_backward_marks: null event %d", i);
+        GH_REQUIRE(after_layer[i] >= 0 && after_layer[i] < (int)plan->layers.size(), "plan_backward_marks: layer %d out of range", after_layer[i]);
+        GH_REQUIRE(i == 0 || after_layer[i] < after_layer[i - 1], "plan_backward_marks: layer indices must decrease (sweep order)");
+        plan->bwd_marks.emplace_back(after_layer[i], (hipEvent_t)events[i]);
+    }
+    return GLOWHIP_OK;
 }
 
 int glowhip_glow_backward(glowhip_plan* plan, const void* packed, const float* x, const void* tape, size_t tape_bytes,

@@ -164,7 +164,9 @@ __host__ __device__ static inline size_t sh2_rowscale_off(int Kp, int M) { retur
 // ---- the whole coupling network f() = f.0 -> f.2 -> f.4 as ONE kernel + a light finishing kernel (cnet_sh.hip) --------
 bool cnet_supported(int Cin, int H, int W, int hidden, int Cout);
 int cnet_g0(int Cin);                 // 8-wide k groups of the f.0 image (even count)
-int cnet_mpad4(int Cout);             // rows of the taps-as-rows f.4 image (multiple of 32)
+int cnet_mpad4(int Cout);             // rows of the taps-as-rows f.4 image (multiple of 32) of ONE group of Cout output channels
+int cnet_groups(int Cout);            // f.4 runs in that many groups of Cout / groups output channels (1 up to 56 channels; 0: unsupported)
+size_t cnet_w4_bytes(int hidden, int Cout);   // all groups' images, one after the other
 size_t cnet_scratch_floats(int N, int H, int W, int Cout);   // partial-sum scratch (floats) for batch N; <= N * the per-sample bound
 size_t cnet_scratch_floats_per_sample(int H, int W, int Cout);
 // What a k_cnet launch leaves behind for whoever finishes the step -- the finishing kernel, or the NEXT step's k_cnet while it

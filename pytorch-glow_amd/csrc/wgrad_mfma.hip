@@ -156,7 +156,9 @@ k_wgrad_gemm(const float* __restrict__ A, long a_bs, const float* __restrict__ B
 // goes from MFMA-bound to operand-delivery-bound.  The gradient operand (A) is multiplied by a_scale = 2^k on the way in (it is
 // ~1e-6 .. 1e-10 early in training, below fp16's normal range) and the partial sums by 2^-k on the way out (exact).
 template <int BN>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)      // two workgroups per CU: at 269 registers (141 + 128 accumulators) the kernel ran ONE
+                                               // wave per SIMD and every k-tile waited out its own HBM round trip (7.4 k cycles per
+                                               // k-tile against 768 of MFMA work)
 k_wgrad_gemm_sh(const float* __restrict__ A, long a_bs, const float* __restrict__ B, long b_bs, float* __restrict__ partial,
                 int HW, int Mpad, int Npad, int ktiles_total, int ktiles_per_split, float a_scale) {
     constexpr int BM = 128, BK = 32;
@@ -283,15 +285,32 @@ k_wgrad_gemm_sh(const float* __restrict__ A, long a_bs, const float* __restrict_
 //   mode 1: m = o*9 + tap, n = i: dW[(o*Nreal + i)*9 + tap]      (f.4: dW4[o][i][tap])
 __global__ void __launch_bounds__(256) k_wgrad_reduce(const float* __restrict__ partial, float* __restrict__ dw, int splits,
                                                       int Mpad, int Npad, int Mreal, int Nreal, int mode) {
+    // four consecutive columns per thread (Npad % 64 == 0: 16-byte loads), eight splits' loads in flight, added in split order
+    const int n4 = (Nreal + 3) >> 2;
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
-    if (e >= (long)Mreal * Nreal) return;
-    const int m = (int)(e / Nreal), n = (int)(e - (long)m * Nreal);
-    float s = 0.f;
-    for (int k = 0; k < splits; ++k) s += partial[((long)k * Mpad + m) * Npad + n];
-    if (mode == 0) dw[e] = s;
-    else {
-        const int o = m / 9, tap = m - o * 9;
-        dw[((long)o * Nreal + n) * 9 + tap] = s;
+    if (e >= (long)Mreal * n4) return;
+    const int m = (int)(e / n4), n0 = (int)(e - (long)m * n4) * 4;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    const float* src = partial + (long)m * Npad + n0;
+    const long stride = (long)Mpad * Npad;
+    int k = 0;
+    for (; k + 8 <= splits; k += 8) {
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(src + (k + u) * stride);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; k < splits; ++k) s += *reinterpret_cast<const f32x4*>(src + k * stride);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = n0 + j;
+        if (n >= Nreal) break;
+        if (mode == 0) dw[(long)m * Nreal + n] = s[j];
+        else {
+            const int o = m / 9, tap = m - o * 9;
+            dw[((long)o * Nreal + n) * 9 + tap] = s[j];
+        }
     }
 }
 
@@ -300,7 +319,7 @@ bool wgrad_mfma_supported(int HW, int Mpad, int Npad) { return HW % 32 == 0 && M
 size_t wgrad_mfma_partial_floats(int Mpad, int Npad, int N, int HW) {
     const int tiles = (Mpad / 128) * (Npad % 128 == 0 ? Npad / 128 : Npad / 64);
     const int total = (int)((long)N * HW / 32);
-    int splits = std::max(1, std::min(total, (384 + tiles - 1) / tiles));
+    int splits = std::max(1, std::min(total, (512 + tiles - 1) / tiles));
     return (size_t)splits * Mpad * Npad;
 }
 
@@ -311,7 +330,7 @@ int launch_wgrad_mfma(const float* A, long a_bs, const float* B, long b_bs, floa
     const bool bn128 = Npad % 128 == 0;
     const int tiles = (Mpad / 128) * (bn128 ? Npad / 128 : Npad / 64);
     const int total = (int)((long)N * HW / 32);
-    int splits = std::max(1, std::min(total, (384 + tiles - 1) / tiles));   // ~1.5 workgroups per CU
+    int splits = std::max(1, std::min(total, (512 + tiles - 1) / tiles));   // 2 workgroups per CU
     const int per = (total + splits - 1) / splits;
     splits = (total + per - 1) / per;
     if (sh_scale > 0.f && bn128)       // f16 matrix pipe, split-half operands (sh_scale = power-of-two pre-scale of the gradient operand)
@@ -327,7 +346,7 @@ int launch_wgrad_mfma(const float* A, long a_bs, const float* B, long b_bs, floa
         hipLaunchKernelGGL(k_wgrad_gemm<64>, dim3(tiles * splits), dim3(256), 0, s, A, a_bs, B, b_bs, partial, HW, Mpad, Npad,
                            total, per);
     GH_LAUNCH_CHECK("k_wgrad_gemm");
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3(cdiv((long)Mreal * Nreal, 256)), dim3(256), 0, s, partial, dw, splits, Mpad, Npad,
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3(cdiv((long)Mreal * ((Nreal + 3) / 4), 256)), dim3(256), 0, s, partial, dw, splits, Mpad, Npad,
                        Mreal, Nreal, mode);
     GH_LAUNCH_CHECK("k_wgrad_reduce");
     return GLOWHIP_OK;

@@ -131,6 +131,16 @@ class FlowModel(nn.Module):
             return self._plans.get(list(self.layers), tuple(x_or_chw.shape[1:]), x_or_chw.device)
         return self._plans.get(list(self.layers), tuple(x_or_chw), device)
 
+    def pop_grad_buckets(self):
+        """[(flat gradient bucket, ready event)] of the backward that just ran (FlowPlan.glow_backward), in the order the buckets
+        become final -- for `parallel.allreduce_buckets`; None when no HIP backward ran since the last call."""
+        for plan in self._plans._plans.values():
+            b = getattr(plan, "last_grad_buckets", None)
+            if b is not None:
+                plan.last_grad_buckets = None
+                return b
+        return None
+
     def invalidate_packed(self):
         """Call after writing parameters through ``.data`` (which torch's version counters do not see)."""
         self._plans.invalidate()

@@ -107,6 +107,41 @@ def allreduce_gradients(module: torch.nn.Module, world: Optional[int] = None, av
         off += n
 
 
+_SIDE_STREAMS = {}
+
+
+def allreduce_buckets(buckets, world: Optional[int] = None, average: bool = True) -> None:
+    """All-reduce flat gradient buckets IN PLACE, each as soon as its `ready` event has passed, on a side stream -- so the
+    collective of the level the backward sweep has already left runs over xGMI while the sweep is still computing the levels
+    below it (`FlowPlan.last_grad_buckets`, csrc glowhip_plan_backward_marks).  buckets: [(flat tensor, event or None)] in the
+    order they become ready.  The current stream waits for the last collective before returning to the caller's work."""
+    world = dist.get_world_size() if world is None else world
+    if world <= 1 or not buckets:
+        return
+    if not buckets[0][0].is_cuda:                     # CPU / gloo (tests): same collectives, no streams
+        for flat, _ in buckets:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            if average:
+                flat /= world
+        return
+    dev = buckets[0][0].device
+    side = _SIDE_STREAMS.get(dev)
+    if side is None:
+        side = _SIDE_STREAMS[dev] = torch.cuda.Stream(device=dev)
+    cur = torch.cuda.current_stream(dev)
+    with torch.cuda.stream(side):
+        for flat, ready in buckets:
+            if ready is not None:
+                side.wait_event(ready)
+            flat.record_stream(side)
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)       # RCCL: ordered after the side stream's wait
+            if average:
+                flat.div_(world)
+    done = torch.cuda.Event()
+    done.record(side)
+    cur.wait_event(done)
+
+
 def train_step(glow, optimizer, x_local: torch.Tensor, world: int = 1, max_grad_clip: float = 0.0,
                max_grad_norm: float = 0.0, skip_nonfinite: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
     """One data-parallel training step of the reference's loop (network/trainer.py:123-150) on this rank's shard:
@@ -119,7 +154,11 @@ def train_step(glow, optimizer, x_local: torch.Tensor, world: int = 1, max_grad_
         z, nll, _ = glow.normal_flow(x_local, None)
         loss = glow.generative_loss(nll)
         loss.backward()
-    allreduce_gradients(glow, world)
+    buckets = glow.flow.pop_grad_buckets() if hasattr(glow, "flow") and hasattr(glow.flow, "pop_grad_buckets") else None
+    if buckets is not None:
+        allreduce_buckets(buckets, world)       # per level, overlapped with the rest of the sweep (already enqueued)
+    else:
+        allreduce_gradients(glow, world)
     if hasattr(optimizer, "fused_step"):     # training.HipAdam / HipAdamax: both clippings + the update in two HIP launches
         grad_norm = optimizer.fused_step(max_grad_clip, max_grad_norm, skip_nonfinite=skip_nonfinite)
     else:

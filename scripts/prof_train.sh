@@ -3,6 +3,6 @@
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p $R/gpurun_out/prof_train
-STEPS=${STEPS:-3} rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_train -o train -- python3 $R/scripts/train_probe.py > $R/gpurun_out/prof_train/log.txt 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_train -o train -- python3 $R/bench.py --mode train --steps ${STEPS:-4} --warmup 2 > $R/gpurun_out/prof_train/log.txt 2>&1
 tail -2 $R/gpurun_out/prof_train/log.txt
 find $R/gpurun_out/prof_train -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $R/gpurun_out/prof_train/kernel_stats.csv

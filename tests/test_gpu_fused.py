@@ -353,7 +353,7 @@ def test_full_size_properties_configs_d_e(name, image, L, K, batch):
     5e11 FLOP per image) through size-independent properties: finite outputs; bitwise reproducible run to run; rows of the
     full batch equal the rows of a 2-image sub-batch (other tile / row-split choices: to rounding); encode -> decode with the
     dropped halves re-derived by a second encode returns the input; kernel selection from the run-time counters (the
-    product kernel k_cnet on every level with C <= 48, W up to 128)."""
+    product kernel k_cnet on every level with C <= 96, W up to 128; config D entirely)."""
     import bench
     cfg = bench.CONFIGS[name]
     glow, hps = bench.build_model(G, G.misc.util, torch.device("cuda:0"), cfg, batch)
@@ -368,7 +368,9 @@ def test_full_size_properties_configs_d_e(name, image, L, K, batch):
     z, nll, _ = glow.normal_flow(x, None, noise=noise)
     counts = plan.launch_counts(reset=True)
     assert torch.isfinite(z).all() and torch.isfinite(nll).all()
-    assert counts.get("k_cnet", 0) == 3 * K and counts.get("k_conv_direct", 0) == 0, counts       # levels 1-3: C = 12, 24, 48
+    assert counts.get("k_cnet", 0) == 4 * K and counts.get("k_conv_direct", 0) == 0, counts       # levels 1-4: C = 12, 24, 48 and 96 (f.4 in two groups)
+    if name == "D":       # every level of config D on the product kernel: no round-1 pair, no fp32 kernel left
+        assert not any(k.endswith("_sh") or k.endswith("_f32") for k in counts), counts
     for rep in range(2):
         z2, nll2, _ = glow.normal_flow(x, None, noise=noise, repack=(rep == 1))
         assert torch.equal(z, z2) and torch.equal(nll, nll2), "not bitwise reproducible"

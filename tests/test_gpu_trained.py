@@ -41,20 +41,29 @@ def _dist(a, b):
     return (a.double().cpu() - b.double().cpu()).abs().max().item()
 
 
-def _compare_with_oracles(glow, sd, cfg, x, noise, eps, what):
-    """HIP forward + decode against the fp32 oracle and an fp64 evaluation of the same weights; returns the table of distances."""
+def _compare_with_oracles(glow, sd, cfg, x, noise, eps, what, may_leave_range=False):
+    """HIP forward + decode against the fp32 oracle and an fp64 evaluation of the same weights; returns the table of distances.
+    may_leave_range: hidden activations beyond the fp16 pairs' 4094 are expected -- the product path must then FLAG the batch
+    (non-finite nll / decode status), and the checked path (safe=True: exact-fp32 re-run) must meet the same bars."""
     plan = glow.flow.plan_for(dev(x))
     plan.launch_counts(reset=True)
     with torch.no_grad():
         z, nll, _ = glow.normal_flow(dev(x), None, noise=dev(noise))
+        left_range = not bool(torch.isfinite(nll).all())
+        assert may_leave_range or not left_range, f"{what}: the product kernels left their range (nll {nll.cpu()})"
+        if left_range:
+            n0 = G.Glow._RANGE_FALLBACKS
+            z, nll, _ = glow.normal_flow(dev(x), None, noise=dev(noise), safe=True)
+            assert G.Glow._RANGE_FALLBACKS == n0 + 1
+            print(f"\n{what}: out of the fp16 pairs' range -> flagged, exact-fp32 re-run")
         z32, nll32, _ = O.glow_forward(x, noise, sd, cfg)
         sd64 = {k: v.double() for k, v in sd.items()}
         z64, nll64, _ = O.glow_forward(x.double(), noise.double(), sd64, cfg)
-        xr = glow.reverse_flow(dev(z32), None, eps=[dev(e) for e in eps])
+        xr = glow.reverse_flow(dev(z32), None, eps=[dev(e) for e in eps], safe=may_leave_range)
         x32 = O.glow_reverse(z32, sd, cfg, eps)
         x64 = O.glow_reverse(z32.double(), sd64, cfg, [e.double() for e in eps])
     counts = plan.launch_counts(reset=True)
-    assert counts.get("k_cnet", 0) > 0 and not any(k.endswith("_sh") or k.endswith("_f32") for k in counts), counts
+    assert counts.get("k_cnet", 0) > 0 and (may_leave_range or not any(k.endswith("_sh") or k.endswith("_f32") for k in counts)), counts
     assert torch.isfinite(nll32).all() and torch.isfinite(x32).all(), "the fp32 oracle itself must be finite for this case"
     rows = {}
     for name, hip, o32, o64 in (("z", z, z32, z64), ("nll", nll, nll32, nll64), ("decode", xr, x32, x64)):
@@ -63,7 +72,8 @@ def _compare_with_oracles(glow, sd, cfg, x, noise, eps, what):
                                      for k, v in rows.items()))
     for name, v in rows.items():
         assert v["vs32"] <= max(1e-4, 3.0 * v["ref"]), (what, name, v)
-        assert v["vs64"] <= 2.0 * v["ref"] + 2e-6, (what, name, v)
+        # (2x for the product kernels; the exact-fp32 fall-back sums in another order than the oracle's oneDNN kernels: 3x)
+        assert v["vs64"] <= (3.0 if left_range else 2.0) * v["ref"] + 2e-6, (what, name, v)
     return rows
 
 
@@ -103,25 +113,27 @@ def test_forward_and_decode_after_250_training_steps():
     _compare_with_oracles(glow, sd, cfg, x, noise, eps, "after 250 training steps")
 
 
-@pytest.mark.parametrize("logs_std", [0.5])
+@pytest.mark.parametrize("logs_std", [0.3, 0.5])
 def test_config_b_geometry_with_wide_logs_and_the_largest_finite_tails(logs_std):
-    """Config-B channel geometry (64x64x3, L=3, hidden 512; K = 4 so that the fp64 oracle finishes in seconds) with every
-    ActNorm / Conv2dZeros `logs` ~ N(0, 0.5) -- scales exp(3 logs) between ~0.05 and ~20 -- and the Conv2dZeros weights at the
-    largest sigma of a fixed ladder for which the fp32 oracle's forward AND decode stay finite with |z| < 1e3."""
+    """Config-B channel geometry (64x64x3, L=3, hidden 512; K = 4 so that the fp64 oracle finishes in seconds) with the `logs`
+    of every ActNorm / Conv2dZeros INSIDE the coupling networks ~ N(0, 0.5) -- per-channel scales exp(3 logs) between ~0.01 and
+    ~100 on h1, h2 and the f.4 rows (sigma 0.3: ~0.07 .. ~15) -- and the Conv2dZeros weights at the largest sigma of a fixed
+    ladder for which the fp32 oracle's forward AND decode stay finite with |z| < 1e3.  (The cliff is steep: at logs sigma 0.5
+    the bench's tail sigma 0.002 sends the oracle's own z to 1e18, and only 1e-5 keeps its decode finite.)"""
     batch = 4
     cfg = O.default_cfg(K=4, batch=batch)
     g = torch.Generator().manual_seed(17)
     x = torch.rand(batch, 3, 64, 64, generator=g)
     noise = torch.rand(batch, 3, 64, 64, generator=g) / 256
     chosen = None
-    for zeros_std in (0.05, 0.02, 0.01, 0.005, 0.002):
+    for zeros_std in (0.02, 0.01, 0.005, 0.002, 1e-3, 5e-4, 2e-4, 1e-4, 5e-5, 2e-5, 1e-5):
         sd = O.seeded_state_dict(cfg, seed=23, zeros_std=zeros_std, invconv_perturb=0.05)
         with torch.no_grad():
             sd = O.glow_init_actnorm(x, noise, sd, cfg)
             gl = torch.Generator().manual_seed(29)
-            for k in sd:
-                if k.endswith("logs"):
-                    sd[k] = sd[k] + torch.randn(sd[k].shape, generator=gl) * logs_std
+            for k in sd:        # inside the coupling networks the full sigma; the flow's own ActNorms (which scale z itself,
+                if k.endswith("logs"):      # 12 times in a row) a fifth of it
+                    sd[k] = sd[k] + torch.randn(sd[k].shape, generator=gl) * (logs_std if ".f." in k else 0.2 * logs_std)
             z32, nll32, _ = O.glow_forward(x, noise, sd, cfg)
             if not (torch.isfinite(z32).all() and torch.isfinite(nll32).all() and z32.abs().max() < 1e3):
                 continue
@@ -133,4 +145,6 @@ def test_config_b_geometry_with_wide_logs_and_the_largest_finite_tails(logs_std)
                 break
     assert chosen is not None, "no rung of the ladder keeps the fp32 oracle finite"
     print(f"Conv2dZeros sigma = {chosen}")
-    _compare_with_oracles(glow.eval(), sd, cfg, x, noise, eps, f"config-B geometry, logs sigma {logs_std}, tails sigma {chosen}")
+    # sigma 0.5: per-channel scales of up to ~100 on unit-variance activations -- beyond 4094 for some channels: flagged + re-run
+    _compare_with_oracles(glow.eval(), sd, cfg, x, noise, eps, f"config-B geometry, logs sigma {logs_std}, tails sigma {chosen}",
+                          may_leave_range=logs_std >= 0.5)
