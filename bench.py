@@ -135,11 +135,16 @@ def setup_workload(G, util, parallel, device, cfg_name, mode, B, rank, world, re
     x = torch.rand(B, 3, cfg["image"], cfg["image"], generator=torch.Generator().manual_seed(2384 + rank)).to(device)
     # data-dependent ActNorm init on rank 0's first batch, then broadcast (reference trainer.py:112-115)
     glow.train()
+    glow.flow.plan_for(x)            # (plan construction is host work: not part of the init pass's time)
+    torch.cuda.synchronize()
+    t_init = time.perf_counter()
     with torch.no_grad():       # (the init pass needs no activation tape)
         parallel.data_dependent_init(glow, x, rank=rank, world=world)
+    torch.cuda.synchronize()
+    t_init = time.perf_counter() - t_init
     glow.eval()
     plan = glow.flow.plan_for(x)
-    wl = dict(glow=glow, hps=hps, plan=plan, x=x, cfg=cfg)
+    wl = dict(glow=glow, hps=hps, plan=plan, x=x, cfg=cfg, init_ms=round(1e3 * t_init, 1))
     if mode == "inverse":
         wl["z_top"] = z_top = torch.randn((B,) + tuple(plan.out_chw), device=device) * 0.7
     if mode == "train":
@@ -218,8 +223,8 @@ def secondary_workloads(G, util, parallel, device, steps=3, warmup=2):
             out[name] = {"value": round(B * steps / dt, 2), "unit": "images/sec", "ms_per_step": round(1e3 * dt / steps, 3),
                          "ms_per_step_gpu_events": round(e0.elapsed_time(e1) / steps, 3), "steps": steps, "warmup": warmup, "batch": B,
                          "workload": f"{cfg['label']}, {mode}, batch {B} ({cfg['ref']})",
-                         "finite": bool(torch.isfinite(last).all()),
-                         "kernel_families": sorted(wl["plan"].launch_counts(reset=True)),
+                         "finite": bool(torch.isfinite(last).all()), "data_dependent_init_ms": wl["init_ms"],
+                         "kernel_families": sorted(k for k in wl["plan"].launch_counts(reset=True) if not k.startswith("variant:")),
                          "wall_s_incl_setup": round(time.perf_counter() - t_wall, 1)}
             del last
         del wl, step
@@ -411,6 +416,7 @@ def main():
             "ms_per_step_min": round(per_step[0], 4), "ms_per_step_median": round(per_step[len(per_step) // 2], 4),
             "ms_per_step_max": round(per_step[-1], 4), "host_enqueue_ms_per_step": round(1e3 * dt_host / args.steps, 4),
             "rccl_world_size": dist.get_world_size() if world > 1 else 1, "launch": wl["launch"],
+            "data_dependent_init_ms": wl["init_ms"],     # first training-mode forward (ActNorm statistics layer by layer + one forward), once
             "arithmetic": "fp32 values carried as 2 x f16 (hi, lo), exact f16 products, fp32 accumulate (csrc/sh.h); "
                           "max-abs vs CPU reference 7e-6 (z), same as the exact-fp32 kernels",
             "config": {"workload": f"{cfg['label']}, {what}, batch {B}/GPU ({cfg['ref']})", "global_batch": world * B,
@@ -438,7 +444,9 @@ def main():
                 glow.normal_flow(x, None, repack=repack)
         recs = plan.timing_read()
         plan.timing(False)
-        launches = {k: v // 3 for k, v in plan.launch_counts(reset=True).items()}     # run-time counters of the 3 instrumented passes
+        counts = plan.launch_counts(reset=True)                                       # run-time counters of the 3 instrumented passes
+        launches = {k: v // 3 for k, v in counts.items() if not k.startswith("variant:")}
+        variants = {k[len("variant:"):]: v // 3 for k, v in counts.items() if k.startswith("variant:")}
         hid = hps.model.hidden_channels
         kinds = {0: "chanmix", 1: "conv_f0_3x3", 2: "conv_f2_1x1", 3: "conv_f4_3x3_tail", 5: "cnet_f0+f2+f4", 6: "cnet_finish"}
         desc = plan.describe(B)
@@ -522,6 +530,7 @@ def main():
         out["breakdown_ms_per_step"] = {k: round(v[0] / 3, 4) for k, v in sorted(bd.items())}
         out["breakdown_sum_ms"] = round(sum(v[0] for v in bd.values()) / 3, 3)
         out["kernel_launches_per_step"] = launches
+        out["k_cnet_instances_per_step"] = variants
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(glow, x[:min(B, cfg["cpu_sample"])].cpu(), cfg)
         if world == 1 and args.mode == "forward" and args.config == "B" and not args.no_secondary and not dbg:

@@ -209,6 +209,10 @@ int glowhip_plan_status(const glowhip_plan* plan, const void* workspace, size_t 
  * a forward with that tensor as `noise` is bitwise equal to the in-kernel draw. */
 int glowhip_plan_set_dequant_rng(glowhip_plan* plan, unsigned long long seed, int enable, unsigned long long* next_call);
 int glowhip_dequant_noise(float* out, long n, unsigned long long seed, unsigned long long call, int n_bits, glowhip_stream_t stream);
+/* The same switch with the position given by the caller: the next glow_forward without a noise tensor draws with (seed, call),
+ * the one after with call + 1 ...  Lets ONE stream serve every plan of a process (each batch shape has its own plan) and lets
+ * the ranks of a data-parallel job key it differently (pytorch-glow_amd/network/model.py: torch's seed, the rank folded in). */
+int glowhip_plan_set_dequant_stream(glowhip_plan* plan, unsigned long long seed, unsigned long long call);
 
 /* Data-dependent ActNorm initialisation pass over a whole plan (first training-mode forward,
  * network/trainer.py:112-115 + network/module.py:45-46,66-67): runs encode on x and writes every

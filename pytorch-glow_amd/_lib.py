@@ -88,6 +88,7 @@ SIGNATURES = {
     "glowhip_plan_get_family": (c_int, [_P]),
     "glowhip_plan_status": (c_int, [_P, _P, c_size_t, c_int, _P, c_long, _P, _P]),
     "glowhip_plan_set_dequant_rng": (c_int, [_P, ctypes.c_ulonglong, c_int, POINTER(ctypes.c_ulonglong)]),
+    "glowhip_plan_set_dequant_stream": (c_int, [_P, ctypes.c_ulonglong, ctypes.c_ulonglong]),
     "glowhip_dequant_noise": (c_int, [_P, c_long, ctypes.c_ulonglong, ctypes.c_ulonglong, c_int, _P]),
     "glowhip_plan_actnorm_init": (c_int, [_P, _P, c_size_t, _P, _P, c_float, c_int, _P, c_size_t, _P]),
     "glowhip_plan_output_shape": (c_int, [_P, c_int, POINTER(c_int32)]),

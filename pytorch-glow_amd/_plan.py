@@ -183,6 +183,10 @@ class FlowPlan:
         check(lib().glowhip_plan_set_dequant_rng(self._h, int(seed) & (2 ** 64 - 1), -1 if enable is None else int(bool(enable)), ctypes.byref(nxt)))
         return int(nxt.value)
 
+    def set_dequant_stream(self, seed, call) -> None:
+        """In-kernel dequantisation noise on, the next forward without a noise tensor draws with (seed, call)."""
+        check(lib().glowhip_plan_set_dequant_stream(self._h, int(seed) & (2 ** 64 - 1), int(call)))
+
     def dequant_noise(self, shape, seed, call, n_bits) -> torch.Tensor:
         """The draw the kernel makes for call number `call` under `seed`, as a tensor shaped like x."""
         out = torch.empty(tuple(shape), dtype=torch.float32, device=self.device)

@@ -115,6 +115,12 @@ static CnetArgs cnet_base(const LayerPlan& L, const void* packed, int N, int rev
     c.acc = w.acc;
     return c;
 }
+// which instance of k_cnet ran (run-time evidence for the tests): "variant:k_cnet<hidden,row split,pixel tile>"
+static void count_cnet_variant(glowhip_plan* p, const CnetArgs& c, const CnetPending& pend) {
+    char name[64];
+    snprintf(name, sizeof name, "variant:k_cnet<%d,%d,%d>", c.hidden, pend.MS, 1 << pend.lpxt);
+    count_launch(p, name);
+}
 static CnetMixer mixer_fwd(const LayerPlan& L, const void* packed) {      // ActNorm + permutation of step L, forward
     const glowhip_layer_desc& d = L.d;
     return CnetMixer{d.C, 0, d.an_bias, at<float>(packed, L.an_scale), d.permutation == GLOWHIP_PERM_INVCONV ? d.invconv_w : nullptr,
@@ -335,6 +341,7 @@ static int run_forward(glowhip_plan* p, const void* packed, const float* x, cons
                     ScopedTimer t(p, GLOWHIP_K_CNET, 1, s);
                     count_launch(p, pending ? "k_cnet+prev_finish" : "k_cnet");
                     GH_TRY(launch_cnet_main(c, s, &pend));
+                    count_cnet_variant(p, c, pend);
                 }
                 pending = chain;
                 if (!chain) {   // finish now; with the NEXT step's mixer when that is a same-shape FlowStep on another kernel family
@@ -435,6 +442,7 @@ static int run_reverse(glowhip_plan* p, const void* packed, const float* z, cons
                     ScopedTimer t(p, GLOWHIP_K_CNET, 1, s);
                     count_launch(p, pending ? "k_cnet+prev_finish" : "k_cnet");
                     GH_TRY(launch_cnet_main(c, s, &pend));
+                    count_cnet_variant(p, c, pend);
                 }
                 pending = chain;
                 if (!chain && d.C <= 96) {
@@ -469,6 +477,10 @@ static int run_reverse(glowhip_plan* p, const void* packed, const float* z, cons
                 }
                 continue;
             }
+            // z2 is updated IN PLACE when `cur` is a workspace buffer (every step but the first of a decode, whose input is the
+            // caller's z): the mixer's inputs then do not alias its output, and the wide mixer may slice its output channels
+            // over workgroups (config E's 4x4 level: 16 workgroups of 384 outputs each took 350 us per step with the alias)
+            if (cur == w.bufA || cur == w.bufB) z2 = const_cast<float*>(cur) + (long)Ch * HW;
             GH_TRY(run_coupling(p, L, packed, cur, chw, cur + (long)Ch * HW, chw, z2, chw, N, 1, w, s));
             ChanMixArgs m{};
             m.in_a = cur; m.in_a_bs = chw; m.in_b = z2; m.in_b_bs = chw; m.Ca = Ch;
@@ -750,6 +762,12 @@ int glowhip_plan_set_dequant_rng(glowhip_plan* plan, unsigned long long seed, in
         plan->rng_on = false;
     }
     if (next_call) *next_call = plan->rng_calls;
+    return GLOWHIP_OK;
+}
+
+int glowhip_plan_set_dequant_stream(glowhip_plan* plan, unsigned long long seed, unsigned long long call) {
+    GH_REQUIRE(plan, "plan_set_dequant_stream: null plan");
+    plan->rng_on = true; plan->rng_seed = seed; plan->rng_calls = call;
     return GLOWHIP_OK;
 }
 

@@ -230,6 +230,33 @@ class _GlowTrainFn(torch.autograd.Function):
         return (None, gx, None, None) + tuple(grads)
 
 
+# ---- the dequantisation stream of the inference path (network/model.py:421: z = x + U(0, 1/2^n_bits), drawn inside the leading
+# squeeze kernel by Philox4x32-10).  ONE stream per process: key = torch's seed with the data-parallel rank folded in (ranks
+# seeded alike still draw different noise), position = a process-wide count of such forwards (plans of different batch shapes
+# do not repeat one another's draws).  A new torch.manual_seed value restarts it at 0; re-seeding with the SAME value cannot
+# be seen from here -- call reset_dequant_stream() to replay.  (The reference consumes torch's CPU generator instead; the
+# draws differ, their distribution does not.  Training mode and explicit `noise=` are unaffected.)
+_DEQUANT_STREAM = {"seed": None, "calls": 0}
+
+
+def reset_dequant_stream():
+    _DEQUANT_STREAM["seed"], _DEQUANT_STREAM["calls"] = None, 0
+
+
+def dequant_position(advance=False):
+    """(key, call) the next in-kernel draw uses; advance=True consumes it."""
+    import torch.distributed as dist
+    seed = torch.initial_seed()
+    st = _DEQUANT_STREAM
+    if st["seed"] != seed:
+        st["seed"], st["calls"] = seed, 0
+    call = st["calls"]
+    if advance:
+        st["calls"] += 1
+    rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+    return (seed + 0x9E3779B97F4A7C15 * rank) & (2 ** 64 - 1), call
+
+
 class GraphedForward:
     """`Glow.normal_flow` (eval, no grad; network/model.py:409-452) for one batch shape, captured in a hipGraph.
 
@@ -342,7 +369,8 @@ class Glow(nn.Module):
                 noise = torch.empty(x.shape, dtype=torch.float32, device=x.device).uniform_(0, 1. / 2 ** n_bits)
             else:     # inference: the leading squeeze draws it (Philox keyed by torch's seed; no noise tensor, no RNG launch)
                 in_kernel_rng = True
-                rng_call = plan.set_dequant_rng(torch.initial_seed(), True)     # the call number this forward will draw with
+                rng_key, rng_call = dequant_position(advance=True)      # (key, call number) this forward draws with
+                plan.set_dequant_stream(rng_key, rng_call)
         else:
             noise = require_device_tensor(noise, "noise")
             assert noise.shape == x.shape
@@ -365,7 +393,7 @@ class Glow(nn.Module):
         z, nll, _ = plan.glow_forward(x, noise, mean, logs, stride, n_bits, repack=repack)
         if safe and not bool(torch.isfinite(nll).all()):
             if in_kernel_rng:     # the re-run sees the same dequantisation draw as the flagged run
-                noise = plan.dequant_noise(x.shape, torch.initial_seed(), rng_call, n_bits)
+                noise = plan.dequant_noise(x.shape, rng_key, rng_call, n_bits)
             z, nll = self._forward_exact_fp32(plan, x.float() / 255.0 if x.dtype == torch.uint8 else x, noise, mean, logs, stride, n_bits)
         return z, nll, None
 

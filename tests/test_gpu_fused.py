@@ -133,6 +133,11 @@ def test_cnet_every_row_split(ms, image, L, hidden, batch):
     finally:
         G.lib().glowhip_debug_force_tail_tile(0)
     assert ncnet(fwd) == 2 * L, fwd
+    # which instance ran, from the executor's run-time counters: at this batch every level takes 64-pixel tiles, so ms = 1 is the
+    # bench's <512, 1, 64> instance (its level 2) and ms = 4 its <512, 4, 64> (level 3), each against the oracle
+    if (image, L, hidden) == (64, 3, 512):
+        got = {k for k in fwd if k.startswith("variant:")}
+        assert f"variant:k_cnet<512,{ms},64>" in got, (ms, got)
 
 
 @pytest.mark.parametrize("tile", [0x2000000, 0x4000000])
@@ -394,8 +399,11 @@ def test_in_kernel_dequantisation_noise():
     glow = make_glow(cfg, sd, 8)
     x = torch.rand(8, 3, 32, 32, generator=torch.Generator().manual_seed(1)).to("cuda:0")
     plan = glow.flow.plan_for(x)
+    from pytorch_glow_amd.network import model as M
     torch.manual_seed(1234)
-    call0 = plan.set_dequant_rng(torch.initial_seed(), None)
+    M.reset_dequant_stream()
+    key, call0 = M.dequant_position()
+    assert (key, call0) == (1234, 0)
     z_a, nll_a, _ = glow.normal_flow(x, None)                      # call number call0
     z_b, nll_b, _ = glow.normal_flow(x, None)                      # call0 + 1
     assert not torch.equal(z_a, z_b)
@@ -409,17 +417,25 @@ def test_in_kernel_dequantisation_noise():
     assert torch.equal(z_j, z_b) and torch.equal(nll_j, nll_b)
     # 8-bit input path
     xu = (x * 255).round().to(torch.uint8)
-    c = plan.set_dequant_rng(1234, None)
+    _, c = M.dequant_position()
+    assert c == call0 + 2          # (forwards with an injected noise tensor do not advance the stream)
     z_u, nll_u, _ = glow.normal_flow(xu, None)
     z_v, nll_v, _ = glow.normal_flow(xu, None, noise=plan.dequant_noise(x.shape, 1234, c, 8))
     assert torch.equal(z_u, z_v) and torch.equal(nll_u, nll_v)
-    # a new seed restarts the stream
+    # a new seed restarts the stream; the same seed again replays after reset_dequant_stream()
     torch.manual_seed(99)
     z_c, _, _ = glow.normal_flow(x, None)
     torch.manual_seed(99)
-    plan.set_dequant_rng(7, True)         # (a different seed in between, so that seed 99 restarts at call 0)
+    M.reset_dequant_stream()
     z_d, _, _ = glow.normal_flow(x, None)
     assert torch.equal(z_c, z_d)
+    # ONE stream per process: a plan of another batch shape continues it instead of repeating call 0
+    glow5 = make_glow(cfg, sd, 5)
+    x5 = x[:5].contiguous()
+    _, cq = M.dequant_position()
+    z5, _, _ = glow5.normal_flow(x5, None)
+    z5_v, _, _ = glow5.normal_flow(x5, None, noise=glow5.flow.plan_for(x5).dequant_noise(x5.shape, 99, cq, 8))
+    assert cq == 1 and torch.equal(z5, z5_v)
 
 
 def test_unused_scratch_slots_may_hold_nan():
