@@ -182,7 +182,7 @@ def setup_workload(G, util, parallel, device, cfg_name, mode, B, rank, world, re
 SECONDARY = [("D", ["forward"]), ("E", ["forward", "inverse"]), ("B", ["train"])]
 
 
-def secondary_workloads(G, util, parallel, device, steps=3, warmup=2):
+def secondary_workloads(G, util, parallel, device, steps=3, warmup=3):
     """The other BASELINE configurations under the SAME process and clock as the headline line, AFTER its timed region (nothing
     of this is in `value` / `ms_per_step`): a few timed steps each of configs[3] (D) and configs[4] (E) forward, E sampling
     (reverse_flow, derived data kept across steps as when sampling from a trained model) and the config-B training step.  One
@@ -206,7 +206,7 @@ def secondary_workloads(G, util, parallel, device, steps=3, warmup=2):
                 def step():
                     plan.ensure_packed(False, use=plan.PACK_INFERENCE | plan.PACK_INVERSE)
                     return glow.reverse_flow(z_top, None, eps_std=0.7).sum()
-            for _ in range(warmup):
+            for _ in range(warmup + (3 if mode == "train" else 0)):      # (the training step's first iterations still allocate)
                 step()
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -322,6 +322,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="forward mode: issue the kernel list eagerly every step instead of "
                     "replaying the captured hipGraph")
+    ap.add_argument("--no-exact-leg", action="store_true", help="skip the same step on the exact-fp32 MFMA kernels that the headline "
+                    "run times for the record (profiling runs: keeps the kernel table to the product path)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the `secondary` workloads (configs D / E, sampling, training "
                     "step) that the default one-GPU headline run appends to its JSON line")
     ap.add_argument("--no-repack", action="store_true", help="inference mode: keep derived parameter data across steps")
@@ -511,7 +513,7 @@ def main():
                            "algorithmic_hbm_bytes_per_launch_avg": dom_bytes / max(dom_n, 1),
                            "hbm_GBps": round(dom_bytes / (dom_ms * 1e-3) / 1e9, 1) if dom_ms > 0 else 0.0,
                            "hbm_frac_of_8TBps": round(dom_bytes / (dom_ms * 1e-3) / 8e12, 4) if dom_ms > 0 else 0.0}
-        if args.mode == "forward" and sh_path and args.config == "B":
+        if args.mode == "forward" and sh_path and args.config == "B" and not args.no_exact_leg:
             # the same step on the exact-fp32 MFMA kernels (split-half path switched off), for the record; rank-local
             plan.set_family(plan.FAMILY_EXACT_FP32)       # a property of this plan (glowhip_plan_set_family), nothing process-wide
             try:

@@ -162,6 +162,8 @@ template <int HID, int MS, int UPW, int PXT, bool PRE, int NG = 1>
 __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
     const bool pre_on = PRE && a.pre_on;
     constexpr int NPT = PXT / 32;                    // pixel tiles of the workgroup: 4 (128 pixels) or 2 (64 pixels)
+    constexpr int ADEPTH = (HID / MS / 32) * NPT / 8 == 8 ? 1 : 2;       // prefetch distance of P2's A fragments (k-steps)
+    constexpr bool MIXSPLIT = PXT == 64 && NG == 1;  // v_fma_mix_f32 in the split epilogues where registers are to spare (sh.h)
     constexpr int CAP = CN_HBUF / (PXT * 4);         // activation channels the LDS buffer holds as (hi, lo) halves: 256 / 512
     constexpr int NH = HID > CAP ? HID / CAP : 1;    // passes over h1
     constexpr int HK = HID / NH;                     // channels per pass
@@ -601,7 +603,7 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
                         f32x4_t v;
 #pragma unroll
                         for (int t = 0; t < 4; ++t) v[t] = nrelu_bits(fmaf(acc1[i][j][4 * gq + t], rs[t], bb[t]));
-                        sh2_split4(v, hi, lo);
+                        sh2_split4<MIXSPLIT>(v, hi, lo);
                         _Float16* dst = hbuf + ((long)chunk * PXT + (pt1 + sp * PTSV + j) * 32 + ml) * 8 + 4 * kl;
                         *reinterpret_cast<h4*>(dst) = hi;
                         *reinterpret_cast<h4*>(dst + (long)NCH * PXT * 8) = lo;
@@ -629,10 +631,12 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
             load_bh(0, bhq[0]);
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
-                h8 (&use)[2 * RT2] = A2[s % 3];
-                h8 (&fill)[2 * RT2] = A2[(s + 2) % 3];
+                // A fragments two k-steps ahead in three named sets -- one k-step ahead in two where the 128 accumulator registers
+                // of a 512-row x 128-pixel block leave no room for the third (ADEPTH)
+                h8 (&use)[2 * RT2] = A2[ADEPTH == 2 ? s % 3 : s & 1];
+                h8 (&fill)[2 * RT2] = A2[ADEPTH == 2 ? (s + 2) % 3 : (s + 1) & 1];
                 h8 (&bh)[PT2] = bhq[s & 1];
-                loadA2(ks0 + min(s + 2, NS - 1), fill);          // unconditional (clamped)
+                loadA2(ks0 + min(s + ADEPTH, NS - 1), fill);     // unconditional (clamped)
                 // the scheduler must not sink these loads towards their use two k-steps later (it does, to save registers, and
                 // the wave then waits a full L2 round trip per k-step: measured 57% of the MFMA rate for a wave on its own)
                 __builtin_amdgcn_sched_barrier(0);
@@ -782,6 +786,7 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) accT[u][j][r] = 0.f;
+    GH_STAMP(27);
 #pragma unroll 1
     for (int l = 0; l < NL; ++l) {
         // the owners of rows [l*LK, (l+1)*LK) pass their h2 to the B side through hbuf
@@ -796,7 +801,7 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
                 for (int j = 0; j < PT2; ++j) {
                     h4 hi, lo;
                     const f32x4_t v = {acc2[i][j][4 * gq], acc2[i][j][4 * gq + 1], acc2[i][j][4 * gq + 2], acc2[i][j][4 * gq + 3]};
-                    sh2_split4(v, hi, lo);
+                    sh2_split4<MIXSPLIT>(v, hi, lo);
                     _Float16* dst = hbuf + ((long)chunk * PXT + (pt2 + j) * 32 + ml) * 8 + 4 * kl;
                     *reinterpret_cast<h4*>(dst) = hi;
                     *reinterpret_cast<h4*>(dst + (long)LCH * PXT * 8) = lo;

@@ -128,14 +128,26 @@ __device__ __forceinline__ void sh2_split(float V, _Float16& hi, _Float16& lo) {
 // Four values at once with the packed conversion (v_cvt_pk_f16_f32: two values per instruction, round to nearest even like the
 // scalar conversion -- same bits as four sh2_split calls)
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+// MIX: the residual V - hi as ONE v_fma_mix_f32 per value (hi read as the f16 half it is; exact like conversion + subtraction):
+// 29.3 -> 23.8 cycles per value-wave in scripts/ubench/epi_split.hip.  As inline asm it pins registers: the level-1 instance of
+// k_cnet (at the 256-register limit) lost its allocation to it (h2 hand-over 5 k -> 32 k cycles), so only instances with registers
+// to spare take it.
+template <bool MIX = false>
 __device__ __forceinline__ void sh2_split4(const f32x4_t& V, h4& hi, h4& lo) {
 #pragma unroll
     for (int t = 0; t < 4; t += 2) {
         const f32x2_t vv = {V[t], V[t + 1]};
         const h2 x = __builtin_convertvector(vv, h2);
-        // (v_fma_mix_f32 would fold the conversion back and the subtraction into one instruction -- 29.3 -> 23.8 cycles per
-        // value-wave in scripts/ubench/epi_split.hip -- but as inline asm it costs the level-1 instance of k_cnet, which sits at
-        // the 256-register limit, its allocation: the h2 hand-over went from 5 k to 32 k cycles.  Left to the compiler.)
+        if (MIX) {
+            const unsigned xb = __builtin_bit_cast(unsigned, x);
+            float m0, m1;
+            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(m0) : "v"(xb), "v"(V[t]));
+            asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(m1) : "v"(xb), "v"(V[t + 1]));
+            const f32x2_t mm = {m0, m1};
+            const h2 ym = __builtin_convertvector(mm, h2);
+            hi[t] = x[0]; hi[t + 1] = x[1]; lo[t] = ym[0]; lo[t + 1] = ym[1];
+            continue;
+        }
         const float r0 = V[t] - (float)x[0], r1 = V[t + 1] - (float)x[1];
         const f32x2_t rr = {r0, r1};
         const h2 y = __builtin_convertvector(rr, h2);

@@ -1,7 +1,8 @@
 #!/bin/bash
-# round 3, GPU call: whole GPU suite + E inverse breakdown
-mkdir -p gpurun_out/r3l
-timeout 2400 python -m pytest tests -x -q -m gpu > gpurun_out/r3l/pytest.txt 2>&1
-tail -6 gpurun_out/r3l/pytest.txt | cut -c1-300
-python bench.py --config E --mode inverse --steps 5 --warmup 2 --no-cpu-baseline 2>&1 | tail -1 | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); print('E inverse', d['value'], d['ms_per_step'], d['kernel_launches_per_step']); print(d['breakdown_ms_per_step'])"
+# round 3, GPU call: kernel-variant A/B (libglowhip_base.so vs libglowhip.so) + parity tests of the fused path + per-wave stamps
+mkdir -p gpurun_out/r3k
+timeout 1500 python -m pytest tests/test_gpu_fused.py tests/test_gpu_parity.py -x -q -m gpu > gpurun_out/r3k/pytest.txt 2>&1
+tail -3 gpurun_out/r3k/pytest.txt | cut -c1-300
+bash scripts/ab2.sh base default > gpurun_out/r3k/ab.txt 2>&1
+cat gpurun_out/r3k/ab.txt | cut -c1-400
+K=1 L=1 python scripts/stamps_cnet_waves.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r3k/stamps_waves.txt; cat gpurun_out/r3k/stamps_waves.txt

@@ -9,7 +9,7 @@ mkdir -p $O
 run_trace() {  # name, bench args...
   local name=$1; shift
   mkdir -p $O/$name
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/$name -o t -- python3 $R/bench.py --no-cpu-baseline --no-secondary "$@" > $O/$name/log.txt 2>&1
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/$name -o t -- python3 $R/bench.py --no-cpu-baseline --no-secondary --no-exact-leg "$@" > $O/$name/log.txt 2>&1
   grep '^{' $O/$name/log.txt | tail -1 > $O/$name/bench_line.json
   # steady state only: the table without the one-off init pass (scripts/trace_stats.py)
   python3 $R/scripts/trace_stats.py $(find $O/$name -name "*kernel_trace.csv" | head -1) $O/$name/steady_kernel_stats.csv

@@ -13,7 +13,7 @@ while read -r group; do
   d=$R/gpurun_out/$TAG/p$i
   mkdir -p $d
   echo "$group" > $d/counters.txt
-  timeout 300 rocprofv3 --pmc $group --kernel-trace --output-format csv -d $d -o pmc -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --no-graph ${BENCH_ARGS} > $d/log.txt 2>&1
+  timeout 300 rocprofv3 --pmc $group --kernel-trace --output-format csv -d $d -o pmc -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --no-exact-leg --no-graph ${BENCH_ARGS} > $d/log.txt 2>&1
   echo "pass $i ($group): rc=$? $(ls $d | tr '\n' ' ')"
 done <<'EOG'
 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_INSTS_VALU_MFMA_MOPS_F16 GRBM_GUI_ACTIVE GRBM_COUNT
