@@ -216,7 +216,8 @@ int glowhip_plan_set_dequant_stream(glowhip_plan* plan, unsigned long long seed,
 
 /* Data-dependent ActNorm initialisation pass over a whole plan (first training-mode forward,
  * network/trainer.py:112-115 + network/module.py:45-46,66-67): runs encode on x and writes every
- * ActNorm's bias/logs THROUGH the parameter pointers of the layer descs (which must be writable). */
+ * ActNorm's bias/logs THROUGH the parameter pointers of the layer descs (which must be writable).  Ends with
+ * glowhip_plan_pack_for(GLOWHIP_PACK_INFERENCE): pack _TRAINING / _INVERSE data before training / decoding. */
 int glowhip_plan_actnorm_init(glowhip_plan* plan, void* packed, size_t packed_bytes, const float* x,
                               const float* noise, float actnorm_scale, int N, void* workspace,
                               size_t workspace_bytes, glowhip_stream_t stream);

@@ -366,8 +366,8 @@ class FlowPlan:
         ws = self._workspace(n)
         check(lib().glowhip_plan_actnorm_init(self._h, ptr(self.packed), self.packed.numel(), ptr(x), ptr(noise),
                                               float(actnorm_scale), n, ptr(ws), ws.numel(), stream_ptr(self.device)))
-        self._packed_version = self._version_signature()   # the init pass ends with a full glowhip_plan_pack
-        self._packed_use = 7
+        self._packed_version = self._version_signature()   # the init pass ends with a pack of the inference kernels' data
+        self._packed_use = self.PACK_INFERENCE
 
 
 class PlanCache:

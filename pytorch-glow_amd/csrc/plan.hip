@@ -869,6 +869,7 @@ int glowhip_plan_pack_for(glowhip_plan* plan, void* packed, size_t packed_bytes,
     }
     GH_TRY(launch_pack_batched(at<ScaleJob>(packed, plan->scale_off), (int)plan->scale_jobs.size(),
                                at<RepackJob>(packed, plan->repack_off), n_kind, tail_blocks, packed, s));
+    if (use & 32) return GLOWHIP_OK;      // (internal: weight images and scale tables only -- the init pass' first pack)
     GH_TRY(launch_step_prepare_batched(at<StepPrepJob>(packed, plan->prep_off), (int)plan->prep_jobs.size(),
                                        plan->max_lds_c, packed, s, (use & (GLOWHIP_PACK_INVERSE | GLOWHIP_PACK_TRAINING)) != 0,
                                        plan->max_c));
@@ -994,7 +995,8 @@ int glowhip_plan_actnorm_init(glowhip_plan* plan, void* packed, size_t packed_by
     GH_TRY(carve(plan, N, workspace, workspace_bytes, w));
     GH_TRY(launch_zero_acc(w.acc, N, s));
     // plain (ActNorm-free) fp32 MFMA weight images of every convolution: the training family's + the init pass's own f.0 image
-    GH_TRY(glowhip_plan_pack_for(plan, packed, packed_bytes, GLOWHIP_PACK_TRAINING | 16, stream));
+    // (no LU here: the invertible 1x1 convolutions are applied with W itself, and the pack at the end factorises them)
+    GH_TRY(glowhip_plan_pack_for(plan, packed, packed_bytes, GLOWHIP_PACK_TRAINING | 16 | 32, stream));
     // Layer by layer: set the ActNorm statistics from the activations that reach it, refresh the packed
     // data of that layer, then run the layer forward with the fresh parameters (first training-mode
     // forward of the reference: network/module.py:45-46,66-67).
@@ -1081,8 +1083,10 @@ int glowhip_plan_actnorm_init(glowhip_plan* plan, void* packed, size_t packed_by
         }
         cur = dst;
     }
-    // everything derived from the parameters is stale now
-    return glowhip_plan_pack(plan, packed, packed_bytes, stream);
+    // everything derived from the parameters is stale now: re-derive what the inference kernels read (log|det W| without W^-1:
+    // the inverse and the training images are packed on demand by whoever decodes or trains next -- W^-1 of config E's 384 x 384
+    // matrices alone costs more than the rest of the init pass)
+    return glowhip_plan_pack_for(plan, packed, packed_bytes, GLOWHIP_PACK_INFERENCE, stream);
 }
 
 }  // extern "C"

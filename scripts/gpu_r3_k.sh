@@ -1,8 +1,14 @@
 #!/bin/bash
-# round 3, GPU call: kernel-variant A/B (libglowhip_base.so vs libglowhip.so) + parity tests of the fused path + per-wave stamps
-mkdir -p gpurun_out/r3k
-timeout 1500 python -m pytest tests/test_gpu_fused.py tests/test_gpu_parity.py -x -q -m gpu > gpurun_out/r3k/pytest.txt 2>&1
-tail -3 gpurun_out/r3k/pytest.txt | cut -c1-300
-bash scripts/ab2.sh base default > gpurun_out/r3k/ab.txt 2>&1
-cat gpurun_out/r3k/ab.txt | cut -c1-400
-K=1 L=1 python scripts/stamps_cnet_waves.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r3k/stamps_waves.txt; cat gpurun_out/r3k/stamps_waves.txt
+# round 3, GPU call: whole GPU suite, then the default bench line (init times, secondary workloads)
+mkdir -p gpurun_out/r3m
+timeout 2400 python -m pytest tests -x -q -m gpu > gpurun_out/r3m/pytest.txt 2>&1
+tail -4 gpurun_out/r3m/pytest.txt | cut -c1-300
+python bench.py --no-cpu-baseline > gpurun_out/r3m/bench.txt 2>&1
+python - <<'PY'
+import json
+for l in open('gpurun_out/r3m/bench.txt'):
+    if l.startswith('{'):
+        d=json.loads(l)
+        print(d['value'], d['ms_per_step'], 'init', d['data_dependent_init_ms'], 'enqueue', d['host_enqueue_ms_per_step'], d['roofline']['frac'])
+        for k,v in d['secondary'].items(): print(k, v['value'], v['ms_per_step'], 'init', v.get('data_dependent_init_ms'), v['wall_s_incl_setup'])
+PY
