@@ -149,6 +149,12 @@ int glowhip_plan_pack(glowhip_plan* plan, void* packed, size_t packed_bytes, glo
 #define GLOWHIP_PACK_INVERSE 4   /* W^-1 of the invertible 1x1 convolutions (decode; implied by TRAINING): without it
                                     log|det W| comes from an LU of the matrix alone (C^3/3 instead of 2 C^3 updates) and W^-1 is stale */
 int glowhip_plan_pack_for(glowhip_plan* plan, void* packed, size_t packed_bytes, int use, glowhip_stream_t stream);
+/* Part of a pack -- the LU factorisations (their log|det W| enters only a forward's final sum) and the weight images only the
+ * deep levels read -- runs on a side stream the plan owns, forked from `stream` and joined by event inside whichever plan call
+ * consumes the results (on that call's stream): a forward's first kernels do not wait for it.  Nothing for the caller to do,
+ * except before capturing plan calls WITHOUT the pack into a hipGraph: glowhip_plan_pack_sync (HOST, blocks) waits for the side
+ * part of the last pack so that the captured calls have nothing outside the graph to join. */
+int glowhip_plan_pack_sync(glowhip_plan* plan);
 
 /* FlowModel.encode: x (N, C0,H0,W0 of layer 0) -> z (output shape of the last layer),
  * logdet_out[n] = (logdet_in ? logdet_in[n] : 0) + sum of all layers' log-determinant terms.
@@ -307,7 +313,8 @@ int glowhip_plan_timing_read(glowhip_plan* plan, glowhip_timing_record* out, int
  * network (cnet) off; | 0x200000 = cnet computes f.0 + f.2 only; bits 22..24 = 1, 2 or 4: that many row splits of cnet;
  * | 0x2000000 = cnet with 128-pixel tiles only, | 0x4000000 = 64-pixel tiles wherever supported,
  * | 0x8000000 = the finishing step of a FlowStep runs inside the next FlowStep's k_cnet (off by default: measured slower),
- * | 0x10000000 = the finishing kernel takes its pixel chunks in block order instead of the XCD-affine order (A/B).
+ * | 0x10000000 = the finishing kernel takes its pixel chunks in block order instead of the XCD-affine order (A/B),
+ * | 0x20000000 = glowhip_plan_pack entirely on the caller's stream, no side-stream fork (A/B).
  * 0 restores automatic selection.
  * Process-wide, not thread safe: a testing hook, not part of the operator surface. */
 void glowhip_debug_force_tail_tile(int pixels_and_flags);

@@ -163,6 +163,10 @@ class FlowPlan:
             # forced = the caller declares the parameters changed (behind the version counters' back): nothing packed earlier counts
             self.pack(use if (force or stale) else (use & ~have), merge=not force)
 
+    def pack_sync(self) -> None:
+        """Host-wait for the side-stream part of the last pack (glowhip_plan_pack_sync): before capturing pack-free calls."""
+        check(lib().glowhip_plan_pack_sync(self._h))
+
     def invalidate(self) -> None:
         self._packed_version = None
 

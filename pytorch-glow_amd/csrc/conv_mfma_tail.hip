@@ -353,6 +353,7 @@ void conv_mfma_tail_force_tile(int v) {
     cnet_force((v >> 22) & 7, (v >> 25) & 15);   // bits 22..24: row splits; bit 25: 128-pixel tiles only, bit 26: 64-pixel tiles, bit 27: finishing chained into the next k_cnet, bit 28: finishing kernel without the XCD-affine chunk order
     tail_sh_force_waves((v >> 16) & 0xf);
     plan_train_disable_sh((v & 0x800) ? 1 : 0);
+    plan_pack_one_stream((v & 0x20000000) ? 1 : 0);      // bit 29: glowhip_plan_pack entirely on the caller's stream (A/B)
 }
 
 }  // namespace glowhip

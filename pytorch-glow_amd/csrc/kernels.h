@@ -95,8 +95,9 @@ struct RepackJob {
 };
 // rj_dev: the repack jobs SORTED by kind group (legacy kinds | SH2_GEMM | SH2_FIRST | SH2_TAIL), n_kind[4] their counts;
 // tail_blocks: workgroups per SH2_TAIL job (8 output channels each)
+// s_legacy: the stream of the legacy-kind image kernel (the same as s, or a side stream forked from it)
 int launch_pack_batched(const ScaleJob* sj_dev, int n_scale, const RepackJob* rj_dev, const int* n_kind, int tail_blocks, void* packed,
-                        hipStream_t s);
+                        hipStream_t s, hipStream_t s_legacy);
 
 // ---------------------------------------------------------------- conv_direct.hip
 struct ConvArgs {

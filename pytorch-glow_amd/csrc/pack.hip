@@ -398,7 +398,7 @@ __global__ void __launch_bounds__(256) k_repack_sh2_batched(const RepackJob* __r
 }
 
 int launch_pack_batched(const ScaleJob* sj_dev, int n_scale, const RepackJob* rj_dev, const int* n_kind, int tail_blocks, void* packed,
-                        hipStream_t s) {
+                        hipStream_t s, hipStream_t s_legacy) {
     if (n_scale > 0) {
         hipLaunchKernelGGL(k_pack_scales_batched, dim3(2, n_scale), dim3(256), 0, s, sj_dev, (char*)packed);
         GH_LAUNCH_CHECK("k_pack_scales_batched");
@@ -407,7 +407,7 @@ int launch_pack_batched(const ScaleJob* sj_dev, int n_scale, const RepackJob* rj
     // ALL jobs with an early exit per foreign job cost the f.4 image kernel 4 300 empty workgroups at two per CU (its registers)
     const RepackJob* rj = rj_dev;
     if (n_kind[0] > 0) {
-        hipLaunchKernelGGL(k_repack_batched, dim3(64, n_kind[0]), dim3(256), 0, s, rj, (char*)packed);
+        hipLaunchKernelGGL(k_repack_batched, dim3(64, n_kind[0]), dim3(256), 0, s_legacy, rj, (char*)packed);
         GH_LAUNCH_CHECK("k_repack_batched");
     }
     rj += n_kind[0];

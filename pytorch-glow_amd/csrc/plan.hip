@@ -78,6 +78,8 @@ static int carve(const glowhip_plan* p, int N, void* ws, size_t bytes, Workspace
 // ---------------------------------------------------------------- coupling network f() (network/module.py:300-319)
 // Runs conv3x3 -> actnorm -> relu -> conv1x1 -> actnorm -> relu -> conv3x3(zeros) and applies the
 // coupling to z2.  x1: first-half channels (batch stride x1_bs).
+static bool g_pack_one_stream = false;     // testing hook: glowhip_plan_pack without the side-stream fork
+void plan_pack_one_stream(int on) { g_pack_one_stream = on != 0; }
 static bool g_sh_disabled = false, g_sh_tail_disabled = false, g_sh_first_disabled = false, g_sh_f02_disabled = false,
             g_sh_mix_disabled = false, g_cnet_disabled = false, g_cnet_h2_only = false;
 void plan_disable_sh(int off) {
@@ -392,9 +394,11 @@ static int run_forward(glowhip_plan* p, const void* packed, const float* x, cons
                     }
                 }
                 float* z2 = dst + (long)Ch * HW;
+                GH_TRY(join_legacy(p, s));
                 GH_TRY(run_coupling(p, L, packed, dst, chw, z2, chw, z2, chw, N, 0, w, s, &nm));
                 premixed = nm.C != 0;
             } else {  // SPLIT2D: score z2 under the prior predicted from z1, keep z1
+                GH_TRY(join_legacy(p, s));
                 GH_TRY(run_split(L, packed, cur, chw, cur + (long)Ch * HW, chw, nullptr, nullptr, 0, N, 0, w, s));
                 GH_TRY(launch_copy_strided(cur, chw, dst, (long)Ch * HW, N, (long)Ch * HW, s));
             }
@@ -708,6 +712,11 @@ glowhip_plan* glowhip_plan_create(const glowhip_layer_desc* layers, int n_layers
 
 void glowhip_plan_destroy(glowhip_plan* plan) {
     if (!plan) return;
+    if (plan->side) {      // (the side stream may still be writing into the caller's `packed` buffer)
+        (void)hipStreamSynchronize(plan->side);
+        (void)hipEventDestroy(plan->ev_fork); (void)hipEventDestroy(plan->ev_legacy); (void)hipEventDestroy(plan->ev_lu);
+        (void)hipStreamDestroy(plan->side);
+    }
     for (hipEvent_t e : plan->ev_pool) (void)hipEventDestroy(e);
     for (TimingSlot& t : plan->ev_used) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     delete plan;
@@ -848,6 +857,7 @@ int glowhip_plan_pack_for(glowhip_plan* plan, void* packed, size_t packed_bytes,
     GH_REQUIRE(packed_bytes >= plan->packed_bytes, "plan_pack: packed buffer too small (%zu < %zu)", packed_bytes,
                plan->packed_bytes);
     hipStream_t s = (hipStream_t)stream;
+    GH_TRY(join_legacy(plan, s)); GH_TRY(join_lu(plan, s));      // (a previous pack's side-stream part writes the same buffer)
     // job tables -> device (plan-constant contents; re-sent because `packed` is caller memory), then 4 launches
     if (hipMemsetAsync(packed, 0, 256, s) != hipSuccess) {
         set_error("plan_pack: hipMemsetAsync failed");
@@ -867,12 +877,44 @@ int glowhip_plan_pack_for(glowhip_plan* plan, void* packed, size_t packed_bytes,
         }
         plan->tables_in = packed; plan->tables_use = use;
     }
+    // Fork: the legacy-kind images and the LU factorisations go to the plan's side stream (created on first use; a host resource
+    // like the timing events) behind everything enqueued so far; whoever reads their results joins (join_legacy / join_lu).  What
+    // the first kernels of a forward need -- scale tables, the product kernels' images -- stays on `stream`.
+    // Only where it pays: plans with invertible 1x1 convolutions beyond 128 channels (blocked LU in global memory, 2.4 ms per pack
+    // at config E: +5 % on its forward).  At config B the side stream's workgroups only get in the way of the k_cnet launch that
+    // runs beside them (-0.5 %): everything stays on `stream` there.
+    hipStream_t side = s;
+    if (!g_pack_one_stream && plan->max_c > 128) {
+        if (!plan->side) {
+            if (hipStreamCreateWithFlags(&plan->side, hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&plan->ev_fork, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&plan->ev_legacy, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&plan->ev_lu, hipEventDisableTiming) != hipSuccess) {
+                set_error("plan_pack: could not create the side stream / events");
+                return GLOWHIP_ELAUNCH;
+            }
+        }
+        side = plan->side;
+        if (hipEventRecord(plan->ev_fork, s) != hipSuccess || hipStreamWaitEvent(side, plan->ev_fork, 0) != hipSuccess) {
+            set_error("plan_pack: fork onto the side stream failed");
+            return GLOWHIP_ELAUNCH;
+        }
+    }
     GH_TRY(launch_pack_batched(at<ScaleJob>(packed, plan->scale_off), (int)plan->scale_jobs.size(),
-                               at<RepackJob>(packed, plan->repack_off), n_kind, tail_blocks, packed, s));
-    if (use & 32) return GLOWHIP_OK;      // (internal: weight images and scale tables only -- the init pass' first pack)
-    GH_TRY(launch_step_prepare_batched(at<StepPrepJob>(packed, plan->prep_off), (int)plan->prep_jobs.size(),
-                                       plan->max_lds_c, packed, s, (use & (GLOWHIP_PACK_INVERSE | GLOWHIP_PACK_TRAINING)) != 0,
-                                       plan->max_c));
+                               at<RepackJob>(packed, plan->repack_off), n_kind, tail_blocks, packed, s, side));
+    if (side != s) {
+        if (hipEventRecord(plan->ev_legacy, side) != hipSuccess) { set_error("plan_pack: hipEventRecord failed"); return GLOWHIP_ELAUNCH; }
+        plan->legacy_pending = true;
+    }
+    if (!(use & 32)) {      // (32, internal: weight images and scale tables only -- the init pass' first pack)
+        GH_TRY(launch_step_prepare_batched(at<StepPrepJob>(packed, plan->prep_off), (int)plan->prep_jobs.size(),
+                                           plan->max_lds_c, packed, side, (use & (GLOWHIP_PACK_INVERSE | GLOWHIP_PACK_TRAINING)) != 0,
+                                           plan->max_c));
+    }
+    if (side != s) {
+        if (hipEventRecord(plan->ev_lu, side) != hipSuccess) { set_error("plan_pack: hipEventRecord failed"); return GLOWHIP_ELAUNCH; }
+        plan->lu_pending = true;
+    }
     return GLOWHIP_OK;
 }
 
@@ -895,6 +937,15 @@ int glowhip_plan_status(const glowhip_plan* plan, const void* workspace, size_t 
     return launch_status(w.acc, N, result, elems_per_sample, status_out, (hipStream_t)stream);
 }
 
+int glowhip_plan_pack_sync(glowhip_plan* plan) {
+    GH_REQUIRE(plan, "plan_pack_sync: null plan");
+    if (plan->side && (plan->legacy_pending || plan->lu_pending)) {
+        if (hipStreamSynchronize(plan->side) != hipSuccess) { set_error("plan_pack_sync: hipStreamSynchronize failed"); return GLOWHIP_ELAUNCH; }
+        plan->legacy_pending = plan->lu_pending = false;
+    }
+    return GLOWHIP_OK;
+}
+
 int glowhip_plan_encode(glowhip_plan* plan, const void* packed, const float* x, const float* noise,
                         const float* logdet_in, float* z, float* logdet_out, int N, void* workspace,
                         size_t workspace_bytes, glowhip_stream_t stream) {
@@ -906,6 +957,7 @@ int glowhip_plan_encode(glowhip_plan* plan, const void* packed, const float* x, 
     GH_TRY(carve(plan, N, workspace, workspace_bytes, w));
     GH_TRY(launch_zero_acc(w.acc, N, s));
     GH_TRY(run_forward(plan, packed, x, noise, z, N, w, s));
+    GH_TRY(join_legacy(plan, s)); GH_TRY(join_lu(plan, s));
     if (logdet_out)
         GH_TRY(launch_finalize(logdet_in, w.acc, at<double>(packed, 0), 1.0, 0.0, 1.0, logdet_out, nullptr, N, s));
     return GLOWHIP_OK;
@@ -923,6 +975,7 @@ int glowhip_plan_decode(glowhip_plan* plan, const void* packed, const float* z, 
     Workspace w;
     GH_TRY(carve(plan, N, workspace, workspace_bytes, w));
     GH_TRY(launch_zero_acc(w.acc, N, s));
+    GH_TRY(join_legacy(plan, s)); GH_TRY(join_lu(plan, s));      // decode reads W^-1 and the deep levels' images first
     GH_TRY(run_reverse(plan, packed, z, eps, n_eps, x, N, w, s));
     if (logdet_out)
         GH_TRY(launch_finalize(logdet_in, w.acc, at<double>(packed, 0), -1.0, 0.0, 1.0, logdet_out, nullptr, N, s));
@@ -947,6 +1000,7 @@ int glowhip_glow_forward(glowhip_plan* plan, const void* packed, const float* x,
     const int* o = plan->out_shape;
     GH_TRY(launch_gaussian_logp(z, (long)o[0] * o[1] * o[2], prior_mean, prior_logs, prior_stride, N, o[0], o[1] * o[2],
                                 w.acc, s));
+    GH_TRY(join_legacy(plan, s)); GH_TRY(join_lu(plan, s));      // the sum of the log|det W| terms enters here
     // objective = -ln(n_bins)*CHW + logdet + logp;  nll = -objective / (ln2 * CHW)   (network/model.py:425-450)
     const double chw = (double)plan->in_shape[0] * plan->in_shape[1] * plan->in_shape[2];
     const double offset = -log(pow(2.0, n_bits)) * chw;
@@ -981,6 +1035,7 @@ int glowhip_glow_forward_u8(glowhip_plan* plan, const void* packed, const uint8_
     GH_TRY(launch_gaussian_logp(z, (long)o[0] * o[1] * o[2], prior_mean, prior_logs, prior_stride, N, o[0], o[1] * o[2],
                                 w.acc, s));
     const double chw = (double)plan->in_shape[0] * plan->in_shape[1] * plan->in_shape[2];
+    GH_TRY(join_legacy(plan, s)); GH_TRY(join_lu(plan, s));
     return launch_finalize(nullptr, w.acc, at<double>(packed, 0), 1.0, -log(pow(2.0, n_bits)) * chw, -1.0 / (log(2.0) * chw),
                            nll_out, objective_out, N, s);
 }
@@ -997,6 +1052,7 @@ int glowhip_plan_actnorm_init(glowhip_plan* plan, void* packed, size_t packed_by
     // plain (ActNorm-free) fp32 MFMA weight images of every convolution: the training family's + the init pass's own f.0 image
     // (no LU here: the invertible 1x1 convolutions are applied with W itself, and the pack at the end factorises them)
     GH_TRY(glowhip_plan_pack_for(plan, packed, packed_bytes, GLOWHIP_PACK_TRAINING | 16 | 32, stream));
+    GH_TRY(join_legacy(plan, s)); GH_TRY(join_lu(plan, s));
     // Layer by layer: set the ActNorm statistics from the activations that reach it, refresh the packed
     // data of that layer, then run the layer forward with the fresh parameters (first training-mode
     // forward of the reference: network/module.py:45-46,66-67).

@@ -53,6 +53,11 @@ struct glowhip_plan {
     std::vector<RepackJob> repack_jobs;
     std::vector<RepackJob> repack_sel;    // the subset selected by the last glowhip_plan_pack_for (kept alive for the async copy)
     size_t prep_off = 0, scale_off = 0, repack_off = 0;
+    // glowhip_plan_pack forks onto a side stream what the first kernels of a forward do not wait for: the round-1 / fp32 weight images
+    // (read by the deep levels and the Split2d priors) and the LU factorisations (log|det W| enters only the final sum; W^-1 is
+    // read by decode / backward).  Consumers join through these events (join_legacy / join_lu).
+    hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_legacy = nullptr, ev_lu = nullptr;
+    bool legacy_pending = false, lu_pending = false;
     const void* tables_in = nullptr; int tables_use = 0;   // the `packed` buffer that already holds the job tables of that use mask
     int max_lds_c = 0, max_c = 0;
     size_t packed_bytes = 0;
@@ -70,6 +75,16 @@ struct glowhip_plan {
 namespace glowhip {
 
 static inline void count_launch(glowhip_plan* p, const char* name) { if (p) ++p->launch_counts[name]; }
+
+// make stream s wait for the side-stream part of the last pack (no-ops when nothing is pending)
+static inline int join_legacy(glowhip_plan* p, hipStream_t s) {
+    if (p->legacy_pending && hipStreamWaitEvent(s, p->ev_legacy, 0) != hipSuccess) { set_error("join_legacy: hipStreamWaitEvent failed"); return GLOWHIP_ELAUNCH; }
+    return GLOWHIP_OK;
+}
+static inline int join_lu(glowhip_plan* p, hipStream_t s) {
+    if (p->lu_pending && hipStreamWaitEvent(s, p->ev_lu, 0) != hipSuccess) { set_error("join_lu: hipStreamWaitEvent failed"); return GLOWHIP_ELAUNCH; }
+    return GLOWHIP_OK;
+}
 
 static inline size_t take(size_t& off, size_t bytes) {
     size_t o = align_up(off, 256);

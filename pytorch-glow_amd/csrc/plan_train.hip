@@ -436,6 +436,7 @@ int glowhip_glow_forward_train(glowhip_plan* plan, const void* packed, const flo
     GH_REQUIRE(workspace_bytes >= train_ws_layout(plan, N, workspace, &w), "glow_forward_train: workspace too small");
     hipStream_t s = (hipStream_t)stream;
     GH_TRY(launch_zero_acc(w.acc, N, s));
+    GH_TRY(join_legacy(plan, s)); GH_TRY(join_lu(plan, s));      // the training kernels read the fp32 images from the first layer on
     GH_TRY(forward_train(plan, packed, x, noise, z, N, (char*)tape, tl, w.acc, w.gsh, s));
     const int* o = plan->out_shape;
     GH_TRY(launch_gaussian_logp(z, (long)o[0] * o[1] * o[2], prior_mean, prior_logs, prior_stride, N, o[0], o[1] * o[2],
@@ -471,6 +472,7 @@ int glowhip_glow_backward(glowhip_plan* plan, const void* packed, const float* x
     for (const LayerPlan& L : plan->layers)
         GH_REQUIRE(L.d.kind != GLOWHIP_LAYER_FLOWSTEP || L.d.C <= 192, "glow_backward: C=%d not supported yet", L.d.C);
     hipStream_t s = (hipStream_t)stream;
+    GH_TRY(join_legacy(plan, s)); GH_TRY(join_lu(plan, s));
     const double chw = (double)plan->in_shape[0] * plan->in_shape[1] * plan->in_shape[2];
     GH_TRY(launch_gld_from_nll(nll_grad, w.gld, N, 1.0 / (log(2.0) * chw), s));
     GH_TRY(launch_sum_gld(w.gld, N, w.gsum, s));

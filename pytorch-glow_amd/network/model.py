@@ -288,6 +288,7 @@ class GraphedForward:
                 self._body()
         torch.cuda.current_stream(x.device).wait_stream(side)
         torch.cuda.synchronize(x.device)
+        plan.pack_sync()            # (repack=False: nothing of an earlier pack is left for the captured calls to join)
         self.graph = torch.cuda.CUDAGraph()
         with torch.no_grad(), torch.cuda.graph(self.graph, stream=side):
             self._body()
