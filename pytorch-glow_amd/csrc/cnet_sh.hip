@@ -1025,7 +1025,7 @@ __global__ void __launch_bounds__(256) k_cfinish(CfinArgs a) {
     const int tid = threadIdx.x;
     const int HW = a.HW, W = a.W;
     const FinSrc f = fin_src(a.p, a.N, a.H, W, HW, a.wshift);
-    constexpr int LPXB = PXB == 64 ? 6 : 4;
+    constexpr int LPXB = PXB == 256 ? 8 : (PXB == 64 ? 6 : 4);
     const int chunk = a.xcd_affine && f.lpxt >= LPXB ? cfin_chunk(blockIdx.x, gridDim.x, f.lpxt - LPXB) : (int)blockIdx.x;
     const long gp0 = (long)chunk * PXB;
     const long n = gp0 / HW;
@@ -1047,7 +1047,9 @@ __global__ void __launch_bounds__(256) k_cfinish(CfinArgs a) {
     const float* zi = a.p.z + n * a.p.z_bs;
     float* zn = a.z_out + n * a.z_out_bs;
     long long ldq = 0;
-    constexpr int U = 2;
+    // elements per thread and round: with 256-pixel workgroups (launches of 131 072 pixels and more: 64-pixel workgroups came
+    // in four rounds per CU, each a full latency chain -- 32 us for 38 MB at config E's 128-wide level) all six at once
+    constexpr int U = PXB == 256 ? 6 : 2;
     const int total = Ch * PXB;
     const bool an = a.mix.C && !a.mix.reverse;
     for (int e0 = tid; e0 < total; e0 += 256 * U) {
@@ -1105,8 +1107,8 @@ __global__ void __launch_bounds__(256) k_cfinish(CfinArgs a) {
     if (a.mix.C) {
         // thread = (output group og, pixel q): outputs o = og, og + OG, ... four at a time (the staged value v[i][q] is read once
         // for four outputs; the matrix rows are wave-uniform LDS broadcasts)
-        constexpr int OG = 256 / PXB;
-        const int q = tid & (PXB - 1), og = tid / PXB;
+        constexpr int OG = PXB >= 256 ? 1 : 256 / PXB;
+        const int q = tid & (PXB - 1), og = PXB >= 256 ? 0 : tid / PXB;
         for (int ob = og; ob < C; ob += 4 * OG) {
             float r[4];
             if (a.mix.matrix) {   // same operation order as k_chanmix: r = fma(m[o][i], v[i], r), i ascending
@@ -1303,7 +1305,8 @@ int launch_cnet_finish(const CnetArgs& a, const CnetPending& p, hipStream_t s) {
     const int C = 2 * (paired ? p.Cout / 2 : p.Cout);
     GH_REQUIRE(a.mix.C == 0 || a.mix.C == C, "cnet: mixer channel count %d != %d", a.mix.C, C);
     const long total_px = (long)a.N * HW;
-    const int pxb = total_px < 32768 ? 16 : 64;      // small levels: 16 pixels per workgroup, so that the launch still covers the chip
+    // small levels: 16 pixels per workgroup, so that the launch still covers the chip; large ones (config D / E level 1): 256
+    const int pxb = total_px < 32768 ? 16 : (total_px >= 131072 && total_px % 256 == 0 && HW % 256 == 0 && p.lpxt <= 8 ? 256 : 64);
     const size_t flds = ((size_t)C * pxb + (a.mix.C && a.mix.matrix ? (size_t)C * C : 0)) * sizeof(float);
     GH_REQUIRE(flds <= 64 * 1024, "cnet: finishing kernel LDS");
     const bool halos = p.NI == 1 && p.R < a.H;
@@ -1317,6 +1320,7 @@ int launch_cnet_finish(const CnetArgs& a, const CnetPending& p, hipStream_t s) {
     }
     GH_CF(16, 1, false) GH_CF(16, 1, true) GH_CF(16, 2, false) GH_CF(16, 2, true) GH_CF(16, 4, false) GH_CF(16, 4, true)
     GH_CF(64, 1, false) GH_CF(64, 1, true) GH_CF(64, 2, false) GH_CF(64, 2, true) GH_CF(64, 4, false) GH_CF(64, 4, true)
+    GH_CF(256, 1, false) GH_CF(256, 1, true) GH_CF(256, 2, false) GH_CF(256, 2, true)
 #undef GH_CF
     GH_REQUIRE(launched, "cnet: no finishing kernel for row split %d", p.MS);
     GH_LAUNCH_CHECK("k_cfinish");
