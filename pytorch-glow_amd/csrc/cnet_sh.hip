@@ -1306,7 +1306,7 @@ int launch_cnet_finish(const CnetArgs& a, const CnetPending& p, hipStream_t s) {
     GH_REQUIRE(a.mix.C == 0 || a.mix.C == C, "cnet: mixer channel count %d != %d", a.mix.C, C);
     const long total_px = (long)a.N * HW;
     // small levels: 16 pixels per workgroup, so that the launch still covers the chip; large ones (config D / E level 1): 256
-    const int pxb = total_px < 32768 ? 16 : (total_px >= 131072 && total_px % 256 == 0 && HW % 256 == 0 && p.lpxt <= 8 ? 256 : 64);
+    const int pxb = total_px < 16384 ? 16 : (total_px >= 131072 && total_px % 256 == 0 && HW % 256 == 0 && p.lpxt <= 8 ? 256 : 64);
     const size_t flds = ((size_t)C * pxb + (a.mix.C && a.mix.matrix ? (size_t)C * C : 0)) * sizeof(float);
     GH_REQUIRE(flds <= 64 * 1024, "cnet: finishing kernel LDS");
     const bool halos = p.NI == 1 && p.R < a.H;

@@ -474,11 +474,12 @@ def test_additive_step_wider_than_the_fused_mixer_both_directions(c):
     close(xi, xr, 5e-5, what="rev x"); ld_close(ldi, ldxr)
 
 
-@pytest.mark.parametrize("c", [132, 200, 448, 452])
+@pytest.mark.parametrize("c", [118, 132, 200, 448, 452])
 def test_invconv_logdet_blocked_lu(c):
     """log|det W| of invconv matrices too large for LDS: the blocked LU (32-column panels; csrc/lu.hip lu_logdet_blocked) takes
     128 < C <= 448 on the forward-only pack -- C = 132 and 200 end on a partial panel, 448 is the largest it takes, 452 falls to
-    the unblocked factorisation -- checked against the oracle's FlowStep (network/module.py:356-357) on a 4x4 map."""
+    the unblocked factorisation -- checked against the oracle's FlowStep (network/module.py:356-357) on a 4x4 map.  (C = 118: the
+    wide channel mixer with matrix rows that are not 16-byte aligned in LDS -- its scalar inner loop.)"""
     st, sd = _rand_step(c, 64, "additive", seed=c)
     x = torch.randn(2, c, 4, 4, generator=torch.Generator().manual_seed(1))
     ld = torch.zeros(2)
