@@ -818,21 +818,29 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
             const int kp = unit / g.NU4, ru = unit - kp * g.NU4;
             const _Float16* ap = a4_base(unit, l);
             const _Float16* bp = hbuf + ((long)(2 * kp * nsl + kl) * PXT + ml) * 8;
+            // (B fragments as in P2 where one round of reads serves all pixel tiles: the hi plane of step st + 1 is requested before
+            // the third sweep of step st, the lo plane of step st at its start -- BPRE4; with 128 accumulator registers live the
+            // tiles go two at a time and every half-step reads its own fragments)
+            constexpr int JW = TP2 == 8 ? 2 : NPT;
+            constexpr bool BPRE4 = JW == NPT;
+            h8 bhn[BPRE4 ? NPT : 1];
+            if (BPRE4) {
+#pragma unroll
+                for (int jj = 0; jj < NPT; ++jj) bhn[jj] = *reinterpret_cast<const h8*>(bp + jj * 256);
+            }
             auto step4 = [&](int st, const h8 (&use)[2 * RTU], h8 (&fill)[2 * RTU]) {
                 loadA4(ap, ru, min(st + 2, nsl - 1), fill);      // unconditional (clamped)
 #if CN_SB_P3
                 __builtin_amdgcn_sched_barrier(0);
 #endif
                 const _Float16* bs = bp + (long)st * (2 * PXT * 8);
-                // all pixel tiles per k-step when the h2 accumulators are small (12 MFMAs behind one round of LDS reads), two at
-                // a time while 128 of them are still live
-                constexpr int JW = TP2 == 8 ? 2 : NPT;
 #pragma unroll
                 for (int jp = 0; jp < NPT / JW; ++jp) {
                     h8 bh[JW], bl[JW];
 #pragma unroll
                     for (int jj = 0; jj < JW; ++jj) {
-                        bh[jj] = *reinterpret_cast<const h8*>(bs + (JW * jp + jj) * 256);
+                        if (BPRE4) bh[jj] = bhn[jj];
+                        else bh[jj] = *reinterpret_cast<const h8*>(bs + (JW * jp + jj) * 256);
                         bl[jj] = *reinterpret_cast<const h8*>(bs + (JW * jp + jj) * 256 + (long)LCH * PXT * 8);
                     }
 #pragma unroll
@@ -847,6 +855,11 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
                         for (int jj = 0; jj < JW; ++jj)
                             accT[u][i * NPT + JW * jp + jj] =
                                 __builtin_amdgcn_mfma_f32_32x32x16_f16(use[i], bl[jj], accT[u][i * NPT + JW * jp + jj], 0, 0, 0);
+                    if (BPRE4) {      // next step's hi plane (clamped: the last step re-reads its own)
+                        const _Float16* bn = bp + (long)min(st + 1, nsl - 1) * (2 * PXT * 8);
+#pragma unroll
+                        for (int jj = 0; jj < JW; ++jj) bhn[jj] = *reinterpret_cast<const h8*>(bn + jj * 256);
+                    }
 #pragma unroll
                     for (int i = 0; i < RTU; ++i)
 #pragma unroll
