@@ -210,3 +210,57 @@ def test_builder_needs_a_hip_device_and_knows_the_reference_tables():
     if not torch.cuda.is_available():
         with pytest.raises(RuntimeError, match="HIP device"):
             Builder(hps).build(training=False)
+
+
+def test_shard_sampler_gives_every_rank_its_slice_of_the_same_global_batches():
+    """Trainer's data loading with one process per GPU: all ranks draw the SAME seeded permutation per epoch, a
+    global batch is a contiguous run of it, rank r keeps positions [r*B/G, (r+1)*B/G) -- no overlap, no omission, 1/G of the
+    loading per rank; a new epoch reshuffles."""
+    from pytorch_glow_amd.network.trainer import _ShardSampler
+    data = list(range(103))
+    world, gb = 4, 16
+    samplers = [_ShardSampler(data, gb, r, world, seed=7) for r in range(world)]
+    epoch0 = [list(s) for s in samplers]
+    per = gb // world
+    nb = len(data) // gb
+    assert all(len(e) == nb * per == len(s) for e, s in zip(epoch0, samplers))
+    for b in range(nb):
+        parts = [e[b * per:(b + 1) * per] for e in epoch0]
+        batch = sum(parts, [])
+        assert len(set(batch)) == gb                                   # disjoint shards
+    allidx = sum(epoch0, [])
+    assert len(set(allidx)) == nb * gb                                 # every sample of the kept batches exactly once
+    # the union equals what ONE process with the global batch would have drawn, in the same order
+    single = list(_ShardSampler(data, gb, 0, 1, seed=7))
+    rebuilt = []
+    for b in range(nb):
+        for r in range(world):
+            rebuilt += epoch0[r][b * per:(b + 1) * per]
+    assert rebuilt == single
+    epoch1 = [list(s) for s in samplers]
+    assert epoch1 != epoch0 and len(set(sum(epoch1, []))) == nb * gb
+
+
+def test_dequant_stream_is_keyed_by_seed_and_rank_and_counts_per_process(monkeypatch):
+    """network/model.py dequant_position: one stream per process -- the key folds the data-parallel rank into torch's seed, the
+    call number counts forwards across ALL plans, a new seed value restarts it, reset_dequant_stream() replays."""
+    import torch
+    import torch.distributed as dist
+    from pytorch_glow_amd.network import model as M
+    torch.manual_seed(11)
+    M.reset_dequant_stream()
+    k0, c0 = M.dequant_position(advance=True)
+    k1, c1 = M.dequant_position(advance=True)
+    assert (k0, c0, c1) == (11, 0, 1) and k1 == k0
+    assert M.dequant_position() == (11, 2)                              # peeking does not advance
+    monkeypatch.setattr(dist, "is_initialized", lambda: True)
+    monkeypatch.setattr(dist, "get_rank", lambda: 3)
+    k3, c3 = M.dequant_position()
+    assert k3 != k0 and c3 == 2 and k3 == (11 + 0x9E3779B97F4A7C15 * 3) % 2 ** 64
+    monkeypatch.undo()
+    torch.manual_seed(12)
+    assert M.dequant_position() == (12, 0)                              # a new seed restarts the stream
+    torch.manual_seed(11)
+    M.dequant_position(advance=True)
+    M.reset_dequant_stream()
+    assert M.dequant_position() == (11, 0)
