@@ -253,7 +253,9 @@ bool f02_sh_supported(int Cin, int H, int W, int hidden) {
     if (!first_sh_supported(Cin, H, W, hidden) || !gemm_sh_supported(hidden, hidden, H, W)) return false;
     if (hidden % 64 != 0 || hidden > 512) return false;      // h1 tile = hidden * 256 bytes of LDS; waves take channel-group pairs
     const int R = 64 / W;
-    return R >= 1 && H % R == 0;
+    if (R < 1 || H % R != 0) return false;
+    const size_t lds = ((size_t)2 * ((Cin + 7) / 8) * (R + 2) * (W + 2) * 8 + (size_t)2 * hidden * 64) * sizeof(_Float16);
+    return lds <= 160 * 1024;      // window planes + the h1 tile
 }
 
 // w0: first_sh image (REPACK_SH_FIRST), w2: gemm_sh image (REPACK_SH_GEMM)

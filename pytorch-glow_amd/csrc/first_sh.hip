@@ -131,8 +131,9 @@ static int first_sh_rows(int W) { return W == 64 ? 1 : (W == 32 ? 2 : 4); }   //
 static int first_sh_groups(int Cin) { return (9 * ((Cin + 7) / 8) + 1) & ~1; }
 
 bool first_sh_supported(int Cin, int H, int W, int Cout) {
-    if (Cout % 128 != 0 || Cin < 1 || Cin > 64) return false;
+    if (Cout % 128 != 0 || Cin < 1 || Cin > 128) return false;      // (Cin = 96: config E's 8x8 level, 47 us on the fp32 kernel)
     if (W != 8 && W != 16 && W != 32 && W != 64) return false;
+    if ((size_t)2 * ((Cin + 7) / 8) * (first_sh_rows(W) + 2) * (W + 2) * 8 * sizeof(_Float16) > 64 * 1024) return false;   // window planes in LDS
     return H % first_sh_rows(W) == 0 && (H * W) % 64 == 0;
 }
 
@@ -153,6 +154,7 @@ int launch_first_sh(const float* x, long x_bs, const void* wsh, _Float16* y_sh, 
     const int wshift = W == 64 ? 6 : (W == 32 ? 5 : (W == 16 ? 4 : 3));
 #define GH_FSH_CASE(nt, r)                                                                                            \
     if (R == r && r * W == 32 * nt) {                                                                                           \
+        if (lds > 32 * 1024) (void)hipFuncSetAttribute((const void*)k_first_sh<nt, r>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL((k_first_sh<nt, r>), dim3(grid, Cout / 128), dim3(256), lds, s, x, x_bs, w, bias, y_sh, N, Cin, H, W, \
                            Cout, wshift, relu);                                                                       \
         GH_LAUNCH_CHECK("k_first_sh");                                                                                \
