@@ -51,6 +51,21 @@ __device__ __forceinline__ void sh_split(float v, _Float16& hi, _Float16& lo) {
     lo = (_Float16)((v - (float)hi) * SH_LO_SCALE);
 }
 
+// Eight values at once (two-accumulator form: lo carries the residual times 2^11), packed conversions and packed fp32 arithmetic:
+// ~3 VALU instructions per value instead of 6; same bits as eight sh_split calls on v * pre (pre: an exact power of two).
+typedef _Float16 h2s __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void sh_split8(const f32x4_t& a, const f32x4_t& b, float pre, h8& hi, h8& lo) {
+#pragma unroll
+    for (int t = 0; t < 8; t += 2) {
+        const float v0 = (t < 4 ? a[t] : b[t - 4]) * pre, v1 = (t < 4 ? a[t + 1] : b[t - 3]) * pre;
+        const f32x2_t vv = {v0, v1};
+        const h2s x = __builtin_convertvector(vv, h2s);
+        const f32x2_t rr = {(v0 - (float)x[0]) * SH_LO_SCALE, (v1 - (float)x[1]) * SH_LO_SCALE};
+        const h2s y = __builtin_convertvector(rr, h2s);
+        hi[t] = x[0]; hi[t + 1] = x[1]; lo[t] = y[0]; lo[t + 1] = y[1];
+    }
+}
+
 // bytes of one SH tensor (both planes)
 static inline size_t sh_bytes(long P, int Ch) { return (size_t)2 * (size_t)P * (size_t)Ch * sizeof(_Float16); }
 

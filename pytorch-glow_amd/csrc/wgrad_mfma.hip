@@ -196,12 +196,7 @@ k_wgrad_gemm_sh(const float* __restrict__ A, long a_bs, const float* __restrict_
 #pragma unroll
         for (int g2 = 0; g2 < A_F4 / 2; ++g2) {
             h8 hi, lo;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                _Float16 x0, x1;
-                sh_split(ra[2 * g2 + (e >> 2)][e & 3] * a_scale, x0, x1);
-                hi[e] = x0; lo[e] = x1;
-            }
+            sh_split8(ra[2 * g2], ra[2 * g2 + 1], a_scale, hi, lo);
             const int grp = a_q * (A_F4 / 2) + g2;
             *reinterpret_cast<h8*>(&As[buf][0][grp][a_row][0]) = hi;
             *reinterpret_cast<h8*>(&As[buf][1][grp][a_row][0]) = lo;
@@ -209,12 +204,7 @@ k_wgrad_gemm_sh(const float* __restrict__ A, long a_bs, const float* __restrict_
 #pragma unroll
         for (int g2 = 0; g2 < B_F4 / 2; ++g2) {
             h8 hi, lo;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                _Float16 x0, x1;
-                sh_split(rb[2 * g2 + (e >> 2)][e & 3], x0, x1);
-                hi[e] = x0; lo[e] = x1;
-            }
+            sh_split8(rb[2 * g2], rb[2 * g2 + 1], 1.0f, hi, lo);
             const int grp = b_q * (B_F4 / 2) + g2;
             *reinterpret_cast<h8*>(&Bs[buf][0][grp][b_row][0]) = hi;
             *reinterpret_cast<h8*>(&Bs[buf][1][grp][b_row][0]) = lo;
