@@ -40,7 +40,7 @@ constexpr int CN_MAXMS = 4;
 struct CnetGeo {
     int wshift, lsub, NI, R, WP, Wpx, nchunk, G, steps0, Mpad4, NRT4, NU4, KS, npass, tiles;
     int winplane;     // halfs per window plane
-    int HW;
+    int HW, lhw;      // pixels per image and its log2
     int lpp;          // log2(pixels per staging pass)
     int pxt, lpxt;    // pixels per workgroup tile (128 or 64) and its log2
     int ng, Cg;       // f.4 in ng groups of Cg output channels (Mpad4, NRT4, NU4, KS, npass describe ONE group): wide steps
@@ -158,7 +158,9 @@ __device__ __forceinline__ long long block_sum_ll(long long v, long long* red) {
 // PRE: the launch may finish the previous step while it builds its window (a.pre_on); without it none of that code is compiled in
 // NG: f.4 output-channel groups (compile time: with one group nothing of the group loop survives -- as a run-time count it kept
 // the h2 accumulators alive through P4 and cost the level-1 instance 88 bytes of spills)
-template <int HID, int MS, int UPW, int PXT, bool PRE, int NG = 1>
+// TAPE: the training forward (plan_train.hip): h1 and h2 also go to memory as fp32 (N, hidden, H, W), stored from the epilogues
+// (a lane holds one pixel x 4 consecutive channels: a wave store is two 128-byte runs of one channel each); needs HW % 32 == 0
+template <int HID, int MS, int UPW, int PXT, bool PRE, int NG = 1, bool TAPE = false>
 __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
     const bool pre_on = PRE && a.pre_on;
     constexpr int NPT = PXT / 32;                    // pixel tiles of the workgroup: 4 (128 pixels) or 2 (64 pixels)
@@ -607,6 +609,14 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
                         _Float16* dst = hbuf + ((long)chunk * PXT + (pt1 + sp * PTSV + j) * 32 + ml) * 8 + 4 * kl;
                         *reinterpret_cast<h4*>(dst) = hi;
                         *reinterpret_cast<h4*>(dst + (long)NCH * PXT * 8) = lo;
+                        if (TAPE) {     // (with a row split every workgroup computes all of h1: each stores its own rows' share)
+                            const long px0 = gp0 + (pt1 + sp * PTSV + j) * 32;
+                            if (px0 < (long)a.N * HW && (MS == 1 || (o >= ms_row0 && o < ms_row0 + MR))) {
+                                float* tb = a.tape_h1 + (((px0 >> g.lhw) * HID) << g.lhw) + (px0 & (HW - 1));
+#pragma unroll
+                                for (int t = 0; t < 4; ++t) tb[((o + t) << g.lhw) + ml] = -v[t] * SH2_ACT_INV;
+                            }
+                        }
                     }
                 }
         }
@@ -734,9 +744,18 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
             const f32x4_t rs = *reinterpret_cast<const f32x4_t*>(t_rs2 + o);
             const f32x4_t bb = *reinterpret_cast<const f32x4_t*>(t_b2 + o);
 #pragma unroll
-            for (int j = 0; j < PT2; ++j)
+            for (int j = 0; j < PT2; ++j) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) acc2[i][j][4 * gq + t] = nrelu_bits(fmaf(acc2[i][j][4 * gq + t], rs[t], bb[t]));
+                if (TAPE) {
+                    const long px0 = gp0 + (pt2 + j) * 32;
+                    if (px0 < (long)a.N * HW) {
+                        float* tb = a.tape_h2 + (((px0 >> g.lhw) * HID) << g.lhw) + (px0 & (HW - 1));
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) tb[((ms_row0 + o + t) << g.lhw) + ml] = -acc2[i][j][4 * gq + t] * SH2_ACT_INV;
+                    }
+                }
+            }
         }
     GH_STAMP(10);
 
@@ -1018,6 +1037,7 @@ struct CfinArgs {
     unsigned long long* acc;
     int N, H, W, HW, wshift;
     int xcd_affine;
+    float* tape_hout;         // training tape (CnetArgs): hout, and the coupled z2 written back into p.z when mixing out of place
 };
 
 // XCD affinity (speed only; any block-to-chunk permutation is correct).  The hardware places block b on XCD b % 8, and each XCD
@@ -1088,6 +1108,12 @@ __global__ void __launch_bounds__(256) k_cfinish(CfinArgs a) {
             float bad = 0.f;
             const float zres = fin_apply_k(f, se[u], so[u], zin[u], kb[u][0], kb[u][1], kb[u][2], kb[u][3], ldq, bad);
             if (bad != 0.f) fix_flag_nonfinite(a.acc, n, a.N, bad);
+            if (a.tape_hout) {
+                const int ce = f.paired ? 2 * c : c;
+                a.tape_hout[(n * f.Cout + ce) * HW + p] = (se[u] + kb[u][0]) * kb[u][1];
+                if (f.paired) a.tape_hout[(n * f.Cout + ce + 1) * HW + p] = (so[u] + kb[u][2]) * kb[u][3];
+                if (zn != zi) const_cast<float*>(zi)[(long)(Ch + c) * HW + p] = zres;
+            }
             if (a.mix.C) {
                 if (!a.mix.reverse) {     // ActNorm of the next step on both halves, staged for its matrix / gather
                     mixv[c * PXB + q] = (z1v[u] + km[u][0]) * km[u][1];
@@ -1193,7 +1219,7 @@ static bool cnet_geo(int Cin, int H, int W, int hidden, int Cout, int N, int pxt
     CnetGeo g{};
     g.ng = ng; g.Cg = Cout / ng;
     Cout = g.Cg;      // everything below describes ONE group of f.4 output channels
-    g.HW = HW;
+    g.HW = HW; g.lhw = __builtin_ctz(HW);
     g.pxt = pxt; g.lpxt = __builtin_ctz(pxt);
     g.wshift = __builtin_ctz(W);
     if (HW >= pxt) { g.NI = 1; g.R = pxt / W; g.lsub = g.lpxt; }
@@ -1260,17 +1286,15 @@ static int launch_cnet_inst(const CnetArgs& a, const CnetGeo& g, hipStream_t s) 
     return GLOWHIP_OK;
 }
 
-int launch_cnet_main(const CnetArgs& a, hipStream_t s, CnetPending* out) {
-    GH_REQUIRE(a.mode == TAIL_AFFINE_FWD || a.mode == TAIL_AFFINE_REV || a.mode == TAIL_ADD_FWD || a.mode == TAIL_ADD_REV,
-               "cnet: coupling modes only");
-    if (a.N == 0) return GLOWHIP_OK;
+// tile size, row split and T units per wave of a launch
+static bool cnet_select(const CnetArgs& a, CnetGeo* gout, int* ms_out, int* upw_out) {
     // Tile size and row split.  128-pixel tiles halve the weight bytes per MFMA and are taken whenever they alone give every CU a
     // workgroup.  Below that, 64-pixel tiles double the workgroup count without recomputing anything; splitting the h2 rows over
     // MS workgroups per tile (each recomputing h1) comes last.
     CnetGeo g128, g64, g;
     const bool ok128 = cnet_geo(a.Cin, a.H, a.W, a.hidden, a.Cout, a.N, 128, &g128);
     const bool ok64 = cnet_geo(a.Cin, a.H, a.W, a.hidden, a.Cout, a.N, 64, &g64);
-    GH_REQUIRE(ok128 || ok64, "cnet: unsupported shape");
+    if (!ok128 && !ok64) return false;
     bool use64 = !ok128 || (ok64 && g128.tiles < 224);
     if (g_cnet_flags & 1) use64 = !ok128;      // testing: 128-pixel tiles wherever they exist
     if (g_cnet_flags & 2) use64 = ok64;        // testing: 64-pixel tiles wherever they exist
@@ -1286,10 +1310,49 @@ int launch_cnet_main(const CnetArgs& a, hipStream_t s, CnetPending* out) {
     const int upw = g.NU4 * g.KS > 8 ? 2 : 1;
     if (upw == 2 && a.hidden == 512 && ms == 1 && !use64 && !a.y_sh) ms = 2;
     while ((a.hidden / ms / 16) / g.KS < 1 && ms > 1) ms /= 2;
+    *gout = g; *ms_out = ms; *upw_out = upw;
+    return true;
+}
+
+// taping instances (TAPE = true): the training shapes -- one group of f.4 output channels, one T unit per wave
+static bool cnet_tape_instance(int hidden, int ms, int upw, int pxt, int ng) {
+    return ng == 1 && upw == 1 && (hidden == 512 || (hidden == 256 && ms <= 2) || (hidden == 128 && ms == 1));
+}
+
+bool cnet_tape_supported(int Cin, int H, int W, int hidden, int Cout, int N) {
+    CnetArgs a{};
+    a.Cin = Cin; a.H = H; a.W = W; a.hidden = hidden; a.Cout = Cout; a.N = N;
+    CnetGeo g; int ms, upw;
+    if ((H * W) % 32 != 0 || !cnet_select(a, &g, &ms, &upw)) return false;
+    return cnet_tape_instance(hidden, ms, upw, g.pxt, g.ng);
+}
+
+template <int HID, int MS, int PXT>
+static int launch_cnet_tape(const CnetArgs& a, const CnetGeo& g, hipStream_t s) {
+    const size_t lds = cnet_lds_bytes(g, HID);
+    (void)hipFuncSetAttribute((const void*)k_cnet<HID, MS, 1, PXT, false, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((k_cnet<HID, MS, 1, PXT, false, 1, true>), dim3(g.tiles, MS), dim3(512), lds, s, a, g);
+    GH_LAUNCH_CHECK("k_cnet (taping)");
+    return GLOWHIP_OK;
+}
+
+int launch_cnet_main(const CnetArgs& a, hipStream_t s, CnetPending* out) {
+    GH_REQUIRE(a.mode == TAIL_AFFINE_FWD || a.mode == TAIL_AFFINE_REV || a.mode == TAIL_ADD_FWD || a.mode == TAIL_ADD_REV,
+               "cnet: coupling modes only");
+    if (a.N == 0) return GLOWHIP_OK;
+    CnetGeo g; int ms, upw;
+    GH_REQUIRE(cnet_select(a, &g, &ms, &upw), "cnet: unsupported shape");
     GH_REQUIRE(!a.pre_on || a.pre.MS == ms, "cnet: a chained launch needs the previous step's row split");
+    const bool tape = a.tape_h1 != nullptr;
+    GH_REQUIRE(!tape || (a.tape_h2 && !a.pre_on && !a.y_sh && g.HW % 32 == 0 && cnet_tape_instance(a.hidden, ms, upw, g.pxt, g.ng)),
+               "cnet: no taping instance for this launch");
     int rc = GLOWHIP_EINVAL;
-#define GH_CN(hid, m, u, px) if (g.ng == 1 && a.hidden == hid && ms == m && upw == u && g.pxt == px) rc = launch_cnet_inst<hid, m, u, px>(a, g, s);
-#define GH_CN2(hid, m, u, px) if (g.ng == 2 && a.hidden == hid && ms == m && upw == u && g.pxt == px) rc = launch_cnet_inst2<hid, m, u, px>(a, g, s);
+#define GH_CNT(hid, m, px) if (tape && a.hidden == hid && ms == m && g.pxt == px) rc = launch_cnet_tape<hid, m, px>(a, g, s);
+    GH_CNT(512, 1, 128) GH_CNT(512, 2, 128) GH_CNT(512, 4, 128) GH_CNT(512, 1, 64) GH_CNT(512, 2, 64) GH_CNT(512, 4, 64)
+    GH_CNT(256, 1, 128) GH_CNT(256, 2, 128) GH_CNT(256, 1, 64) GH_CNT(256, 2, 64) GH_CNT(128, 1, 128) GH_CNT(128, 1, 64)
+#undef GH_CNT
+#define GH_CN(hid, m, u, px) if (!tape && g.ng == 1 && a.hidden == hid && ms == m && upw == u && g.pxt == px) rc = launch_cnet_inst<hid, m, u, px>(a, g, s);
+#define GH_CN2(hid, m, u, px) if (!tape && g.ng == 2 && a.hidden == hid && ms == m && upw == u && g.pxt == px) rc = launch_cnet_inst2<hid, m, u, px>(a, g, s);
     GH_CN2(512, 1, 1, 64) GH_CN2(512, 2, 1, 64) GH_CN2(512, 4, 1, 64) GH_CN2(256, 1, 1, 64) GH_CN2(256, 2, 1, 64) GH_CN2(128, 1, 1, 64)
 #undef GH_CN2
     GH_CN(512, 1, 1, 128) GH_CN(512, 2, 1, 128) GH_CN(512, 4, 1, 128) GH_CN(256, 1, 1, 128) GH_CN(256, 2, 1, 128) GH_CN(256, 4, 1, 128)
@@ -1313,7 +1376,7 @@ int launch_cnet_main(const CnetArgs& a, hipStream_t s, CnetPending* out) {
 int launch_cnet_finish(const CnetArgs& a, const CnetPending& p, hipStream_t s) {
     if (a.N == 0) return GLOWHIP_OK;
     const int HW = a.H * a.W;
-    CfinArgs f{p, a.mix, a.z_out, a.z_out_bs, a.acc, a.N, a.H, a.W, HW, __builtin_ctz(a.W), (g_cnet_flags & 8) ? 0 : 1};
+    CfinArgs f{p, a.mix, a.z_out, a.z_out_bs, a.acc, a.N, a.H, a.W, HW, __builtin_ctz(a.W), (g_cnet_flags & 8) ? 0 : 1, a.tape_hout};
     const bool paired = p.mode == TAIL_AFFINE_FWD || p.mode == TAIL_AFFINE_REV;
     const int C = 2 * (paired ? p.Cout / 2 : p.Cout);
     GH_REQUIRE(a.mix.C == 0 || a.mix.C == C, "cnet: mixer channel count %d != %d", a.mix.C, C);

@@ -660,15 +660,15 @@ glowhip_plan* glowhip_plan_create(const glowhip_layer_desc* layers, int n_layers
             }
             if (L.cnet) {
                 RepackJob r0{}; r0.w = d.f0_w; r0.out_off = L.cn_w0; r0.kind = REPACK_SH2_FIRST; r0.Cin = d.C / 2; r0.Cout = d.hidden;
-                r0.K = cnet_g0(d.C / 2); r0.fold_bias = d.f0_an_bias; r0.fold_logs = d.f0_an_logs; r0.use = 1;
+                r0.K = cnet_g0(d.C / 2); r0.fold_bias = d.f0_an_bias; r0.fold_logs = d.f0_an_logs; r0.use = 3;
                 p->repack_jobs.push_back(r0);
                 RepackJob r2{}; r2.w = d.f2_w; r2.out_off = L.cn_w2; r2.kind = REPACK_SH2_GEMM; r2.Cin = d.hidden; r2.Cout = d.hidden;
-                r2.K = d.hidden; r2.fold_bias = d.f2_an_bias; r2.fold_logs = d.f2_an_logs; r2.use = 1; p->repack_jobs.push_back(r2);
+                r2.K = d.hidden; r2.fold_bias = d.f2_an_bias; r2.fold_logs = d.f2_an_logs; r2.use = 3; p->repack_jobs.push_back(r2);
                 const int ng = cnet_groups(L.Cout), cg = L.Cout / ng;       // one image per group of f.4 output channels
                 for (int gi = 0; gi < ng; ++gi) {
                     RepackJob r4{}; r4.w = d.f4_w + (size_t)gi * cg * d.hidden * 9; r4.out_off = L.cn_w4 + gi * sh2_image_bytes(d.hidden, cnet_mpad4(cg));
                     r4.kind = REPACK_SH2_TAIL; r4.Cin = d.hidden; r4.Cout = cg;
-                    r4.Kpad = cnet_mpad4(cg); r4.use = 1; p->repack_jobs.push_back(r4);
+                    r4.Kpad = cnet_mpad4(cg); r4.use = 3; p->repack_jobs.push_back(r4);
                 }
             }
             if (L.sh_tail) {

