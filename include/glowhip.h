@@ -315,7 +315,8 @@ int glowhip_plan_timing_read(glowhip_plan* plan, glowhip_timing_record* out, int
  * | 0x8000000 = the finishing step of a FlowStep runs inside the next FlowStep's k_cnet (off by default: measured slower),
  * | 0x10000000 = the finishing kernel takes its pixel chunks in block order instead of the XCD-affine order (A/B),
  * | 0x20000000 = glowhip_plan_pack entirely on the caller's stream, no side-stream fork (A/B),
- * | 0x40000000 = glowhip_glow_forward_train on the per-layer kernels instead of the taping k_cnet (A/B, parity tests).
+ * | 0x40000000 = glowhip_glow_forward_train on the per-layer kernels instead of the taping k_cnet (A/B, parity tests),
+ * | 0x80000000 = glowhip_glow_backward's input-gradient chain on the per-layer kernels instead of the backward k_cnet.
  * 0 restores automatic selection.
  * Process-wide, not thread safe: a testing hook, not part of the operator surface. */
 void glowhip_debug_force_tail_tile(int pixels_and_flags);

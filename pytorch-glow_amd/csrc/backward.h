@@ -53,7 +53,8 @@ int launch_shift_expand(const float* src, long src_bs, float* out, int N, int C,
 bool wgrad_mfma_supported(int HW, int Mpad, int Npad);
 size_t wgrad_mfma_partial_floats(int Mpad, int Npad, int N, int HW);
 int launch_wgrad_mfma(const float* A, long a_bs, const float* B, long b_bs, float* partial, float* dw, int N, int HW,
-                      int Mpad, int Npad, int Mreal, int Nreal, int mode, hipStream_t s, float sh_scale = 0.f);   // sh_scale > 0: f16-pipe kernel, gradient operand A pre-scaled by it
+                      int Mpad, int Npad, int Mreal, int Nreal, int mode, hipStream_t s, float sh_scale = 0.f,   // sh_scale > 0: f16-pipe kernel, gradient operand A pre-scaled by it
+                      double* rowsum = nullptr);   // (f16-pipe kernel) rowsum[m] += sum over all pixels of A's row m -- the bias gradient when A = g_u
 
 // one launch for all reduction-type parameter gradients of a backward sweep
 struct GradJob {
@@ -62,6 +63,11 @@ struct GradJob {
     const float* winv; int C; // out[o*C+i] = acc[o*C+i] + gsum * add_mul * winv[i*C+o]   (invconv weight)
 };
 int launch_grad_finalize_batched(const GradJob* jobs_dev, int n_jobs, const double* gsum, hipStream_t s);
+// ActNorm log-scale gradient of a convolution layer y = (conv(x, W) + b) * exp(3 logs) from its weight and bias gradients:
+//   d logs[r] = 3 sum_p g_y y = 3 sum_p g_u (u + b) = 3 (<W[r], dW[r]> + b[r] db[r]),   g_u = g_y exp(3 logs), u = conv(x, W)
+// (sum_p g_u[r][p] u[r][p] = sum_k W[r][k] sum_p g_u[r][p] x_k[p] = <W[r], dW[r]>): no pass over the activations at all.
+struct LogsJob { const float* w; const float* dw; const float* b; const double* db; float* out; int rows, K; };
+int launch_logs_from_dw_batched(const LogsJob* jobs_dev, int n_jobs, hipStream_t s);
 int launch_grad_finalize(const double* acc, float* out, int n, const double* gsum, double add_mul, hipStream_t s);
 int launch_grad_finalize_w(const double* acc, float* out, int C, const double* gsum, double hw, const float* winv,
                            hipStream_t s);

@@ -74,6 +74,27 @@ __global__ void __launch_bounds__(256) k_coupling_bwd(CouplingBwdArgs a) {
     }
 }
 
+// one wave per row: out[r] = 3 (<w[r], dw[r]> + b[r] db[r]) in fp64 (backward.h LogsJob)
+__global__ void __launch_bounds__(256) k_logs_from_dw(const LogsJob* __restrict__ jobs) {
+    const LogsJob j = jobs[blockIdx.y];
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= j.rows) return;
+    const float* w = j.w + (long)r * j.K;
+    const float* dw = j.dw + (long)r * j.K;
+    double s = 0.0;
+    for (int k = lane; k < j.K; k += 64) s += (double)w[k] * (double)dw[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if (lane == 0) j.out[r] = (float)(3.0 * (s + (double)j.b[r] * j.db[r]));
+}
+
+int launch_logs_from_dw_batched(const LogsJob* jobs_dev, int n_jobs, hipStream_t s) {
+    if (n_jobs == 0) return GLOWHIP_OK;
+    hipLaunchKernelGGL(k_logs_from_dw, dim3(128, n_jobs), dim3(256), 0, s, jobs_dev);      // (rows <= 512)
+    GH_LAUNCH_CHECK("k_logs_from_dw");
+    return GLOWHIP_OK;
+}
+
 int launch_coupling_bwd(const CouplingBwdArgs& a, hipStream_t s) {
     if (a.N == 0) return GLOWHIP_OK;
     hipLaunchKernelGGL(k_coupling_bwd, dim3(cdiv(a.HW, 256), a.Ch, a.N), dim3(256), 0, s, a);

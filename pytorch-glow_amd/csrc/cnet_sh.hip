@@ -158,10 +158,17 @@ __device__ __forceinline__ long long block_sum_ll(long long v, long long* red) {
 // PRE: the launch may finish the previous step while it builds its window (a.pre_on); without it none of that code is compiled in
 // NG: f.4 output-channel groups (compile time: with one group nothing of the group loop survives -- as a run-time count it kept
 // the h2 accumulators alive through P4 and cost the level-1 instance 88 bytes of spills)
-// TAPE: the training forward (plan_train.hip): h1 and h2 also go to memory as fp32 (N, hidden, H, W), stored from the epilogues
-// (a lane holds one pixel x 4 consecutive channels: a wave store is two 128-byte runs of one channel each); needs HW % 32 == 0
-template <int HID, int MS, int UPW, int PXT, bool PRE, int NG = 1, bool TAPE = false>
+// MODE 1 (TAPE), the training forward (plan_train.hip): h1 and h2 also go to memory as fp32 (N, hidden, H, W), stored from the
+// epilogues (a lane holds one pixel x 4 consecutive channels: a wave store is two 128-byte runs of one channel each), and their
+// signs as bit masks (a lane's 16 accumulator registers of a 32-row tile = one 16-bit word; mask[(row tile * P + pixel) * 2 + kl]).
+// MODE 2 (BWD), the input-gradient chain of the same network (it has the same shape: 3x3 Cout -> hidden with f.4's transposed
+// weights, 1x1 hidden -> hidden with f.2's, 3x3 hidden -> C/2 with f.0's): x = d L / d(f.4 output), the "activation" of the
+// first two layers is  g_u = g_h * (h > 0) * exp(3 logs)  (the scale folded into the weight image's rows, the mask from the
+// tape's bit masks), and g_u2 / g_u0 go to memory as fp32 for the weight-gradient GEMMs.  Needs HW % 32 == 0.
+template <int HID, int MS, int UPW, int PXT, bool PRE, int NG = 1, int MODE = 0>
 __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
+    constexpr bool TAPE = MODE == 1, BWD = MODE == 2, STORE = MODE != 0;
+    const long P_all = (long)a.N * g.HW;          // pixels of the batch (row stride of the bit masks)
     const bool pre_on = PRE && a.pre_on;
     constexpr int NPT = PXT / 32;                    // pixel tiles of the workgroup: 4 (128 pixels) or 2 (64 pixels)
     constexpr int ADEPTH = (HID / MS / 32) * NPT / 8 == 8 ? 1 : 2;       // prefetch distance of P2's A fragments (k-steps)
@@ -480,7 +487,7 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
         h8 hi, lo;
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            const float vv = (in && ch * 8 + q < a.Cin) ? canon_nan(v[q] * SH2_ACT_SCALE) : 0.f;
+            const float vv = (in && ch * 8 + q < a.Cin) ? canon_nan(v[q] * (STORE ? a.in_scale : SH2_ACT_SCALE)) : 0.f;
             _Float16 x0, x1;
             sh2_split(vv, x0, x1);
             hi[q] = x0; lo[q] = x1;
@@ -519,6 +526,16 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
                 for (int j = 0; j < PTSV; ++j)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc1[i][j][r] = 0.f;
+            unsigned mw1[BWD ? RT1 : 1][BWD ? PTSV : 1];     // BWD: sign words of h2 for this block, requested before its MFMAs
+            if (BWD) {
+#pragma unroll
+                for (int i = 0; i < RT1; ++i)
+#pragma unroll
+                    for (int j = 0; j < PTSV; ++j) {
+                        const long px = min(gp0 + (pt1 + sp * PTSV + j) * 32 + ml, P_all - 1);
+                        mw1[BWD ? i : 0][BWD ? j : 0] = a.mask2[((long)(hh * (HK / 32) + rt1 + i) * P_all + px) * 2 + kl];
+                    }
+            }
             // k groups of f.0 are ordered (8-channel chunk, tap), tap fastest: group gk -> chunk gk / 9, tap gk % 9 (divisions by
             // constants); groups past 9 * nchunk carry zero weights and read window offset 0.  With at most two pixel tiles the B
             // fragments of step st + 1 -- tap-shifted window addresses -- are requested while the MFMAs of step st issue.  The A
@@ -592,7 +609,10 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
             }
             // -relu (sh.h nrelu_bits), split, store into the B-operand image: a lane's 4 consecutive channels = 8 bytes per plane
 #pragma unroll
-            for (int i = 0; i < RT1; ++i)
+            for (int i = 0; i < RT1; ++i) {
+                unsigned mb[PTSV];
+#pragma unroll
+                for (int j = 0; j < PTSV; ++j) mb[j] = BWD ? mw1[i][j] : 0u;
 #pragma unroll
                 for (int gq = 0; gq < 4; ++gq) {
                     const int o = hh * HK + (rt1 + i) * 32 + 8 * gq + 4 * kl;
@@ -604,21 +624,36 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
                         h4 hi, lo;
                         f32x4_t v;
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) v[t] = nrelu_bits(fmaf(acc1[i][j][4 * gq + t], rs[t], bb[t]));
+                        for (int t = 0; t < 4; ++t) {
+                            const float tt = fmaf(acc1[i][j][4 * gq + t], rs[t], bb[t]);
+                            if (BWD) v[t] = (mb[j] >> (4 * gq + t)) & 1u ? tt : 0.f;      // (-g_u2, scaled: tables as in the forward)
+                            else v[t] = nrelu_bits(tt);
+                            if (TAPE) mb[j] |= (v[t] < 0.f ? 1u : 0u) << (4 * gq + t);
+                        }
                         sh2_split4<MIXSPLIT>(v, hi, lo);
                         _Float16* dst = hbuf + ((long)chunk * PXT + (pt1 + sp * PTSV + j) * 32 + ml) * 8 + 4 * kl;
                         *reinterpret_cast<h4*>(dst) = hi;
                         *reinterpret_cast<h4*>(dst + (long)NCH * PXT * 8) = lo;
-                        if (TAPE) {     // (with a row split every workgroup computes all of h1: each stores its own rows' share)
+                        if (STORE) {     // (with a row split every workgroup computes all of these rows: each stores its own rows' share)
                             const long px0 = gp0 + (pt1 + sp * PTSV + j) * 32;
-                            if (px0 < (long)a.N * HW && (MS == 1 || (o >= ms_row0 && o < ms_row0 + MR))) {
+                            if (px0 < P_all && (MS == 1 || (o >= ms_row0 && o < ms_row0 + MR))) {
                                 float* tb = a.tape_h1 + (((px0 >> g.lhw) * HID) << g.lhw) + (px0 & (HW - 1));
 #pragma unroll
-                                for (int t = 0; t < 4; ++t) tb[((o + t) << g.lhw) + ml] = -v[t] * SH2_ACT_INV;
+                                for (int t = 0; t < 4; ++t) tb[((o + t) << g.lhw) + ml] = -v[t] * a.out_scale;
                             }
                         }
                     }
                 }
+                if (TAPE) {
+                    const int R = hh * (HK / 32) + rt1 + i;
+#pragma unroll
+                    for (int j = 0; j < PTSV; ++j) {
+                        const long px0 = gp0 + (pt1 + sp * PTSV + j) * 32;
+                        if (px0 < P_all && (MS == 1 || (R * 32 >= ms_row0 && R * 32 < ms_row0 + MR)))
+                            a.mask1[((long)R * P_all + px0 + ml) * 2 + kl] = (unsigned short)mb[j];
+                    }
+                }
+            }
         }
     };
     auto p2_pass = [&](int hh) {
@@ -736,6 +771,21 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
     }
 
     // ---- -h2 = -relu(t2), t2 = true sum * rowscale + bias (times SH2_ACT_SCALE), in place (the accumulators hold the negated sum)
+    unsigned mw2[STORE ? RT2 : 1][STORE ? PT2 : 1];
+    if (BWD) {          // sign words of h1 for this wave's block
+#pragma unroll
+        for (int i = 0; i < RT2; ++i)
+#pragma unroll
+            for (int j = 0; j < PT2; ++j) {
+                const long px = min(gp0 + (pt2 + j) * 32 + ml, P_all - 1);
+                mw2[STORE ? i : 0][STORE ? j : 0] = a.mask1[((long)(ms_row0 / 32 + rt2 + i) * P_all + px) * 2 + kl];
+            }
+    } else if (TAPE) {
+#pragma unroll
+        for (int i = 0; i < RT2; ++i)
+#pragma unroll
+            for (int j = 0; j < PT2; ++j) mw2[STORE ? i : 0][STORE ? j : 0] = 0u;
+    }
 #pragma unroll
     for (int i = 0; i < RT2; ++i)
 #pragma unroll
@@ -746,17 +796,32 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
 #pragma unroll
             for (int j = 0; j < PT2; ++j) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) acc2[i][j][4 * gq + t] = nrelu_bits(fmaf(acc2[i][j][4 * gq + t], rs[t], bb[t]));
-                if (TAPE) {
+                for (int t = 0; t < 4; ++t) {
+                    const float tt = fmaf(acc2[i][j][4 * gq + t], rs[t], bb[t]);
+                    if (BWD) acc2[i][j][4 * gq + t] = (mw2[STORE ? i : 0][STORE ? j : 0] >> (4 * gq + t)) & 1u ? tt : 0.f;
+                    else acc2[i][j][4 * gq + t] = nrelu_bits(tt);
+                    if (TAPE) mw2[STORE ? i : 0][STORE ? j : 0] |= (acc2[i][j][4 * gq + t] < 0.f ? 1u : 0u) << (4 * gq + t);
+                }
+                if (STORE) {
                     const long px0 = gp0 + (pt2 + j) * 32;
-                    if (px0 < (long)a.N * HW) {
+                    if (px0 < P_all) {
                         float* tb = a.tape_h2 + (((px0 >> g.lhw) * HID) << g.lhw) + (px0 & (HW - 1));
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) tb[((ms_row0 + o + t) << g.lhw) + ml] = -acc2[i][j][4 * gq + t] * SH2_ACT_INV;
+                        for (int t = 0; t < 4; ++t) tb[((ms_row0 + o + t) << g.lhw) + ml] = -acc2[i][j][4 * gq + t] * a.out_scale;
                     }
                 }
             }
         }
+    if (TAPE) {
+#pragma unroll
+        for (int i = 0; i < RT2; ++i)
+#pragma unroll
+            for (int j = 0; j < PT2; ++j) {
+                const long px0 = gp0 + (pt2 + j) * 32;
+                if (px0 < P_all)
+                    a.mask2[((long)(ms_row0 / 32 + rt2 + i) * P_all + px0 + ml) * 2 + kl] = (unsigned short)mw2[STORE ? i : 0][STORE ? j : 0];
+            }
+    }
     GH_STAMP(10);
 
     if (a.y_sh) {   // testing: h2 as an (old-format) SH tensor, f.4 left to k_tail_sh
@@ -1327,11 +1392,11 @@ bool cnet_tape_supported(int Cin, int H, int W, int hidden, int Cout, int N) {
     return cnet_tape_instance(hidden, ms, upw, g.pxt, g.ng);
 }
 
-template <int HID, int MS, int PXT>
+template <int HID, int MS, int PXT, int MODE>
 static int launch_cnet_tape(const CnetArgs& a, const CnetGeo& g, hipStream_t s) {
     const size_t lds = cnet_lds_bytes(g, HID);
-    (void)hipFuncSetAttribute((const void*)k_cnet<HID, MS, 1, PXT, false, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((k_cnet<HID, MS, 1, PXT, false, 1, true>), dim3(g.tiles, MS), dim3(512), lds, s, a, g);
+    (void)hipFuncSetAttribute((const void*)k_cnet<HID, MS, 1, PXT, false, 1, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((k_cnet<HID, MS, 1, PXT, false, 1, MODE>), dim3(g.tiles, MS), dim3(512), lds, s, a, g);
     GH_LAUNCH_CHECK("k_cnet (taping)");
     return GLOWHIP_OK;
 }
@@ -1344,10 +1409,13 @@ int launch_cnet_main(const CnetArgs& a, hipStream_t s, CnetPending* out) {
     GH_REQUIRE(cnet_select(a, &g, &ms, &upw), "cnet: unsupported shape");
     GH_REQUIRE(!a.pre_on || a.pre.MS == ms, "cnet: a chained launch needs the previous step's row split");
     const bool tape = a.tape_h1 != nullptr;
-    GH_REQUIRE(!tape || (a.tape_h2 && !a.pre_on && !a.y_sh && g.HW % 32 == 0 && cnet_tape_instance(a.hidden, ms, upw, g.pxt, g.ng)),
-               "cnet: no taping instance for this launch");
+    GH_REQUIRE(!tape || (a.tape_h2 && a.mask1 && a.mask2 && !a.pre_on && !a.y_sh && g.HW % 32 == 0 &&
+                         cnet_tape_instance(a.hidden, ms, upw, g.pxt, g.ng)),
+               "cnet: no taping / backward instance for this launch");
     int rc = GLOWHIP_EINVAL;
-#define GH_CNT(hid, m, px) if (tape && a.hidden == hid && ms == m && g.pxt == px) rc = launch_cnet_tape<hid, m, px>(a, g, s);
+#define GH_CNT(hid, m, px)                                                                                     \
+    if (tape && a.hidden == hid && ms == m && g.pxt == px)                                                     \
+        rc = a.bwd ? launch_cnet_tape<hid, m, px, 2>(a, g, s) : launch_cnet_tape<hid, m, px, 1>(a, g, s);
     GH_CNT(512, 1, 128) GH_CNT(512, 2, 128) GH_CNT(512, 4, 128) GH_CNT(512, 1, 64) GH_CNT(512, 2, 64) GH_CNT(512, 4, 64)
     GH_CNT(256, 1, 128) GH_CNT(256, 2, 128) GH_CNT(256, 1, 64) GH_CNT(256, 2, 64) GH_CNT(128, 1, 128) GH_CNT(128, 1, 64)
 #undef GH_CNT
@@ -1400,6 +1468,32 @@ int launch_cnet_finish(const CnetArgs& a, const CnetPending& p, hipStream_t s) {
 #undef GH_CF
     GH_REQUIRE(launched, "cnet: no finishing kernel for row split %d", p.MS);
     GH_LAUNCH_CHECK("k_cfinish");
+    return GLOWHIP_OK;
+}
+
+// finishing step of a backward launch (k_cnet MODE 2): g[n][c][p] += out_scale * (MS partial sums + the neighbour tiles' halo rows)
+__global__ void __launch_bounds__(256) k_cbwd_finish(CnetPending p, float* __restrict__ g, long g_bs, int N, int H, int W, int HW,
+                                                     int wshift, float out_scale) {
+    const FinSrc f = fin_src(p, N, H, W, HW, wshift);
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long)N * p.Cout * HW) return;
+    const int px = (int)(e % HW);
+    const long nc = e / HW;
+    const int c = (int)(nc % p.Cout);
+    const long n = nc / p.Cout;
+    float se, so;
+    fin_gather_t<0, true>(f, n, c, px, se, so);
+    g[n * g_bs + (long)c * HW + px] += se * out_scale;
+}
+
+int launch_cnet_bwd_finish(const CnetArgs& a, const CnetPending& p, float* g, long g_bs, float out_scale, hipStream_t s) {
+    if (a.N == 0) return GLOWHIP_OK;
+    GH_REQUIRE(p.mode == TAIL_ADD_FWD, "cnet_bwd_finish: additive partial sums expected");
+    const int HW = a.H * a.W;
+    const long total = (long)a.N * p.Cout * HW;
+    hipLaunchKernelGGL(k_cbwd_finish, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p, g, g_bs, a.N, a.H, a.W, HW,
+                       __builtin_ctz(a.W), out_scale);
+    GH_LAUNCH_CHECK("k_cbwd_finish");
     return GLOWHIP_OK;
 }
 

@@ -355,6 +355,7 @@ void conv_mfma_tail_force_tile(int v) {
     plan_train_disable_sh((v & 0x800) ? 1 : 0);
     plan_pack_one_stream((v & 0x20000000) ? 1 : 0);      // bit 29: glowhip_plan_pack entirely on the caller's stream (A/B)
     plan_train_disable_cnet((v & 0x40000000) ? 1 : 0);   // bit 30: training forward on the per-layer kernels (no taping k_cnet)
+    plan_train_disable_cnet_bwd(((unsigned)v & 0x80000000u) ? 1 : 0);   // bit 31: input-gradient chain on the per-layer kernels
 }
 
 }  // namespace glowhip

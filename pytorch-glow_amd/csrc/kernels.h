@@ -92,7 +92,12 @@ struct RepackJob {
     int use;                     // who reads this image: bit 0 = inference kernels (encode/decode/glow_forward), bit 1 = training
     int transposed;              // source is the FORWARD weight (Cin,Cout,3,3) of which this is the input-gradient conv:
                                  // element (o, ci, tap) = w[ci][o][8 - tap]
+    size_t w_off;                // w == nullptr: the source is packed + w_off (a transposed copy made by launch_flipT_batched)
 };
+// dst[i][o][ks-1-tap] = src[o][i][tap] (ks = 9: 3x3 weights, 1: a plain transpose): the weight of the input-gradient convolution,
+// in the reference layout, for the SH2 image kernels of the backward k_cnet launch (plan_train.hip)
+struct FlipJob { const float* src; size_t dst_off; int O, I, ks; };
+int launch_flipT_batched(const FlipJob* jobs_dev, int n_jobs, int max_tiles, void* packed, hipStream_t s);
 // rj_dev: the repack jobs SORTED by kind group (legacy kinds | SH2_GEMM | SH2_FIRST | SH2_TAIL), n_kind[4] their counts;
 // tail_blocks: workgroups per SH2_TAIL job (8 output channels each)
 // s_legacy: the stream of the legacy-kind image kernel (the same as s, or a side stream forked from it)

@@ -128,8 +128,13 @@ __global__ void __launch_bounds__(256) k_repack_batched(const RepackJob* __restr
 //   SH2_FIRST (f.0): row o, k = (8-channel chunk, tap, 8 channels), tap fastest; same folding; j.K = G groups
 //   SH2_TAIL  (f.4): row m = tap * Cout + co (< j.Kpad = Mpad4 rows, zero beyond 9 Cout), k = input channel;
 //                    rowscale = 2^-e / 16 (undoes the activation scale as well), no bias
+__device__ __forceinline__ const float* repack_src(const RepackJob& j, const char* packed) {
+    return j.w ? j.w : reinterpret_cast<const float*>(packed + j.w_off);
+}
+
 template <int KIND>
 __device__ __forceinline__ void repack_sh2_rows(const RepackJob& j, char* packed) {
+    const float* jw = repack_src(j, packed);
     // a wave takes EIGHT consecutive rows: lane = (k group within the pass) * 8 + row, so the eight 16-byte groups of one k group
     // are 128 contiguous bytes of the image (a single row per wave wrote 16 bytes every M * 16)
     const int lane = threadIdx.x & 63, r8 = lane & 7, gl = lane >> 3;
@@ -151,7 +156,7 @@ __device__ __forceinline__ void repack_sh2_rows(const RepackJob& j, char* packed
             for (int k8 = 0; k8 < 8; ++k8) v[k8] = 0.f;
             if (!rv || gi >= ngroups) return;
             if (KIND == REPACK_SH2_GEMM) {          // contiguous in memory: two 16-byte loads when the row length allows
-                const float* src = j.w + (long)r * j.Cin + gi * 8;
+                const float* src = jw + (long)r * j.Cin + gi * 8;
                 if ((j.Cin & 3) == 0) {
                     const f32x4_t a = *reinterpret_cast<const f32x4_t*>(src), b = *reinterpret_cast<const f32x4_t*>(src + 4);
 #pragma unroll
@@ -165,12 +170,12 @@ __device__ __forceinline__ void repack_sh2_rows(const RepackJob& j, char* packed
                 if (ch < nchunk) {
 #pragma unroll
                     for (int k8 = 0; k8 < 8; ++k8)
-                        if (ch * 8 + k8 < j.Cin) v[k8] = j.w[((long)r * j.Cin + ch * 8 + k8) * 9 + tap] * fold;
+                        if (ch * 8 + k8 < j.Cin) v[k8] = jw[((long)r * j.Cin + ch * 8 + k8) * 9 + tap] * fold;
                 }
             } else if (r < 9 * j.Cout) {
                 const int tap = r / j.Cout, co = r - tap * j.Cout;
 #pragma unroll
-                for (int k8 = 0; k8 < 8; ++k8) v[k8] = j.w[((long)co * j.Cin + gi * 8 + k8) * 9 + tap];
+                for (int k8 = 0; k8 < 8; ++k8) v[k8] = jw[((long)co * j.Cin + gi * 8 + k8) * 9 + tap];
             }
         };
         // pass 1: the row's largest magnitude (the values are re-read in pass 2: they come from L2, and holding them would cost
@@ -279,7 +284,7 @@ __device__ __forceinline__ void repack_sh2_first(const RepackJob& j, char* packe
     const int nchunk = (j.Cin + 7) / 8;
     for (int r = blockIdx.x * 256 + threadIdx.x; r < M; r += gridDim.x * 256) {
         const float fold = j.fold_logs ? expf(j.fold_logs[r] * LOGSCALE) : 1.f;
-        const float* row = j.w + (long)r * j.Cin * 9;
+        const float* row = repack_src(j, packed) + (long)r * j.Cin * 9;
         float mx = 0.f;
         for (int ch = 0; ch < nchunk; ++ch) {
             float b[72];
@@ -327,7 +332,7 @@ __device__ __forceinline__ void repack_sh2_tail(const RepackJob& j, char* packed
     for (int co0 = blockIdx.x * 8; co0 < j.Cout; co0 += gridDim.x * 8) {
         const int co = co0 + r8;
         const bool rv = co < j.Cout;
-        const float* row = j.w + (long)(rv ? co : 0) * j.Cin * 9;
+        const float* row = repack_src(j, packed) + (long)(rv ? co : 0) * j.Cin * 9;
         float mx[9];
 #pragma unroll
         for (int t = 0; t < 9; ++t) mx[t] = 0.f;
@@ -395,6 +400,37 @@ __global__ void __launch_bounds__(256) k_repack_sh2_batched(const RepackJob* __r
     if (KIND == REPACK_SH2_GEMM) repack_sh2_rows<REPACK_SH2_GEMM>(j, packed);
     else if (KIND == REPACK_SH2_FIRST) repack_sh2_first(j, packed);
     else repack_sh2_tail(j, packed);
+}
+
+// dst[i][o][ks-1-tap] = src[o][i][tap]: a workgroup moves a 32 (o) x 32 (i) tile through LDS -- reads are runs of 32 ks floats of
+// one source row, writes runs of 32 ks floats of one destination row
+__global__ void __launch_bounds__(256) k_flipT_batched(const FlipJob* __restrict__ jobs, char* packed) {
+    __shared__ float tile[32][32 * 9 + 1];
+    const FlipJob j = jobs[blockIdx.y];
+    const int ti = (j.I + 31) / 32, to = (j.O + 31) / 32;
+    if ((int)blockIdx.x >= ti * to) return;
+    const int o0 = (blockIdx.x / ti) * 32, i0 = (blockIdx.x % ti) * 32;
+    const int ks = j.ks, run = 32 * ks;
+    float* dst = reinterpret_cast<float*>(packed + j.dst_off);
+    for (int e = threadIdx.x; e < 32 * run; e += 256) {
+        const int ol = e / run, r = e - ol * run;
+        const int o = o0 + ol, i = i0 + r / ks;
+        tile[ol][r] = (o < j.O && i < j.I) ? j.src[((long)o * j.I + i0) * ks + r] : 0.f;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 32 * run; e += 256) {
+        const int il = e / run, r = e - il * run;
+        const int ol = r / ks, tap = r - ol * ks;
+        const int i = i0 + il, o = o0 + ol;
+        if (i < j.I && o < j.O) dst[((long)i * j.O + o0) * ks + r] = tile[ol][il * ks + (ks - 1 - tap)];
+    }
+}
+
+int launch_flipT_batched(const FlipJob* jobs_dev, int n_jobs, int max_tiles, void* packed, hipStream_t s) {
+    if (n_jobs == 0) return GLOWHIP_OK;
+    hipLaunchKernelGGL(k_flipT_batched, dim3(max_tiles, n_jobs), dim3(256), 0, s, jobs_dev, (char*)packed);
+    GH_LAUNCH_CHECK("k_flipT_batched");
+    return GLOWHIP_OK;
 }
 
 int launch_pack_batched(const ScaleJob* sj_dev, int n_scale, const RepackJob* rj_dev, const int* n_kind, int tail_blocks, void* packed,

@@ -589,6 +589,16 @@ glowhip_plan* glowhip_plan_create(const glowhip_layer_desc* layers, int n_layers
                 L.cn_w2 = take(off, sh2_image_bytes(d.hidden, d.hidden));
                 L.cn_w4 = take(off, cnet_w4_bytes(d.hidden, L.Cout));
                 p->max_hidden = std::max(p->max_hidden, (long)cnet_scratch_floats_per_sample(H, W, L.Cout));
+                // the input-gradient chain on the same kernel: f.4^T is its first layer (Cin = Cout), f.0^T its last (Cout = C / 2)
+                L.cnet_bwd = d.hidden <= 512 && cnet_groups(C / 2) == 1 && cnet_supported(L.Cout, H, W, d.hidden, C / 2);
+                if (L.cnet_bwd) {
+                    L.cb_w0 = take(off, sh2_image_bytes(cnet_g0(L.Cout) * 8, d.hidden));
+                    L.cb_w2 = take(off, sh2_image_bytes(d.hidden, d.hidden));
+                    L.cb_w4 = take(off, cnet_w4_bytes(d.hidden, C / 2));
+                    L.wt4 = take(off, (size_t)L.Cout * d.hidden * 9 * 4);
+                    L.wt2 = take(off, (size_t)d.hidden * d.hidden * 4);
+                    L.wt0 = take(off, (size_t)d.hidden * (C / 2) * 9 * 4);
+                }
             }
             if (L.mfma_last) L.f4_wp = take(off, conv_mfma_tail_packed_bytes(d.hidden, L.Cout));
             L.wide_last = !L.mfma_last && conv_mfma_wide_supported(d.hidden, H, W, L.Cout, 3);
@@ -671,6 +681,20 @@ glowhip_plan* glowhip_plan_create(const glowhip_layer_desc* layers, int n_layers
                     r4.Kpad = cnet_mpad4(cg); r4.use = 3; p->repack_jobs.push_back(r4);
                 }
             }
+            if (L.cnet_bwd) {      // (training only) transposed copies, then the same three image kinds over them
+                const int Ch = d.C / 2;
+                p->flip_jobs.push_back(FlipJob{d.f4_w, L.wt4, L.Cout, d.hidden, 9});     // wt4[k][co][8 - tap] = W4[co][k][tap]
+                p->flip_jobs.push_back(FlipJob{d.f2_w, L.wt2, d.hidden, d.hidden, 1});   // wt2[i][o] = W2[o][i]
+                p->flip_jobs.push_back(FlipJob{d.f0_w, L.wt0, d.hidden, Ch, 9});         // wt0[ci][k][8 - tap] = W0[k][ci][tap]
+                p->flip_tiles = std::max(p->flip_tiles, ((d.hidden + 31) / 32) * ((std::max(d.hidden, L.Cout) + 31) / 32));
+                RepackJob r0{}; r0.w = nullptr; r0.w_off = L.wt4; r0.out_off = L.cb_w0; r0.kind = REPACK_SH2_FIRST; r0.Cin = L.Cout; r0.Cout = d.hidden;
+                r0.K = cnet_g0(L.Cout); r0.fold_bias = nullptr; r0.fold_logs = d.f2_an_logs; r0.use = 2;      // g_u2 = g_h2 (h2 > 0) exp(3 logs2)
+                p->repack_jobs.push_back(r0);
+                RepackJob r2{}; r2.w = nullptr; r2.w_off = L.wt2; r2.out_off = L.cb_w2; r2.kind = REPACK_SH2_GEMM; r2.Cin = d.hidden; r2.Cout = d.hidden;
+                r2.K = d.hidden; r2.fold_bias = nullptr; r2.fold_logs = d.f0_an_logs; r2.use = 2; p->repack_jobs.push_back(r2);
+                RepackJob r4{}; r4.w = nullptr; r4.w_off = L.wt0; r4.out_off = L.cb_w4; r4.kind = REPACK_SH2_TAIL; r4.Cin = d.hidden; r4.Cout = Ch;
+                r4.Kpad = cnet_mpad4(Ch); r4.use = 2; p->repack_jobs.push_back(r4);
+            }
             if (L.sh_tail) {
                 RepackJob r{}; r.w = d.f4_w; r.out_off = L.f4_sh; r.kind = REPACK_SH_TAIL; r.Cin = d.hidden; r.Cout = L.Cout;
                 r.Kpad = tail_sh_mpad(d.hidden, d.H, d.W, L.Cout, &r.MT); r.use = L.cnet ? 8 : 1; p->repack_jobs.push_back(r);
@@ -706,6 +730,7 @@ glowhip_plan* glowhip_plan_create(const glowhip_layer_desc* layers, int n_layers
     p->prep_off = take(off, p->prep_jobs.size() * sizeof(StepPrepJob));
     p->scale_off = take(off, p->scale_jobs.size() * sizeof(ScaleJob));
     p->repack_off = take(off, p->repack_jobs.size() * sizeof(RepackJob));
+    p->flip_off = take(off, p->flip_jobs.size() * sizeof(FlipJob));
     p->packed_bytes = align_up(off, 256);
     return p;
 }
@@ -871,7 +896,8 @@ int glowhip_plan_pack_for(glowhip_plan* plan, void* packed, size_t packed_bytes,
     if (plan->tables_in != packed || plan->tables_use != use) {
         if (!upload(plan->prep_off, plan->prep_jobs.data(), plan->prep_jobs.size() * sizeof(StepPrepJob)) ||
             !upload(plan->scale_off, plan->scale_jobs.data(), plan->scale_jobs.size() * sizeof(ScaleJob)) ||
-            !upload(plan->repack_off, plan->repack_sel.data(), plan->repack_sel.size() * sizeof(RepackJob))) {
+            !upload(plan->repack_off, plan->repack_sel.data(), plan->repack_sel.size() * sizeof(RepackJob)) ||
+            !upload(plan->flip_off, plan->flip_jobs.data(), plan->flip_jobs.size() * sizeof(FlipJob))) {
             set_error("plan_pack: hipMemcpyAsync of the job tables failed");
             return GLOWHIP_ELAUNCH;
         }
@@ -900,6 +926,8 @@ int glowhip_plan_pack_for(glowhip_plan* plan, void* packed, size_t packed_bytes,
             return GLOWHIP_ELAUNCH;
         }
     }
+    if (use & GLOWHIP_PACK_TRAINING)      // transposed weight copies for the backward k_cnet images (read by the image kernels below)
+        GH_TRY(launch_flipT_batched(at<FlipJob>(packed, plan->flip_off), (int)plan->flip_jobs.size(), plan->flip_tiles, packed, s));
     GH_TRY(launch_pack_batched(at<ScaleJob>(packed, plan->scale_off), (int)plan->scale_jobs.size(),
                                at<RepackJob>(packed, plan->repack_off), n_kind, tail_blocks, packed, s, side));
     if (side != s) {

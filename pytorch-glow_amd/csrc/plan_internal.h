@@ -29,6 +29,9 @@ struct LayerPlan {
     bool sh_f02 = false;                       // f.0 + f.2 as one kernel (f02_sh.hip), h1 never written
     bool sh_tail = false; size_t f4_sh = 0;   // f.2 writes h2 as an SH tensor, f.4 + coupling on tail_sh.hip
     bool cnet = false; size_t cn_w0 = 0, cn_w2 = 0, cn_w4 = 0;   // whole coupling network as one kernel (cnet_sh.hip), SH2 images
+    // the input-gradient chain as one k_cnet launch (MODE 2): SH2 images of the transposed weights (cb_w0: f.4^T as the 3x3 first
+    // layer, cb_w2: f.2^T, cb_w4: f.0^T as the 3x3 last layer) and the transposed fp32 copies they are built from (wt4 / wt2 / wt0)
+    bool cnet_bwd = false; size_t cb_w0 = 0, cb_w2 = 0, cb_w4 = 0, wt4 = 0, wt2 = 0, wt0 = 0;
     bool wide_last = false; size_t f4_wt = 0;   // f.4 on k_conv_wide<3> (+ separate coupling tail): levels no tail kernel takes (4x4 pixels)
     bool first_halo = false;  // f.0 on k_conv_first (stationary pixel window) instead of k_conv_wide<3>
     size_t f0_init = 0;       // data-dependent init pass: PLAIN K-major image of f.0 for k_conv_wide<3> (the k_conv_first image has
@@ -51,6 +54,7 @@ struct glowhip_plan {
     std::vector<StepPrepJob> prep_jobs;
     std::vector<ScaleJob> scale_jobs;
     std::vector<RepackJob> repack_jobs;
+    std::vector<FlipJob> flip_jobs; int flip_tiles = 1; size_t flip_off = 0;
     std::vector<RepackJob> repack_sel;    // the subset selected by the last glowhip_plan_pack_for (kept alive for the async copy)
     size_t prep_off = 0, scale_off = 0, repack_off = 0;
     // glowhip_plan_pack forks onto a side stream what the first kernels of a forward do not wait for: the round-1 / fp32 weight images
@@ -65,6 +69,7 @@ struct glowhip_plan {
     long max_chw = 0;      // max over layer inputs/outputs of C*H*W
     long max_hidden = 0;   // max over steps of max(hidden, Cout) * H*W
     int n_split = 0;
+    std::vector<glowhip::LogsJob> logs_jobs;   // the same for the log-scale gradients derived from dW / db (backward.h)
     std::vector<glowhip::GradJob> grad_jobs;   // host copy of the last backward's finalize table (kept alive for the async copy)
     bool rng_on = false; unsigned long long rng_seed = 0, rng_calls = 0;   // in-kernel dequantisation noise (glowhip_plan_set_dequant_rng)
     std::vector<std::pair<int, hipEvent_t>> bwd_marks;   // (layer index, event): glowhip_plan_backward_marks

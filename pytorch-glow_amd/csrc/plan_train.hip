@@ -17,7 +17,7 @@ using namespace glowhip;
 
 namespace glowhip {
 
-struct TapeLayer { size_t out = 0, h1 = 0, h2 = 0, hout = 0; };
+struct TapeLayer { size_t out = 0, h1 = 0, h2 = 0, hout = 0, m1 = 0, m2 = 0; };   // m1 / m2: sign bits of h1 / h2 (k_cnet MODE 1)
 
 static size_t tape_layout(const glowhip_plan* p, int N, std::vector<TapeLayer>* tl) {
     size_t off = 0;
@@ -34,6 +34,10 @@ static size_t tape_layout(const glowhip_plan* p, int N, std::vector<TapeLayer>* 
             t.h1 = take(off, (size_t)N * d.hidden * hw * 4);
             t.h2 = take(off, (size_t)N * d.hidden * hw * 4);
             t.hout = take(off, (size_t)N * L.Cout * hw * 4);
+            if (L.cnet) {
+                t.m1 = take(off, (size_t)N * d.hidden * hw / 8);
+                t.m2 = take(off, (size_t)N * d.hidden * hw / 8);
+            }
         } else {
             t.out = take(off, (size_t)N * (d.C / 2) * hw * 4);
             t.hout = take(off, (size_t)N * d.C * hw * 4);
@@ -50,6 +54,7 @@ struct TrainWs {
     float* gsh;                   // split-half copy of a hidden-layer gradient (input of the f16-pipe dgrad GEMM) / of h1 (forward)
     float* col; float* partial;   // shift-expanded small operand / split-K partial tiles of the MFMA weight gradients
     GradJob* jobs;                // device copy of the finalize job table (<= 9 per layer)
+    LogsJob* ljobs;               // ... and of the log-scale job table (<= 2 per layer)
     size_t dacc_doubles;
 };
 
@@ -92,6 +97,17 @@ void plan_train_disable_cnet(int off) { g_train_cnet = off == 0; }
 
 // Does FlowStep L run its training forward as the product path's two launches -- k_cnet storing h1 / h2 from its epilogues, the
 // finishing kernel storing hout and the step output (cnet_sh.hip, TAPE)?  `scratch_floats`: room for the partial sums.
+static bool tape_cnet(const glowhip_plan* p, const LayerPlan& L, int N, size_t scratch_floats);
+static bool g_train_cnet_bwd = true;   // testing hook: 0 = the input-gradient chain on the per-layer kernels
+void plan_train_disable_cnet_bwd(int off) { g_train_cnet_bwd = off == 0; }
+// ... and its input-gradient chain as one backward k_cnet launch?  Needs the taping forward (the sign bits) and all of the
+// coupling network's weight gradients requested (the log-scale gradients are derived from them).
+static bool bwd_cnet(const glowhip_plan* p, const LayerPlan& L, const glowhip_layer_grads& G, int N, size_t scratch_floats) {
+    const glowhip_layer_desc& d = L.d;
+    return g_train_cnet_bwd && L.cnet_bwd && tape_cnet(p, L, N, scratch_floats) && G.f0_w && G.f2_w && G.f4_w &&
+           cnet_tape_supported(L.Cout, d.H, d.W, d.hidden, d.C / 2, N) &&
+           cnet_scratch_floats(N, d.H, d.W, d.C / 2) <= scratch_floats;
+}
 static bool tape_cnet(const glowhip_plan* p, const LayerPlan& L, int N, size_t scratch_floats) {
     const glowhip_layer_desc& d = L.d;
     return g_train_cnet && train_sh_enabled(p) && d.kind == GLOWHIP_LAYER_FLOWSTEP && L.cnet && d.C <= 96 &&
@@ -131,8 +147,9 @@ static size_t train_ws_layout(const glowhip_plan* p, int N, void* base, TrainWs*
     wgrad_scratch_floats(p, N, &colf, &partf);
     const size_t o_col = take(off, colf * 4), o_part = take(off, partf * 4);
     const size_t o_jobs = take(off, p->layers.size() * 9 * sizeof(GradJob));
+    const size_t o_ljobs = take(off, p->layers.size() * 2 * sizeof(LogsJob));
     if (w && base) {
-        w->col = at<float>(base, o_col); w->partial = at<float>(base, o_part); w->jobs = at<GradJob>(base, o_jobs);
+        w->col = at<float>(base, o_col); w->partial = at<float>(base, o_part); w->jobs = at<GradJob>(base, o_jobs); w->ljobs = at<LogsJob>(base, o_ljobs);
         w->acc = at<unsigned long long>(base, o_acc); w->gld = at<float>(base, o_gld); w->gsum = at<double>(base, o_gsum);
         w->gA = at<float>(base, o_gA); w->gB = at<float>(base, o_gB); w->gh1 = at<float>(base, o_h1);
         w->gh2 = at<float>(base, o_h2); w->gpre = at<float>(base, o_gpre); w->wT = at<float>(base, o_wT);
@@ -188,6 +205,8 @@ static int forward_train(glowhip_plan* p, const void* packed, const float* x, co
                 c.x = dst; c.x_bs = chw; c.z_in = dst; c.z_in_bs = chw;
                 c.z_out = dst; c.z_out_bs = chw;
                 c.tape_h1 = h1; c.tape_h2 = h2; c.tape_hout = hout;
+                c.mask1 = at<unsigned short>(tape, tl[li].m1); c.mask2 = at<unsigned short>(tape, tl[li].m2);
+                c.in_scale = SH2_ACT_SCALE; c.out_scale = SH2_ACT_INV;
                 if (li + 1 < nl) {
                     const LayerPlan& Ln = p->layers[li + 1];
                     const glowhip_layer_desc& dn = Ln.d;
@@ -311,6 +330,7 @@ static int backward_sweep(glowhip_plan* p, const void* packed, const float* x_in
     const int nl = (int)p->layers.size();
     std::vector<GradJob>& jobs = p->grad_jobs;
     jobs.clear();
+    p->logs_jobs.clear();
     std::vector<size_t> acc_base(nl, 0);
     {
         size_t o = 0;
@@ -358,6 +378,46 @@ static int backward_sweep(glowhip_plan* p, const void* packed, const float* x_in
             GH_TRY(launch_coupling_bwd(cb, s));
             // (b) f.4: weight gradient, then input gradient -> g_h2 (raw), then ReLU/ActNorm of f.2
             const bool fastw = wgrad_fast(L);
+            if (fastw && bwd_cnet(p, L, G, N, (size_t)N * p->max_hidden)) {
+                // The input-gradient chain g_pre -> g_u2 -> g_u0 -> d y1 as ONE k_cnet launch (MODE 2, cnet_sh.hip) on the transposed
+                // weight images, the ReLU masks from the tape's sign bits; the bias gradients are row sums inside the weight-gradient
+                // GEMMs that read g_u2 / g_u0 anyway, the log-scale gradients follow from dW and db (backward.h LogsJob).
+                const int m4 = round_up(L.Cout * 9, 128), n0 = round_up(Ch * 9, 64);
+                GH_TRY(launch_shift_expand(w.gpre, (long)L.Cout * HW, w.col, N, L.Cout, d.H, d.W, m4, -1, s));
+                GH_TRY(launch_wgrad_mfma(w.col, (long)m4 * HW, h2, (long)hid * HW, w.partial, G.f4_w, N, HW, m4, hid,
+                                         L.Cout * 9, hid, 1, s, sh_grad_scale));
+                CnetArgs c{};
+                c.w0 = at<char>(packed, L.cb_w0); c.w2 = at<char>(packed, L.cb_w2); c.w4 = at<char>(packed, L.cb_w4);
+                c.N = N; c.Cin = L.Cout; c.H = d.H; c.W = d.W; c.hidden = hid; c.Cout = Ch;
+                c.scratch = w.gsh; c.mode = TAIL_ADD_FWD;
+                c.x = w.gpre; c.x_bs = (long)L.Cout * HW; c.z_in = w.gpre; c.z_in_bs = (long)L.Cout * HW;
+                c.tape_h1 = w.gh2; c.tape_h2 = w.gh1;
+                c.mask1 = const_cast<unsigned short*>(at<unsigned short>(tape, tl[li].m1));
+                c.mask2 = const_cast<unsigned short*>(at<unsigned short>(tape, tl[li].m2));
+                c.in_scale = SH2_ACT_SCALE * sh_grad_scale; c.out_scale = 1.0f / c.in_scale; c.bwd = 1;
+                CnetPending pend{};
+                count_launch(p, "k_cnet(bwd)");
+                GH_TRY(launch_cnet_main(c, s, &pend));
+                GH_TRY(launch_cnet_bwd_finish(c, pend, g, chw, 1.0f / sh_grad_scale, s));
+                GH_TRY(launch_wgrad_mfma(w.gh2, (long)hid * HW, h1, (long)hid * HW, w.partial, G.f2_w, N, HW, hid, hid, hid, hid,
+                                         0, s, sh_grad_scale, a2b));
+                GH_TRY(launch_shift_expand(out, chw, w.col, N, Ch, d.H, d.W, n0, +1, s));
+                GH_TRY(launch_wgrad_mfma(w.gh1, (long)hid * HW, w.col, (long)n0 * HW, w.partial, G.f0_w, N, HW, hid, n0, hid,
+                                         Ch * 9, 0, s, sh_grad_scale, a0b));
+                if (G.f2_an_logs) p->logs_jobs.push_back(LogsJob{d.f2_w, G.f2_w, d.f2_an_bias, a2b, G.f2_an_logs, hid, hid});
+                if (G.f0_an_logs) p->logs_jobs.push_back(LogsJob{d.f0_w, G.f0_w, d.f0_an_bias, a0b, G.f0_an_logs, hid, Ch * 9});
+                ChanMixBwdArgs mb{xin, chw, g, g, chw, d.an_bias, at<float>(packed, L.an_scale),
+                                  d.permutation == GLOWHIP_PERM_INVCONV ? d.invconv_w : nullptr,
+                                  d.permutation == GLOWHIP_PERM_GATHER ? d.perm_idx_inv : nullptr, aW, aAb, aAl, N, d.C, HW};
+                GH_TRY(launch_chanmix_bwd(mb, s));
+                if (d.permutation == GLOWHIP_PERM_INVCONV) fin(aW, G.invconv_w, d.C * d.C, (double)HW, at<float>(packed, L.winv), d.C);
+                fin(aAb, G.an_bias, d.C, 0.0);
+                fin(aAl, G.an_logs, d.C, 3.0 * HW);
+                fin(a0b, G.f0_an_bias, hid, 0.0);
+                fin(a2b, G.f2_an_bias, hid, 0.0);
+                fin(a4b, G.f4_bias, L.Cout, 0.0); fin(a4l, G.f4_logs, L.Cout, 0.0);
+                continue;
+            }
             if (fastw) {   // dW4[o][i][tap] = sum_p g_pre[o][p - d(tap)] * h2[i][p]
                 const int m4 = round_up(L.Cout * 9, 128);
                 GH_TRY(launch_shift_expand(w.gpre, (long)L.Cout * HW, w.col, N, L.Cout, d.H, d.W, m4, -1, s));
@@ -452,6 +512,13 @@ static int backward_sweep(glowhip_plan* p, const void* packed, const float* x_in
             return GLOWHIP_ELAUNCH;
         }
         GH_TRY(launch_grad_finalize_batched(w.jobs, (int)jobs.size(), w.gsum, s));
+    }
+    if (!p->logs_jobs.empty()) {      // log-scale gradients of the layers whose input-gradient chain ran as one k_cnet launch
+        if (hipMemcpyAsync(w.ljobs, p->logs_jobs.data(), p->logs_jobs.size() * sizeof(LogsJob), hipMemcpyHostToDevice, s) != hipSuccess) {
+            set_error("backward: hipMemcpyAsync of the log-scale job table failed");
+            return GLOWHIP_ELAUNCH;
+        }
+        GH_TRY(launch_logs_from_dw_batched(w.ljobs, (int)p->logs_jobs.size(), s));
     }
     return GLOWHIP_OK;
 }

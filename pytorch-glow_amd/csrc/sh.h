@@ -229,7 +229,16 @@ struct CnetArgs {
     // when it mixes out of place (z_out != z_in), ALSO writes the coupled z2 back into z_in -- which then holds this step's
     // output (y1, z2'), the tensor the backward sweep reads.
     float* tape_h1; float* tape_h2; float* tape_hout;
+    unsigned short* mask1; unsigned short* mask2;     // sign bits of h1 / h2: [hidden / 32][N H W][2] 16-bit words (k_cnet MODE 1 writes, 2 reads)
+    float in_scale, out_scale;                        // taping / backward launches: window values * in_scale, stored tensors * out_scale
+    // ---- backward launch (bwd = 1; plan_train.hip): x = d L / d(f.4 output) (N, Cin = f.4's Cout, H, W); w0 / w2 / w4 = the SH2
+    // images of f.4's, f.2's, f.0's TRANSPOSED weights (exp(3 logs) of f.2 / f.0 folded into the first two); tape_h1 <- g_u2,
+    // tape_h2 <- g_u0 (fp32 (N, hidden, H, W)); the partial sums in `scratch` are d L / d y1's contribution (Cout = C/2 channels),
+    // added into the gradient by launch_cnet_bwd_finish
+    int bwd;
 };
+// g[n][c][p] += out_scale * (sum of the partial sums k_cnet left in a.scratch), c < a.Cout: the finishing step of a backward launch
+int launch_cnet_bwd_finish(const CnetArgs& a, const CnetPending& p, float* g, long g_bs, float out_scale, hipStream_t s);
 int launch_cnet_main(const CnetArgs& a, hipStream_t s, CnetPending* out);            // k_cnet only; *out describes its partial sums
 int launch_cnet_finish(const CnetArgs& a, const CnetPending& p, hipStream_t s);     // the finishing kernel for those sums
 int launch_cnet(const CnetArgs& a, hipStream_t s);                                   // both

@@ -160,7 +160,7 @@ __global__ void __launch_bounds__(256, 2)      // two workgroups per CU: at 269 
                                                // wave per SIMD and every k-tile waited out its own HBM round trip (7.4 k cycles per
                                                // k-tile against 768 of MFMA work)
 k_wgrad_gemm_sh(const float* __restrict__ A, long a_bs, const float* __restrict__ B, long b_bs, float* __restrict__ partial,
-                int HW, int Mpad, int Npad, int ktiles_total, int ktiles_per_split, float a_scale) {
+                int HW, int Mpad, int Npad, int ktiles_total, int ktiles_per_split, float a_scale, double* __restrict__ rowsum) {
     constexpr int BM = 128, BK = 32;
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
     constexpr int A_F4 = BM * BK / 4 / 256, B_F4 = BN * BK / 4 / 256;   // float4 per thread per K-tile (4, 4|2)
@@ -192,7 +192,12 @@ k_wgrad_gemm_sh(const float* __restrict__ A, long a_bs, const float* __restrict_
 #pragma unroll
         for (int j = 0; j < B_F4; ++j) rb[j] = *reinterpret_cast<const f32x4*>(bp + j * 4);
     };
+    float rsum = 0.f;                  // rowsum != null: sum over this slice's pixels of the thread's A row (the bias gradient)
     auto store_tile = [&](int buf) {   // 8 consecutive pixels of a row = one fragment group; lanes = consecutive rows: conflict-free
+        if (rowsum) {
+#pragma unroll
+            for (int j = 0; j < A_F4; ++j) rsum += (ra[j][0] + ra[j][1]) + (ra[j][2] + ra[j][3]);
+        }
 #pragma unroll
         for (int g2 = 0; g2 < A_F4 / 2; ++g2) {
             h8 hi, lo;
@@ -257,6 +262,12 @@ k_wgrad_gemm_sh(const float* __restrict__ A, long a_bs, const float* __restrict_
             __syncthreads();
         }
     }
+    if (rowsum && tile_n == 0) {       // (uniform per workgroup) the two pixel halves of a row, then one fp64 atomic per row and slice
+        float* rs_sm = reinterpret_cast<float*>(&As[0][0][0][0][0]);
+        if (a_q == 1) rs_sm[a_row] = rsum;
+        __syncthreads();
+        if (a_q == 0 && kt0 < kt1) atomicAdd(rowsum + tile_m * BM + a_row, (double)(rsum + rs_sm[a_row]));
+    }
     const float inv = 1.0f / a_scale;
     float* out = partial + ((long)split * Mpad + tile_m * BM) * Npad + tile_n * BN;
 #pragma unroll
@@ -314,7 +325,8 @@ size_t wgrad_mfma_partial_floats(int Mpad, int Npad, int N, int HW) {
 }
 
 int launch_wgrad_mfma(const float* A, long a_bs, const float* B, long b_bs, float* partial, float* dw, int N, int HW,
-                      int Mpad, int Npad, int Mreal, int Nreal, int mode, hipStream_t s, float sh_scale) {
+                      int Mpad, int Npad, int Mreal, int Nreal, int mode, hipStream_t s, float sh_scale, double* rowsum) {
+    GH_REQUIRE(!rowsum || sh_scale > 0.f, "wgrad_mfma: row sums only on the split-half kernel");
     GH_REQUIRE(wgrad_mfma_supported(HW, Mpad, Npad), "wgrad_mfma: unsupported shape");
     if (N == 0) return GLOWHIP_OK;
     const bool bn128 = Npad % 128 == 0;
@@ -325,10 +337,10 @@ int launch_wgrad_mfma(const float* A, long a_bs, const float* B, long b_bs, floa
     splits = (total + per - 1) / per;
     if (sh_scale > 0.f && bn128)       // f16 matrix pipe, split-half operands (sh_scale = power-of-two pre-scale of the gradient operand)
         hipLaunchKernelGGL(k_wgrad_gemm_sh<128>, dim3(tiles * splits), dim3(256), 0, s, A, a_bs, B, b_bs, partial, HW, Mpad, Npad,
-                           total, per, sh_scale);
+                           total, per, sh_scale, rowsum);
     else if (sh_scale > 0.f)
         hipLaunchKernelGGL(k_wgrad_gemm_sh<64>, dim3(tiles * splits), dim3(256), 0, s, A, a_bs, B, b_bs, partial, HW, Mpad, Npad,
-                           total, per, sh_scale);
+                           total, per, sh_scale, rowsum);
     else if (bn128)
         hipLaunchKernelGGL(k_wgrad_gemm<128>, dim3(tiles * splits), dim3(256), 0, s, A, a_bs, B, b_bs, partial, HW, Mpad, Npad,
                            total, per);

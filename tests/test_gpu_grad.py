@@ -282,11 +282,13 @@ def test_tiny_gradients_behind_near_zero_tail_weights_purely_relative():
     assert checked == 3 * K * 6
 
 
-def test_training_forward_is_the_taping_cnet_and_agrees_with_the_per_layer_kernels():
-    """The training forward of a config-B FlowStep is the product path's two launches (k_cnet with TAPE = true storing h1 / h2
-    from its epilogues, the finishing kernel storing hout, the step output and the next step's mixer output): asserted from the
-    launch counters, and compared -- z, nll, every gradient -- with the same step on the per-layer kernels (debug flag
-    0x40000000: k_conv_first + k_gemm_sh + k_conv_tail_dma), which the oracle tests above pin separately."""
+def test_training_step_runs_on_k_cnet_and_agrees_with_the_per_layer_kernels():
+    """The training forward of a config-B FlowStep is the product path's two launches (k_cnet MODE 1 storing h1 / h2 and their
+    sign bits from its epilogues, the finishing kernel storing hout, the step output and the next step's mixer output), its
+    input-gradient chain ONE k_cnet launch on the transposed weight images (MODE 2: ReLU masks from the sign bits, g_u2 / g_u0
+    stored for the weight-gradient GEMMs, bias gradients as row sums inside those GEMMs, log-scale gradients from dW and db):
+    asserted from the launch counters, and compared -- z, nll, every gradient -- with the same step on the per-layer kernels
+    (debug flags 0x40000000: forward, 0x80000000: backward), which the oracle tests above pin separately."""
     from pytorch_glow_amd import _lib
     K, batch = 2, 4
     cfg = O.default_cfg(K=K, batch=batch)
@@ -297,8 +299,8 @@ def test_training_forward_is_the_taping_cnet_and_agrees_with_the_per_layer_kerne
     sd = O.glow_init_actnorm(x, noise, sd, cfg)
     res = {}
     try:
-        for flag in (0x40000000, 0):
-            _lib.lib().glowhip_debug_force_tail_tile(flag)
+        for flag in (0x40000000, 0x80000000, 0):
+            _lib.lib().glowhip_debug_force_tail_tile(flag - (1 << 32) if flag >= (1 << 31) else flag)
             glow = G.Glow(hps_for(cfg, batch))
             glow.load_state_dict(sd)
             glow.set_actnorm_inited()
@@ -311,13 +313,17 @@ def test_training_forward_is_the_taping_cnet_and_agrees_with_the_per_layer_kerne
                                                                  if p.grad is not None}, counts)
     finally:
         _lib.lib().glowhip_debug_force_tail_tile(0)
-    (z0, n0, g0, c0), (z1, n1, g1, c1) = res[0x40000000], res[0]
-    assert c0.get("k_cnet(tape)", 0) == 0 and c1.get("k_cnet(tape)", 0) == 3 * K, (c0, c1)
-    assert (z1 - z0).abs().max().item() <= 2e-5 and (n1 - n0).abs().max().item() <= 2e-6
-    for name, a in g0.items():
-        scale = a.abs().max().item()
-        err = (g1[name] - a).abs()
-        assert err.pow(2).mean().sqrt().item() <= 1e-3 * scale + 1e-9 and err.max().item() <= 0.05 * scale + 1e-8, (name, scale, err.max().item())
+    z0, n0, g0, c0 = res[0x40000000]
+    assert c0.get("k_cnet(tape)", 0) == 0 and c0.get("k_cnet(bwd)", 0) == 0, c0
+    for flag, want_bwd in ((0x80000000, 0), (0, 3 * K)):
+        z1, n1, g1, c1 = res[flag]
+        assert c1.get("k_cnet(tape)", 0) == 3 * K and c1.get("k_cnet(bwd)", 0) == want_bwd, (hex(flag), c1)
+        assert (z1 - z0).abs().max().item() <= 2e-5 and (n1 - n0).abs().max().item() <= 2e-6
+        for name, a in g0.items():
+            scale = a.abs().max().item()
+            err = (g1[name] - a).abs()
+            assert err.pow(2).mean().sqrt().item() <= 1e-3 * scale + 1e-9 and err.max().item() <= 0.05 * scale + 1e-8, \
+                (hex(flag), name, scale, err.max().item())
 
 
 @pytest.mark.parametrize("kind", ["adam", "adamax"])
