@@ -163,6 +163,57 @@ def test_gradients_at_celeba_geometry_vs_autograd_oracle():
         f"dL/dx err {egx.max().item():.3e} vs max|g| {gscale:.3e}"
 
 
+def test_log_scale_gradients_from_dw_with_dominant_actnorm_biases():
+    """The backward k_cnet path derives d logs of the hidden ActNorms from the weight and bias gradients,
+    d logs[r] = 3 (<W[r], dW[r]> + b[r] db[r]), instead of a pass over the activations.  The two terms cancel when |b| is large
+    against the spread of the convolution output -- the regime a trained ActNorm can reach (not the data-dependent init, which
+    centres the output).  Here half of the hidden channels get biases of +2.5 / -1.5 (in units of the output's std) and log-scales
+    of +-0.1 on top of the init; bias and log-scale gradients of f.0 / f.2 against the fp64 oracle at the usual bound."""
+    K, batch = 2, 4
+    cfg = O.default_cfg(K=K, batch=batch)
+    sd = O.seeded_state_dict(cfg, seed=17, invconv_perturb=0.02, zeros_std=0.01)
+    g = torch.Generator().manual_seed(17)
+    x = torch.rand(batch, 3, 64, 64, generator=g)
+    noise = torch.rand(batch, 3, 64, 64, generator=g) / 256
+    sd = O.glow_init_actnorm(x, noise, sd, cfg)
+    for k in list(sd):
+        if (".f.0.actnorm." in k or ".f.2.actnorm." in k):
+            v = sd[k]
+            ch = torch.arange(v.numel()).reshape(v.shape)
+            if k.endswith("bias"):      # bias is added before the scale exp(3 logs): shift in units of the output's std
+                logs = sd[k.replace("bias", "logs")]
+                shift = torch.where(ch % 4 == 0, 2.5, torch.where(ch % 4 == 1, -1.5, 0.0)) / torch.exp(3 * logs)
+                sd[k] = v + shift.to(v.dtype)
+    for k in list(sd):
+        if (".f.0.actnorm.logs" in k or ".f.2.actnorm.logs" in k):
+            v = sd[k]
+            ch = torch.arange(v.numel()).reshape(v.shape)
+            sd[k] = v + torch.where(ch % 2 == 0, 0.1, -0.1).to(v.dtype) / 3
+    glow = G.Glow(hps_for(cfg, batch))
+    glow.load_state_dict(sd)
+    glow.set_actnorm_inited()
+    glow = glow.to(DEV).train()
+    ref, _, loss_ref = oracle_grads(cfg, {k: v.double() for k, v in sd.items()}, x.double(), noise.double())
+    with torch.enable_grad():
+        z, nll, _ = glow.normal_flow(x.to(DEV), None, noise=noise.to(DEV))
+        loss = G.Glow.generative_loss(nll)
+        loss.backward()
+    assert glow.flow.plan_for(x.to(DEV)).launch_counts().get("k_cnet(bwd)", 0) == 3 * K
+    assert abs(loss.item() - loss_ref) < 1e-4
+    checked = 0
+    for name, p in glow.named_parameters():
+        if ".actnorm." not in name or not (".f.0." in name or ".f.2." in name):
+            continue
+        r = ref[name]
+        err = (p.grad.cpu().double() - r).abs()
+        scale = r.abs().max().item()
+        outliers = (err > 2e-4 * scale + 1e-7).double().mean().item()
+        assert outliers <= 0.01 and err.max().item() <= 0.05 * scale + 1e-7, \
+            f"{name}: {outliers:.2%} beyond 2e-4 of max|g| = {scale:.3e}, max err {err.max().item():.3e}"
+        checked += 1
+    assert checked == 3 * K * 4
+
+
 def test_forward_after_an_optimizer_step_matches_oracle():
     """The optimiser updates the parameters in place; the next forward must see them (derived data is re-packed from the
     live parameters every training step) and agree with the oracle evaluated on the SAME updated state_dict."""
