@@ -39,6 +39,10 @@ struct ChanMixBwdArgs {
     const int32_t* gather_inv;       // inverse permutation table or null
     double* acc_w; double* acc_b; double* acc_l;
     int N, C, HW;
+    // the accumulators exist in acc_copies copies acc_stride doubles apart (workgroup b adds into copy b % acc_copies; the
+    // finalize job sums them): 1024 workgroups x (C^2 + 2C) fp64 atomics on ten cache lines ran at the rate of those lines'
+    // L2 channels (35 us per launch, whatever the level)
+    int acc_copies = 1; long acc_stride = 0;
 };
 int launch_chanmix_bwd(const ChanMixBwdArgs& a, hipStream_t s);
 
@@ -61,6 +65,7 @@ struct GradJob {
     const double* acc; float* out; int n;
     double add_mul;          // out[i] = acc[i] + gsum * add_mul            (winv == null)
     const float* winv; int C; // out[o*C+i] = acc[o*C+i] + gsum * add_mul * winv[i*C+o]   (invconv weight)
+    int copies = 1; long stride = 0;   // acc[i] = sum over copies of acc[copy * stride + i]
 };
 int launch_grad_finalize_batched(const GradJob* jobs_dev, int n_jobs, const double* gsum, hipStream_t s);
 // ActNorm log-scale gradient of a convolution layer y = (conv(x, W) + b) * exp(3 logs) from its weight and bias gradients:

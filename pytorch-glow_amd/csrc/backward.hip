@@ -95,8 +95,81 @@ int launch_logs_from_dw_batched(const LogsJob* jobs_dev, int n_jobs, hipStream_t
     return GLOWHIP_OK;
 }
 
+// The same, four consecutive pixels per thread (16-byte accesses) and no LDS: a workgroup takes 1024 consecutive elements of one
+// image's (Ch, HW) plane -- HW / 4 threads per channel, a power of two -- sums per channel in fp32 inside the wave (or inside the
+// channel's lane segment when a wave spans several channels), one fp64 atomic per wave (segment), channel and quantity.  The
+// one-pixel-per-thread kernel above (four fp64 block reductions, eight barriers, 1536 workgroups of one wave's worth of work
+// each) took 22 us per launch at any level.
+__global__ void __launch_bounds__(256) k_coupling_bwd4(CouplingBwdArgs a) {
+    const long n = blockIdx.y;
+    const int HW = a.HW, tpc = HW >> 2;
+    const long off = (long)blockIdx.x * 1024 + threadIdx.x * 4;          // element of the (Ch, HW) plane
+    const bool ok = off < (long)a.Ch * HW;
+    const int c = ok ? (int)(off / HW) : 0;
+    const int p = ok ? (int)(off - (long)c * HW) : 0;
+    float sb[2] = {0.f, 0.f}, sl[2] = {0.f, 0.f};
+    const int oc0 = a.affine ? 2 * c : c, oc1 = a.affine ? 2 * c + 1 : c;
+    if (ok) {
+        const float4 g2 = *reinterpret_cast<const float4*>(a.g2 + n * a.g_bs + (long)c * HW + p);
+        const float g2v[4] = {g2.x, g2.y, g2.z, g2.w};
+        float gy[4], gp0[4], gp1[4];
+        if (a.affine) {
+            const float4 h0 = *reinterpret_cast<const float4*>(a.hout + (n * a.Cout + oc0) * HW + p);
+            const float4 h1 = *reinterpret_cast<const float4*>(a.hout + (n * a.Cout + oc1) * HW + p);
+            const float4 zz = *reinterpret_cast<const float4*>(a.z2out + n * a.z_bs + (long)c * HW + p);
+            const float h0v[4] = {h0.x, h0.y, h0.z, h0.w}, h1v[4] = {h1.x, h1.y, h1.z, h1.w}, zv[4] = {zz.x, zz.y, zz.z, zz.w};
+            const float e0 = a.e4[oc0], e1 = a.e4[oc1], gld = a.gld[n];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float sg = sigmoidf_(h1v[j] + 2.0f);
+                const float y2s = zv[j] / sg;                 // = y2 + shift
+                gy[j] = g2v[j] * sg;
+                const float gh0 = g2v[j] * sg;
+                const float gh1 = (g2v[j] * y2s + gld / sg) * sg * (1.0f - sg);
+                gp0[j] = gh0 * e0; gp1[j] = gh1 * e1;
+                sb[0] += gp0[j]; sb[1] += gp1[j];
+                sl[0] += gh0 * h0v[j]; sl[1] += gh1 * h1v[j];
+            }
+            *reinterpret_cast<float4*>(a.gpre + (n * a.Cout + oc1) * HW + p) = make_float4(gp1[0], gp1[1], gp1[2], gp1[3]);
+        } else {
+            const float4 h0 = *reinterpret_cast<const float4*>(a.hout + (n * a.Cout + oc0) * HW + p);
+            const float h0v[4] = {h0.x, h0.y, h0.z, h0.w};
+            const float e0 = a.e4[oc0];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                gy[j] = g2v[j];
+                gp0[j] = g2v[j] * e0;
+                sb[0] += gp0[j];
+                sl[0] += g2v[j] * h0v[j];
+            }
+        }
+        *reinterpret_cast<float4*>(a.gy2 + n * a.g_bs + (long)c * HW + p) = make_float4(gy[0], gy[1], gy[2], gy[3]);
+        *reinterpret_cast<float4*>(a.gpre + (n * a.Cout + oc0) * HW + p) = make_float4(gp0[0], gp0[1], gp0[2], gp0[3]);
+    }
+    // per-channel sums: segments of min(tpc, 64) consecutive lanes share a channel
+    const int seg = tpc < 64 ? tpc : 64;
+    const int nsub = a.affine ? 2 : 1;
+    for (int k = 0; k < nsub; ++k) {
+        float vb = sb[k], vl = sl[k];
+        for (int o = seg >> 1; o > 0; o >>= 1) { vb += __shfl_down(vb, o, 64); vl += __shfl_down(vl, o, 64); }
+        if ((threadIdx.x & (seg - 1)) == 0 && ok) {
+            const int o = k == 0 ? oc0 : oc1;
+            atomic_add_f64(a.acc_b + o, (double)vb);
+            atomic_add_f64(a.acc_l + o, 3.0 * (double)vl);
+        }
+    }
+}
+
 int launch_coupling_bwd(const CouplingBwdArgs& a, hipStream_t s) {
     if (a.N == 0) return GLOWHIP_OK;
+    const bool pow2 = a.HW >= 4 && (a.HW & (a.HW - 1)) == 0;
+    const bool aligned = a.g_bs % 4 == 0 && a.z_bs % 4 == 0 && ((size_t)a.g2 & 15) == 0 && ((size_t)a.gy2 & 15) == 0 &&
+                         ((size_t)a.z2out & 15) == 0 && ((size_t)a.hout & 15) == 0 && ((size_t)a.gpre & 15) == 0;
+    if (pow2 && aligned) {
+        hipLaunchKernelGGL(k_coupling_bwd4, dim3((unsigned)(((long)a.Ch * a.HW + 1023) / 1024), a.N), dim3(256), 0, s, a);
+        GH_LAUNCH_CHECK("k_coupling_bwd4");
+        return GLOWHIP_OK;
+    }
     hipLaunchKernelGGL(k_coupling_bwd, dim3(cdiv(a.HW, 256), a.Ch, a.N), dim3(256), 0, s, a);
     GH_LAUNCH_CHECK("k_coupling_bwd");
     return GLOWHIP_OK;
@@ -392,13 +465,14 @@ __global__ void __launch_bounds__(256) k_chanmix_bwd(ChanMixBwdArgs a) {
     __syncthreads();
     // reductions over the 64 pixels of this workgroup
     const int tid = threadIdx.x;
+    const long aco = (long)(blockIdx.x % a.acc_copies) * a.acc_stride;      // this workgroup's copy of the accumulators
     if (a.matrix) {
         for (int pair = tid; pair < C * C; pair += 256) {
             const int o = pair / C, i = pair - o * C;
             float s = 0.f;
 #pragma unroll 8
             for (int q = 0; q < CB_PX; ++q) s = fmaf(gy[o * CB_PX + q], v[i * CB_PX + q], s);
-            atomic_add_f64(a.acc_w + pair, (double)s);
+            atomic_add_f64(a.acc_w + aco + pair, (double)s);
         }
     }
     for (int c = tid; c < C; c += 256) {
@@ -407,8 +481,8 @@ __global__ void __launch_bounds__(256) k_chanmix_bwd(ChanMixBwdArgs a) {
             sb = fmaf(gv[c * CB_PX + q], a.scale[c], sb);
             sl = fmaf(gv[c * CB_PX + q], v[c * CB_PX + q], sl);
         }
-        atomic_add_f64(a.acc_b + c, (double)sb);
-        atomic_add_f64(a.acc_l + c, (double)sl * 3.0);
+        atomic_add_f64(a.acc_b + aco + c, (double)sb);
+        atomic_add_f64(a.acc_l + aco + c, (double)sl * 3.0);
     }
 }
 
@@ -547,6 +621,7 @@ __global__ void __launch_bounds__(256) k_grad_finalize_batched(const GradJob* __
     const double g = gsum[0] * j.add_mul;
     for (int e = blockIdx.x * 256 + threadIdx.x; e < j.n; e += gridDim.x * 256) {
         double v = j.acc[e];
+        for (int k = 1; k < j.copies; ++k) v += j.acc[k * j.stride + e];
         if (j.winv) {
             const int o = e / j.C, i = e - o * j.C;
             v += g * (double)j.winv[i * j.C + o];

@@ -74,9 +74,10 @@ static size_t max_weight_floats(const glowhip_plan* p) {
 }
 
 // fp64 accumulators of every layer's reduction-type gradients live side by side: zeroed once, converted once
+constexpr int MIX_ACC_COPIES = 16;     // copies of a FlowStep's mixer accumulators [W C*C][an_b C][an_l C] (backward.h ChanMixBwdArgs)
 static size_t layer_acc_doubles(const LayerPlan& L) {
     const glowhip_layer_desc& d = L.d;
-    if (d.kind == GLOWHIP_LAYER_FLOWSTEP) return (size_t)d.C * d.C + 2 * d.C + 4 * d.hidden + 2 * L.Cout;
+    if (d.kind == GLOWHIP_LAYER_FLOWSTEP) return MIX_ACC_COPIES * ((size_t)d.C * d.C + 2 * d.C) + 4 * d.hidden + 2 * L.Cout;
     if (d.kind == GLOWHIP_LAYER_SPLIT2D) return (size_t)2 * L.Cout;
     return 0;
 }
@@ -337,8 +338,9 @@ static int backward_sweep(glowhip_plan* p, const void* packed, const float* x_in
         for (int i = 0; i < nl; ++i) { acc_base[i] = o; o += layer_acc_doubles(p->layers[i]); }
         GH_TRY(zero_f64(w.dacc, o, s));
     }
-    auto fin = [&](const double* acc, float* out, int n, double add_mul, const float* winv = nullptr, int C = 0) {
-        if (out) jobs.push_back(GradJob{acc, out, n, add_mul, winv, C});
+    auto fin = [&](const double* acc, float* out, int n, double add_mul, const float* winv = nullptr, int C = 0, int copies = 1,
+                   long stride = 0) {
+        if (out) jobs.push_back(GradJob{acc, out, n, add_mul, winv, C, copies, stride});
     };
     size_t mark_i = 0;      // gradient-ready marks (glowhip_plan_backward_marks), in sweep order
     auto marks_down_to = [&](int li) {
@@ -369,8 +371,9 @@ static int backward_sweep(glowhip_plan* p, const void* packed, const float* x_in
             const float* hout = at<float>(tape, tl[li].hout);
             const int affine = d.coupling == GLOWHIP_COUPLING_AFFINE;
             // accumulators: [W C*C][an_b C][an_l C][f0_b hid][f0_l hid][f2_b hid][f2_l hid][f4_b Cout][f4_l Cout]
+            const long mstride = (long)d.C * d.C + 2 * d.C;       // one copy of the mixer accumulators
             double* aW = w.dacc + acc_base[li]; double* aAb = aW + (size_t)d.C * d.C; double* aAl = aAb + d.C;
-            double* a0b = aAl + d.C; double* a0l = a0b + hid; double* a2b = a0l + hid; double* a2l = a2b + hid;
+            double* a0b = aW + MIX_ACC_COPIES * mstride; double* a0l = a0b + hid; double* a2b = a0l + hid; double* a2l = a2b + hid;
             double* a4b = a2l + hid; double* a4l = a4b + L.Cout;
             // (a) coupling tail: g (second half) becomes g_y2 in place; gpre = gradient of f.4's (conv + bias)
             CouplingBwdArgs cb{hout, out + (long)Ch * HW, chw, g + (long)Ch * HW, chw, g + (long)Ch * HW, w.gpre,
@@ -409,10 +412,11 @@ static int backward_sweep(glowhip_plan* p, const void* packed, const float* x_in
                 ChanMixBwdArgs mb{xin, chw, g, g, chw, d.an_bias, at<float>(packed, L.an_scale),
                                   d.permutation == GLOWHIP_PERM_INVCONV ? d.invconv_w : nullptr,
                                   d.permutation == GLOWHIP_PERM_GATHER ? d.perm_idx_inv : nullptr, aW, aAb, aAl, N, d.C, HW};
+                mb.acc_copies = MIX_ACC_COPIES; mb.acc_stride = mstride;
                 GH_TRY(launch_chanmix_bwd(mb, s));
-                if (d.permutation == GLOWHIP_PERM_INVCONV) fin(aW, G.invconv_w, d.C * d.C, (double)HW, at<float>(packed, L.winv), d.C);
-                fin(aAb, G.an_bias, d.C, 0.0);
-                fin(aAl, G.an_logs, d.C, 3.0 * HW);
+                if (d.permutation == GLOWHIP_PERM_INVCONV) fin(aW, G.invconv_w, d.C * d.C, (double)HW, at<float>(packed, L.winv), d.C, MIX_ACC_COPIES, mstride);
+                fin(aAb, G.an_bias, d.C, 0.0, nullptr, 0, MIX_ACC_COPIES, mstride);
+                fin(aAl, G.an_logs, d.C, 3.0 * HW, nullptr, 0, MIX_ACC_COPIES, mstride);
                 fin(a0b, G.f0_an_bias, hid, 0.0);
                 fin(a2b, G.f2_an_bias, hid, 0.0);
                 fin(a4b, G.f4_bias, L.Cout, 0.0); fin(a4l, G.f4_logs, L.Cout, 0.0);
@@ -479,12 +483,13 @@ static int backward_sweep(glowhip_plan* p, const void* packed, const float* x_in
             ChanMixBwdArgs mb{xin, chw, g, g, chw, d.an_bias, at<float>(packed, L.an_scale),
                               d.permutation == GLOWHIP_PERM_INVCONV ? d.invconv_w : nullptr,
                               d.permutation == GLOWHIP_PERM_GATHER ? d.perm_idx_inv : nullptr, aW, aAb, aAl, N, d.C, HW};
-            GH_TRY(launch_chanmix_bwd(mb, s));
+            mb.acc_copies = MIX_ACC_COPIES; mb.acc_stride = mstride;
+                GH_TRY(launch_chanmix_bwd(mb, s));
             // (f) fp64 accumulators -> fp32 gradients (+ the log-det terms that do not depend on the data): queued,
             // converted by ONE launch after the sweep
-            if (d.permutation == GLOWHIP_PERM_INVCONV) fin(aW, G.invconv_w, d.C * d.C, (double)HW, at<float>(packed, L.winv), d.C);
-            fin(aAb, G.an_bias, d.C, 0.0);
-            fin(aAl, G.an_logs, d.C, 3.0 * HW);
+            if (d.permutation == GLOWHIP_PERM_INVCONV) fin(aW, G.invconv_w, d.C * d.C, (double)HW, at<float>(packed, L.winv), d.C, MIX_ACC_COPIES, mstride);
+            fin(aAb, G.an_bias, d.C, 0.0, nullptr, 0, MIX_ACC_COPIES, mstride);
+            fin(aAl, G.an_logs, d.C, 3.0 * HW, nullptr, 0, MIX_ACC_COPIES, mstride);
             fin(a0b, G.f0_an_bias, hid, 0.0); fin(a0l, G.f0_an_logs, hid, 0.0);
             fin(a2b, G.f2_an_bias, hid, 0.0); fin(a2l, G.f2_an_logs, hid, 0.0);
             fin(a4b, G.f4_bias, L.Cout, 0.0); fin(a4l, G.f4_logs, L.Cout, 0.0);
