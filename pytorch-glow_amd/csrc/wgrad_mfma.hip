@@ -180,39 +180,53 @@ k_wgrad_gemm_sh(const float* __restrict__ A, long a_bs, const float* __restrict_
     const int kt0 = split * ktiles_per_split;
     const int kt1 = min(ktiles_total, kt0 + ktiles_per_split);
     const int tiles_per_img = HW / BK;
-    const int a_row = tid & (BM - 1), a_q = tid / BM;
-    const int b_row = tid & (BN - 1), b_q = tid / BN;
+    // Operand loader: chunk q = tid + 256 j of a tile is (row q / 8, pixels 4 (q % 8) .. + 4) -- eight consecutive lanes read the
+    // 128 contiguous bytes one row contributes to a k-tile, a wave instruction 8 whole cache lines.  (One row per lane, 64 bytes
+    // each, asked the texture-address path for 64 partial lines per instruction: f.2's gradient at level 1 took 166 us for the
+    // 67 us of HBM time its operands need.)
+    const int l_row = tid >> 3, l_c = tid & 7;
     f32x4 ra[A_F4], rb[B_F4];
     auto load_tile = [&](int kt) {
         const int img = kt / tiles_per_img, p0 = (kt - img * tiles_per_img) * BK;
-        const float* ap = A + (long)img * a_bs + (long)(tile_m * BM + a_row) * HW + p0 + a_q * (A_F4 * 4);
-        const float* bp = B + (long)img * b_bs + (long)(tile_n * BN + b_row) * HW + p0 + b_q * (B_F4 * 4);
+        const float* ap = A + (long)img * a_bs + (long)(tile_m * BM + l_row) * HW + p0 + l_c * 4;
+        const float* bp = B + (long)img * b_bs + (long)(tile_n * BN + l_row) * HW + p0 + l_c * 4;
 #pragma unroll
-        for (int j = 0; j < A_F4; ++j) ra[j] = *reinterpret_cast<const f32x4*>(ap + j * 4);
+        for (int j = 0; j < A_F4; ++j) ra[j] = *reinterpret_cast<const f32x4*>(ap + (long)j * 32 * HW);
 #pragma unroll
-        for (int j = 0; j < B_F4; ++j) rb[j] = *reinterpret_cast<const f32x4*>(bp + j * 4);
+        for (int j = 0; j < B_F4; ++j) rb[j] = *reinterpret_cast<const f32x4*>(bp + (long)j * 32 * HW);
     };
-    float rsum = 0.f;                  // rowsum != null: sum over this slice's pixels of the thread's A row (the bias gradient)
-    auto store_tile = [&](int buf) {   // 8 consecutive pixels of a row = one fragment group; lanes = consecutive rows: conflict-free
+    auto split4 = [](const f32x4& v, float pre, h4& hi, h4& lo) {      // (same bits as sh_split on v * pre)
+#pragma unroll
+        for (int t = 0; t < 4; t += 2) {
+            const float v0 = v[t] * pre, v1 = v[t + 1] * pre;
+            const f32x2_t vv = {v0, v1};
+            const h2s x = __builtin_convertvector(vv, h2s);
+            const f32x2_t rr = {(v0 - (float)x[0]) * SH_LO_SCALE, (v1 - (float)x[1]) * SH_LO_SCALE};
+            const h2s y = __builtin_convertvector(rr, h2s);
+            hi[t] = x[0]; hi[t + 1] = x[1]; lo[t] = y[0]; lo[t + 1] = y[1];
+        }
+    };
+    float rsum[A_F4];                  // rowsum != null: sum over this slice's pixels of the thread's A chunks (the bias gradient)
+#pragma unroll
+    for (int j = 0; j < A_F4; ++j) rsum[j] = 0.f;
+    auto store_tile = [&](int buf) {   // 4 consecutive pixels of a row = half a fragment group: 8-byte stores, 16 lanes = 128 contiguous bytes
         if (rowsum) {
 #pragma unroll
-            for (int j = 0; j < A_F4; ++j) rsum += (ra[j][0] + ra[j][1]) + (ra[j][2] + ra[j][3]);
+            for (int j = 0; j < A_F4; ++j) rsum[j] += (ra[j][0] + ra[j][1]) + (ra[j][2] + ra[j][3]);
         }
 #pragma unroll
-        for (int g2 = 0; g2 < A_F4 / 2; ++g2) {
-            h8 hi, lo;
-            sh_split8(ra[2 * g2], ra[2 * g2 + 1], a_scale, hi, lo);
-            const int grp = a_q * (A_F4 / 2) + g2;
-            *reinterpret_cast<h8*>(&As[buf][0][grp][a_row][0]) = hi;
-            *reinterpret_cast<h8*>(&As[buf][1][grp][a_row][0]) = lo;
+        for (int j = 0; j < A_F4; ++j) {
+            h4 hi, lo;
+            split4(ra[j], a_scale, hi, lo);
+            *reinterpret_cast<h4*>(&As[buf][0][l_c >> 1][l_row + 32 * j][(l_c & 1) * 4]) = hi;
+            *reinterpret_cast<h4*>(&As[buf][1][l_c >> 1][l_row + 32 * j][(l_c & 1) * 4]) = lo;
         }
 #pragma unroll
-        for (int g2 = 0; g2 < B_F4 / 2; ++g2) {
-            h8 hi, lo;
-            sh_split8(rb[2 * g2], rb[2 * g2 + 1], 1.0f, hi, lo);
-            const int grp = b_q * (B_F4 / 2) + g2;
-            *reinterpret_cast<h8*>(&Bs[buf][0][grp][b_row][0]) = hi;
-            *reinterpret_cast<h8*>(&Bs[buf][1][grp][b_row][0]) = lo;
+        for (int j = 0; j < B_F4; ++j) {
+            h4 hi, lo;
+            split4(rb[j], 1.0f, hi, lo);
+            *reinterpret_cast<h4*>(&Bs[buf][0][l_c >> 1][l_row + 32 * j][(l_c & 1) * 4]) = hi;
+            *reinterpret_cast<h4*>(&Bs[buf][1][l_c >> 1][l_row + 32 * j][(l_c & 1) * 4]) = lo;
         }
     };
 
@@ -262,11 +276,13 @@ k_wgrad_gemm_sh(const float* __restrict__ A, long a_bs, const float* __restrict_
             __syncthreads();
         }
     }
-    if (rowsum && tile_n == 0) {       // (uniform per workgroup) the two pixel halves of a row, then one fp64 atomic per row and slice
-        float* rs_sm = reinterpret_cast<float*>(&As[0][0][0][0][0]);
-        if (a_q == 1) rs_sm[a_row] = rsum;
-        __syncthreads();
-        if (a_q == 0 && kt0 < kt1) atomicAdd(rowsum + tile_m * BM + a_row, (double)(rsum + rs_sm[a_row]));
+    if (rowsum && tile_n == 0 && kt0 < kt1) {      // the eight chunks of a row sit in eight consecutive lanes: one fp64 atomic per row and slice
+#pragma unroll
+        for (int j = 0; j < A_F4; ++j) {
+            float v = rsum[j];
+            v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+            if (l_c == 0) atomicAdd(rowsum + tile_m * BM + l_row + 32 * j, (double)v);
+        }
     }
     const float inv = 1.0f / a_scale;
     float* out = partial + ((long)split * Mpad + tile_m * BM) * Npad + tile_n * BN;
