@@ -14,6 +14,7 @@ struct CouplingBwdArgs {
     const float* gld;        // (N) dL/dlogdet_n
     double* acc_b; double* acc_l;    // (Cout) f.4 bias / logs gradient accumulators
     int N, Ch, Cout, HW, affine;
+    int acc_copies = 1; long acc_stride = 0;   // as in ChanMixBwdArgs: workgroup b adds into copy b % acc_copies (k_coupling_bwd4)
 };
 int launch_coupling_bwd(const CouplingBwdArgs& a, hipStream_t s);
 

@@ -153,9 +153,11 @@ __global__ void __launch_bounds__(256) k_coupling_bwd4(CouplingBwdArgs a) {
         float vb = sb[k], vl = sl[k];
         for (int o = seg >> 1; o > 0; o >>= 1) { vb += __shfl_down(vb, o, 64); vl += __shfl_down(vl, o, 64); }
         if ((threadIdx.x & (seg - 1)) == 0 && ok) {
+            // (6 144 atomics on the two cache lines of a 12-channel level took 30 us: the copies spread them over 16 x as many)
+            const long aco = (long)((blockIdx.x + blockIdx.y * gridDim.x + (threadIdx.x >> 6)) % a.acc_copies) * a.acc_stride;
             const int o = k == 0 ? oc0 : oc1;
-            atomic_add_f64(a.acc_b + o, (double)vb);
-            atomic_add_f64(a.acc_l + o, 3.0 * (double)vl);
+            atomic_add_f64(a.acc_b + aco + o, (double)vb);
+            atomic_add_f64(a.acc_l + aco + o, 3.0 * (double)vl);
         }
     }
 }
@@ -435,7 +437,10 @@ __global__ void __launch_bounds__(256) k_chanmix_bwd(ChanMixBwdArgs a) {
     float* v = sm;                   // [C][64]
     float* gy = sm + C * CB_PX;      // [C][64]
     float* gv = gy + C * CB_PX;      // [C][64]
-    const int px = threadIdx.x & (CB_PX - 1), grp = threadIdx.x >> 6;
+    const int px = threadIdx.x & (CB_PX - 1);
+    const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // wave-uniform: the matrix element W[o][i] of the g_v loop
+                                                                           // below is then a scalar load (it was a vector load per
+                                                                           // FMA: 41 us per launch at C = 48)
     const long gp = (long)blockIdx.x * CB_PX + px;
     const long total = (long)a.N * a.HW;
     const bool valid = gp < total;

@@ -77,7 +77,7 @@ static size_t max_weight_floats(const glowhip_plan* p) {
 constexpr int MIX_ACC_COPIES = 16;     // copies of a FlowStep's mixer accumulators [W C*C][an_b C][an_l C] (backward.h ChanMixBwdArgs)
 static size_t layer_acc_doubles(const LayerPlan& L) {
     const glowhip_layer_desc& d = L.d;
-    if (d.kind == GLOWHIP_LAYER_FLOWSTEP) return MIX_ACC_COPIES * ((size_t)d.C * d.C + 2 * d.C) + 4 * d.hidden + 2 * L.Cout;
+    if (d.kind == GLOWHIP_LAYER_FLOWSTEP) return MIX_ACC_COPIES * ((size_t)d.C * d.C + 2 * d.C + 2 * L.Cout) + 4 * d.hidden;
     if (d.kind == GLOWHIP_LAYER_SPLIT2D) return (size_t)2 * L.Cout;
     return 0;
 }
@@ -378,6 +378,7 @@ static int backward_sweep(glowhip_plan* p, const void* packed, const float* x_in
             // (a) coupling tail: g (second half) becomes g_y2 in place; gpre = gradient of f.4's (conv + bias)
             CouplingBwdArgs cb{hout, out + (long)Ch * HW, chw, g + (long)Ch * HW, chw, g + (long)Ch * HW, w.gpre,
                                at<float>(packed, L.f4_scale), w.gld, a4b, a4l, N, Ch, L.Cout, HW, affine};
+            cb.acc_copies = MIX_ACC_COPIES; cb.acc_stride = 2 * L.Cout;
             GH_TRY(launch_coupling_bwd(cb, s));
             // (b) f.4: weight gradient, then input gradient -> g_h2 (raw), then ReLU/ActNorm of f.2
             const bool fastw = wgrad_fast(L);
@@ -419,7 +420,7 @@ static int backward_sweep(glowhip_plan* p, const void* packed, const float* x_in
                 fin(aAl, G.an_logs, d.C, 3.0 * HW, nullptr, 0, MIX_ACC_COPIES, mstride);
                 fin(a0b, G.f0_an_bias, hid, 0.0);
                 fin(a2b, G.f2_an_bias, hid, 0.0);
-                fin(a4b, G.f4_bias, L.Cout, 0.0); fin(a4l, G.f4_logs, L.Cout, 0.0);
+                fin(a4b, G.f4_bias, L.Cout, 0.0, nullptr, 0, MIX_ACC_COPIES, 2 * L.Cout); fin(a4l, G.f4_logs, L.Cout, 0.0, nullptr, 0, MIX_ACC_COPIES, 2 * L.Cout);
                 continue;
             }
             if (fastw) {   // dW4[o][i][tap] = sum_p g_pre[o][p - d(tap)] * h2[i][p]
@@ -492,7 +493,7 @@ static int backward_sweep(glowhip_plan* p, const void* packed, const float* x_in
             fin(aAl, G.an_logs, d.C, 3.0 * HW, nullptr, 0, MIX_ACC_COPIES, mstride);
             fin(a0b, G.f0_an_bias, hid, 0.0); fin(a0l, G.f0_an_logs, hid, 0.0);
             fin(a2b, G.f2_an_bias, hid, 0.0); fin(a2l, G.f2_an_logs, hid, 0.0);
-            fin(a4b, G.f4_bias, L.Cout, 0.0); fin(a4l, G.f4_logs, L.Cout, 0.0);
+            fin(a4b, G.f4_bias, L.Cout, 0.0, nullptr, 0, MIX_ACC_COPIES, 2 * L.Cout); fin(a4l, G.f4_logs, L.Cout, 0.0, nullptr, 0, MIX_ACC_COPIES, 2 * L.Cout);
         } else {  // SPLIT2D: output z1 (N,Ch,HW); input x = (z1, z2)
             const float* hout = at<float>(tape, tl[li].hout);
             double* a4b = w.dacc + acc_base[li]; double* a4l = a4b + L.Cout;
