@@ -57,9 +57,13 @@ int launch_shift_expand(const float* src, long src_bs, float* out, int N, int C,
                         hipStream_t s);
 bool wgrad_mfma_supported(int HW, int Mpad, int Npad);
 size_t wgrad_mfma_partial_floats(int Mpad, int Npad, int N, int HW);
+// operand (0: A, 1: B) of launch_wgrad_mfma given as the (N, C, H, W) tensor whose shift-expanded rows (c * 9 + tap) it stands for
+// (what launch_shift_expand would write): the GEMM's loader gathers them itself.  The operand pointer / batch stride are the tensor's.
+struct WgradTaps { int operand, C, H, W, sign; };
 int launch_wgrad_mfma(const float* A, long a_bs, const float* B, long b_bs, float* partial, float* dw, int N, int HW,
                       int Mpad, int Npad, int Mreal, int Nreal, int mode, hipStream_t s, float sh_scale = 0.f,   // sh_scale > 0: f16-pipe kernel, gradient operand A pre-scaled by it
-                      double* rowsum = nullptr);   // (f16-pipe kernel) rowsum[m] += sum over all pixels of A's row m -- the bias gradient when A = g_u
+                      double* rowsum = nullptr,    // (f16-pipe kernel) rowsum[m] += sum over all pixels of A's row m -- the bias gradient when A = g_u
+                      const WgradTaps* taps = nullptr);
 
 // one launch for all reduction-type parameter gradients of a backward sweep
 struct GradJob {

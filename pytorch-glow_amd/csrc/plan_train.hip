@@ -387,9 +387,17 @@ static int backward_sweep(glowhip_plan* p, const void* packed, const float* x_in
                 // weight images, the ReLU masks from the tape's sign bits; the bias gradients are row sums inside the weight-gradient
                 // GEMMs that read g_u2 / g_u0 anyway, the log-scale gradients follow from dW and db (backward.h LogsJob).
                 const int m4 = round_up(L.Cout * 9, 128), n0 = round_up(Ch * 9, 64);
-                GH_TRY(launch_shift_expand(w.gpre, (long)L.Cout * HW, w.col, N, L.Cout, d.H, d.W, m4, -1, s));
-                GH_TRY(launch_wgrad_mfma(w.col, (long)m4 * HW, h2, (long)hid * HW, w.partial, G.f4_w, N, HW, m4, hid,
-                                         L.Cout * 9, hid, 1, s, sh_grad_scale));
+                // (the 3x3 layers' shift-expanded operands are gathered by the GEMM's loader: WgradTaps)
+                const bool vtaps = d.W >= 4 && (d.W & (d.W - 1)) == 0;
+                const WgradTaps t4{0, L.Cout, d.H, d.W, -1}, t0{1, Ch, d.H, d.W, +1};
+                if (vtaps) {
+                    GH_TRY(launch_wgrad_mfma(w.gpre, (long)L.Cout * HW, h2, (long)hid * HW, w.partial, G.f4_w, N, HW, m4, hid,
+                                             L.Cout * 9, hid, 1, s, sh_grad_scale, nullptr, &t4));
+                } else {
+                    GH_TRY(launch_shift_expand(w.gpre, (long)L.Cout * HW, w.col, N, L.Cout, d.H, d.W, m4, -1, s));
+                    GH_TRY(launch_wgrad_mfma(w.col, (long)m4 * HW, h2, (long)hid * HW, w.partial, G.f4_w, N, HW, m4, hid,
+                                             L.Cout * 9, hid, 1, s, sh_grad_scale));
+                }
                 CnetArgs c{};
                 c.w0 = at<char>(packed, L.cb_w0); c.w2 = at<char>(packed, L.cb_w2); c.w4 = at<char>(packed, L.cb_w4);
                 c.N = N; c.Cin = L.Cout; c.H = d.H; c.W = d.W; c.hidden = hid; c.Cout = Ch;
@@ -405,9 +413,14 @@ static int backward_sweep(glowhip_plan* p, const void* packed, const float* x_in
                 GH_TRY(launch_cnet_bwd_finish(c, pend, g, chw, 1.0f / sh_grad_scale, s));
                 GH_TRY(launch_wgrad_mfma(w.gh2, (long)hid * HW, h1, (long)hid * HW, w.partial, G.f2_w, N, HW, hid, hid, hid, hid,
                                          0, s, sh_grad_scale, a2b));
-                GH_TRY(launch_shift_expand(out, chw, w.col, N, Ch, d.H, d.W, n0, +1, s));
-                GH_TRY(launch_wgrad_mfma(w.gh1, (long)hid * HW, w.col, (long)n0 * HW, w.partial, G.f0_w, N, HW, hid, n0, hid,
-                                         Ch * 9, 0, s, sh_grad_scale, a0b));
+                if (vtaps) {
+                    GH_TRY(launch_wgrad_mfma(w.gh1, (long)hid * HW, out, chw, w.partial, G.f0_w, N, HW, hid, n0, hid,
+                                             Ch * 9, 0, s, sh_grad_scale, a0b, &t0));
+                } else {
+                    GH_TRY(launch_shift_expand(out, chw, w.col, N, Ch, d.H, d.W, n0, +1, s));
+                    GH_TRY(launch_wgrad_mfma(w.gh1, (long)hid * HW, w.col, (long)n0 * HW, w.partial, G.f0_w, N, HW, hid, n0, hid,
+                                             Ch * 9, 0, s, sh_grad_scale, a0b));
+                }
                 if (G.f2_an_logs) p->logs_jobs.push_back(LogsJob{d.f2_w, G.f2_w, d.f2_an_bias, a2b, G.f2_an_logs, hid, hid});
                 if (G.f0_an_logs) p->logs_jobs.push_back(LogsJob{d.f0_w, G.f0_w, d.f0_an_bias, a0b, G.f0_an_logs, hid, Ch * 9});
                 ChanMixBwdArgs mb{xin, chw, g, g, chw, d.an_bias, at<float>(packed, L.an_scale),

@@ -155,12 +155,16 @@ k_wgrad_gemm(const float* __restrict__ A, long a_bs, const float* __restrict__ B
 // product is three v_mfma_f32_32x32x16_f16.  24 MFMAs of 32 cycles per 32-pixel k-tile instead of 64 of 64 cycles: the kernel
 // goes from MFMA-bound to operand-delivery-bound.  The gradient operand (A) is multiplied by a_scale = 2^k on the way in (it is
 // ~1e-6 .. 1e-10 early in training, below fp16's normal range) and the partial sums by 2^-k on the way out (exact).
-template <int BN>
+// VA / VB: operand A / B is VIRTUAL -- the shift-expanded rows (c * 9 + tap) : src[c][p + sign * d(tap)] of a (N, vC, vH, vW)
+// tensor (rows >= 9 vC are zero), gathered by the loader itself (four 4-byte loads per chunk, clamped addresses, selected
+// values) instead of being written out by k_shift_expand and read back (33 + 17 MB per level-1 FlowStep, 17 + 12 us of launches)
+template <int BN, bool VA = false, bool VB = false>
 __global__ void __launch_bounds__(256, 2)      // two workgroups per CU: at 269 registers (141 + 128 accumulators) the kernel ran ONE
                                                // wave per SIMD and every k-tile waited out its own HBM round trip (7.4 k cycles per
                                                // k-tile against 768 of MFMA work)
 k_wgrad_gemm_sh(const float* __restrict__ A, long a_bs, const float* __restrict__ B, long b_bs, float* __restrict__ partial,
-                int HW, int Mpad, int Npad, int ktiles_total, int ktiles_per_split, float a_scale, double* __restrict__ rowsum) {
+                int HW, int Mpad, int Npad, int ktiles_total, int ktiles_per_split, float a_scale, double* __restrict__ rowsum,
+                int vC, int vH, int vW, int vsign) {
     constexpr int BM = 128, BK = 32;
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
     constexpr int A_F4 = BM * BK / 4 / 256, B_F4 = BN * BK / 4 / 256;   // float4 per thread per K-tile (4, 4|2)
@@ -186,14 +190,51 @@ k_wgrad_gemm_sh(const float* __restrict__ A, long a_bs, const float* __restrict_
     // 67 us of HBM time its operands need.)
     const int l_row = tid >> 3, l_c = tid & 7;
     f32x4 ra[A_F4], rb[B_F4];
+    // virtual operand: per chunk row (fixed over the k loop) the source offset c * HW + dy * vW + dx, dy, dx; off < 0: a zero row
+    constexpr int VN = VA ? A_F4 : (VB ? B_F4 : 1);
+    int v_off[VN], v_dy[VN], v_dx[VN];
+    if (VA || VB) {
+#pragma unroll
+        for (int j = 0; j < VN; ++j) {
+            const int r = (VA ? tile_m * BM : tile_n * BN) + l_row + 32 * j;
+            const int c = r / 9, tap = r - c * 9;
+            v_dy[j] = (tap / 3 - 1) * vsign; v_dx[j] = (tap % 3 - 1) * vsign;
+            v_off[j] = r < 9 * vC ? c * HW + v_dy[j] * vW + v_dx[j] : -(1 << 30);
+        }
+    }
+    const int vlw = (VA || VB) ? __builtin_ctz(vW) : 0;
+    auto load_virtual = [&](const float* V, long v_bs, int img, int p0, f32x4* dst) {
+        const int p = p0 + l_c * 4, y = p >> vlw, x = p & (vW - 1);
+        const float* vb = V + (long)img * v_bs + p;
+#pragma unroll
+        for (int j = 0; j < VN; ++j) {
+            const int yy = y + v_dy[j];
+            const bool rowok = v_off[j] > -(1 << 29) && yy >= 0 && yy < vH;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int xx = x + e + v_dx[j];
+                const bool ok = rowok && xx >= 0 && xx < vW;
+                const float v = ok ? vb[v_off[j] + e] : V[0];      // (unconditional load from a valid address, selected)
+                dst[j][e] = ok ? v : 0.f;
+            }
+        }
+    };
     auto load_tile = [&](int kt) {
         const int img = kt / tiles_per_img, p0 = (kt - img * tiles_per_img) * BK;
-        const float* ap = A + (long)img * a_bs + (long)(tile_m * BM + l_row) * HW + p0 + l_c * 4;
-        const float* bp = B + (long)img * b_bs + (long)(tile_n * BN + l_row) * HW + p0 + l_c * 4;
+        if constexpr (VA) {
+            load_virtual(A, a_bs, img, p0, ra);
+        } else {
+            const float* ap = A + (long)img * a_bs + (long)(tile_m * BM + l_row) * HW + p0 + l_c * 4;
 #pragma unroll
-        for (int j = 0; j < A_F4; ++j) ra[j] = *reinterpret_cast<const f32x4*>(ap + (long)j * 32 * HW);
+            for (int j = 0; j < A_F4; ++j) ra[j] = *reinterpret_cast<const f32x4*>(ap + (long)j * 32 * HW);
+        }
+        if constexpr (VB) {
+            load_virtual(B, b_bs, img, p0, rb);
+        } else {
+            const float* bp = B + (long)img * b_bs + (long)(tile_n * BN + l_row) * HW + p0 + l_c * 4;
 #pragma unroll
-        for (int j = 0; j < B_F4; ++j) rb[j] = *reinterpret_cast<const f32x4*>(bp + (long)j * 32 * HW);
+            for (int j = 0; j < B_F4; ++j) rb[j] = *reinterpret_cast<const f32x4*>(bp + (long)j * 32 * HW);
+        }
     };
     auto split4 = [](const f32x4& v, float pre, h4& hi, h4& lo) {      // (same bits as sh_split on v * pre)
 #pragma unroll
@@ -341,8 +382,12 @@ size_t wgrad_mfma_partial_floats(int Mpad, int Npad, int N, int HW) {
 }
 
 int launch_wgrad_mfma(const float* A, long a_bs, const float* B, long b_bs, float* partial, float* dw, int N, int HW,
-                      int Mpad, int Npad, int Mreal, int Nreal, int mode, hipStream_t s, float sh_scale, double* rowsum) {
+                      int Mpad, int Npad, int Mreal, int Nreal, int mode, hipStream_t s, float sh_scale, double* rowsum,
+                      const WgradTaps* taps) {
     GH_REQUIRE(!rowsum || sh_scale > 0.f, "wgrad_mfma: row sums only on the split-half kernel");
+    GH_REQUIRE(!taps || (sh_scale > 0.f && taps->H * taps->W == HW && taps->W >= 4 && (taps->W & (taps->W - 1)) == 0 &&
+                         (taps->operand == 0 || taps->operand == 1)),
+               "wgrad_mfma: virtual operand needs the split-half kernel and a power-of-two width >= 4");
     GH_REQUIRE(wgrad_mfma_supported(HW, Mpad, Npad), "wgrad_mfma: unsupported shape");
     if (N == 0) return GLOWHIP_OK;
     const bool bn128 = Npad % 128 == 0;
@@ -351,12 +396,20 @@ int launch_wgrad_mfma(const float* A, long a_bs, const float* B, long b_bs, floa
     int splits = std::max(1, std::min(total, (512 + tiles - 1) / tiles));   // 2 workgroups per CU
     const int per = (total + splits - 1) / splits;
     splits = (total + per - 1) / per;
-    if (sh_scale > 0.f && bn128)       // f16 matrix pipe, split-half operands (sh_scale = power-of-two pre-scale of the gradient operand)
-        hipLaunchKernelGGL(k_wgrad_gemm_sh<128>, dim3(tiles * splits), dim3(256), 0, s, A, a_bs, B, b_bs, partial, HW, Mpad, Npad,
-                           total, per, sh_scale, rowsum);
-    else if (sh_scale > 0.f)
-        hipLaunchKernelGGL(k_wgrad_gemm_sh<64>, dim3(tiles * splits), dim3(256), 0, s, A, a_bs, B, b_bs, partial, HW, Mpad, Npad,
-                           total, per, sh_scale, rowsum);
+    const int vC = taps ? taps->C : 0, vH = taps ? taps->H : 0, vW = taps ? taps->W : 1, vs = taps ? taps->sign : 0;
+#define GH_WG(bn, va, vb)                                                                                                      \
+    hipLaunchKernelGGL((k_wgrad_gemm_sh<bn, va, vb>), dim3(tiles * splits), dim3(256), 0, s, A, a_bs, B, b_bs, partial, HW, Mpad, \
+                       Npad, total, per, sh_scale, rowsum, vC, vH, vW, vs)
+    if (sh_scale > 0.f && bn128) {     // f16 matrix pipe, split-half operands (sh_scale = power-of-two pre-scale of the gradient operand)
+        if (taps && taps->operand == 0) GH_WG(128, true, false);
+        else if (taps) GH_WG(128, false, true);
+        else GH_WG(128, false, false);
+    } else if (sh_scale > 0.f) {
+        if (taps && taps->operand == 0) GH_WG(64, true, false);
+        else if (taps) GH_WG(64, false, true);
+        else GH_WG(64, false, false);
+    }
+#undef GH_WG
     else if (bn128)
         hipLaunchKernelGGL(k_wgrad_gemm<128>, dim3(tiles * splits), dim3(256), 0, s, A, a_bs, B, b_bs, partial, HW, Mpad, Npad,
                            total, per);
