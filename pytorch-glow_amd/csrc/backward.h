@@ -60,10 +60,15 @@ size_t wgrad_mfma_partial_floats(int Mpad, int Npad, int N, int HW);
 // operand (0: A, 1: B) of launch_wgrad_mfma given as the (N, C, H, W) tensor whose shift-expanded rows (c * 9 + tap) it stands for
 // (what launch_shift_expand would write): the GEMM's loader gathers them itself.  The operand pointer / batch stride are the tensor's.
 struct WgradTaps { int operand, C, H, W, sign; };
+struct WgradReduceJob;
 int launch_wgrad_mfma(const float* A, long a_bs, const float* B, long b_bs, float* partial, float* dw, int N, int HW,
                       int Mpad, int Npad, int Mreal, int Nreal, int mode, hipStream_t s, float sh_scale = 0.f,   // sh_scale > 0: f16-pipe kernel, gradient operand A pre-scaled by it
                       double* rowsum = nullptr,    // (f16-pipe kernel) rowsum[m] += sum over all pixels of A's row m -- the bias gradient when A = g_u
-                      const WgradTaps* taps = nullptr);
+                      const WgradTaps* taps = nullptr,
+                      struct WgradReduceJob* defer = nullptr);   // non-null: skip the split-K reduction, describe it in *defer instead
+struct WgradReduceJob { const float* partial; float* dw; int splits, Mpad, Npad, Mreal, Nreal, mode; };
+struct WgradReduceJobs { WgradReduceJob job[3]; int n; };
+int launch_wgrad_reduce_batched(const WgradReduceJobs& j, hipStream_t s);
 
 // one launch for all reduction-type parameter gradients of a backward sweep
 struct GradJob {

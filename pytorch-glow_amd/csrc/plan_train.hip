@@ -53,6 +53,7 @@ struct TrainWs {
     float* gA; float* gB; float* gh1; float* gh2; float* gpre; float* wT; double* dacc;
     float* gsh;                   // split-half copy of a hidden-layer gradient (input of the f16-pipe dgrad GEMM) / of h1 (forward)
     float* col; float* partial;   // shift-expanded small operand / split-K partial tiles of the MFMA weight gradients
+    size_t partial_floats;        // floats of ONE of the three split-K partial regions behind `partial`
     GradJob* jobs;                // device copy of the finalize job table (<= 9 per layer)
     LogsJob* ljobs;               // ... and of the log-scale job table (<= 2 per layer)
     size_t dacc_doubles;
@@ -146,11 +147,11 @@ static size_t train_ws_layout(const glowhip_plan* p, int N, void* base, TrainWs*
     const size_t o_dacc = take(off, nd * 8);
     size_t colf, partf;
     wgrad_scratch_floats(p, N, &colf, &partf);
-    const size_t o_col = take(off, colf * 4), o_part = take(off, partf * 4);
+    const size_t o_col = take(off, colf * 4), o_part = take(off, 3 * partf * 4);      // three regions: a FlowStep's three GEMMs, reduced together
     const size_t o_jobs = take(off, p->layers.size() * 9 * sizeof(GradJob));
     const size_t o_ljobs = take(off, p->layers.size() * 2 * sizeof(LogsJob));
     if (w && base) {
-        w->col = at<float>(base, o_col); w->partial = at<float>(base, o_part); w->jobs = at<GradJob>(base, o_jobs); w->ljobs = at<LogsJob>(base, o_ljobs);
+        w->col = at<float>(base, o_col); w->partial = at<float>(base, o_part); w->partial_floats = partf; w->jobs = at<GradJob>(base, o_jobs); w->ljobs = at<LogsJob>(base, o_ljobs);
         w->acc = at<unsigned long long>(base, o_acc); w->gld = at<float>(base, o_gld); w->gsum = at<double>(base, o_gsum);
         w->gA = at<float>(base, o_gA); w->gB = at<float>(base, o_gB); w->gh1 = at<float>(base, o_h1);
         w->gh2 = at<float>(base, o_h2); w->gpre = at<float>(base, o_gpre); w->wT = at<float>(base, o_wT);
@@ -390,13 +391,15 @@ static int backward_sweep(glowhip_plan* p, const void* packed, const float* x_in
                 // (the 3x3 layers' shift-expanded operands are gathered by the GEMM's loader: WgradTaps)
                 const bool vtaps = d.W >= 4 && (d.W & (d.W - 1)) == 0;
                 const WgradTaps t4{0, L.Cout, d.H, d.W, -1}, t0{1, Ch, d.H, d.W, +1};
+                WgradReduceJobs rj{};      // the three split-K reductions of this step run as one launch at its end
+                rj.n = 3;
                 if (vtaps) {
                     GH_TRY(launch_wgrad_mfma(w.gpre, (long)L.Cout * HW, h2, (long)hid * HW, w.partial, G.f4_w, N, HW, m4, hid,
-                                             L.Cout * 9, hid, 1, s, sh_grad_scale, nullptr, &t4));
+                                             L.Cout * 9, hid, 1, s, sh_grad_scale, nullptr, &t4, &rj.job[0]));
                 } else {
                     GH_TRY(launch_shift_expand(w.gpre, (long)L.Cout * HW, w.col, N, L.Cout, d.H, d.W, m4, -1, s));
                     GH_TRY(launch_wgrad_mfma(w.col, (long)m4 * HW, h2, (long)hid * HW, w.partial, G.f4_w, N, HW, m4, hid,
-                                             L.Cout * 9, hid, 1, s, sh_grad_scale));
+                                             L.Cout * 9, hid, 1, s, sh_grad_scale, nullptr, nullptr, &rj.job[0]));
                 }
                 CnetArgs c{};
                 c.w0 = at<char>(packed, L.cb_w0); c.w2 = at<char>(packed, L.cb_w2); c.w4 = at<char>(packed, L.cb_w4);
@@ -411,16 +414,17 @@ static int backward_sweep(glowhip_plan* p, const void* packed, const float* x_in
                 count_launch(p, "k_cnet(bwd)");
                 GH_TRY(launch_cnet_main(c, s, &pend));
                 GH_TRY(launch_cnet_bwd_finish(c, pend, g, chw, 1.0f / sh_grad_scale, s));
-                GH_TRY(launch_wgrad_mfma(w.gh2, (long)hid * HW, h1, (long)hid * HW, w.partial, G.f2_w, N, HW, hid, hid, hid, hid,
-                                         0, s, sh_grad_scale, a2b));
+                GH_TRY(launch_wgrad_mfma(w.gh2, (long)hid * HW, h1, (long)hid * HW, w.partial + w.partial_floats, G.f2_w, N, HW, hid, hid,
+                                         hid, hid, 0, s, sh_grad_scale, a2b, nullptr, &rj.job[1]));
                 if (vtaps) {
-                    GH_TRY(launch_wgrad_mfma(w.gh1, (long)hid * HW, out, chw, w.partial, G.f0_w, N, HW, hid, n0, hid,
-                                             Ch * 9, 0, s, sh_grad_scale, a0b, &t0));
+                    GH_TRY(launch_wgrad_mfma(w.gh1, (long)hid * HW, out, chw, w.partial + 2 * w.partial_floats, G.f0_w, N, HW, hid, n0,
+                                             hid, Ch * 9, 0, s, sh_grad_scale, a0b, &t0, &rj.job[2]));
                 } else {
                     GH_TRY(launch_shift_expand(out, chw, w.col, N, Ch, d.H, d.W, n0, +1, s));
-                    GH_TRY(launch_wgrad_mfma(w.gh1, (long)hid * HW, w.col, (long)n0 * HW, w.partial, G.f0_w, N, HW, hid, n0, hid,
-                                             Ch * 9, 0, s, sh_grad_scale, a0b));
+                    GH_TRY(launch_wgrad_mfma(w.gh1, (long)hid * HW, w.col, (long)n0 * HW, w.partial + 2 * w.partial_floats, G.f0_w, N, HW,
+                                             hid, n0, hid, Ch * 9, 0, s, sh_grad_scale, a0b, nullptr, &rj.job[2]));
                 }
+                GH_TRY(launch_wgrad_reduce_batched(rj, s));
                 if (G.f2_an_logs) p->logs_jobs.push_back(LogsJob{d.f2_w, G.f2_w, d.f2_an_bias, a2b, G.f2_an_logs, hid, hid});
                 if (G.f0_an_logs) p->logs_jobs.push_back(LogsJob{d.f0_w, G.f0_w, d.f0_an_bias, a0b, G.f0_an_logs, hid, Ch * 9});
                 ChanMixBwdArgs mb{xin, chw, g, g, chw, d.an_bias, at<float>(packed, L.an_scale),

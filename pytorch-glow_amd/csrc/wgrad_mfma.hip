@@ -341,8 +341,8 @@ k_wgrad_gemm_sh(const float* __restrict__ A, long a_bs, const float* __restrict_
 // dW[f(m, n)] = sum_split partial[split][m][n], splits added in order.
 //   mode 0: dW[m*Nreal + n]                      (f.2: [512][512];  f.0: [512][Ch*9] = dW0[o][i][tap] flat)
 //   mode 1: m = o*9 + tap, n = i: dW[(o*Nreal + i)*9 + tap]      (f.4: dW4[o][i][tap])
-__global__ void __launch_bounds__(256) k_wgrad_reduce(const float* __restrict__ partial, float* __restrict__ dw, int splits,
-                                                      int Mpad, int Npad, int Mreal, int Nreal, int mode) {
+__device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ partial, float* __restrict__ dw, int splits,
+                                                  int Mpad, int Npad, int Mreal, int Nreal, int mode) {
     // four consecutive columns per thread (Npad % 64 == 0: 16-byte loads), eight splits' loads in flight, added in split order
     const int n4 = (Nreal + 3) >> 2;
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
@@ -372,6 +372,27 @@ __global__ void __launch_bounds__(256) k_wgrad_reduce(const float* __restrict__ 
     }
 }
 
+__global__ void __launch_bounds__(256) k_wgrad_reduce(const float* __restrict__ partial, float* __restrict__ dw, int splits,
+                                                      int Mpad, int Npad, int Mreal, int Nreal, int mode) {
+    wgrad_reduce_body(partial, dw, splits, Mpad, Npad, Mreal, Nreal, mode);
+}
+
+// the reductions of up to three weight-gradient GEMMs in ONE launch (blockIdx.y = job): a FlowStep's three were three launches
+// of ~7 us each, mostly launch latency
+__global__ void __launch_bounds__(256) k_wgrad_reduce_batched(WgradReduceJobs j) {
+    const WgradReduceJob& r = j.job[blockIdx.y];
+    wgrad_reduce_body(r.partial, r.dw, r.splits, r.Mpad, r.Npad, r.Mreal, r.Nreal, r.mode);
+}
+
+int launch_wgrad_reduce_batched(const WgradReduceJobs& j, hipStream_t s) {
+    if (j.n == 0) return GLOWHIP_OK;
+    long blocks = 1;
+    for (int i = 0; i < j.n; ++i) blocks = std::max(blocks, (long)cdiv((long)j.job[i].Mreal * ((j.job[i].Nreal + 3) / 4), 256));
+    hipLaunchKernelGGL(k_wgrad_reduce_batched, dim3((unsigned)blocks, j.n), dim3(256), 0, s, j);
+    GH_LAUNCH_CHECK("k_wgrad_reduce_batched");
+    return GLOWHIP_OK;
+}
+
 bool wgrad_mfma_supported(int HW, int Mpad, int Npad) { return HW % 32 == 0 && Mpad % 128 == 0 && Npad % 64 == 0; }
 
 size_t wgrad_mfma_partial_floats(int Mpad, int Npad, int N, int HW) {
@@ -383,7 +404,7 @@ size_t wgrad_mfma_partial_floats(int Mpad, int Npad, int N, int HW) {
 
 int launch_wgrad_mfma(const float* A, long a_bs, const float* B, long b_bs, float* partial, float* dw, int N, int HW,
                       int Mpad, int Npad, int Mreal, int Nreal, int mode, hipStream_t s, float sh_scale, double* rowsum,
-                      const WgradTaps* taps) {
+                      const WgradTaps* taps, WgradReduceJob* defer) {
     GH_REQUIRE(!rowsum || sh_scale > 0.f, "wgrad_mfma: row sums only on the split-half kernel");
     GH_REQUIRE(!taps || (sh_scale > 0.f && taps->H * taps->W == HW && taps->W >= 4 && (taps->W & (taps->W - 1)) == 0 &&
                          (taps->operand == 0 || taps->operand == 1)),
@@ -417,6 +438,10 @@ int launch_wgrad_mfma(const float* A, long a_bs, const float* B, long b_bs, floa
         hipLaunchKernelGGL(k_wgrad_gemm<64>, dim3(tiles * splits), dim3(256), 0, s, A, a_bs, B, b_bs, partial, HW, Mpad, Npad,
                            total, per);
     GH_LAUNCH_CHECK("k_wgrad_gemm");
+    if (defer) {       // the caller reduces later (launch_wgrad_reduce_batched): `partial` must stay untouched until then
+        *defer = WgradReduceJob{partial, dw, splits, Mpad, Npad, Mreal, Nreal, mode};
+        return GLOWHIP_OK;
+    }
     hipLaunchKernelGGL(k_wgrad_reduce, dim3(cdiv((long)Mreal * ((Nreal + 3) / 4), 256)), dim3(256), 0, s, partial, dw, splits, Mpad, Npad,
                        Mreal, Nreal, mode);
     GH_LAUNCH_CHECK("k_wgrad_reduce");
