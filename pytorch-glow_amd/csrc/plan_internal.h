@@ -69,6 +69,7 @@ struct glowhip_plan {
     long max_chw = 0;      // max over layer inputs/outputs of C*H*W
     long max_hidden = 0;   // max over steps of max(hidden, Cout) * H*W
     int n_split = 0;
+    std::vector<char> tape_has_masks;          // per layer: the last glow_forward_train stored the ReLU sign bits (k_cnet MODE 1)
     std::vector<glowhip::LogsJob> logs_jobs;   // the same for the log-scale gradients derived from dW / db (backward.h)
     std::vector<glowhip::GradJob> grad_jobs;   // host copy of the last backward's finalize table (kept alive for the async copy)
     bool rng_on = false; unsigned long long rng_seed = 0, rng_calls = 0;   // in-kernel dequantisation noise (glowhip_plan_set_dequant_rng)

@@ -104,9 +104,10 @@ static bool g_train_cnet_bwd = true;   // testing hook: 0 = the input-gradient c
 void plan_train_disable_cnet_bwd(int off) { g_train_cnet_bwd = off == 0; }
 // ... and its input-gradient chain as one backward k_cnet launch?  Needs the taping forward (the sign bits) and all of the
 // coupling network's weight gradients requested (the log-scale gradients are derived from them).
-static bool bwd_cnet(const glowhip_plan* p, const LayerPlan& L, const glowhip_layer_grads& G, int N, size_t scratch_floats) {
+static bool bwd_cnet(const glowhip_plan* p, const LayerPlan& L, int li, const glowhip_layer_grads& G, int N, size_t scratch_floats) {
     const glowhip_layer_desc& d = L.d;
     return g_train_cnet_bwd && L.cnet_bwd && tape_cnet(p, L, N, scratch_floats) && G.f0_w && G.f2_w && G.f4_w &&
+           li < (int)p->tape_has_masks.size() && p->tape_has_masks[li] &&      // (the forward that filled this tape stored the sign bits)
            cnet_tape_supported(L.Cout, d.H, d.W, d.hidden, d.C / 2, N) &&
            cnet_scratch_floats(N, d.H, d.W, d.C / 2) <= scratch_floats;
 }
@@ -168,6 +169,7 @@ static int forward_train(glowhip_plan* p, const void* packed, const float* x, co
     const int nl = (int)p->layers.size();
     const size_t scratch_floats = (size_t)N * p->max_hidden;
     bool premixed = false;      // this step's ActNorm + permutation output is already in its tape slot (the previous step's finishing kernel)
+    p->tape_has_masks.assign(nl, 0);
     for (int li = 0; li < nl; ++li) {
         const LayerPlan& L = p->layers[li];
         const glowhip_layer_desc& d = L.d;
@@ -220,6 +222,7 @@ static int forward_train(glowhip_plan* p, const void* packed, const float* x, co
                         premixed = true;
                     }
                 }
+                p->tape_has_masks[li] = 1;
                 count_launch(p, "k_cnet(tape)");
                 GH_TRY(launch_cnet(c, s));
                 cur = dst;
@@ -383,7 +386,7 @@ static int backward_sweep(glowhip_plan* p, const void* packed, const float* x_in
             GH_TRY(launch_coupling_bwd(cb, s));
             // (b) f.4: weight gradient, then input gradient -> g_h2 (raw), then ReLU/ActNorm of f.2
             const bool fastw = wgrad_fast(L);
-            if (fastw && bwd_cnet(p, L, G, N, (size_t)N * p->max_hidden)) {
+            if (fastw && bwd_cnet(p, L, li, G, N, (size_t)N * p->max_hidden)) {
                 // The input-gradient chain g_pre -> g_u2 -> g_u0 -> d y1 as ONE k_cnet launch (MODE 2, cnet_sh.hip) on the transposed
                 // weight images, the ReLU masks from the tape's sign bits; the bias gradients are row sums inside the weight-gradient
                 // GEMMs that read g_u2 / g_u0 anyway, the log-scale gradients follow from dW and db (backward.h LogsJob).
