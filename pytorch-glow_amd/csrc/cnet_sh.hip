@@ -160,7 +160,8 @@ __device__ __forceinline__ long long block_sum_ll(long long v, long long* red) {
 // the h2 accumulators alive through P4 and cost the level-1 instance 88 bytes of spills)
 // MODE 1 (TAPE), the training forward (plan_train.hip): h1 and h2 also go to memory as fp32 (N, hidden, H, W), stored from the
 // epilogues (a lane holds one pixel x 4 consecutive channels: a wave store is two 128-byte runs of one channel each), and their
-// signs as bit masks (a lane's 16 accumulator registers of a 32-row tile = one 16-bit word; mask[(row tile * P + pixel) * 2 + kl]).
+// signs as bit masks (a lane's 16 accumulator registers of a 32-row tile = one 16-bit word, register k in bit 15 - k;
+// mask[(row tile * P + pixel) * 2 + kl]).
 // MODE 2 (BWD), the input-gradient chain of the same network (it has the same shape: 3x3 Cout -> hidden with f.4's transposed
 // weights, 1x1 hidden -> hidden with f.2's, 3x3 hidden -> C/2 with f.0's): x = d L / d(f.4 output), the "activation" of the
 // first two layers is  g_u = g_h * (h > 0) * exp(3 logs)  (the scale folded into the weight image's rows, the mask from the
@@ -626,9 +627,11 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
 #pragma unroll
                         for (int t = 0; t < 4; ++t) {
                             const float tt = fmaf(acc1[i][j][4 * gq + t], rs[t], bb[t]);
-                            if (BWD) v[t] = (mb[j] >> (4 * gq + t)) & 1u ? tt : 0.f;      // (-g_u2, scaled: tables as in the forward)
+                            if (BWD) v[t] = (mb[j] >> (15 - (4 * gq + t))) & 1u ? tt : 0.f;      // (-g_u2, scaled: tables as in the forward)
                             else v[t] = nrelu_bits(tt);
-                            if (TAPE) mb[j] |= (v[t] < 0.f ? 1u : 0u) << (4 * gq + t);
+                            // sign word: value k = 4 gq + t ends up in bit 15 - k (one v_alignbit per value: the word shifted left
+                            // by one, the sign bit of -h -- set exactly where h > 0 -- shifted in)
+                            if (TAPE) mb[j] = __builtin_amdgcn_alignbit(mb[j], __float_as_uint(v[t]), 31);
                         }
                         sh2_split4<MIXSPLIT>(v, hi, lo);
                         _Float16* dst = hbuf + ((long)chunk * PXT + (pt1 + sp * PTSV + j) * 32 + ml) * 8 + 4 * kl;
@@ -639,7 +642,7 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
                             if (px0 < P_all && (MS == 1 || (o >= ms_row0 && o < ms_row0 + MR))) {
                                 float* tb = a.tape_h1 + (((px0 >> g.lhw) * HID) << g.lhw) + (px0 & (HW - 1));
 #pragma unroll
-                                for (int t = 0; t < 4; ++t) tb[((o + t) << g.lhw) + ml] = -v[t] * a.out_scale;
+                                for (int t = 0; t < 4; ++t) __builtin_nontemporal_store(-v[t] * a.out_scale, tb + ((o + t) << g.lhw) + ml);
                             }
                         }
                     }
@@ -798,16 +801,16 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const float tt = fmaf(acc2[i][j][4 * gq + t], rs[t], bb[t]);
-                    if (BWD) acc2[i][j][4 * gq + t] = (mw2[STORE ? i : 0][STORE ? j : 0] >> (4 * gq + t)) & 1u ? tt : 0.f;
+                    if (BWD) acc2[i][j][4 * gq + t] = (mw2[STORE ? i : 0][STORE ? j : 0] >> (15 - (4 * gq + t))) & 1u ? tt : 0.f;
                     else acc2[i][j][4 * gq + t] = nrelu_bits(tt);
-                    if (TAPE) mw2[STORE ? i : 0][STORE ? j : 0] |= (acc2[i][j][4 * gq + t] < 0.f ? 1u : 0u) << (4 * gq + t);
+                    if (TAPE) mw2[STORE ? i : 0][STORE ? j : 0] = __builtin_amdgcn_alignbit(mw2[STORE ? i : 0][STORE ? j : 0], __float_as_uint(acc2[i][j][4 * gq + t]), 31);
                 }
                 if (STORE) {
                     const long px0 = gp0 + (pt2 + j) * 32;
                     if (px0 < P_all) {
                         float* tb = a.tape_h2 + (((px0 >> g.lhw) * HID) << g.lhw) + (px0 & (HW - 1));
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) tb[((ms_row0 + o + t) << g.lhw) + ml] = -acc2[i][j][4 * gq + t] * a.out_scale;
+                        for (int t = 0; t < 4; ++t) __builtin_nontemporal_store(-acc2[i][j][4 * gq + t] * a.out_scale, tb + ((ms_row0 + o + t) << g.lhw) + ml);
                     }
                 }
             }
