@@ -169,6 +169,16 @@ __device__ __forceinline__ long long block_sum_ll(long long v, long long* red) {
 template <int HID, int MS, int UPW, int PXT, bool PRE, int NG = 1, int MODE = 0>
 __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
     constexpr bool TAPE = MODE == 1, BWD = MODE == 2, STORE = MODE != 0;
+#ifdef CN_DBG_NOF32
+    constexpr bool F32ST = false;       // (timing experiments only: the fp32 tensors are not stored)
+#else
+    constexpr bool F32ST = STORE;
+#endif
+#ifdef CN_DBG_NOMASK
+    constexpr bool MSKST = false;       // (timing experiments only: the sign words are not stored)
+#else
+    constexpr bool MSKST = TAPE;
+#endif
     const long P_all = (long)a.N * g.HW;          // pixels of the batch (row stride of the bit masks)
     const bool pre_on = PRE && a.pre_on;
     constexpr int NPT = PXT / 32;                    // pixel tiles of the workgroup: 4 (128 pixels) or 2 (64 pixels)
@@ -609,53 +619,72 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
                 GH_STAMP(5 + 4 * (hh - 1));
             }
             // -relu (sh.h nrelu_bits), split, store into the B-operand image: a lane's 4 consecutive channels = 8 bytes per plane
+            // one 32 x 32 tile's group gq of four rows; mbw: the tile's sign word (read in BWD, built in TAPE)
+            auto p1_group = [&](int i, int j, int gq, unsigned& mbw) {
+                const int o = hh * HK + (rt1 + i) * 32 + 8 * gq + 4 * kl;
+                const f32x4_t rs = *reinterpret_cast<const f32x4_t*>(t_rs0 + o);
+                const f32x4_t bb = *reinterpret_cast<const f32x4_t*>(t_b0 + o);
+                const int chunk = (rt1 + i) * 4 + gq;
+                h4 hi, lo;
+                f32x4_t v;
 #pragma unroll
-            for (int i = 0; i < RT1; ++i) {
-                unsigned mb[PTSV];
+                for (int t = 0; t < 4; ++t) {
+                    const float tt = fmaf(acc1[i][j][4 * gq + t], rs[t], bb[t]);
+                    if (BWD) v[t] = (mbw >> (15 - (4 * gq + t))) & 1u ? tt : 0.f;      // (-g_u2, scaled: tables as in the forward)
+                    else v[t] = nrelu_bits(tt);
+                    // sign word: value k = 4 gq + t ends up in bit 15 - k (one v_alignbit per value: the word shifted left by
+                    // one, the sign bit of -h -- set exactly where h > 0 -- shifted in)
+                    if (TAPE) mbw = __builtin_amdgcn_alignbit(mbw, __float_as_uint(v[t]), 31);
+                }
+                sh2_split4<MIXSPLIT>(v, hi, lo);
+                _Float16* dst = hbuf + ((long)chunk * PXT + (pt1 + sp * PTSV + j) * 32 + ml) * 8 + 4 * kl;
+                *reinterpret_cast<h4*>(dst) = hi;
+                *reinterpret_cast<h4*>(dst + (long)NCH * PXT * 8) = lo;
+                if (F32ST) {     // (with a row split every workgroup computes all of these rows: each stores its own rows' share)
+                    const long px0 = gp0 + (pt1 + sp * PTSV + j) * 32;
+                    if (px0 < P_all && (MS == 1 || (o >= ms_row0 && o < ms_row0 + MR))) {
+                        float* tb = a.tape_h1 + (((px0 >> g.lhw) * HID) << g.lhw) + (px0 & (HW - 1));
 #pragma unroll
-                for (int j = 0; j < PTSV; ++j) mb[j] = BWD ? mw1[i][j] : 0u;
+                        for (int t = 0; t < 4; ++t) __builtin_nontemporal_store(-v[t] * a.out_scale, tb + ((o + t) << g.lhw) + ml);
+                    }
+                }
+            };
+            if (!STORE) {        // product kernel: row groups outermost (the tables are read once per group)
 #pragma unroll
-                for (int gq = 0; gq < 4; ++gq) {
-                    const int o = hh * HK + (rt1 + i) * 32 + 8 * gq + 4 * kl;
-                    const f32x4_t rs = *reinterpret_cast<const f32x4_t*>(t_rs0 + o);
-                    const f32x4_t bb = *reinterpret_cast<const f32x4_t*>(t_b0 + o);
-                    const int chunk = (rt1 + i) * 4 + gq;
+                for (int i = 0; i < RT1; ++i)
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        const int o = hh * HK + (rt1 + i) * 32 + 8 * gq + 4 * kl;
+                        const f32x4_t rs = *reinterpret_cast<const f32x4_t*>(t_rs0 + o);
+                        const f32x4_t bb = *reinterpret_cast<const f32x4_t*>(t_b0 + o);
+                        const int chunk = (rt1 + i) * 4 + gq;
+#pragma unroll
+                        for (int j = 0; j < PTSV; ++j) {
+                            h4 hi, lo;
+                            f32x4_t v;
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) v[t] = nrelu_bits(fmaf(acc1[i][j][4 * gq + t], rs[t], bb[t]));
+                            sh2_split4<MIXSPLIT>(v, hi, lo);
+                            _Float16* dst = hbuf + ((long)chunk * PXT + (pt1 + sp * PTSV + j) * 32 + ml) * 8 + 4 * kl;
+                            *reinterpret_cast<h4*>(dst) = hi;
+                            *reinterpret_cast<h4*>(dst + (long)NCH * PXT * 8) = lo;
+                        }
+                    }
+            } else {             // taping / backward: tile by tile, one sign word live at a time
+#pragma unroll
+                for (int i = 0; i < RT1; ++i)
 #pragma unroll
                     for (int j = 0; j < PTSV; ++j) {
-                        h4 hi, lo;
-                        f32x4_t v;
+                        unsigned mbw = BWD ? mw1[BWD ? i : 0][BWD ? j : 0] : 0u;
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) {
-                            const float tt = fmaf(acc1[i][j][4 * gq + t], rs[t], bb[t]);
-                            if (BWD) v[t] = (mb[j] >> (15 - (4 * gq + t))) & 1u ? tt : 0.f;      // (-g_u2, scaled: tables as in the forward)
-                            else v[t] = nrelu_bits(tt);
-                            // sign word: value k = 4 gq + t ends up in bit 15 - k (one v_alignbit per value: the word shifted left
-                            // by one, the sign bit of -h -- set exactly where h > 0 -- shifted in)
-                            if (TAPE) mb[j] = __builtin_amdgcn_alignbit(mb[j], __float_as_uint(v[t]), 31);
-                        }
-                        sh2_split4<MIXSPLIT>(v, hi, lo);
-                        _Float16* dst = hbuf + ((long)chunk * PXT + (pt1 + sp * PTSV + j) * 32 + ml) * 8 + 4 * kl;
-                        *reinterpret_cast<h4*>(dst) = hi;
-                        *reinterpret_cast<h4*>(dst + (long)NCH * PXT * 8) = lo;
-                        if (STORE) {     // (with a row split every workgroup computes all of these rows: each stores its own rows' share)
+                        for (int gq = 0; gq < 4; ++gq) p1_group(i, j, gq, mbw);
+                        if (MSKST) {
+                            const int R = hh * (HK / 32) + rt1 + i;
                             const long px0 = gp0 + (pt1 + sp * PTSV + j) * 32;
-                            if (px0 < P_all && (MS == 1 || (o >= ms_row0 && o < ms_row0 + MR))) {
-                                float* tb = a.tape_h1 + (((px0 >> g.lhw) * HID) << g.lhw) + (px0 & (HW - 1));
-#pragma unroll
-                                for (int t = 0; t < 4; ++t) __builtin_nontemporal_store(-v[t] * a.out_scale, tb + ((o + t) << g.lhw) + ml);
-                            }
+                            if (px0 < P_all && (MS == 1 || (R * 32 >= ms_row0 && R * 32 < ms_row0 + MR)))
+                                a.mask1[((long)R * P_all + px0 + ml) * 2 + kl] = (unsigned short)mbw;
                         }
                     }
-                }
-                if (TAPE) {
-                    const int R = hh * (HK / 32) + rt1 + i;
-#pragma unroll
-                    for (int j = 0; j < PTSV; ++j) {
-                        const long px0 = gp0 + (pt1 + sp * PTSV + j) * 32;
-                        if (px0 < P_all && (MS == 1 || (R * 32 >= ms_row0 && R * 32 < ms_row0 + MR)))
-                            a.mask1[((long)R * P_all + px0 + ml) * 2 + kl] = (unsigned short)mb[j];
-                    }
-                }
             }
         }
     };
@@ -774,55 +803,60 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
     }
 
     // ---- -h2 = -relu(t2), t2 = true sum * rowscale + bias (times SH2_ACT_SCALE), in place (the accumulators hold the negated sum)
-    unsigned mw2[STORE ? RT2 : 1][STORE ? PT2 : 1];
-    if (BWD) {          // sign words of h1 for this wave's block
+    auto p2_group = [&](int i, int j, int gq, unsigned& mbw) {
+        const int o = (rt2 + i) * 32 + 8 * gq + 4 * kl;           // workgroup-local row
+        const f32x4_t rs = *reinterpret_cast<const f32x4_t*>(t_rs2 + o);
+        const f32x4_t bb = *reinterpret_cast<const f32x4_t*>(t_b2 + o);
 #pragma unroll
-        for (int i = 0; i < RT2; ++i)
+        for (int t = 0; t < 4; ++t) {
+            const float tt = fmaf(acc2[i][j][4 * gq + t], rs[t], bb[t]);
+            if (BWD) acc2[i][j][4 * gq + t] = (mbw >> (15 - (4 * gq + t))) & 1u ? tt : 0.f;
+            else acc2[i][j][4 * gq + t] = nrelu_bits(tt);
+            if (TAPE) mbw = __builtin_amdgcn_alignbit(mbw, __float_as_uint(acc2[i][j][4 * gq + t]), 31);
+        }
+        if (F32ST) {
+            const long px0 = gp0 + (pt2 + j) * 32;
+            if (px0 < P_all) {
+                float* tb = a.tape_h2 + (((px0 >> g.lhw) * HID) << g.lhw) + (px0 & (HW - 1));
 #pragma unroll
-            for (int j = 0; j < PT2; ++j) {
-                const long px = min(gp0 + (pt2 + j) * 32 + ml, P_all - 1);
-                mw2[STORE ? i : 0][STORE ? j : 0] = a.mask1[((long)(ms_row0 / 32 + rt2 + i) * P_all + px) * 2 + kl];
-            }
-    } else if (TAPE) {
-#pragma unroll
-        for (int i = 0; i < RT2; ++i)
-#pragma unroll
-            for (int j = 0; j < PT2; ++j) mw2[STORE ? i : 0][STORE ? j : 0] = 0u;
-    }
-#pragma unroll
-    for (int i = 0; i < RT2; ++i)
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-            const int o = (rt2 + i) * 32 + 8 * gq + 4 * kl;           // workgroup-local row
-            const f32x4_t rs = *reinterpret_cast<const f32x4_t*>(t_rs2 + o);
-            const f32x4_t bb = *reinterpret_cast<const f32x4_t*>(t_b2 + o);
-#pragma unroll
-            for (int j = 0; j < PT2; ++j) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const float tt = fmaf(acc2[i][j][4 * gq + t], rs[t], bb[t]);
-                    if (BWD) acc2[i][j][4 * gq + t] = (mw2[STORE ? i : 0][STORE ? j : 0] >> (15 - (4 * gq + t))) & 1u ? tt : 0.f;
-                    else acc2[i][j][4 * gq + t] = nrelu_bits(tt);
-                    if (TAPE) mw2[STORE ? i : 0][STORE ? j : 0] = __builtin_amdgcn_alignbit(mw2[STORE ? i : 0][STORE ? j : 0], __float_as_uint(acc2[i][j][4 * gq + t]), 31);
-                }
-                if (STORE) {
-                    const long px0 = gp0 + (pt2 + j) * 32;
-                    if (px0 < P_all) {
-                        float* tb = a.tape_h2 + (((px0 >> g.lhw) * HID) << g.lhw) + (px0 & (HW - 1));
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) __builtin_nontemporal_store(-acc2[i][j][4 * gq + t] * a.out_scale, tb + ((ms_row0 + o + t) << g.lhw) + ml);
-                    }
-                }
+                for (int t = 0; t < 4; ++t)
+                    __builtin_nontemporal_store(-acc2[i][j][4 * gq + t] * a.out_scale, tb + ((ms_row0 + o + t) << g.lhw) + ml);
             }
         }
-    if (TAPE) {
+    };
+    if (!STORE) {
+#pragma unroll
+        for (int i = 0; i < RT2; ++i)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int o = (rt2 + i) * 32 + 8 * gq + 4 * kl;           // workgroup-local row
+                const f32x4_t rs = *reinterpret_cast<const f32x4_t*>(t_rs2 + o);
+                const f32x4_t bb = *reinterpret_cast<const f32x4_t*>(t_b2 + o);
+#pragma unroll
+                for (int j = 0; j < PT2; ++j)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc2[i][j][4 * gq + t] = nrelu_bits(fmaf(acc2[i][j][4 * gq + t], rs[t], bb[t]));
+            }
+    } else {
+        // taping / backward: tile by tile -- BWD requests a tile's sign word of h1 one tile ahead
+        unsigned mnext = 0u;
+        auto load_m = [&](int i, int j) {
+            const long px = min(gp0 + (pt2 + j) * 32 + ml, P_all - 1);
+            return (unsigned)a.mask1[((long)(ms_row0 / 32 + rt2 + i) * P_all + px) * 2 + kl];
+        };
+        if (BWD) mnext = load_m(0, 0);
 #pragma unroll
         for (int i = 0; i < RT2; ++i)
 #pragma unroll
             for (int j = 0; j < PT2; ++j) {
-                const long px0 = gp0 + (pt2 + j) * 32;
-                if (px0 < P_all)
-                    a.mask2[((long)(ms_row0 / 32 + rt2 + i) * P_all + px0 + ml) * 2 + kl] = (unsigned short)mw2[STORE ? i : 0][STORE ? j : 0];
+                unsigned mbw = BWD ? mnext : 0u;
+                if (BWD && (i * PT2 + j + 1 < RT2 * PT2)) mnext = load_m((i * PT2 + j + 1) / PT2, (i * PT2 + j + 1) % PT2);
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) p2_group(i, j, gq, mbw);
+                if (MSKST) {
+                    const long px0 = gp0 + (pt2 + j) * 32;
+                    if (px0 < P_all) a.mask2[((long)(ms_row0 / 32 + rt2 + i) * P_all + px0 + ml) * 2 + kl] = (unsigned short)mbw;
+                }
             }
     }
     GH_STAMP(10);
