@@ -163,6 +163,60 @@ def test_gradients_at_celeba_geometry_vs_autograd_oracle():
         f"dL/dx err {egx.max().item():.3e} vs max|g| {gscale:.3e}"
 
 
+@pytest.mark.parametrize("coup,perm,hidden", [("additive", "reverse", 512), ("additive", "shuffle", 256), ("affine", "invconv", 256)])
+def test_k_cnet_training_step_other_couplings_and_widths_vs_autograd_oracle(coup, perm, hidden):
+    """The taping / backward k_cnet launches beyond the headline's affine + invconv at hidden 512: additive coupling (f.4 has C/2
+    output channels, so the backward launch's first layer has C/2 inputs and its last C/2 outputs), permutations without a
+    matrix, hidden 256.  Every gradient against autograd through the fp64 oracle; the kernels asserted from the launch counters."""
+    K, batch = 2, 4
+    cfg = O.default_cfg(K=K, batch=batch, hidden_channels=hidden, flow_coupling=coup, flow_permutation=perm)
+    np.random.seed(3)
+    glow = G.Glow(hps_for(cfg, batch))
+    g = torch.Generator().manual_seed(29)
+    sd = {k: v.detach().clone() for k, v in glow.state_dict().items()}
+    for k in sd:
+        if k == "h_top" or not sd[k].is_floating_point():
+            continue
+        if k.endswith("invconv.weight"):
+            c = sd[k].shape[0]
+            sd[k] = torch.from_numpy(np.linalg.qr(np.random.randn(c, c))[0].astype("float32")) + 0.02 * torch.randn(c, c, generator=g)
+        elif k.endswith("logs") or k.endswith("bias"):
+            sd[k] = torch.randn(sd[k].shape, generator=g) * 0.1
+        elif ".f.4." in k or "conv2d_zeros" in k:
+            sd[k] = torch.randn(sd[k].shape, generator=g) * 0.01
+        elif ".f.2." in k:
+            sd[k] = torch.randn(sd[k].shape, generator=g) * (1.0 / hidden) ** 0.5
+        else:
+            sd[k] = torch.randn(sd[k].shape, generator=g) * 0.1
+    glow.load_state_dict(sd)
+    glow.set_actnorm_inited()
+    tables = None
+    if perm != "invconv":
+        tables = {i: (getattr(l, perm).indices, getattr(l, perm).indices_inverse)
+                  for i, l in enumerate(glow.flow.layers) if hasattr(l, perm)}
+    glow = glow.to(DEV).train()
+    x = torch.rand(batch, 3, 64, 64, generator=g)
+    noise = torch.rand(batch, 3, 64, 64, generator=g) / 256
+    ref, _, loss_ref = oracle_grads(cfg, {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}, x.double(), noise.double(),
+                                    tables)
+    with torch.enable_grad():
+        z, nll, _ = glow.normal_flow(x.to(DEV), None, noise=noise.to(DEV))
+        loss = G.Glow.generative_loss(nll)
+        loss.backward()
+    counts = glow.flow.plan_for(x.to(DEV)).launch_counts()
+    assert counts.get("k_cnet(tape)", 0) == 3 * K and counts.get("k_cnet(bwd)", 0) == 3 * K, counts
+    assert abs(loss.item() - loss_ref) < 1e-4
+    for name, p in glow.named_parameters():
+        if name == "h_top" or p.grad is None:
+            continue
+        r = ref[name]
+        err = (p.grad.cpu().double() - r).abs()
+        scale = r.abs().max().item()
+        outliers = (err > 2e-4 * scale + 1e-7).double().mean().item()
+        assert outliers <= 0.01, f"{name}: {outliers:.2%} of the entries off by more than 2e-4 of max|g| = {scale:.3e}"
+        assert err.max().item() <= 0.05 * scale + 1e-7, f"{name}: max err {err.max().item():.3e}, max|g| {scale:.3e}"
+
+
 def test_log_scale_gradients_from_dw_with_dominant_actnorm_biases():
     """The backward k_cnet path derives d logs of the hidden ActNorms from the weight and bias gradients,
     d logs[r] = 3 (<W[r], dW[r]> + b[r] db[r]), instead of a pass over the activations.  The two terms cancel when |b| is large
