@@ -431,12 +431,14 @@ int launch_act_bwd(float* g, const float* h, const float* e, int N, int Cm, int 
 // pair-by-pair over the 64 pixels and added with one fp64 atomic per pair per workgroup.
 // ------------------------------------------------------------------------------------------------
 constexpr int CB_PX = 64;
+constexpr int CB_LD = CB_PX + 1;    // LDS row stride: the reductions below read one COLUMN q of many rows per instruction -- with a stride of
+                                    // 64 words every lane hit the same bank (64-way conflicts: 41 us per launch at C = 48)
 __global__ void __launch_bounds__(256) k_chanmix_bwd(ChanMixBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int C = a.C;
     float* v = sm;                   // [C][64]
-    float* gy = sm + C * CB_PX;      // [C][64]
-    float* gv = gy + C * CB_PX;      // [C][64]
+    float* gy = sm + C * CB_LD;      // [C][64 (+1)]
+    float* gv = gy + C * CB_LD;      // [C][64 (+1)]
     const int px = threadIdx.x & (CB_PX - 1);
     const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // wave-uniform: the matrix element W[o][i] of the g_v loop
                                                                            // below is then a scalar load (it was a vector load per
@@ -452,19 +454,19 @@ __global__ void __launch_bounds__(256) k_chanmix_bwd(ChanMixBwdArgs a) {
             xv = (a.x[n * a.x_bs + (long)c * a.HW + p] + a.bias[c]) * a.scale[c];
             g = a.gy[n * a.g_bs + (long)c * a.HW + p];
         }
-        v[c * CB_PX + px] = xv;
-        gy[c * CB_PX + px] = g;
+        v[c * CB_LD + px] = xv;
+        gy[c * CB_LD + px] = g;
     }
     __syncthreads();
     // g_v = W^T g_y : g_v[i] = sum_o W[o][i] g_y[o]   (gather: g_v[idx[o]] = g_y[o])
     for (int i = grp; i < C; i += 4) {
         float r = 0.f;
         if (a.matrix) {
-            for (int o = 0; o < C; ++o) r = fmaf(a.matrix[o * C + i], gy[o * CB_PX + px], r);
+            for (int o = 0; o < C; ++o) r = fmaf(a.matrix[o * C + i], gy[o * CB_LD + px], r);
         } else {
-            r = gy[(a.gather_inv ? a.gather_inv[i] : i) * CB_PX + px];
+            r = gy[(a.gather_inv ? a.gather_inv[i] : i) * CB_LD + px];
         }
-        gv[i * CB_PX + px] = r;
+        gv[i * CB_LD + px] = r;
         if (valid) a.gx[n * a.g_bs + (long)i * a.HW + p] = r * a.scale[i];
     }
     __syncthreads();
@@ -476,15 +478,15 @@ __global__ void __launch_bounds__(256) k_chanmix_bwd(ChanMixBwdArgs a) {
             const int o = pair / C, i = pair - o * C;
             float s = 0.f;
 #pragma unroll 8
-            for (int q = 0; q < CB_PX; ++q) s = fmaf(gy[o * CB_PX + q], v[i * CB_PX + q], s);
+            for (int q = 0; q < CB_PX; ++q) s = fmaf(gy[o * CB_LD + q], v[i * CB_LD + q], s);
             atomic_add_f64(a.acc_w + aco + pair, (double)s);
         }
     }
     for (int c = tid; c < C; c += 256) {
         float sb = 0.f, sl = 0.f;
         for (int q = 0; q < CB_PX; ++q) {
-            sb = fmaf(gv[c * CB_PX + q], a.scale[c], sb);
-            sl = fmaf(gv[c * CB_PX + q], v[c * CB_PX + q], sl);
+            sb = fmaf(gv[c * CB_LD + q], a.scale[c], sb);
+            sl = fmaf(gv[c * CB_LD + q], v[c * CB_LD + q], sl);
         }
         atomic_add_f64(a.acc_b + aco + c, (double)sb);
         atomic_add_f64(a.acc_l + aco + c, (double)sl * 3.0);
@@ -495,7 +497,7 @@ int launch_chanmix_bwd(const ChanMixBwdArgs& a, hipStream_t s) {
     GH_REQUIRE(a.C > 0 && a.C <= 192, "chanmix backward: C=%d unsupported (1..192)", a.C);
     const long total = (long)a.N * a.HW;
     if (total == 0) return GLOWHIP_OK;
-    const size_t lds = (size_t)3 * a.C * CB_PX * sizeof(float);
+    const size_t lds = (size_t)3 * a.C * CB_LD * sizeof(float);
     if (lds > 32 * 1024)
         (void)hipFuncSetAttribute((const void*)k_chanmix_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k_chanmix_bwd, dim3(cdiv(total, CB_PX)), dim3(256), lds, s, a);
