@@ -44,6 +44,10 @@ struct ChanMixBwdArgs {
     // finalize job sums them): 1024 workgroups x (C^2 + 2C) fp64 atomics on ten cache lines ran at the rate of those lines'
     // L2 channels (35 us per launch, whatever the level)
     int acc_copies = 1; long acc_stride = 0;
+    // add_part != null: the gradient of y's FIRST add_C channels is gy + add_scale * (the partial sums a backward k_cnet launch left
+    // in add_part: MS row-split copies + halo rows, geometry add_*) -- gathered here instead of by a k_cbwd_finish launch
+    const float* add_part = nullptr; float add_scale = 0.f;
+    int add_C = 0, add_MS = 0, add_tiles = 0, add_R = 0, add_NI = 0, add_lpxt = 0, add_H = 0, add_W = 0;
 };
 int launch_chanmix_bwd(const ChanMixBwdArgs& a, hipStream_t s);
 

@@ -17,6 +17,7 @@
 #include "kernels.h"
 #include "backward.h"
 #include "sh.h"
+#include "cnet_fin.h"
 
 namespace glowhip {
 
@@ -448,11 +449,23 @@ __global__ void __launch_bounds__(256) k_chanmix_bwd(ChanMixBwdArgs a) {
     const bool valid = gp < total;
     const long n = valid ? gp / a.HW : 0;
     const int p = valid ? (int)(gp - n * a.HW) : 0;
+    FinSrc addf{};
+    if (a.add_part) {
+        CnetPending pd{};
+        pd.scratch = a.add_part; pd.MS = a.add_MS; pd.tiles = a.add_tiles; pd.R = a.add_R; pd.NI = a.add_NI; pd.lpxt = a.add_lpxt;
+        pd.mode = TAIL_ADD_FWD; pd.Cout = a.add_C;
+        addf = fin_src(pd, a.N, a.add_H, a.add_W, a.HW, __builtin_ctz(a.add_W));
+    }
     for (int c = grp; c < C; c += 4) {
         float xv = 0.f, g = 0.f;
         if (valid) {
             xv = (a.x[n * a.x_bs + (long)c * a.HW + p] + a.bias[c]) * a.scale[c];
             g = a.gy[n * a.g_bs + (long)c * a.HW + p];
+            if (a.add_part && c < a.add_C) {      // + d L / d y1 from the backward k_cnet launch's partial sums (cnet_fin.h)
+                float se, so;
+                fin_gather_t<0, true>(addf, n, c, p, se, so);
+                g += se * a.add_scale;
+            }
         }
         v[c * CB_LD + px] = xv;
         gy[c * CB_LD + px] = g;

@@ -416,7 +416,7 @@ static int backward_sweep(glowhip_plan* p, const void* packed, const float* x_in
                 CnetPending pend{};
                 count_launch(p, "k_cnet(bwd)");
                 GH_TRY(launch_cnet_main(c, s, &pend));
-                GH_TRY(launch_cnet_bwd_finish(c, pend, g, chw, 1.0f / sh_grad_scale, s));
+                // (its finishing step -- g_y1 += the partial sums -- rides in k_chanmix_bwd below)
                 GH_TRY(launch_wgrad_mfma(w.gh2, (long)hid * HW, h1, (long)hid * HW, w.partial + w.partial_floats, G.f2_w, N, HW, hid, hid,
                                          hid, hid, 0, s, sh_grad_scale, a2b, nullptr, &rj.job[1]));
                 if (vtaps) {
@@ -434,6 +434,8 @@ static int backward_sweep(glowhip_plan* p, const void* packed, const float* x_in
                                   d.permutation == GLOWHIP_PERM_INVCONV ? d.invconv_w : nullptr,
                                   d.permutation == GLOWHIP_PERM_GATHER ? d.perm_idx_inv : nullptr, aW, aAb, aAl, N, d.C, HW};
                 mb.acc_copies = MIX_ACC_COPIES; mb.acc_stride = mstride;
+                mb.add_part = pend.scratch; mb.add_scale = 1.0f / sh_grad_scale; mb.add_C = Ch; mb.add_MS = pend.MS;
+                mb.add_tiles = pend.tiles; mb.add_R = pend.R; mb.add_NI = pend.NI; mb.add_lpxt = pend.lpxt; mb.add_H = d.H; mb.add_W = d.W;
                 GH_TRY(launch_chanmix_bwd(mb, s));
                 if (d.permutation == GLOWHIP_PERM_INVCONV) fin(aW, G.invconv_w, d.C * d.C, (double)HW, at<float>(packed, L.winv), d.C, MIX_ACC_COPIES, mstride);
                 fin(aAb, G.an_bias, d.C, 0.0, nullptr, 0, MIX_ACC_COPIES, mstride);
