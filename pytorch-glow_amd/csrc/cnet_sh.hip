@@ -1458,32 +1458,6 @@ int launch_cnet_finish(const CnetArgs& a, const CnetPending& p, hipStream_t s) {
     return GLOWHIP_OK;
 }
 
-// finishing step of a backward launch (k_cnet MODE 2): g[n][c][p] += out_scale * (MS partial sums + the neighbour tiles' halo rows)
-__global__ void __launch_bounds__(256) k_cbwd_finish(CnetPending p, float* __restrict__ g, long g_bs, int N, int H, int W, int HW,
-                                                     int wshift, float out_scale) {
-    const FinSrc f = fin_src(p, N, H, W, HW, wshift);
-    const long e = (long)blockIdx.x * 256 + threadIdx.x;
-    if (e >= (long)N * p.Cout * HW) return;
-    const int px = (int)(e % HW);
-    const long nc = e / HW;
-    const int c = (int)(nc % p.Cout);
-    const long n = nc / p.Cout;
-    float se, so;
-    fin_gather_t<0, true>(f, n, c, px, se, so);
-    g[n * g_bs + (long)c * HW + px] += se * out_scale;
-}
-
-int launch_cnet_bwd_finish(const CnetArgs& a, const CnetPending& p, float* g, long g_bs, float out_scale, hipStream_t s) {
-    if (a.N == 0) return GLOWHIP_OK;
-    GH_REQUIRE(p.mode == TAIL_ADD_FWD, "cnet_bwd_finish: additive partial sums expected");
-    const int HW = a.H * a.W;
-    const long total = (long)a.N * p.Cout * HW;
-    hipLaunchKernelGGL(k_cbwd_finish, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p, g, g_bs, a.N, a.H, a.W, HW,
-                       __builtin_ctz(a.W), out_scale);
-    GH_LAUNCH_CHECK("k_cbwd_finish");
-    return GLOWHIP_OK;
-}
-
 int launch_cnet(const CnetArgs& a, hipStream_t s) {
     CnetPending p{};
     GH_TRY(launch_cnet_main(a, s, &p));

@@ -234,11 +234,9 @@ struct CnetArgs {
     // ---- backward launch (bwd = 1; plan_train.hip): x = d L / d(f.4 output) (N, Cin = f.4's Cout, H, W); w0 / w2 / w4 = the SH2
     // images of f.4's, f.2's, f.0's TRANSPOSED weights (exp(3 logs) of f.2 / f.0 folded into the first two); tape_h1 <- g_u2,
     // tape_h2 <- g_u0 (fp32 (N, hidden, H, W)); the partial sums in `scratch` are d L / d y1's contribution (Cout = C/2 channels),
-    // added into the gradient by launch_cnet_bwd_finish
+    // added into the gradient by k_chanmix_bwd (backward.h ChanMixBwdArgs::add_part)
     int bwd;
 };
-// g[n][c][p] += out_scale * (sum of the partial sums k_cnet left in a.scratch), c < a.Cout: the finishing step of a backward launch
-int launch_cnet_bwd_finish(const CnetArgs& a, const CnetPending& p, float* g, long g_bs, float out_scale, hipStream_t s);
 int launch_cnet_main(const CnetArgs& a, hipStream_t s, CnetPending* out);            // k_cnet only; *out describes its partial sums
 int launch_cnet_finish(const CnetArgs& a, const CnetPending& p, hipStream_t s);     // the finishing kernel for those sums
 int launch_cnet(const CnetArgs& a, hipStream_t s);                                   // both
