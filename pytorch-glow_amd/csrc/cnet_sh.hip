@@ -1187,7 +1187,11 @@ __global__ void __launch_bounds__(256) k_cfinish(CfinArgs a) {
                         // atomics queued up behind one another and doubled the launch time), issued before the mixer phase,
                         // whose time hides its round trip
         const long long tot = block_sum_ll<256>(ldq, red);
-        if (tid == 0 && tot != 0) atomicAdd(a.acc + n, (unsigned long long)tot);
+        // (row blockIdx % (1 + ACC_EXTRA) of the sample's accumulators, common.h: k_finalize adds the rows)
+        if (tid == 0 && tot != 0) {
+            const int row = blockIdx.x % (1 + ACC_EXTRA);
+            atomicAdd(a.acc + (row == 0 ? n : (long)(1 + row) * a.N + n), (unsigned long long)tot);
+        }
     } else if (a.mix.C) {
         __syncthreads();
     }

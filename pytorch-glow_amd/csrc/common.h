@@ -40,7 +40,10 @@ constexpr float LOGSCALE = 3.0f;  // network/module.py:10 logscale_factor
 // Kept as signed Q31.32 fixed point in a u64 so that atomic accumulation from many workgroups is
 // order-independent (bitwise reproducible), unlike float atomics.
 constexpr double FIX_SCALE = 4294967296.0;
-// acc: 2 N words -- acc[n] the accumulator of sample n, acc[N + n] its STICKY NON-FINITE FLAG.  A NaN / inf partial sum cannot
+constexpr int ACC_EXTRA = 7;
+// acc: 2 N words -- acc[n] the accumulator of sample n, acc[N + n] its STICKY NON-FINITE FLAG -- and, in a plan's workspace,
+// ACC_EXTRA more accumulator rows acc[(2 + k) N + n] that k_finalize adds to acc[n]: the finishing kernel of the product path
+// spreads its one-per-workgroup atomics over them (1 024 workgroups on the four cache lines of 64 samples' accumulators queue up).  A NaN / inf partial sum cannot
 // be represented in fixed point (the conversion would silently turn NaN into 0): it raises the flag instead, and k_finalize
 // reports NaN / +inf / -inf for a flagged sample -- an fp16-range overflow in the split-half kernels, diverged weights or out-of-distribution
 // input surface as a non-finite nll exactly as in the reference, never as a finite wrong one.

@@ -53,7 +53,7 @@ struct Workspace {
 
 static size_t workspace_bytes(const glowhip_plan* p, int N) {
     size_t off = 0;
-    take(off, (size_t)N * 16);
+    take(off, (size_t)N * 8 * (2 + ACC_EXTRA));
     take(off, (size_t)N * p->max_chw * 4);
     take(off, (size_t)N * p->max_chw * 4);
     take(off, (size_t)N * p->max_hidden * 4);
@@ -67,7 +67,7 @@ static int carve(const glowhip_plan* p, int N, void* ws, size_t bytes, Workspace
         return GLOWHIP_EWORKSPACE;
     }
     size_t off = 0;
-    w.acc = at<unsigned long long>(ws, take(off, (size_t)N * 16));
+    w.acc = at<unsigned long long>(ws, take(off, (size_t)N * 8 * (2 + ACC_EXTRA)));
     w.bufA = at<float>(ws, take(off, (size_t)N * p->max_chw * 4));
     w.bufB = at<float>(ws, take(off, (size_t)N * p->max_chw * 4));
     w.h1 = at<float>(ws, take(off, (size_t)N * p->max_hidden * 4));
@@ -983,11 +983,11 @@ int glowhip_plan_encode(glowhip_plan* plan, const void* packed, const float* x, 
     hipStream_t s = (hipStream_t)stream;
     Workspace w;
     GH_TRY(carve(plan, N, workspace, workspace_bytes, w));
-    GH_TRY(launch_zero_acc(w.acc, N, s));
+    GH_TRY(launch_zero_acc(w.acc, N, s, ACC_EXTRA));
     GH_TRY(run_forward(plan, packed, x, noise, z, N, w, s));
     GH_TRY(join_legacy(plan, s)); GH_TRY(join_lu(plan, s));
     if (logdet_out)
-        GH_TRY(launch_finalize(logdet_in, w.acc, at<double>(packed, 0), 1.0, 0.0, 1.0, logdet_out, nullptr, N, s));
+        GH_TRY(launch_finalize(logdet_in, w.acc, at<double>(packed, 0), 1.0, 0.0, 1.0, logdet_out, nullptr, N, s, ACC_EXTRA));
     return GLOWHIP_OK;
 }
 
@@ -1002,11 +1002,11 @@ int glowhip_plan_decode(glowhip_plan* plan, const void* packed, const float* z, 
     hipStream_t s = (hipStream_t)stream;
     Workspace w;
     GH_TRY(carve(plan, N, workspace, workspace_bytes, w));
-    GH_TRY(launch_zero_acc(w.acc, N, s));
+    GH_TRY(launch_zero_acc(w.acc, N, s, ACC_EXTRA));
     GH_TRY(join_legacy(plan, s)); GH_TRY(join_lu(plan, s));      // decode reads W^-1 and the deep levels' images first
     GH_TRY(run_reverse(plan, packed, z, eps, n_eps, x, N, w, s));
     if (logdet_out)
-        GH_TRY(launch_finalize(logdet_in, w.acc, at<double>(packed, 0), -1.0, 0.0, 1.0, logdet_out, nullptr, N, s));
+        GH_TRY(launch_finalize(logdet_in, w.acc, at<double>(packed, 0), -1.0, 0.0, 1.0, logdet_out, nullptr, N, s, ACC_EXTRA));
     return GLOWHIP_OK;
 }
 
@@ -1021,7 +1021,7 @@ int glowhip_glow_forward(glowhip_plan* plan, const void* packed, const float* x,
     hipStream_t s = (hipStream_t)stream;
     Workspace w;
     GH_TRY(carve(plan, N, workspace, workspace_bytes, w));
-    GH_TRY(launch_zero_acc(w.acc, N, s));
+    GH_TRY(launch_zero_acc(w.acc, N, s, ACC_EXTRA));
     RngSpec rng{plan->rng_on && !noise, plan->rng_seed, plan->rng_calls, (float)(1.0 / pow(2.0, n_bits))};
     if (rng.on) ++plan->rng_calls;
     GH_TRY(run_forward(plan, packed, x, noise, z, N, w, s, 0, rng.on ? &rng : nullptr));
@@ -1033,7 +1033,7 @@ int glowhip_glow_forward(glowhip_plan* plan, const void* packed, const float* x,
     const double chw = (double)plan->in_shape[0] * plan->in_shape[1] * plan->in_shape[2];
     const double offset = -log(pow(2.0, n_bits)) * chw;
     const double scale = -1.0 / (log(2.0) * chw);
-    GH_TRY(launch_finalize(nullptr, w.acc, at<double>(packed, 0), 1.0, offset, scale, nll_out, objective_out, N, s));
+    GH_TRY(launch_finalize(nullptr, w.acc, at<double>(packed, 0), 1.0, offset, scale, nll_out, objective_out, N, s, ACC_EXTRA));
     return GLOWHIP_OK;
 }
 
@@ -1052,7 +1052,7 @@ int glowhip_glow_forward_u8(glowhip_plan* plan, const void* packed, const uint8_
     hipStream_t s = (hipStream_t)stream;
     Workspace w;
     GH_TRY(carve(plan, N, workspace, workspace_bytes, w));
-    GH_TRY(launch_zero_acc(w.acc, N, s));
+    GH_TRY(launch_zero_acc(w.acc, N, s, ACC_EXTRA));
     const glowhip_layer_desc& d0 = plan->layers[0].d;
     plan->cur_layer = 0;
     RngSpec rng{plan->rng_on && !noise, plan->rng_seed, plan->rng_calls, (float)(1.0 / pow(2.0, n_bits))};
@@ -1065,7 +1065,7 @@ int glowhip_glow_forward_u8(glowhip_plan* plan, const void* packed, const uint8_
     const double chw = (double)plan->in_shape[0] * plan->in_shape[1] * plan->in_shape[2];
     GH_TRY(join_legacy(plan, s)); GH_TRY(join_lu(plan, s));
     return launch_finalize(nullptr, w.acc, at<double>(packed, 0), 1.0, -log(pow(2.0, n_bits)) * chw, -1.0 / (log(2.0) * chw),
-                           nll_out, objective_out, N, s);
+                           nll_out, objective_out, N, s, ACC_EXTRA);
 }
 
 int glowhip_plan_actnorm_init(glowhip_plan* plan, void* packed, size_t packed_bytes, const float* x, const float* noise,
@@ -1076,7 +1076,7 @@ int glowhip_plan_actnorm_init(glowhip_plan* plan, void* packed, size_t packed_by
     hipStream_t s = (hipStream_t)stream;
     Workspace w;
     GH_TRY(carve(plan, N, workspace, workspace_bytes, w));
-    GH_TRY(launch_zero_acc(w.acc, N, s));
+    GH_TRY(launch_zero_acc(w.acc, N, s, ACC_EXTRA));
     // plain (ActNorm-free) fp32 MFMA weight images of every convolution: the training family's + the init pass's own f.0 image
     // (no LU here: the invertible 1x1 convolutions are applied with W itself, and the pack at the end factorises them)
     GH_TRY(glowhip_plan_pack_for(plan, packed, packed_bytes, GLOWHIP_PACK_TRAINING | 16 | 32, stream));

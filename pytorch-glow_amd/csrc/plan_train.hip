@@ -138,7 +138,7 @@ static void wgrad_scratch_floats(const glowhip_plan* p, int N, size_t* col, size
 
 static size_t train_ws_layout(const glowhip_plan* p, int N, void* base, TrainWs* w) {
     size_t off = 0;
-    const size_t o_acc = take(off, (size_t)N * 16), o_gld = take(off, (size_t)N * 4), o_gsum = take(off, 64);
+    const size_t o_acc = take(off, (size_t)N * 8 * (2 + ACC_EXTRA)), o_gld = take(off, (size_t)N * 4), o_gsum = take(off, 64);
     const size_t o_gA = take(off, (size_t)N * p->max_chw * 4), o_gB = take(off, (size_t)N * p->max_chw * 4);
     const size_t o_h1 = take(off, (size_t)N * p->max_hidden * 4), o_h2 = take(off, (size_t)N * p->max_hidden * 4);
     const size_t o_gpre = take(off, (size_t)N * p->max_chw * 4);
@@ -575,7 +575,7 @@ int glowhip_glow_forward_train(glowhip_plan* plan, const void* packed, const flo
     TrainWs w;
     GH_REQUIRE(workspace_bytes >= train_ws_layout(plan, N, workspace, &w), "glow_forward_train: workspace too small");
     hipStream_t s = (hipStream_t)stream;
-    GH_TRY(launch_zero_acc(w.acc, N, s));
+    GH_TRY(launch_zero_acc(w.acc, N, s, ACC_EXTRA));
     GH_TRY(join_legacy(plan, s)); GH_TRY(join_lu(plan, s));      // the training kernels read the fp32 images from the first layer on
     GH_TRY(forward_train(plan, packed, x, noise, z, N, (char*)tape, tl, w.acc, w.gsh, s));
     const int* o = plan->out_shape;
@@ -584,7 +584,7 @@ int glowhip_glow_forward_train(glowhip_plan* plan, const void* packed, const flo
     const double chw = (double)plan->in_shape[0] * plan->in_shape[1] * plan->in_shape[2];
     const double offset = -log(pow(2.0, n_bits)) * chw;
     const double scale = -1.0 / (log(2.0) * chw);
-    return launch_finalize(nullptr, w.acc, at<double>(packed, 0), 1.0, offset, scale, nll_out, objective_out, N, s);
+    return launch_finalize(nullptr, w.acc, at<double>(packed, 0), 1.0, offset, scale, nll_out, objective_out, N, s, ACC_EXTRA);
 }
 
 int glowhip_plan_backward_marks(glowhip_plan* plan, const int32_t* after_layer, void* const* events, int n) {

@@ -502,14 +502,15 @@ int launch_gaussian_logp(const float* x, long xbs, const float* mean, const floa
     return GLOWHIP_OK;
 }
 
-__global__ void __launch_bounds__(256) k_zero_acc(unsigned long long* acc, int N) {
+__global__ void __launch_bounds__(256) k_zero_acc(unsigned long long* acc, int words) {
     int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < 2 * N) acc[i] = 0ull;      // accumulators and non-finite flags
+    if (i < words) acc[i] = 0ull;      // accumulators, non-finite flags (and the extra accumulator rows)
 }
 
-int launch_zero_acc(unsigned long long* acc, int N, hipStream_t s) {
+int launch_zero_acc(unsigned long long* acc, int N, hipStream_t s, int extra_rows) {
     if (N == 0) return GLOWHIP_OK;
-    hipLaunchKernelGGL(k_zero_acc, dim3(cdiv(2 * N, 256)), dim3(256), 0, s, acc, N);
+    const int words = (2 + extra_rows) * N;
+    hipLaunchKernelGGL(k_zero_acc, dim3(cdiv(words, 256)), dim3(256), 0, s, acc, words);
     GH_LAUNCH_CHECK("k_zero_acc");
     return GLOWHIP_OK;
 }
@@ -518,10 +519,12 @@ __global__ void __launch_bounds__(256) k_finalize(const float* __restrict__ in,
                                                   const unsigned long long* __restrict__ acc,
                                                   const double* __restrict__ konst, double sign, double offset,
                                                   double scale, float* __restrict__ out,
-                                                  float* __restrict__ out_unscaled, int N) {
+                                                  float* __restrict__ out_unscaled, int N, int extra_rows) {
     int n = blockIdx.x * 256 + threadIdx.x;
     if (n >= N) return;
-    double v = (in ? (double)in[n] : 0.0) + offset + (konst ? sign * konst[0] : 0.0) + (acc ? fix_to_double(acc[n]) : 0.0);
+    unsigned long long a = acc ? acc[n] : 0ull;
+    for (int k = 0; k < extra_rows; ++k) a += acc[(long)(2 + k) * N + n];      // (two's-complement sums: any grouping gives the same bits)
+    double v = (in ? (double)in[n] : 0.0) + offset + (konst ? sign * konst[0] : 0.0) + (acc ? fix_to_double(a) : 0.0);
     if (acc && acc[N + n] != 0ull) {      // partial sums of this sample that were NaN / +inf / -inf (common.h)
         const unsigned long long fl = acc[N + n];
         v = ((fl & 1ull) || (fl & 6ull) == 6ull) ? __builtin_nan("") : ((fl & 2ull) ? __builtin_inf() : -__builtin_inf());
@@ -531,10 +534,10 @@ __global__ void __launch_bounds__(256) k_finalize(const float* __restrict__ in,
 }
 
 int launch_finalize(const float* in, const unsigned long long* acc, const double* konst, double sign, double offset,
-                    double scale, float* out, float* out_unscaled, int N, hipStream_t s) {
+                    double scale, float* out, float* out_unscaled, int N, hipStream_t s, int extra_rows) {
     if (N == 0) return GLOWHIP_OK;
     hipLaunchKernelGGL(k_finalize, dim3(cdiv(N, 256)), dim3(256), 0, s, in, acc, konst, sign, offset, scale, out,
-                       out_unscaled, N);
+                       out_unscaled, N, acc ? extra_rows : 0);
     GH_LAUNCH_CHECK("k_finalize");
     return GLOWHIP_OK;
 }
