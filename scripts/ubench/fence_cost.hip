@@ -6,25 +6,34 @@
 #include <cstdio>
 
 template <int MODE>   // 0: no communication (baseline)  1: __threadfence (agent scope) + atomic, last reads  2: workgroup-scope fence only
+                      // 3: no fence at all: the data itself travels as agent-scope relaxed atomic stores / loads (sc1: write-through /
+                      //    read-around the XCD's L2), s_waitcnt vmcnt(0) in front of the counter's atomic
 __global__ void __launch_bounds__(512) k(float* buf, unsigned* cnt, unsigned* bad, int iters, unsigned long long* cyc) {
     const int tid = threadIdx.x, g = blockIdx.x >> 2;
     __shared__ unsigned s_last;
     unsigned long long t0 = __builtin_readcyclecounter();
     for (int it = 0; it < iters; ++it) {
         float* mine = buf + ((long)it * gridDim.x + blockIdx.x) * 6144;
-        for (int e = tid; e < 6144; e += 512) mine[e] = (float)(blockIdx.x + it);
+        if (MODE == 3) {
+            for (int e = tid; e < 6144; e += 512) __hip_atomic_store(mine + e, (float)(blockIdx.x + it), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            for (int e = tid; e < 6144; e += 512) mine[e] = (float)(blockIdx.x + it);
+        }
         if (MODE == 0) continue;
         if (MODE == 1) __threadfence();
-        else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        else if (MODE == 2) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __syncthreads();
-        if (tid == 0) s_last = atomicAdd(cnt + it * (gridDim.x >> 2) + g, 1u) == 3u;
+        if (tid == 0) s_last = (MODE == 3 ? __hip_atomic_fetch_add(cnt + it * (gridDim.x >> 2) + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                          : atomicAdd(cnt + it * (gridDim.x >> 2) + g, 1u)) == 3u;
         __syncthreads();
         if (s_last) {
             if (MODE == 1) __threadfence();
             unsigned wrong = 0;
             for (int b = 0; b < 4; ++b) {
                 const float* p = buf + ((long)it * gridDim.x + (g * 4 + b)) * 6144;
-                for (int e = tid; e < 6144; e += 512) wrong += p[e] != (float)(g * 4 + b + it);
+                for (int e = tid; e < 6144; e += 512)
+                    wrong += (MODE == 3 ? __hip_atomic_load(p + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : p[e]) != (float)(g * 4 + b + it);
             }
             if (wrong) atomicAdd(bad, wrong);
         }
@@ -55,5 +64,7 @@ int main() {
     run<2>("workgroup-scope fence + counter, last reads");
     run<0>("stores only");
     run<1>("agent-scope fence + counter, last reads");
+    run<3>("sc1 stores / loads + counter, no fence");
+    run<3>("sc1 stores / loads + counter, no fence");
     return 0;
 }
