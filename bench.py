@@ -206,13 +206,14 @@ def secondary_workloads(G, util, parallel, device, steps=3, warmup=3):
                 def step():
                     plan.ensure_packed(False, use=plan.PACK_INFERENCE | plan.PACK_INVERSE)
                     return glow.reverse_flow(z_top, None, eps_std=0.7).sum()
-            for _ in range(warmup + (3 if mode == "train" else 0)):      # (the training step's first iterations still allocate)
-                step()
+            n_timed = steps + (2 if mode == "train" else 0)
+            for _ in range(warmup + (7 if mode == "train" else 0)):      # (the training step's first iterations still allocate:
+                step()                                                   #  12 GB of tape, gradient buckets, optimiser state)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             t0 = time.perf_counter()
             e0.record()
-            for _ in range(steps):
+            for _ in range(n_timed):
                 last = step()
             e1.record()
             torch.cuda.synchronize()
@@ -220,8 +221,9 @@ def secondary_workloads(G, util, parallel, device, steps=3, warmup=3):
             if "loop" in wl:
                 wl["loop"].flush()
             name = f"{cfg_name}_{mode}"
-            out[name] = {"value": round(B * steps / dt, 2), "unit": "images/sec", "ms_per_step": round(1e3 * dt / steps, 3),
-                         "ms_per_step_gpu_events": round(e0.elapsed_time(e1) / steps, 3), "steps": steps, "warmup": warmup, "batch": B,
+            out[name] = {"value": round(B * n_timed / dt, 2), "unit": "images/sec", "ms_per_step": round(1e3 * dt / n_timed, 3),
+                         "ms_per_step_gpu_events": round(e0.elapsed_time(e1) / n_timed, 3), "steps": n_timed,
+                         "warmup": warmup + (7 if mode == "train" else 0), "batch": B,
                          "workload": f"{cfg['label']}, {mode}, batch {B} ({cfg['ref']})",
                          "finite": bool(torch.isfinite(last).all()), "data_dependent_init_ms": wl["init_ms"],
                          "kernel_families": sorted(k for k in wl["plan"].launch_counts(reset=True) if not k.startswith("variant:")),
