@@ -69,7 +69,8 @@ int launch_wgrad_mfma(const float* A, long a_bs, const float* B, long b_bs, floa
                       int Mpad, int Npad, int Mreal, int Nreal, int mode, hipStream_t s, float sh_scale = 0.f,   // sh_scale > 0: f16-pipe kernel, gradient operand A pre-scaled by it
                       double* rowsum = nullptr,    // (f16-pipe kernel) rowsum[m] += sum over all pixels of A's row m -- the bias gradient when A = g_u
                       const WgradTaps* taps = nullptr,
-                      struct WgradReduceJob* defer = nullptr);   // non-null: skip the split-K reduction, describe it in *defer instead
+                      struct WgradReduceJob* defer = nullptr,    // non-null: skip the split-K reduction, describe it in *defer instead
+                      int b_valid = 0);   // > 0 (f16-pipe kernel, plain B): only that many rows of B exist, the rest of the column tile is zero
 struct WgradReduceJob { const float* partial; float* dw; int splits, Mpad, Npad, Mreal, Nreal, mode; };
 struct WgradReduceJobs { WgradReduceJob job[3]; int n; };
 int launch_wgrad_reduce_batched(const WgradReduceJobs& j, hipStream_t s);

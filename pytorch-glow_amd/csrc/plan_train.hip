@@ -524,7 +524,18 @@ static int backward_sweep(glowhip_plan* p, const void* packed, const float* x_in
             SplitBwdArgs sb{hout, xin + (long)Ch * HW, chw, gnext + (long)Ch * HW, chw, w.gpre,
                             at<float>(packed, L.f4_scale), w.gld, a4b, a4l, N, Ch, HW};
             GH_TRY(launch_split_bwd(sb, s));
-            GH_TRY(launch_wgrad_direct(w.gpre, xin, chw, G.f4_w, N, Ch, d.H, d.W, L.Cout, 3, s));
+            {   // Conv2dZeros weight gradient: the split-K GEMM of the FlowSteps (A = gathered taps of g_pre, B = z1's Ch rows)
+                const int m4 = round_up(L.Cout * 9, 128);
+                const bool mf = train_sh_enabled(p) && G.f4_w && HW % 32 == 0 && Ch <= 64 && d.W >= 4 && (d.W & (d.W - 1)) == 0 &&
+                                wgrad_mfma_partial_floats(m4, 64, N, HW) <= w.partial_floats;
+                if (mf) {
+                    const WgradTaps t4{0, L.Cout, d.H, d.W, -1};
+                    GH_TRY(launch_wgrad_mfma(w.gpre, (long)L.Cout * HW, xin, chw, w.partial, G.f4_w, N, HW, m4, 64, L.Cout * 9, Ch, 1, s,
+                                             sh_grad_scale, nullptr, &t4, nullptr, Ch));
+                } else {
+                    GH_TRY(launch_wgrad_direct(w.gpre, xin, chw, G.f4_w, N, Ch, d.H, d.W, L.Cout, 3, s));
+                }
+            }
             GH_TRY(dgrad_direct(w.gpre, d.f4_w, w.wT, w.gh1, N, Ch, d.H, d.W, L.Cout, 3, s));     // (N,Ch,HW)
             hipLaunchKernelGGL(k_add_inplace, dim3(cdiv((long)Ch * HW, 256), N), dim3(256), 0, s, gnext, chw, w.gh1,
                                (long)Ch * HW, (long)Ch * HW);

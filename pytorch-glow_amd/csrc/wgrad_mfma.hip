@@ -158,13 +158,14 @@ k_wgrad_gemm(const float* __restrict__ A, long a_bs, const float* __restrict__ B
 // VA / VB: operand A / B is VIRTUAL -- the shift-expanded rows (c * 9 + tap) : src[c][p + sign * d(tap)] of a (N, vC, vH, vW)
 // tensor (rows >= 9 vC are zero), gathered by the loader itself (four 4-byte loads per chunk, clamped addresses, selected
 // values) instead of being written out by k_shift_expand and read back (33 + 17 MB per level-1 FlowStep, 17 + 12 us of launches)
-template <int BN, bool VA = false, bool VB = false>
+// BV: only b_valid rows of the plain operand B exist (an operand narrower than a column tile); the others are zero
+template <int BN, bool VA = false, bool VB = false, bool BV = false>
 __global__ void __launch_bounds__(256, 2)      // two workgroups per CU: at 269 registers (141 + 128 accumulators) the kernel ran ONE
                                                // wave per SIMD and every k-tile waited out its own HBM round trip (7.4 k cycles per
                                                // k-tile against 768 of MFMA work)
 k_wgrad_gemm_sh(const float* __restrict__ A, long a_bs, const float* __restrict__ B, long b_bs, float* __restrict__ partial,
                 int HW, int Mpad, int Npad, int ktiles_total, int ktiles_per_split, float a_scale, double* __restrict__ rowsum,
-                int vC, int vH, int vW, int vsign) {
+                int vC, int vH, int vW, int vsign, int b_valid) {
     constexpr int BM = 128, BK = 32;
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
     constexpr int A_F4 = BM * BK / 4 / 256, B_F4 = BN * BK / 4 / 256;   // float4 per thread per K-tile (4, 4|2)
@@ -231,9 +232,20 @@ k_wgrad_gemm_sh(const float* __restrict__ A, long a_bs, const float* __restrict_
         if constexpr (VB) {
             load_virtual(B, b_bs, img, p0, rb);
         } else {
-            const float* bp = B + (long)img * b_bs + (long)(tile_n * BN + l_row) * HW + p0 + l_c * 4;
+            if constexpr (BV) {      // rows >= b_valid do not exist in the tensor: loaded from row 0, zeroed
 #pragma unroll
-            for (int j = 0; j < B_F4; ++j) rb[j] = *reinterpret_cast<const f32x4*>(bp + (long)j * 32 * HW);
+                for (int j = 0; j < B_F4; ++j) {
+                    const int row = tile_n * BN + l_row + 32 * j;
+                    const bool ok = row < b_valid;
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(B + (long)img * b_bs + (long)(ok ? row : 0) * HW + p0 + l_c * 4);
+                    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                    rb[j] = ok ? v : z;
+                }
+            } else {
+                const float* bp = B + (long)img * b_bs + (long)(tile_n * BN + l_row) * HW + p0 + l_c * 4;
+#pragma unroll
+                for (int j = 0; j < B_F4; ++j) rb[j] = *reinterpret_cast<const f32x4*>(bp + (long)j * 32 * HW);
+            }
         }
     };
     auto split4 = [](const f32x4& v, float pre, h4& hi, h4& lo) {      // (same bits as sh_split on v * pre)
@@ -404,8 +416,9 @@ size_t wgrad_mfma_partial_floats(int Mpad, int Npad, int N, int HW) {
 
 int launch_wgrad_mfma(const float* A, long a_bs, const float* B, long b_bs, float* partial, float* dw, int N, int HW,
                       int Mpad, int Npad, int Mreal, int Nreal, int mode, hipStream_t s, float sh_scale, double* rowsum,
-                      const WgradTaps* taps, WgradReduceJob* defer) {
+                      const WgradTaps* taps, WgradReduceJob* defer, int b_valid) {
     GH_REQUIRE(!rowsum || sh_scale > 0.f, "wgrad_mfma: row sums only on the split-half kernel");
+    GH_REQUIRE(b_valid <= 0 || (sh_scale > 0.f && taps && taps->operand == 0 && Npad == 64), "wgrad_mfma: b_valid only with gathered A and a 64-column B");
     GH_REQUIRE(!taps || (sh_scale > 0.f && taps->H * taps->W == HW && taps->W >= 4 && (taps->W & (taps->W - 1)) == 0 &&
                          (taps->operand == 0 || taps->operand == 1)),
                "wgrad_mfma: virtual operand needs the split-half kernel and a power-of-two width >= 4");
@@ -420,13 +433,16 @@ int launch_wgrad_mfma(const float* A, long a_bs, const float* B, long b_bs, floa
     const int vC = taps ? taps->C : 0, vH = taps ? taps->H : 0, vW = taps ? taps->W : 1, vs = taps ? taps->sign : 0;
 #define GH_WG(bn, va, vb)                                                                                                      \
     hipLaunchKernelGGL((k_wgrad_gemm_sh<bn, va, vb>), dim3(tiles * splits), dim3(256), 0, s, A, a_bs, B, b_bs, partial, HW, Mpad, \
-                       Npad, total, per, sh_scale, rowsum, vC, vH, vW, vs)
+                       Npad, total, per, sh_scale, rowsum, vC, vH, vW, vs, b_valid > 0 ? b_valid : Npad)
     if (sh_scale > 0.f && bn128) {     // f16 matrix pipe, split-half operands (sh_scale = power-of-two pre-scale of the gradient operand)
         if (taps && taps->operand == 0) GH_WG(128, true, false);
         else if (taps) GH_WG(128, false, true);
         else GH_WG(128, false, false);
     } else if (sh_scale > 0.f) {
-        if (taps && taps->operand == 0) GH_WG(64, true, false);
+        if (taps && taps->operand == 0 && b_valid > 0)
+            hipLaunchKernelGGL((k_wgrad_gemm_sh<64, true, false, true>), dim3(tiles * splits), dim3(256), 0, s, A, a_bs, B, b_bs, partial, HW,
+                               Mpad, Npad, total, per, sh_scale, rowsum, vC, vH, vW, vs, b_valid);
+        else if (taps && taps->operand == 0) GH_WG(64, true, false);
         else if (taps) GH_WG(64, false, true);
         else GH_WG(64, false, false);
     }
