@@ -1,0 +1,54 @@
+# debug: randomised comparison of the training step on k_cnet (tape + backward) with the per-layer kernels (debug flags) --
+# shapes beyond the parity tests' (hidden widths, couplings, permutations, image sizes, odd batches)
+import sys, os, random, torch, numpy as np
+root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tests"))
+import conftest  # noqa
+import pytorch_glow_amd as G
+from pytorch_glow_amd import _lib
+from oracle import glow_oracle as O
+from test_gpu_grad import hps_for
+DEV = "cuda:0"
+rng = random.Random(int(os.environ.get("SEED", "1")))
+bad = 0
+for case in range(int(os.environ.get("CASES", "14"))):
+    hidden = rng.choice([128, 256, 512]); coup = rng.choice(["affine", "additive"]); perm = rng.choice(["invconv", "reverse", "shuffle"])
+    image = rng.choice([32, 64]); L = rng.choice([2, 3]); K = rng.choice([1, 2]); batch = rng.choice([1, 2, 3, 5, 8])
+    cfg = O.default_cfg(image_shape=(image, image, 3), hidden_channels=hidden, K=K, L=L, flow_permutation=perm, flow_coupling=coup, batch=batch)
+    np.random.seed(case)
+    g = torch.Generator().manual_seed(100 + case)
+    x = torch.rand(batch, 3, image, image, generator=g); noise = torch.rand(batch, 3, image, image, generator=g) / 256
+    res = {}
+    sd = None
+    for flag in (0x40000000 | 0x80000000, 0):
+        _lib.lib().glowhip_debug_force_tail_tile(flag - (1 << 32) if flag >= (1 << 31) else flag)
+        np.random.seed(case)
+        glow = G.Glow(hps_for(cfg, batch))
+        if sd is None:
+            sd = {k: v.detach().clone() for k, v in glow.state_dict().items()}
+            for k in sd:
+                if k == "h_top" or not sd[k].is_floating_point(): continue
+                if k.endswith("invconv.weight"):
+                    c = sd[k].shape[0]; sd[k] = torch.from_numpy(np.linalg.qr(np.random.randn(c, c))[0].astype("float32")) + 0.02 * torch.randn(c, c, generator=g)
+                elif k.endswith("logs") or k.endswith("bias"): sd[k] = torch.randn(sd[k].shape, generator=g) * 0.1
+                elif ".f.4." in k or "conv2d_zeros" in k: sd[k] = torch.randn(sd[k].shape, generator=g) * 0.01
+                elif ".f.2." in k: sd[k] = torch.randn(sd[k].shape, generator=g) * (1.0 / hidden) ** 0.5
+                else: sd[k] = torch.randn(sd[k].shape, generator=g) * 0.1
+        glow.load_state_dict(sd); glow.set_actnorm_inited(); glow = glow.to(DEV).train()
+        with torch.enable_grad():
+            z, nll, _ = glow.normal_flow(x.to(DEV), None, noise=noise.to(DEV))
+            G.Glow.generative_loss(nll).backward()
+        counts = glow.flow.plan_for(x.to(DEV)).launch_counts()
+        res[flag] = (z.detach().cpu(), nll.detach().cpu(), {n: p.grad.cpu().double() for n, p in glow.named_parameters() if p.grad is not None}, counts)
+    _lib.lib().glowhip_debug_force_tail_tile(0)
+    (z0, n0, g0, c0), (z1, n1, g1, c1) = res[0x40000000 | 0x80000000], res[0]
+    worst = 0.0; wname = ""
+    for name, a in g0.items():
+        sc = a.abs().max().item() + 1e-30
+        e = (g1[name] - a).abs().max().item() / sc
+        if e > worst: worst, wname = e, name
+    ok = (z1 - z0).abs().max().item() <= 5e-5 and (n1 - n0).abs().max().item() <= 5e-6 and worst <= 0.05
+    bad += not ok
+    print(f"{'ok ' if ok else 'BAD'} hidden {hidden} {coup:8s} {perm:8s} image {image} L {L} K {K} batch {batch}: dz {(z1 - z0).abs().max().item():.1e} dnll {(n1 - n0).abs().max().item():.1e} "
+          f"worst grad rel {worst:.1e} ({wname}) tape {c1.get('k_cnet(tape)', 0)} bwd {c1.get('k_cnet(bwd)', 0)} finite {bool(torch.isfinite(n1).all())}")
+print("BAD cases:", bad)
