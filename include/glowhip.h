@@ -155,6 +155,10 @@ int glowhip_plan_pack_for(glowhip_plan* plan, void* packed, size_t packed_bytes,
  * except before capturing plan calls WITHOUT the pack into a hipGraph: glowhip_plan_pack_sync (HOST, blocks) waits for the side
  * part of the last pack so that the captured calls have nothing outside the graph to join. */
 int glowhip_plan_pack_sync(glowhip_plan* plan);
+/* The pack keeps its (plan-constant) job tables inside `packed` and sends them only once per buffer ADDRESS.  A caller that frees
+ * `packed` and passes a new allocation -- which may come back at the same address -- says so with this call (HOST bookkeeping);
+ * the next pack uploads the tables again. */
+int glowhip_plan_forget_packed(glowhip_plan* plan);
 
 /* FlowModel.encode: x (N, C0,H0,W0 of layer 0) -> z (output shape of the last layer),
  * logdet_out[n] = (logdet_in ? logdet_in[n] : 0) + sum of all layers' log-determinant terms.

@@ -81,6 +81,7 @@ SIGNATURES = {
     "glowhip_plan_pack": (c_int, [_P, _P, c_size_t, _P]),
     "glowhip_plan_pack_for": (c_int, [_P, _P, c_size_t, c_int, _P]),
     "glowhip_plan_pack_sync": (c_int, [_P]),
+    "glowhip_plan_forget_packed": (c_int, [_P]),
     "glowhip_plan_encode": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, _P, c_size_t, _P]),
     "glowhip_plan_decode": (c_int, [_P, _P, _P, POINTER(c_void_p), c_int, _P, _P, _P, c_int, _P, c_size_t, _P]),
     "glowhip_glow_forward": (c_int, [_P, _P, _P, _P, _P, _P, c_long, c_int, _P, _P, _P, c_int, _P, c_size_t, _P]),

@@ -729,7 +729,9 @@ glowhip_plan* glowhip_plan_create(const glowhip_layer_desc* layers, int n_layers
     }
     p->prep_off = take(off, p->prep_jobs.size() * sizeof(StepPrepJob));
     p->scale_off = take(off, p->scale_jobs.size() * sizeof(ScaleJob));
-    p->repack_off = take(off, p->repack_jobs.size() * sizeof(RepackJob));
+    // one slot of selected repack jobs per combination of the use bits that select images (1, 2, 8, 16): a pack of one mask never
+    // rewrites the table a captured graph of another mask launches over
+    p->repack_off = take(off, REPACK_SLOTS * p->repack_jobs.size() * sizeof(RepackJob));
     p->flip_off = take(off, p->flip_jobs.size() * sizeof(FlipJob));
     p->packed_bytes = align_up(off, 256);
     return p;
@@ -865,7 +867,8 @@ int glowhip_plan_pack_for(glowhip_plan* plan, void* packed, size_t packed_bytes,
     GH_REQUIRE(use & (GLOWHIP_PACK_INFERENCE | GLOWHIP_PACK_TRAINING), "plan_pack: empty use mask");
     // with a kernel family switched off through the debug hook the other family's images are needed after all
     // use bit 8 (internal): the round-1 split-half images of layers that normally run k_cnet -- needed only with cnet switched off
-    if (g_sh_disabled || g_sh_tail_disabled || g_sh_first_disabled) use = GLOWHIP_PACK_INFERENCE | GLOWHIP_PACK_TRAINING | 8;
+    // (OR-ed in: the internal bits 16 = init pass' f.0 image and 32 = no LU of the caller's mask survive)
+    if (g_sh_disabled || g_sh_tail_disabled || g_sh_first_disabled) use |= GLOWHIP_PACK_INFERENCE | GLOWHIP_PACK_TRAINING | 8;
     // a plan on the exact-fp32 family reads the fp32 MFMA images, which are the training path's
     if (plan->family == GLOWHIP_FAMILY_EXACT_FP32) use |= GLOWHIP_PACK_TRAINING;
     if ((use & GLOWHIP_PACK_INFERENCE) && (g_cnet_disabled || g_cnet_h2_only)) use |= 8;
@@ -891,17 +894,30 @@ int glowhip_plan_pack_for(glowhip_plan* plan, void* packed, size_t packed_bytes,
     auto upload = [&](size_t off, const void* src, size_t bytes) {
         return bytes == 0 || hipMemcpyAsync((char*)packed + off, src, bytes, hipMemcpyHostToDevice, s) == hipSuccess;
     };
-    // The job tables are plan constants: they travel once per (buffer, use mask) and stay in `packed` -- a re-pack of the same
-    // buffer is then kernel launches only (no host-to-device copy per step, and the sequence can be captured in a hipGraph)
-    if (plan->tables_in != packed || plan->tables_use != use) {
+    // The job tables are plan constants: they travel once per buffer -- the selected repack jobs once per (buffer, image bits of the
+    // use mask), each mask into its OWN slot -- and stay in `packed`: a re-pack of the same buffer is then kernel launches only (no
+    // host-to-device copy per step, and the sequence can be captured in a hipGraph whose table no later pack of another mask --
+    // a training step, the exact-fp32 fall-back, the init pass -- overwrites).
+    const int slot = repack_slot(use);
+    const size_t slot_off = plan->repack_off + (size_t)slot * plan->repack_jobs.size() * sizeof(RepackJob);
+    if (plan->tables_in != packed) {
         if (!upload(plan->prep_off, plan->prep_jobs.data(), plan->prep_jobs.size() * sizeof(StepPrepJob)) ||
             !upload(plan->scale_off, plan->scale_jobs.data(), plan->scale_jobs.size() * sizeof(ScaleJob)) ||
-            !upload(plan->repack_off, plan->repack_sel.data(), plan->repack_sel.size() * sizeof(RepackJob)) ||
             !upload(plan->flip_off, plan->flip_jobs.data(), plan->flip_jobs.size() * sizeof(FlipJob))) {
             set_error("plan_pack: hipMemcpyAsync of the job tables failed");
             return GLOWHIP_ELAUNCH;
         }
-        plan->tables_in = packed; plan->tables_use = use;
+        plan->tables_in = packed; plan->slots_in = 0;
+    }
+    if (!(plan->slots_in & (1u << slot))) {
+        // (hipMemcpyAsync from pageable memory stages the source before it returns; the per-slot host copy is kept anyway)
+        std::vector<RepackJob>& keep = plan->repack_slot_host[slot];
+        keep = plan->repack_sel;
+        if (!upload(slot_off, keep.data(), keep.size() * sizeof(RepackJob))) {
+            set_error("plan_pack: hipMemcpyAsync of the repack job table failed");
+            return GLOWHIP_ELAUNCH;
+        }
+        plan->slots_in |= 1u << slot;
     }
     // Fork: the legacy-kind images and the LU factorisations go to the plan's side stream (created on first use; a host resource
     // like the timing events) behind everything enqueued so far; whoever reads their results joins (join_legacy / join_lu).  What
@@ -929,10 +945,10 @@ int glowhip_plan_pack_for(glowhip_plan* plan, void* packed, size_t packed_bytes,
     if (use & GLOWHIP_PACK_TRAINING)      // transposed weight copies for the backward k_cnet images (read by the image kernels below)
         GH_TRY(launch_flipT_batched(at<FlipJob>(packed, plan->flip_off), (int)plan->flip_jobs.size(), plan->flip_tiles, packed, s));
     GH_TRY(launch_pack_batched(at<ScaleJob>(packed, plan->scale_off), (int)plan->scale_jobs.size(),
-                               at<RepackJob>(packed, plan->repack_off), n_kind, tail_blocks, packed, s, side));
+                               at<RepackJob>(packed, slot_off), n_kind, tail_blocks, packed, s, side));
     if (side != s) {
         if (hipEventRecord(plan->ev_legacy, side) != hipSuccess) { set_error("plan_pack: hipEventRecord failed"); return GLOWHIP_ELAUNCH; }
-        plan->legacy_pending = true;
+        plan->legacy_pending = true; plan->pending_captured = stream_capturing(s);
     }
     if (!(use & 32)) {      // (32, internal: weight images and scale tables only -- the init pass' first pack)
         GH_TRY(launch_step_prepare_batched(at<StepPrepJob>(packed, plan->prep_off), (int)plan->prep_jobs.size(),
@@ -941,7 +957,7 @@ int glowhip_plan_pack_for(glowhip_plan* plan, void* packed, size_t packed_bytes,
     }
     if (side != s) {
         if (hipEventRecord(plan->ev_lu, side) != hipSuccess) { set_error("plan_pack: hipEventRecord failed"); return GLOWHIP_ELAUNCH; }
-        plan->lu_pending = true;
+        plan->lu_pending = true; plan->pending_captured = stream_capturing(s);
     }
     return GLOWHIP_OK;
 }
@@ -971,6 +987,12 @@ int glowhip_plan_pack_sync(glowhip_plan* plan) {
         if (hipStreamSynchronize(plan->side) != hipSuccess) { set_error("plan_pack_sync: hipStreamSynchronize failed"); return GLOWHIP_ELAUNCH; }
         plan->legacy_pending = plan->lu_pending = false;
     }
+    return GLOWHIP_OK;
+}
+
+int glowhip_plan_forget_packed(glowhip_plan* plan) {
+    GH_REQUIRE(plan, "plan_forget_packed: null plan");
+    plan->tables_in = nullptr; plan->slots_in = 0;
     return GLOWHIP_OK;
 }
 

@@ -62,7 +62,10 @@ struct glowhip_plan {
     // read by decode / backward).  Consumers join through these events (join_legacy / join_lu).
     hipStream_t side = nullptr; hipEvent_t ev_fork = nullptr, ev_legacy = nullptr, ev_lu = nullptr;
     bool legacy_pending = false, lu_pending = false;
-    const void* tables_in = nullptr; int tables_use = 0;   // the `packed` buffer that already holds the job tables of that use mask
+    const void* tables_in = nullptr;      // the `packed` buffer that already holds the job tables (glowhip_plan_forget_packed resets)
+    unsigned slots_in = 0;                // ... and which of its repack-table slots (repack_slot) have been filled
+    std::vector<RepackJob> repack_slot_host[16];
+    bool pending_captured = false;        // ev_legacy / ev_lu were last recorded inside a stream capture (see join_legacy)
     int max_lds_c = 0, max_c = 0;
     size_t packed_bytes = 0;
     int in_shape[3] = {0, 0, 0}, out_shape[3] = {0, 0, 0};
@@ -82,13 +85,30 @@ namespace glowhip {
 
 static inline void count_launch(glowhip_plan* p, const char* name) { if (p) ++p->launch_counts[name]; }
 
+constexpr int REPACK_SLOTS = 16;
+// slot of a use mask's selected repack jobs: the four bits that select images (1 inference, 2 training, 8 round-1 images of cnet
+// layers, 16 init pass' f.0 image); 4 (W^-1) and 32 (no LU) do not change the table
+static inline int repack_slot(int use) { return (use & 3) | ((use & 8) >> 1) | ((use & 16) >> 1); }
+
+static inline bool stream_capturing(hipStream_t s) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    return hipStreamIsCapturing(s, &st) == hipSuccess && st == hipStreamCaptureStatusActive;
+}
+// An event recorded inside a stream capture belongs to that capture: waiting for it from a stream that is not capturing fails with
+// hipErrorCapturedEvent -- and there is nothing to wait for: the capture joined its own fork, and replays order themselves as graph
+// nodes.  So pending flags set during a capture are dropped by the first join that comes from outside one.
+static inline bool drop_captured_pending(glowhip_plan* p, hipStream_t s) {
+    if (!p->pending_captured || stream_capturing(s)) return false;
+    p->legacy_pending = p->lu_pending = p->pending_captured = false;
+    return true;
+}
 // make stream s wait for the side-stream part of the last pack (no-ops when nothing is pending)
 static inline int join_legacy(glowhip_plan* p, hipStream_t s) {
-    if (p->legacy_pending && hipStreamWaitEvent(s, p->ev_legacy, 0) != hipSuccess) { set_error("join_legacy: hipStreamWaitEvent failed"); return GLOWHIP_ELAUNCH; }
+    if (p->legacy_pending && !drop_captured_pending(p, s) && hipStreamWaitEvent(s, p->ev_legacy, 0) != hipSuccess) { set_error("join_legacy: hipStreamWaitEvent failed"); return GLOWHIP_ELAUNCH; }
     return GLOWHIP_OK;
 }
 static inline int join_lu(glowhip_plan* p, hipStream_t s) {
-    if (p->lu_pending && hipStreamWaitEvent(s, p->ev_lu, 0) != hipSuccess) { set_error("join_lu: hipStreamWaitEvent failed"); return GLOWHIP_ELAUNCH; }
+    if (p->lu_pending && !drop_captured_pending(p, s) && hipStreamWaitEvent(s, p->ev_lu, 0) != hipSuccess) { set_error("join_lu: hipStreamWaitEvent failed"); return GLOWHIP_ELAUNCH; }
     return GLOWHIP_OK;
 }
 

@@ -346,9 +346,27 @@ static int backward_sweep(glowhip_plan* p, const void* packed, const float* x_in
                    long stride = 0) {
         if (out) jobs.push_back(GradJob{acc, out, n, add_mul, winv, C, copies, stride});
     };
+    // log-scale gradients of the layers whose input-gradient chain ran as one k_cnet launch: d logs = 3 (<W, dW> + b db) READS the
+    // weight gradients, which live in the per-level buckets a data-parallel run all-reduces (in place, on a side stream) as soon as
+    // the level's mark has passed.  So the pending jobs are launched BEFORE a mark is recorded (computed after the sweep
+    // they could see dW half reduced or summed but not yet averaged); without marks (one GPU) they run as one launch at the end.
+    p->logs_jobs.reserve((size_t)nl * 2);      // (the host table is the source of asynchronous copies: it must not move)
+    size_t logs_done = 0;
+    auto flush_logs = [&]() {
+        const size_t n = p->logs_jobs.size() - logs_done;
+        if (n == 0) return GLOWHIP_OK;
+        if (hipMemcpyAsync(w.ljobs + logs_done, p->logs_jobs.data() + logs_done, n * sizeof(LogsJob), hipMemcpyHostToDevice, s) != hipSuccess) {
+            set_error("backward: hipMemcpyAsync of the log-scale job table failed");
+            return GLOWHIP_ELAUNCH;
+        }
+        GH_TRY(launch_logs_from_dw_batched(w.ljobs + logs_done, (int)n, s));
+        logs_done = p->logs_jobs.size();
+        return GLOWHIP_OK;
+    };
     size_t mark_i = 0;      // gradient-ready marks (glowhip_plan_backward_marks), in sweep order
     auto marks_down_to = [&](int li) {
         while (mark_i < p->bwd_marks.size() && p->bwd_marks[mark_i].first >= li) {
+            GH_TRY(flush_logs());
             if (hipEventRecord(p->bwd_marks[mark_i].second, s) != hipSuccess) { set_error("backward: hipEventRecord of a mark failed"); return GLOWHIP_ELAUNCH; }
             ++mark_i;
         }
@@ -552,13 +570,7 @@ static int backward_sweep(glowhip_plan* p, const void* packed, const float* x_in
         }
         GH_TRY(launch_grad_finalize_batched(w.jobs, (int)jobs.size(), w.gsum, s));
     }
-    if (!p->logs_jobs.empty()) {      // log-scale gradients of the layers whose input-gradient chain ran as one k_cnet launch
-        if (hipMemcpyAsync(w.ljobs, p->logs_jobs.data(), p->logs_jobs.size() * sizeof(LogsJob), hipMemcpyHostToDevice, s) != hipSuccess) {
-            set_error("backward: hipMemcpyAsync of the log-scale job table failed");
-            return GLOWHIP_ELAUNCH;
-        }
-        GH_TRY(launch_logs_from_dw_batched(w.ljobs, (int)p->logs_jobs.size(), s));
-    }
+    GH_TRY(flush_logs());
     return GLOWHIP_OK;
 }
 

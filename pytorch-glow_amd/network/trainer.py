@@ -55,8 +55,10 @@ class _ShardSampler(torch.utils.data.Sampler):
     """Indices of rank `rank`'s shard of every global batch: one seeded permutation per epoch (the same on every rank), cut
     into global batches of `global_batch`, of which this rank yields positions [rank*per, (rank+1)*per)."""
 
-    def __init__(self, dataset, global_batch, rank, world, seed=0):
+    def __init__(self, dataset, global_batch, rank, world, seed=None):
         assert global_batch % world == 0, f"global batch {global_batch} not divisible by {world} ranks"
+        if seed is None:      # no profile seed: follow torch's seed as DataLoader(shuffle=True) does (trainer.py:36-41) -- every rank
+            seed = torch.initial_seed() % (2 ** 31)       # of a data-parallel run seeds alike (util.manual_seed), so the shards line up
         self.n, self.gb, self.rank, self.world, self.seed, self.epoch = len(dataset), global_batch, rank, world, seed, 0
         self.per = global_batch // world
 
@@ -93,7 +95,8 @@ class Trainer:
         # positions [r*B/G, (r+1)*B/G) of it -- no overlap, no omission, no G-fold loading.
         self.data_loader = DataLoader(dataset, batch_size=self.batch_size // world, num_workers=self.hps.dataset.num_workers,
                                       sampler=_ShardSampler(dataset, self.batch_size, rank, world,
-                                                            seed=int(getattr(self.hps.ablation, "seed", 0) or 0)),
+                                                            seed=(int(self.hps.ablation.seed) if getattr(self.hps.ablation, "seed", None)
+                                                                  is not None else None)),
                                       drop_last=True)
         self.num_epochs = (self.hps.optim.num_epochs + len(self.data_loader) - 1) // len(self.data_loader)
         self.y_condition = self.hps.ablation.y_condition

@@ -143,11 +143,14 @@ def allreduce_buckets(buckets, world: Optional[int] = None, average: bool = True
 
 
 def train_step(glow, optimizer, x_local: torch.Tensor, world: int = 1, max_grad_clip: float = 0.0,
-               max_grad_norm: float = 0.0, skip_nonfinite: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+               max_grad_norm: float = 0.0, skip_nonfinite: bool = False,
+               before_update: Optional[Callable[[], None]] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """One data-parallel training step of the reference's loop (network/trainer.py:123-150) on this rank's shard:
     forward (HIP, with tape) -> loss = mean(nll) -> backward (HIP reverse sweep) -> gradient all-reduce (RCCL) ->
     clip_grad_value_ / clip_grad_norm_ -> optimizer.step().  Returns (global mean loss, gradient norm).
     ``skip_nonfinite`` (HIP optimisers): a NaN / inf gradient norm skips the update on the device (training.TrainLoop's range check).
+    ``before_update``: called after forward, backward and the gradient exchange are enqueued and before the optimiser step is --
+    the place where TrainLoop looks at the PREVIOUS step's norm (the device is still a whole forward + backward behind the host).
     The local loss is mean over the LOCAL shard; averaging the gradients over ranks makes it the global mean."""
     optimizer.zero_grad(set_to_none=True)
     with torch.enable_grad():
@@ -159,6 +162,8 @@ def train_step(glow, optimizer, x_local: torch.Tensor, world: int = 1, max_grad_
         allreduce_buckets(buckets, world)       # per level, overlapped with the rest of the sweep (already enqueued)
     else:
         allreduce_gradients(glow, world)
+    if before_update is not None:
+        before_update()
     if hasattr(optimizer, "fused_step"):     # training.HipAdam / HipAdamax: both clippings + the update in two HIP launches
         grad_norm = optimizer.fused_step(max_grad_clip, max_grad_norm, skip_nonfinite=skip_nonfinite)
     else:

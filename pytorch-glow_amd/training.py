@@ -195,6 +195,9 @@ class TrainLoop:
         self.range_check = range_check
         self.range_fallbacks = 0
         self.diverged_steps = 0
+        self.reruns = []             # (global step at the time, loss, grad norm) of every batch that was run again (range check)
+        self.last_rerun = None
+        self._rerun = None
         self._pending = None
         self._host = None
         self.optimizer = optimizer or build_optimizer(hps, glow.parameters())
@@ -214,50 +217,69 @@ class TrainLoop:
         for group in self.optimizer.param_groups:           # trainer.py:89-91
             group["lr"] = self.lr
         checked = self.range_check and hasattr(self.optimizer, "undo_step") and x_local.is_cuda
+        self._rerun = None
         loss, grad_norm = parallel.train_step(self.glow, self.optimizer, x_local, world=self.world,
                                               max_grad_clip=self.max_grad_clip, max_grad_norm=self.max_grad_norm,
-                                              skip_nonfinite=checked)
+                                              skip_nonfinite=checked, before_update=self._check_previous if checked else None)
         self.global_step += 1
         if checked:
-            prev, self._pending = self._pending, self._stash(x_local, grad_norm)
-            if prev is not None:
-                self._resolve(prev)
+            self._pending = self._stash(x_local, grad_norm, self.lr)
+            if self._rerun is not None:
+                self._run_again(self._rerun)
         return loss, grad_norm
 
     # ---- deferred range check (no host sync on the step's own work)
-    def _stash(self, x_local, grad_norm):
+    def _stash(self, x_local, grad_norm, lr):
         if self._host is None:       # two pinned words, used alternately
             self._host = [torch.zeros(1, pin_memory=True), torch.zeros(1, pin_memory=True)]
         host = self._host[self.global_step & 1]
         host.copy_(grad_norm.detach().reshape(1), non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
-        return x_local, host, ev
+        return x_local, host, ev, lr
 
-    def _resolve(self, pending):
-        x_local, host, ev = pending
-        ev.synchronize()                        # that step's norm has landed (its successor is already queued behind it)
-        if bool(torch.isfinite(host).all()):
+    def _check_previous(self):
+        """Runs between this step's gradient exchange and its optimiser step (`parallel.train_step`): the previous step's norm has
+        landed long ago -- the device still has this step's forward and backward in front of it, so the wait stalls nothing.  If
+        the device skipped that update, its count is taken back BEFORE this step's bias corrections are computed from it, and the
+        batch is queued to run again right after this step."""
+        pending, self._pending = self._pending, None
+        if pending is None:
             return
-        # the device skipped that update: take the count back and run the batch again on the exact-fp32 kernels
+        pending[2].synchronize()
+        if bool(torch.isfinite(pending[1]).all()):
+            return
         self.optimizer.undo_step()
         self.range_fallbacks += 1
+        self._rerun = pending
+
+    def _run_again(self, pending):
+        """The skipped batch on the exact-fp32 family, with the learning rate of the step it belonged to.  Its loss and norm
+        replace nothing that was already returned (that step reported NaN): they are kept in ``reruns`` / ``last_rerun``."""
+        x_local, _, _, lr = pending
         plan = self.glow.flow.plan_for(x_local)
         prev = plan.family
         plan.set_family(plan.FAMILY_EXACT_FP32)
+        for group in self.optimizer.param_groups:
+            group["lr"] = lr
         try:
             loss, grad_norm = parallel.train_step(self.glow, self.optimizer, x_local, world=self.world,
                                                   max_grad_clip=self.max_grad_clip, max_grad_norm=self.max_grad_norm,
                                                   skip_nonfinite=True)
         finally:
             plan.set_family(prev)
+            for group in self.optimizer.param_groups:
+                group["lr"] = self.lr
         if not bool(torch.isfinite(grad_norm).all()):      # (a sync, on a path that only runs after an overflow)
             self.optimizer.undo_step()
             self.diverged_steps += 1
         self.last_rerun = (loss, grad_norm)
+        self.reruns.append((self.global_step, float(loss), float(grad_norm)))
 
     def flush(self):
         """Resolve the check of the last step (call before reading parameters for a snapshot, and at the end of training)."""
-        pending, self._pending = self._pending, None
-        if pending is not None:
-            self._resolve(pending)
+        self._rerun = None
+        self._check_previous()
+        if self._rerun is not None:
+            self._run_again(self._rerun)
+            self._rerun = None

@@ -459,3 +459,60 @@ def test_unused_scratch_slots_may_hold_nan():
     plan._ws.view(torch.float32).fill_(float("nan"))
     xr = glow.reverse_flow(dev(z_ref), None, eps=[dev(e) for e in eps])
     close(xr, x_ref, 1e-4, what="decode")
+
+
+def test_captured_forward_survives_packs_of_other_use_masks():
+    """the pack keeps its job tables inside `packed`; a captured forward (repack=True) launches its image
+    kernels over the INFERENCE table with grids baked at capture time.  A training step, an exact-fp32 pack or the init pass
+    on the same plan selects other jobs -- they must go to their own table slot, or the next replay builds its weight images
+    from a table sorted for another mask.  Replays after each kind of foreign pack must still equal the eager forward bit for
+    bit, also after a real parameter update (the 'optimizer step between replays' the capture advertises)."""
+    cfg = O.default_cfg(image_shape=(32, 32, 3), hidden_channels=128, K=3, L=2, batch=6)
+    sd = O.seeded_state_dict(cfg, seed=6)
+    glow = make_glow(cfg, sd, 6).eval()
+    g = torch.Generator().manual_seed(8)
+    x = dev(torch.rand(6, 3, 32, 32, generator=g))
+    with torch.no_grad():
+        gf = glow.capture_forward(x, repack=True)
+        plan = gf.plan
+        for use in (plan.PACK_TRAINING, plan.PACK_INFERENCE | plan.PACK_TRAINING | plan.PACK_INVERSE, plan.PACK_TRAINING | plan.PACK_INVERSE):
+            plan.pack(use, merge=False)              # a foreign mask rewrites ITS slot only
+            z, n = (t.clone() for t in gf())
+            ze, ne, _ = glow.normal_flow(x, None, noise=gf.noise.clone())
+            assert torch.equal(z, ze) and torch.equal(n, ne), f"replay after a pack with use={use}"
+    # a training step (training pack + optimiser update of every parameter) between replays
+    from pytorch_glow_amd import training
+    glow.train()
+    opt = training.HipAdam([p for p in glow.parameters()], lr=1e-3)
+    with torch.enable_grad():
+        _, nll, _ = glow.normal_flow(x, None)
+        G.Glow.generative_loss(nll).backward()
+    opt.fused_step(5.0, 100.0)
+    glow.eval()
+    with torch.no_grad():
+        z, n = (t.clone() for t in gf())
+        ze, ne, _ = glow.normal_flow(x, None, noise=gf.noise.clone())
+        assert torch.equal(z, ze) and torch.equal(n, ne), "replay after a training step"
+        z_ref, nll_ref, _ = O.glow_forward(x.cpu(), gf.noise.cpu(), {k: v.detach().cpu() for k, v in glow.state_dict().items()}, cfg)
+        close(z, z_ref, 1e-4, what="z (replay after a training step)"); close(n, nll_ref, 1e-4, what="nll")
+
+
+def test_eager_calls_after_a_capture_with_side_stream_pack():
+    """plans with C > 128 fork part of their pack onto a side stream and consumers join through events.  Events
+    last recorded INSIDE a capture cannot be waited for from an eager stream (hipErrorCapturedEvent): after
+    capture_forward(repack=True) the first eager encode / decode / pack must drop the stale pending flags instead."""
+    cfg = O.default_cfg(image_shape=(64, 64, 3), hidden_channels=64, K=1, L=5, batch=2)     # levels up to C = 192 on 2x2 pixels
+    sd = O.seeded_state_dict(cfg, seed=12)
+    glow = make_glow(cfg, sd, 2).eval()
+    g = torch.Generator().manual_seed(3)
+    x = dev(torch.rand(2, 3, 64, 64, generator=g))
+    with torch.no_grad():
+        gf = glow.capture_forward(x, repack=True)
+        z1, n1 = (t.clone() for t in gf())
+        ze, ne, _ = glow.normal_flow(x, None, noise=gf.noise.clone())          # eager call right after the capture
+        assert torch.equal(z1, ze) and torch.equal(n1, ne)
+        xr = glow.reverse_flow(ze, None, eps_std=0.0)                           # decode packs W^-1 eagerly, joins the side stream
+        assert torch.isfinite(xr).all()
+        z2, n2 = (t.clone() for t in gf())
+        ze2, ne2, _ = glow.normal_flow(x, None, noise=gf.noise.clone())
+        assert torch.equal(z2, ze2) and torch.equal(n2, ne2)

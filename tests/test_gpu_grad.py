@@ -547,3 +547,53 @@ def test_training_overflow_is_skipped_on_device_then_rerun_on_exact_fp32():
     assert any(not torch.equal(before[k], after[k]) for k in before if k != "h_top"), "the re-run applies the update"
     assert all(torch.isfinite(v).all() for v in after.values())
     assert glow.flow.plan_for(x.to(DEV)).family == 0 and loop.optimizer._steps == 1
+
+
+def test_log_scale_gradients_do_not_read_weight_gradients_after_their_bucket_is_handed_over():
+    """on the backward-k_cnet path d logs of the hidden ActNorms is computed FROM the weight gradients, and those
+    live in the per-level flat buckets a data-parallel run all-reduces in place, on a side stream, as soon as the level's
+    gradient-ready event has passed.  The sweep must therefore have finished every read of a bucket before it records that
+    bucket's event.  Simulated on one GPU: a side stream waits for each event and then CLOBBERS the bucket (what an in-place
+    all-reduce + division does to it, only more so).  The log-scale gradients must equal those of an undisturbed backward bit
+    for bit; the buckets of the levels above the last one are overwritten long before the sweep ends, so a sweep that reads
+    them late fails deterministically."""
+    K, batch = 2, 4
+    cfg = O.default_cfg(K=K, batch=batch)
+    sd = O.seeded_state_dict(cfg, seed=23, invconv_perturb=0.02, zeros_std=0.01)
+    g = torch.Generator().manual_seed(23)
+    x = torch.rand(batch, 3, 64, 64, generator=g)
+    noise = torch.rand(batch, 3, 64, 64, generator=g) / 256
+    sd = O.glow_init_actnorm(x, noise, sd, cfg)
+    glow = G.Glow(hps_for(cfg, batch))
+    glow.load_state_dict(sd)
+    glow.set_actnorm_inited()
+    glow = glow.to(DEV).train()
+    side = torch.cuda.Stream(device=DEV)
+
+    def run(clobber):
+        glow.zero_grad(set_to_none=True)
+        with torch.enable_grad():
+            z, nll, _ = glow.normal_flow(x.to(DEV), None, noise=noise.to(DEV))
+            G.Glow.generative_loss(nll).backward()
+        buckets = glow.flow.pop_grad_buckets()
+        assert buckets is not None and len(buckets) == 3 + 1          # one per level + the small one
+        if clobber:
+            with torch.cuda.stream(side):
+                for flat, ready in buckets[:-1]:
+                    side.wait_event(ready)
+                    flat.fill_(float("nan"))
+            torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        return {n: p.grad.detach().clone() for n, p in glow.named_parameters() if p.grad is not None}
+
+    clean = run(False)
+    assert glow.flow.plan_for(x.to(DEV)).launch_counts().get("k_cnet(bwd)", 0) >= 3 * K
+    hit = run(True)
+    checked = 0
+    for name, gc in clean.items():
+        if name.endswith(("f.0.weight", "f.2.weight", "f.4.weight", "conv2d_zeros.weight")):
+            assert torch.isnan(hit[name]).all(), name         # (the views into the buckets: the clobber did land)
+            continue
+        assert torch.equal(hit[name], gc), f"{name} was computed from a bucket that had already been handed over"
+        checked += name.endswith("actnorm.logs")
+    assert checked >= 3 * K * 3
