@@ -297,7 +297,9 @@ int glowhip_optim_step(const glowhip_optim_chunk* chunks_dev, int n_chunks, int 
  * every encode/decode appends records.  glowhip_plan_timing_read synchronises with the recorded events,
  * copies up to `max` records (launch order) and clears the list. */
 enum { GLOWHIP_K_CHANMIX = 0, GLOWHIP_K_CONV_F0 = 1, GLOWHIP_K_CONV_F2 = 2, GLOWHIP_K_CONV_F4 = 3, GLOWHIP_K_OTHER = 4,
-       GLOWHIP_K_CNET = 5 /* k_cnet: f.0 + f.2 + f.4 of a FlowStep */, GLOWHIP_K_CFINISH = 6 /* its finishing kernel */ };
+       GLOWHIP_K_CNET = 5 /* k_cnet: f.0 + f.2 + f.4 of a FlowStep */, GLOWHIP_K_CFINISH = 6 /* its finishing kernel */,
+       GLOWHIP_K_CNET_TAPE = 7 /* training forward: k_cnet storing h1 / h2 */, GLOWHIP_K_CNET_BWD = 8 /* input-gradient chain on k_cnet */,
+       GLOWHIP_K_WGRAD = 9 /* a FlowStep's three weight-gradient GEMMs + their split-K reduction */ };
 typedef struct glowhip_timing_record {
     int32_t kind;   /* GLOWHIP_K_* */
     int32_t layer;  /* index into the plan's layer list */

@@ -25,6 +25,7 @@
 #include "cnet_fin.h"
 
 GH_STAMPS_DEFINE(cnet)
+GH_WGTIMES_DEFINE(cnet)
 
 #ifndef CN_SB_P1
 #define CN_SB_P1 0
@@ -209,6 +210,7 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
         }
     };
     GH_STAMP(0);
+    GH_WG_BEGIN();
     GH_STAMP_VAL(63, __builtin_amdgcn_s_getreg((31 << 11) | 4));      // HW_REG_HW_ID: wave slot [3:0], SIMD [5:4], CU [11:8]
     // requested before the window is built (their L2 round trips overlap P0): the first two A sets of P1 and of P2
     loadA1(0, 0, A1[0]);
@@ -1073,6 +1075,7 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
         if (v != 0 && n0 + lane < a.N) atomicAdd(a.acc + (n0 + lane), (unsigned long long)v);
     }
     GH_STAMP(21);
+    GH_WG_END();
 }
 
 // ------------------------------------------------------------------------------------------------ finishing kernel

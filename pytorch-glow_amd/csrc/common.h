@@ -111,6 +111,18 @@ __device__ __forceinline__ float relu_(float v) { return v < 0.f ? 0.f : v; }
     extern "C" int glowhip_debug_read_stamps_all_##name(unsigned long long* dst) {   /* [wave][stamp] */        \
         return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(glowhip::g_stamps_local), sizeof(unsigned long long) * 8 * 64); \
     }
+// launch timeline: every workgroup of the last stamped launch records (s_memrealtime at start, at end, HW_ID, XCC_ID) -- 100 MHz
+// chip-wide clock, comparable across CUs
+#define GH_WGTIMES_DEFINE(name)                                                                                 \
+    namespace glowhip { __device__ unsigned long long g_wg_times[4096 * 4]; }                                   \
+    extern "C" int glowhip_debug_read_wgtimes_##name(unsigned long long* dst, int n) {                          \
+        return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(glowhip::g_wg_times), sizeof(unsigned long long) * 4 * n); \
+    }
+#define GH_WG_BEGIN() do { if ((threadIdx.x) == 0) { const int b_ = blockIdx.y * gridDim.x + blockIdx.x; if (b_ < 4096) { \
+        g_wg_times[b_ * 4] = __builtin_amdgcn_s_memrealtime(); g_wg_times[b_ * 4 + 2] = __builtin_amdgcn_s_getreg((31 << 11) | 4); \
+        g_wg_times[b_ * 4 + 3] = __builtin_amdgcn_s_getreg((31 << 11) | 20); } } } while (0)
+#define GH_WG_END() do { if ((threadIdx.x) == 0) { const int b_ = blockIdx.y * gridDim.x + blockIdx.x; if (b_ < 4096) \
+        g_wg_times[b_ * 4 + 1] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #ifndef GH_STAMP_BLOCK
 #define GH_STAMP_BLOCK 0
 #endif
@@ -119,6 +131,9 @@ __device__ __forceinline__ float relu_(float v) { return v < 0.f ? 0.f : v; }
 #define GH_STAMP_VAL(i, v) do { if (blockIdx.x == GH_STAMP_BLOCK && blockIdx.y == 0 && (threadIdx.x & 63) == 0) g_stamps_local[(threadIdx.x >> 6) * 64 + (i)] = (unsigned long long)(v); } while (0)
 #else
 #define GH_STAMPS_DEFINE(name)
+#define GH_WGTIMES_DEFINE(name)
+#define GH_WG_BEGIN() do { } while (0)
+#define GH_WG_END() do { } while (0)
 #define GH_STAMP(i) do { } while (0)
 #define GH_STAMP_VAL(i, v) do { } while (0)
 #endif

@@ -13,19 +13,6 @@
 
 namespace glowhip {
 
-// ---------------------------------------------------------------- optional per-launch timing
-struct ScopedTimer {
-    glowhip_plan* p; hipStream_t s; TimingSlot slot; bool on;
-    ScopedTimer(glowhip_plan* plan, int kind, int mfma, hipStream_t st) : p(plan), s(st), on(plan && plan->timing) {
-        if (!on) return;
-        auto get = [&]() { hipEvent_t e; if (!p->ev_pool.empty()) { e = p->ev_pool.back(); p->ev_pool.pop_back(); }
-                           else (void)hipEventCreate(&e); return e; };
-        slot.kind = kind; slot.layer = p->cur_layer; slot.mfma = mfma; slot.a = get(); slot.b = get();
-        (void)hipEventRecord(slot.a, s);
-    }
-    ~ScopedTimer() { if (on) { (void)hipEventRecord(slot.b, s); p->ev_used.push_back(slot); } }
-};
-
 // ---------------------------------------------------------------- pack kernels
 __global__ void __launch_bounds__(256) k_pack_scales(const float* __restrict__ logs, int n, float* __restrict__ scale,
                                                      float* __restrict__ inv_scale) {

@@ -85,6 +85,20 @@ namespace glowhip {
 
 static inline void count_launch(glowhip_plan* p, const char* name) { if (p) ++p->launch_counts[name]; }
 
+// ---------------------------------------------------------------- optional per-launch timing
+struct ScopedTimer {
+    glowhip_plan* p; hipStream_t s; TimingSlot slot; bool on;
+    ScopedTimer(glowhip_plan* plan, int kind, int mfma, hipStream_t st) : p(plan), s(st), on(plan && plan->timing) {
+        if (!on) return;
+        auto get = [&]() { hipEvent_t e; if (!p->ev_pool.empty()) { e = p->ev_pool.back(); p->ev_pool.pop_back(); }
+                           else (void)hipEventCreate(&e); return e; };
+        slot.kind = kind; slot.layer = p->cur_layer; slot.mfma = mfma; slot.a = get(); slot.b = get();
+        (void)hipEventRecord(slot.a, s);
+    }
+    ~ScopedTimer() { if (on) { (void)hipEventRecord(slot.b, s); p->ev_used.push_back(slot); } }
+};
+
+
 constexpr int REPACK_SLOTS = 16;
 // slot of a use mask's selected repack jobs: the four bits that select images (1 inference, 2 training, 8 round-1 images of cnet
 // layers, 16 init pass' f.0 image); 4 (W^-1) and 32 (no LU) do not change the table

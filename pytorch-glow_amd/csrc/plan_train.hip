@@ -224,7 +224,15 @@ static int forward_train(glowhip_plan* p, const void* packed, const float* x, co
                 }
                 p->tape_has_masks[li] = 1;
                 count_launch(p, "k_cnet(tape)");
-                GH_TRY(launch_cnet(c, s));
+                {
+                    CnetPending pend{};
+                    {
+                        ScopedTimer t(p, GLOWHIP_K_CNET_TAPE, 1, s);
+                        GH_TRY(launch_cnet_main(c, s, &pend));
+                    }
+                    ScopedTimer t(p, GLOWHIP_K_CFINISH, 0, s);
+                    GH_TRY(launch_cnet_finish(c, pend, s));
+                }
                 cur = dst;
                 continue;
             }
@@ -374,6 +382,7 @@ static int backward_sweep(glowhip_plan* p, const void* packed, const float* x_in
     };
     for (int li = nl - 1; li >= 0; --li) {
         GH_TRY(marks_down_to(li + 1));      // every layer above li has been swept
+        p->cur_layer = li;
         const LayerPlan& L = p->layers[li];
         const glowhip_layer_desc& d = L.d;
         const glowhip_layer_grads& G = grads[li];
@@ -415,12 +424,12 @@ static int backward_sweep(glowhip_plan* p, const void* packed, const float* x_in
                 WgradReduceJobs rj{};      // the three split-K reductions of this step run as one launch at its end
                 rj.n = 3;
                 if (vtaps) {
-                    GH_TRY(launch_wgrad_mfma(w.gpre, (long)L.Cout * HW, h2, (long)hid * HW, w.partial, G.f4_w, N, HW, m4, hid,
-                                             L.Cout * 9, hid, 1, s, sh_grad_scale, nullptr, &t4, &rj.job[0]));
+                    { ScopedTimer tw(p, GLOWHIP_K_WGRAD, 1, s); GH_TRY(launch_wgrad_mfma(w.gpre, (long)L.Cout * HW, h2, (long)hid * HW, w.partial, G.f4_w, N, HW, m4, hid,
+                                             L.Cout * 9, hid, 1, s, sh_grad_scale, nullptr, &t4, &rj.job[0])); }
                 } else {
                     GH_TRY(launch_shift_expand(w.gpre, (long)L.Cout * HW, w.col, N, L.Cout, d.H, d.W, m4, -1, s));
-                    GH_TRY(launch_wgrad_mfma(w.col, (long)m4 * HW, h2, (long)hid * HW, w.partial, G.f4_w, N, HW, m4, hid,
-                                             L.Cout * 9, hid, 1, s, sh_grad_scale, nullptr, nullptr, &rj.job[0]));
+                    { ScopedTimer tw(p, GLOWHIP_K_WGRAD, 1, s); GH_TRY(launch_wgrad_mfma(w.col, (long)m4 * HW, h2, (long)hid * HW, w.partial, G.f4_w, N, HW, m4, hid,
+                                             L.Cout * 9, hid, 1, s, sh_grad_scale, nullptr, nullptr, &rj.job[0])); }
                 }
                 CnetArgs c{};
                 c.w0 = at<char>(packed, L.cb_w0); c.w2 = at<char>(packed, L.cb_w2); c.w4 = at<char>(packed, L.cb_w4);
@@ -433,19 +442,22 @@ static int backward_sweep(glowhip_plan* p, const void* packed, const float* x_in
                 c.in_scale = SH2_ACT_SCALE * sh_grad_scale; c.out_scale = 1.0f / c.in_scale; c.bwd = 1;
                 CnetPending pend{};
                 count_launch(p, "k_cnet(bwd)");
-                GH_TRY(launch_cnet_main(c, s, &pend));
+                {
+                    ScopedTimer t(p, GLOWHIP_K_CNET_BWD, 1, s);
+                    GH_TRY(launch_cnet_main(c, s, &pend));
+                }
                 // (its finishing step -- g_y1 += the partial sums -- rides in k_chanmix_bwd below)
-                GH_TRY(launch_wgrad_mfma(w.gh2, (long)hid * HW, h1, (long)hid * HW, w.partial + w.partial_floats, G.f2_w, N, HW, hid, hid,
-                                         hid, hid, 0, s, sh_grad_scale, a2b, nullptr, &rj.job[1]));
+                { ScopedTimer tw(p, GLOWHIP_K_WGRAD, 1, s); GH_TRY(launch_wgrad_mfma(w.gh2, (long)hid * HW, h1, (long)hid * HW, w.partial + w.partial_floats, G.f2_w, N, HW, hid, hid,
+                                         hid, hid, 0, s, sh_grad_scale, a2b, nullptr, &rj.job[1])); }
                 if (vtaps) {
-                    GH_TRY(launch_wgrad_mfma(w.gh1, (long)hid * HW, out, chw, w.partial + 2 * w.partial_floats, G.f0_w, N, HW, hid, n0,
-                                             hid, Ch * 9, 0, s, sh_grad_scale, a0b, &t0, &rj.job[2]));
+                    { ScopedTimer tw(p, GLOWHIP_K_WGRAD, 1, s); GH_TRY(launch_wgrad_mfma(w.gh1, (long)hid * HW, out, chw, w.partial + 2 * w.partial_floats, G.f0_w, N, HW, hid, n0,
+                                             hid, Ch * 9, 0, s, sh_grad_scale, a0b, &t0, &rj.job[2])); }
                 } else {
                     GH_TRY(launch_shift_expand(out, chw, w.col, N, Ch, d.H, d.W, n0, +1, s));
-                    GH_TRY(launch_wgrad_mfma(w.gh1, (long)hid * HW, w.col, (long)n0 * HW, w.partial + 2 * w.partial_floats, G.f0_w, N, HW,
-                                             hid, n0, hid, Ch * 9, 0, s, sh_grad_scale, a0b, nullptr, &rj.job[2]));
+                    { ScopedTimer tw(p, GLOWHIP_K_WGRAD, 1, s); GH_TRY(launch_wgrad_mfma(w.gh1, (long)hid * HW, w.col, (long)n0 * HW, w.partial + 2 * w.partial_floats, G.f0_w, N, HW,
+                                             hid, n0, hid, Ch * 9, 0, s, sh_grad_scale, a0b, nullptr, &rj.job[2])); }
                 }
-                GH_TRY(launch_wgrad_reduce_batched(rj, s));
+                { ScopedTimer tw(p, GLOWHIP_K_WGRAD, 0, s); GH_TRY(launch_wgrad_reduce_batched(rj, s)); }
                 if (G.f2_an_logs) p->logs_jobs.push_back(LogsJob{d.f2_w, G.f2_w, d.f2_an_bias, a2b, G.f2_an_logs, hid, hid});
                 if (G.f0_an_logs) p->logs_jobs.push_back(LogsJob{d.f0_w, G.f0_w, d.f0_an_bias, a0b, G.f0_an_logs, hid, Ch * 9});
                 ChanMixBwdArgs mb{xin, chw, g, g, chw, d.an_bias, at<float>(packed, L.an_scale),

@@ -32,6 +32,8 @@ try:
     out["commit"] = subprocess.check_output(["git", "-C", root, "rev-parse", "--short", "HEAD"]).decode().strip()
 except Exception:
     out["commit"] = None
+import hashlib
+out["cnet_sh_sha16"] = hashlib.sha256(open(os.path.join(root, "pytorch-glow_amd", "csrc", "cnet_sh.hip"), "rb").read()).hexdigest()[:16]
 out["k_cnet_hbm_bytes_per_launch"] = int(2 * f + w)
 out["k_cnet_detail"] = {
     "fetch_bytes_corrected_x2": int(2 * f), "write_bytes": int(w),

@@ -224,3 +224,10 @@ def test_bench_line_carries_the_contract_fields_and_the_secondary_workloads():
     for name, r in sec.items():
         assert r["finite"] and r["value"] > 0 and r["steps"] == (5 if name == "B_train" else 3), (name, r)
     assert "k_cnet" in sec["D_forward"]["kernel_families"] and "k_cnet" in sec["E_forward"]["kernel_families"]
+    # every secondary workload carries the roofline of ITS dominant kernel from the same live-event pass as the headline's
+    for name, r in sec.items():
+        rf = r["roofline"]
+        assert rf["bound"] == "mfma" and rf["launches"] > 0 and 0 < rf["frac"] < 1 and rf["peak"] == d["roofline"]["peak"], (name, rf)
+        assert rf["dominant_kernel_ms_per_step"] < r["ms_per_step_gpu_events"] * 1.05, (name, rf)      # (a part of the step, not more)
+    assert sec["B_train"]["roofline"]["launches"] == 2 * 96          # taping forward + input-gradient chain per FlowStep
+    assert d["roofline"]["launches"] == 96 and set(d["roofline"]["per_level"]) == {"C12_32x32", "C24_16x16", "C48_8x8"}
