@@ -92,7 +92,8 @@ struct RepackJob {
     int use;                     // who reads this image: bit 0 = inference kernels (encode/decode/glow_forward), bit 1 = training
     int transposed;              // source is the FORWARD weight (Cin,Cout,3,3) of which this is the input-gradient conv:
                                  // element (o, ci, tap) = w[ci][o][8 - tap]
-    size_t w_off;                // w == nullptr: the source is packed + w_off (a transposed copy made by launch_flipT_batched)
+    size_t w_off;                // w == nullptr: the source is packed + w_off (a transposed copy made by launch_flipT_batched, or W^-1)
+    int after_lu;                // the source is W^-1 (packed + w_off): built after the LU factorisations, on their stream
 };
 // dst[i][o][ks-1-tap] = src[o][i][tap] (ks = 9: 3x3 weights, 1: a plain transpose): the weight of the input-gradient convolution,
 // in the reference layout, for the SH2 image kernels of the backward k_cnet launch (plan_train.hip)
@@ -103,6 +104,8 @@ int launch_flipT_batched(const FlipJob* jobs_dev, int n_jobs, int max_tiles, voi
 // s_legacy: the stream of the legacy-kind image kernel (the same as s, or a side stream forked from it)
 int launch_pack_batched(const ScaleJob* sj_dev, int n_scale, const RepackJob* rj_dev, const int* n_kind, int tail_blocks, void* packed,
                         hipStream_t s, hipStream_t s_legacy);
+// n SH2_GEMM jobs on their own (the images of W^-1, after the LU factorisations)
+int launch_repack_sh2_gemm(const RepackJob* rj_dev, int n, void* packed, hipStream_t s);
 
 // ---------------------------------------------------------------- conv_direct.hip
 struct ConvArgs {

@@ -457,4 +457,11 @@ int launch_pack_batched(const ScaleJob* sj_dev, int n_scale, const RepackJob* rj
     return GLOWHIP_OK;
 }
 
+int launch_repack_sh2_gemm(const RepackJob* rj_dev, int n, void* packed, hipStream_t s) {
+    if (n <= 0) return GLOWHIP_OK;
+    hipLaunchKernelGGL(k_repack_sh2_batched<REPACK_SH2_GEMM>, dim3(16, n), dim3(256), 0, s, rj_dev, (char*)packed);
+    GH_LAUNCH_CHECK("k_repack_sh2_batched (after LU)");
+    return GLOWHIP_OK;
+}
+
 }  // namespace glowhip

@@ -89,6 +89,96 @@ static bool sh_off(const glowhip_plan* p) { return g_sh_disabled || (p && p->fam
 static bool tail_runs_sh(const glowhip_plan* p, const LayerPlan& L) { return L.sh_mid && L.sh_tail && !sh_off(p) && !g_sh_tail_disabled; }
 static bool cnet_runs(const glowhip_plan* p, const LayerPlan& L) { return L.cnet && !sh_off(p) && !g_cnet_disabled; }
 
+// deep levels (dnet_sh.hip): layers k_cnet does not take, with an invertible 1x1 convolution, on the product family
+static bool dnet_runs(const glowhip_plan* p, const LayerPlan& L) { return L.dnet && !sh_off(p) && !g_cnet_disabled && !g_sh_tail_disabled && !g_sh_first_disabled; }
+// the run of consecutive FlowSteps of li's shape that take the deep-level kernels, walking in direction `dir` (+1 encode, -1 decode)
+static int dnet_run_end(const glowhip_plan* p, int li, int dir) {
+    const int nl = (int)p->layers.size();
+    const glowhip_layer_desc& d = p->layers[li].d;
+    int lj = li;
+    while (lj + dir >= 0 && lj + dir < nl) {
+        const LayerPlan& Ln = p->layers[lj + dir];
+        if (Ln.d.kind != GLOWHIP_LAYER_FLOWSTEP || !dnet_runs(p, Ln) || Ln.d.C != d.C || Ln.d.H != d.H || Ln.d.W != d.W ||
+            Ln.d.hidden != d.hidden || Ln.Cout != p->layers[li].Cout) break;
+        lj += dir;
+    }
+    return lj;
+}
+static int tail_mode(const glowhip_layer_desc& d, int reverse) {
+    return d.coupling == GLOWHIP_COUPLING_AFFINE ? (reverse ? TAIL_AFFINE_REV : TAIL_AFFINE_FWD) : (reverse ? TAIL_ADD_REV : TAIL_ADD_FWD);
+}
+// One level's run of FlowSteps [li .. lj] (encode) on the deep-level kernels: PREP, then MIX -> F0 -> F2 -> F4 -> FIN per step; the
+// result is left in `S` (N, C, H, W).
+static int run_dnet_forward(glowhip_plan* p, const void* packed, int li, int lj, const float* cur, float* S, int N, const Workspace& w,
+                            hipStream_t s) {
+    const LayerPlan& L0 = p->layers[li];
+    const glowhip_layer_desc& d = L0.d;
+    const long chw = (long)d.C * d.H * d.W;
+    DnetLevel D{N, d.C, d.H, d.W, d.hidden, L0.Cout, S, chw, w.h1};
+    GH_TRY(dnet_level_begin(D, s));
+    p->cur_layer = li;
+    {
+        ScopedTimer t(p, GLOWHIP_K_OTHER, 0, s);
+        count_launch(p, "k_dn_prep");
+        GH_TRY(dnet_prep(D, cur, chw, d.an_bias, at<float>(packed, L0.an_scale), 0, s));
+    }
+    for (int k = li; k <= lj; ++k) {
+        const LayerPlan& L = p->layers[k];
+        p->cur_layer = k;
+        {
+            ScopedTimer t(p, GLOWHIP_K_CHANMIX, 1, s);
+            count_launch(p, "k_dn_gemm(mix)");
+            GH_TRY(dnet_mix(D, at<char>(packed, L.dn_mix), nullptr, nullptr, 1, s));
+        }
+        int ks = 1;
+        {
+            ScopedTimer t(p, GLOWHIP_K_CONV_F2, 1, s);
+            count_launch(p, "k_dn_gemm(f0,f2,f4)");
+            GH_TRY(dnet_coupling_net(D, at<char>(packed, L.dn_w0), at<char>(packed, L.dn_w2), at<char>(packed, L.dn_w4), &ks, s));
+        }
+        const LayerPlan* Ln = k < lj ? &p->layers[k + 1] : nullptr;
+        ScopedTimer t(p, GLOWHIP_K_CFINISH, 0, s);
+        count_launch(p, "k_dn_fin");
+        GH_TRY(dnet_finish(D, ks, L.d.f4_bias, at<float>(packed, L.f4_scale), tail_mode(L.d, 0), w.acc, Ln ? Ln->d.an_bias : nullptr,
+                           Ln ? at<float>(packed, Ln->an_scale) : nullptr, Ln != nullptr, s));
+    }
+    return GLOWHIP_OK;
+}
+// ... and decode: steps li, li - 1, ..., lj (li >= lj): PREP, then F0 -> F2 -> F4 -> FIN -> MIX^-1 per step
+static int run_dnet_reverse(glowhip_plan* p, const void* packed, int li, int lj, const float* cur, float* S, int N, const Workspace& w,
+                            hipStream_t s) {
+    const LayerPlan& L0 = p->layers[li];
+    const glowhip_layer_desc& d = L0.d;
+    const long chw = (long)d.C * d.H * d.W;
+    DnetLevel D{N, d.C, d.H, d.W, d.hidden, L0.Cout, S, chw, w.h1};
+    GH_TRY(dnet_level_begin(D, s));
+    p->cur_layer = li;
+    {
+        ScopedTimer t(p, GLOWHIP_K_OTHER, 0, s);
+        count_launch(p, "k_dn_prep");
+        GH_TRY(dnet_prep(D, cur, chw, nullptr, nullptr, 1, s));
+    }
+    for (int k = li; k >= lj; --k) {
+        const LayerPlan& L = p->layers[k];
+        p->cur_layer = k;
+        int ks = 1;
+        {
+            ScopedTimer t(p, GLOWHIP_K_CONV_F2, 1, s);
+            count_launch(p, "k_dn_gemm(f0,f2,f4)");
+            GH_TRY(dnet_coupling_net(D, at<char>(packed, L.dn_w0), at<char>(packed, L.dn_w2), at<char>(packed, L.dn_w4), &ks, s));
+        }
+        {
+            ScopedTimer t(p, GLOWHIP_K_CFINISH, 0, s);
+            count_launch(p, "k_dn_fin");
+            GH_TRY(dnet_finish(D, ks, L.d.f4_bias, at<float>(packed, L.f4_scale), tail_mode(L.d, 1), w.acc, nullptr, nullptr, 1, s));
+        }
+        ScopedTimer t(p, GLOWHIP_K_CHANMIX, 1, s);
+        count_launch(p, "k_dn_gemm(mix)");
+        GH_TRY(dnet_mix(D, at<char>(packed, L.dn_mixinv), at<float>(packed, L.an_inv_scale), L.d.an_bias, k > lj, s));
+    }
+    return GLOWHIP_OK;
+}
+
 // ---- the one-kernel coupling network (cnet_sh.hip).  A FlowStep is k_cnet (partial sums of h = f(z1)) + a finishing step
 // (coupling, log-det, channel mixer); the finishing step of step k runs either as its own kernel or inside step k+1's k_cnet
 // while that builds its window ("pending").
@@ -299,6 +389,16 @@ static int run_forward(glowhip_plan* p, const void* packed, const float* x, cons
                 if (li != nl - 1) dst = w.bufB;
             }
             const int Ch = d.C / 2;
+            if (d.kind == GLOWHIP_LAYER_FLOWSTEP && dnet_runs(p, L) && !premixed && !pending) {
+                // ---- deep level: the whole run of same-shape FlowSteps on the per-layer SH2 kernels (dnet_sh.hip)
+                const int lj = dnet_run_end(p, li, +1);
+                float* S = other_buf(w, cur);
+                GH_TRY(run_dnet_forward(p, packed, li, lj, cur, S, N, w, s));
+                if (lj == nl - 1) GH_TRY(launch_copy_strided(S, chw, z_out, chw, N, chw, s));
+                cur = S;
+                li = lj;
+                continue;
+            }
             if (d.kind == GLOWHIP_LAYER_FLOWSTEP && cnet_runs(p, L) && !g_cnet_h2_only) {
                 // ---- k_cnet path.  `cur` holds the input of this step's mixer, or -- `premixed` -- its output, or -- `pending` --
                 // the state the PREVIOUS step's k_cnet read, whose finishing (coupling + this step's mixer) this launch does itself
@@ -416,6 +516,15 @@ static int run_reverse(glowhip_plan* p, const void* packed, const float* z, cons
             GH_TRY(launch_squeeze(cur, nullptr, dst, N, d.C * 4, d.H / 2, d.W / 2, 2, 1, s));
         } else if (d.kind == GLOWHIP_LAYER_FLOWSTEP) {
             float* z2 = dst + (long)Ch * HW;
+            if (dnet_runs(p, L) && !pending) {
+                const int lj = dnet_run_end(p, li, -1);
+                float* S = other_buf(w, cur);
+                GH_TRY(run_dnet_reverse(p, packed, li, lj, cur, S, N, w, s));
+                if (lj == 0) GH_TRY(launch_copy_strided(S, chw, x_out, chw, N, chw, s));
+                cur = S;
+                li = lj;
+                continue;
+            }
             if (cnet_runs(p, L) && !g_cnet_h2_only) {
                 // coupling^-1, permutation^-1 and ActNorm^-1 by the finishing step -- run by the next-executed step's k_cnet where
                 // the two chain, by the finishing kernel otherwise
@@ -587,6 +696,15 @@ glowhip_plan* glowhip_plan_create(const glowhip_layer_desc* layers, int n_layers
                     L.wt0 = take(off, (size_t)d.hidden * (C / 2) * 9 * 4);
                 }
             }
+            L.dnet = !L.cnet && d.permutation == GLOWHIP_PERM_INVCONV && dnet_supported(C, H, W, d.hidden, L.Cout);
+            if (L.dnet) {
+                L.dn_mix = take(off, sh2_image_bytes(C, C));
+                L.dn_mixinv = take(off, sh2_image_bytes(C, C));
+                L.dn_w0 = take(off, sh2_image_bytes(cnet_g0(C / 2) * 8, d.hidden));
+                L.dn_w2 = take(off, sh2_image_bytes(d.hidden, d.hidden));
+                L.dn_w4 = take(off, sh2_image_bytes(cnet_g0(d.hidden) * 8, L.Cout));
+                p->max_hidden = std::max(p->max_hidden, (long)((dnet_scratch_bytes_per_sample(C, H, W, d.hidden, L.Cout) + 3) / 4));
+            }
             if (L.mfma_last) L.f4_wp = take(off, conv_mfma_tail_packed_bytes(d.hidden, L.Cout));
             L.wide_last = !L.mfma_last && conv_mfma_wide_supported(d.hidden, H, W, L.Cout, 3);
             if (L.wide_last) L.f4_wt = take(off, conv_mfma_wide_packed_bytes(d.hidden, L.Cout, 3));
@@ -627,13 +745,16 @@ glowhip_plan* glowhip_plan_create(const glowhip_layer_desc* layers, int n_layers
             p->scale_jobs.push_back(ScaleJob{d.f0_an_logs, L.f0_scale, 0, d.hidden, 0});
             p->scale_jobs.push_back(ScaleJob{d.f2_an_logs, L.f2_scale, 0, d.hidden, 0});
             p->scale_jobs.push_back(ScaleJob{d.f4_logs, L.f4_scale, 0, L.Cout, 0});
+            // inference-use bit of the round-1 / fp32 images: layers that run k_cnet or the deep-level kernels read them only under
+            // the family switches (bit 8)
+            const int inf = (L.cnet || L.dnet) ? 8 : 1;
             if (L.first_halo) {
                 RepackJob r{}; r.w = d.f0_w; r.out_off = L.f0_wt; r.kind = REPACK_FIRST; r.Cin = d.C / 2; r.Cout = d.hidden;
-                r.fold_bias = d.f0_an_bias; r.fold_logs = d.f0_an_logs; r.use = 2 | (L.sh_first ? 0 : 1);
+                r.fold_bias = d.f0_an_bias; r.fold_logs = d.f0_an_logs; r.use = 2 | (L.sh_first ? 0 : inf);
                 p->repack_jobs.push_back(r);
             } else if (L.mfma_first) {
                 RepackJob r{}; r.w = d.f0_w; r.out_off = L.f0_wt; r.kind = REPACK_WIDE; r.Cin = d.C / 2; r.Cout = d.hidden;
-                r.K = r.Cin * 9; r.Kpad = wide_kpad(r.Cin, 3); r.use = 3; p->repack_jobs.push_back(r);
+                r.K = r.Cin * 9; r.Kpad = wide_kpad(r.Cin, 3); r.use = 2 | inf; p->repack_jobs.push_back(r);
             }
             if (L.first_halo && L.f0_init) {   // use bit 16 (internal): read by the data-dependent init pass only
                 RepackJob r{}; r.w = d.f0_w; r.out_off = L.f0_init; r.kind = REPACK_WIDE; r.Cin = d.C / 2; r.Cout = d.hidden;
@@ -641,18 +762,18 @@ glowhip_plan* glowhip_plan_create(const glowhip_layer_desc* layers, int n_layers
             }
             if (L.mfma_mid) {
                 RepackJob r{}; r.w = d.f2_w; r.out_off = L.f2_wt; r.kind = REPACK_WIDE; r.Cin = d.hidden; r.Cout = d.hidden;
-                r.K = r.Cin; r.Kpad = wide_kpad(r.Cin, 1); r.use = 2 | (L.sh_mid ? 0 : 1); p->repack_jobs.push_back(r);
+                r.K = r.Cin; r.Kpad = wide_kpad(r.Cin, 1); r.use = 2 | (L.sh_mid ? 0 : inf); p->repack_jobs.push_back(r);
             }
             if (L.sh_mid) {
                 RepackJob r{}; r.w = d.f2_w; r.out_off = L.f2_sh; r.kind = REPACK_SH_GEMM; r.Cin = d.hidden; r.Cout = d.hidden;
-                r.K = d.hidden; r.fold_bias = d.f2_an_bias; r.fold_logs = d.f2_an_logs; r.use = 2 | (L.cnet ? 8 : 1); p->repack_jobs.push_back(r);
+                r.K = d.hidden; r.fold_bias = d.f2_an_bias; r.fold_logs = d.f2_an_logs; r.use = 2 | inf; p->repack_jobs.push_back(r);
                 // input gradient of f.2 on the same kernel: W2^T, nothing folded (training only)
                 RepackJob t{}; t.w = d.f2_w; t.out_off = L.f2T_sh; t.kind = REPACK_SH_GEMM; t.Cin = d.hidden; t.Cout = d.hidden;
                 t.K = d.hidden; t.transposed = 1; t.use = 2; p->repack_jobs.push_back(t);
             }
             if (L.sh_first) {
                 RepackJob r{}; r.w = d.f0_w; r.out_off = L.f0_sh; r.kind = REPACK_SH_FIRST; r.Cin = d.C / 2; r.Cout = d.hidden;
-                r.K = (9 * ((r.Cin + 7) / 8) + 1) & ~1; r.fold_bias = d.f0_an_bias; r.fold_logs = d.f0_an_logs; r.use = L.cnet ? 8 : 1;
+                r.K = (9 * ((r.Cin + 7) / 8) + 1) & ~1; r.fold_bias = d.f0_an_bias; r.fold_logs = d.f0_an_logs; r.use = inf;
                 p->repack_jobs.push_back(r);
             }
             if (L.cnet) {
@@ -667,6 +788,18 @@ glowhip_plan* glowhip_plan_create(const glowhip_layer_desc* layers, int n_layers
                     r4.kind = REPACK_SH2_TAIL; r4.Cin = d.hidden; r4.Cout = cg;
                     r4.Kpad = cnet_mpad4(cg); r4.use = 3; p->repack_jobs.push_back(r4);
                 }
+            }
+            if (L.dnet) {      // deep levels: the mixer as a GEMM image (W; W^-1 after the LU), f.0 / f.4 as (chunk, tap) images, f.2
+                RepackJob rm{}; rm.w = d.invconv_w; rm.out_off = L.dn_mix; rm.kind = REPACK_SH2_GEMM; rm.Cin = d.C; rm.Cout = d.C; rm.K = d.C; rm.use = 1;
+                p->repack_jobs.push_back(rm);
+                RepackJob ri{}; ri.w = nullptr; ri.w_off = L.winv; ri.out_off = L.dn_mixinv; ri.kind = REPACK_SH2_GEMM; ri.Cin = d.C; ri.Cout = d.C;
+                ri.K = d.C; ri.use = 4; ri.after_lu = 1; p->repack_jobs.push_back(ri);
+                RepackJob r0{}; r0.w = d.f0_w; r0.out_off = L.dn_w0; r0.kind = REPACK_SH2_FIRST; r0.Cin = d.C / 2; r0.Cout = d.hidden;
+                r0.K = cnet_g0(d.C / 2); r0.fold_bias = d.f0_an_bias; r0.fold_logs = d.f0_an_logs; r0.use = 1; p->repack_jobs.push_back(r0);
+                RepackJob r2{}; r2.w = d.f2_w; r2.out_off = L.dn_w2; r2.kind = REPACK_SH2_GEMM; r2.Cin = d.hidden; r2.Cout = d.hidden;
+                r2.K = d.hidden; r2.fold_bias = d.f2_an_bias; r2.fold_logs = d.f2_an_logs; r2.use = 1; p->repack_jobs.push_back(r2);
+                RepackJob r4{}; r4.w = d.f4_w; r4.out_off = L.dn_w4; r4.kind = REPACK_SH2_FIRST; r4.Cin = d.hidden; r4.Cout = L.Cout;
+                r4.K = cnet_g0(d.hidden); r4.use = 1; p->repack_jobs.push_back(r4);
             }
             if (L.cnet_bwd) {      // (training only) transposed copies, then the same three image kinds over them
                 const int Ch = d.C / 2;
@@ -684,17 +817,17 @@ glowhip_plan* glowhip_plan_create(const glowhip_layer_desc* layers, int n_layers
             }
             if (L.sh_tail) {
                 RepackJob r{}; r.w = d.f4_w; r.out_off = L.f4_sh; r.kind = REPACK_SH_TAIL; r.Cin = d.hidden; r.Cout = L.Cout;
-                r.Kpad = tail_sh_mpad(d.hidden, d.H, d.W, L.Cout, &r.MT); r.use = L.cnet ? 8 : 1; p->repack_jobs.push_back(r);
+                r.Kpad = tail_sh_mpad(d.hidden, d.H, d.W, L.Cout, &r.MT); r.use = inf; p->repack_jobs.push_back(r);
             }
             if (L.mfma_last) {
                 RepackJob r{}; r.w = d.f4_w; r.out_off = L.f4_wp; r.kind = REPACK_TAIL; r.Cin = d.hidden; r.Cout = L.Cout;
                 r.paired = d.coupling == GLOWHIP_COUPLING_AFFINE; r.MT = tail_mt(L.Cout, r.paired);
-                r.use = 2 | (L.sh_tail ? 0 : 1);
+                r.use = 2 | (L.sh_tail ? 0 : inf);
                 r.total = (long)tail_chunks(r.Cin) * (TAIL_CK / 4) * 9 * r.MT * 64; p->repack_jobs.push_back(r);
             }
             if (L.wide_last) {
                 RepackJob r{}; r.w = d.f4_w; r.out_off = L.f4_wt; r.kind = REPACK_WIDE; r.Cin = d.hidden; r.Cout = L.Cout;
-                r.K = r.Cin * 9; r.Kpad = wide_kpad(r.Cin, 3); r.use = 3; p->repack_jobs.push_back(r);
+                r.K = r.Cin * 9; r.Kpad = wide_kpad(r.Cin, 3); r.use = 2 | inf; p->repack_jobs.push_back(r);
             }
             if (L.dg4_first) {   // input gradient of f.4 = 3x3 conv Cout -> hidden with w[ci][o][8-tap]
                 RepackJob r{}; r.w = d.f4_w; r.out_off = L.f4T_wf; r.kind = REPACK_FIRST; r.Cin = L.Cout; r.Cout = d.hidden;
@@ -826,7 +959,10 @@ int glowhip_plan_describe_for(const glowhip_plan* plan, int N, char* buf, size_t
             // "-sh": split-half f16 matrix-pipe kernels (sh.h) are selected for this convolution (unless disabled by the
             // debug switch); the name before it is the exact-fp32 kernel that would run otherwise
             const bool sh = L.sh_mid && !sh_off(plan);
-            if (cnet_runs(plan, L) && !g_cnet_h2_only)
+            if (dnet_runs(plan, L))
+                snprintf(line, sizeof line, "%d flowstep C=%d H=%d W=%d hidden=%d f=dnet-sh2 (mix, f.0, f.2, f.4, finish: one launch per layer)\n", li, d.C,
+                         d.H, d.W, d.hidden);
+            else if (cnet_runs(plan, L) && !g_cnet_h2_only)
                 snprintf(line, sizeof line, "%d flowstep C=%d H=%d W=%d hidden=%d f=cnet-sh2 (f.0+f.2+f.4 one kernel + finish)\n", li, d.C, d.H,
                          d.W, d.hidden);
             else
@@ -860,9 +996,10 @@ int glowhip_plan_pack_for(glowhip_plan* plan, void* packed, size_t packed_bytes,
     if (plan->family == GLOWHIP_FAMILY_EXACT_FP32) use |= GLOWHIP_PACK_TRAINING;
     if ((use & GLOWHIP_PACK_INFERENCE) && (g_cnet_disabled || g_cnet_h2_only)) use |= 8;
     plan->repack_sel.clear();
-    int n_kind[4] = {0, 0, 0, 0}, tail_blocks = 1;
-    auto group = [](const RepackJob& r) { return r.kind < REPACK_SH2_GEMM ? 0 : r.kind - REPACK_SH2_GEMM + 1; };
-    for (int gk = 0; gk < 4; ++gk)            // sorted by kind group: each image kernel is launched over its own jobs only
+    int n_kind[5] = {0, 0, 0, 0, 0}, tail_blocks = 1;
+    // (group 4: SH2 GEMM images of W^-1 -- launched after the LU factorisations, on their stream)
+    auto group = [](const RepackJob& r) { return r.after_lu ? 4 : (r.kind < REPACK_SH2_GEMM ? 0 : r.kind - REPACK_SH2_GEMM + 1); };
+    for (int gk = 0; gk < 5; ++gk)            // sorted by kind group: each image kernel is launched over its own jobs only
         for (const RepackJob& r : plan->repack_jobs)
             if ((r.use & use) && group(r) == gk) {
                 plan->repack_sel.push_back(r);
@@ -941,6 +1078,8 @@ int glowhip_plan_pack_for(glowhip_plan* plan, void* packed, size_t packed_bytes,
         GH_TRY(launch_step_prepare_batched(at<StepPrepJob>(packed, plan->prep_off), (int)plan->prep_jobs.size(),
                                            plan->max_lds_c, packed, side, (use & (GLOWHIP_PACK_INVERSE | GLOWHIP_PACK_TRAINING)) != 0,
                                            plan->max_c));
+        if ((use & GLOWHIP_PACK_INVERSE) && n_kind[4] > 0)
+            GH_TRY(launch_repack_sh2_gemm(at<RepackJob>(packed, slot_off) + (n_kind[0] + n_kind[1] + n_kind[2] + n_kind[3]), n_kind[4], packed, side));
     }
     if (side != s) {
         if (hipEventRecord(plan->ev_lu, side) != hipSuccess) { set_error("plan_pack: hipEventRecord failed"); return GLOWHIP_ELAUNCH; }

@@ -32,6 +32,9 @@ struct LayerPlan {
     // the input-gradient chain as one k_cnet launch (MODE 2): SH2 images of the transposed weights (cb_w0: f.4^T as the 3x3 first
     // layer, cb_w2: f.2^T, cb_w4: f.0^T as the 3x3 last layer) and the transposed fp32 copies they are built from (wt4 / wt2 / wt0)
     bool cnet_bwd = false; size_t cb_w0 = 0, cb_w2 = 0, cb_w4 = 0, wt4 = 0, wt2 = 0, wt0 = 0;
+    // deep levels (dnet_sh.hip): one launch per layer on SH2 images -- the mixer W (and W^-1, built after the LU), f.0 and f.4 as
+    // (chunk, tap) implicit-GEMM images, f.2 as a plain GEMM image
+    bool dnet = false; size_t dn_mix = 0, dn_mixinv = 0, dn_w0 = 0, dn_w2 = 0, dn_w4 = 0;
     bool wide_last = false; size_t f4_wt = 0;   // f.4 on k_conv_wide<3> (+ separate coupling tail): levels no tail kernel takes (4x4 pixels)
     bool first_halo = false;  // f.0 on k_conv_first (stationary pixel window) instead of k_conv_wide<3>
     size_t f0_init = 0;       // data-dependent init pass: PLAIN K-major image of f.0 for k_conv_wide<3> (the k_conv_first image has
@@ -64,7 +67,7 @@ struct glowhip_plan {
     bool legacy_pending = false, lu_pending = false;
     const void* tables_in = nullptr;      // the `packed` buffer that already holds the job tables (glowhip_plan_forget_packed resets)
     unsigned slots_in = 0;                // ... and which of its repack-table slots (repack_slot) have been filled
-    std::vector<RepackJob> repack_slot_host[16];
+    std::vector<RepackJob> repack_slot_host[32];
     bool pending_captured = false;        // ev_legacy / ev_lu were last recorded inside a stream capture (see join_legacy)
     int max_lds_c = 0, max_c = 0;
     size_t packed_bytes = 0;
@@ -99,10 +102,10 @@ struct ScopedTimer {
 };
 
 
-constexpr int REPACK_SLOTS = 16;
-// slot of a use mask's selected repack jobs: the four bits that select images (1 inference, 2 training, 8 round-1 images of cnet
-// layers, 16 init pass' f.0 image); 4 (W^-1) and 32 (no LU) do not change the table
-static inline int repack_slot(int use) { return (use & 3) | ((use & 8) >> 1) | ((use & 16) >> 1); }
+constexpr int REPACK_SLOTS = 32;
+// slot of a use mask's selected repack jobs: the five bits that select images (1 inference, 2 training, 4 inverse: the W^-1 images
+// of the deep levels, 8 round-1 images of cnet / dnet layers, 16 init pass' f.0 image); 32 (no LU) does not change the table
+static inline int repack_slot(int use) { return use & 31; }
 
 static inline bool stream_capturing(hipStream_t s) {
     hipStreamCaptureStatus st = hipStreamCaptureStatusNone;

@@ -245,4 +245,28 @@ bool cnet_chain_enabled();   // testing hook (off by default: measured slower, s
 bool cnet_pre_supported(int Cin, int H, int W, int hidden, int Cout, int C);         // window-time finishing fits the LDS
 void cnet_force(int ms, int flags);   // testing hook: ms in {0 (automatic), 1, 2, 4}
 
+// ---- FlowSteps of the deep levels (C >= 192, a few hundred pixels per launch): one launch per LAYER, rows split over workgroups,
+// activations between the launches as ready-made SH2 B operands in L2 (dnet_sh.hip) -------------------------------------------
+constexpr int DNET_KS_MAX = 8;                 // largest K split of the f.4 launch (partial-sum copies in the scratch)
+struct DnetLevel {
+    int N, C, H, W, hidden, Cout;
+    float* state; long state_bs;               // (N, C, H, W) fp32: the level's running state, updated in place
+    void* scratch;                             // N * dnet_scratch_bytes_per_sample(...) bytes
+};
+bool dnet_supported(int C, int H, int W, int hidden, int Cout);
+size_t dnet_scratch_bytes_per_sample(int C, int H, int W, int hidden, int Cout);
+int dnet_level_begin(const DnetLevel& L, hipStream_t s);      // zero the padded operands' borders (once per level and call)
+// first launch of a level: forward u = SH2((src + an_bias) * an_scale); reverse: src's first C/2 channels as the padded F0 operand;
+// both copy src into L.state when it lives elsewhere
+int dnet_prep(const DnetLevel& L, const float* src, long src_bs, const float* an_bias, const float* an_scale, int reverse, hipStream_t s);
+// MIX: state <- W u (forward; w_image = SH2_GEMM image of W) or (W^-1 u) * post_scale - post_bias (reverse); want_pad: also the
+// first C/2 channels as the padded operand of the next F0
+int dnet_mix(const DnetLevel& L, const void* w_image, const float* post_scale, const float* post_bias, int want_pad, hipStream_t s);
+// F0 -> F2 -> F4 on the padded z1 operand; *ks_out = number of K-split partial copies F4 left in the scratch
+int dnet_coupling_net(const DnetLevel& L, const void* w0_sh2_first, const void* w2_sh2_gemm, const void* w4_sh2_first, int* ks_out, hipStream_t s);
+// FIN: coupling (mode = TailMode) on L.state in place + log-det; want_u: the next MIX's operand, with the next step's ActNorm
+// (u_bias / u_scale, forward) or plain (null, reverse)
+int dnet_finish(const DnetLevel& L, int ks, const float* f4_bias, const float* f4_scale, int mode, unsigned long long* acc,
+                const float* u_bias, const float* u_scale, int want_u, hipStream_t s);
+
 }  // namespace glowhip

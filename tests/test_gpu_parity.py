@@ -650,3 +650,52 @@ def test_uint8_pixels_equal_the_float_path_bitwise():
     close(z8, z_ref, 1e-4, what="z"); close(nll8, nll_ref, 1e-4, what="nll")
     with pytest.raises(G.GlowHipError):
         glow.normal_flow(u8.to(DEV).to(torch.int16), None)
+
+
+@pytest.mark.parametrize("image,L,hidden,batch,coup", [
+    (128, 5, 64, 4, "affine"),       # levels 64^2 .. 4x4; C = 192 at 4x4 pixels on the deep-level kernels, P = 64 pixels
+    (128, 5, 64, 3, "additive"),     # P = 48: not a whole number of 32-pixel tiles; additive coupling (f.4 has C/2 rows)
+    (64, 5, 32, 5, "affine"),        # C = 96 at 4x4 (k_cnet needs >= 64 pixels per image) and C = 192 at 2x2 pixels
+    (32, 3, 64, 2, "affine"),        # only narrow levels (C <= 48): the deep-level kernels must NOT be selected
+])
+def test_deep_level_kernels_vs_oracle(image, L, hidden, batch, coup):
+    """FlowSteps of the deep levels (dnet_sh.hip: k_cnet does not take them; C a multiple of 32) run one launch per LAYER -- mixer
+    (the invertible 1x1 convolution as an SH2 GEMM), f.0, f.2, f.4 with K-split partial sums, finishing kernel -- forward and
+    inverse.  z / nll / decode against the oracle on every element; the kernel selection is read from the executor's launch
+    counters: no round-1 / fp32 convolution kernel may run for a layer the deep-level kernels take.  Reference:
+    network/model.py:82-154 (FlowStep), network/module.py:344-369 (Invertible1x1Conv) at the shapes of model.py:242-261."""
+    K = 2
+    cfg = O.default_cfg(image_shape=(image, image, 3), hidden_channels=hidden, K=K, L=L, flow_coupling=coup, batch=batch)
+    sd = O.seeded_state_dict(cfg, seed=31, zeros_std=0.01, invconv_perturb=0.03)
+    g = torch.Generator().manual_seed(32)
+    x = torch.rand(batch, 3, image, image, generator=g)
+    noise = torch.rand(batch, 3, image, image, generator=g) / 256
+    with torch.no_grad():
+        sd = O.glow_init_actnorm(x, noise, sd, cfg)
+        z_ref, nll_ref, _ = O.glow_forward(x, noise, sd, cfg)
+    assert torch.isfinite(nll_ref).all()
+    glow = make_glow(cfg, sd, batch)
+    plan = glow.flow.plan_for(dev(x))
+    desc = plan.describe(batch)
+    deep = [l for l in desc.splitlines() if "dnet-sh2" in l]
+    assert (len(deep) >= K) if L >= 5 else (len(deep) == 0), desc
+    plan.launch_counts(reset=True)
+    z, nll, _ = glow.normal_flow(dev(x), None, noise=dev(noise))
+    fwd = plan.launch_counts(reset=True)
+    ez = close(z, z_ref, 1e-4, what="z"); en = close(nll, nll_ref, 1e-4, what="nll")
+    eps = [torch.randn(batch, *s, generator=g) * 0.7 for s in glow.flow.split_shapes((3, image, image))]
+    with torch.no_grad():
+        x_ref = O.glow_reverse(z_ref, sd, cfg, eps)
+    xr = glow.reverse_flow(dev(z_ref), None, eps=[dev(e) for e in eps])
+    rev = plan.launch_counts(reset=True)
+    ex = close(xr, x_ref, 1e-4, what="decode")
+    print(f"{image}x{image} L={L} hidden={hidden} B={batch} {coup}: {len(deep)} deep steps; max-abs z {ez:.2e} nll {en:.2e} decode {ex:.2e}\n {fwd}\n {rev}")
+    for counts in (fwd, rev):
+        assert counts.get("k_dn_gemm(mix)", 0) == len(deep) and counts.get("k_dn_fin", 0) == len(deep), counts
+        assert counts.get("k_dn_gemm(f0,f2,f4)", 0) == len(deep), counts
+    if deep and len(deep) == sum("flowstep" in l and "cnet-sh2" not in l for l in desc.splitlines()):
+        legacy = {"k_first_sh", "k_gemm_sh", "k_tail_sh", "k_tail_sh+mixer", "k_conv_wide_f32", "k_gemm_f32", "k_conv_first_f32", "k_conv_tail_f32", "k_f02_sh"}
+        assert not (legacy & set(fwd)) and not (legacy & set(rev)), (fwd, rev)
+    # bitwise reproducible run to run (fixed reduction orders, fixed-point log-det)
+    z2, nll2, _ = glow.normal_flow(dev(x), None, noise=dev(noise))
+    assert torch.equal(z, z2) and torch.equal(nll, nll2)
