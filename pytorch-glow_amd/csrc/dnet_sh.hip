@@ -48,7 +48,7 @@ __device__ __forceinline__ long dn_pad_slot(int p, int HW, int W) {
 // NW waves; tile = RT x PT MFMA tiles of 32 rows x 32 pixels; the waves split the k-steps (two 8-wide k groups each) and their
 // partial tiles are added through LDS in a fixed order.  Operands come straight from L2: the launch is a few microseconds of
 // latency-bound work whatever is done, what matters is that each weight is read by one workgroup row only.
-template <int NW, int RT, int PT>
+template <int NW, int RT, int PT, int NPF>
 __global__ void __launch_bounds__(NW * 64) k_dn_gemm(DnGemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) float red[];      // [NW][RT * PT][16][64]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, kl = lane >> 5, ml = lane & 31;
@@ -71,7 +71,13 @@ __global__ void __launch_bounds__(NW * 64) k_dn_gemm(DnGemmArgs a) {
         for (int j = 0; j < PT; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    h8 Ac[2 * RT], Bc[2 * PT], An[2 * RT], Bn[2 * PT];
+    // Operand sets NPF k-steps ahead, in NAMED register sets (the loop is unrolled by NPF).  A wave has only a handful of k-steps and
+    // the weights come from HBM (every weight of a forward is read once: 580 MB at config E, nothing of it stays in a cache): with
+    // one set in flight the launch was a chain of memory round trips (13 per wave in F0 at C = 384).  Every load is issued
+    // unconditionally from a clamped (valid) step, so the waits are counted; only the MFMAs of a step past the wave's last are skipped.
+    h8 Af[NPF][2 * RT], Bf[NPF][2 * PT];
+    const int n_mine = max(0, (s_hi - s_lo - wid + NW - 1) / NW);       // k-steps of this wave: s_lo + wid + t * NW
+    auto step_of = [&](int t) { return min(s_lo + wid + min(t, max(n_mine - 1, 0)) * NW, S - 1); };
     auto load = [&](int s, h8 (&A)[2 * RT], h8 (&B)[2 * PT]) {
         const int g = 2 * s + kl;
         const _Float16* pa = ap + (long)g * a.M * 8;
@@ -95,28 +101,26 @@ __global__ void __launch_bounds__(NW * 64) k_dn_gemm(DnGemmArgs a) {
             B[PT + j] = *reinterpret_cast<const h8*>(pb + a.b_plane);
         }
     };
-    int s = s_lo + wid;
-    if (s < s_hi) load(s, Ac, Bc);
-    for (; s < s_hi; s += NW) {
-        const bool more = s + NW < s_hi;
-        if (more) load(s + NW, An, Bn);
 #pragma unroll
-        for (int i = 0; i < RT; ++i)
+    for (int d = 0; d < NPF; ++d) load(step_of(d), Af[d], Bf[d]);
+    for (int t0 = 0; t0 < n_mine; t0 += NPF) {
 #pragma unroll
-            for (int j = 0; j < PT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ac[i], Bc[j], acc[i][j], 0, 0, 0);
+        for (int d = 0; d < NPF; ++d) {
+            if (t0 + d < n_mine) {         // (wave-uniform)
 #pragma unroll
-        for (int i = 0; i < RT; ++i)
+                for (int i = 0; i < RT; ++i)
 #pragma unroll
-            for (int j = 0; j < PT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ac[i], Bc[PT + j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < PT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Af[d][i], Bf[d][j], acc[i][j], 0, 0, 0);
 #pragma unroll
-        for (int i = 0; i < RT; ++i)
+                for (int i = 0; i < RT; ++i)
 #pragma unroll
-            for (int j = 0; j < PT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ac[RT + i], Bc[j], acc[i][j], 0, 0, 0);
-        if (more) {
+                    for (int j = 0; j < PT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Af[d][i], Bf[d][PT + j], acc[i][j], 0, 0, 0);
 #pragma unroll
-            for (int i = 0; i < 2 * RT; ++i) Ac[i] = An[i];
+                for (int i = 0; i < RT; ++i)
 #pragma unroll
-            for (int j = 0; j < 2 * PT; ++j) Bc[j] = Bn[j];
+                    for (int j = 0; j < PT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Af[d][RT + i], Bf[d][j], acc[i][j], 0, 0, 0);
+            }
+            load(step_of(t0 + d + NPF), Af[d], Bf[d]);
         }
     }
     // ---- the waves' partial tiles -> LDS [wave][tile][register][lane] (lane-contiguous: conflict-free both ways)
@@ -236,11 +240,18 @@ __global__ void __launch_bounds__(256) k_dn_fin(DnFinArgs a) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int c = cc + q, ce = paired ? 2 * c : c, co = ce + (paired ? 1 : 0);
+        float pe[DNET_KS_MAX], po[DNET_KS_MAX];             // every partial requested before the first is used (clamped, selected)
+#pragma unroll
+        for (int k = 0; k < DNET_KS_MAX; ++k) {
+            const float* pp = a.part + (((long)min(k, a.ks - 1) * a.N + n) * a.Cout + ce) * HW + q_;
+            pe[k] = pp[0];
+            po[k] = pp[paired ? HW : 0];
+        }
         float se = 0.f, so = 0.f;
-        for (int k = 0; k < a.ks; ++k) {                   // fixed order
-            const float* pp = a.part + (((long)k * a.N + n) * a.Cout + ce) * HW + q_;
-            se += pp[0];
-            so += pp[paired ? HW : 0];
+#pragma unroll
+        for (int k = 0; k < DNET_KS_MAX; ++k) {            // fixed order
+            se += k < a.ks ? pe[k] : 0.f;
+            so += k < a.ks ? po[k] : 0.f;
         }
         z1[q] = zp[(long)c * HW];
         const float zin = zp[(long)(Ch + c) * HW];
@@ -299,10 +310,10 @@ bool dnet_supported(int C, int H, int W, int hidden, int Cout) {
     return C % 32 == 0 && (C / 2) % 8 == 0 && Cout % 32 == 0 && hidden % 32 == 0 && H >= 1 && W >= 1 && H * W <= 4096;
 }
 
-static int dn_ksplit(int M, int P, int S) {      // K split of F4: towards 192 workgroups, at least two k-steps per wave
-    const int tiles = ((M + 63) / 64) * ((P + 63) / 64);
+static int dn_ksplit(int M, int P, int S) {      // K split of F4: every wave's k-steps in flight at once (NPF), >= 4 of them per wave
+    const int tiles = ((M + (P >= 512 ? 63 : 31)) / (P >= 512 ? 64 : 32)) * ((P + 63) / 64);
     int ks = 1;
-    while (ks < DNET_KS_MAX && tiles * ks < 160 && S / (ks * 2) >= 16) ks *= 2;
+    while (ks < DNET_KS_MAX && tiles * ks < 320 && S / (ks * 2) >= 16) ks *= 2;
     return ks;
 }
 
@@ -312,16 +323,21 @@ size_t dnet_scratch_bytes_per_sample(int C, int H, int W, int hidden, int Cout) 
 }
 
 static int dn_launch_gemm(const DnGemmArgs& a, hipStream_t s) {
-    const bool rt2 = a.M % 64 == 0, pt2 = a.P > 32;
+    // 32-row tiles unless the launch has pixels to spare (every row tile re-reads the B operand from L2, every weight is read once
+    // either way): more workgroups, and -- with fewer registers per operand set -- more k-steps of weights in flight per wave
+    const bool pt2 = a.P > 32, rt2 = a.M % 64 == 0 && a.P >= 512;
     const dim3 grid((a.P + (pt2 ? 63 : 31)) / (pt2 ? 64 : 32), a.M / (rt2 ? 64 : 32), a.ksplit);
-#define DN_GO(RT, PT)                                                                                                         \
-    {                                                                                                                         \
-        const size_t lds = (size_t)8 * RT * PT * 16 * 64 * sizeof(float);                                                     \
-        if (lds > 32 * 1024)                                                                                                  \
-            (void)hipFuncSetAttribute((const void*)k_dn_gemm<8, RT, PT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((k_dn_gemm<8, RT, PT>), grid, dim3(512), lds, s, a);                                               \
+#define DN_GO(RT, PT, NPF)                                                                                                          \
+    {                                                                                                                               \
+        const size_t lds = (size_t)8 * RT * PT * 16 * 64 * sizeof(float);                                                           \
+        static bool attr_set = false;      /* (per instance: the attribute sticks to the function) */                              \
+        if (lds > 32 * 1024 && !attr_set) {                                                                                         \
+            (void)hipFuncSetAttribute((const void*)k_dn_gemm<8, RT, PT, NPF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            attr_set = true;                                                                                                        \
+        }                                                                                                                           \
+        hipLaunchKernelGGL((k_dn_gemm<8, RT, PT, NPF>), grid, dim3(512), lds, s, a);                                                \
     }
-    if (rt2 && pt2) DN_GO(2, 2) else if (rt2) DN_GO(2, 1) else if (pt2) DN_GO(1, 2) else DN_GO(1, 1)
+    if (rt2 && pt2) DN_GO(2, 2, 4) else if (pt2) DN_GO(1, 2, 6) else DN_GO(1, 1, 8)
 #undef DN_GO
     GH_LAUNCH_CHECK("k_dn_gemm");
     return GLOWHIP_OK;

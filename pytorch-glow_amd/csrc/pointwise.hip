@@ -98,11 +98,95 @@ __global__ void __launch_bounds__(256) k_squeeze_u8(const uint8_t* __restrict__ 
     y[idx] = v;
 }
 
+// Factor-2 squeeze / unsqueeze as a register transpose (the shapes every flow plan uses; W % 4 == 0): a thread owns FOUR consecutive
+// pixels of an input row pair -- two 16-byte loads of fully coalesced rows -- and emits the four output planes' two-pixel runs as
+// 8-byte stores (a wave writes 512 contiguous bytes per plane).  One Philox call serves the four pixels of a row segment (the
+// generic kernel evaluates all ten rounds per element and keeps one word of four).  32-bit index arithmetic, no LDS.  Same values,
+// bit for bit, as k_squeeze / k_squeeze_u8 (tests/test_gpu_parity.py, test_gpu_infer.py).
+__device__ __forceinline__ void dequant_noise4(unsigned long long seed, unsigned long long call, unsigned long long i4, float scale, float (&out)[4]) {
+    unsigned int c0 = (unsigned int)(i4 >> 2), c1 = (unsigned int)(i4 >> 34), c2 = (unsigned int)call, c3 = (unsigned int)(call >> 32);
+    unsigned int k0 = (unsigned int)seed, k1 = (unsigned int)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+        const unsigned int n0 = (unsigned int)(p1 >> 32) ^ c1 ^ k0, n2 = (unsigned int)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (unsigned int)p1; c3 = (unsigned int)p0; c0 = n0; c2 = n2;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    const unsigned int w[4] = {c0, c1, c2, c3};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) out[q] = (float)(w[q] >> 8) * (1.0f / 16777216.0f) * scale;
+}
+
+// SRC: 0 = float input, 1 = 8-bit input (forward only).  grid.x covers (plane, row pair, group of 4 input pixels) of ONE image.
+template <int SRC>
+__global__ void __launch_bounds__(256) k_squeeze2_fwd(const void* __restrict__ xin, const float* __restrict__ noise, float* __restrict__ y,
+                                                      int C, int H, int W, float divisor, RngSpec rng) {
+    const int W4 = W >> 2, Ho = H >> 1, Wo = W >> 1;
+    const int per_img = C * Ho * W4;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= per_img) return;
+    const int n = blockIdx.y;
+    const int k = t % W4, r = t / W4, h = r % Ho, c = r / Ho;
+    const long img_in = (long)n * C * H * W;
+    float v[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const long src = img_in + ((long)c * H + 2 * h + i) * W + 4 * k;
+        if (SRC == 1) {
+            const uchar4 u = *reinterpret_cast<const uchar4*>((const uint8_t*)xin + src);
+            v[i][0] = (float)u.x / divisor; v[i][1] = (float)u.y / divisor; v[i][2] = (float)u.z / divisor; v[i][3] = (float)u.w / divisor;
+        } else {
+            const float4 f = *reinterpret_cast<const float4*>((const float*)xin + src);
+            v[i][0] = f.x; v[i][1] = f.y; v[i][2] = f.z; v[i][3] = f.w;
+        }
+        if (noise) {
+            const float4 f = *reinterpret_cast<const float4*>(noise + src);
+            v[i][0] += f.x; v[i][1] += f.y; v[i][2] += f.z; v[i][3] += f.w;
+        } else if (rng.on) {
+            float z[4];
+            dequant_noise4(rng.seed, rng.call, (unsigned long long)src, rng.scale, z);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[i][q] += z[q];
+        }
+    }
+    // out[n][4c + 2i + j][h][2k + m] = in[n][c][2h + i][4k + 2m + j]
+    float* o = y + ((long)n * 4 * C + 4 * c) * Ho * Wo + (long)h * Wo + 2 * k;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            *reinterpret_cast<float2*>(o + (long)(2 * i + j) * Ho * Wo) = make_float2(v[i][j], v[i][2 + j]);
+}
+
+// unsqueeze: x (N, C, H, W) -> y (N, C/4, 2H, 2W); a thread reads two pixels of each of the four planes, writes two 16-byte row segments
+__global__ void __launch_bounds__(256) k_squeeze2_rev(const float* __restrict__ x, float* __restrict__ y, int C, int H, int W) {
+    const int W2 = W >> 1, Co = C >> 2;
+    const int per_img = Co * H * W2;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= per_img) return;
+    const int n = blockIdx.y;
+    const int k = t % W2, r = t / W2, h = r % H, c = r / H;
+    const float* in = x + ((long)n * C + 4 * c) * H * W + (long)h * W + 2 * k;
+    float2 p[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) p[q] = *reinterpret_cast<const float2*>(in + (long)q * H * W);
+    float* o = y + (((long)n * Co + c) * 2 * H + 2 * h) * (2 * W) + 4 * k;
+    *reinterpret_cast<float4*>(o) = make_float4(p[0].x, p[1].x, p[0].y, p[1].y);
+    *reinterpret_cast<float4*>(o + 2 * W) = make_float4(p[2].x, p[3].x, p[2].y, p[3].y);
+}
+
 int launch_squeeze_u8(const uint8_t* x, const float* noise, float* y, int N, int C, int H, int W, int f, float divisor,
                       hipStream_t s, const RngSpec* rng) {
     GH_REQUIRE(f >= 1 && H % f == 0 && W % f == 0, "squeeze2d(u8): H,W must be divisible by the factor");
     long total = (long)N * C * H * W;
     if (total == 0) return GLOWHIP_OK;
+    if (f == 2 && W % 4 == 0 && N <= 65535 && (long)C * H * W < (1l << 31) && ((size_t)x & 3) == 0 && (!noise || ((size_t)noise & 15) == 0)) {
+        hipLaunchKernelGGL(k_squeeze2_fwd<1>, dim3(cdiv((long)C * (H / 2) * (W / 4), 256), N), dim3(256), 0, s, (const void*)x, noise, y, C, H, W,
+                           divisor, rng ? *rng : RngSpec{});
+        GH_LAUNCH_CHECK("k_squeeze2_fwd(u8)");
+        return GLOWHIP_OK;
+    }
     hipLaunchKernelGGL(k_squeeze_u8, dim3(cdiv(total, 256)), dim3(256), 0, s, x, noise, y, total, C, H, W, f, divisor, rng ? *rng : RngSpec{});
     GH_LAUNCH_CHECK("k_squeeze_u8");
     return GLOWHIP_OK;
@@ -115,6 +199,18 @@ int launch_squeeze(const float* x, const float* noise, float* y, int N, int C, i
     else GH_REQUIRE(C >= f * f && C % (f * f) == 0, "unsqueeze2d: C must be a multiple of factor^2");
     long total = (long)N * C * H * W;
     if (total == 0) return GLOWHIP_OK;
+    const bool small = N <= 65535 && (long)C * H * W < (1l << 31);
+    if (f == 2 && !reverse && W % 4 == 0 && small && ((size_t)x & 15) == 0 && ((size_t)y & 7) == 0 && (!noise || ((size_t)noise & 15) == 0)) {
+        hipLaunchKernelGGL(k_squeeze2_fwd<0>, dim3(cdiv((long)C * (H / 2) * (W / 4), 256), N), dim3(256), 0, s, (const void*)x, noise, y, C, H, W,
+                           1.0f, rng ? *rng : RngSpec{});
+        GH_LAUNCH_CHECK("k_squeeze2_fwd");
+        return GLOWHIP_OK;
+    }
+    if (f == 2 && reverse && W % 2 == 0 && small && !noise && !(rng && rng->on) && ((size_t)x & 7) == 0 && ((size_t)y & 15) == 0) {
+        hipLaunchKernelGGL(k_squeeze2_rev, dim3(cdiv((long)(C / 4) * H * (W / 2), 256), N), dim3(256), 0, s, x, y, C, H, W);
+        GH_LAUNCH_CHECK("k_squeeze2_rev");
+        return GLOWHIP_OK;
+    }
     hipLaunchKernelGGL(k_squeeze, dim3(cdiv(total, 256)), dim3(256), 0, s, x, noise, y, total, C, H, W, f, reverse, rng ? *rng : RngSpec{});
     GH_LAUNCH_CHECK("k_squeeze");
     return GLOWHIP_OK;

@@ -443,7 +443,7 @@ def test_mfma_flowstep_vs_oracle(c, h, w, hidden, coup, n):
     x = torch.randn(n, c, h, w, generator=torch.Generator().manual_seed(1))
     ld = torch.randn(n, generator=torch.Generator().manual_seed(2))
     desc = st._plan(dev(x)).describe()
-    assert "cnet-sh2" in desc or ("f0=mfma" in desc and "f2=mfma" in desc and "f4=mfma" in desc), desc
+    assert "cnet-sh2" in desc or "dnet-sh2" in desc or ("f0=mfma" in desc and "f2=mfma" in desc and "f4=mfma" in desc), desc
     z, ldz = st(dev(x), dev(ld))
     zr, ldr = O.flowstep(x, ld, sd, "", "invconv", coup)
     close(z, zr, 2e-5, what="fwd z"); ld_close(ldz, ldr)
