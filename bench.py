@@ -254,7 +254,7 @@ def setup_workload(G, util, parallel, device, cfg_name, mode, B, rank, world, re
     t_init = time.perf_counter() - t_init
     glow.eval()
     plan = glow.flow.plan_for(x)
-    wl = dict(glow=glow, hps=hps, plan=plan, x=x, cfg=cfg, init_ms=round(1e3 * t_init, 1))
+    wl = dict(glow=glow, hps=hps, plan=plan, x=x, cfg=cfg, init_ms=round(1e3 * t_init, 1), step0=dict(parallel.STEP0))
     if mode == "inverse":
         wl["z_top"] = z_top = torch.randn((B,) + tuple(plan.out_chw), device=device) * 0.7
     if mode == "train":
@@ -476,7 +476,9 @@ def main():
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        import datetime
+        # (generous: ranks != 0 sit in the step-0 barrier while rank 0 runs the data-dependent init pass)
+        dist.init_process_group("nccl", device_id=device, timeout=datetime.timedelta(minutes=30))
         assert dist.get_world_size() == args.gpus, f"{dist.get_world_size()} ranks joined, --gpus {args.gpus}"
 
     import pytorch_glow_amd as G
@@ -537,6 +539,7 @@ def main():
             "ms_per_step_max": round(per_step[-1], 4), "host_enqueue_ms_per_step": round(1e3 * dt_host / args.steps, 4),
             "rccl_world_size": dist.get_world_size() if world > 1 else 1, "launch": wl["launch"],
             "data_dependent_init_ms": wl["init_ms"],     # first training-mode forward (ActNorm statistics layer by layer + one forward), once
+            "step0_exchange_ms": wl["step0"],            # rank 0: init pass | wait of the others in the barrier | flat parameter broadcast
             "arithmetic": "fp32 values carried as 2 x f16 (hi, lo), exact f16 products, fp32 accumulate (csrc/sh.h); "
                           "max-abs vs CPU reference 7e-6 (z), same as the exact-fp32 kernels",
             "config": {"workload": f"{cfg['label']}, {what}, batch {B}/GPU ({cfg['ref']})", "global_batch": world * B,

@@ -103,6 +103,16 @@ __global__ void __launch_bounds__(NW * 64) k_dn_gemm(DnGemmArgs a) {
     };
 #pragma unroll
     for (int d = 0; d < NPF; ++d) load(step_of(d), Af[d], Bf[d]);
+    // row scale / bias of the wave's first epilogue item: requested here, so that their round trip is not paid after the barrier
+    const float* rowscale = reinterpret_cast<const float*>(a.A + 2 * a_plane);
+    const float* rbias = rowscale + a.M;
+    f32x4_t rs_first, bb_first;
+    {
+        const int t = wid >> 2, gq = wid & 3, i = t / PT;
+        const int row = min(r0 + i * 32 + 8 * gq + 4 * kl, a.M - 4);
+        rs_first = *reinterpret_cast<const f32x4_t*>(rowscale + row);
+        bb_first = *reinterpret_cast<const f32x4_t*>(rbias + row);
+    }
     for (int t0 = 0; t0 < n_mine; t0 += NPF) {
 #pragma unroll
         for (int d = 0; d < NPF; ++d) {
@@ -132,8 +142,6 @@ __global__ void __launch_bounds__(NW * 64) k_dn_gemm(DnGemmArgs a) {
             for (int r = 0; r < 16; ++r) red[((wid * (RT * PT) + i * PT + j) * 16 + r) * 64 + lane] = acc[i][j][r];
     __syncthreads();
     // ---- items = (tile, group of four accumulator registers = four consecutive rows of one pixel per lane), wave w takes w, w + NW, ...
-    const float* rowscale = reinterpret_cast<const float*>(a.A + 2 * a_plane);
-    const float* rbias = rowscale + a.M;
     for (int it = wid; it < RT * PT * 4; it += NW) {
         const int t = it >> 2, gq = it & 3, i = t / PT, j = t - i * PT;
         f32x4_t v = {0.f, 0.f, 0.f, 0.f};
@@ -144,7 +152,7 @@ __global__ void __launch_bounds__(NW * 64) k_dn_gemm(DnGemmArgs a) {
         const int row = r0 + i * 32 + 8 * gq + 4 * kl;     // first of the lane's four rows
         const int p = p0 + j * 32 + ml;
         if (p >= a.P || row >= a.M) continue;
-        const f32x4_t rs = *reinterpret_cast<const f32x4_t*>(rowscale + row);
+        const f32x4_t rs = it == wid ? rs_first : *reinterpret_cast<const f32x4_t*>(rowscale + row);
         const int n = p / HW, q_ = p - n * HW;
         if (a.epi == DN_EPI_PARTIAL) {                     // true value of the partial sum (the activation scale undone)
             float* o = a.out_f32 + (((long)blockIdx.z * a.N + n) * a.M + row) * HW + q_;
@@ -154,7 +162,7 @@ __global__ void __launch_bounds__(NW * 64) k_dn_gemm(DnGemmArgs a) {
         }
         f32x4_t val;                                       // the layer output times SH2_ACT_SCALE
         if (a.epi == DN_EPI_ACT) {
-            const f32x4_t bb = *reinterpret_cast<const f32x4_t*>(rbias + row);
+            const f32x4_t bb = it == wid ? bb_first : *reinterpret_cast<const f32x4_t*>(rbias + row);
 #pragma unroll
             for (int q = 0; q < 4; ++q) val[q] = relu_(fmaf(v[q], rs[q], bb[q]));
         } else {
@@ -310,10 +318,13 @@ bool dnet_supported(int C, int H, int W, int hidden, int Cout) {
     return C % 32 == 0 && (C / 2) % 8 == 0 && Cout % 32 == 0 && hidden % 32 == 0 && H >= 1 && W >= 1 && H * W <= 4096;
 }
 
-static int dn_ksplit(int M, int P, int S) {      // K split of F4: every wave's k-steps in flight at once (NPF), >= 4 of them per wave
-    const int tiles = ((M + (P >= 512 ? 63 : 31)) / (P >= 512 ? 64 : 32)) * ((P + 63) / 64);
+static int dn_ksplit(int M, int P, int S) {      // K split of F4: all workgroups resident at once (64-row x 64-pixel tiles take 128 KB of
+                                                 // LDS: one per CU; the smaller ones two), >= 4 k-steps per wave
+    const bool big = P >= 512 && M % 64 == 0;
+    const int tiles = ((M + (big ? 63 : 31)) / (big ? 64 : 32)) * ((P + 63) / 64);
+    const int cap = big ? 256 : 512;
     int ks = 1;
-    while (ks < DNET_KS_MAX && tiles * ks < 320 && S / (ks * 2) >= 16) ks *= 2;
+    while (ks < DNET_KS_MAX && tiles * ks * 2 <= cap && S / (ks * 2) >= 32) ks *= 2;
     return ks;
 }
 

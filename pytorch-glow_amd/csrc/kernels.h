@@ -102,8 +102,9 @@ int launch_flipT_batched(const FlipJob* jobs_dev, int n_jobs, int max_tiles, voi
 // rj_dev: the repack jobs SORTED by kind group (legacy kinds | SH2_GEMM | SH2_FIRST | SH2_TAIL), n_kind[4] their counts;
 // tail_blocks: workgroups per SH2_TAIL job (8 output channels each)
 // s_legacy: the stream of the legacy-kind image kernel (the same as s, or a side stream forked from it)
+// first_blocks: workgroups per SH2_FIRST job (32 rows each for the jobs with >= 64 input channels; 2 x 256 rows otherwise)
 int launch_pack_batched(const ScaleJob* sj_dev, int n_scale, const RepackJob* rj_dev, const int* n_kind, int tail_blocks, void* packed,
-                        hipStream_t s, hipStream_t s_legacy);
+                        hipStream_t s, hipStream_t s_legacy, int first_blocks = 2);
 // n SH2_GEMM jobs on their own (the images of W^-1, after the LU factorisations)
 int launch_repack_sh2_gemm(const RepackJob* rj_dev, int n, void* packed, hipStream_t s);
 

@@ -320,6 +320,63 @@ __device__ __forceinline__ void repack_sh2_first(const RepackJob& j, char* packe
     }
 }
 
+// SH2_FIRST with many input channels (the deep levels' f.4 as a direct 3x3 image: 64 chunks per row; their f.0: 12 / 24): a WAVE takes
+// eight rows, lane = (brick-in-pass) * 8 + row, so a row's bricks are spread over eight lanes (one lane per row walked 64 bricks
+// twice: 0.67 ms per pack at config E).  Same values as repack_sh2_first: the row maximum is a maximum, the split is per element.
+__device__ __forceinline__ void repack_sh2_first_wide(const RepackJob& j, char* packed) {
+    const int M = j.Cout, G = j.K, Kp = G * 8;
+    _Float16* oh = (_Float16*)(packed + j.out_off);
+    float* rowscale = (float*)(packed + j.out_off + (size_t)2 * Kp * M * sizeof(_Float16));
+    float* rbias = rowscale + M;
+    const int nchunk = (j.Cin + 7) / 8;
+    const int lane = threadIdx.x & 63, r8 = lane & 7, gl = lane >> 3;
+    for (int r0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 8; r0 < M; r0 += gridDim.x * 32) {
+        const int r = r0 + r8;
+        const bool rv = r < M;
+        const float fold = (rv && j.fold_logs) ? expf(j.fold_logs[r] * LOGSCALE) : 1.f;
+        const float* row = repack_src(j, packed) + (long)(rv ? r : 0) * j.Cin * 9;
+        float mx = 0.f;
+        for (int ch = gl; ch < nchunk; ch += 8) {
+            float b[72];
+            load_brick(row + ch * 72, min(8, j.Cin - ch * 8), rv, b);
+#pragma unroll
+            for (int i = 0; i < 72; ++i) mx = fmaxf(mx, fabsf(b[i] * fold));
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 8, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const int e = sh2_row_exponent(mx);
+        const float up = ldexpf(1.f, e);
+        for (int ch = gl; ch < nchunk; ch += 8) {
+            float b[72];
+            load_brick(row + ch * 72, min(8, j.Cin - ch * 8), rv, b);
+#pragma unroll
+            for (int i = 0; i < 72; ++i) b[i] *= fold;      // same rounding order as the row maximum: (w * fold) * 2^e
+            if (!rv) continue;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                h8 hi, lo;
+                brick_emit(b, tap, up, hi, lo);
+                const int gi = ch * 9 + tap;
+                *reinterpret_cast<h8*>(oh + ((long)gi * M + r) * 8) = hi;
+                *reinterpret_cast<h8*>(oh + ((long)(G + gi) * M + r) * 8) = lo;
+            }
+        }
+        if (!rv) continue;
+        h8 z;
+#pragma unroll
+        for (int k8 = 0; k8 < 8; ++k8) z[k8] = (_Float16)0.f;
+        for (int gi = nchunk * 9 + gl; gi < G; gi += 8) {   // the k padding up to a whole number of pipeline steps
+            *reinterpret_cast<h8*>(oh + ((long)gi * M + r) * 8) = z;
+            *reinterpret_cast<h8*>(oh + ((long)(G + gi) * M + r) * 8) = z;
+        }
+        if (gl == 0) {
+            rowscale[r] = ldexpf(1.f, -e);
+            rbias[r] = (j.fold_bias ? j.fold_bias[r] * fold : 0.f) * SH2_ACT_SCALE;
+        }
+    }
+}
+
 // SH2_TAIL: a block takes EIGHT output channels (lane = brick-in-pass * 8 + channel, the four waves split the bricks) and emits
 // their 9 x 8 rows; row maxima go through LDS.  Rows beyond 9 Cout (the padding to whole row tiles) are zero-filled.
 __device__ __forceinline__ void repack_sh2_tail(const RepackJob& j, char* packed) {
@@ -398,7 +455,7 @@ __global__ void __launch_bounds__(256) k_repack_sh2_batched(const RepackJob* __r
     const RepackJob j = jobs[blockIdx.y];
     if (j.kind != KIND) return;
     if (KIND == REPACK_SH2_GEMM) repack_sh2_rows<REPACK_SH2_GEMM>(j, packed);
-    else if (KIND == REPACK_SH2_FIRST) repack_sh2_first(j, packed);
+    else if (KIND == REPACK_SH2_FIRST) { if (j.Cin >= 64) repack_sh2_first_wide(j, packed); else repack_sh2_first(j, packed); }
     else repack_sh2_tail(j, packed);
 }
 
@@ -434,7 +491,7 @@ int launch_flipT_batched(const FlipJob* jobs_dev, int n_jobs, int max_tiles, voi
 }
 
 int launch_pack_batched(const ScaleJob* sj_dev, int n_scale, const RepackJob* rj_dev, const int* n_kind, int tail_blocks, void* packed,
-                        hipStream_t s, hipStream_t s_legacy) {
+                        hipStream_t s, hipStream_t s_legacy, int first_blocks) {
     if (n_scale > 0) {
         hipLaunchKernelGGL(k_pack_scales_batched, dim3(2, n_scale), dim3(256), 0, s, sj_dev, (char*)packed);
         GH_LAUNCH_CHECK("k_pack_scales_batched");
@@ -449,7 +506,7 @@ int launch_pack_batched(const ScaleJob* sj_dev, int n_scale, const RepackJob* rj
     rj += n_kind[0];
     if (n_kind[1] > 0) hipLaunchKernelGGL(k_repack_sh2_batched<REPACK_SH2_GEMM>, dim3(16, n_kind[1]), dim3(256), 0, s, rj, (char*)packed);
     rj += n_kind[1];
-    if (n_kind[2] > 0) hipLaunchKernelGGL(k_repack_sh2_batched<REPACK_SH2_FIRST>, dim3(2, n_kind[2]), dim3(256), 0, s, rj, (char*)packed);
+    if (n_kind[2] > 0) hipLaunchKernelGGL(k_repack_sh2_batched<REPACK_SH2_FIRST>, dim3(first_blocks > 2 ? first_blocks : 2, n_kind[2]), dim3(256), 0, s, rj, (char*)packed);
     rj += n_kind[2];
     if (n_kind[3] > 0)
         hipLaunchKernelGGL(k_repack_sh2_batched<REPACK_SH2_TAIL>, dim3(tail_blocks > 0 ? tail_blocks : 1, n_kind[3]), dim3(256), 0, s, rj, (char*)packed);

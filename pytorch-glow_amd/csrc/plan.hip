@@ -996,7 +996,7 @@ int glowhip_plan_pack_for(glowhip_plan* plan, void* packed, size_t packed_bytes,
     if (plan->family == GLOWHIP_FAMILY_EXACT_FP32) use |= GLOWHIP_PACK_TRAINING;
     if ((use & GLOWHIP_PACK_INFERENCE) && (g_cnet_disabled || g_cnet_h2_only)) use |= 8;
     plan->repack_sel.clear();
-    int n_kind[5] = {0, 0, 0, 0, 0}, tail_blocks = 1;
+    int n_kind[5] = {0, 0, 0, 0, 0}, tail_blocks = 1, first_blocks = 2;
     // (group 4: SH2 GEMM images of W^-1 -- launched after the LU factorisations, on their stream)
     auto group = [](const RepackJob& r) { return r.after_lu ? 4 : (r.kind < REPACK_SH2_GEMM ? 0 : r.kind - REPACK_SH2_GEMM + 1); };
     for (int gk = 0; gk < 5; ++gk)            // sorted by kind group: each image kernel is launched over its own jobs only
@@ -1005,6 +1005,7 @@ int glowhip_plan_pack_for(glowhip_plan* plan, void* packed, size_t packed_bytes,
                 plan->repack_sel.push_back(r);
                 ++n_kind[gk];
                 if (gk == 3) tail_blocks = std::max(tail_blocks, (r.Cout + 7) / 8);
+                if (gk == 2 && r.Cin >= 64) first_blocks = std::max(first_blocks, std::min(16, (r.Cout + 31) / 32));
             }
     GH_REQUIRE(packed_bytes >= plan->packed_bytes, "plan_pack: packed buffer too small (%zu < %zu)", packed_bytes,
                plan->packed_bytes);
@@ -1069,7 +1070,7 @@ int glowhip_plan_pack_for(glowhip_plan* plan, void* packed, size_t packed_bytes,
     if (use & GLOWHIP_PACK_TRAINING)      // transposed weight copies for the backward k_cnet images (read by the image kernels below)
         GH_TRY(launch_flipT_batched(at<FlipJob>(packed, plan->flip_off), (int)plan->flip_jobs.size(), plan->flip_tiles, packed, s));
     GH_TRY(launch_pack_batched(at<ScaleJob>(packed, plan->scale_off), (int)plan->scale_jobs.size(),
-                               at<RepackJob>(packed, slot_off), n_kind, tail_blocks, packed, s, side));
+                               at<RepackJob>(packed, slot_off), n_kind, tail_blocks, packed, s, side, first_blocks));
     if (side != s) {
         if (hipEventRecord(plan->ev_legacy, side) != hipSuccess) { set_error("plan_pack: hipEventRecord failed"); return GLOWHIP_ELAUNCH; }
         plan->legacy_pending = true; plan->pending_captured = stream_capturing(s);

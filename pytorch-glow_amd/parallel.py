@@ -53,10 +53,19 @@ def broadcast_parameters(module: torch.nn.Module, src: int = 0, world: Optional[
             off += n
 
 
+STEP0 = {}      # timing of the last step-0 exchange on this rank: {"init_ms", "wait_ms", "broadcast_ms"} (bench.py reports it)
+
+
 def data_dependent_init(glow, x_local: torch.Tensor, rank: int, world: int,
                         init_fn: Optional[Callable] = None) -> None:
     """Step-0 exchange: rank 0 initialises every ActNorm from ITS shard, everyone receives the result.
-    `init_fn(glow, x)` defaults to one training-mode forward (which performs the init on the HIP path)."""
+    `init_fn(glow, x)` defaults to one training-mode forward (which performs the init on the HIP path).
+    The other ranks have nothing to do while rank 0 runs the init pass (66 ms at config B, 0.3 s at config E, once): they wait in a
+    barrier of their own first, so that the wait is visible as such (`STEP0["wait_ms"]`) and the parameter broadcast behind it is
+    timed on its own; the process group's timeout (bench.py / Trainer: 30 minutes) is what bounds the wait, not RCCL's default."""
+    import time
+    sync = (lambda: torch.cuda.synchronize(x_local.device)) if x_local.is_cuda else (lambda: None)
+    t0 = time.perf_counter()
     if rank == 0:
         if init_fn is None:
             was_training = glow.training
@@ -65,7 +74,15 @@ def data_dependent_init(glow, x_local: torch.Tensor, rank: int, world: int,
             glow.train(was_training)
         else:
             init_fn(glow, x_local)
+    sync()
+    t1 = time.perf_counter()
+    if world > 1:
+        dist.barrier()
+    t2 = time.perf_counter()
     broadcast_parameters(glow, src=0, world=world)
+    sync()
+    t3 = time.perf_counter()
+    STEP0.update(init_ms=round(1e3 * (t1 - t0), 2), wait_ms=round(1e3 * (t2 - t1), 2), broadcast_ms=round(1e3 * (t3 - t2), 2))
     glow.set_actnorm_inited(True)
 
 

@@ -113,6 +113,46 @@ def test_forward_and_decode_after_250_training_steps():
     _compare_with_oracles(glow, sd, cfg, x, noise, eps, "after 250 training steps")
 
 
+def test_config_b_geometry_after_160_training_steps():
+    """The trained-scale pin at the HEADLINE geometry: 64x64x3, L = 3, hidden 512 (C = 12 / 24 / 48 on 32^2 / 16^2 /
+    8^2 pixels: the three product instances of k_cnet, taping and backward included), K = 4 so that the fp64 oracle finishes in
+    seconds.  160 steps of the HIP training loop on structured images (batch 16, Adam, noam warm-up 40, clip 5 / 100), then
+    forward / nll / decode of the resulting weights on held-out images against the fp32 and fp64 oracles at the usual bars."""
+    from pytorch_glow_amd import training
+    torch.manual_seed(1)
+    np.random.seed(1)
+    batch = 16
+    cfg = O.default_cfg(K=4, batch=batch)
+    hps = hps_for(cfg, batch)
+    hps.optim.update(optimizer="adam", optimizer_args=dict(lr=1e-3, betas=[0.9, 0.9999], eps=1e-8),
+                     lr_scheduler="noam", lr_scheduler_args=dict(warmup_steps=40, min_lr=1e-4))
+    hps.ablation.update(max_grad_clip=5, max_grad_norm=100)
+    glow = G.Glow(hps).to(DEV)
+    loop = training.TrainLoop(glow, hps)
+    data = _structured_images(64, 64, seed=2).to(DEV)
+    losses = []
+    for step in range(160):
+        xb = data[(step * batch) % 64:(step * batch) % 64 + batch]
+        loss, _ = loop.step(xb)
+        if step % 20 == 0 or step == 159:
+            losses.append(loss.item())
+    loop.flush()
+    counts = glow.flow.plan_for(data[:batch]).launch_counts(reset=True)
+    assert counts.get("k_cnet(tape)", 0) > 0 and counts.get("k_cnet(bwd)", 0) > 0, counts       # the product training kernels ran
+    assert loop.range_fallbacks == 0 and loop.diverged_steps == 0
+    assert losses[-1] < losses[0] - 1.5, losses
+    sd = {k: v.detach().cpu().clone() for k, v in glow.state_dict().items()}
+    tails = torch.cat([v.flatten() for k, v in sd.items() if k.endswith("f.4.weight")])
+    assert tails.abs().max() > 0.01 and tails.std() > 1e-3, (tails.abs().max(), tails.std())     # (zero at initialisation)
+    glow.eval()
+    x = _structured_images(4, 64, seed=9)
+    noise = torch.rand(4, 3, 64, 64, generator=torch.Generator().manual_seed(3)) / 256
+    eps = [torch.randn(4, *s, generator=torch.Generator().manual_seed(5 + i)) * 0.7
+           for i, s in enumerate(glow.flow.split_shapes((3, 64, 64)))]
+    print("loss (bits/dim) every 20 steps:", [round(v, 3) for v in losses])
+    _compare_with_oracles(glow, sd, cfg, x, noise, eps, "config-B geometry after 160 training steps")
+
+
 @pytest.mark.parametrize("logs_std", [0.3, 0.5])
 def test_config_b_geometry_with_wide_logs_and_the_largest_finite_tails(logs_std):
     """Config-B channel geometry (64x64x3, L=3, hidden 512; K = 4 so that the fp64 oracle finishes in seconds) with the `logs`
