@@ -28,8 +28,14 @@ struct ChanMixArgs {
     const int32_t* gather; // (C) channel gather table, or null
     int reverse;           // 0: actnorm then mix; 1: mix then inverse actnorm
     int N, C, HW;
+    // Optional (forward, k_chanmix only): the input is the SQUEEZED view of an un-squeezed tensor that is never materialised --
+    // channel c of pixel (h, w) = sq_src[n][c / 4][2 h + (c / 2) % 2][2 w + c % 2] (Squeeze2d, network/module.py:573-592), with the
+    // dequantisation noise of network/model.py:421 (tensor or in-kernel Philox draw) and the 8-bit scaling of the data loader
+    // (dataset/celeba.py:74-86) applied on the way in.  sq_src: float (sq_u8 = 0) or uint8 (sq_u8 = 1) of shape (N, C/4, 2 Ho, sq_W).
+    const void* sq_src; int sq_u8; float sq_div; const float* sq_noise; RngSpec sq_rng; int sq_W;
 };
 int launch_chanmix(const ChanMixArgs& a, hipStream_t s);
+bool chanmix_squeeze_foldable(int C);      // the squeezed-view input (ChanMixArgs::sq_src) is served for this channel count
 
 int launch_add_const_logdet(const float* in, float* out, int N, const float* term_a, float mul_a, int count_a,
                             float sign, hipStream_t s);

@@ -14,13 +14,32 @@ __global__ void __launch_bounds__(256) k_optim_clip_sumsq(const glowhip_optim_ch
     __shared__ double red[4];
     const glowhip_optim_chunk c = chunks[blockIdx.x];
     double ss = 0.0;
-    for (int i = threadIdx.x; i < c.n; i += 256) {
-        float g = c.grad[i];
-        if (clip_value > 0.f) {                       // torch.nn.utils.clip_grad_value_: clamp_(-v, v) (NaN stays NaN)
-            g = g < -clip_value ? -clip_value : (g > clip_value ? clip_value : g);
-            c.grad[i] = g;
+    // 16-byte accesses where the chunk allows (chunks start on 256-byte slots of the flat gradient buckets); the sum of squares is
+    // accumulated per thread in the element order i, i + 1024, ... either way -- the same partial sums as the scalar loop's lanes
+    // would NOT come out, so the vector path keeps its own fixed order: deterministic run to run, like the scalar one
+    const bool vec = ((size_t)c.grad & 15) == 0 && (c.n & 3) == 0;
+    if (vec) {
+        float4* g4 = reinterpret_cast<float4*>(c.grad);
+        for (int i = threadIdx.x; i < (c.n >> 2); i += 256) {
+            float4 g = g4[i];
+            if (clip_value > 0.f) {                   // torch.nn.utils.clip_grad_value_: clamp_(-v, v) (NaN stays NaN)
+                g.x = g.x < -clip_value ? -clip_value : (g.x > clip_value ? clip_value : g.x);
+                g.y = g.y < -clip_value ? -clip_value : (g.y > clip_value ? clip_value : g.y);
+                g.z = g.z < -clip_value ? -clip_value : (g.z > clip_value ? clip_value : g.z);
+                g.w = g.w < -clip_value ? -clip_value : (g.w > clip_value ? clip_value : g.w);
+                g4[i] = g;
+            }
+            ss += (double)g.x * (double)g.x + (double)g.y * (double)g.y + (double)g.z * (double)g.z + (double)g.w * (double)g.w;
         }
-        ss += (double)g * (double)g;
+    } else {
+        for (int i = threadIdx.x; i < c.n; i += 256) {
+            float g = c.grad[i];
+            if (clip_value > 0.f) {
+                g = g < -clip_value ? -clip_value : (g > clip_value ? clip_value : g);
+                c.grad[i] = g;
+            }
+            ss += (double)g * (double)g;
+        }
     }
     const double tot = block_sum<256>(ss, red);
     if (threadIdx.x == 0) partial[blockIdx.x] = tot;
@@ -56,31 +75,38 @@ __global__ void __launch_bounds__(256) k_optim_update(const glowhip_optim_chunk*
     const glowhip_optim_chunk c = chunks[blockIdx.x];
     const float step_size = (float)((double)lr / bc1);
     const float bc2_sqrt = (float)sqrt(bc2);
-    for (int i = threadIdx.x; i < c.n; i += 256) {
-        float g = c.grad[i];
-        if (max_norm > 0.f) {                         // clip_grad_norm_ multiplies every gradient by the clamped coefficient
-            g = g * coef;
-            c.grad[i] = g;
-        }
-        float p = c.param[i];
-        if (weight_decay != 0.f) g = g + weight_decay * p;
-        float m = c.m[i];
-        m = m + (g - m) * omb1;                       // exp_avg.lerp_(grad, 1 - beta1); omb1 = float(1 - beta1 in double), as torch
-        c.m[i] = m;
+    auto elem = [&](float& g, float& p, float& m, float& v) {
+        if (max_norm > 0.f) g = g * coef;             // clip_grad_norm_ multiplies every gradient by the clamped coefficient
+        float ge = g;
+        if (weight_decay != 0.f) ge = ge + weight_decay * p;
+        m = m + (ge - m) * omb1;                      // exp_avg.lerp_(grad, 1 - beta1); omb1 = float(1 - beta1 in double), as torch
         if (kind == 0) {
-            float v = c.v[i];
-            v = v * beta2 + omb2 * g * g;             // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
-            c.v[i] = v;
+            v = v * beta2 + omb2 * ge * ge;           // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
             const float denom = sqrtf(v) / bc2_sqrt + eps;
             p = p - step_size * (m / denom);          // param.addcdiv_(exp_avg, denom, value=-step_size)
         } else {
-            float u = c.v[i];                         // exp_inf
-            const float a = u * beta2, b = fabsf(g) + eps;
-            u = a > b ? a : b;
-            c.v[i] = u;
-            p = p - step_size * (m / u);              // clr = lr / bias_correction1
+            const float a = v * beta2, b = fabsf(ge) + eps;       // exp_inf
+            v = a > b ? a : b;
+            p = p - step_size * (m / v);              // clr = lr / bias_correction1
         }
-        c.param[i] = p;
+    };
+    const bool vec = (c.n & 3) == 0 && (((size_t)c.grad | (size_t)c.param | (size_t)c.m | (size_t)c.v) & 15) == 0;
+    if (vec) {      // the same arithmetic per element, four elements per 16-byte access
+        float4* g4 = reinterpret_cast<float4*>(c.grad); float4* p4 = reinterpret_cast<float4*>(c.param);
+        float4* m4 = reinterpret_cast<float4*>(c.m); float4* v4 = reinterpret_cast<float4*>(c.v);
+        for (int i = threadIdx.x; i < (c.n >> 2); i += 256) {
+            float4 g = g4[i], p = p4[i], m = m4[i], v = v4[i];
+            elem(g.x, p.x, m.x, v.x); elem(g.y, p.y, m.y, v.y); elem(g.z, p.z, m.z, v.z); elem(g.w, p.w, m.w, v.w);
+            if (max_norm > 0.f) g4[i] = g;
+            p4[i] = p; m4[i] = m; v4[i] = v;
+        }
+    } else {
+        for (int i = threadIdx.x; i < c.n; i += 256) {
+            float g = c.grad[i], p = c.param[i], m = c.m[i], v = c.v[i];
+            elem(g, p, m, v);
+            if (max_norm > 0.f) c.grad[i] = g;
+            c.param[i] = p; c.m[i] = m; c.v[i] = v;
+        }
     }
 }
 

@@ -362,9 +362,18 @@ static int run_split(const LayerPlan& L, const void* packed, const float* z1, lo
 static float* other_buf(const Workspace& w, const float* cur) { return cur == w.bufA ? w.bufB : w.bufA; }
 
 // ---------------------------------------------------------------- encode (network/model.py:263-276)
+// A Squeeze2d layer whose output only the NEXT layer's k_chanmix reads (the first FlowStep of a level on the k_cnet path or the
+// kernel pairs) is not run at all: the mixer gathers the squeezed view itself, dequantisation noise and 8-bit scaling included
+// ("fuse uint8 -> fp32 scaling + noise + first squeeze into the first kernel").
+struct SqueezeFold { const void* src; int u8; float div; const float* noise; RngSpec rng; int W; };
+// (testing: the mixer-fusion switch glowhip_debug_force_tail_tile(0x8000) also brings the squeeze kernels back -- the two must
+// agree bit for bit)
+
 static int run_forward(glowhip_plan* p, const void* packed, const float* x, const float* noise, float* z_out, int N,
-                       const Workspace& w, hipStream_t s, int first_layer = 0, const RngSpec* rng = nullptr) {
+                       const Workspace& w, hipStream_t s, int first_layer = 0, const RngSpec* rng = nullptr,
+                       const uint8_t* x_u8 = nullptr, float u8_div = 1.f) {
     const float* cur = x;
+    SqueezeFold fold{};      // set by a skipped squeeze layer, consumed by the next layer's k_chanmix
     const int nl = (int)p->layers.size();
     bool premixed = false;   // `cur` already holds this step's ActNorm + permutation output (applied by the previous tail)
     bool pending = false;    // the previous FlowStep's k_cnet has run, its finishing step has not (cnet_chain)
@@ -378,7 +387,21 @@ static int run_forward(glowhip_plan* p, const void* packed, const float* x, cons
         const int HW = d.H * d.W;
         const long chw = (long)d.C * HW;
         if (d.kind == GLOWHIP_LAYER_SQUEEZE) {
-            GH_TRY(launch_squeeze(cur, noise, dst, N, d.C, d.H, d.W, 2, 0, s, li == 0 ? rng : nullptr));
+            const bool u8 = x_u8 != nullptr && li == 0;
+            bool foldable = false;
+            if (!g_sh_mix_disabled && li + 1 < nl - 1 && d.W % 2 == 0) {
+                const LayerPlan& Ln = p->layers[li + 1];
+                foldable = Ln.d.kind == GLOWHIP_LAYER_FLOWSTEP && !dnet_runs(p, Ln) && chanmix_squeeze_foldable(Ln.d.C) && !g_cnet_h2_only;
+            }
+            if (foldable) {
+                fold = SqueezeFold{u8 ? (const void*)x_u8 : (const void*)cur, u8 ? 1 : 0, u8_div, noise,
+                                   (li == 0 && rng) ? *rng : RngSpec{}, d.W};
+                count_launch(p, "squeeze(folded)");
+                noise = nullptr; rng = nullptr;
+                continue;      // `cur` stays the un-squeezed tensor; the next layer reads it through `fold`
+            }
+            if (u8) GH_TRY(launch_squeeze_u8(x_u8, noise, dst, N, d.C, d.H, d.W, 2, u8_div, s, rng));
+            else GH_TRY(launch_squeeze(cur, noise, dst, N, d.C, d.H, d.W, 2, 0, s, li == 0 ? rng : nullptr));
             noise = nullptr; rng = nullptr;
         } else {
             if (noise || (rng && li == 0)) {  // dequantisation noise with no leading squeeze (only possible at layer 0, cur == x):
@@ -417,6 +440,7 @@ static int run_forward(glowhip_plan* p, const void* packed, const float* x, cons
                         m.matrix = d.permutation == GLOWHIP_PERM_INVCONV ? d.invconv_w : nullptr;
                         m.gather = d.permutation == GLOWHIP_PERM_GATHER ? d.perm_idx : nullptr;
                         m.reverse = 0; m.N = N; m.C = d.C; m.HW = HW;
+                        if (fold.src) { m.sq_src = fold.src; m.sq_u8 = fold.u8; m.sq_div = fold.div; m.sq_noise = fold.noise; m.sq_rng = fold.rng; m.sq_W = fold.W; fold = SqueezeFold{}; }
                         ScopedTimer tm(p, GLOWHIP_K_CHANMIX, 0, s);
                         count_launch(p, "k_chanmix");
                         GH_TRY(launch_chanmix(m, s));
@@ -462,6 +486,7 @@ static int run_forward(glowhip_plan* p, const void* packed, const float* x, cons
                     m.matrix = d.permutation == GLOWHIP_PERM_INVCONV ? d.invconv_w : nullptr;
                     m.gather = d.permutation == GLOWHIP_PERM_GATHER ? d.perm_idx : nullptr;
                     m.reverse = 0; m.N = N; m.C = d.C; m.HW = HW;
+                    if (fold.src) { m.sq_src = fold.src; m.sq_u8 = fold.u8; m.sq_div = fold.div; m.sq_noise = fold.noise; m.sq_rng = fold.rng; m.sq_W = fold.W; fold = SqueezeFold{}; }
                     ScopedTimer tm(p, GLOWHIP_K_CHANMIX, 0, s);
                     count_launch(p, "k_chanmix");
                     GH_TRY(launch_chanmix(m, s));
@@ -1206,8 +1231,8 @@ int glowhip_glow_forward_u8(glowhip_plan* plan, const void* packed, const uint8_
     plan->cur_layer = 0;
     RngSpec rng{plan->rng_on && !noise, plan->rng_seed, plan->rng_calls, (float)(1.0 / pow(2.0, n_bits))};
     if (rng.on) ++plan->rng_calls;
-    GH_TRY(launch_squeeze_u8(x_u8, noise, w.bufA, N, d0.C, d0.H, d0.W, 2, divisor, s, rng.on ? &rng : nullptr));
-    GH_TRY(run_forward(plan, packed, w.bufA, nullptr, z, N, w, s, 1));
+    (void)d0;
+    GH_TRY(run_forward(plan, packed, w.bufA, noise, z, N, w, s, 0, rng.on ? &rng : nullptr, x_u8, divisor));
     const int* o = plan->out_shape;
     GH_TRY(launch_gaussian_logp(z, (long)o[0] * o[1] * o[2], prior_mean, prior_logs, prior_stride, N, o[0], o[1] * o[2],
                                 w.acc, s));

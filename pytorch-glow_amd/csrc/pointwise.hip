@@ -305,6 +305,21 @@ __global__ void __launch_bounds__(256) k_chanmix(ChanMixArgs a, int stage_matrix
     const float* pb = a.in_b + n * a.in_b_bs + p;
     float* po = a.out + n * a.out_bs + p;
     const bool an = a.bias != nullptr;
+    if (a.sq_src) {       // squeezed view of the un-squeezed input (+ dequantisation noise, 8-bit scaling): the squeeze pass is gone
+        const int Wo = a.sq_W >> 1, h = p / Wo, w = p - h * Wo, C0 = C >> 2;
+        const long img = (long)n * C0 * (4l * a.HW);
+        for (int c = og; c < C; c += OG) {
+            float xv = 0.f;
+            if (valid) {
+                const long src = img + ((long)(c >> 2) * (2 * (a.HW / Wo)) + 2 * h + ((c >> 1) & 1)) * a.sq_W + 2 * w + (c & 1);
+                xv = a.sq_u8 ? (float)reinterpret_cast<const uint8_t*>(a.sq_src)[src] / a.sq_div : reinterpret_cast<const float*>(a.sq_src)[src];
+                if (a.sq_noise) xv += a.sq_noise[src];
+                else if (a.sq_rng.on) xv += dequant_noise(a.sq_rng.seed, a.sq_rng.call, (unsigned long long)src, a.sq_rng.scale);
+            }
+            if (!a.reverse && an) xv = (xv + a.bias[c]) * a.scale[c];
+            v[c * PX + px] = xv;
+        }
+    } else
     for (int c = og; c < C; c += OG) {
         float xv = 0.f;
         if (valid) xv = (c < a.Ca) ? pa[(long)c * a.HW] : pb[(long)(c - a.Ca) * a.HW];
@@ -443,10 +458,13 @@ __global__ void __launch_bounds__(256) k_chanmix_wide(ChanMixArgs a) {
     }
 }
 
+bool chanmix_squeeze_foldable(int C) { return C % 4 == 0 && (size_t)C * C * sizeof(float) <= 48 * 1024; }
+
 int launch_chanmix(const ChanMixArgs& a, hipStream_t s) {
     GH_REQUIRE(a.C > 0 && a.C <= 512, "channel mixer: C=%d unsupported (1..512)", a.C);
     const long total = (long)a.N * a.HW;
     if (total == 0) return GLOWHIP_OK;
+    GH_REQUIRE(!a.sq_src || (chanmix_squeeze_foldable(a.C) && !a.reverse), "channel mixer: the squeezed-view input needs the LDS-matrix kernel, forward");
     if ((size_t)a.C * a.C * sizeof(float) > 48 * 1024) {
         // output slices over gridDim.y only when the output does not alias an input (other workgroups read the same pixels)
         const float* o_lo = a.out; const float* o_hi = a.out + (long)a.N * a.out_bs;
