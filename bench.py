@@ -142,7 +142,7 @@ def traffic_record(cnet_path, sh_path):
     if not os.path.exists(tpath):
         return None, None
     tj = json.load(open(tpath))
-    key = "k_cnet_hbm_bytes_per_launch" if cnet_path else ("k_f02_sh_hbm_bytes_per_launch" if sh_path else "k_gemm_glds_hbm_bytes_per_launch")
+    key = "k_cnet_hbm_bytes_per_launch" if cnet_path else "k_gemm_glds_hbm_bytes_per_launch"
     src = {"file": "profiles/pmc_traffic.json", "collected_at_commit": tj.get("commit"),
            "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (scripts/prof_pmc.sh), not re-measured by this run"}
     if cnet_path:
@@ -176,16 +176,13 @@ def instrumented_pass(plan, hps, B, run_once, passes=3, with_traffic=False, trai
     hid = hps.model.hidden_channels
     desc = plan.describe(B)
     cnet_path = "cnet-sh2" in desc
-    sh_path = "f2=mfma-sh" in desc or cnet_path
-    fused = {int(l.split()[0]) for l in desc.splitlines() if "-sh-fused" in l}   # layers whose f.0 + f.2 run as k_f02_sh at this N
+    sh_path = cnet_path
     bd = {}
     dom_ms, dom_flop, dom_bytes, dom_n = 0.0, 0.0, 0.0, 0
     per_level = {}
     for kind, layer, mfma, ms in recs:
         d = plan._descs[layer]
         key = f"{KERNEL_KINDS.get(kind, 'other')}_C{d.C}_{d.H}x{d.W}"
-        if kind == 2 and layer in fused:
-            key = f"conv_f0+f2_fused_C{d.C}_{d.H}x{d.W}"
         bd.setdefault(key, [0.0, 0])
         bd[key][0] += ms
         bd[key][1] += 1
@@ -201,11 +198,6 @@ def instrumented_pass(plan, hps, B, run_once, passes=3, with_traffic=False, trai
                 by = 4.0 * (d.C // 2) * total_px + 4.0 * cout * total_px
                 if kind != 5:        # taping / backward launches also store the two hidden tensors (fp32) and read / write sign words
                     by += 2 * 4.0 * hid * total_px + 2 * hid * total_px / 8
-        elif sh_path:
-            # dominant kernel = k_f02_sh: f.0 (3x3, C/2 -> hidden) + f.2 (1x1, hidden -> hidden) fused, h1 never in HBM
-            if key.startswith("conv_f0+f2_fused"):
-                dom, fl = True, (2.0 * hid * hid + 2.0 * 9 * (d.C // 2) * hid) * total_px   # algorithmic (fp32-equivalent)
-                by = 4.0 * (d.C // 2) * total_px + 4.0 * hid * total_px                      # read z1, write h2
         elif kind == 2 and mfma and uses_128:   # exact-fp32 path: k_gemm_glds (128x128 tiles)
             dom, fl, by = True, 2.0 * hid * hid * total_px, 2.0 * 4.0 * hid * total_px
         if dom:
@@ -217,8 +209,6 @@ def instrumented_pass(plan, hps, B, run_once, passes=3, with_traffic=False, trai
     peak = PEAK_SPLIT_TFLOPS if sh_path else PEAK_FP32_MFMA_TFLOPS
     name = (CNET_DESC + ("; here the taping forward (MODE 1: also stores h1 / h2 as fp32 + sign words) and the input-gradient chain "
                          "(MODE 2) launches of the training step" if train else "")) if cnet_path else \
-           ("k_f02_sh (f.0 3x3 conv C/2->512 + f.2 1x1 conv 512->512, both with ActNorm + ReLU, fused; fp32-accurate products as 3 f16 "
-            "MFMAs, peak = 2500/3 TFLOP/s algorithmic)") if sh_path else \
            "k_gemm_glds (f.2: 1x1 conv 512->512 + ActNorm + ReLU, fp32-input MFMA, 128x128 tiles)"
     roof = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
             "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
@@ -450,6 +440,8 @@ def main():
     ap.add_argument("--mode", choices=["forward", "inverse", "train"], default="forward",
                     help="forward = the headline metric (Glow.normal_flow); inverse = Glow.reverse_flow sampling throughput; "
                          "train = full training step (fwd with tape + HIP backward + RCCL gradient all-reduce + clip + Adam)")
+    ap.add_argument("--debug-flags", default="0", help="glowhip_debug_force_tail_tile value for kernel-variant A/B runs; the JSON line "
+                    "is then marked `debug_flags` and its metric `[debug run]` -- never part of a headline run")
     ap.add_argument("--dry-run-cpu", action="store_true", help="launcher / rendezvous / timing-protocol check without a GPU: the "
                     "ranks join a gloo group and time empty steps (tests/test_host.py); prints a line marked dry_run")
     args = ap.parse_args()
@@ -485,7 +477,8 @@ def main():
     from pytorch_glow_amd.misc import util
     from pytorch_glow_amd import parallel
 
-    dbg = int(os.environ.get("GLOWHIP_DEBUG_FLAGS", "0"), 0)   # kernel-variant A/B runs (scripts/ab_flags.sh); 0 = product default
+    # kernel-variant A/B runs only (scripts/ab_flags.sh): an explicit option, and the line says so -- a headline run takes no debug flags
+    dbg = int(args.debug_flags, 0)
     if dbg:
         G.lib().glowhip_debug_force_tail_tile(dbg)
     cfg = CONFIGS[args.config]
@@ -530,6 +523,8 @@ def main():
             metric = HEADLINE_METRIC
         else:
             metric = f"images/sec Glow {what}, {cfg['image']}x{cfg['image']}x3 L={cfg['L']} K={cfg['K']} [secondary metric]"
+        if dbg:
+            metric += f" [debug run, flags {dbg:#x}]"
         out = {
             "metric": metric,
             "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -312,11 +312,10 @@ int glowhip_plan_timing_read(glowhip_plan* plan, glowhip_timing_record* out, int
 /* Testing hook for the fused tail convolution, so every variant can be exercised at any batch size: low byte =
  * pixels per workgroup (16/32/64/128; 0 = automatic, chosen by a cost model), | 0x100 = always split the
  * out-channel tiles over blockIdx.y, | 0x200 = never split, | 0x400 = no LDS-DMA tail kernels.
- * Kernel-family switches (A/B runs, and the parity tests of the exact-fp32 kernels): | 0x800 = exact-fp32 MFMA kernels only
- * (split-half f16 path off), | 0x1000 = fp32 tail behind the split-half GEMM, | 0x2000 = fp32-MFMA f.0 writing the
- * split-half tensor, | 0x4000 = f.0 and f.2 as separate kernels, | 0x8000 = k_chanmix instead of the mixer fused into the
- * previous tail; bits 16..19 = 4 or 8: only that wave count of the split-half tail; | 0x100000 = the one-kernel coupling
- * network (cnet) off; | 0x200000 = cnet computes f.0 + f.2 only; bits 22..24 = 1, 2 or 4: that many row splits of cnet;
+ * Kernel-family switches (the parity tests of the exact-fp32 kernels, A/B runs): | 0x800 = exact-fp32 MFMA kernels only
+ * (split-half f16 path off, training included), | 0x8000 = no fusion around the channel mixer: k_squeeze + k_chanmix + a plain
+ * finishing kernel as separate launches (bitwise equal to the fused forms); bits 22..24 = 1, 2 or 4: that many row splits of
+ * k_cnet;
  * | 0x2000000 = cnet with 128-pixel tiles only, | 0x4000000 = 64-pixel tiles wherever supported,
  * | 0x8000000 = the finishing step of a FlowStep runs inside the next FlowStep's k_cnet (off by default: measured slower),
  * | 0x10000000 = the finishing kernel takes its pixel chunks in block order instead of the XCD-affine order (A/B),

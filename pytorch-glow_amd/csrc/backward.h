@@ -30,7 +30,7 @@ struct SplitBwdArgs {
 int launch_split_bwd(const SplitBwdArgs& a, hipStream_t s);
 
 int launch_act_bwd(float* g, const float* h, const float* e, int N, int Cm, int HW, double* acc_b, double* acc_l,
-                   hipStream_t s, _Float16* g_sh = nullptr, float sh_scale = 1.0f);   // g_sh holds g * sh_scale (a power of two)   // g_sh: also write the result as a split-half tensor
+                   hipStream_t s);
 
 struct ChanMixBwdArgs {
     const float* x; long x_bs;       // step input

@@ -309,109 +309,9 @@ __global__ void __launch_bounds__(256) k_act_bwd1(float* __restrict__ g, const f
     }
 }
 
-// The same, and the masked gradient ALSO as a split-half tensor (sh.h) for the f16-pipe input-gradient GEMM that follows.
-// Workgroup = 64 pixels (one SH tile) x 32 channels; a wave owns one 8-channel group of its 64 pixels, i.e. a lane holds exactly
-// the 8 values of one 16-byte group per plane and stores them itself (64 lanes = 1 KiB contiguous) -- no LDS, no barrier; the
-// per-channel sums are wave reductions in fp32 (64 terms) feeding one fp64 atomic pair per wave and channel.
-// (The first version used 8-channel workgroups with an LDS transpose and fp64 wave reductions: 2.8 TB/s.)
-__global__ void __launch_bounds__(256) k_act_bwd_sh(float* __restrict__ g, const float* __restrict__ h,
-                                                    const float* __restrict__ e, int Cm, int HW, double* __restrict__ acc_b,
-                                                    double* __restrict__ acc_l, _Float16* __restrict__ gsh, float sh_scale) {
-    const int px = threadIdx.x & 63, cq = threadIdx.x >> 6;
-    const int chunk = blockIdx.y * 4 + cq;                 // 8-channel group of this wave
-    const long n = blockIdx.z;
-    const int p = blockIdx.x * 64 + px;
-    if (chunk * 8 >= Cm) return;                           // (wave-uniform)
-    float hv[8], gh[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {                          // all sixteen loads in flight together
-        const long idx = (n * Cm + chunk * 8 + k) * HW + p;
-        hv[k] = h[idx]; gh[k] = g[idx];
-    }
-    h8 hi, lo;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const int c = chunk * 8 + k;
-        const float gu = hv[k] > 0.f ? gh[k] * e[c] : 0.f;
-        g[(n * Cm + c) * HW + p] = gu;
-        // The split-half copy carries gu * 2^k (exact): with loss = mean(nll), dL/d(objective) = 1 / (B ln2 CHW) ~ 1e-6 and the
-        // gradients behind the near-zero Conv2dZeros weights are ~1e-8 .. 1e-10 -- below fp16's normal range (6.1e-5), where
-        // the pair is only absolutely accurate (2.9e-11).  2^k = B ln2 CHW rounded to a power of two brings them back to
-        // O(1)-relative magnitudes; the GEMM that consumes the tensor multiplies its result by 2^-k.
-        _Float16 a, b;
-        sh_split(gu * sh_scale, a, b);
-        hi[k] = a; lo[k] = b;
-        const float tb = wave_sum(gu), tl = wave_sum(gh[k] * hv[k]);
-        if (px == 0) {
-            atomic_add_f64(acc_b + c, (double)tb);
-            atomic_add_f64(acc_l + c, 3.0 * (double)tl);
-        }
-    }
-    const long gp = n * HW + p;
-    *reinterpret_cast<h8*>(gsh + sh_off(Cm >> 3, 0, chunk, gp)) = hi;
-    *reinterpret_cast<h8*>(gsh + sh_off(Cm >> 3, 1, chunk, gp)) = lo;
-}
-
-// The same for HW % 256 == 0: one WAVE = 256 consecutive pixels x one 8-channel group, four pixels per lane as 16-byte accesses
-// (a wave instruction moves 1 KiB contiguous per channel; the 64-pixel kernel above moves 256 B pieces 4 KiB apart and sat at
-// 2.7 TB/s next to k_act_bwd's 4.5).  A lane's four pixels are four consecutive 16-byte groups of the SH tile.
-__global__ void __launch_bounds__(64) k_act_bwd_sh4(float* __restrict__ g, const float* __restrict__ h,
-                                                    const float* __restrict__ e, int Cm, int HW, double* __restrict__ acc_b,
-                                                    double* __restrict__ acc_l, _Float16* __restrict__ gsh, float sh_scale) {
-    const int lane = threadIdx.x;
-    const int chunk = blockIdx.y;
-    const long n = blockIdx.z;
-    const int p = blockIdx.x * 256 + lane * 4;
-    float4 hv[8], gh[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {                          // sixteen 16-byte loads in flight
-        const long idx = (n * Cm + chunk * 8 + k) * HW + p;
-        hv[k] = *reinterpret_cast<const float4*>(h + idx);
-        gh[k] = *reinterpret_cast<const float4*>(g + idx);
-    }
-    h8 hi[4], lo[4];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const int c = chunk * 8 + k;
-        const float ec = e[c];
-        const float hvv[4] = {hv[k].x, hv[k].y, hv[k].z, hv[k].w}, ghv[4] = {gh[k].x, gh[k].y, gh[k].z, gh[k].w};
-        float gu[4], sb = 0.f, sl = 0.f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            gu[j] = hvv[j] > 0.f ? ghv[j] * ec : 0.f;
-            sb += gu[j];
-            sl += ghv[j] * hvv[j];
-            _Float16 a, b;
-            sh_split(gu[j] * sh_scale, a, b);              // (pre-scale: see k_act_bwd_sh)
-            hi[j][k] = a; lo[j][k] = b;
-        }
-        *reinterpret_cast<float4*>(g + (n * Cm + c) * HW + p) = make_float4(gu[0], gu[1], gu[2], gu[3]);
-        const float tb = wave_sum(sb), tl = wave_sum(sl);
-        if (lane == 0) {
-            atomic_add_f64(acc_b + c, (double)tb);
-            atomic_add_f64(acc_l + c, 3.0 * (double)tl);
-        }
-    }
-    const long gp = n * HW + p;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        *reinterpret_cast<h8*>(gsh + sh_off(Cm >> 3, 0, chunk, gp + j)) = hi[j];
-        *reinterpret_cast<h8*>(gsh + sh_off(Cm >> 3, 1, chunk, gp + j)) = lo[j];
-    }
-}
-
 int launch_act_bwd(float* g, const float* h, const float* e, int N, int Cm, int HW, double* acc_b, double* acc_l,
-                   hipStream_t s, _Float16* g_sh, float sh_scale) {
+                   hipStream_t s) {
     if (N == 0) return GLOWHIP_OK;
-    if (g_sh) {
-        GH_REQUIRE(HW % 64 == 0 && Cm % 8 == 0, "act_bwd: split-half copy needs HW %% 64 == 0 and channels %% 8 == 0");
-        if (HW % 256 == 0)
-            hipLaunchKernelGGL(k_act_bwd_sh4, dim3(HW / 256, Cm / 8, N), dim3(64), 0, s, g, h, e, Cm, HW, acc_b, acc_l, g_sh, sh_scale);
-        else
-            hipLaunchKernelGGL(k_act_bwd_sh, dim3(HW / 64, (Cm / 8 + 3) / 4, N), dim3(256), 0, s, g, h, e, Cm, HW, acc_b, acc_l, g_sh, sh_scale);
-        GH_LAUNCH_CHECK("k_act_bwd_sh");
-        return GLOWHIP_OK;
-    }
     const bool pow2 = HW >= 4 && (HW & (HW - 1)) == 0;
     if (pow2) {
         const long per_img = (long)Cm * HW;

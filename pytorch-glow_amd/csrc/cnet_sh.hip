@@ -11,7 +11,7 @@
 //        64 rows x 128 pixels (8 MFMA tiles, ONE fp32 accumulator each).  P1/P2 alternate over the two channel halves.
 //        128 pixels per workgroup instead of 64 halve the weight bytes fetched per MFMA, which is what bounded k_f02_sh
 //        (vector-memory return path, ~30 B/clk/CU); the single accumulator of SH2 is what makes the 128 x 512 tile fit.
-//   P3   f.4 with the filter taps moved to the OUTPUT side (tail_sh.hip): T[tap*Cout + co][px] = sum_k W4[co][k][tap] h2[k][px],
+//   P3   f.4 with the filter taps moved to the OUTPUT side: T[tap*Cout + co][px] = sum_k W4[co][k][tap] h2[k][px],
 //        h2 passed to the B side through the same LDS buffer (256 channels at a time), T accumulated in registers
 //   P4   T -> LDS, shifted 9-tap sums.  Rows of the tile's own pixels go to `hpart`; what the tile's first / last image row
 //        contributes to the rows just outside the tile goes to `hup` / `hdn` (no halo recompute, no atomics: deterministic).
@@ -744,7 +744,7 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
             dst[RTU + i] = *reinterpret_cast<const h8*>(ap + (long)st * (2 * g.Mpad4 * 8) + rt4 * 256 + w4_plane);
         }
     };
-    if (!a.y_sh && wid < nunits) {
+    if (wid < nunits) {
         const _Float16* ap = a4_base(wid, 0);
         loadA4(ap, wid % g.NU4, 0, A4[0]);
         loadA4(ap, wid % g.NU4, nsl > 1 ? 1 : 0, A4[1]);
@@ -808,31 +808,6 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
             }
     }
     GH_STAMP(10);
-
-    if (a.y_sh) {   // testing: h2 as an (old-format) SH tensor, f.4 left to k_tail_sh
-#pragma unroll
-        for (int i = 0; i < RT2; ++i)
-#pragma unroll
-            for (int j = 0; j < PT2; ++j) {
-                const long px = gp0 + (pt2 + j) * 32 + ml;
-                if (px >= (long)a.N * HW) continue;
-#pragma unroll
-                for (int gq = 0; gq < 4; ++gq) {
-                    const int o = ms_row0 + (rt2 + i) * 32 + 8 * gq + 4 * kl;
-                    h4 hi, lo;
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        _Float16 x0, x1;
-                        sh_split(-acc2[i][j][4 * gq + t] * SH2_ACT_INV, x0, x1);
-                        hi[t] = x0; lo[t] = x1;
-                    }
-                    _Float16* dst = a.y_sh + sh_off(HID / 8, 0, o >> 3, px) + (o & 7);
-                    *reinterpret_cast<h4*>(dst) = hi;
-                    *reinterpret_cast<h4*>(dst + (long)(HID / 8) * SH_CHUNK_STEP) = lo;
-                }
-            }
-        return;
-    }
 
     // ---- P3: T[m][px] = sum_k W4t[m][k] h2[k][px] over this workgroup's h2 rows (= k range [ms_row0, ms_row0 + MR))
     f32x16_t accT[UPW][4];     // tile 4-index = (row tile within the unit) * NPT + pixel tile
@@ -1353,7 +1328,6 @@ static bool cnet_select(const CnetArgs& a, CnetGeo* gout, int* ms_out, int* upw_
     bool use64 = !ok128 || (ok64 && g128.tiles < 224);
     if (g_cnet_flags & 1) use64 = !ok128;      // testing: 128-pixel tiles wherever they exist
     if (g_cnet_flags & 2) use64 = ok64;        // testing: 64-pixel tiles wherever they exist
-    if (a.y_sh && ok128) use64 = false;
     // taping / backward launches: the 128-pixel instance is at the register limit and spills once the stores and the sign words
     // are in (184 B); 64-pixel tiles measured 2 % faster on the training step
     if (a.tape_h1 && ok64 && !(g_cnet_flags & 1)) use64 = true;
@@ -1362,11 +1336,10 @@ static bool cnet_select(const CnetArgs& a, CnetGeo* gout, int* ms_out, int* upw_
     const int ms_max = std::min(CN_MAXMS, a.hidden / (use64 ? 128 : 64));
     while (ms < ms_max && g.tiles * ms < 160) ms *= 2;
     if (g_cnet_ms) ms = std::min(g_cnet_ms, ms_max);
-    if (a.y_sh) ms = 1;
     // T units per wave: (unit rows of T) x (k parts) over 8 waves.  Two units per wave next to the 128 accumulator registers of
     // a 512-row x 128-pixel h2 block would spill: that combination runs with the rows split in two
     const int upw = g.NU4 * g.KS > 8 ? 2 : 1;
-    if (upw == 2 && a.hidden == 512 && ms == 1 && !use64 && !a.y_sh) ms = 2;
+    if (upw == 2 && a.hidden == 512 && ms == 1 && !use64) ms = 2;
     while ((a.hidden / ms / 16) / g.KS < 1 && ms > 1) ms /= 2;
     *gout = g; *ms_out = ms; *upw_out = upw;
     return true;
@@ -1403,7 +1376,7 @@ int launch_cnet_main(const CnetArgs& a, hipStream_t s, CnetPending* out) {
     GH_REQUIRE(cnet_select(a, &g, &ms, &upw), "cnet: unsupported shape");
     GH_REQUIRE(!a.pre_on || a.pre.MS == ms, "cnet: a chained launch needs the previous step's row split");
     const bool tape = a.tape_h1 != nullptr;
-    GH_REQUIRE(!tape || (a.tape_h2 && a.mask1 && a.mask2 && !a.pre_on && !a.y_sh && g.HW % 32 == 0 &&
+    GH_REQUIRE(!tape || (a.tape_h2 && a.mask1 && a.mask2 && !a.pre_on && g.HW % 32 == 0 &&
                          cnet_tape_instance(a.hidden, ms, upw, g.pxt, g.ng)),
                "cnet: no taping / backward instance for this launch");
     int rc = GLOWHIP_EINVAL;
@@ -1468,7 +1441,7 @@ int launch_cnet_finish(const CnetArgs& a, const CnetPending& p, hipStream_t s) {
 int launch_cnet(const CnetArgs& a, hipStream_t s) {
     CnetPending p{};
     GH_TRY(launch_cnet_main(a, s, &p));
-    if (a.y_sh || a.N == 0) return GLOWHIP_OK;
+    if (a.N == 0) return GLOWHIP_OK;
     return launch_cnet_finish(a, p, s);
 }
 

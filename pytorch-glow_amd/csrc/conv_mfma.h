@@ -22,9 +22,8 @@ void conv_mfma_wide_disable_glds(int off);  // testing hook: 1 = use the registe
 bool conv_mfma_first_supported(int Cin, int H, int W, int Cout);
 size_t conv_mfma_first_packed_bytes(int Cin, int Cout);
 // wf: packed image (weights * exp(3 logs), then bias * exp(3 logs)) produced by the REPACK_FIRST job
-// y_sh non-NULL: write the result as a split-half tensor (sh.h) of N*H*W pixels; y non-NULL: as fp32 NCHW (either or both)
 int launch_conv_mfma_first(const float* x, long x_bs, const float* wf, const float* bias_scaled, float* y, int N,
-                           int Cin, int H, int W, int Cout, hipStream_t s, int relu = 1, _Float16* y_sh = nullptr);
+                           int Cin, int H, int W, int Cout, hipStream_t s, int relu = 1);
 
 // "Tail" convolution: 3x3, few output channels (f.4 / Split2d prior), with the coupling / prior
 // arithmetic and the per-sample log-det reduction fused into the epilogue.

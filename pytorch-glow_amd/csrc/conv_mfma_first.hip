@@ -49,8 +49,7 @@ size_t conv_mfma_first_packed_bytes(int Cin, int Cout) { return ((size_t)9 * Cin
 template <int BN, int WF>
 __global__ void __launch_bounds__(256, 2)     // (at 193 + 64 = 257 registers the BN = 128 instances ran one wave per SIMD)
 k_conv_first(const float* __restrict__ X, long x_bs, const float* __restrict__ Wf, const float* __restrict__ bs,
-             float* __restrict__ Y, int N, int Cin, int H, int W, int M, FirstGeom gr, int relu,
-             _Float16* __restrict__ Ysh) {
+             float* __restrict__ Y, int N, int Cin, int H, int W, int M, FirstGeom gr, int relu) {
     constexpr int BM = FIRST_BM, BK = FIRST_BK;
     constexpr int RS = WF + 8, TR = BN / WF, W4 = WF / 4, CHS = first_chs(BN / WF, WF);
     struct { int RS, CHS, TR, W4, MB; } g = {RS, CHS, TR, W4, gr.MB};
@@ -167,32 +166,7 @@ k_conv_first(const float* __restrict__ X, long x_bs, const float* __restrict__ W
         if (st + 1 < steps) store_A(buf ^ 1);
         if (ch == nch - 1) {
             // epilogue of this output-channel tile: ActNorm + ReLU, C[row = o][col = pixel]
-            if (Ysh) {
-                // split-half output (sh.h): a lane's 4 consecutive channels of its pixel = 8 bytes of the hi plane and of the lo plane
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const long px = n * HW + p0 + wc * WN + j * 32 + ml;
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-                        for (int gq = 0; gq < 4; ++gq) {
-                            const int o0 = mt * BM + wr * WM + i * 32 + 8 * gq + 4 * kl;
-                            h4 hi, lo;
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                const float v = relu ? relu_(acc[i][j][4 * gq + q]) : acc[i][j][4 * gq + q];
-                                _Float16 a, b;
-                                sh_split(v, a, b);
-                                hi[q] = a; lo[q] = b;
-                            }
-                            _Float16* dst = Ysh + sh_off(M >> 3, 0, o0 >> 3, px) + (o0 & 7);
-                            *reinterpret_cast<h4*>(dst) = hi;
-                            *reinterpret_cast<h4*>(dst + (long)(M >> 3) * SH_CHUNK_STEP) = lo;
-                        }
-                    }
-                }
-            }
-            if (Y) {   // fp32 NCHW output (both may be requested: the training forward keeps fp32 on the tape)
+            {
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int p = p0 + wc * WN + j * 32 + ml;
@@ -213,7 +187,7 @@ k_conv_first(const float* __restrict__ X, long x_bs, const float* __restrict__ W
 }
 
 int launch_conv_mfma_first(const float* x, long x_bs, const float* wf_, const float* bias_scaled, float* y, int N,
-                           int Cin, int H, int W, int Cout, hipStream_t s, int relu, _Float16* y_sh) {
+                           int Cin, int H, int W, int Cout, hipStream_t s, int relu) {
     GH_REQUIRE(conv_mfma_first_supported(Cin, H, W, Cout), "conv_mfma_first: unsupported shape");
     if (N == 0) return GLOWHIP_OK;
     const int HW = H * W;
@@ -236,7 +210,7 @@ int launch_conv_mfma_first(const float* x, long x_bs, const float* wf_, const fl
         (void)hipFuncSetAttribute((const void*)k_conv_first<bn, wf>, hipFuncAttributeMaxDynamicSharedMemorySize,    \
                                   (int)lds);                                                                         \
         hipLaunchKernelGGL((k_conv_first<bn, wf>), dim3(grid), dim3(256), lds, s, x, x_bs, wf_, bias_scaled, y, N,   \
-                           Cin, H, W, Cout, g, relu, y_sh);                                                          \
+                           Cin, H, W, Cout, g, relu);                                                                \
         GH_LAUNCH_CHECK("k_conv_first");                                                                             \
         return GLOWHIP_OK;                                                                                           \
     }

@@ -346,12 +346,10 @@ void conv_mfma_tail_force_tile(int v) {
     g_force_tp = v & 0xff;
     g_force_msplit = (v & 0x100) ? 1 : ((v & 0x200) ? 0 : -1);
     g_disable_tail_dma = (v & 0x400) != 0;   // | 0x400: register-staged kernels only
-    // split-half path switches (include/glowhip.h): 0x800 whole path off, 0x1000 tail, 0x2000 f.0, 0x4000 f.0+f.2 fusion,
-    // 0x8000 next-step mixer inside the tail; bits 16..19: 4 / 8 = only those wave counts of k_tail_sh
-    plan_disable_sh(((v & 0x800) ? 1 : 0) | ((v & 0x1000) ? 2 : 0) | ((v & 0x2000) ? 4 : 0) | ((v & 0x4000) ? 8 : 0) |
-                    ((v & 0x8000) ? 16 : 0) | ((v & 0x100000) ? 32 : 0) | ((v & 0x200000) ? 64 : 0));
+    // 0x800: the split-half path off (every coupling network on the exact-fp32 kernels, training included); 0x8000: no mixer of the
+    // next step inside the finishing kernel and no squeeze folded into a mixer (the fused and the separate forms must agree bit for bit)
+    plan_disable_sh(((v & 0x800) ? 1 : 0) | ((v & 0x8000) ? 16 : 0));
     cnet_force((v >> 22) & 7, (v >> 25) & 15);   // bits 22..24: row splits; bit 25: 128-pixel tiles only, bit 26: 64-pixel tiles, bit 27: finishing chained into the next k_cnet, bit 28: finishing kernel without the XCD-affine chunk order
-    tail_sh_force_waves((v >> 16) & 0xf);
     plan_train_disable_sh((v & 0x800) ? 1 : 0);
     plan_pack_one_stream((v & 0x20000000) ? 1 : 0);      // bit 29: glowhip_plan_pack entirely on the caller's stream (A/B)
     plan_train_disable_cnet((v & 0x40000000) ? 1 : 0);   // bit 30: training forward on the per-layer kernels (no taping k_cnet)

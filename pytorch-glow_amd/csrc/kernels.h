@@ -88,8 +88,8 @@ int launch_step_prepare_batched(const StepPrepJob* jobs_dev, int n, int max_lds_
                                 int max_c = 0);   // want_inverse = 0: log|det W| only (W^-1 is left stale)
 
 struct ScaleJob { const float* logs; size_t scale_off, inv_off; int n; int has_inv; };
-enum { REPACK_WIDE = 0, REPACK_TAIL = 1, REPACK_FIRST = 2, REPACK_SH_GEMM = 3, REPACK_SH_TAIL = 4, REPACK_SH_FIRST = 5,
-       REPACK_SH2_GEMM = 6, REPACK_SH2_FIRST = 7, REPACK_SH2_TAIL = 8 };   // true-scale split-half images with per-row scales (sh.h SH2)
+enum { REPACK_WIDE = 0, REPACK_TAIL = 1, REPACK_FIRST = 2,                 // exact-fp32 MFMA kernels' images
+       REPACK_SH2_GEMM = 3, REPACK_SH2_FIRST = 4, REPACK_SH2_TAIL = 5 };   // true-scale split-half images with per-row scales (sh.h SH2)
 struct RepackJob {
     const float* w; size_t out_off; int kind;
     int Cin, Cout, K, Kpad;      // wide: K = Cin*k*k

@@ -46,65 +46,6 @@ __global__ void __launch_bounds__(256) k_repack_batched(const RepackJob* __restr
         }
         for (long o = (long)blockIdx.x * 256 + threadIdx.x; o < j.Cout; o += (long)gridDim.x * 256)
             out[total + o] = j.fold_logs ? j.fold_bias[o] * expf(j.fold_logs[o] * LOGSCALE) : 0.f;
-    } else if (j.kind == REPACK_SH_GEMM) {
-        // split-half GEMM image (sh.h): half [plane][K/8][M][8] of w[o][k] * exp(3 logs[o]), then M floats bias * exp(3 logs)
-        const long total = (long)j.K * j.Cout;
-        _Float16* oh = (_Float16*)out;
-        for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-            const int k8 = (int)(e & 7);
-            const int o = (int)((e >> 3) % j.Cout);
-            const int k = (int)((e >> 3) / j.Cout) * 8 + k8;
-            const float wv = (j.transposed ? j.w[(long)k * j.Cout + o] : j.w[(long)o * j.K + k]) *
-                             (j.fold_logs ? expf(j.fold_logs[o] * LOGSCALE) : 1.f);
-            _Float16 hi, lo;
-            sh_split(wv, hi, lo);
-            oh[e] = hi;
-            oh[total + e] = lo;
-        }
-        float* fb = (float*)((char*)out + align_up_dev((size_t)2 * total * sizeof(_Float16), 16));
-        for (long o = (long)blockIdx.x * 256 + threadIdx.x; o < j.Cout; o += (long)gridDim.x * 256)
-            fb[o] = j.fold_logs ? j.fold_bias[o] * expf(j.fold_logs[o] * LOGSCALE) : 0.f;
-    } else if (j.kind == REPACK_SH_FIRST) {
-        // split-half f.0 image (first_sh.hip): half [plane][G][Cout][8]; group g = tap*nchunk + chunk, channel ci = chunk*8 + k8;
-        // zero for padded groups / channels; ActNorm scale folded; then Cout floats bias * exp(3 logs).  j.K = G
-        const int nchunk = (j.Cin + 7) / 8, G = j.K;
-        const long total = (long)G * j.Cout * 8;
-        _Float16* oh = (_Float16*)out;
-        for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-            const int k8 = (int)(e & 7);
-            const int o = (int)((e >> 3) % j.Cout);
-            const int g = (int)((e >> 3) / j.Cout);
-            const int tap = g / nchunk, ci = (g - tap * nchunk) * 8 + k8;
-            float wv = 0.f;
-            if (g < 9 * nchunk && ci < j.Cin)
-                wv = j.w[((long)o * j.Cin + ci) * 9 + tap] * (j.fold_logs ? expf(j.fold_logs[o] * LOGSCALE) : 1.f);
-            _Float16 hi, lo;
-            sh_split(wv, hi, lo);
-            oh[e] = hi;
-            oh[total + e] = lo;
-        }
-        float* fb = (float*)((char*)out + align_up_dev((size_t)2 * total * sizeof(_Float16), 16));
-        for (long o = (long)blockIdx.x * 256 + threadIdx.x; o < j.Cout; o += (long)gridDim.x * 256)
-            fb[o] = j.fold_logs ? j.fold_bias[o] * expf(j.fold_logs[o] * LOGSCALE) : 0.f;
-    } else if (j.kind == REPACK_SH_TAIL) {
-        // split-half tail image (tail_sh.hip): half [group][plane][Cin/8][Mpad][8], row m = tap*Cg + co_in_group, zero rows
-        // m >= 9*Cg; j.MT = channel groups, j.Kpad = Mpad
-        const int Mpad = j.Kpad, groups = j.MT, Cg = j.Cout / groups;
-        const long per_plane = (long)j.Cin * Mpad, total = per_plane * groups;
-        _Float16* oh = (_Float16*)out;
-        for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-            const int g = (int)(e / per_plane);
-            const long el = e - (long)g * per_plane;
-            const int k8 = (int)(el & 7);
-            const int m = (int)((el >> 3) % Mpad);
-            const int k = (int)((el >> 3) / Mpad) * 8 + k8;
-            const int tap = m / Cg, co = g * Cg + (m - tap * Cg);
-            const float wv = m < 9 * Cg ? j.w[((long)co * j.Cin + k) * 9 + tap] : 0.f;
-            _Float16 hi, lo;
-            sh_split(wv, hi, lo);
-            oh[(long)g * 2 * per_plane + el] = hi;
-            oh[(long)g * 2 * per_plane + per_plane + el] = lo;
-        }
     } else {
         for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < j.total; e += (long)gridDim.x * 256) {
             const int i = (int)(e & 15), kq = (int)((e >> 4) & 3);

@@ -67,30 +67,18 @@ static int carve(const glowhip_plan* p, int N, void* ws, size_t bytes, Workspace
 // coupling to z2.  x1: first-half channels (batch stride x1_bs).
 static bool g_pack_one_stream = false;     // testing hook: glowhip_plan_pack without the side-stream fork
 void plan_pack_one_stream(int on) { g_pack_one_stream = on != 0; }
-static bool g_sh_disabled = false, g_sh_tail_disabled = false, g_sh_first_disabled = false, g_sh_f02_disabled = false,
-            g_sh_mix_disabled = false, g_cnet_disabled = false, g_cnet_h2_only = false;
+static bool g_sh_disabled = false, g_sh_mix_disabled = false;
 void plan_disable_sh(int off) {
-    g_sh_disabled = (off & 1) != 0; g_sh_tail_disabled = (off & 2) != 0; g_sh_first_disabled = (off & 4) != 0;
-    g_sh_f02_disabled = (off & 8) != 0;
-    g_sh_mix_disabled = (off & 16) != 0;
-    g_cnet_disabled = (off & 32) != 0;     // the one-kernel coupling network (cnet_sh.hip) off: the round-1 kernel pairs run
-    g_cnet_h2_only = (off & 64) != 0;      // cnet computes f.0 + f.2 only and hands h2 to k_tail_sh (testing)
+    g_sh_disabled = (off & 1) != 0;        // the whole split-half path off: every coupling network on the exact-fp32 MFMA kernels
+    g_sh_mix_disabled = (off & 16) != 0;   // no mixer of the next step inside the finishing kernel, no squeeze folded into a mixer
 }
-
-// Mixer of the NEXT step for tail_sh.hip to apply (forward only); C = 0: none
-struct NextMix { int C; float* out; long out_bs; const float* bias; const float* scale; const float* matrix; const int32_t* gather; };
-
-// fused f.0 + f.2 only when its one-workgroup-per-64-pixels grid still covers most of the chip (measured: with 64
-// workgroups at the 8x8 level of a 64-image batch the two separate kernels are faster).  N = 0: batch unknown (plan time)
-static bool f02_runs_at(int N, int HW) { return N <= 0 || (long)N * HW / 64 >= 192; }
 
 // split-half f16 kernels off for this plan: its own family (glowhip_plan_set_family) or the process-wide testing hook
 static bool sh_off(const glowhip_plan* p) { return g_sh_disabled || (p && p->family == GLOWHIP_FAMILY_EXACT_FP32); }
-static bool tail_runs_sh(const glowhip_plan* p, const LayerPlan& L) { return L.sh_mid && L.sh_tail && !sh_off(p) && !g_sh_tail_disabled; }
-static bool cnet_runs(const glowhip_plan* p, const LayerPlan& L) { return L.cnet && !sh_off(p) && !g_cnet_disabled; }
+static bool cnet_runs(const glowhip_plan* p, const LayerPlan& L) { return L.cnet && !sh_off(p); }
 
 // deep levels (dnet_sh.hip): layers k_cnet does not take, with an invertible 1x1 convolution, on the product family
-static bool dnet_runs(const glowhip_plan* p, const LayerPlan& L) { return L.dnet && !sh_off(p) && !g_cnet_disabled && !g_sh_tail_disabled && !g_sh_first_disabled; }
+static bool dnet_runs(const glowhip_plan* p, const LayerPlan& L) { return L.dnet && !sh_off(p); }
 // the run of consecutive FlowSteps of li's shape that take the deep-level kernels, walking in direction `dir` (+1 encode, -1 decode)
 static int dnet_run_end(const glowhip_plan* p, int li, int dir) {
     const int nl = (int)p->layers.size();
@@ -216,92 +204,51 @@ static CnetMixer mixer_rev(const LayerPlan& L, const void* packed) {      // per
 // glowhip_debug_force_tail_tile(0x8000000) with its bitwise-equality test.)
 static bool cnet_chain(const glowhip_plan* p, const LayerPlan& A, const LayerPlan& B) {
     const glowhip_layer_desc& a = A.d; const glowhip_layer_desc& b = B.d;
-    return cnet_chain_enabled() && !g_sh_mix_disabled && !g_cnet_h2_only && a.kind == GLOWHIP_LAYER_FLOWSTEP && b.kind == GLOWHIP_LAYER_FLOWSTEP &&
+    return cnet_chain_enabled() && !g_sh_mix_disabled && a.kind == GLOWHIP_LAYER_FLOWSTEP && b.kind == GLOWHIP_LAYER_FLOWSTEP &&
            cnet_runs(p, A) && cnet_runs(p, B) && a.C == b.C && a.H == b.H && a.W == b.W && a.coupling == b.coupling &&
            cnet_pre_supported(b.C / 2, b.H, b.W, b.hidden, B.Cout, b.C);
 }
 
+// The coupling network of a FlowStep that neither k_cnet nor the deep-level kernels take (odd hidden widths, tiny images, the
+// exact-fp32 family): one exact-fp32 kernel per layer.
 static int run_coupling(glowhip_plan* P, const LayerPlan& L, const void* packed, const float* x1, long x1_bs, const float* z2_in,
                         long z2_in_bs, float* z2_out, long z2_out_bs, int N, int reverse, const Workspace& w,
-                        hipStream_t s, const NextMix* mix = nullptr) {
+                        hipStream_t s) {
     const glowhip_layer_desc& d = L.d;
     const int Ch = d.C / 2, HW = d.H * d.W, hid = d.hidden;
-    const bool use_sh = L.sh_mid && !sh_off(P);
-    const bool use_sh_tail = use_sh && L.sh_tail && !g_sh_tail_disabled;
-    const bool use_f02 = use_sh_tail && L.sh_f02 && !g_sh_f02_disabled && f02_runs_at(N, HW);
-    const bool cnet_h2 = use_sh_tail && L.cnet && g_cnet_h2_only && !g_cnet_disabled;
-    if (cnet_h2) {   // testing: f.0 + f.2 by the cnet kernel, h2 handed to k_tail_sh as an SH tensor
-        ScopedTimer t2(P, GLOWHIP_K_CONV_F2, 1, s);
-        count_launch(P, "k_cnet_h2");
-        CnetArgs c{};
-        c.x = x1; c.x_bs = x1_bs; c.w0 = at<char>(packed, L.cn_w0); c.w2 = at<char>(packed, L.cn_w2); c.w4 = at<char>(packed, L.cn_w4);
-        c.N = N; c.Cin = Ch; c.H = d.H; c.W = d.W; c.hidden = hid; c.Cout = L.Cout; c.scratch = w.h1; c.y_sh = (_Float16*)w.h2;
-        c.mode = TAIL_ADD_FWD;
-        GH_TRY(launch_cnet(c, s));
-    } else if (use_f02) {   // f.0 + f.2 fused: h1 stays in LDS (f02_sh.hip)
-        ScopedTimer t2(P, GLOWHIP_K_CONV_F2, 1, s);
-        count_launch(P, "k_f02_sh");
-        GH_TRY(launch_f02_sh(x1, x1_bs, at<char>(packed, L.f0_sh), at<char>(packed, L.f2_sh), (_Float16*)w.h2, N, Ch, d.H, d.W,
-                             hid, s));
+    {   // f.0: 3x3, Cin=C/2 -> hidden, ActNorm + ReLU epilogue
+        ScopedTimer t0(P, GLOWHIP_K_CONV_F0, L.mfma_first || L.first_halo, s);
+        if (L.first_halo) {
+            const float* wf = at<float>(packed, L.f0_wt);
+            count_launch(P, "k_conv_first_f32");
+            GH_TRY(launch_conv_mfma_first(x1, x1_bs, wf, wf + (size_t)9 * Ch * hid, w.h1, N, Ch, d.H, d.W, hid, s, 1));
+        } else if (L.mfma_first) {
+            count_launch(P, "k_conv_wide_f32");
+            GH_TRY(launch_conv_mfma_wide(x1, x1_bs, at<float>(packed, L.f0_wt), d.f0_an_bias, at<float>(packed, L.f0_scale),
+                                         w.h1, N, Ch, d.H, d.W, hid, 3, s, 1, w.h2, (size_t)N * P->max_hidden));
+        } else {
+            ConvArgs c{x1, x1_bs, d.f0_w, nullptr, d.f0_an_bias, nullptr, at<float>(packed, L.f0_scale), 1, w.h1,
+                       N, Ch, d.H, d.W, hid, 3};
+            count_launch(P, "k_conv_direct");
+            GH_TRY(launch_conv_direct(c, s));
+        }
     }
-    // f.0: 3x3, Cin=C/2 -> hidden, ActNorm + ReLU epilogue
-    if (!use_f02 && !cnet_h2) {
-    ScopedTimer t0(P, GLOWHIP_K_CONV_F0, L.mfma_first || L.first_halo, s);
-    if (use_sh && L.sh_first && !g_sh_first_disabled) {
-        count_launch(P, "k_first_sh");
-        GH_TRY(launch_first_sh(x1, x1_bs, at<char>(packed, L.f0_sh), (_Float16*)w.h1, N, Ch, d.H, d.W, hid, 1, s));
-    } else if (L.first_halo) {
-        const float* wf = at<float>(packed, L.f0_wt);
-        count_launch(P, "k_conv_first_f32");
-        GH_TRY(launch_conv_mfma_first(x1, x1_bs, wf, wf + (size_t)9 * Ch * hid, use_sh ? nullptr : w.h1, N, Ch, d.H, d.W, hid,
-                                      s, 1, use_sh ? (_Float16*)w.h1 : nullptr));
-    } else if (L.mfma_first) {
-        count_launch(P, "k_conv_wide_f32");
-        GH_TRY(launch_conv_mfma_wide(x1, x1_bs, at<float>(packed, L.f0_wt), d.f0_an_bias, at<float>(packed, L.f0_scale),
-                                     w.h1, N, Ch, d.H, d.W, hid, 3, s, 1, w.h2, (size_t)N * P->max_hidden));
-    } else {
-        ConvArgs c{x1, x1_bs, d.f0_w, nullptr, d.f0_an_bias, nullptr, at<float>(packed, L.f0_scale), 1, w.h1,
-                   N, Ch, d.H, d.W, hid, 3};
-        count_launch(P, "k_conv_direct");
-        GH_TRY(launch_conv_direct(c, s));
-    }
-    }
-    // f.2: 1x1, hidden -> hidden, ActNorm + ReLU epilogue
-    if (!use_f02 && !cnet_h2) {
-    ScopedTimer t2(P, GLOWHIP_K_CONV_F2, L.mfma_mid, s);
-    if (use_sh) {
-        count_launch(P, "k_gemm_sh");
-        GH_TRY(launch_gemm_sh((const _Float16*)w.h1, at<char>(packed, L.f2_sh), use_sh_tail ? nullptr : w.h2,
-                              use_sh_tail ? (_Float16*)w.h2 : nullptr, N, hid, HW, hid, 1, s));
-    } else if (L.mfma_mid) {
-        count_launch(P, "k_gemm_f32");
-        GH_TRY(launch_conv_mfma_wide(w.h1, (long)hid * HW, at<float>(packed, L.f2_wt), d.f2_an_bias,
-                                     at<float>(packed, L.f2_scale), w.h2, N, hid, d.H, d.W, hid, 1, s));
-    } else {
-        ConvArgs c{w.h1, (long)hid * HW, d.f2_w, nullptr, d.f2_an_bias, nullptr, at<float>(packed, L.f2_scale), 1, w.h2,
-                   N, hid, d.H, d.W, hid, 1};
-        count_launch(P, "k_conv_direct");
-        GH_TRY(launch_conv_direct(c, s));
-    }
+    {   // f.2: 1x1, hidden -> hidden, ActNorm + ReLU epilogue
+        ScopedTimer t2(P, GLOWHIP_K_CONV_F2, L.mfma_mid, s);
+        if (L.mfma_mid) {
+            count_launch(P, "k_gemm_f32");
+            GH_TRY(launch_conv_mfma_wide(w.h1, (long)hid * HW, at<float>(packed, L.f2_wt), d.f2_an_bias,
+                                         at<float>(packed, L.f2_scale), w.h2, N, hid, d.H, d.W, hid, 1, s));
+        } else {
+            ConvArgs c{w.h1, (long)hid * HW, d.f2_w, nullptr, d.f2_an_bias, nullptr, at<float>(packed, L.f2_scale), 1, w.h2,
+                       N, hid, d.H, d.W, hid, 1};
+            count_launch(P, "k_conv_direct");
+            GH_TRY(launch_conv_direct(c, s));
+        }
     }
     // f.4: 3x3 zeros conv (+bias, *exp(3 logs)) and the coupling itself
     ScopedTimer t4(P, GLOWHIP_K_CONV_F4, L.mfma_last, s);
-    if (use_sh_tail) {
-        TailShArgs t{};
-        t.x_sh = (const _Float16*)w.h2; t.P = (long)N * HW; t.wsh = at<char>(packed, L.f4_sh); t.bias = d.f4_bias;
-        t.scale = at<float>(packed, L.f4_scale);
-        t.N = N; t.Cin = hid; t.H = d.H; t.W = d.W; t.Cout = L.Cout;
-        t.mode = d.coupling == GLOWHIP_COUPLING_AFFINE ? (reverse ? TAIL_AFFINE_REV : TAIL_AFFINE_FWD)
-                                                       : (reverse ? TAIL_ADD_REV : TAIL_ADD_FWD);
-        t.z2_in = z2_in; t.z2_in_bs = z2_in_bs; t.z2_out = z2_out; t.z2_out_bs = z2_out_bs; t.acc = w.acc;
-        t.zeros = at<float>(packed, 64);
-        if (mix && mix->C) {
-            t.mix_C = mix->C; t.mix_z1 = x1; t.mix_z1_bs = x1_bs; t.mix_out = mix->out; t.mix_out_bs = mix->out_bs;
-            t.mix_bias = mix->bias; t.mix_scale = mix->scale; t.mix_matrix = mix->matrix; t.mix_gather = mix->gather;
-        }
-        count_launch(P, t.mix_C ? "k_tail_sh+mixer" : "k_tail_sh");
-        GH_TRY(launch_tail_sh(t, s));
-    } else if (L.mfma_last) {
+    if (L.mfma_last) {
         TailConvArgs t{};
         t.x = w.h2; t.x_bs = (long)hid * HW; t.wp = at<float>(packed, L.f4_wp); t.bias = d.f4_bias;
         t.scale = at<float>(packed, L.f4_scale);
@@ -313,7 +260,7 @@ static int run_coupling(glowhip_plan* P, const LayerPlan& L, const void* packed,
         count_launch(P, "k_conv_tail_f32");
         GH_TRY(launch_conv_mfma_tail(t, s));
     } else {
-        if (L.wide_last && !use_sh_tail) {     // (conv + bias) * exp(3 logs) on the fp32 MFMA implicit-GEMM kernel
+        if (L.wide_last) {     // (conv + bias) * exp(3 logs) on the fp32 MFMA implicit-GEMM kernel
             count_launch(P, "k_conv_wide_f32");
             // split-K partial sums go behind the output in the same (level-1 sized) buffer
             const size_t out_f = (size_t)N * L.Cout * HW, h1_f = (size_t)N * P->max_hidden;
@@ -391,7 +338,7 @@ static int run_forward(glowhip_plan* p, const void* packed, const float* x, cons
             bool foldable = false;
             if (!g_sh_mix_disabled && li + 1 < nl - 1 && d.W % 2 == 0) {
                 const LayerPlan& Ln = p->layers[li + 1];
-                foldable = Ln.d.kind == GLOWHIP_LAYER_FLOWSTEP && !dnet_runs(p, Ln) && chanmix_squeeze_foldable(Ln.d.C) && !g_cnet_h2_only;
+                foldable = Ln.d.kind == GLOWHIP_LAYER_FLOWSTEP && !dnet_runs(p, Ln) && chanmix_squeeze_foldable(Ln.d.C);
             }
             if (foldable) {
                 fold = SqueezeFold{u8 ? (const void*)x_u8 : (const void*)cur, u8 ? 1 : 0, u8_div, noise,
@@ -422,7 +369,7 @@ static int run_forward(glowhip_plan* p, const void* packed, const float* x, cons
                 li = lj;
                 continue;
             }
-            if (d.kind == GLOWHIP_LAYER_FLOWSTEP && cnet_runs(p, L) && !g_cnet_h2_only) {
+            if (d.kind == GLOWHIP_LAYER_FLOWSTEP && cnet_runs(p, L)) {
                 // ---- k_cnet path.  `cur` holds the input of this step's mixer, or -- `premixed` -- its output, or -- `pending` --
                 // the state the PREVIOUS step's k_cnet read, whose finishing (coupling + this step's mixer) this launch does itself
                 float* scratch = (scr_i ^= 1) ? w.h1 : w.h2;
@@ -491,24 +438,10 @@ static int run_forward(glowhip_plan* p, const void* packed, const float* x, cons
                     count_launch(p, "k_chanmix");
                     GH_TRY(launch_chanmix(m, s));
                 }
-                // Let this step's tail apply the NEXT step's channel mixer (one launch less per step) when the next layer is
-                // a FlowStep of the same shape that may run in place (i.e. is not the one writing z_out)
-                NextMix nm{};
-                if (li + 1 < nl - 1 && !g_sh_mix_disabled && tail_runs_sh(p, L)) {
-                    const LayerPlan& Ln = p->layers[li + 1];
-                    const glowhip_layer_desc& dn = Ln.d;
-                    if (dn.kind == GLOWHIP_LAYER_FLOWSTEP && dn.C == d.C && dn.H == d.H && dn.W == d.W &&
-                        tail_sh_mix_supported(d.hidden, d.H, d.W, L.Cout, d.C)) {
-                        nm.C = d.C; nm.out = dst; nm.out_bs = chw;
-                        nm.bias = dn.an_bias; nm.scale = at<float>(packed, Ln.an_scale);
-                        nm.matrix = dn.permutation == GLOWHIP_PERM_INVCONV ? dn.invconv_w : nullptr;
-                        nm.gather = dn.permutation == GLOWHIP_PERM_GATHER ? dn.perm_idx : nullptr;
-                    }
-                }
                 float* z2 = dst + (long)Ch * HW;
                 GH_TRY(join_legacy(p, s));
-                GH_TRY(run_coupling(p, L, packed, dst, chw, z2, chw, z2, chw, N, 0, w, s, &nm));
-                premixed = nm.C != 0;
+                GH_TRY(run_coupling(p, L, packed, dst, chw, z2, chw, z2, chw, N, 0, w, s));
+                premixed = false;
             } else {  // SPLIT2D: score z2 under the prior predicted from z1, keep z1
                 GH_TRY(join_legacy(p, s));
                 GH_TRY(run_split(L, packed, cur, chw, cur + (long)Ch * HW, chw, nullptr, nullptr, 0, N, 0, w, s));
@@ -550,7 +483,7 @@ static int run_reverse(glowhip_plan* p, const void* packed, const float* z, cons
                 li = lj;
                 continue;
             }
-            if (cnet_runs(p, L) && !g_cnet_h2_only) {
+            if (cnet_runs(p, L)) {
                 // coupling^-1, permutation^-1 and ActNorm^-1 by the finishing step -- run by the next-executed step's k_cnet where
                 // the two chain, by the finishing kernel otherwise
                 float* scratch = (scr_i ^= 1) ? w.h1 : w.h2;
@@ -697,13 +630,6 @@ glowhip_plan* glowhip_plan_create(const glowhip_layer_desc* layers, int n_layers
             if (L.mfma_mid) L.f2_wt = take(off, conv_mfma_wide_packed_bytes(d.hidden, d.hidden, 1));
             if (L.first_halo && L.mfma_first) L.f0_init = take(off, conv_mfma_wide_packed_bytes(C / 2, d.hidden, 3));
             else if (L.mfma_first) L.f0_init = L.f0_wt;      // already the plain K-major image
-            L.sh_mid = L.first_halo && gemm_sh_supported(d.hidden, d.hidden, H, W);
-            if (L.sh_mid) { L.f2_sh = take(off, gemm_sh_packed_bytes(d.hidden, d.hidden)); L.f2T_sh = take(off, gemm_sh_packed_bytes(d.hidden, d.hidden)); }
-            L.sh_first = L.sh_mid && first_sh_supported(C / 2, H, W, d.hidden);
-            if (L.sh_first) L.f0_sh = take(off, first_sh_packed_bytes(C / 2, d.hidden));
-            L.sh_tail = L.sh_mid && tail_sh_supported(d.hidden, H, W, L.Cout);
-            L.sh_f02 = L.sh_first && L.sh_tail && f02_sh_supported(C / 2, H, W, d.hidden);
-            if (L.sh_tail) L.f4_sh = take(off, tail_sh_packed_bytes(d.hidden, H, W, L.Cout));
             L.cnet = cnet_supported(C / 2, H, W, d.hidden, L.Cout);
             if (L.cnet) {
                 L.cn_w0 = take(off, sh2_image_bytes(cnet_g0(C / 2) * 8, d.hidden));
@@ -770,12 +696,12 @@ glowhip_plan* glowhip_plan_create(const glowhip_layer_desc* layers, int n_layers
             p->scale_jobs.push_back(ScaleJob{d.f0_an_logs, L.f0_scale, 0, d.hidden, 0});
             p->scale_jobs.push_back(ScaleJob{d.f2_an_logs, L.f2_scale, 0, d.hidden, 0});
             p->scale_jobs.push_back(ScaleJob{d.f4_logs, L.f4_scale, 0, L.Cout, 0});
-            // inference-use bit of the round-1 / fp32 images: layers that run k_cnet or the deep-level kernels read them only under
-            // the family switches (bit 8)
+            // inference-use bit of the exact-fp32 images: layers that run k_cnet or the deep-level kernels read them only under the
+            // family switches (bit 8)
             const int inf = (L.cnet || L.dnet) ? 8 : 1;
             if (L.first_halo) {
                 RepackJob r{}; r.w = d.f0_w; r.out_off = L.f0_wt; r.kind = REPACK_FIRST; r.Cin = d.C / 2; r.Cout = d.hidden;
-                r.fold_bias = d.f0_an_bias; r.fold_logs = d.f0_an_logs; r.use = 2 | (L.sh_first ? 0 : inf);
+                r.fold_bias = d.f0_an_bias; r.fold_logs = d.f0_an_logs; r.use = 2 | inf;
                 p->repack_jobs.push_back(r);
             } else if (L.mfma_first) {
                 RepackJob r{}; r.w = d.f0_w; r.out_off = L.f0_wt; r.kind = REPACK_WIDE; r.Cin = d.C / 2; r.Cout = d.hidden;
@@ -787,19 +713,7 @@ glowhip_plan* glowhip_plan_create(const glowhip_layer_desc* layers, int n_layers
             }
             if (L.mfma_mid) {
                 RepackJob r{}; r.w = d.f2_w; r.out_off = L.f2_wt; r.kind = REPACK_WIDE; r.Cin = d.hidden; r.Cout = d.hidden;
-                r.K = r.Cin; r.Kpad = wide_kpad(r.Cin, 1); r.use = 2 | (L.sh_mid ? 0 : inf); p->repack_jobs.push_back(r);
-            }
-            if (L.sh_mid) {
-                RepackJob r{}; r.w = d.f2_w; r.out_off = L.f2_sh; r.kind = REPACK_SH_GEMM; r.Cin = d.hidden; r.Cout = d.hidden;
-                r.K = d.hidden; r.fold_bias = d.f2_an_bias; r.fold_logs = d.f2_an_logs; r.use = 2 | inf; p->repack_jobs.push_back(r);
-                // input gradient of f.2 on the same kernel: W2^T, nothing folded (training only)
-                RepackJob t{}; t.w = d.f2_w; t.out_off = L.f2T_sh; t.kind = REPACK_SH_GEMM; t.Cin = d.hidden; t.Cout = d.hidden;
-                t.K = d.hidden; t.transposed = 1; t.use = 2; p->repack_jobs.push_back(t);
-            }
-            if (L.sh_first) {
-                RepackJob r{}; r.w = d.f0_w; r.out_off = L.f0_sh; r.kind = REPACK_SH_FIRST; r.Cin = d.C / 2; r.Cout = d.hidden;
-                r.K = (9 * ((r.Cin + 7) / 8) + 1) & ~1; r.fold_bias = d.f0_an_bias; r.fold_logs = d.f0_an_logs; r.use = inf;
-                p->repack_jobs.push_back(r);
+                r.K = r.Cin; r.Kpad = wide_kpad(r.Cin, 1); r.use = 2 | inf; p->repack_jobs.push_back(r);
             }
             if (L.cnet) {
                 RepackJob r0{}; r0.w = d.f0_w; r0.out_off = L.cn_w0; r0.kind = REPACK_SH2_FIRST; r0.Cin = d.C / 2; r0.Cout = d.hidden;
@@ -840,14 +754,10 @@ glowhip_plan* glowhip_plan_create(const glowhip_layer_desc* layers, int n_layers
                 RepackJob r4{}; r4.w = nullptr; r4.w_off = L.wt0; r4.out_off = L.cb_w4; r4.kind = REPACK_SH2_TAIL; r4.Cin = d.hidden; r4.Cout = Ch;
                 r4.Kpad = cnet_mpad4(Ch); r4.use = 2; p->repack_jobs.push_back(r4);
             }
-            if (L.sh_tail) {
-                RepackJob r{}; r.w = d.f4_w; r.out_off = L.f4_sh; r.kind = REPACK_SH_TAIL; r.Cin = d.hidden; r.Cout = L.Cout;
-                r.Kpad = tail_sh_mpad(d.hidden, d.H, d.W, L.Cout, &r.MT); r.use = inf; p->repack_jobs.push_back(r);
-            }
             if (L.mfma_last) {
                 RepackJob r{}; r.w = d.f4_w; r.out_off = L.f4_wp; r.kind = REPACK_TAIL; r.Cin = d.hidden; r.Cout = L.Cout;
                 r.paired = d.coupling == GLOWHIP_COUPLING_AFFINE; r.MT = tail_mt(L.Cout, r.paired);
-                r.use = 2 | (L.sh_tail ? 0 : inf);
+                r.use = 2 | inf;
                 r.total = (long)tail_chunks(r.Cin) * (TAIL_CK / 4) * 9 * r.MT * 64; p->repack_jobs.push_back(r);
             }
             if (L.wide_last) {
@@ -981,21 +891,16 @@ int glowhip_plan_describe_for(const glowhip_plan* plan, int N, char* buf, size_t
         if (d.kind == GLOWHIP_LAYER_SQUEEZE) snprintf(line, sizeof line, "%d squeeze C=%d H=%d W=%d\n", li, d.C, d.H, d.W);
         else if (d.kind == GLOWHIP_LAYER_FLOWSTEP)
         {
-            // "-sh": split-half f16 matrix-pipe kernels (sh.h) are selected for this convolution (unless disabled by the
-            // debug switch); the name before it is the exact-fp32 kernel that would run otherwise
-            const bool sh = L.sh_mid && !sh_off(plan);
             if (dnet_runs(plan, L))
                 snprintf(line, sizeof line, "%d flowstep C=%d H=%d W=%d hidden=%d f=dnet-sh2 (mix, f.0, f.2, f.4, finish: one launch per layer)\n", li, d.C,
                          d.H, d.W, d.hidden);
-            else if (cnet_runs(plan, L) && !g_cnet_h2_only)
+            else if (cnet_runs(plan, L))
                 snprintf(line, sizeof line, "%d flowstep C=%d H=%d W=%d hidden=%d f=cnet-sh2 (f.0+f.2+f.4 one kernel + finish)\n", li, d.C, d.H,
                          d.W, d.hidden);
-            else
-            snprintf(line, sizeof line, "%d flowstep C=%d H=%d W=%d hidden=%d f0=%s%s f2=%s%s f4=%s%s\n", li, d.C, d.H, d.W,
-                     d.hidden, L.first_halo ? "mfma-halo" : (L.mfma_first ? "mfma" : "direct"),
-                     sh && L.sh_first && !g_sh_first_disabled ? (L.sh_f02 && L.sh_tail && !g_sh_tail_disabled && !g_sh_f02_disabled && f02_runs_at(N, d.H * d.W) ? "-sh-fused" : "-sh") : "",
-                     L.mfma_mid ? "mfma" : "direct", sh ? "-sh" : "",
-                     L.mfma_last ? "mfma" : "direct", sh && L.sh_tail && !g_sh_tail_disabled ? "-sh" : "");
+            else      // the exact-fp32 kernels, layer by layer
+                snprintf(line, sizeof line, "%d flowstep C=%d H=%d W=%d hidden=%d f0=%s f2=%s f4=%s\n", li, d.C, d.H, d.W, d.hidden,
+                         L.first_halo ? "mfma-halo" : (L.mfma_first ? "mfma" : "direct"), L.mfma_mid ? "mfma" : "direct",
+                         L.mfma_last ? "mfma" : (L.wide_last ? "mfma-wide" : "direct"));
         }
         else snprintf(line, sizeof line, "%d split2d C=%d H=%d W=%d prior=%s\n", li, d.C, d.H, d.W,
                       L.mfma_last ? "mfma" : "direct");
@@ -1013,13 +918,12 @@ int glowhip_plan_pack(glowhip_plan* plan, void* packed, size_t packed_bytes, glo
 int glowhip_plan_pack_for(glowhip_plan* plan, void* packed, size_t packed_bytes, int use, glowhip_stream_t stream) {
     GH_REQUIRE(plan && packed, "plan_pack: null argument");
     GH_REQUIRE(use & (GLOWHIP_PACK_INFERENCE | GLOWHIP_PACK_TRAINING), "plan_pack: empty use mask");
-    // with a kernel family switched off through the debug hook the other family's images are needed after all
-    // use bit 8 (internal): the round-1 split-half images of layers that normally run k_cnet -- needed only with cnet switched off
+    // use bit 8 (internal): the exact-fp32 images of layers that normally run k_cnet / the deep-level kernels -- read by the inference
+    // calls only with the split-half path switched off through the debug hook
     // (OR-ed in: the internal bits 16 = init pass' f.0 image and 32 = no LU of the caller's mask survive)
-    if (g_sh_disabled || g_sh_tail_disabled || g_sh_first_disabled) use |= GLOWHIP_PACK_INFERENCE | GLOWHIP_PACK_TRAINING | 8;
+    if (g_sh_disabled) use |= GLOWHIP_PACK_INFERENCE | GLOWHIP_PACK_TRAINING | 8;
     // a plan on the exact-fp32 family reads the fp32 MFMA images, which are the training path's
     if (plan->family == GLOWHIP_FAMILY_EXACT_FP32) use |= GLOWHIP_PACK_TRAINING;
-    if ((use & GLOWHIP_PACK_INFERENCE) && (g_cnet_disabled || g_cnet_h2_only)) use |= 8;
     plan->repack_sel.clear();
     int n_kind[5] = {0, 0, 0, 0, 0}, tail_blocks = 1, first_blocks = 2;
     // (group 4: SH2 GEMM images of W^-1 -- launched after the LU factorisations, on their stream)

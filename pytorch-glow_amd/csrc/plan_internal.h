@@ -23,11 +23,6 @@ struct LayerPlan {
     // training: input-gradient convolutions run on the forward kernels with flipped/transposed weight images
     size_t f4T_wf = 0, f0T_wp = 0;
     bool dg4_first = false, dg0_tail = false;
-    // split-half path (sh.h): f.0 writes h1 as an SH tensor, f.2 runs on the f16 matrix pipe (gemm_sh.hip)
-    bool sh_mid = false; size_t f2_sh = 0, f2T_sh = 0;   // f2T_sh: W2^T image for the input gradient (training)
-    bool sh_first = false; size_t f0_sh = 0;  // f.0 itself on the f16 pipe (first_sh.hip)
-    bool sh_f02 = false;                       // f.0 + f.2 as one kernel (f02_sh.hip), h1 never written
-    bool sh_tail = false; size_t f4_sh = 0;   // f.2 writes h2 as an SH tensor, f.4 + coupling on tail_sh.hip
     bool cnet = false; size_t cn_w0 = 0, cn_w2 = 0, cn_w4 = 0;   // whole coupling network as one kernel (cnet_sh.hip), SH2 images
     // the input-gradient chain as one k_cnet launch (MODE 2): SH2 images of the transposed weights (cb_w0: f.4^T as the 3x3 first
     // layer, cb_w2: f.2^T, cb_w4: f.0^T as the 3x3 last layer) and the transposed fp32 copies they are built from (wt4 / wt2 / wt0)

@@ -51,7 +51,7 @@ static size_t tape_layout(const glowhip_plan* p, int N, std::vector<TapeLayer>* 
 struct TrainWs {
     unsigned long long* acc; float* gld; double* gsum;
     float* gA; float* gB; float* gh1; float* gh2; float* gpre; float* wT; double* dacc;
-    float* gsh;                   // split-half copy of a hidden-layer gradient (input of the f16-pipe dgrad GEMM) / of h1 (forward)
+    float* gsh;                   // partial-sum scratch of the taping / backward k_cnet launches
     float* col; float* partial;   // shift-expanded small operand / split-K partial tiles of the MFMA weight gradients
     size_t partial_floats;        // floats of ONE of the three split-K partial regions behind `partial`
     GradJob* jobs;                // device copy of the finalize job table (<= 9 per layer)
@@ -236,14 +236,10 @@ static int forward_train(glowhip_plan* p, const void* packed, const float* x, co
                 cur = dst;
                 continue;
             }
-            // f.0
-            // f.2 on the f16 matrix pipe (gemm_sh.hip) when f.0 can hand it h1 as a split-half tensor next to the fp32 copy
-            // the tape keeps; the tape itself stays fp32 (the weight-gradient GEMMs read it)
-            const bool sh2 = L.first_halo && L.sh_mid && train_sh_enabled(p);
+            // f.0 (shapes the taping k_cnet does not take: the exact-fp32 kernels, layer by layer)
             if (L.first_halo) {
                 const float* wf = at<float>(packed, L.f0_wt);
-                GH_TRY(launch_conv_mfma_first(dst, chw, wf, wf + (size_t)9 * Ch * hid, h1, N, Ch, d.H, d.W, hid, s, 1,
-                                              sh2 ? (_Float16*)sh_scratch : nullptr));
+                GH_TRY(launch_conv_mfma_first(dst, chw, wf, wf + (size_t)9 * Ch * hid, h1, N, Ch, d.H, d.W, hid, s, 1));
             } else if (L.mfma_first) {
                 GH_TRY(launch_conv_mfma_wide(dst, chw, at<float>(packed, L.f0_wt), d.f0_an_bias,
                                              at<float>(packed, L.f0_scale), h1, N, Ch, d.H, d.W, hid, 3, s));
@@ -253,9 +249,7 @@ static int forward_train(glowhip_plan* p, const void* packed, const float* x, co
                 GH_TRY(launch_conv_direct(c, s));
             }
             // f.2
-            if (sh2) {
-                GH_TRY(launch_gemm_sh((const _Float16*)sh_scratch, at<char>(packed, L.f2_sh), h2, nullptr, N, hid, HW, hid, 1, s));
-            } else if (L.mfma_mid) {
+            if (L.mfma_mid) {
                 GH_TRY(launch_conv_mfma_wide(h1, (long)hid * HW, at<float>(packed, L.f2_wt), d.f2_an_bias,
                                              at<float>(packed, L.f2_scale), h2, N, hid, d.H, d.W, hid, 1, s));
             } else {
@@ -337,7 +331,7 @@ static int backward_sweep(glowhip_plan* p, const void* packed, const float* x_in
                           TrainWs& w, float* g_top, hipStream_t s) {
     // g: gradient w.r.t. the current layer's OUTPUT (contiguous (N, C_out, H, W)), held in gA/gB
     float* g = g_top;
-    // power-of-two pre-scale of the gradients that travel as fp16 pairs (k_act_bwd_sh): 2^round(log2(B ln2 CHW)), the inverse
+    // power-of-two pre-scale of the gradients that travel as fp16 pairs (backward k_cnet, weight-gradient GEMMs): 2^round(log2(B ln2 CHW)), the inverse
     // of dL/d(objective) for loss = mean(nll) (network/model.py:448-450, 496-506)
     const float sh_grad_scale = exp2f(rintf(log2f((float)N * 0.6931472f * (float)p->in_shape[0] * p->in_shape[1] * p->in_shape[2])));
     const int nl = (int)p->layers.size();
@@ -490,9 +484,7 @@ static int backward_sweep(glowhip_plan* p, const void* packed, const float* x_in
             } else {
                 GH_TRY(dgrad_direct(w.gpre, d.f4_w, w.wT, w.gh2, N, hid, d.H, d.W, L.Cout, 3, s));
             }
-            const bool shd = L.sh_mid && train_sh_enabled(p) && HW % 64 == 0;   // f.2's input gradient on the f16 pipe
-            GH_TRY(launch_act_bwd(w.gh2, h2, at<float>(packed, L.f2_scale), N, hid, HW, a2b, a2l, s,
-                                  shd ? (_Float16*)w.gsh : nullptr, sh_grad_scale));
+            GH_TRY(launch_act_bwd(w.gh2, h2, at<float>(packed, L.f2_scale), N, hid, HW, a2b, a2l, s));
             // (c) f.2 (1x1)
             if (fastw) {
                 GH_TRY(launch_wgrad_mfma(w.gh2, (long)hid * HW, h1, (long)hid * HW, w.partial, G.f2_w, N, HW, hid, hid, hid, hid,
@@ -500,10 +492,7 @@ static int backward_sweep(glowhip_plan* p, const void* packed, const float* x_in
             } else {
                 GH_TRY(launch_wgrad_direct(w.gh2, h1, (long)hid * HW, G.f2_w, N, hid, d.H, d.W, hid, 1, s));
             }
-            if (shd) {
-                GH_TRY(launch_gemm_sh((const _Float16*)w.gsh, at<char>(packed, L.f2T_sh), w.gh1, nullptr, N, hid, HW, hid, 0, s,
-                                      1.0f / sh_grad_scale));
-            } else if (L.mfma_mid) {   // W2 in its reference layout [o][i] is already the K-major image of the transposed GEMM
+            if (L.mfma_mid) {   // W2 in its reference layout [o][i] is already the K-major image of the transposed GEMM
                 GH_TRY(launch_conv_mfma_wide(w.gh2, (long)hid * HW, d.f2_w, nullptr, nullptr, w.gh1, N, hid, d.H, d.W, hid, 1,
                                              s, 0));
             } else {

@@ -10,22 +10,14 @@
 // (v - hi is exact in fp32; the 2^11 pre-scale keeps lo a NORMAL fp16 number.)  A product is evaluated as
 //   a*b ~= a.hi*b.hi + (a.hi*b.lo + a.lo*b.hi) / 2^11            (the dropped lo*lo term is <= 2^-24 |a b|)
 // with every fp16 x fp16 product exact in the fp32 accumulator (11+11 bits), two accumulators (main, cross) and
-// fp32 accumulation as in the fp32 MFMA.  (This two-accumulator form serves the round-1 kernel pairs and the training GEMMs; the
-// product path, cnet_sh.hip, uses the single-accumulator SH2 form at the end of this file.)  Three f16 MFMAs per k-step instead of one fp32 MFMA of 1/16 the rate.
+// fp32 accumulation as in the fp32 MFMA.  (This two-accumulator form serves the weight-gradient GEMMs of the training step, whose
+// gradient operand needs its 30 binades; the forward / inverse / input-gradient kernels -- cnet_sh.hip, dnet_sh.hip -- use the
+// single-accumulator SH2 form at the end of this file.)  Three f16 MFMAs per k-step instead of one fp32 MFMA of 1/16 the rate.
 // Range: |v| < 65504 (fp16 max; larger values become inf and surface as a non-finite nll, they are never clipped
 // silently); below 6.1e-5 the representation is absolute, 2.9e-11.  tests/diag_split_precision.py: on the celeba64
 // model the deviation from an fp64 evaluation is 5.8e-6 (z), the fp32 reference's own is 5.4e-6.
 //
-// HBM layout of an SH activation tensor with Ch channels over P = N*H*W pixels (pixel index p = n*HW + y*W + x; P % 64 == 0):
-//   half [P/64][plane {hi, lo}][Ch/8][64][8]       (8 consecutive channels of one pixel = 16 bytes; a 64-pixel tile with all
-//                                                   its channels and both planes is ONE contiguous block of Ch*256 bytes)
-// (the first version was plane-major / chunk-major over the whole tensor: every workgroup then touched 128 separate 2-KiB
-// runs a megabyte apart, and all three kernels sat at ~3 TB/s of HBM traffic)
-// This is at once what the MFMA epilogue produces (a lane owns 4 consecutive channels of its pixel; the two
-// half-waves complete the 16-byte group, 32 lanes = 512 contiguous bytes per store instruction) and what the consumer's
-// operand fetch wants (a lane's B fragment = 8 consecutive k of its pixel = ONE 16-byte group; 64 lanes of an LDS-DMA
-// instruction read 1 KiB contiguous and land as the conflict-free [chunk][pixel][8] LDS image -- no swizzle, no padding).
-// Weights use the same form: half [plane][K/8][M][8].
+// Weights use the form half [plane][K/8][M][8] (8 consecutive k of a row = one 16-byte group = a lane's MFMA A fragment).
 #pragma once
 #include "common.h"
 
@@ -40,85 +32,10 @@ typedef float f32x2_t __attribute__((ext_vector_type(2)));
 constexpr float SH_LO_SCALE = 2048.0f;
 constexpr float SH_LO_INV = 1.0f / 2048.0f;
 
-// offset (halfs) of the 16-byte group (plane q, 8-channel chunk c, pixel p) of an SH tensor with NC = Ch/8 chunks
-__host__ __device__ __forceinline__ long sh_off(int NC, int q, int c, long p) {
-    return ((((p >> 6) * 2 + q) * NC + c) * 64 + (p & 63)) * 8;
-}
-constexpr long SH_CHUNK_STEP = 64 * 8;   // halfs from one chunk to the next inside a tile
-
 __device__ __forceinline__ void sh_split(float v, _Float16& hi, _Float16& lo) {
     hi = (_Float16)v;
     lo = (_Float16)((v - (float)hi) * SH_LO_SCALE);
 }
-
-// Eight values at once (two-accumulator form: lo carries the residual times 2^11), packed conversions and packed fp32 arithmetic:
-// ~3 VALU instructions per value instead of 6; same bits as eight sh_split calls on v * pre (pre: an exact power of two).
-typedef _Float16 h2s __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void sh_split8(const f32x4_t& a, const f32x4_t& b, float pre, h8& hi, h8& lo) {
-#pragma unroll
-    for (int t = 0; t < 8; t += 2) {
-        const float v0 = (t < 4 ? a[t] : b[t - 4]) * pre, v1 = (t < 4 ? a[t + 1] : b[t - 3]) * pre;
-        const f32x2_t vv = {v0, v1};
-        const h2s x = __builtin_convertvector(vv, h2s);
-        const f32x2_t rr = {(v0 - (float)x[0]) * SH_LO_SCALE, (v1 - (float)x[1]) * SH_LO_SCALE};
-        const h2s y = __builtin_convertvector(rr, h2s);
-        hi[t] = x[0]; hi[t + 1] = x[1]; lo[t] = y[0]; lo[t + 1] = y[1];
-    }
-}
-
-// bytes of one SH tensor (both planes)
-static inline size_t sh_bytes(long P, int Ch) { return (size_t)2 * (size_t)P * (size_t)Ch * sizeof(_Float16); }
-
-// ---- f.2 as an SH GEMM (gemm_sh.hip) ------------------------------------------------------------
-// Y[o][px] = relu( sum_k W'[o][k] X[k][px] + b'[o] ),  W' = W * exp(3 logs[o]), b' = bias * exp(3 logs[o]) (ActNorm folded)
-// wsh: packed image = half [2][K/8][M][8] followed (16-byte aligned) by M floats b'.
-bool gemm_sh_supported(int K, int M, int H, int W);
-size_t gemm_sh_packed_bytes(int K, int M);
-// exactly one of y_f32 (N,M,H,W fp32) / y_sh (SH tensor, P = N*HW) is written
-int launch_gemm_sh(const _Float16* x_sh, const void* wsh, float* y_f32, _Float16* y_sh, int N, int K, int HW, int M, int relu,
-                   hipStream_t s, float out_scale = 1.0f);   // out_scale: exact power of two applied to the result
-
-// ---- f.0 on SH operands (first_sh.hip): fp32 z in, SH h1 out -----------------------------------------
-// wsh: half [2][G][Cout][8] (k group g = tap * nchunk + chunk, 8 channels each; ActNorm scale folded), then Cout floats b'
-bool first_sh_supported(int Cin, int H, int W, int Cout);
-size_t first_sh_packed_bytes(int Cin, int Cout);
-int launch_first_sh(const float* x, long x_bs, const void* wsh, _Float16* y_sh, int N, int Cin, int H, int W, int Cout,
-                    int relu, hipStream_t s);
-
-// ---- f.0 + f.2 fused (f02_sh.hip): fp32 z in, SH h2 out; h1 stays in LDS ----------------------------------
-bool f02_sh_supported(int Cin, int H, int W, int hidden);
-int launch_f02_sh(const float* x, long x_bs, const void* w0_first_sh_image, const void* w2_gemm_sh_image, _Float16* y_sh, int N,
-                  int Cin, int H, int W, int hidden, hipStream_t s);
-
-// ---- f.4 + coupling on SH operands (tail_sh.hip) ---------------------------------------------------
-struct TailShArgs {
-    const _Float16* x_sh; long P;     // h2 as an SH tensor of P = N*H*W pixels, Cin channels
-    const void* wsh;                  // packed image: half [group][2][Cin/8][Mpad][8], row m = tap*Cg + co_in_group (REPACK_SH_TAIL)
-    const float* bias;                // (Cout)
-    const float* scale;               // (Cout) exp(3 logs)
-    int N, Cin, H, W, Cout;
-    int mode;                         // TailMode (conv_mfma.h): the four coupling modes
-    const float* z2_in; long z2_in_bs;
-    float* z2_out; long z2_out_bs;
-    unsigned long long* acc;
-    const float* zeros;               // >= 16 B of zeros in global memory
-    // Optional: the NEXT FlowStep's channel mixer (ActNorm + invertible 1x1 conv / permutation, forward) applied to this
-    // step's output z = (z1, z2_out) before it is written: y = M ((z + bias) * scale) goes to mix_out (N,C,H,W; may be the
-    // buffer z lives in -- a workgroup reads and writes only its own pixels) and z2_out is not written.  Saves the
-    // k_chanmix launch of the next step.  mix_C = 0: off.  Needs one channel group (all of z2 in one workgroup).
-    int mix_C;
-    const float* mix_z1; long mix_z1_bs;      // z1 of this step (first C/2 channels)
-    float* mix_out; long mix_out_bs;
-    const float* mix_bias; const float* mix_scale;   // (C) of the next step's ActNorm: bias, exp(3 logs)
-    const float* mix_matrix;                  // (C,C) row-major, or null
-    const int32_t* mix_gather;                // (C) gather table, or null
-};
-bool tail_sh_mix_supported(int Cin, int H, int W, int Cout, int C);
-bool tail_sh_supported(int Cin, int H, int W, int Cout);
-size_t tail_sh_packed_bytes(int Cin, int H, int W, int Cout);
-int tail_sh_mpad(int Cin, int H, int W, int Cout, int* groups);   // padded rows per channel group of the packed image
-int launch_tail_sh(const TailShArgs& a, hipStream_t s);
-void tail_sh_force_waves(int nwaves);   // testing hook: only the 4- or the 8-wave variants (0 = automatic)
 
 // =====================================================================================================================
 // SH2: split-half operands at their TRUE scale -> ONE accumulator per output (cnet_sh.hip)
@@ -212,7 +129,6 @@ struct CnetArgs {
     const void* w0; const void* w2; const void* w4;   // SH2 images (REPACK_SH2_FIRST / _GEMM / _TAIL)
     int N, Cin, H, W, hidden, Cout;
     float* scratch;                              // cnet_scratch_floats(N, ...) floats
-    _Float16* y_sh;                              // testing: write h2 as an (old-format) SH tensor and stop before f.4
     // ---- finishing kernel of THIS step: coupling + log-det + channel mixer
     const float* bias; const float* scale;       // f.4 bias (Cout), exp(3 logs) (Cout)
     int mode;                                    // TailMode: the four coupling modes

@@ -253,9 +253,9 @@ k_wgrad_gemm_sh(const float* __restrict__ A, long a_bs, const float* __restrict_
         for (int t = 0; t < 4; t += 2) {
             const float v0 = v[t] * pre, v1 = v[t + 1] * pre;
             const f32x2_t vv = {v0, v1};
-            const h2s x = __builtin_convertvector(vv, h2s);
+            const h2 x = __builtin_convertvector(vv, h2);
             const f32x2_t rr = {(v0 - (float)x[0]) * SH_LO_SCALE, (v1 - (float)x[1]) * SH_LO_SCALE};
-            const h2s y = __builtin_convertvector(rr, h2s);
+            const h2 y = __builtin_convertvector(rr, h2);
             hi[t] = x[0]; hi[t + 1] = x[1]; lo[t] = y[0]; lo[t + 1] = y[1];
         }
     };

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Per-kernel durations of the bench step (run on the GPU box via gpurun): rocprofv3 kernel trace, top kernels by total time.
-# usage: scripts/ktrace.sh <tag> [bench args...]   (GLOWHIP_DEBUG_FLAGS is passed through)
+# usage: scripts/ktrace.sh <tag> [bench args...]   (kernel-variant switches: pass --debug-flags <value> among the bench args)
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=${1:-kt}; shift

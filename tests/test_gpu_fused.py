@@ -1,8 +1,8 @@
-"""`-m gpu` parity of the kernels that only run at large grids: the fused f.0 + f.2 kernel (k_f02_sh, the dominant kernel of the
-bench step) is selected when a launch has >= 192 workgroups, i.e. at batches the small-case parity tests never reach.  These
-tests run config-B geometry (hidden 512, 64x64x3, L=3) and the 64-pixel-wide level of config D at such batches against the
-oracle on EVERY element -- with K reduced so the CPU oracle stays at seconds -- and take the evidence of which kernel ran
-from the executor's run-time launch counters (glowhip_plan_launch_counts), not from a static description.
+"""`-m gpu` parity at the shapes and batches the small-case tests never reach: config-B geometry (hidden 512, 64x64x3, L=3) and the
+64-pixel-wide level of config D at batches that fill the chip, against the oracle on EVERY element -- with K reduced so the CPU
+oracle stays at seconds -- on both kernel families that remain (the product path: k_cnet + finishing kernel; the exact-fp32 MFMA
+kernels that serve as range fall-back and reference point), with the evidence of which kernel ran taken from the executor's
+run-time launch counters (glowhip_plan_launch_counts), not from a static description.
 Reference: network/module.py:300-319 (f), network/model.py:82-154 (FlowStep)."""
 import numpy as np
 import pytest
@@ -14,15 +14,15 @@ from test_gpu_parity import close, dev, make_glow
 
 pytestmark = pytest.mark.gpu
 
-CNET_OFF = 0x100000      # glowhip_debug_force_tail_tile: the one-kernel coupling network off -> the round-1 kernel pairs run
+EXACT_FP32 = 0x800      # glowhip_debug_force_tail_tile: the split-half path off -> every coupling network on the exact-fp32 kernels
 
 
-@pytest.fixture(params=["cnet", "pairs"])
+@pytest.fixture(params=["cnet", "fp32"])
 def path(request):
     """Both kernel families behind the same tests: the product default (k_cnet: f.0 + f.2 + f.4 in one kernel + finishing
-    kernel) and the kernel pairs it replaced (k_f02_sh / k_first_sh + k_gemm_sh, then k_tail_sh), which stay as the fall-back
-    for shapes cnet does not take."""
-    G.lib().glowhip_debug_force_tail_tile(CNET_OFF if request.param == "pairs" else 0)
+    kernel) and the exact-fp32 MFMA kernels (one launch per layer), the fall-back for out-of-range batches and for shapes the
+    product kernels do not take."""
+    G.lib().glowhip_debug_force_tail_tile(EXACT_FP32 if request.param == "fp32" else 0)
     try:
         yield request.param
     finally:
@@ -66,59 +66,48 @@ def _case(image, L, K, hidden, batch, seed=5, coup="affine", perm="invconv"):
     return plan, fwd, rev
 
 
-def test_fused_f02_runs_and_matches_oracle_config_b_geometry(path):
-    """Config-B geometry at batch 48, full z / nll / decode vs the oracle at 1e-4.  cnet: every FlowStep is one k_cnet launch
-    (+ finishing kernel), forward and inverse.  pairs: levels 1 (768 workgroups) and 2 (192) take the fused f.0 + f.2 kernel,
-    level 3 (48 workgroups) the separate pair."""
+FP32_KERNELS = ("k_conv_first_f32", "k_conv_wide_f32", "k_gemm_f32", "k_conv_tail_f32")
+
+
+def _family_ran(path, fwd, rev, steps):
+    if path == "cnet":      # one k_cnet + one finishing kernel per FlowStep, nothing of the other family
+        assert ncnet(fwd) == steps and ncnet(rev) == steps, (fwd, rev)
+        assert nfinish(fwd) == steps and nfinish(rev) == steps, (fwd, rev)
+        assert not any(k in fwd for k in FP32_KERNELS + ("k_conv_direct",)), fwd
+    else:
+        assert ncnet(fwd) == 0 and ncnet(rev) == 0, (fwd, rev)
+        assert fwd.get("k_gemm_f32", 0) == steps and rev.get("k_gemm_f32", 0) == steps, (fwd, rev)
+        assert fwd.get("k_conv_direct", 0) == 0, fwd
+
+
+def test_config_b_geometry_matches_oracle(path):
+    """Config-B geometry at batch 48, full z / nll / decode vs the oracle at 1e-4, forward and inverse."""
     K = 4
     plan, fwd, rev = _case(64, 3, K, 512, 48)
+    _family_ran(path, fwd, rev, 3 * K)
     if path == "cnet":
-        # one k_cnet + one finishing kernel per FlowStep
-        assert ncnet(fwd) == 3 * K and ncnet(rev) == 3 * K, (fwd, rev)
-        assert nfinish(fwd) == 3 * K and nfinish(rev) == 3 * K, (fwd, rev)
-        assert not any(k in fwd for k in ("k_f02_sh", "k_gemm_sh", "k_tail_sh", "k_conv_direct", "k_gemm_f32")), fwd
         assert sum("cnet-sh2" in l for l in plan.describe(48).splitlines()) == 3 * K
-        return
-    assert fwd.get("k_f02_sh", 0) == 2 * K, fwd          # levels 1 and 2, every step
-    assert fwd.get("k_first_sh", 0) == K and fwd.get("k_gemm_sh", 0) == K, fwd   # level 3
-    assert rev.get("k_f02_sh", 0) == 2 * K, rev
-    assert fwd.get("k_conv_direct", 0) == 0 and fwd.get("k_gemm_f32", 0) == 0, fwd
-    # the batch-aware description agrees with what ran
-    d48, d4 = plan.describe(48), plan.describe(4)
-    assert sum("-sh-fused" in l for l in d48.splitlines()) == 2 * K
-    assert sum("-sh-fused" in l for l in d4.splitlines()) == 0
 
 
-def test_fused_f02_level1_only_batch16(path):
-    """Batch 16: in the pairs family only level 1 (256 workgroups) reaches the fused kernel; cnet splits the h2 rows over 2 / 4
-    workgroups per tile at the levels whose pixel tiles alone would leave CUs idle."""
+def test_config_b_geometry_batch16(path):
+    """Batch 16: k_cnet splits the h2 rows over 2 / 4 workgroups per tile at the levels whose pixel tiles alone would leave CUs idle."""
     K = 3
     plan, fwd, rev = _case(64, 3, K, 512, 16, seed=6)
-    if path == "cnet":
-        assert ncnet(fwd) == 3 * K, fwd
-    else:
-        assert fwd.get("k_f02_sh", 0) == K and fwd.get("k_gemm_sh", 0) == 2 * K, fwd
+    _family_ran(path, fwd, rev, 3 * K)
 
 
-def test_fused_f02_w64_level(path):
-    """The 64-pixel-wide level (config D level 1, 128x128 input): a 64-pixel tile is one image row (wshift = 6).  Batch 3 ->
-    192 workgroups."""
+def test_w64_level(path):
+    """The 64-pixel-wide level (config D level 1, 128x128 input): a 64-pixel tile is one image row (wshift = 6)."""
     K = 2
     plan, fwd, rev = _case(128, 2, K, 256, 3, seed=7)
-    if path == "cnet":
-        assert ncnet(fwd) == 2 * K and ncnet(rev) == 2 * K, (fwd, rev)
-    else:
-        assert fwd.get("k_f02_sh", 0) >= K and rev.get("k_f02_sh", 0) >= K, (fwd, rev)   # the W=64 level is fused at this batch
+    _family_ran(path, fwd, rev, 2 * K)
 
 
-def test_fused_f02_additive_and_shuffle(path):
-    """Additive coupling (Cout = C/2 tail rows) and a gather permutation behind the fused kernel."""
+def test_additive_and_shuffle(path):
+    """Additive coupling (Cout = C/2 tail rows) and a gather permutation."""
     K = 2
     plan, fwd, rev = _case(64, 2, K, 512, 16, seed=8, coup="additive", perm="reverse")
-    if path == "cnet":
-        assert ncnet(fwd) == 2 * K, fwd
-    else:
-        assert fwd.get("k_f02_sh", 0) >= K, fwd
+    _family_ran(path, fwd, rev, 2 * K)
 
 
 @pytest.mark.parametrize("ms", [1, 2, 4])
@@ -194,9 +183,9 @@ def _range_case(scale_h):
     return cfg, sd, x, noise, z_ref, nll_ref
 
 
-@pytest.mark.parametrize("flags", [0, 0x100000, 0x800])
+@pytest.mark.parametrize("flags", [0, 0x800])
 def test_range_overflow_is_never_a_finite_wrong_answer(flags):
-    """Hidden activations of ~1e5 overflow the fp16 pairs (product kernels: cnet; 0x100000: the kernel pairs) but not fp32 (0x800:
+    """Hidden activations of ~1e5 overflow the fp16 pairs of the product kernels but not fp32 (0x800:
     exact-fp32 kernels).  The reference stays finite.  Overflowing paths must report a NON-FINITE nll (sticky per-sample flag:
     a NaN partial sum cannot hide in the fixed-point accumulator), never a finite wrong one; the fp32 kernels must match the
     oracle; and safe=True must recover the reference's answer through the exact-fp32 re-run."""
@@ -211,7 +200,7 @@ def test_range_overflow_is_never_a_finite_wrong_answer(flags):
             return
         ok = torch.isfinite(nll).cpu()
         assert not ok.any() or (nll.cpu()[ok] - nll_ref[ok]).abs().max() < 1e-4, "finite AND wrong nll after an fp16-range overflow"
-        if flags == 0:     # (the kernel pairs fall back to exact-fp32 kernels at this small hidden width: no overflow there)
+        if flags == 0:
             assert (~ok).any(), "this input is meant to overflow the split-half range"
     finally:
         G.lib().glowhip_debug_force_tail_tile(0)
@@ -234,7 +223,7 @@ def test_nan_input_gives_nan_nll_on_every_path():
     sticky flag does."""
     cfg, sd, x, noise, _, nll_ref = _range_case(1.0)
     x = x.clone(); x[2, 1, 5, 5] = float("nan")
-    for flags in (0, 0x100000, 0x800):
+    for flags in (0, 0x800):
         G.lib().glowhip_debug_force_tail_tile(flags)
         try:
             glow = make_glow(cfg, sd, 4)

@@ -308,7 +308,7 @@ def test_split_half_survives_large_and_tiny_activations():
                 st.f[0].weight.mul_(wmul); st.f[2].weight.mul_(wmul)
             sd = {k: v.detach().cpu().clone() for k, v in st.state_dict().items()}
         x = torch.randn(2, 12, 32, 32, generator=torch.Generator().manual_seed(6)) * scale
-        assert "cnet-sh2" in st._plan(dev(x)).describe() or "f2=mfma-sh" in st._plan(dev(x)).describe()
+        assert "cnet-sh2" in st._plan(dev(x)).describe()
         z, ld = st(dev(x), 0.)
         zr, ldr = O.flowstep(x, torch.zeros(2), sd, "", "invconv", "affine")
         tol = 2e-5 * max(1.0, zr.abs().max().item())
@@ -455,8 +455,8 @@ def test_mfma_flowstep_vs_oracle(c, h, w, hidden, coup, n):
 @pytest.mark.parametrize("c", [100, 104, 112])
 def test_additive_step_wider_than_the_fused_mixer_both_directions(c):
     """additive coupling with 96 < C <= 112 still runs k_cnet (Cout = C/2 <= 56) but is wider than the finishing kernel's
-    fused mixer.  Forward and reverse must take the SAME kernel family (the reverse used to fall back to the round-1 pairs, whose
-    weight images the decode pack does not write): both checked against the oracle, k_cnet asserted from the launch counters."""
+    fused mixer.  Forward and reverse must take the SAME kernel family (the reverse once fell back to another family whose weight
+    images the decode pack does not write): both checked against the oracle, k_cnet asserted from the launch counters."""
     st, sd = _rand_step(c, 128, "additive", seed=c)
     x = torch.randn(3, c, 8, 8, generator=torch.Generator().manual_seed(1))
     ld = torch.randn(3, generator=torch.Generator().manual_seed(2))
@@ -591,12 +591,11 @@ def test_deep_multiscale_configs_vs_oracle(name, image, L, K, hidden, batch):
 @pytest.mark.parametrize("coup,perm", [("affine", "invconv"), ("additive", "reverse"), ("affine", "shuffle"),
                                        ("additive", "invconv")])
 def test_split_half_stack_every_coupling_and_permutation(coup, perm):
-    """A 3-level stack (32^2, 16^2, 8^2 pixels; hidden 128; batch 12) whose FlowSteps all take the split-half kernels: the
-    fused f.0+f.2 kernel at level 1 (192 workgroups at this batch -- asserted from the executor's launch counters), the
-    separate f.0 / f.2 pair below it, the taps-as-rows tail with both coupling kinds, and the tail applying the NEXT step's channel
-    mixer -- as a matrix (invconv) and as a gather (reverse / shuffle).  Checked against the oracle, forward and inverse,
-    and against the same run with the mixer fusion switched off: the fused mixer keeps k_chanmix's operation order, so the
-    two must agree bit for bit."""
+    """A 3-level stack (32^2, 16^2, 8^2 pixels; hidden 128; batch 12) whose FlowSteps all take the product kernels: both
+    coupling kinds, the finishing kernel applying the NEXT step's channel mixer -- as a matrix (invconv) and as a gather
+    (reverse / shuffle) -- and every level's leading squeeze folded into its first mixer.  Checked against the oracle, forward and
+    inverse, and against the same run with the fusions switched off (0x8000: k_squeeze, k_chanmix and a plain finishing kernel as
+    separate launches): the fused forms keep the separate kernels' operation order, so the two must agree bit for bit."""
     batch = 12
     cfg = O.default_cfg(image_shape=(64, 64, 3), hidden_channels=128, K=3, L=3, flow_permutation=perm, flow_coupling=coup,
                         batch=batch)
@@ -619,12 +618,15 @@ def test_split_half_stack_every_coupling_and_permutation(coup, perm):
     z, nll, _ = glow.normal_flow(dev(x), None, noise=dev(noise))
     counts = plan.launch_counts(reset=True)
     assert counts.get("k_cfinish+mixer", 0) >= 4 and counts.get("k_conv_direct", 0) == 0, counts
+    assert counts.get("squeeze(folded)", 0) == 3, counts
     close(z, z_ref, 1e-4, what="z"); close(nll, nll_ref, 1e-4, what="nll")
-    G.lib().glowhip_debug_force_tail_tile(0x8000)      # the same without the mixer fused into the tails
+    G.lib().glowhip_debug_force_tail_tile(0x8000)      # the same without the mixer fused into the finishing kernel / the squeeze into the mixer
     try:
         z_u, nll_u, _ = glow.normal_flow(dev(x), None, noise=dev(noise))
+        counts_u = plan.launch_counts(reset=True)
     finally:
         G.lib().glowhip_debug_force_tail_tile(0)
+    assert "squeeze(folded)" not in counts_u and "k_cfinish+mixer" not in counts_u, counts_u
     assert torch.equal(z, z_u) and torch.equal(nll, nll_u)
     eps = [torch.randn(batch, *s, generator=torch.Generator().manual_seed(6 + i)) * 0.7
            for i, s in enumerate(glow.flow.split_shapes((3, 64, 64)))]
@@ -646,6 +648,12 @@ def test_uint8_pixels_equal_the_float_path_bitwise():
     z8, nll8, _ = glow.normal_flow(u8.to(DEV), None, noise=dev(noise))
     zf, nllf, _ = glow.normal_flow(dev(xf), None, noise=dev(noise))
     assert torch.equal(z8, zf) and torch.equal(nll8, nllf)
+    G.lib().glowhip_debug_force_tail_tile(0x8000)      # ... and the squeeze kernel on the bytes instead of the mixer gathering them
+    try:
+        z8u, nll8u, _ = glow.normal_flow(u8.to(DEV), None, noise=dev(noise))
+    finally:
+        G.lib().glowhip_debug_force_tail_tile(0)
+    assert torch.equal(z8, z8u) and torch.equal(nll8, nll8u)
     z_ref, nll_ref, _ = O.glow_forward(xf, noise, sd, cfg)
     close(z8, z_ref, 1e-4, what="z"); close(nll8, nll_ref, 1e-4, what="nll")
     with pytest.raises(G.GlowHipError):
@@ -694,7 +702,7 @@ def test_deep_level_kernels_vs_oracle(image, L, hidden, batch, coup):
         assert counts.get("k_dn_gemm(mix)", 0) == len(deep) and counts.get("k_dn_fin", 0) == len(deep), counts
         assert counts.get("k_dn_gemm(f0,f2,f4)", 0) == len(deep), counts
     if deep and len(deep) == sum("flowstep" in l and "cnet-sh2" not in l for l in desc.splitlines()):
-        legacy = {"k_first_sh", "k_gemm_sh", "k_tail_sh", "k_tail_sh+mixer", "k_conv_wide_f32", "k_gemm_f32", "k_conv_first_f32", "k_conv_tail_f32", "k_f02_sh"}
+        legacy = {"k_conv_wide_f32", "k_gemm_f32", "k_conv_first_f32", "k_conv_tail_f32"}
         assert not (legacy & set(fwd)) and not (legacy & set(rev)), (fwd, rev)
     # bitwise reproducible run to run (fixed reduction orders, fixed-point log-det)
     z2, nll2, _ = glow.normal_flow(dev(x), None, noise=dev(noise))
