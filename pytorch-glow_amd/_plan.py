@@ -262,7 +262,11 @@ class FlowPlan:
 
     # ------------------------------------------------------------------ training step
     def _grad_fields(self):
-        """[(layer index, LayerGrads field, parameter)] for every parameter the C backward produces a gradient for."""
+        """[(layer index, LayerGrads field, parameter)] for every parameter the C backward produces a gradient for (cached: the
+        plan is rebuilt when a parameter is replaced, PlanCache.get / still_valid)."""
+        cached = getattr(self, "_fields", None)
+        if cached is not None:
+            return cached
         out = []
         for i, layer in enumerate(self.layers):
             kind = layer.glowhip_kind
@@ -277,10 +281,13 @@ class FlowPlan:
             elif kind == _lib.LAYER_SPLIT2D:
                 cz = layer.conv2d_zeros
                 out += [(i, "f4_w", cz.weight), (i, "f4_bias", cz.bias), (i, "f4_logs", cz.logs)]
+        self._fields = out
+        self._trainable = [p for _, _, p in out]
         return out
 
     def trainable_parameters(self):
-        return [p for _, _, p in self._grad_fields()]
+        self._grad_fields()
+        return self._trainable
 
     def glow_forward_train(self, x, noise, prior_mean, prior_logs, prior_stride, n_bits):
         """Forward that records the activation tape; returns (z, nll, tape)."""

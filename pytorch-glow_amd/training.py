@@ -82,11 +82,23 @@ class _HipOptimizer(torch.optim.Optimizer):
         self._ensure_state()
         group0 = self.param_groups[0]
         dev = group0["params"][0].device
-        chunks = []
         for g in self.param_groups:
             if (g["betas"], g["eps"], g["weight_decay"]) != (group0["betas"], group0["eps"], group0["weight_decay"]) or g["lr"] != group0["lr"]:
                 raise _lib.GlowHipError("the HIP optimiser takes one set of hyper-parameters for all parameter groups")
-            for p in g["params"]:
+        # The chunk table holds parameter, gradient and state addresses.  The caching allocator usually hands the gradients the same
+        # addresses again, so the table is keyed by (parameter address, gradient address) of every parameter -- two data_ptr() calls
+        # each -- and rebuilt (with the full checks) only when one of them moved; the state addresses change only with the state
+        # buffers, which resets the key (a reloaded state or a re-allocated parameter must not reuse the table).
+        plist = [p for g in self.param_groups for p in g["params"]]
+        key = tuple((p.data_ptr(), p.grad.data_ptr()) if p.grad is not None else (0, 0) for p in plist)
+        self._steps += 1
+        self._publish_step()
+        norm = torch.zeros(1, device=dev)
+        if getattr(self, "_table_key", None) == key:
+            table, n_chunks = self._keep, self._n_chunks
+        else:
+            chunks = []
+            for p in plist:
                 if p.grad is None:
                     continue
                 gr = p.grad
@@ -96,27 +108,20 @@ class _HipOptimizer(torch.optim.Optimizer):
                 n, base = p.numel(), (p.data_ptr(), gr.data_ptr(), st["exp_avg"].data_ptr(), st[self.SECOND].data_ptr())
                 for o in range(0, n, self.CHUNK):
                     chunks.append((base[0] + 4 * o, base[1] + 4 * o, base[2] + 4 * o, base[3] + 4 * o, min(self.CHUNK, n - o)))
-        self._steps += 1
-        for st in self.state.values():
-            if "step" in st:
-                st["step"] = torch.tensor(float(self._steps))
-        norm = torch.zeros(1, device=dev)
-        if not chunks:
+            n_chunks = len(chunks)
+            if n_chunks:
+                arr = (_lib.OptimChunk * n_chunks)(*[_lib.OptimChunk(*c, 0) for c in chunks])
+                host = torch.frombuffer(bytearray(ctypes.string_at(arr, ctypes.sizeof(arr))), dtype=torch.uint8)
+                table = host.to(dev, non_blocking=False)
+            else:
+                table = None
+            self._table_key, self._n_chunks = key, n_chunks
+        if not n_chunks:
             return norm[0]
-        # the caching allocator usually hands the gradients the same addresses again; the table also holds the parameter and the
-        # two state addresses, so ALL of them key the cache (a reloaded state or a re-allocated parameter must not reuse it)
-        key = hash(tuple(chunks))
-        if getattr(self, "_table_key", None) == (key, len(chunks)):
-            table = self._keep
-        else:
-            arr = (_lib.OptimChunk * len(chunks))(*[_lib.OptimChunk(*c, 0) for c in chunks])
-            host = torch.frombuffer(bytearray(ctypes.string_at(arr, ctypes.sizeof(arr))), dtype=torch.uint8)
-            table = host.to(dev, non_blocking=False)
-            self._table_key = (key, len(chunks))
-        if self._partial is None or self._partial.numel() < len(chunks):
-            self._partial = torch.empty(len(chunks), dtype=torch.float64, device=dev)
+        if self._partial is None or self._partial.numel() < n_chunks:
+            self._partial = torch.empty(n_chunks, dtype=torch.float64, device=dev)
         _lib.check(_lib.lib().glowhip_optim_step(
-            _lib.ptr(table), len(chunks), self.KIND, float(group0["lr"]), float(group0["betas"][0]), float(group0["betas"][1]),
+            _lib.ptr(table), n_chunks, self.KIND, float(group0["lr"]), float(group0["betas"][0]), float(group0["betas"][1]),
             float(group0["eps"]), float(group0["weight_decay"]), self._steps, float(max_grad_clip or 0.0), float(max_grad_norm or 0.0),
             _lib.ptr(self._partial), _lib.ptr(norm), int(bool(skip_nonfinite)), _lib.stream_ptr(dev)))
         self._keep = table      # alive until the stream has consumed it (the next step replaces it)
@@ -131,12 +136,18 @@ class _HipOptimizer(torch.optim.Optimizer):
         self.fused_step(0.0, 0.0)
         return loss
 
+    def _publish_step(self):
+        """`step` of every parameter's state (torch's optimisers keep one tensor per parameter; the value is the same for all of
+        them here, so ONE tensor object is shared -- a thousand torch.tensor() calls per step were 1.5 ms of host time)."""
+        t = torch.tensor(float(self._steps))
+        for st in self.state.values():
+            if "step" in st:
+                st["step"] = t
+
     def undo_step(self):
         """Take back the count of a step the device skipped (fused_step(skip_nonfinite=True) with a non-finite norm)."""
         self._steps = max(self._steps - 1, 0)
-        for st in self.state.values():
-            if "step" in st:
-                st["step"] = torch.tensor(float(self._steps))
+        self._publish_step()
 
 
 class HipAdam(_HipOptimizer):
@@ -212,7 +223,8 @@ class TrainLoop:
             # data-dependent ActNorm init on rank 0's batch, broadcast to the others (trainer.py:112-115)
             self.glow.train()
             parallel.data_dependent_init(self.glow, x_local, rank=self.rank, world=self.world)
-        self.glow.train()
+        if not self.glow.training:      # (nn.Module.train() walks all ~6 400 sub-modules: 4.5 ms of host time when called every step)
+            self.glow.train()
         self.lr = self.scheduler(global_step=self.global_step)
         for group in self.optimizer.param_groups:           # trainer.py:89-91
             group["lr"] = self.lr
