@@ -70,7 +70,10 @@ int launch_wgrad_mfma(const float* A, long a_bs, const float* B, long b_bs, floa
                       double* rowsum = nullptr,    // (f16-pipe kernel) rowsum[m] += sum over all pixels of A's row m -- the bias gradient when A = g_u
                       const WgradTaps* taps = nullptr,
                       struct WgradReduceJob* defer = nullptr,    // non-null: skip the split-K reduction, describe it in *defer instead
-                      int b_valid = 0);   // > 0 (f16-pipe kernel, plain B): only that many rows of B exist, the rest of the column tile is zero
+                      int b_valid = 0,    // > 0 (f16-pipe kernel, plain B): only that many rows of B exist, the rest of the column tile is zero
+                      int b_half = 0);    // 1 (f16-pipe kernel, plain B): B points at an fp16 (N, Npad, H, W) tensor (the taped h1 / h2), b_bs in elements
+// fp16 -> fp32 copy of a taped hidden tensor (the per-layer backward kernels read fp32)
+int launch_half_to_float(const void* src_half, float* dst, long n, hipStream_t s);
 struct WgradReduceJob { const float* partial; float* dw; int splits, Mpad, Npad, Mreal, Nreal, mode; };
 struct WgradReduceJobs { WgradReduceJob job[3]; int n; };
 int launch_wgrad_reduce_batched(const WgradReduceJobs& j, hipStream_t s);

@@ -309,6 +309,25 @@ __global__ void __launch_bounds__(256) k_act_bwd1(float* __restrict__ g, const f
     }
 }
 
+__global__ void __launch_bounds__(256) k_half_to_float(const _Float16* __restrict__ src, float* __restrict__ dst, long n) {
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (i + 8 <= n) {
+        const h8 v = *reinterpret_cast<const h8*>(src + i);
+        f32x4_t a = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]}, b = {(float)v[4], (float)v[5], (float)v[6], (float)v[7]};
+        *reinterpret_cast<f32x4_t*>(dst + i) = a;
+        *reinterpret_cast<f32x4_t*>(dst + i + 4) = b;
+    } else {
+        for (long k = i; k < n; ++k) dst[k] = (float)src[k];
+    }
+}
+
+int launch_half_to_float(const void* src_half, float* dst, long n, hipStream_t s) {
+    if (n <= 0) return GLOWHIP_OK;
+    hipLaunchKernelGGL(k_half_to_float, dim3((unsigned)((n + 2047) / 2048)), dim3(256), 0, s, (const _Float16*)src_half, dst, n);
+    GH_LAUNCH_CHECK("k_half_to_float");
+    return GLOWHIP_OK;
+}
+
 int launch_act_bwd(float* g, const float* h, const float* e, int N, int Cm, int HW, double* acc_b, double* acc_l,
                    hipStream_t s) {
     if (N == 0) return GLOWHIP_OK;

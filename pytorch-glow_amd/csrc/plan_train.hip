@@ -2,7 +2,8 @@
 // sweep that turns dL/dnll into parameter gradients.
 //
 // Tape (one contiguous caller-provided buffer): the output of every layer, and per FlowStep the coupling network's
-// hidden activations h1, h2 (N,hidden,H,W) and its post-scale output hout (N,Cout,H,W); per Split2d the prior
+// hidden activations h1, h2 (N,hidden,H,W) -- fp16 where the taping k_cnet wrote them (tape_has_masks; the slot keeps its fp32
+// size), fp32 from the per-layer kernels -- and its post-scale output hout (N,Cout,H,W); per Split2d the prior
 // conv output.  With 288 GB of HBM keeping them (11.6 GB at B=64 for the celeba64 model) is cheaper than the
 // reversible-recompute alternative (a second forward through the MFMA-bound coupling nets).
 //
@@ -419,11 +420,11 @@ static int backward_sweep(glowhip_plan* p, const void* packed, const float* x_in
                 rj.n = 3;
                 if (vtaps) {
                     { ScopedTimer tw(p, GLOWHIP_K_WGRAD, 1, s); GH_TRY(launch_wgrad_mfma(w.gpre, (long)L.Cout * HW, h2, (long)hid * HW, w.partial, G.f4_w, N, HW, m4, hid,
-                                             L.Cout * 9, hid, 1, s, sh_grad_scale, nullptr, &t4, &rj.job[0])); }
+                                             L.Cout * 9, hid, 1, s, sh_grad_scale, nullptr, &t4, &rj.job[0], 0, 1)); }
                 } else {
                     GH_TRY(launch_shift_expand(w.gpre, (long)L.Cout * HW, w.col, N, L.Cout, d.H, d.W, m4, -1, s));
                     { ScopedTimer tw(p, GLOWHIP_K_WGRAD, 1, s); GH_TRY(launch_wgrad_mfma(w.col, (long)m4 * HW, h2, (long)hid * HW, w.partial, G.f4_w, N, HW, m4, hid,
-                                             L.Cout * 9, hid, 1, s, sh_grad_scale, nullptr, nullptr, &rj.job[0])); }
+                                             L.Cout * 9, hid, 1, s, sh_grad_scale, nullptr, nullptr, &rj.job[0], 0, 1)); }
                 }
                 CnetArgs c{};
                 c.w0 = at<char>(packed, L.cb_w0); c.w2 = at<char>(packed, L.cb_w2); c.w4 = at<char>(packed, L.cb_w4);
@@ -442,7 +443,7 @@ static int backward_sweep(glowhip_plan* p, const void* packed, const float* x_in
                 }
                 // (its finishing step -- g_y1 += the partial sums -- rides in k_chanmix_bwd below)
                 { ScopedTimer tw(p, GLOWHIP_K_WGRAD, 1, s); GH_TRY(launch_wgrad_mfma(w.gh2, (long)hid * HW, h1, (long)hid * HW, w.partial + w.partial_floats, G.f2_w, N, HW, hid, hid,
-                                         hid, hid, 0, s, sh_grad_scale, a2b, nullptr, &rj.job[1])); }
+                                         hid, hid, 0, s, sh_grad_scale, a2b, nullptr, &rj.job[1], 0, 1)); }
                 if (vtaps) {
                     { ScopedTimer tw(p, GLOWHIP_K_WGRAD, 1, s); GH_TRY(launch_wgrad_mfma(w.gh1, (long)hid * HW, out, chw, w.partial + 2 * w.partial_floats, G.f0_w, N, HW, hid, n0,
                                              hid, Ch * 9, 0, s, sh_grad_scale, a0b, &t0, &rj.job[2])); }
@@ -469,6 +470,13 @@ static int backward_sweep(glowhip_plan* p, const void* packed, const float* x_in
                 fin(a4b, G.f4_bias, L.Cout, 0.0, nullptr, 0, MIX_ACC_COPIES, 2 * L.Cout); fin(a4l, G.f4_logs, L.Cout, 0.0, nullptr, 0, MIX_ACC_COPIES, 2 * L.Cout);
                 continue;
             }
+            // The per-layer kernels below read fp32: a tape written by the taping k_cnet holds h1 / h2 as fp16 -- converted into the
+            // partial-sum scratch (unused on this path), h2 first, h1 once h2 has been consumed.
+            const bool half_tape = li < (int)p->tape_has_masks.size() && p->tape_has_masks[li];
+            if (half_tape) {
+                GH_TRY(launch_half_to_float(h2, w.gsh, (long)N * hid * HW, s));
+                h2 = w.gsh;
+            }
             if (fastw) {   // dW4[o][i][tap] = sum_p g_pre[o][p - d(tap)] * h2[i][p]
                 const int m4 = round_up(L.Cout * 9, 128);
                 GH_TRY(launch_shift_expand(w.gpre, (long)L.Cout * HW, w.col, N, L.Cout, d.H, d.W, m4, -1, s));
@@ -485,6 +493,10 @@ static int backward_sweep(glowhip_plan* p, const void* packed, const float* x_in
                 GH_TRY(dgrad_direct(w.gpre, d.f4_w, w.wT, w.gh2, N, hid, d.H, d.W, L.Cout, 3, s));
             }
             GH_TRY(launch_act_bwd(w.gh2, h2, at<float>(packed, L.f2_scale), N, hid, HW, a2b, a2l, s));
+            if (half_tape) {
+                GH_TRY(launch_half_to_float(h1, w.gsh, (long)N * hid * HW, s));
+                h1 = w.gsh;
+            }
             // (c) f.2 (1x1)
             if (fastw) {
                 GH_TRY(launch_wgrad_mfma(w.gh2, (long)hid * HW, h1, (long)hid * HW, w.partial, G.f2_w, N, HW, hid, hid, hid, hid,

@@ -140,8 +140,8 @@ struct CnetArgs {
     // workgroup applies `pre`'s coupling and `pre_mix` to every window pixel (its own and the halo), takes z1 of the result as its
     // f.0 input and writes the result of its OWN pixels to pre_z_new (a buffer other than pre.z: neighbours still read that).
     int pre_on; CnetPending pre; CnetMixer pre_mix; float* pre_z_new; long pre_z_new_bs;
-    // ---- optional: the training tape (plan_train.hip).  k_cnet stores h1 = relu(f.0 ...) and h2 = relu(f.2 ...) as fp32
-    // (N, hidden, H, W) from its epilogues; the finishing kernel stores hout = (f.4 + bias) * exp(3 logs) as (N, Cout, H, W) and,
+    // ---- optional: the training tape (plan_train.hip).  k_cnet stores h1 = relu(f.0 ...) and h2 = relu(f.2 ...) as FP16
+    // (N, hidden, H, W) from its epilogues (the pointers are typed float* for the backward launch, which stores fp32 through them); the finishing kernel stores hout = (f.4 + bias) * exp(3 logs) as (N, Cout, H, W) and,
     // when it mixes out of place (z_out != z_in), ALSO writes the coupled z2 back into z_in -- which then holds this step's
     // output (y1, z2'), the tensor the backward sweep reads.
     float* tape_h1; float* tape_h2; float* tape_hout;

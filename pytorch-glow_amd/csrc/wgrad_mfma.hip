@@ -159,7 +159,10 @@ k_wgrad_gemm(const float* __restrict__ A, long a_bs, const float* __restrict__ B
 // tensor (rows >= 9 vC are zero), gathered by the loader itself (four 4-byte loads per chunk, clamped addresses, selected
 // values) instead of being written out by k_shift_expand and read back (33 + 17 MB per level-1 FlowStep, 17 + 12 us of launches)
 // BV: only b_valid rows of the plain operand B exist (an operand narrower than a column tile); the others are zero
-template <int BN, bool VA = false, bool VB = false, bool BV = false>
+// BH: operand B is an fp16 tensor (the hidden activations h1 / h2 as the taping k_cnet stores them: 2 bytes per value on the tape
+// and in this loader); it goes into LDS as it is -- no lo plane, and the a.hi x b.lo product falls away (two MFMAs per k-step
+// instead of three).  The gradient operand A keeps both planes: it is what needs the range.
+template <int BN, bool VA = false, bool VB = false, bool BV = false, bool BH = false>
 __global__ void __launch_bounds__(256, 2)      // two workgroups per CU: at 269 registers (141 + 128 accumulators) the kernel ran ONE
                                                // wave per SIMD and every k-tile waited out its own HBM round trip (7.4 k cycles per
                                                // k-tile against 768 of MFMA work)
@@ -170,7 +173,8 @@ k_wgrad_gemm_sh(const float* __restrict__ A, long a_bs, const float* __restrict_
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
     constexpr int A_F4 = BM * BK / 4 / 256, B_F4 = BN * BK / 4 / 256;   // float4 per thread per K-tile (4, 4|2)
     __shared__ __attribute__((aligned(16))) _Float16 As[2][2][BK / 8][BM][8];    // [buffer][plane][k group][row][8]
-    __shared__ __attribute__((aligned(16))) _Float16 Bs[2][2][BK / 8][BN][8];
+    __shared__ __attribute__((aligned(16))) _Float16 Bs[2][BH ? 1 : 2][BK / 8][BN][8];
+    static_assert(!BH || (!VB && !BV), "an fp16 operand B is a plain one");
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wr = wid >> 1, wc = wid & 1, kl = lane >> 5, ml = lane & 31;
     // XCD-aware order (8 XCDs with private L2s, block b lands on XCD b % 8): the tiles of ONE pixel slice share their operand
@@ -190,7 +194,8 @@ k_wgrad_gemm_sh(const float* __restrict__ A, long a_bs, const float* __restrict_
     // each, asked the texture-address path for 64 partial lines per instruction: f.2's gradient at level 1 took 166 us for the
     // 67 us of HBM time its operands need.)
     const int l_row = tid >> 3, l_c = tid & 7;
-    f32x4 ra[A_F4], rb[B_F4];
+    f32x4 ra[A_F4], rb[BH ? 1 : B_F4];
+    h4 rbh[BH ? B_F4 : 1];
     // virtual operand: per chunk row (fixed over the k loop) the source offset c * HW + dy * vW + dx, dy, dx; off < 0: a zero row
     constexpr int VN = VA ? A_F4 : (VB ? B_F4 : 1);
     int v_off[VN], v_dy[VN], v_dx[VN];
@@ -229,7 +234,11 @@ k_wgrad_gemm_sh(const float* __restrict__ A, long a_bs, const float* __restrict_
 #pragma unroll
             for (int j = 0; j < A_F4; ++j) ra[j] = *reinterpret_cast<const f32x4*>(ap + (long)j * 32 * HW);
         }
-        if constexpr (VB) {
+        if constexpr (BH) {
+            const _Float16* bp = reinterpret_cast<const _Float16*>(B) + (long)img * b_bs + (long)(tile_n * BN + l_row) * HW + p0 + l_c * 4;
+#pragma unroll
+            for (int j = 0; j < B_F4; ++j) rbh[j] = *reinterpret_cast<const h4*>(bp + (long)j * 32 * HW);
+        } else if constexpr (VB) {
             load_virtual(B, b_bs, img, p0, rb);
         } else {
             if constexpr (BV) {      // rows >= b_valid do not exist in the tensor: loaded from row 0, zeroed
@@ -274,12 +283,17 @@ k_wgrad_gemm_sh(const float* __restrict__ A, long a_bs, const float* __restrict_
             *reinterpret_cast<h4*>(&As[buf][0][l_c >> 1][l_row + 32 * j][(l_c & 1) * 4]) = hi;
             *reinterpret_cast<h4*>(&As[buf][1][l_c >> 1][l_row + 32 * j][(l_c & 1) * 4]) = lo;
         }
+        if constexpr (BH) {
 #pragma unroll
-        for (int j = 0; j < B_F4; ++j) {
-            h4 hi, lo;
-            split4(rb[j], 1.0f, hi, lo);
-            *reinterpret_cast<h4*>(&Bs[buf][0][l_c >> 1][l_row + 32 * j][(l_c & 1) * 4]) = hi;
-            *reinterpret_cast<h4*>(&Bs[buf][1][l_c >> 1][l_row + 32 * j][(l_c & 1) * 4]) = lo;
+            for (int j = 0; j < B_F4; ++j) *reinterpret_cast<h4*>(&Bs[buf][0][l_c >> 1][l_row + 32 * j][(l_c & 1) * 4]) = rbh[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < B_F4; ++j) {
+                h4 hi, lo;
+                split4(rb[j], 1.0f, hi, lo);
+                *reinterpret_cast<h4*>(&Bs[buf][0][l_c >> 1][l_row + 32 * j][(l_c & 1) * 4]) = hi;
+                *reinterpret_cast<h4*>(&Bs[buf][BH ? 0 : 1][l_c >> 1][l_row + 32 * j][(l_c & 1) * 4]) = lo;
+            }
         }
     };
 
@@ -301,7 +315,7 @@ k_wgrad_gemm_sh(const float* __restrict__ A, long a_bs, const float* __restrict_
 #pragma unroll
             for (int ks = 0; ks < BK / 16; ++ks) {
                 const int grp = 2 * ks + kl;
-                h8 ah[TM], al[TM], bh[TN], bl[TN];
+                h8 ah[TM], al[TM], bh[TN], bl[BH ? 1 : TN];
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
                     ah[i] = *reinterpret_cast<const h8*>(&As[buf][0][grp][wr * WM + i * 32 + ml][0]);
@@ -310,16 +324,18 @@ k_wgrad_gemm_sh(const float* __restrict__ A, long a_bs, const float* __restrict_
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     bh[j] = *reinterpret_cast<const h8*>(&Bs[buf][0][grp][wc * WN + j * 32 + ml][0]);
-                    bl[j] = *reinterpret_cast<const h8*>(&Bs[buf][1][grp][wc * WN + j * 32 + ml][0]);
+                    if constexpr (!BH) bl[j] = *reinterpret_cast<const h8*>(&Bs[buf][BH ? 0 : 1][grp][wc * WN + j * 32 + ml][0]);
                 }
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j) accm[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], accm[i][j], 0, 0, 0);
+                if constexpr (!BH) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
+                    for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], accx[i][j], 0, 0, 0);
+                        for (int j = 0; j < TN; ++j) accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], accx[i][j], 0, 0, 0);
+                }
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -416,8 +432,9 @@ size_t wgrad_mfma_partial_floats(int Mpad, int Npad, int N, int HW) {
 
 int launch_wgrad_mfma(const float* A, long a_bs, const float* B, long b_bs, float* partial, float* dw, int N, int HW,
                       int Mpad, int Npad, int Mreal, int Nreal, int mode, hipStream_t s, float sh_scale, double* rowsum,
-                      const WgradTaps* taps, WgradReduceJob* defer, int b_valid) {
+                      const WgradTaps* taps, WgradReduceJob* defer, int b_valid, int b_half) {
     GH_REQUIRE(!rowsum || sh_scale > 0.f, "wgrad_mfma: row sums only on the split-half kernel");
+    GH_REQUIRE(!b_half || (sh_scale > 0.f && b_valid <= 0 && !(taps && taps->operand == 1)), "wgrad_mfma: an fp16 operand B needs the split-half kernel and a plain B");
     GH_REQUIRE(b_valid <= 0 || (sh_scale > 0.f && taps && taps->operand == 0 && Npad == 64), "wgrad_mfma: b_valid only with gathered A and a 64-column B");
     GH_REQUIRE(!taps || (sh_scale > 0.f && taps->H * taps->W == HW && taps->W >= 4 && (taps->W & (taps->W - 1)) == 0 &&
                          (taps->operand == 0 || taps->operand == 1)),
@@ -434,6 +451,14 @@ int launch_wgrad_mfma(const float* A, long a_bs, const float* B, long b_bs, floa
 #define GH_WG(bn, va, vb)                                                                                                      \
     hipLaunchKernelGGL((k_wgrad_gemm_sh<bn, va, vb>), dim3(tiles * splits), dim3(256), 0, s, A, a_bs, B, b_bs, partial, HW, Mpad, \
                        Npad, total, per, sh_scale, rowsum, vC, vH, vW, vs, b_valid > 0 ? b_valid : Npad)
+#define GH_WGH(bn, va)                                                                                                         \
+    hipLaunchKernelGGL((k_wgrad_gemm_sh<bn, va, false, false, true>), dim3(tiles * splits), dim3(256), 0, s, A, a_bs, B, b_bs, partial, \
+                       HW, Mpad, Npad, total, per, sh_scale, rowsum, vC, vH, vW, vs, Npad)
+    if (b_half) {                      // B = h1 / h2 as fp16 from the tape
+        const bool va = taps && taps->operand == 0;
+        if (bn128) { if (va) GH_WGH(128, true); else GH_WGH(128, false); }
+        else { if (va) GH_WGH(64, true); else GH_WGH(64, false); }
+    } else
     if (sh_scale > 0.f && bn128) {     // f16 matrix pipe, split-half operands (sh_scale = power-of-two pre-scale of the gradient operand)
         if (taps && taps->operand == 0) GH_WG(128, true, false);
         else if (taps) GH_WG(128, false, true);
@@ -447,6 +472,7 @@ int launch_wgrad_mfma(const float* A, long a_bs, const float* B, long b_bs, floa
         else GH_WG(64, false, false);
     }
 #undef GH_WG
+#undef GH_WGH
     else if (bn128)
         hipLaunchKernelGGL(k_wgrad_gemm<128>, dim3(tiles * splits), dim3(256), 0, s, A, a_bs, B, b_bs, partial, HW, Mpad, Npad,
                            total, per);

@@ -144,6 +144,14 @@ class _HipOptimizer(torch.optim.Optimizer):
             if "step" in st:
                 st["step"] = t
 
+    def state_dict(self):
+        """torch's optimisers increment `step` IN PLACE per parameter after a load_state_dict: whoever receives this state must get
+        one tensor object per parameter, not the shared one."""
+        for st in self.state.values():
+            if "step" in st:
+                st["step"] = torch.tensor(float(self._steps))
+        return super().state_dict()
+
     def undo_step(self):
         """Take back the count of a step the device skipped (fused_step(skip_nonfinite=True) with a non-finite norm)."""
         self._steps = max(self._steps - 1, 0)
