@@ -1003,14 +1003,14 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
         // own rows: out[c][r][x] = sum over taps whose source row r + dy - 1 lies inside the sub-tile.  One item = one output
         // channel of one pixel; every LDS read is unconditional (the tile's own pixel when the tap falls outside) and SELECTED,
         // so the nine reads of a k part are in flight together.
-        const int items = Cout << g.lpp;
-        for (int e = tid; e < items; e += 512) {
-            const int ce = e >> g.lpp, ql = e & (ppx - 1);
+        // (512 threads are a whole number of passes' pixels: a thread keeps ITS pixel and walks the channels -- the tap geometry is
+        // computed once per thread, not once per item)
+        {
+            const int ql = tid & (ppx - 1);
             const int q = (pass << g.lpp) + ql;
             const int sub = q >> g.lsub, qq = q & submask;
             const int r = qq >> g.wshift, x = qq & (W - 1);
             const long n = n0 + sub;
-            if (n >= a.N) continue;
             int off[9];
             bool ok[9];
 #pragma unroll
@@ -1019,18 +1019,25 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
                 for (int dx = 0; dx < 3; ++dx) {
                     const int tap = dy * 3 + dx;              // out(r, x) += T[tap (dy, dx)][source (r + dy - 1, x + dx - 1)]
                     ok[tap] = r + dy - 1 >= 0 && r + dy - 1 < g.R && x + dx - 1 >= 0 && x + dx - 1 < W;
-                    off[tap] = ((tap * Cout + ce) << g.lpp) + ql + (ok[tap] ? (dy - 1) * W + (dx - 1) : 0);
+                    off[tap] = ((tap * Cout) << g.lpp) + ql + (ok[tap] ? (dy - 1) * W + (dx - 1) : 0);
                 }
-            float sum = 0.f;
-            const float* tp = T;
-            for (int kp = 0; kp < g.KS; ++kp, tp += slab) {   // k parts of the reduction, fixed order
-                float v[9];
+            if (n < a.N) {
+                float* hp = hpart + ((msN + n) * CoutT + c0) * HW + (long)(y0 + r) * W + x;
+                const int cstep = 512 >> g.lpp;
+                for (int ce = tid >> g.lpp; ce < Cout; ce += cstep) {
+                    const int cb = ce << g.lpp;
+                    float sum = 0.f;
+                    const float* tp = T + cb;
+                    for (int kp = 0; kp < g.KS; ++kp, tp += slab) {   // k parts of the reduction, fixed order
+                        float v[9];
 #pragma unroll
-                for (int tap = 0; tap < 9; ++tap) v[tap] = tp[off[tap]];
+                        for (int tap = 0; tap < 9; ++tap) v[tap] = tp[off[tap]];
 #pragma unroll
-                for (int tap = 0; tap < 9; ++tap) sum += ok[tap] ? v[tap] : 0.f;
+                        for (int tap = 0; tap < 9; ++tap) sum += ok[tap] ? v[tap] : 0.f;
+                    }
+                    hp[(long)ce * HW] = sum;
+                }
             }
-            hpart[((msN + n) * CoutT + c0 + ce) * HW + (long)(y0 + r) * W + x] = sum;
         }
         // halo rows (NI = 1 only): what the tile's first row gives to image row y0 - 1, its last row to row y0 + R
         if (g.NI == 1 && g.R < H) {
