@@ -977,8 +977,10 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
             }
     const int slab = g.Mpad4 << g.lpp;                        // floats per k part: every row of the padded image has a slot, so
                                                               // the stores below need no per-row predicate
-#pragma unroll 1
-    for (int pass = 0; pass < g.npass; ++pass) {
+    // T staging of one pass; lpc: log2(pixels per pass) -- a compile-time constant when the tile is staged in one pass (every product
+    // shape), so that the sixteen stores of a tile take immediate offsets from ONE base address instead of sixteen computed ones
+    auto stage_T = [&](int pass, auto lpc) {
+        const int lp = lpc;
 #pragma unroll
         for (int u = 0; u < UPW; ++u) {
             const int unit = wid + 8 * u;
@@ -988,16 +990,22 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
             for (int j = 0; j < 4; ++j) {
                 const int rtile = ru * RTU + j / NPT;
                 if (rtile >= g.NRT4) continue;                              // (wave-uniform) a unit's surplus row tile
-                if ((((j % NPT) * 32) >> g.lpp) != pass) continue;          // (wave-uniform) pixel tile of the other pass
+                if ((((j % NPT) * 32) >> lp) != pass) continue;             // (wave-uniform) pixel tile of the other pass
                 const int q = (j % NPT) * 32 + ml;
-                float* dst = T + kp * slab + ((rtile * 32 + 4 * kl) << g.lpp) + (q - (pass << g.lpp));
+                float* dst = T + kp * slab + ((rtile * 32 + 4 * kl) << lp) + (q - (pass << lp));
 #pragma unroll
                 for (int gq = 0; gq < 4; ++gq)
 #pragma unroll
                     for (int t = 0; t < 4; ++t)
-                        dst[(8 * gq + t) << g.lpp] = accT[u][j][4 * gq + t] * rs4v[u][j / NPT][gq][t];
+                        dst[(8 * gq + t) << lp] = accT[u][j][4 * gq + t] * rs4v[u][j / NPT][gq][t];
             }
         }
+    };
+    constexpr int LPXT = PXT == 128 ? 7 : (PXT == 64 ? 6 : 5);
+#pragma unroll 1
+    for (int pass = 0; pass < g.npass; ++pass) {
+        if (g.npass == 1) stage_T(0, std::integral_constant<int, LPXT>{});
+        else stage_T(pass, g.lpp);
         __syncthreads();
         GH_STAMP(20);
         // own rows: out[c][r][x] = sum over taps whose source row r + dy - 1 lies inside the sub-tile.  One item = one output
