@@ -519,8 +519,13 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
                 }
             };
             if (BPRE) loadB(Bc);
-            auto step1 = [&](int st, const h8 (&use)[2 * RT1], h8 (&fill)[2 * RT1]) {
-                loadA1(hh, min(st + 2, g.steps0 - 1), fill);     // unconditional (clamped): no branch, counted waits
+            // ld: std::true_type in the steady loop (the load is always a real one there: no branch, counted waits), a run-time flag in
+            // the tail -- the last two k-steps have nothing left to request.  (They used to re-request the last set, clamped: the
+            // loads were still in flight when the phase ended and whatever reused their registers next waited a full round trip
+            // for data nobody reads: stamps showed 1.8 k - 4.4 k cycles of it after P3.)
+            auto step1 = [&](int st, const h8 (&use)[2 * RT1], h8 (&fill)[2 * RT1], auto ld) {
+                if constexpr (std::is_same_v<decltype(ld), std::true_type>) loadA1(hh, st + 2, fill);
+                else if (ld) loadA1(hh, st + 2, fill);
 #if CN_SB_P1
                 __builtin_amdgcn_sched_barrier(0);               // (as in P2: keep the request here)
 #endif
@@ -545,15 +550,17 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
             };
             int st = 0;
 #pragma unroll 1
-            for (; st + 3 <= g.steps0; st += 3) {
-                step1(st, A1[0], A1[2]);
-                step1(st + 1, A1[1], A1[0]);
-                step1(st + 2, A1[2], A1[1]);
+            for (; st + 5 <= g.steps0; st += 3) {                // every request of these triples is a real one
+                step1(st, A1[0], A1[2], std::true_type{});
+                step1(st + 1, A1[1], A1[0], std::true_type{});
+                step1(st + 2, A1[2], A1[1], std::true_type{});
             }
-            // the one or two k-steps left over (the reduction is padded to whole k-steps only, not to whole triples: level 1
+            // the two to four k-steps left over (the reduction is padded to whole k-steps only, not to whole triples: level 1
             // has 5 k-steps for its 54 real k values, a sixth would be a sixth of the phase's MFMAs for nothing)
-            if (st < g.steps0) step1(st, A1[0], A1[2]);
-            if (st + 1 < g.steps0) step1(st + 1, A1[1], A1[0]);
+            if (st < g.steps0) step1(st, A1[0], A1[2], st + 2 < g.steps0);
+            if (st + 1 < g.steps0) step1(st + 1, A1[1], A1[0], st + 3 < g.steps0);
+            if (st + 2 < g.steps0) step1(st + 2, A1[2], A1[1], st + 4 < g.steps0);
+            if (st + 3 < g.steps0) step1(st + 3, A1[0], A1[2], false);
             // A sets of the next P1 pass (next pixel sub-pass of this channel pass, or the next channel pass): in flight during
             // the epilogue, the barrier and P2
             {
@@ -670,7 +677,8 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
                 h8 (&use)[2 * RT2] = A2[ADEPTH == 2 ? s % 3 : s & 1];
                 h8 (&fill)[2 * RT2] = A2[ADEPTH == 2 ? (s + 2) % 3 : (s + 1) & 1];
                 h8 (&bh)[PT2] = bhq[s & 1];
-                loadA2(ks0 + min(s + ADEPTH, NS - 1), fill);     // unconditional (clamped)
+                if (s + ADEPTH < NS) loadA2(ks0 + s + ADEPTH, fill);      // (s is a compile-time constant: no branch; the last ADEPTH
+                                                                          //  k-steps have nothing left to request)
                 // the scheduler must not sink these loads towards their use two k-steps later (it does, to save registers, and
                 // the wave then waits a full L2 round trip per k-step: measured 57% of the MFMA rate for a wave on its own)
                 __builtin_amdgcn_sched_barrier(0);
@@ -888,8 +896,9 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
 #pragma unroll
                 for (int jj = 0; jj < NPT; ++jj) bhn[jj] = *reinterpret_cast<const h8*>(bp + jj * 256);
             }
-            auto step4 = [&](int st, const h8 (&use)[2 * RTU], h8 (&fill)[2 * RTU]) {
-                loadA4(ap, ru, min(st + 2, nsl - 1), fill);      // unconditional (clamped)
+            auto step4 = [&](int st, const h8 (&use)[2 * RTU], h8 (&fill)[2 * RTU], auto ld) {      // ld: as in P1
+                if constexpr (std::is_same_v<decltype(ld), std::true_type>) loadA4(ap, ru, st + 2, fill);
+                else if (ld) loadA4(ap, ru, st + 2, fill);
 #if CN_SB_P3
                 __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -930,13 +939,15 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
             };
             int st = 0;
 #pragma unroll 1
-            for (; st + 3 <= nsl; st += 3) {
-                step4(st, A4[0], A4[2]);
-                step4(st + 1, A4[1], A4[0]);
-                step4(st + 2, A4[2], A4[1]);
+            for (; st + 5 <= nsl; st += 3) {
+                step4(st, A4[0], A4[2], std::true_type{});
+                step4(st + 1, A4[1], A4[0], std::true_type{});
+                step4(st + 2, A4[2], A4[1], std::true_type{});
             }
-            if (st < nsl) step4(st, A4[0], A4[2]);
-            if (st + 1 < nsl) step4(st + 1, A4[1], A4[0]);
+            if (st < nsl) step4(st, A4[0], A4[2], st + 2 < nsl);
+            if (st + 1 < nsl) step4(st + 1, A4[1], A4[0], st + 3 < nsl);
+            if (st + 2 < nsl) step4(st + 2, A4[2], A4[1], st + 4 < nsl);
+            if (st + 3 < nsl) step4(st + 3, A4[0], A4[2], false);
             // first two A sets of the wave's next (unit, load)
             {
                 int nu = unit + 8, nl = l;
@@ -966,15 +977,15 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
     // row scales of this wave's T rows, fetched before the loop (one LDS round trip instead of one per group of four rows)
     f32x4_t rs4v[UPW][RTU][4];
 #pragma unroll
-    for (int u = 0; u < UPW; ++u)
+    for (int u = 0; u < UPW; ++u) {
+        const int unit = wid + 8 * u;
+        const int ru = unit < nunits ? unit % g.NU4 : 0;      // (once per unit: as an expression below it was re-derived per element)
 #pragma unroll
         for (int i = 0; i < RTU; ++i)
 #pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                const int unit = wid + 8 * u;
-                const int ru = unit < nunits ? unit % g.NU4 : 0;
+            for (int gq = 0; gq < 4; ++gq)
                 rs4v[u][i][gq] = *reinterpret_cast<const f32x4_t*>(t_rs4 + min(ru * RTU + i, g.NRT4 - 1) * 32 + 8 * gq + 4 * kl);
-            }
+    }
     const int slab = g.Mpad4 << g.lpp;                        // floats per k part: every row of the padded image has a slot, so
                                                               // the stores below need no per-row predicate
     // T staging of one pass; lpc: log2(pixels per pass) -- a compile-time constant when the tile is staged in one pass (every product
@@ -1004,8 +1015,10 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
     constexpr int LPXT = PXT == 128 ? 7 : (PXT == 64 ? 6 : 5);
 #pragma unroll 1
     for (int pass = 0; pass < g.npass; ++pass) {
+        GH_STAMP(28);
         if (g.npass == 1) stage_T(0, std::integral_constant<int, LPXT>{});
         else stage_T(pass, g.lpp);
+        GH_STAMP(29);
         __syncthreads();
         GH_STAMP(20);
         // own rows: out[c][r][x] = sum over taps whose source row r + dy - 1 lies inside the sub-tile.  One item = one output

@@ -24,7 +24,7 @@ G.lib().glowhip_debug_read_stamps_all_cnet(buf)
 t = [list(buf[w * 64:(w + 1) * 64]) for w in range(8)]
 names = {0: "start", 26: "tables+first loads", 1: "window built", 2: "P1a done", 3: "barrier", 4: "P2a (+P1b first MFMAs) done", 5: "barrier", 6: "P1b done",
          7: "barrier", 8: "P2b done", 9: "barrier", 10: "h2 epilogue", 27: "T accumulators zeroed", 11: "h2 load0 written", 12: "barrier", 13: "P3 load0 done",
-         14: "barrier", 15: "h2 load1 written", 16: "barrier", 17: "P3 load1 done", 18: "barrier", 20: "T staged", 21: "end"}
+         14: "barrier", 15: "h2 load1 written", 16: "barrier", 17: "P3 load1 done", 18: "barrier", 28: "rs4 fetched", 29: "T stores issued", 20: "T staged", 21: "end"}
 t0 = min(t[w][0] for w in range(8))
 print("wave:      " + " ".join(f"{w:7d}" for w in range(8)))
 print("SIMD/slot: " + " ".join(f"  {(t[w][63] >> 4) & 3}/{t[w][63] & 15:<3d}" for w in range(8)))
