@@ -45,6 +45,7 @@ struct CnetGeo {
     int HW, lhw;      // pixels per image and its log2
     int lpp;          // log2(pixels per staging pass)
     int pxt, lpxt;    // pixels per workgroup tile (128 or 64) and its log2
+    unsigned m_nwin, m_Wpx, m_WP;     // ceil(2^32 / d) of the window's three divisors: n / d = umulhi(n, m) for the slot indices (< 2^16)
     int ng, Cg;       // f.4 in ng groups of Cg output channels (Mpad4, NRT4, NU4, KS, npass describe ONE group): wide steps
                       // (C = 96: Cout = 96 = 2 x 48) run P3 + P4 once per group, h2 handed over again from the registers
 };
@@ -229,10 +230,11 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
     // window slot e -> (inside the image?, address of its first channel); the address is always valid (clamped)
     int slot_r, slot_c, slot_sub;      // window row / column / sub-image of the slot slot_src was last asked about
     auto slot_src = [&](int e, bool& in, int& ch) {
-        ch = e / nwin;
+        // (three divisions by run-time constants, on the way to the kernel's FIRST loads: one v_mul_hi each instead of ~25 instructions)
+        ch = (int)__umulhi((unsigned)e, g.m_nwin);
         const int rem = e - ch * nwin;
-        const int sub = rem / g.Wpx, wp = rem - sub * g.Wpx;
-        const int r = wp / g.WP, c = wp - r * g.WP;
+        const int sub = (int)__umulhi((unsigned)rem, g.m_Wpx), wp = rem - sub * g.Wpx;
+        const int r = (int)__umulhi((unsigned)wp, g.m_WP), c = wp - r * g.WP;
         slot_r = r; slot_c = c; slot_sub = sub;
         const int yy = y0 - 1 + r, xx = c - 1;
         const long n = n0 + sub;
@@ -1314,6 +1316,9 @@ static bool cnet_geo(int Cin, int H, int W, int hidden, int Cout, int N, int pxt
     g.npass = (size_t)pxt * 9 * Cout * g.KS * sizeof(float) > (size_t)CN_HBUF ? 2 : 1;     // T staging [k part][9 Cout][pixels] fp32
     if (g.npass == 2 && (g.NI != 2 || (size_t)(pxt / 2) * 9 * Cout * g.KS * sizeof(float) > (size_t)CN_HBUF)) return false;
     g.winplane = g.nchunk * g.NI * g.Wpx * 8;
+    auto magic = [](unsigned d) { return (unsigned)((0x100000000ull + d - 1) / d); };      // exact quotients for numerators < 2^16
+    g.m_nwin = magic((unsigned)(g.NI * g.Wpx)); g.m_Wpx = magic((unsigned)g.Wpx); g.m_WP = magic((unsigned)g.WP);
+    if ((long)g.nchunk * g.NI * g.Wpx >= 65536) return false;
     g.lpp = g.lpxt - (g.npass - 1);
     if (cnet_lds_bytes(g, hidden) > 160 * 1024) return false;
     g.tiles = N > 0 ? (int)(((long)N * HW + pxt - 1) / pxt) : 0;
