@@ -219,10 +219,9 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
     loadA1(0, 0, A1[0]);
     loadA1(0, g.steps0 > 1 ? 1 : 0, A1[1]);
     constexpr bool A2_LATE = TP2 == 8;    // 128 accumulator registers live across P1: P2's first A sets are requested after P1
-    if (!A2_LATE) {
-        loadA2(0, A2[0]);
-        loadA2(1, A2[1]);
-    }
+    // (otherwise right after the window is built -- not here: 256 workgroups asking for 64 KB of f.2 weights each in the same
+    // instant as their windows stretched the kernel's first trip to memory from 4.8 k to 6.7 k cycles at level 2, and P2 is
+    // a whole P1 away)
 
     // ---- P0: tables, then the window -> (hi, lo) halves in LDS; slot e = (chunk, sub-tile, window pixel), 8 channels each
     const int nwin = g.NI * g.Wpx;
@@ -460,6 +459,10 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
     }
     __syncthreads();
     GH_STAMP(1);
+    if (!A2_LATE) {
+        loadA2(0, A2[0]);
+        loadA2(1, A2[1]);
+    }
 
     // window offset (halfs) of tile pixel q for tap (0,0), chunk 0
     auto pix_base = [&](int q) {
