@@ -303,9 +303,28 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
     // accumulators hold the negated sums.  So the tables carry the signs: f.0 (-rs0, -b0) turns the true accumulator into -t;
     // f.2 (rs2, -b2) turns the negated accumulator into -t; f.4's row scale -rs4 turns the negated T back.  canon_nan: a NaN
     // from memory gets the sign bit the hardware's own NaNs have.
-    for (int e = tid; e < 2 * HID; e += 512) t_rs0[e] = canon_nan(-rs0[e]);                   // rs0 | b0 are adjacent in the image
-    for (int e = tid; e < MR; e += 512) { t_rs2[e] = canon_nan(rs2[ms_row0 + e]); t_b2[e] = canon_nan(-rs2[HID + ms_row0 + e]); }
-    for (int e = tid; e < g.Mpad4; e += 512) t_rs4[e] = canon_nan(-rs4[e]);      // (group 0; the others are loaded in the group loop)
+    // ALL table values are requested here, in the same round as the window values and the first A sets, from clamped addresses, and
+    // stored afterwards: as three copy loops every iteration was a round trip of its own (load, s_waitcnt vmcnt(0) -- which also
+    // waited for everything requested before -- store): four to five serialised trips to L2 in front of the window, 4.8 k - 6.7 k
+    // cycles by the stamps.
+    constexpr int N0 = (2 * HID + 511) / 512, N2 = (MR + 511) / 512;
+    float tv0[N0], tv2[N2], tvb[N2], tv4;
+#pragma unroll
+    for (int i = 0; i < N0; ++i) tv0[i] = rs0[min(tid + 512 * i, 2 * HID - 1)];                  // rs0 | b0 are adjacent in the image
+#pragma unroll
+    for (int i = 0; i < N2; ++i) {
+        const int e = min(tid + 512 * i, MR - 1);
+        tv2[i] = rs2[ms_row0 + e]; tvb[i] = rs2[HID + ms_row0 + e];
+    }
+    tv4 = rs4[min(tid, g.Mpad4 - 1)];             // (Mpad4 <= 512; group 0: the others are loaded in the group loop)
+    __builtin_amdgcn_sched_barrier(0);            // (hipcc sinks the last request behind the first store otherwise: one more trip)
+#pragma unroll
+    for (int i = 0; i < N0; ++i)
+        if (tid + 512 * i < 2 * HID) t_rs0[tid + 512 * i] = canon_nan(-tv0[i]);
+#pragma unroll
+    for (int i = 0; i < N2; ++i)
+        if (tid + 512 * i < MR) { t_rs2[tid + 512 * i] = canon_nan(tv2[i]); t_b2[tid + 512 * i] = canon_nan(-tvb[i]); }
+    if (tid < g.Mpad4) t_rs4[tid] = canon_nan(-tv4);
     float* nz = nullptr;     // with `pre`: z1 of the freshly finished state, fp32 [Cin][KP]
     if (pre_on) {
         // ---- finish the PREVIOUS step on the window pixels: coupling (+ log-det for the tile's own pixels), then the channel mixer;
