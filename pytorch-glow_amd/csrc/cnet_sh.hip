@@ -1167,9 +1167,10 @@ __global__ void __launch_bounds__(256) k_cfinish(CfinArgs a) {
     constexpr int MREG = 10;                     // C <= 48: 2304 / 256 = 9 values per thread; wider mixers use the loop below
     float mreg[MREG];
     const bool mfast = a.mix.C && a.mix.matrix && C * C <= MREG * 256;
-    if (mfast) {
+    if (mfast) {      // unconditional, from clamped addresses (a lane-predicated load is a branch: hipcc then waited for ALL of these
+                      // before it issued the first load of the round below -- two trips to memory instead of one)
 #pragma unroll
-        for (int k = 0; k < MREG; ++k) mreg[k] = tid + 256 * k < C * C ? a.mix.matrix[tid + 256 * k] : 0.f;
+        for (int k = 0; k < MREG; ++k) mreg[k] = a.mix.matrix[min(tid + 256 * k, C * C - 1)];
     }
     const float* zi = a.p.z + n * a.p.z_bs;
     float* zn = a.z_out + n * a.z_out_bs;
@@ -1179,7 +1180,9 @@ __global__ void __launch_bounds__(256) k_cfinish(CfinArgs a) {
     constexpr int U = PXB == 256 ? 6 : 2;
     const int total = Ch * PXB;
     const bool an = a.mix.C && !a.mix.reverse;
-    for (int e0 = tid; e0 < total; e0 += 256 * U) {
+    // The first round is peeled: as the first trip of a loop its loads were issued only after everything requested in front of the
+    // loop had arrived (the wait-count pass merges the loop's own back edge into the header: `s_waitcnt vmcnt(0)` at its top).
+    auto round = [&](int e0) {
         float se[U], so[U], zin[U], z1v[U], kb[U][4], km[U][4];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -1221,13 +1224,22 @@ __global__ void __launch_bounds__(256) k_cfinish(CfinArgs a) {
                 if (zn != zi) zn[(long)c * HW + p] = z1v[u];       // out of place: z1 travels along
             }
         }
-    }
+    };
+    round(tid);
+    for (int e0 = tid + 256 * U; e0 < total; e0 += 256 * U) round(e0);
     if (mfast) {
 #pragma unroll
         for (int k = 0; k < MREG; ++k)
             if (tid + 256 * k < C * C) mixm[tid + 256 * k] = mreg[k];
-    } else if (a.mix.C && a.mix.matrix) {
-        for (int e = tid; e < C * C; e += 256) mixm[e] = a.mix.matrix[e];
+    } else if (a.mix.C && a.mix.matrix) {      // wider mixers: eight requests in flight per trip (as a plain copy loop every element was a trip)
+        for (int e0 = tid; e0 < C * C; e0 += 256 * 8) {
+            float mv[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) mv[k] = a.mix.matrix[min(e0 + 256 * k, C * C - 1)];
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (e0 + 256 * k < C * C) mixm[e0 + 256 * k] = mv[k];
+        }
     }
     if (f.paired) {     // per-sample log-det: ONE atomic per workgroup (64 workgroups and more share a sample's accumulator: per-wave
                         // atomics queued up behind one another and doubled the launch time), issued before the mixer phase,

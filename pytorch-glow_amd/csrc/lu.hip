@@ -13,6 +13,18 @@ size_t invconv_scratch_bytes(int C) { return (size_t)C * 2 * C * sizeof(double);
 constexpr int LU_LDS_MAX_C = 64;  // 64 * 128 * 8 B = 64 KiB
 constexpr int LU_LDS_ONLY_MAX_C = 128;   // log-det only: 128 * 128 * 8 B = 128 KiB
 
+// matrix -> fp64 working copy, eight requests in flight per trip (a plain copy loop waits out one memory round trip per element)
+__device__ __forceinline__ void lu_load_matrix(const float* __restrict__ w, int n, double* A) {
+    for (int e0 = threadIdx.x; e0 < n; e0 += 256 * 8) {
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = w[min(e0 + 256 * k, n - 1)];
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (e0 + 256 * k < n) A[e0 + 256 * k] = (double)v[k];
+    }
+}
+
 // Workgroup-wide Gauss-Jordan on A = [W | I] (C x 2C doubles, LDS or global).  Returns log|det W| (thread 192).
 // Three barriers per pivot: (1) pivot row and value published by wave 0; (2) rows k and p swapped with the pivot row scaled
 // on the way (two rows, one pass); (3) column k eliminated from every other row.  Column k of the left half is never read
@@ -23,12 +35,21 @@ __device__ double lu_gauss_jordan(const float* __restrict__ w, int C, float* __r
     const int tid = threadIdx.x, W2 = 2 * C;
     __syncthreads();  // A may still be read by a previous use in this workgroup
     {
-        int r = tid / W2, c = tid - r * W2;
-        const int dr = 256 / W2, dc = 256 - dr * W2;
-        for (int e = tid; e < C * W2; e += 256) {
-            A[e] = (c < C) ? (double)w[r * C + c] : ((c - C == r) ? 1.0 : 0.0);
-            r += dr; c += dc;
-            if (c >= W2) { c -= W2; ++r; }
+        // [W | I]: the W half eight requests at a time (clamped addresses, selected values)
+        for (int e0 = tid; e0 < C * W2; e0 += 256 * 8) {
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int e = min(e0 + 256 * k, C * W2 - 1), r = e / W2, c = e - r * W2;
+                v[k] = w[r * C + min(c, C - 1)];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int e = e0 + 256 * k;
+                if (e >= C * W2) continue;
+                const int r = e / W2, c = e - r * W2;
+                A[e] = (c < C) ? (double)v[k] : ((c - C == r) ? 1.0 : 0.0);
+            }
         }
     }
     double logdet = 0.0;   // meaningful in thread 192
@@ -93,7 +114,7 @@ __device__ double lu_logdet_only(const float* __restrict__ w, int C, double* A) 
     __shared__ double s_pivval2;
     const int tid = threadIdx.x;
     __syncthreads();
-    for (int e = tid; e < C * C; e += 256) A[e] = (double)w[e];
+    lu_load_matrix(w, C * C, A);
     double logdet = 0.0;   // meaningful in thread 192
     __syncthreads();
     for (int k = 0; k < C; ++k) {
@@ -171,7 +192,7 @@ __device__ double lu_logdet_blocked(const float* __restrict__ w, int C, double* 
     __shared__ double s_pv;
     const int tid = threadIdx.x;
     __syncthreads();
-    for (int e = tid; e < C * C; e += 256) A[e] = (double)w[e];
+    lu_load_matrix(w, C * C, A);
     double logdet = 0.0;   // meaningful in thread 192
     __syncthreads();
     for (int k0 = 0; k0 < C; k0 += NB) {

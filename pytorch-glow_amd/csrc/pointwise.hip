@@ -320,17 +320,37 @@ __global__ void __launch_bounds__(256) k_chanmix(ChanMixArgs a, int stage_matrix
             v[c * PX + px] = xv;
         }
     } else
-    for (int c = og; c < C; c += OG) {
-        float xv = 0.f;
-        if (valid) xv = (c < a.Ca) ? pa[(long)c * a.HW] : pb[(long)(c - a.Ca) * a.HW];
-        if (!a.reverse && an) xv = (xv + a.bias[c]) * a.scale[c];
-        v[c * PX + px] = xv;
+    // four channels per trip, every load of a trip issued (from clamped, always valid addresses) before the first value is used
+    for (int c0 = og; c0 < C; c0 += 4 * OG) {
+        float xv[4], bb[4], sc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = min(c0 + u * OG, C - 1);
+            xv[u] = (c < a.Ca) ? pa[(long)c * a.HW] : pb[(long)(c - a.Ca) * a.HW];
+            bb[u] = (!a.reverse && an) ? a.bias[c] : 0.f;
+            sc[u] = (!a.reverse && an) ? a.scale[c] : 1.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = c0 + u * OG;
+            if (c >= C) continue;
+            float x = valid ? xv[u] : 0.f;
+            if (!a.reverse && an) x = (x + bb[u]) * sc[u];
+            v[c * PX + px] = x;
+        }
     }
     // the matrix goes through LDS as well (one coalesced pass): read from global inside the FMA loop, its C*C dependent
-    // loads were the whole run time of this kernel at the deep levels
+    // loads were the whole run time of this kernel at the deep levels.  Eight requests in flight per trip.
     float* mlds = v + C * PX;
     if (a.matrix && stage_matrix)
-        for (int e = threadIdx.x; e < C * C; e += 256) mlds[e] = a.matrix[e];
+        for (int e0 = threadIdx.x; e0 < C * C; e0 += 256 * 8) {
+            float mv[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) mv[k] = a.matrix[min(e0 + 256 * k, C * C - 1)];
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (e0 + 256 * k < C * C) mlds[e0 + 256 * k] = mv[k];
+        }
     __syncthreads();
     const int per = (C + OG - 1) / OG;
     const int o_begin = og * per, o_end = min(C, o_begin + per);
