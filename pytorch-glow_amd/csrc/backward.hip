@@ -309,21 +309,26 @@ __global__ void __launch_bounds__(256) k_act_bwd1(float* __restrict__ g, const f
     }
 }
 
-__global__ void __launch_bounds__(256) k_half_to_float(const _Float16* __restrict__ src, float* __restrict__ dst, long n) {
-    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 8;
-    if (i + 8 <= n) {
-        const h8 v = *reinterpret_cast<const h8*>(src + i);
-        f32x4_t a = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]}, b = {(float)v[4], (float)v[5], (float)v[6], (float)v[7]};
-        *reinterpret_cast<f32x4_t*>(dst + i) = a;
-        *reinterpret_cast<f32x4_t*>(dst + i + 4) = b;
-    } else {
-        for (long k = i; k < n; ++k) dst[k] = (float)src[k];
-    }
+// The hidden activations as the taping k_cnet stores them -- fp16, pixel-tile-major [pixel / 32][R][pixel % 32] over the batch's
+// N * HW pixels (sh.h) -- as the fp32 (N, R, HW) tensor the per-layer backward kernels read.  HW % 32 == 0.
+__global__ void __launch_bounds__(256) k_half_to_float(const _Float16* __restrict__ src, float* __restrict__ dst, long n, int R, int HW) {
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 8;       // 8 consecutive pixels of one row of one pixel tile
+    if (i >= n) return;
+    const h8 v = *reinterpret_cast<const h8*>(src + i);
+    const long tr = i >> 5;                                           // tile * R + row
+    const long tile = tr / R, row = tr - tile * R, pix = tile * 32 + (i & 31);
+    const long img = pix / HW, p = pix - img * HW;
+    float* d = dst + (img * R + row) * HW + p;
+    const f32x4_t a = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]}, b = {(float)v[4], (float)v[5], (float)v[6], (float)v[7]};
+    *reinterpret_cast<f32x4_t*>(d) = a;
+    *reinterpret_cast<f32x4_t*>(d + 4) = b;
 }
 
-int launch_half_to_float(const void* src_half, float* dst, long n, hipStream_t s) {
+int launch_half_to_float(const void* src_half, float* dst, int N, int R, int HW, hipStream_t s) {
+    const long n = (long)N * R * HW;
     if (n <= 0) return GLOWHIP_OK;
-    hipLaunchKernelGGL(k_half_to_float, dim3((unsigned)((n + 2047) / 2048)), dim3(256), 0, s, (const _Float16*)src_half, dst, n);
+    if (HW % 32 != 0) return GLOWHIP_EINVAL;
+    hipLaunchKernelGGL(k_half_to_float, dim3((unsigned)((n + 2047) / 2048)), dim3(256), 0, s, (const _Float16*)src_half, dst, n, R, HW);
     GH_LAUNCH_CHECK("k_half_to_float");
     return GLOWHIP_OK;
 }

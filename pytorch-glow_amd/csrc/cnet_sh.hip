@@ -106,7 +106,10 @@ __device__ __forceinline__ long long block_sum_ll(long long v, long long* red) {
 // PRE: the launch may finish the previous step while it builds its window (a.pre_on); without it none of that code is compiled in
 // NG: f.4 output-channel groups (compile time: with one group nothing of the group loop survives -- as a run-time count it kept
 // the h2 accumulators alive through P4 and cost the level-1 instance 88 bytes of spills)
-// MODE 1 (TAPE), the training forward (plan_train.hip): h1 and h2 also go to memory as FP16 (N, hidden, H, W) -- what the
+// MODE 1 (TAPE), the training forward (plan_train.hip): h1 and h2 also go to memory as FP16, pixel-tile-major
+// [pixel / 32][hidden][pixel % 32] over the batch's pixels (sh.h "T32": the 8 rows x 32 pixels a wave stores are one contiguous
+// 512-byte block, and a weight-gradient GEMM's 128-row x 32-pixel operand panel is one contiguous block instead of 128 runs
+// 2 - 4 KB apart) -- what the
 // weight-gradient GEMMs read as their B operand (wgrad_mfma.hip BH: 2 bytes per value on the tape and in their loaders; the
 // gradient operand keeps both planes) -- stored from the
 // epilogues (a lane holds one pixel x 4 consecutive channels: a wave store is two 64-byte runs of one channel each), and their
@@ -115,7 +118,7 @@ __device__ __forceinline__ long long block_sum_ll(long long v, long long* red) {
 // MODE 2 (BWD), the input-gradient chain of the same network (it has the same shape: 3x3 Cout -> hidden with f.4's transposed
 // weights, 1x1 hidden -> hidden with f.2's, 3x3 hidden -> C/2 with f.0's): x = d L / d(f.4 output), the "activation" of the
 // first two layers is  g_u = g_h * (h > 0) * exp(3 logs)  (the scale folded into the weight image's rows, the mask from the
-// tape's bit masks), and g_u2 / g_u0 go to memory as fp32 for the weight-gradient GEMMs.  Needs HW % 32 == 0.
+// tape's bit masks), and g_u2 / g_u0 go to memory as fp32, pixel-tile-major like the tape, for the weight-gradient GEMMs.  Needs HW % 32 == 0.
 template <int HID, int MS, int UPW, int PXT, bool PRE, int NG = 1, int MODE = 0>
 __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
     constexpr bool TAPE = MODE == 1, BWD = MODE == 2, STORE = MODE != 0;
@@ -624,15 +627,15 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
                 if (F32ST) {     // (with a row split every workgroup computes all of these rows: each stores its own rows' share)
                     const long px0 = gp0 + (pt1 + sp * PTSV + j) * 32;
                     if (px0 < P_all && (MS == 1 || (o >= ms_row0 && o < ms_row0 + MR))) {
-                        const long tb_off = (((px0 >> g.lhw) * HID) << g.lhw) + (px0 & (HW - 1));
+                        const long tb_off = (px0 >> 5) * (HID * 32);     // pixel-tile-major: [pixel / 32][row][pixel % 32] (sh.h)
                         if (TAPE) {      // h1 as fp16
                             _Float16* tb = reinterpret_cast<_Float16*>(a.tape_h1) + tb_off;
 #pragma unroll
-                            for (int t = 0; t < 4; ++t) tb[((o + t) << g.lhw) + ml] = (_Float16)(-v[t] * a.out_scale);
+                            for (int t = 0; t < 4; ++t) tb[((o + t) << 5) + ml] = (_Float16)(-v[t] * a.out_scale);
                         } else {         // g_u2 as fp32
                             float* tb = a.tape_h1 + tb_off;
 #pragma unroll
-                            for (int t = 0; t < 4; ++t) __builtin_nontemporal_store(-v[t] * a.out_scale, tb + ((o + t) << g.lhw) + ml);
+                            for (int t = 0; t < 4; ++t) __builtin_nontemporal_store(-v[t] * a.out_scale, tb + ((o + t) << 5) + ml);
                         }
                     }
                 }
@@ -806,16 +809,16 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
         if (F32ST) {
             const long px0 = gp0 + (pt2 + j) * 32;
             if (px0 < P_all) {
-                const long tb_off = (((px0 >> g.lhw) * HID) << g.lhw) + (px0 & (HW - 1));
+                const long tb_off = (px0 >> 5) * (HID * 32);
                 if (TAPE) {
                     _Float16* tb = reinterpret_cast<_Float16*>(a.tape_h2) + tb_off;
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) tb[((ms_row0 + o + t) << g.lhw) + ml] = (_Float16)(-acc2[i][j][4 * gq + t] * a.out_scale);
+                    for (int t = 0; t < 4; ++t) tb[((ms_row0 + o + t) << 5) + ml] = (_Float16)(-acc2[i][j][4 * gq + t] * a.out_scale);
                 } else {
                     float* tb = a.tape_h2 + tb_off;
 #pragma unroll
                     for (int t = 0; t < 4; ++t)
-                        __builtin_nontemporal_store(-acc2[i][j][4 * gq + t] * a.out_scale, tb + ((ms_row0 + o + t) << g.lhw) + ml);
+                        __builtin_nontemporal_store(-acc2[i][j][4 * gq + t] * a.out_scale, tb + ((ms_row0 + o + t) << 5) + ml);
                 }
             }
         }

@@ -420,11 +420,11 @@ static int backward_sweep(glowhip_plan* p, const void* packed, const float* x_in
                 rj.n = 3;
                 if (vtaps) {
                     { ScopedTimer tw(p, GLOWHIP_K_WGRAD, 1, s); GH_TRY(launch_wgrad_mfma(w.gpre, (long)L.Cout * HW, h2, (long)hid * HW, w.partial, G.f4_w, N, HW, m4, hid,
-                                             L.Cout * 9, hid, 1, s, sh_grad_scale, nullptr, &t4, &rj.job[0], 0, 1)); }
+                                             L.Cout * 9, hid, 1, s, sh_grad_scale, nullptr, &t4, &rj.job[0], 0, 1, 2)); }
                 } else {
                     GH_TRY(launch_shift_expand(w.gpre, (long)L.Cout * HW, w.col, N, L.Cout, d.H, d.W, m4, -1, s));
                     { ScopedTimer tw(p, GLOWHIP_K_WGRAD, 1, s); GH_TRY(launch_wgrad_mfma(w.col, (long)m4 * HW, h2, (long)hid * HW, w.partial, G.f4_w, N, HW, m4, hid,
-                                             L.Cout * 9, hid, 1, s, sh_grad_scale, nullptr, nullptr, &rj.job[0], 0, 1)); }
+                                             L.Cout * 9, hid, 1, s, sh_grad_scale, nullptr, nullptr, &rj.job[0], 0, 1, 2)); }
                 }
                 CnetArgs c{};
                 c.w0 = at<char>(packed, L.cb_w0); c.w2 = at<char>(packed, L.cb_w2); c.w4 = at<char>(packed, L.cb_w4);
@@ -434,7 +434,7 @@ static int backward_sweep(glowhip_plan* p, const void* packed, const float* x_in
                 c.tape_h1 = w.gh2; c.tape_h2 = w.gh1;
                 c.mask1 = const_cast<unsigned short*>(at<unsigned short>(tape, tl[li].m1));
                 c.mask2 = const_cast<unsigned short*>(at<unsigned short>(tape, tl[li].m2));
-                c.in_scale = SH2_ACT_SCALE * sh_grad_scale; c.out_scale = 1.0f / c.in_scale; c.bwd = 1;
+                c.in_scale = SH2_ACT_SCALE * sh_grad_scale; c.out_scale = SH2_ACT_INV; c.bwd = 1;      // (g_u2 / g_u0 are stored times sh_grad_scale: what the weight-gradient GEMMs split)
                 CnetPending pend{};
                 count_launch(p, "k_cnet(bwd)");
                 {
@@ -443,14 +443,14 @@ static int backward_sweep(glowhip_plan* p, const void* packed, const float* x_in
                 }
                 // (its finishing step -- g_y1 += the partial sums -- rides in k_chanmix_bwd below)
                 { ScopedTimer tw(p, GLOWHIP_K_WGRAD, 1, s); GH_TRY(launch_wgrad_mfma(w.gh2, (long)hid * HW, h1, (long)hid * HW, w.partial + w.partial_floats, G.f2_w, N, HW, hid, hid,
-                                         hid, hid, 0, s, sh_grad_scale, a2b, nullptr, &rj.job[1], 0, 1)); }
+                                         hid, hid, 0, s, sh_grad_scale, a2b, nullptr, &rj.job[1], 0, 1, 7)); }
                 if (vtaps) {
                     { ScopedTimer tw(p, GLOWHIP_K_WGRAD, 1, s); GH_TRY(launch_wgrad_mfma(w.gh1, (long)hid * HW, out, chw, w.partial + 2 * w.partial_floats, G.f0_w, N, HW, hid, n0,
-                                             hid, Ch * 9, 0, s, sh_grad_scale, a0b, &t0, &rj.job[2])); }
+                                             hid, Ch * 9, 0, s, sh_grad_scale, a0b, &t0, &rj.job[2], 0, 0, 5)); }
                 } else {
                     GH_TRY(launch_shift_expand(out, chw, w.col, N, Ch, d.H, d.W, n0, +1, s));
                     { ScopedTimer tw(p, GLOWHIP_K_WGRAD, 1, s); GH_TRY(launch_wgrad_mfma(w.gh1, (long)hid * HW, w.col, (long)n0 * HW, w.partial + 2 * w.partial_floats, G.f0_w, N, HW,
-                                             hid, n0, hid, Ch * 9, 0, s, sh_grad_scale, a0b, nullptr, &rj.job[2])); }
+                                             hid, n0, hid, Ch * 9, 0, s, sh_grad_scale, a0b, nullptr, &rj.job[2], 0, 0, 5)); }
                 }
                 { ScopedTimer tw(p, GLOWHIP_K_WGRAD, 0, s); GH_TRY(launch_wgrad_reduce_batched(rj, s)); }
                 if (G.f2_an_logs) p->logs_jobs.push_back(LogsJob{d.f2_w, G.f2_w, d.f2_an_bias, a2b, G.f2_an_logs, hid, hid});
@@ -474,7 +474,7 @@ static int backward_sweep(glowhip_plan* p, const void* packed, const float* x_in
             // partial-sum scratch (unused on this path), h2 first, h1 once h2 has been consumed.
             const bool half_tape = li < (int)p->tape_has_masks.size() && p->tape_has_masks[li];
             if (half_tape) {
-                GH_TRY(launch_half_to_float(h2, w.gsh, (long)N * hid * HW, s));
+                GH_TRY(launch_half_to_float(h2, w.gsh, N, hid, HW, s));
                 h2 = w.gsh;
             }
             if (fastw) {   // dW4[o][i][tap] = sum_p g_pre[o][p - d(tap)] * h2[i][p]
@@ -494,7 +494,7 @@ static int backward_sweep(glowhip_plan* p, const void* packed, const float* x_in
             }
             GH_TRY(launch_act_bwd(w.gh2, h2, at<float>(packed, L.f2_scale), N, hid, HW, a2b, a2l, s));
             if (half_tape) {
-                GH_TRY(launch_half_to_float(h1, w.gsh, (long)N * hid * HW, s));
+                GH_TRY(launch_half_to_float(h1, w.gsh, N, hid, HW, s));
                 h1 = w.gsh;
             }
             // (c) f.2 (1x1)

@@ -11,6 +11,9 @@
 // them in a fixed order (deterministic) while scattering into the reference weight layout.
 #include "backward.h"
 #include "sh.h"
+#include <type_traits>
+
+GH_STAMPS_DEFINE(wgrad)
 
 namespace glowhip {
 
@@ -167,13 +170,18 @@ __global__ void __launch_bounds__(256, 2)      // two workgroups per CU: at 269 
                                                // wave per SIMD and every k-tile waited out its own HBM round trip (7.4 k cycles per
                                                // k-tile against 768 of MFMA work)
 k_wgrad_gemm_sh(const float* __restrict__ A, long a_bs, const float* __restrict__ B, long b_bs, float* __restrict__ partial,
-                int HW, int Mpad, int Npad, int ktiles_total, int ktiles_per_split, float a_scale, double* __restrict__ rowsum,
-                int vC, int vH, int vW, int vsign, int b_valid) {
+                int HW, int Mpad, int Npad, int ktiles_total, int ktiles_per_split, float a_scale, float a_pre, double* __restrict__ rowsum,
+                int vC, int vH, int vW, int vsign, int b_valid, int tiled) {
     constexpr int BM = 128, BK = 32;
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
     constexpr int A_F4 = BM * BK / 4 / 256, B_F4 = BN * BK / 4 / 256;   // float4 per thread per K-tile (4, 4|2)
-    __shared__ __attribute__((aligned(16))) _Float16 As[2][2][BK / 8][BM][8];    // [buffer][plane][k group][row][8]
-    __shared__ __attribute__((aligned(16))) _Float16 Bs[2][BH ? 1 : 2][BK / 8][BN][8];
+    // [buffer][plane][k group][row][8], every k group 32 bytes longer than its rows: the loader's 8-byte stores of a quarter wave
+    // are 2 rows x 4 k groups, and with a group stride of a whole number of 128-byte bank rounds the four groups of a row met in
+    // the same 4 banks (SQ_LDS_BANK_CONFLICT: 0.6 of the LDS-active cycles); now each group has its own 8 banks.  Rows stay
+    // contiguous: the fragment reads (32 rows x 16 bytes) are as before.
+    constexpr int GPAD = 2;                      // (rows of padding per k group)
+    __shared__ __attribute__((aligned(16))) _Float16 As[2][2][BK / 8][BM + GPAD][8];
+    __shared__ __attribute__((aligned(16))) _Float16 Bs[2][BH ? 1 : 2][BK / 8][BN + GPAD][8];
     static_assert(!BH || (!VB && !BV), "an fp16 operand B is a plain one");
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wr = wid >> 1, wc = wid & 1, kl = lane >> 5, ml = lane & 31;
@@ -194,8 +202,21 @@ k_wgrad_gemm_sh(const float* __restrict__ A, long a_bs, const float* __restrict_
     // each, asked the texture-address path for 64 partial lines per instruction: f.2's gradient at level 1 took 166 us for the
     // 67 us of HBM time its operands need.)
     const int l_row = tid >> 3, l_c = tid & 7;
-    f32x4 ra[A_F4], rb[BH ? 1 : B_F4];
-    h4 rbh[BH ? B_F4 : 1];
+    // A plain operand comes in one of two layouts: (N, rows, HW), or -- `tiled` bit 0 (A) / 1 (B), what the taping / backward
+    // k_cnet write -- pixel-tile-major [pixel / 32][rows][pixel % 32] over the batch's pixels: a k-tile's 128-row panel is ONE
+    // contiguous block (16 KB fp32 / 8 KB fp16; a wave request 1 KB / 512 B of consecutive addresses) instead of 128 runs of
+    // 128 / 64 bytes HW * 4 bytes apart -- 32 K sequential streams per launch in DRAM's view, which the loads paid for with 40 of
+    // the kernel's 93 us at level 1 (same kernel with no requests: 54 us).
+    const bool a_t = tiled & 1, b_t = tiled & 2;
+    const int a_rs = a_t ? BK : HW, b_rs = b_t ? BK : HW;            // row stride in elements
+    const unsigned lane_off_a = (unsigned)(l_row * a_rs + l_c * 4), lane_off_b = (unsigned)(l_row * b_rs + l_c * 4);
+    // One k-tile's operand chunks in registers.  THREE of them by name (s0 / s1 / s2, the k loop is unrolled by three): tile
+    // t + 3 is requested while tile t is multiplied and tile t + 1 goes into LDS -- a request has two k-tiles' worth of MFMAs (of
+    // two workgroups per CU) to come back in.  One stage, requested one tile ahead, left every k-tile waiting out most of its own
+    // trip to memory (~3.5 k cycles per k-tile against 1 k of MFMA issue per SIMD at level 1).
+    // (two stages where both operands are fp32 at 128 columns: 32 registers per stage next to the 128 accumulators)
+    struct Stage { f32x4 ra[A_F4], rb[BH ? 1 : B_F4]; h4 rbh[BH ? B_F4 : 1]; };
+    constexpr int NST = ((BN == 128 && !BH) || VA) ? 2 : 3;      // (a gathered A: 16 requests + their in-image masks per stage)
     // virtual operand: per chunk row (fixed over the k loop) the source offset c * HW + dy * vW + dx, dy, dx; off < 0: a zero row
     constexpr int VN = VA ? A_F4 : (VB ? B_F4 : 1);
     int v_off[VN], v_dy[VN], v_dx[VN];
@@ -209,11 +230,10 @@ k_wgrad_gemm_sh(const float* __restrict__ A, long a_bs, const float* __restrict_
         }
     }
     const int vlw = (VA || VB) ? __builtin_ctz(vW) : 0;
-    auto load_virtual = [&](const float* V, long v_bs, int img, int p0, f32x4* dst) {
+    auto load_virtual = [&](const float* V, long v_bs, int img, int p0, f32x4* dst, int j) {
         const int p = p0 + l_c * 4, y = p >> vlw, x = p & (vW - 1);
         const float* vb = V + (long)img * v_bs + p;
-#pragma unroll
-        for (int j = 0; j < VN; ++j) {
+        {
             const int yy = y + v_dy[j];
             const bool rowok = v_off[j] > -(1 << 29) && yy >= 0 && yy < vH;
 #pragma unroll
@@ -225,61 +245,82 @@ k_wgrad_gemm_sh(const float* __restrict__ A, long a_bs, const float* __restrict_
             }
         }
     };
-    auto load_tile = [&](int kt) {
+    // part q of a k-tile's requests: the thread's q-th row chunk of either operand (a k-tile = 4 parts; step() issues them
+    // between its MFMA groups)
+    auto load_part = [&](int kt, Stage& st, int q) {
+        f32x4 (&ra)[A_F4] = st.ra; f32x4 (&rb)[BH ? 1 : B_F4] = st.rb; h4 (&rbh)[BH ? B_F4 : 1] = st.rbh;
+        (void)ra; (void)rb; (void)rbh;
+#ifdef WG_ABL_NOLOAD        // (timing experiments only: nothing is requested from memory)
+        if constexpr (!VA && BH) {
+            ra[q] = f32x4{(float)kt, 1.f, 2.f, 3.f}; rbh[q] = h4{(_Float16)kt, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f};
+            return;
+        }
+#endif
         const int img = kt / tiles_per_img, p0 = (kt - img * tiles_per_img) * BK;
         if constexpr (VA) {
-            load_virtual(A, a_bs, img, p0, ra);
+            load_virtual(A, a_bs, img, p0, ra, q);
         } else {
-            const float* ap = A + (long)img * a_bs + (long)(tile_m * BM + l_row) * HW + p0 + l_c * 4;
-#pragma unroll
-            for (int j = 0; j < A_F4; ++j) ra[j] = *reinterpret_cast<const f32x4*>(ap + (long)j * 32 * HW);
+            // (uniform base + the thread's 32-bit offset: no 64-bit address arithmetic per request)
+            const char* ap = reinterpret_cast<const char*>(A + (a_t ? ((long)kt * Mpad + tile_m * BM) * BK : (long)img * a_bs + (long)tile_m * BM * HW + p0));
+            ra[q] = *reinterpret_cast<const f32x4*>(ap + (long)q * 32 * a_rs * 4 + lane_off_a * 4u);
         }
+        if (q >= B_F4) return;
         if constexpr (BH) {
-            const _Float16* bp = reinterpret_cast<const _Float16*>(B) + (long)img * b_bs + (long)(tile_n * BN + l_row) * HW + p0 + l_c * 4;
-#pragma unroll
-            for (int j = 0; j < B_F4; ++j) rbh[j] = *reinterpret_cast<const h4*>(bp + (long)j * 32 * HW);
+            const char* bp = reinterpret_cast<const char*>(reinterpret_cast<const _Float16*>(B) +
+                                                           (b_t ? ((long)kt * Npad + tile_n * BN) * BK : (long)img * b_bs + (long)tile_n * BN * HW + p0));
+            rbh[q] = *reinterpret_cast<const h4*>(bp + (long)q * 32 * b_rs * 2 + lane_off_b * 2u);
         } else if constexpr (VB) {
-            load_virtual(B, b_bs, img, p0, rb);
+            load_virtual(B, b_bs, img, p0, rb, q);
+        } else if constexpr (BV) {      // rows >= b_valid do not exist in the tensor: loaded from row 0, zeroed
+            const int row = tile_n * BN + l_row + 32 * q;
+            const bool ok = row < b_valid;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(B + (long)img * b_bs + (long)(ok ? row : 0) * HW + p0 + l_c * 4);
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            rb[q] = ok ? v : z;
         } else {
-            if constexpr (BV) {      // rows >= b_valid do not exist in the tensor: loaded from row 0, zeroed
-#pragma unroll
-                for (int j = 0; j < B_F4; ++j) {
-                    const int row = tile_n * BN + l_row + 32 * j;
-                    const bool ok = row < b_valid;
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(B + (long)img * b_bs + (long)(ok ? row : 0) * HW + p0 + l_c * 4);
-                    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                    rb[j] = ok ? v : z;
-                }
-            } else {
-                const float* bp = B + (long)img * b_bs + (long)(tile_n * BN + l_row) * HW + p0 + l_c * 4;
-#pragma unroll
-                for (int j = 0; j < B_F4; ++j) rb[j] = *reinterpret_cast<const f32x4*>(bp + (long)j * 32 * HW);
-            }
+            const char* bp = reinterpret_cast<const char*>(B + (b_t ? ((long)kt * Npad + tile_n * BN) * BK : (long)img * b_bs + (long)tile_n * BN * HW + p0));
+            rb[q] = *reinterpret_cast<const f32x4*>(bp + (long)q * 32 * b_rs * 4 + lane_off_b * 4u);
         }
     };
-    auto split4 = [](const f32x4& v, float pre, h4& hi, h4& lo) {      // (same bits as sh_split on v * pre)
+    auto load_tile = [&](int kt, Stage& st) {
+#pragma unroll
+        for (int q = 0; q < A_F4; ++q) load_part(kt, st, q);
+    };
+    // (same bits as sh_split on v * pre: the residual t - hi is exact either way; here it is ONE v_fma_mix_f32 per value, which
+    // reads hi as the f16 half it is, and the two scalings are packed multiplications: 3 VALU instructions per value instead of 5)
+    // (PS: a plain A next to the fp16 tape is the backward k_cnet's g_u, stored already multiplied by a_scale -- no multiply here.
+    // The 2^11 on lo stays: early in training g * a_scale is ~1e-5 and smaller (f.4 starts at zero), where a true-scale lo would
+    // be gone and hi itself subnormal -- test_tiny_gradients_behind_near_zero_tail_weights_purely_relative.)
+    constexpr bool PS = BH && !VA;
+    auto split4 = [](const f32x4& v, float pre, h4& hi, h4& lo, auto ps) {
 #pragma unroll
         for (int t = 0; t < 4; t += 2) {
-            const float v0 = v[t] * pre, v1 = v[t + 1] * pre;
-            const f32x2_t vv = {v0, v1};
+            const f32x2_t vv = ps.value ? f32x2_t{v[t], v[t + 1]} : f32x2_t{v[t], v[t + 1]} * pre;
             const h2 x = __builtin_convertvector(vv, h2);
-            const f32x2_t rr = {(v0 - (float)x[0]) * SH_LO_SCALE, (v1 - (float)x[1]) * SH_LO_SCALE};
+            const f32x2_t rr = f32x2_t{__builtin_fmaf((float)x[0], -1.0f, vv[0]), __builtin_fmaf((float)x[1], -1.0f, vv[1])} * SH_LO_SCALE;
             const h2 y = __builtin_convertvector(rr, h2);
             hi[t] = x[0]; hi[t + 1] = x[1]; lo[t] = y[0]; lo[t + 1] = y[1];
         }
     };
     float rsum[A_F4];                  // rowsum != null: sum over this slice's pixels of the thread's A chunks (the bias gradient)
+    const bool do_rsum = rowsum && tile_n == 0;      // (only the first column tile's workgroups hand their sums over)
 #pragma unroll
     for (int j = 0; j < A_F4; ++j) rsum[j] = 0.f;
-    auto store_tile = [&](int buf) {   // 4 consecutive pixels of a row = half a fragment group: 8-byte stores, 16 lanes = 128 contiguous bytes
-        if (rowsum) {
+    auto store_tile = [&](int buf, Stage& st) {   // 4 consecutive pixels of a row = half a fragment group: 8-byte stores, 16 lanes = 128 contiguous bytes
+        f32x4 (&ra)[A_F4] = st.ra; f32x4 (&rb)[BH ? 1 : B_F4] = st.rb; h4 (&rbh)[BH ? B_F4 : 1] = st.rbh;
+        (void)ra; (void)rb; (void)rbh;
+        if (do_rsum) {
 #pragma unroll
             for (int j = 0; j < A_F4; ++j) rsum[j] += (ra[j][0] + ra[j][1]) + (ra[j][2] + ra[j][3]);
         }
 #pragma unroll
         for (int j = 0; j < A_F4; ++j) {
             h4 hi, lo;
-            split4(ra[j], a_scale, hi, lo);
+#ifdef WG_ABL_NOCONV        // (timing experiments only: no split)
+            hi = __builtin_bit_cast(h4, f32x2_t{ra[j][0], ra[j][1]}); lo = __builtin_bit_cast(h4, f32x2_t{ra[j][2], ra[j][3]});
+#else
+            split4(ra[j], a_pre, hi, lo, std::integral_constant<bool, PS>{});
+#endif
             *reinterpret_cast<h4*>(&As[buf][0][l_c >> 1][l_row + 32 * j][(l_c & 1) * 4]) = hi;
             *reinterpret_cast<h4*>(&As[buf][1][l_c >> 1][l_row + 32 * j][(l_c & 1) * 4]) = lo;
         }
@@ -290,7 +331,7 @@ k_wgrad_gemm_sh(const float* __restrict__ A, long a_bs, const float* __restrict_
 #pragma unroll
             for (int j = 0; j < B_F4; ++j) {
                 h4 hi, lo;
-                split4(rb[j], 1.0f, hi, lo);
+                split4(rb[j], 1.0f, hi, lo, std::true_type{});
                 *reinterpret_cast<h4*>(&Bs[buf][0][l_c >> 1][l_row + 32 * j][(l_c & 1) * 4]) = hi;
                 *reinterpret_cast<h4*>(&Bs[buf][BH ? 0 : 1][l_c >> 1][l_row + 32 * j][(l_c & 1) * 4]) = lo;
             }
@@ -305,13 +346,15 @@ k_wgrad_gemm_sh(const float* __restrict__ A, long a_bs, const float* __restrict_
 #pragma unroll
             for (int r = 0; r < 16; ++r) { accm[i][j][r] = 0.f; accx[i][j][r] = 0.f; }
 
-    if (kt0 < kt1) {
-        load_tile(kt0);
-        store_tile(0);
-        __syncthreads();
-        for (int kt = kt0; kt < kt1; ++kt) {
-            const int buf = (kt - kt0) & 1;
-            if (kt + 1 < kt1) load_tile(kt + 1);
+    const int nk = kt1 - kt0;
+    if (nk > 0) {
+        Stage s0, s1, s2;
+#ifdef WG_ABL_SAMETILE      // (timing experiments only: every request hits the same k-tile -- L2 hits)
+        auto tile_of = [&](int t) { return kt0 + (min(t, nk - 1) & 1); };
+#else
+        auto tile_of = [&](int t) { return kt0 + min(t, nk - 1); };     // (clamped: the steady loop does not branch around its requests)
+#endif
+        auto multiply = [&](int buf, auto&& between) {
 #pragma unroll
             for (int ks = 0; ks < BK / 16; ++ks) {
                 const int grp = 2 * ks + kl;
@@ -326,10 +369,12 @@ k_wgrad_gemm_sh(const float* __restrict__ A, long a_bs, const float* __restrict_
                     bh[j] = *reinterpret_cast<const h8*>(&Bs[buf][0][grp][wc * WN + j * 32 + ml][0]);
                     if constexpr (!BH) bl[j] = *reinterpret_cast<const h8*>(&Bs[buf][BH ? 0 : 1][grp][wc * WN + j * 32 + ml][0]);
                 }
+                between(2 * ks);
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j) accm[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], accm[i][j], 0, 0, 0);
+                between(2 * ks + 1);
                 if constexpr (!BH) {
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
@@ -341,16 +386,72 @@ k_wgrad_gemm_sh(const float* __restrict__ A, long a_bs, const float* __restrict_
 #pragma unroll
                     for (int j = 0; j < TN; ++j) accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], accx[i][j], 0, 0, 0);
             }
-            if (kt + 1 < kt1) store_tile(buf ^ 1);
+        };
+        // step t: tile t is in LDS buffer t & 1; `done` held it and takes tile t + NST, `next` holds tile t + 1 and goes into LDS
+        // The requests of tile t + NST go out in four parts BETWEEN the MFMA groups: issued in one burst at the head of the step
+        // the 64 wave requests of a CU's eight waves queued up in its memory pipeline (56 B/clk: ~860 cycles for the 48 KB of two
+        // k-tiles) and every wave sat behind its own requests before its first MFMA -- the requests cost 30 of 93 us at level 1
+        // even when they all hit the L2.
+#ifdef GLOWHIP_DEBUG_STAMPS
+        unsigned long long tph[5] = {0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
+#define WG_PH(i) do { if (BH && !VA) { const unsigned long long c_ = __builtin_readcyclecounter(); tph[i] += c_ - tprev; tprev = c_; } } while (0)
+#else
+#define WG_PH(i) do { } while (0)
+#endif
+        auto step = [&](int t, Stage& done, Stage& next, auto last) {
+            const bool req = !last.value || t + NST < nk;
+            const int ktn = tile_of(t + NST);
+            WG_PH(3);
+            constexpr bool SPREAD = BH || BN == 64;      // (the two-plane 128-column instances have no registers for it: 16 spilled)
+            if (!SPREAD && req) { load_tile(ktn, done); __builtin_amdgcn_sched_barrier(0); }
+#ifndef WG_ABL_NOMFMA
+            multiply(t & 1, [&](int q) {
+                if constexpr (SPREAD) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (req) load_part(ktn, done, q);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            });
+#else
+            if (SPREAD && req) load_tile(ktn, done);
+#endif
+            WG_PH(0);
+#ifdef GLOWHIP_DEBUG_STAMPS
+            if (BH && !VA && NST == 3) { asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); WG_PH(4); }     // (the next tile's values are here)
+#endif
+            if (!last.value || t + 1 < nk) store_tile((t + 1) & 1, next);
+            WG_PH(1);
             __syncthreads();
+            WG_PH(2);
+        };
+        load_tile(tile_of(0), s0); load_tile(tile_of(1), s1);
+        if constexpr (NST == 3) load_tile(tile_of(2), s2);
+        store_tile(0, s0);
+        __syncthreads();
+        int t = 0;
+        if constexpr (NST == 3) {
+            for (; t + 4 <= nk; t += 3) {
+                step(t, s0, s1, std::false_type{}); step(t + 1, s1, s2, std::false_type{}); step(t + 2, s2, s0, std::false_type{});
+            }
+            if (t < nk) step(t, s0, s1, std::true_type{});
+            if (t + 1 < nk) step(t + 1, s1, s2, std::true_type{});
+            if (t + 2 < nk) step(t + 2, s2, s0, std::true_type{});
+        } else {
+            for (; t + 3 <= nk; t += 2) { step(t, s0, s1, std::false_type{}); step(t + 1, s1, s0, std::false_type{}); }
+            if (t < nk) step(t, s0, s1, std::true_type{});
+            if (t + 1 < nk) step(t + 1, s1, s0, std::true_type{});
         }
+#ifdef GLOWHIP_DEBUG_STAMPS
+        if (BH && !VA) { GH_STAMP_VAL(0, tph[0]); GH_STAMP_VAL(1, tph[1]); GH_STAMP_VAL(2, tph[2]); GH_STAMP_VAL(3, tph[3]); GH_STAMP_VAL(5, tph[4]); GH_STAMP_VAL(4, nk);
+                         GH_STAMP_VAL(63, __builtin_amdgcn_s_getreg((31 << 11) | 4)); }
+#endif
     }
-    if (rowsum && tile_n == 0 && kt0 < kt1) {      // the eight chunks of a row sit in eight consecutive lanes: one fp64 atomic per row and slice
+    if (do_rsum && nk > 0) {      // the eight chunks of a row sit in eight consecutive lanes: one fp64 atomic per row and slice
 #pragma unroll
         for (int j = 0; j < A_F4; ++j) {
             float v = rsum[j];
             v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
-            if (l_c == 0) atomicAdd(rowsum + tile_m * BM + l_row + 32 * j, (double)v);
+            if (l_c == 0) atomicAdd(rowsum + tile_m * BM + l_row + 32 * j, (double)v * (double)(a_pre / a_scale));      // (a pre-scaled A: back to g)
         }
     }
     const float inv = 1.0f / a_scale;
@@ -432,7 +533,12 @@ size_t wgrad_mfma_partial_floats(int Mpad, int Npad, int N, int HW) {
 
 int launch_wgrad_mfma(const float* A, long a_bs, const float* B, long b_bs, float* partial, float* dw, int N, int HW,
                       int Mpad, int Npad, int Mreal, int Nreal, int mode, hipStream_t s, float sh_scale, double* rowsum,
-                      const WgradTaps* taps, WgradReduceJob* defer, int b_valid, int b_half) {
+                      const WgradTaps* taps, WgradReduceJob* defer, int b_valid, int b_half, int tiled) {
+    const float a_pre = (tiled & 4) ? 1.0f : sh_scale;     // bit 2: A is stored already multiplied by sh_scale (the backward k_cnet's g_u)
+    GH_REQUIRE(!b_half || (taps && taps->operand == 0) || (tiled & 4), "wgrad_mfma: with an fp16 B a plain A comes pre-scaled");
+    GH_REQUIRE(!tiled || (sh_scale > 0.f && !(tiled & ~7) && !((tiled & 1) && taps && taps->operand == 0) &&
+                          !((tiled & 2) && ((taps && taps->operand == 1) || b_valid > 0))),
+               "wgrad_mfma: the pixel-tile-major layout is for plain operands of the split-half kernel");
     GH_REQUIRE(!rowsum || sh_scale > 0.f, "wgrad_mfma: row sums only on the split-half kernel");
     GH_REQUIRE(!b_half || (sh_scale > 0.f && b_valid <= 0 && !(taps && taps->operand == 1)), "wgrad_mfma: an fp16 operand B needs the split-half kernel and a plain B");
     GH_REQUIRE(b_valid <= 0 || (sh_scale > 0.f && taps && taps->operand == 0 && Npad == 64), "wgrad_mfma: b_valid only with gathered A and a 64-column B");
@@ -450,10 +556,10 @@ int launch_wgrad_mfma(const float* A, long a_bs, const float* B, long b_bs, floa
     const int vC = taps ? taps->C : 0, vH = taps ? taps->H : 0, vW = taps ? taps->W : 1, vs = taps ? taps->sign : 0;
 #define GH_WG(bn, va, vb)                                                                                                      \
     hipLaunchKernelGGL((k_wgrad_gemm_sh<bn, va, vb>), dim3(tiles * splits), dim3(256), 0, s, A, a_bs, B, b_bs, partial, HW, Mpad, \
-                       Npad, total, per, sh_scale, rowsum, vC, vH, vW, vs, b_valid > 0 ? b_valid : Npad)
+                       Npad, total, per, sh_scale, a_pre, rowsum, vC, vH, vW, vs, b_valid > 0 ? b_valid : Npad, tiled)
 #define GH_WGH(bn, va)                                                                                                         \
     hipLaunchKernelGGL((k_wgrad_gemm_sh<bn, va, false, false, true>), dim3(tiles * splits), dim3(256), 0, s, A, a_bs, B, b_bs, partial, \
-                       HW, Mpad, Npad, total, per, sh_scale, rowsum, vC, vH, vW, vs, Npad)
+                       HW, Mpad, Npad, total, per, sh_scale, a_pre, rowsum, vC, vH, vW, vs, Npad, tiled)
     if (b_half) {                      // B = h1 / h2 as fp16 from the tape
         const bool va = taps && taps->operand == 0;
         if (bn128) { if (va) GH_WGH(128, true); else GH_WGH(128, false); }
@@ -466,7 +572,7 @@ int launch_wgrad_mfma(const float* A, long a_bs, const float* B, long b_bs, floa
     } else if (sh_scale > 0.f) {
         if (taps && taps->operand == 0 && b_valid > 0)
             hipLaunchKernelGGL((k_wgrad_gemm_sh<64, true, false, true>), dim3(tiles * splits), dim3(256), 0, s, A, a_bs, B, b_bs, partial, HW,
-                               Mpad, Npad, total, per, sh_scale, rowsum, vC, vH, vW, vs, b_valid);
+                               Mpad, Npad, total, per, sh_scale, a_pre, rowsum, vC, vH, vW, vs, b_valid, tiled);
         else if (taps && taps->operand == 0) GH_WG(64, true, false);
         else if (taps) GH_WG(64, false, true);
         else GH_WG(64, false, false);
