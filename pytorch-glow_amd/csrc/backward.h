@@ -74,7 +74,7 @@ int launch_wgrad_mfma(const float* A, long a_bs, const float* B, long b_bs, floa
                       int b_half = 0,     // 1 (f16-pipe kernel, plain B): B points at an fp16 tensor (the taped h1 / h2), b_bs in elements
                       int tiled = 0);     // bit 0 / bit 1 (f16-pipe kernel, plain operand): A / B is pixel-tile-major [pixel / 32][rows][pixel % 32]
                                           // over the batch's pixels (what the taping / backward k_cnet write, sh.h), rows = Mpad / Npad; its batch stride is unused
-                                          // bit 2: A holds g * sh_scale already (the backward k_cnet's g_u2 / g_u0); row sums and dW come out as for g
+                                          // bit 2: A holds g * sh_scale * 2^11 (the backward k_cnet's g_u2 / g_u0); row sums and dW come out as for g
 // fp16 pixel-tile-major [pixel / 32][R][pixel % 32] -> fp32 (N, R, HW): a taped hidden tensor for the per-layer backward kernels
 int launch_half_to_float(const void* src_half, float* dst, int N, int R, int HW, hipStream_t s);
 struct WgradReduceJob { const float* partial; float* dw; int splits, Mpad, Npad, Mreal, Nreal, mode; };

@@ -434,7 +434,7 @@ static int backward_sweep(glowhip_plan* p, const void* packed, const float* x_in
                 c.tape_h1 = w.gh2; c.tape_h2 = w.gh1;
                 c.mask1 = const_cast<unsigned short*>(at<unsigned short>(tape, tl[li].m1));
                 c.mask2 = const_cast<unsigned short*>(at<unsigned short>(tape, tl[li].m2));
-                c.in_scale = SH2_ACT_SCALE * sh_grad_scale; c.out_scale = SH2_ACT_INV; c.bwd = 1;      // (g_u2 / g_u0 are stored times sh_grad_scale: what the weight-gradient GEMMs split)
+                c.in_scale = SH2_ACT_SCALE * sh_grad_scale; c.out_scale = SH2_ACT_INV * SH_LO_SCALE; c.bwd = 1;      // (g_u2 / g_u0 are stored times sh_grad_scale * 2^11: what the weight-gradient GEMMs split with two instructions per value)
                 CnetPending pend{};
                 count_launch(p, "k_cnet(bwd)");
                 {

@@ -288,10 +288,9 @@ k_wgrad_gemm_sh(const float* __restrict__ A, long a_bs, const float* __restrict_
     };
     // (same bits as sh_split on v * pre: the residual t - hi is exact either way; here it is ONE v_fma_mix_f32 per value, which
     // reads hi as the f16 half it is, and the two scalings are packed multiplications: 3 VALU instructions per value instead of 5)
-    // (PS: a plain A next to the fp16 tape is the backward k_cnet's g_u, stored already multiplied by a_scale -- no multiply here.
-    // The 2^11 on lo stays: early in training g * a_scale is ~1e-5 and smaller (f.4 starts at zero), where a true-scale lo would
-    // be gone and hi itself subnormal -- test_tiny_gradients_behind_near_zero_tail_weights_purely_relative.)
-    constexpr bool PS = BH && !VA;
+    // (a_pre: a_scale for a plain g; 2^-11 for the backward k_cnet's g_u0, which is stored times a_scale * 2^11 for the kernel
+    // below.  The 2^11 on lo is what keeps the range: early in training g * a_scale is ~1e-5 and smaller (f.4 starts at zero),
+    // where a true-scale lo would be gone and hi itself subnormal -- test_tiny_gradients_behind_near_zero_tail_weights_purely_relative.)
     auto split4 = [](const f32x4& v, float pre, h4& hi, h4& lo, auto ps) {
 #pragma unroll
         for (int t = 0; t < 4; t += 2) {
@@ -319,7 +318,7 @@ k_wgrad_gemm_sh(const float* __restrict__ A, long a_bs, const float* __restrict_
 #ifdef WG_ABL_NOCONV        // (timing experiments only: no split)
             hi = __builtin_bit_cast(h4, f32x2_t{ra[j][0], ra[j][1]}); lo = __builtin_bit_cast(h4, f32x2_t{ra[j][2], ra[j][3]});
 #else
-            split4(ra[j], a_pre, hi, lo, std::integral_constant<bool, PS>{});
+            split4(ra[j], a_pre, hi, lo, std::false_type{});
 #endif
             *reinterpret_cast<h4*>(&As[buf][0][l_c >> 1][l_row + 32 * j][(l_c & 1) * 4]) = hi;
             *reinterpret_cast<h4*>(&As[buf][1][l_c >> 1][l_row + 32 * j][(l_c & 1) * 4]) = lo;
@@ -467,6 +466,363 @@ k_wgrad_gemm_sh(const float* __restrict__ A, long a_bs, const float* __restrict_
             }
 }
 
+// The f.2 case of the kernel above -- plain A = the backward k_cnet's g_u2, stored times a_scale * 2^11 (PS), plain B = the fp16
+// tape -- with the step rebuilt around the wave's own MFMA stream: see step().  (The template keeps the general kernel's
+// parameters; the gathered / two-plane instances measured slower in this form -- a gathered value's in-image select pinned
+// into the slot of its request waits out the request -- and stay on the kernel above.)
+template <int BN, bool VA = false, bool VB = false, bool BV = false, bool BH = false, bool PS = false>
+__global__ void __launch_bounds__(256, 2)      // two workgroups per CU: at 269 registers (141 + 128 accumulators) the kernel ran ONE
+                                               // wave per SIMD and every k-tile waited out its own HBM round trip (7.4 k cycles per
+                                               // k-tile against 768 of MFMA work)
+k_wgrad_gemm_ps(const float* __restrict__ A, long a_bs, const float* __restrict__ B, long b_bs, float* __restrict__ partial,
+                int HW, int Mpad, int Npad, int ktiles_total, int ktiles_per_split, float a_scale, float a_pre, double* __restrict__ rowsum,
+                int vC, int vH, int vW, int vsign, int b_valid, int tiled) {
+    constexpr int BM = 128, BK = 32;
+    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+    constexpr int A_F4 = BM * BK / 4 / 256, B_F4 = BN * BK / 4 / 256;   // float4 per thread per K-tile (4, 4|2)
+    // [buffer][plane][k group][row][8], every k group 32 bytes longer than its rows: the loader's 8-byte stores of a quarter wave
+    // are 2 rows x 4 k groups, and with a group stride of a whole number of 128-byte bank rounds the four groups of a row met in
+    // the same 4 banks (SQ_LDS_BANK_CONFLICT: 0.6 of the LDS-active cycles); now each group has its own 8 banks.  Rows stay
+    // contiguous: the fragment reads (32 rows x 16 bytes) are as before.
+    constexpr int GPAD = 2;                      // (rows of padding per k group)
+    __shared__ __attribute__((aligned(16))) _Float16 As[2][2][BK / 8][BM + GPAD][8];
+    __shared__ __attribute__((aligned(16))) _Float16 Bs[2][BH ? 1 : 2][BK / 8][BN + GPAD][8];
+    static_assert(!BH || (!VB && !BV), "an fp16 operand B is a plain one");
+    static_assert(!PS || !VA, "a pre-scaled A is a plain one");
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wr = wid >> 1, wc = wid & 1, kl = lane >> 5, ml = lane & 31;
+    // XCD-aware order (8 XCDs with private L2s, block b lands on XCD b % 8): the tiles of ONE pixel slice share their operand
+    // panels -- every A panel is read by all tile_n, every B panel by all tile_m -- so they go to the same XCD back to back and
+    // the panels travel from HBM once per slice instead of once per tile (the tile-major grid spread a slice over all 8 L2s:
+    // 4x the operand bytes from memory at 512 x 512).
+    const int tiles_n = Npad / BN;
+    const int ntiles = (Mpad / BM) * tiles_n;
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = logical / ntiles, tile = logical - split * ntiles;
+    const int tile_m = tile / tiles_n, tile_n = tile % tiles_n;
+    const int kt0 = split * ktiles_per_split;
+    const int kt1 = min(ktiles_total, kt0 + ktiles_per_split);
+    const int tiles_per_img = HW / BK;
+    // Operand loader: chunk q = tid + 256 j of a tile is (row q / 8, pixels 4 (q % 8) .. + 4) -- eight consecutive lanes read the
+    // 128 contiguous bytes one row contributes to a k-tile, a wave instruction 8 whole cache lines.  (One row per lane, 64 bytes
+    // each, asked the texture-address path for 64 partial lines per instruction: f.2's gradient at level 1 took 166 us for the
+    // 67 us of HBM time its operands need.)
+    const int l_row = tid >> 3, l_c = tid & 7;
+    // A plain operand comes in one of two layouts: (N, rows, HW), or -- `tiled` bit 0 (A) / 1 (B), what the taping / backward
+    // k_cnet write -- pixel-tile-major [pixel / 32][rows][pixel % 32] over the batch's pixels: a k-tile's 128-row panel is ONE
+    // contiguous block (16 KB fp32 / 8 KB fp16; a wave request 1 KB / 512 B of consecutive addresses) instead of 128 runs of
+    // 128 / 64 bytes HW * 4 bytes apart -- 32 K sequential streams per launch in DRAM's view, which the loads paid for with 40 of
+    // the kernel's 93 us at level 1 (same kernel with no requests: 54 us).
+    const bool a_t = tiled & 1, b_t = tiled & 2;
+    const int a_rs = a_t ? BK : HW, b_rs = b_t ? BK : HW;            // row stride in elements
+    const unsigned lane_off_a = (unsigned)(l_row * a_rs + l_c * 4), lane_off_b = (unsigned)(l_row * b_rs + l_c * 4);
+    // panel of k-tile kt = (image img, tile tin of the image): base + img * s_img + tin * s_tin elements, either layout (no
+    // branch on the layout inside the k loop)
+    const long a_img = a_t ? (long)tiles_per_img * Mpad * BK : a_bs, a_tin = a_t ? (long)Mpad * BK : BK;
+    const long b_img = b_t ? (long)tiles_per_img * Npad * BK : b_bs, b_tin = b_t ? (long)Npad * BK : BK;
+    const long a_base = (long)tile_m * BM * a_rs, b_base = (long)tile_n * BN * b_rs;
+    // One k-tile's operand chunks in registers.  TWO of them by name (sx / sy, the k loop is unrolled by two), refilled chunk by
+    // chunk: during step t the stage holding tile t + 1 is split and stored into LDS one chunk at a time, and each chunk's
+    // registers are re-requested for tile t + 3 as soon as they have been read -- a request has two steps to come back in (the
+    // wait in front of the split: 8 cycles per k-tile by the stamps), with the registers of two tiles.
+    struct Stage { f32x4 ra[A_F4], rb[BH ? 1 : B_F4]; h4 rbh[BH ? B_F4 : 1]; };
+    // virtual operand: per chunk row (fixed over the k loop) the source offset c * HW + dy * vW + dx, dy, dx; off < 0: a zero row
+    constexpr int VN = VA ? A_F4 : (VB ? B_F4 : 1);
+    int v_off[VN], v_dy[VN], v_dx[VN];
+    if (VA || VB) {
+#pragma unroll
+        for (int j = 0; j < VN; ++j) {
+            const int r = (VA ? tile_m * BM : tile_n * BN) + l_row + 32 * j;
+            const int c = r / 9, tap = r - c * 9;
+            v_dy[j] = (tap / 3 - 1) * vsign; v_dx[j] = (tap % 3 - 1) * vsign;
+            v_off[j] = r < 9 * vC ? c * HW + v_dy[j] * vW + v_dx[j] : -(1 << 30);
+        }
+    }
+    const int vlw = (VA || VB) ? __builtin_ctz(vW) : 0;
+    auto load_virtual = [&](const float* V, long v_bs, int img, int p0, f32x4* dst, int j) {
+        const int p = p0 + l_c * 4, y = p >> vlw, x = p & (vW - 1);
+        const float* vb = V + (long)img * v_bs + p;
+        {
+            const int yy = y + v_dy[j];
+            const bool rowok = v_off[j] > -(1 << 29) && yy >= 0 && yy < vH;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int xx = x + e + v_dx[j];
+                const bool ok = rowok && xx >= 0 && xx < vW;
+                const float v = ok ? vb[v_off[j] + e] : V[0];      // (unconditional load from a valid address, selected)
+                dst[j][e] = ok ? v : 0.f;
+            }
+        }
+    };
+    // part q of a k-tile's requests: the thread's q-th row chunk of either operand (a k-tile = 4 parts; step() issues them
+    // between its MFMA groups)
+    auto load_part = [&](int kt, Stage& st, int q) {
+        f32x4 (&ra)[A_F4] = st.ra; f32x4 (&rb)[BH ? 1 : B_F4] = st.rb; h4 (&rbh)[BH ? B_F4 : 1] = st.rbh;
+        (void)ra; (void)rb; (void)rbh;
+#ifdef WG_ABL_NOLOAD        // (timing experiments only: nothing is requested from memory)
+        if constexpr (!VA && BH) {
+            ra[q] = f32x4{(float)kt, 1.f, 2.f, 3.f}; rbh[q] = h4{(_Float16)kt, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f};
+            return;
+        }
+#endif
+        const int img = kt / tiles_per_img, tin = kt - img * tiles_per_img, p0 = tin * BK;
+        (void)p0;
+        if constexpr (VA) {
+            load_virtual(A, a_bs, img, p0, ra, q);
+        } else {
+            // (uniform base + the thread's 32-bit offset: no 64-bit address arithmetic per request)
+            const char* ap = reinterpret_cast<const char*>(A + a_base + img * a_img + tin * a_tin);
+            ra[q] = *reinterpret_cast<const f32x4*>(ap + (long)q * 32 * a_rs * 4 + lane_off_a * 4u);
+        }
+        if (q >= B_F4) return;
+        if constexpr (BH) {
+            const char* bp = reinterpret_cast<const char*>(reinterpret_cast<const _Float16*>(B) + b_base + img * b_img + tin * b_tin);
+            rbh[q] = *reinterpret_cast<const h4*>(bp + (long)q * 32 * b_rs * 2 + lane_off_b * 2u);
+        } else if constexpr (VB) {
+            load_virtual(B, b_bs, img, p0, rb, q);
+        } else if constexpr (BV) {      // rows >= b_valid do not exist in the tensor: loaded from row 0, zeroed
+            const int row = tile_n * BN + l_row + 32 * q;
+            const bool ok = row < b_valid;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(B + (long)img * b_bs + (long)(ok ? row : 0) * HW + p0 + l_c * 4);
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            rb[q] = ok ? v : z;
+        } else {
+            const char* bp = reinterpret_cast<const char*>(B + b_base + img * b_img + tin * b_tin);
+            rb[q] = *reinterpret_cast<const f32x4*>(bp + (long)q * 32 * b_rs * 4 + lane_off_b * 4u);
+        }
+    };
+    auto load_tile = [&](int kt, Stage& st) {
+#pragma unroll
+        for (int q = 0; q < A_F4; ++q) load_part(kt, st, q);
+    };
+    // Split of one pair of values into (hi, lo * 2^11) halves: same bits as sh_split on v * pre (the residual t - hi is exact).
+    // PS -- a plain A written by the backward k_cnet, which stores T = g * a_scale * 2^11: hi = fp16(T * 2^-11) and
+    // lo = fp16(T - 2^11 hi), each ONE v_fma_mix{lo,hi}_f16 that rounds straight into its half of the packed word: 2 instructions
+    // per value, none of them a packed fp32 operation (v_pk_mul_f32 / v_pk_add_f32 next to a running MFMA stream are the most
+    // expensive VALU instructions there are: scripts/ubench/mfma_valu_shadow.hip).  The 2^11 on lo is what keeps the range: early
+    // in training g * a_scale is ~1e-5 and smaller (f.4 starts at zero), where a true-scale lo would be gone and hi itself
+    // subnormal (test_tiny_gradients_behind_near_zero_tail_weights_purely_relative).
+    auto split2 = [](float v0, float v1, float pre, unsigned& hi, unsigned& lo, auto ps) {
+        if constexpr (decltype(ps)::value) {
+            const float c_dn = SH_LO_INV, c_up = -SH_LO_SCALE;
+            asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hi) : "v"(v0), "s"(c_dn));
+            asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hi) : "v"(v1), "s"(c_dn));
+            asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(hi), "s"(c_up), "v"(v0));
+            asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hi), "s"(c_up), "v"(v1));
+        } else {
+            const f32x2_t vv = f32x2_t{v0, v1} * pre;
+            const h2 x = __builtin_convertvector(vv, h2);
+            const f32x2_t rr = f32x2_t{__builtin_fmaf((float)x[0], -1.0f, vv[0]), __builtin_fmaf((float)x[1], -1.0f, vv[1])} * SH_LO_SCALE;
+            hi = __builtin_bit_cast(unsigned, x);
+            lo = __builtin_bit_cast(unsigned, __builtin_convertvector(rr, h2));
+        }
+    };
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    float rsum[A_F4];                  // rowsum != null: sum over this slice's pixels of the thread's A chunks (the bias gradient)
+    const bool do_rsum = rowsum && tile_n == 0;      // (only the first column tile's workgroups hand their sums over)
+#pragma unroll
+    for (int j = 0; j < A_F4; ++j) rsum[j] = 0.f;
+    // The next tile's way into LDS in pieces (step() runs them between its MFMAs): pair h of A chunk q -> packed halves in
+    // (ahi, alo); the chunk's two 8-byte stores (4 consecutive pixels of a row = half a fragment group, 16 lanes = 128 contiguous
+    // bytes); B chunk q (fp16 tape: as it is; fp32: split like A, exact scale 1).
+    u32x2 ahi, alo, bhi, blo;
+    auto conv_a = [&](Stage& st, int q, int h) {
+        if (h == 0) rsum[q] += (st.ra[q][0] + st.ra[q][1]) + (st.ra[q][2] + st.ra[q][3]);     // (every workgroup: a branch here would cut the step into blocks)
+#ifdef WG_ABL_NOCONV        // (timing experiments only: no split)
+        ahi[h] = __float_as_uint(st.ra[q][2 * h]); alo[h] = __float_as_uint(st.ra[q][2 * h + 1]);
+#else
+        unsigned x, y;
+        split2(st.ra[q][2 * h], st.ra[q][2 * h + 1], a_pre, x, y, std::integral_constant<bool, PS>{});
+        ahi[h] = x; alo[h] = y;
+#endif
+    };
+    auto store_a = [&](int buf, int q) {
+        *reinterpret_cast<u32x2*>(&As[buf][0][l_c >> 1][l_row + 32 * q][(l_c & 1) * 4]) = ahi;
+        *reinterpret_cast<u32x2*>(&As[buf][1][l_c >> 1][l_row + 32 * q][(l_c & 1) * 4]) = alo;
+    };
+    auto conv_b = [&](Stage& st, int q, int h) {
+        if constexpr (!BH) {
+            if (q < B_F4) {
+                unsigned x, y;
+                split2(st.rb[q][2 * h], st.rb[q][2 * h + 1], 1.0f, x, y, std::false_type{});
+                bhi[h] = x; blo[h] = y;
+            }
+        }
+    };
+    auto store_b = [&](int buf, Stage& st, int q) {
+        if (q >= B_F4) return;
+        if constexpr (BH) {
+            *reinterpret_cast<h4*>(&Bs[buf][0][l_c >> 1][l_row + 32 * q][(l_c & 1) * 4]) = st.rbh[q];
+        } else {
+            *reinterpret_cast<u32x2*>(&Bs[buf][0][l_c >> 1][l_row + 32 * q][(l_c & 1) * 4]) = bhi;
+            *reinterpret_cast<u32x2*>(&Bs[buf][BH ? 0 : 1][l_c >> 1][l_row + 32 * q][(l_c & 1) * 4]) = blo;
+        }
+    };
+    auto store_tile = [&](int buf, Stage& st) {       // (the first tile: nothing to hide behind)
+#pragma unroll
+        for (int q = 0; q < A_F4; ++q) {
+            conv_a(st, q, 0); conv_a(st, q, 1); store_a(buf, q);
+            conv_b(st, q, 0); conv_b(st, q, 1); store_b(buf, st, q);
+        }
+    };
+
+    f32x16_t accm[TM][TN], accx[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { accm[i][j][r] = 0.f; accx[i][j][r] = 0.f; }
+
+    const int nk = kt1 - kt0;
+    if (nk > 0) {
+        Stage sx;
+#ifdef WG_ABL_SAMETILE      // (timing experiments only: every request hits the same k-tile -- L2 hits)
+        auto tile_of = [&](int t) { return kt0 + (min(t, nk - 1) & 1); };
+#else
+        auto tile_of = [&](int t) { return kt0 + min(t, nk - 1); };     // (clamped: the steady loop does not branch around its requests)
+#endif
+        // One step = the 16 (fp16 B) or 24 MFMAs of tile t from LDS buffer t & 1, and BETWEEN them, one piece after each MFMA, in
+        // this order: the split of tile t + 1 (stage `cur`) and its stores into the other LDS buffer, each chunk followed by
+        // the request of the same chunk of tile t + 3.  A wave that multiplied first and converted afterwards spent 1 310 + 1 030 cycles per k-tile on the two
+        // (scripts/stamps_wgrad.py; 512 would be the MFMAs alone): its VALU work ran at ~1/3 of its rate next to the partner
+        // wave's MFMA stream and its own MFMAs at ~40 %.  In the shadow of the wave's OWN MFMA (32 clocks on the pipe, 4 to issue)
+        // up to six plain VALU instructions are free (ubench: 39 clocks per MFMA + 6 v_fma_f32).  sched_barrier pins the order.
+        constexpr int NM = (BH ? 2 : 3) * TM * TN * (BK / 16), QM = NM / A_F4;       // MFMAs per step, per quarter (= per chunk q)
+        // (the gathered-A and two-plane instances at 128 columns have no registers for the pieces or a second stage -- they
+        // spilled, and a spill's reload waits for every request in flight: they multiply first, then split + store tile t + 1
+        // from their ONE stage and request tile t + 2 into it)
+        constexpr bool SPREAD = BN == 64 || (BH && !VA);
+        constexpr int AHEAD = SPREAD ? 3 : 2;
+        static_assert(NM % A_F4 == 0 && QM >= 2, "pieces per chunk over its MFMA slots");
+#ifdef GLOWHIP_DEBUG_STAMPS
+        unsigned long long tph[5] = {0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
+#define WG_PH(i) do { if (BH && !VA) { const unsigned long long c_ = __builtin_readcyclecounter(); tph[i] += c_ - tprev; tprev = c_; } } while (0)
+#else
+#define WG_PH(i) do { } while (0)
+#endif
+        auto step = [&](int t, Stage& cur, auto last) {
+            const bool req = !last.value || t + AHEAD < nk, st_on = !last.value || t + 1 < nk;
+            const int ktn = tile_of(t + AHEAD), buf = t & 1, nbuf = buf ^ 1;
+            WG_PH(3);
+            // fragment reads: a k-step's at the latest point that still gives them four MFMAs to arrive -- ah of step ks + 1 when
+            // the last group using ah of ks is done, the B fragments one MFMA later, al at the head of ks + 1 (it is used last):
+            // 32 fragment registers live at the peak instead of 48 (with 128 accumulators and three stages there are no more)
+            h8 ah[BK / 16][TM], al[BK / 16][TM], bh[BK / 16][TN], bl[BK / 16][BH ? 1 : TN];
+            auto rd_ah = [&](int ks) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) ah[ks][i] = *reinterpret_cast<const h8*>(&As[buf][0][2 * ks + kl][wr * WM + i * 32 + ml][0]);
+            };
+            auto rd_al = [&](int ks) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) al[ks][i] = *reinterpret_cast<const h8*>(&As[buf][1][2 * ks + kl][wr * WM + i * 32 + ml][0]);
+            };
+            auto rd_b = [&](int ks) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    bh[ks][j] = *reinterpret_cast<const h8*>(&Bs[buf][0][2 * ks + kl][wc * WN + j * 32 + ml][0]);
+                    if constexpr (!BH) bl[ks][j] = *reinterpret_cast<const h8*>(&Bs[buf][BH ? 0 : 1][2 * ks + kl][wc * WN + j * 32 + ml][0]);
+                }
+            };
+            constexpr int GM = TM * TN, KM = NM / (BK / 16);            // MFMAs per group, per k-step
+            constexpr int AH_DONE = (BH ? 1 : 2) * GM;                  // slot (within a k-step) after which ah is dead
+            rd_ah(0); rd_b(0); rd_al(0);
+            int m = 0;
+            auto side = [&](int mm) {
+                if constexpr (!SPREAD) return;
+                const int q = mm / QM, r = mm - q * QM;
+                const int ks = mm / KM, rk = mm - ks * KM;
+                auto at = [&](int piece) { return (QM >= 4 ? piece : piece * QM / 4) == r; };      // four pieces over QM slots
+                __builtin_amdgcn_sched_barrier(0);
+                if (ks + 1 < BK / 16) {
+                    if (rk == AH_DONE - 1) rd_ah(ks + 1);
+                    if (rk == AH_DONE) rd_b(ks + 1);
+                    if (rk == KM - 1) rd_al(ks + 1);
+                }
+                if (at(0)) { if (st_on) conv_a(cur, q, 0); }
+                if (at(1)) { if (st_on) conv_a(cur, q, 1); }
+                if (at(2)) { if (st_on) { store_a(nbuf, q); conv_b(cur, q, 0); } }
+                if (at(3)) { if (st_on) { conv_b(cur, q, 1); store_b(nbuf, cur, q); } if (req) load_part(ktn, cur, q); }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+#ifndef WG_ABL_NOMFMA
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                if constexpr (!SPREAD) { if (ks > 0) { rd_ah(ks); rd_b(ks); rd_al(ks); } }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) { accm[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks][i], bh[ks][j], accm[i][j], 0, 0, 0); side(m++); }
+                if constexpr (!BH) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) { accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks][i], bl[ks][j], accx[i][j], 0, 0, 0); side(m++); }
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) { accx[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks][i], bh[ks][j], accx[i][j], 0, 0, 0); side(m++); }
+            }
+#else
+#pragma unroll
+            for (int mm = 0; mm < NM; ++mm) side(mm);
+#endif
+            WG_PH(0);
+            if constexpr (!SPREAD) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (st_on) store_tile(nbuf, cur);
+                if (req) load_tile(ktn, cur);
+            }
+            WG_PH(1);
+            __syncthreads();
+            WG_PH(2);
+        };
+        int t = 0;
+        if constexpr (SPREAD) {
+            Stage sy;
+            load_tile(tile_of(0), sx); load_tile(tile_of(1), sy);
+            store_tile(0, sx);
+            load_tile(tile_of(2), sx);
+            __syncthreads();
+            // step t splits tile t + 1: odd tiles live in sy, even ones in sx
+            for (; t + 3 <= nk; t += 2) { step(t, sy, std::false_type{}); step(t + 1, sx, std::false_type{}); }
+            if (t < nk) step(t, sy, std::true_type{});
+            if (t + 1 < nk) step(t + 1, sx, std::true_type{});
+        } else {
+            load_tile(tile_of(0), sx);
+            store_tile(0, sx);
+            load_tile(tile_of(1), sx);
+            __syncthreads();
+            for (; t + 2 <= nk; ++t) step(t, sx, std::false_type{});
+            if (t < nk) step(t, sx, std::true_type{});
+        }
+#ifdef GLOWHIP_DEBUG_STAMPS
+        if (BH && !VA) { GH_STAMP_VAL(0, tph[0]); GH_STAMP_VAL(1, tph[1]); GH_STAMP_VAL(2, tph[2]); GH_STAMP_VAL(3, tph[3]); GH_STAMP_VAL(5, tph[4]); GH_STAMP_VAL(4, nk);
+                         GH_STAMP_VAL(63, __builtin_amdgcn_s_getreg((31 << 11) | 4)); }
+#endif
+    }
+    if (do_rsum && nk > 0) {      // the eight chunks of a row sit in eight consecutive lanes: one fp64 atomic per row and slice
+#pragma unroll
+        for (int j = 0; j < A_F4; ++j) {
+            float v = rsum[j];
+            v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+            if (l_c == 0) atomicAdd(rowsum + tile_m * BM + l_row + 32 * j, (double)v * (double)(PS ? SH_LO_INV / a_scale : a_pre / a_scale));      // (a pre-scaled A: back to g)
+        }
+    }
+    const float inv = 1.0f / a_scale;
+    float* out = partial + ((long)split * Mpad + tile_m * BM) * Npad + tile_n * BN;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wr * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl;
+                out[(long)row * Npad + wc * WN + j * 32 + ml] = (accm[i][j][r] + accx[i][j][r] * SH_LO_INV) * inv;
+            }
+}
+
 // dW[f(m, n)] = sum_split partial[split][m][n], splits added in order.
 //   mode 0: dW[m*Nreal + n]                      (f.2: [512][512];  f.0: [512][Ch*9] = dW0[o][i][tap] flat)
 //   mode 1: m = o*9 + tap, n = i: dW[(o*Nreal + i)*9 + tap]      (f.4: dW4[o][i][tap])
@@ -534,8 +890,9 @@ size_t wgrad_mfma_partial_floats(int Mpad, int Npad, int N, int HW) {
 int launch_wgrad_mfma(const float* A, long a_bs, const float* B, long b_bs, float* partial, float* dw, int N, int HW,
                       int Mpad, int Npad, int Mreal, int Nreal, int mode, hipStream_t s, float sh_scale, double* rowsum,
                       const WgradTaps* taps, WgradReduceJob* defer, int b_valid, int b_half, int tiled) {
-    const float a_pre = (tiled & 4) ? 1.0f : sh_scale;     // bit 2: A is stored already multiplied by sh_scale (the backward k_cnet's g_u)
-    GH_REQUIRE(!b_half || (taps && taps->operand == 0) || (tiled & 4), "wgrad_mfma: with an fp16 B a plain A comes pre-scaled");
+    const bool ps = tiled & 4;          // bit 2: A holds g * sh_scale * 2^11 (the backward k_cnet's g_u2 / g_u0)
+    const float a_pre = ps ? SH_LO_INV : sh_scale;
+    GH_REQUIRE(!ps || !(taps && taps->operand == 0), "wgrad_mfma: a pre-scaled A is a plain one");
     GH_REQUIRE(!tiled || (sh_scale > 0.f && !(tiled & ~7) && !((tiled & 1) && taps && taps->operand == 0) &&
                           !((tiled & 2) && ((taps && taps->operand == 1) || b_valid > 0))),
                "wgrad_mfma: the pixel-tile-major layout is for plain operands of the split-half kernel");
@@ -560,6 +917,14 @@ int launch_wgrad_mfma(const float* A, long a_bs, const float* B, long b_bs, floa
 #define GH_WGH(bn, va)                                                                                                         \
     hipLaunchKernelGGL((k_wgrad_gemm_sh<bn, va, false, false, true>), dim3(tiles * splits), dim3(256), 0, s, A, a_bs, B, b_bs, partial, \
                        HW, Mpad, Npad, total, per, sh_scale, a_pre, rowsum, vC, vH, vW, vs, Npad, tiled)
+    if (b_half && ps) {                // f.2 behind the backward k_cnet: its own kernel
+        if (bn128)
+            hipLaunchKernelGGL((k_wgrad_gemm_ps<128, false, false, false, true, true>), dim3(tiles * splits), dim3(256), 0, s, A, a_bs, B, b_bs, partial,
+                               HW, Mpad, Npad, total, per, sh_scale, a_pre, rowsum, vC, vH, vW, vs, Npad, tiled);
+        else
+            hipLaunchKernelGGL((k_wgrad_gemm_ps<64, false, false, false, true, true>), dim3(tiles * splits), dim3(256), 0, s, A, a_bs, B, b_bs, partial,
+                               HW, Mpad, Npad, total, per, sh_scale, a_pre, rowsum, vC, vH, vW, vs, Npad, tiled);
+    } else
     if (b_half) {                      // B = h1 / h2 as fp16 from the tape
         const bool va = taps && taps->operand == 0;
         if (bn128) { if (va) GH_WGH(128, true); else GH_WGH(128, false); }
