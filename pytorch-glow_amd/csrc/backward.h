@@ -75,6 +75,12 @@ int launch_wgrad_mfma(const float* A, long a_bs, const float* B, long b_bs, floa
                       int tiled = 0);     // bit 0 / bit 1 (f16-pipe kernel, plain operand): A / B is pixel-tile-major [pixel / 32][rows][pixel % 32]
                                           // over the batch's pixels (what the taping / backward k_cnet write, sh.h), rows = Mpad / Npad; its batch stride is unused
                                           // bit 2: A holds g * sh_scale * 2^11 (the backward k_cnet's g_u2 / g_u0); row sums and dW come out as for g
+// f.4's + f.0's GEMMs of one FlowStep as one launch (wgrad_mfma.hip); GLOWHIP_EINVAL (nothing launched) for shapes it does not take
+bool wgrad_pair_ok(int HW, int m4, int hid, int n0);
+int launch_wgrad_pair(const float* gpre, long gpre_bs, const void* h2_half, float* partial4, float* dw4, int m4, int m4_real,
+                      const float* gu0, const float* y1, long y1_bs, float* partial0, float* dw0, int n0, int n0_real,
+                      int N, int HW, int hid, float sh_scale, double* rowsum0, const WgradTaps& t4, const WgradTaps& t0, int tiled4,
+                      int tiled0, struct WgradReduceJob* rj4, struct WgradReduceJob* rj0, hipStream_t s);
 // fp16 pixel-tile-major [pixel / 32][R][pixel % 32] -> fp32 (N, R, HW): a taped hidden tensor for the per-layer backward kernels
 int launch_half_to_float(const void* src_half, float* dst, int N, int R, int HW, hipStream_t s);
 struct WgradReduceJob { const float* partial; float* dw; int splits, Mpad, Npad, Mreal, Nreal, mode; };

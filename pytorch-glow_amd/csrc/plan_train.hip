@@ -418,7 +418,11 @@ static int backward_sweep(glowhip_plan* p, const void* packed, const float* x_in
                 const WgradTaps t4{0, L.Cout, d.H, d.W, -1}, t0{1, Ch, d.H, d.W, +1};
                 WgradReduceJobs rj{};      // the three split-K reductions of this step run as one launch at its end
                 rj.n = 3;
-                if (vtaps) {
+                // f.4's GEMM does not depend on the chain below, but it shares a launch with f.0's, which does (launch_wgrad_pair);
+                // shapes that launch does not take run here, alone
+                const bool pair = vtaps && wgrad_pair_ok(HW, m4, hid, n0);
+                if (pair) {      // (launched below, behind the chain)
+                } else if (vtaps) {
                     { ScopedTimer tw(p, GLOWHIP_K_WGRAD, 1, s); GH_TRY(launch_wgrad_mfma(w.gpre, (long)L.Cout * HW, h2, (long)hid * HW, w.partial, G.f4_w, N, HW, m4, hid,
                                              L.Cout * 9, hid, 1, s, sh_grad_scale, nullptr, &t4, &rj.job[0], 0, 1, 2)); }
                 } else {
@@ -444,7 +448,11 @@ static int backward_sweep(glowhip_plan* p, const void* packed, const float* x_in
                 // (its finishing step -- g_y1 += the partial sums -- rides in k_chanmix_bwd below)
                 { ScopedTimer tw(p, GLOWHIP_K_WGRAD, 1, s); GH_TRY(launch_wgrad_mfma(w.gh2, (long)hid * HW, h1, (long)hid * HW, w.partial + w.partial_floats, G.f2_w, N, HW, hid, hid,
                                          hid, hid, 0, s, sh_grad_scale, a2b, nullptr, &rj.job[1], 0, 1, 7)); }
-                if (vtaps) {
+                if (pair) {
+                    ScopedTimer tw(p, GLOWHIP_K_WGRAD, 1, s);
+                    GH_TRY(launch_wgrad_pair(w.gpre, (long)L.Cout * HW, h2, w.partial, G.f4_w, m4, L.Cout * 9, w.gh1, out, chw, w.partial + 2 * w.partial_floats,
+                                             G.f0_w, n0, Ch * 9, N, HW, hid, sh_grad_scale, a0b, t4, t0, 2, 5, &rj.job[0], &rj.job[2], s));
+                } else if (vtaps) {
                     { ScopedTimer tw(p, GLOWHIP_K_WGRAD, 1, s); GH_TRY(launch_wgrad_mfma(w.gh1, (long)hid * HW, out, chw, w.partial + 2 * w.partial_floats, G.f0_w, N, HW, hid, n0,
                                              hid, Ch * 9, 0, s, sh_grad_scale, a0b, &t0, &rj.job[2], 0, 0, 5)); }
                 } else {

@@ -165,13 +165,24 @@ k_wgrad_gemm(const float* __restrict__ A, long a_bs, const float* __restrict__ B
 // BH: operand B is an fp16 tensor (the hidden activations h1 / h2 as the taping k_cnet stores them: 2 bytes per value on the tape
 // and in this loader); it goes into LDS as it is -- no lo plane, and the a.hi x b.lo product falls away (two MFMAs per k-step
 // instead of three).  The gradient operand A keeps both planes: it is what needs the range.
+// One GEMM's arguments (the kernel body below is shared by the one-GEMM launch and by the launch that runs f.4's and f.0's GEMMs
+// side by side: k_wgrad_gemm_pair)
+struct WgArgs {
+    const float* A; long a_bs; const float* B; long b_bs; float* partial;
+    int HW, Mpad, Npad, ktiles_total, ktiles_per_split; float a_scale, a_pre; double* rowsum;
+    int vC, vH, vW, vsign, b_valid, tiled;
+    int nblocks;       // workgroups of this GEMM (tiles x splits)
+};
+template <int BN, bool BH> constexpr int wgrad_sh_lds_bytes() {
+    return (2 * 2 * 4 * (128 + 2) * 8 + 2 * (BH ? 1 : 2) * 4 * (BN + 2) * 8) * (int)sizeof(_Float16);
+}
 template <int BN, bool VA = false, bool VB = false, bool BV = false, bool BH = false>
-__global__ void __launch_bounds__(256, 2)      // two workgroups per CU: at 269 registers (141 + 128 accumulators) the kernel ran ONE
-                                               // wave per SIMD and every k-tile waited out its own HBM round trip (7.4 k cycles per
-                                               // k-tile against 768 of MFMA work)
-k_wgrad_gemm_sh(const float* __restrict__ A, long a_bs, const float* __restrict__ B, long b_bs, float* __restrict__ partial,
-                int HW, int Mpad, int Npad, int ktiles_total, int ktiles_per_split, float a_scale, float a_pre, double* __restrict__ rowsum,
-                int vC, int vH, int vW, int vsign, int b_valid, int tiled) {
+__device__ __forceinline__ void wgrad_sh_body(const WgArgs& wa, const int block /* logical: tiles of a pixel slice adjacent */, char* lds) {
+    const float* __restrict__ A = wa.A; const long a_bs = wa.a_bs; const float* __restrict__ B = wa.B; const long b_bs = wa.b_bs;
+    float* __restrict__ partial = wa.partial;
+    const int HW = wa.HW, Mpad = wa.Mpad, Npad = wa.Npad, ktiles_total = wa.ktiles_total, ktiles_per_split = wa.ktiles_per_split;
+    const float a_scale = wa.a_scale, a_pre = wa.a_pre; double* __restrict__ rowsum = wa.rowsum;
+    const int vC = wa.vC, vH = wa.vH, vW = wa.vW, vsign = wa.vsign, b_valid = wa.b_valid, tiled = wa.tiled;
     constexpr int BM = 128, BK = 32;
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
     constexpr int A_F4 = BM * BK / 4 / 256, B_F4 = BN * BK / 4 / 256;   // float4 per thread per K-tile (4, 4|2)
@@ -180,8 +191,11 @@ k_wgrad_gemm_sh(const float* __restrict__ A, long a_bs, const float* __restrict_
     // the same 4 banks (SQ_LDS_BANK_CONFLICT: 0.6 of the LDS-active cycles); now each group has its own 8 banks.  Rows stay
     // contiguous: the fragment reads (32 rows x 16 bytes) are as before.
     constexpr int GPAD = 2;                      // (rows of padding per k group)
-    __shared__ __attribute__((aligned(16))) _Float16 As[2][2][BK / 8][BM + GPAD][8];
-    __shared__ __attribute__((aligned(16))) _Float16 Bs[2][BH ? 1 : 2][BK / 8][BN + GPAD][8];
+    static_assert(wgrad_sh_lds_bytes<BN, BH>() == (int)((2 * 2 * (BK / 8) * (BM + GPAD) * 8 + 2 * (BH ? 1 : 2) * (BK / 8) * (BN + GPAD) * 8) * sizeof(_Float16)), "LDS size");
+    typedef _Float16 (*AsT)[2][BK / 8][BM + GPAD][8];
+    typedef _Float16 (*BsT)[BH ? 1 : 2][BK / 8][BN + GPAD][8];
+    const AsT As = reinterpret_cast<AsT>(lds);
+    const BsT Bs = reinterpret_cast<BsT>(lds + 2 * 2 * (BK / 8) * (BM + GPAD) * 8 * sizeof(_Float16));
     static_assert(!BH || (!VB && !BV), "an fp16 operand B is a plain one");
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wr = wid >> 1, wc = wid & 1, kl = lane >> 5, ml = lane & 31;
@@ -191,7 +205,7 @@ k_wgrad_gemm_sh(const float* __restrict__ A, long a_bs, const float* __restrict_
     // 4x the operand bytes from memory at 512 x 512).
     const int tiles_n = Npad / BN;
     const int ntiles = (Mpad / BM) * tiles_n;
-    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int logical = block;      // (the caller's xcd_remap of its block index)
     const int split = logical / ntiles, tile = logical - split * ntiles;
     const int tile_m = tile / tiles_n, tile_n = tile % tiles_n;
     const int kt0 = split * ktiles_per_split;
@@ -391,16 +405,9 @@ k_wgrad_gemm_sh(const float* __restrict__ A, long a_bs, const float* __restrict_
         // the 64 wave requests of a CU's eight waves queued up in its memory pipeline (56 B/clk: ~860 cycles for the 48 KB of two
         // k-tiles) and every wave sat behind its own requests before its first MFMA -- the requests cost 30 of 93 us at level 1
         // even when they all hit the L2.
-#ifdef GLOWHIP_DEBUG_STAMPS
-        unsigned long long tph[5] = {0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
-#define WG_PH(i) do { if (BH && !VA) { const unsigned long long c_ = __builtin_readcyclecounter(); tph[i] += c_ - tprev; tprev = c_; } } while (0)
-#else
-#define WG_PH(i) do { } while (0)
-#endif
         auto step = [&](int t, Stage& done, Stage& next, auto last) {
             const bool req = !last.value || t + NST < nk;
             const int ktn = tile_of(t + NST);
-            WG_PH(3);
             constexpr bool SPREAD = BH || BN == 64;      // (the two-plane 128-column instances have no registers for it: 16 spilled)
             if (!SPREAD && req) { load_tile(ktn, done); __builtin_amdgcn_sched_barrier(0); }
 #ifndef WG_ABL_NOMFMA
@@ -414,14 +421,8 @@ k_wgrad_gemm_sh(const float* __restrict__ A, long a_bs, const float* __restrict_
 #else
             if (SPREAD && req) load_tile(ktn, done);
 #endif
-            WG_PH(0);
-#ifdef GLOWHIP_DEBUG_STAMPS
-            if (BH && !VA && NST == 3) { asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); WG_PH(4); }     // (the next tile's values are here)
-#endif
             if (!last.value || t + 1 < nk) store_tile((t + 1) & 1, next);
-            WG_PH(1);
             __syncthreads();
-            WG_PH(2);
         };
         load_tile(tile_of(0), s0); load_tile(tile_of(1), s1);
         if constexpr (NST == 3) load_tile(tile_of(2), s2);
@@ -440,10 +441,6 @@ k_wgrad_gemm_sh(const float* __restrict__ A, long a_bs, const float* __restrict_
             if (t < nk) step(t, s0, s1, std::true_type{});
             if (t + 1 < nk) step(t + 1, s1, s0, std::true_type{});
         }
-#ifdef GLOWHIP_DEBUG_STAMPS
-        if (BH && !VA) { GH_STAMP_VAL(0, tph[0]); GH_STAMP_VAL(1, tph[1]); GH_STAMP_VAL(2, tph[2]); GH_STAMP_VAL(3, tph[3]); GH_STAMP_VAL(5, tph[4]); GH_STAMP_VAL(4, nk);
-                         GH_STAMP_VAL(63, __builtin_amdgcn_s_getreg((31 << 11) | 4)); }
-#endif
     }
     if (do_rsum && nk > 0) {      // the eight chunks of a row sit in eight consecutive lanes: one fp64 atomic per row and slice
 #pragma unroll
@@ -464,6 +461,31 @@ k_wgrad_gemm_sh(const float* __restrict__ A, long a_bs, const float* __restrict_
                 const int row = wr * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl;
                 out[(long)row * Npad + wc * WN + j * 32 + ml] = (accm[i][j][r] + accx[i][j][r] * SH_LO_INV) * inv;
             }
+}
+
+template <int BN, bool VA = false, bool VB = false, bool BV = false, bool BH = false>
+__global__ void __launch_bounds__(256, 2)      // two workgroups per CU: at 269 registers (141 + 128 accumulators) the kernel ran ONE
+                                               // wave per SIMD and every k-tile waited out its own HBM round trip (7.4 k cycles per
+                                               // k-tile against 768 of MFMA work)
+k_wgrad_gemm_sh(WgArgs a) {
+    __shared__ __attribute__((aligned(16))) char lds[wgrad_sh_lds_bytes<BN, BH>()];
+    wgrad_sh_body<BN, VA, VB, BV, BH>(a, xcd_remap(blockIdx.x, gridDim.x), lds);
+}
+
+// f.4's GEMM (gathered A, fp16 B) and f.0's (plain A, gathered B with BN0 columns) of one FlowStep in ONE launch: the first
+// a4.nblocks workgroups (a multiple of 8: xcd_remap) are f.4's.  Side by side the two fill the chip with half the pixel slices
+// each -- and the partial tiles they write and k_wgrad_reduce_batched reads back are what those launches mostly cost
+// (4 tiles x 128 slices x 64 KB = 32 MB for f.4 alone, at every level).
+template <int BN0>
+__global__ void __launch_bounds__(256, 2) k_wgrad_gemm_pair(WgArgs a4, WgArgs a0, int live4) {
+    constexpr int L4 = wgrad_sh_lds_bytes<128, true>(), L0 = wgrad_sh_lds_bytes<BN0, false>();
+    __shared__ __attribute__((aligned(16))) char lds[L4 > L0 ? L4 : L0];
+    if ((int)blockIdx.x < a4.nblocks) {      // (a4.nblocks is live4 rounded up to a multiple of 8; the blocks in between have no tile)
+        const int l = xcd_remap(blockIdx.x, a4.nblocks);
+        if (l < live4) wgrad_sh_body<128, true, false, false, true>(a4, l, lds);
+    } else {
+        wgrad_sh_body<BN0, false, true, false, false>(a0, xcd_remap(blockIdx.x - a4.nblocks, a0.nblocks), lds);
+    }
 }
 
 // The f.2 case of the kernel above -- plain A = the backward k_cnet's g_u2, stored times a_scale * 2^11 (PS), plain B = the fp16
@@ -879,12 +901,57 @@ int launch_wgrad_reduce_batched(const WgradReduceJobs& j, hipStream_t s) {
 }
 
 bool wgrad_mfma_supported(int HW, int Mpad, int Npad) { return HW % 32 == 0 && Mpad % 128 == 0 && Npad % 64 == 0; }
+static bool t1_ok(const WgradTaps& t, int HW) { return t.H * t.W == HW && t.W >= 4 && (t.W & (t.W - 1)) == 0; }
 
 size_t wgrad_mfma_partial_floats(int Mpad, int Npad, int N, int HW) {
     const int tiles = (Mpad / 128) * (Npad % 128 == 0 ? Npad / 128 : Npad / 64);
     const int total = (int)((long)N * HW / 32);
     int splits = std::max(1, std::min(total, (512 + tiles - 1) / tiles));
     return (size_t)splits * Mpad * Npad;
+}
+
+bool wgrad_pair_ok(int HW, int m4, int hid, int n0) {
+    return wgrad_mfma_supported(HW, m4, hid) && wgrad_mfma_supported(HW, hid, n0) && hid % 128 == 0 && (n0 == 64 || n0 % 128 == 0);
+}
+
+// f.4's and f.0's weight-gradient GEMMs of one FlowStep (both behind the backward k_cnet, both with a gathered 3x3 operand) as ONE
+// launch (k_wgrad_gemm_pair): the ~512 workgroups that fill the chip are shared out by MFMA work, so each GEMM is cut into half
+// as many pixel slices as it would take alone -- half the partial tiles to write and to reduce.  Returns GLOWHIP_EINVAL without
+// launching anything when the shapes are not the pair kernel's (the caller then launches the two GEMMs one by one).
+//   f.4: A = gathered g_pre (t4: Cout x 9 rows -> m4), B = h2 fp16 (hid rows);   f.0: A = g_u0 (hid rows, pre-scaled), B = gathered y1 (t0 -> n0)
+int launch_wgrad_pair(const float* gpre, long gpre_bs, const void* h2_half, float* partial4, float* dw4, int m4, int m4_real,
+                      const float* gu0, const float* y1, long y1_bs, float* partial0, float* dw0, int n0, int n0_real,
+                      int N, int HW, int hid, float sh_scale, double* rowsum0, const WgradTaps& t4, const WgradTaps& t0, int tiled4,
+                      int tiled0, WgradReduceJob* rj4, WgradReduceJob* rj0, hipStream_t s) {
+    const bool ok = sh_scale > 0.f && N > 0 && wgrad_pair_ok(HW, m4, hid, n0) && t4.operand == 0 && t1_ok(t4, HW) && t0.operand == 1 && t1_ok(t0, HW) &&
+                    tiled4 == 2 && tiled0 == 5;
+    if (!ok) return GLOWHIP_EINVAL;
+    const int total = (int)((long)N * HW / 32);
+    const int bn0 = n0 == 64 ? 64 : 128;
+    const int tiles4 = (m4 / 128) * (hid / 128), tiles0 = (hid / 128) * (n0 / bn0);
+    // MFMAs per k-tile: f.4 two per product (fp16 B), f.0 three
+    const double w4 = 2.0 * m4 * hid, w0 = 3.0 * hid * n0;
+    auto slices = [&](int tiles, double share, int* per) {
+        int sp = std::max(1, std::min(total, (int)(512.0 * share / tiles + 0.5)));
+        *per = (total + sp - 1) / sp;
+        return (total + *per - 1) / *per;
+    };
+    int per4, per0;
+    const int sp4 = slices(tiles4, w4 / (w4 + w0), &per4), sp0 = slices(tiles0, w0 / (w4 + w0), &per0);
+    const int nb4 = (tiles4 * sp4 + 7) / 8 * 8, nb0 = tiles0 * sp0;      // (f.0's blocks start on XCD 0: xcd_remap)
+    WgArgs a4{gpre, gpre_bs, reinterpret_cast<const float*>(h2_half), (long)hid * HW, partial4, HW, m4, hid, total, per4, sh_scale, sh_scale, nullptr,
+              t4.C, t4.H, t4.W, t4.sign, hid, tiled4, tiles4 * sp4};
+    WgArgs a0{gu0, (long)hid * HW, y1, y1_bs, partial0, HW, hid, n0, total, per0, sh_scale, SH_LO_INV, rowsum0,
+              t0.C, t0.H, t0.W, t0.sign, n0, tiled0, nb0};
+    // (blocks tiles4 * sp4 .. nb4 of f.4's range have no tile: the body's split index runs past its k-tiles and they only write
+    // nothing -- see the guard in the wrapper)
+    a4.nblocks = nb4;
+    if (bn0 == 64) hipLaunchKernelGGL(k_wgrad_gemm_pair<64>, dim3(nb4 + nb0), dim3(256), 0, s, a4, a0, tiles4 * sp4);
+    else hipLaunchKernelGGL(k_wgrad_gemm_pair<128>, dim3(nb4 + nb0), dim3(256), 0, s, a4, a0, tiles4 * sp4);
+    GH_LAUNCH_CHECK("k_wgrad_gemm_pair");
+    *rj4 = WgradReduceJob{partial4, dw4, sp4, m4, hid, m4_real, hid, 1};
+    *rj0 = WgradReduceJob{partial0, dw0, sp0, hid, n0, hid, n0_real, 0};
+    return GLOWHIP_OK;
 }
 
 int launch_wgrad_mfma(const float* A, long a_bs, const float* B, long b_bs, float* partial, float* dw, int N, int HW,
@@ -911,12 +978,10 @@ int launch_wgrad_mfma(const float* A, long a_bs, const float* B, long b_bs, floa
     const int per = (total + splits - 1) / splits;
     splits = (total + per - 1) / per;
     const int vC = taps ? taps->C : 0, vH = taps ? taps->H : 0, vW = taps ? taps->W : 1, vs = taps ? taps->sign : 0;
-#define GH_WG(bn, va, vb)                                                                                                      \
-    hipLaunchKernelGGL((k_wgrad_gemm_sh<bn, va, vb>), dim3(tiles * splits), dim3(256), 0, s, A, a_bs, B, b_bs, partial, HW, Mpad, \
-                       Npad, total, per, sh_scale, a_pre, rowsum, vC, vH, vW, vs, b_valid > 0 ? b_valid : Npad, tiled)
-#define GH_WGH(bn, va)                                                                                                         \
-    hipLaunchKernelGGL((k_wgrad_gemm_sh<bn, va, false, false, true>), dim3(tiles * splits), dim3(256), 0, s, A, a_bs, B, b_bs, partial, \
-                       HW, Mpad, Npad, total, per, sh_scale, a_pre, rowsum, vC, vH, vW, vs, Npad, tiled)
+    const WgArgs wa{A, a_bs, B, b_bs, partial, HW, Mpad, Npad, total, per, sh_scale, a_pre, rowsum, vC, vH, vW, vs,
+                    b_valid > 0 ? b_valid : Npad, tiled, tiles * splits};
+#define GH_WG(bn, va, vb) hipLaunchKernelGGL((k_wgrad_gemm_sh<bn, va, vb>), dim3(tiles * splits), dim3(256), 0, s, wa)
+#define GH_WGH(bn, va) hipLaunchKernelGGL((k_wgrad_gemm_sh<bn, va, false, false, true>), dim3(tiles * splits), dim3(256), 0, s, wa)
     if (b_half && ps) {                // f.2 behind the backward k_cnet: its own kernel
         if (bn128)
             hipLaunchKernelGGL((k_wgrad_gemm_ps<128, false, false, false, true, true>), dim3(tiles * splits), dim3(256), 0, s, A, a_bs, B, b_bs, partial,
@@ -936,8 +1001,7 @@ int launch_wgrad_mfma(const float* A, long a_bs, const float* B, long b_bs, floa
         else GH_WG(128, false, false);
     } else if (sh_scale > 0.f) {
         if (taps && taps->operand == 0 && b_valid > 0)
-            hipLaunchKernelGGL((k_wgrad_gemm_sh<64, true, false, true>), dim3(tiles * splits), dim3(256), 0, s, A, a_bs, B, b_bs, partial, HW,
-                               Mpad, Npad, total, per, sh_scale, a_pre, rowsum, vC, vH, vW, vs, b_valid, tiled);
+            hipLaunchKernelGGL((k_wgrad_gemm_sh<64, true, false, true>), dim3(tiles * splits), dim3(256), 0, s, wa);
         else if (taps && taps->operand == 0) GH_WG(64, true, false);
         else if (taps) GH_WG(64, false, true);
         else GH_WG(64, false, false);
