@@ -81,6 +81,12 @@ int launch_wgrad_pair(const float* gpre, long gpre_bs, const void* h2_half, floa
                       const float* gu0, const float* y1, long y1_bs, float* partial0, float* dw0, int n0, int n0_real,
                       int N, int HW, int hid, float sh_scale, double* rowsum0, const WgradTaps& t4, const WgradTaps& t0, int tiled4,
                       int tiled0, struct WgradReduceJob* rj4, struct WgradReduceJob* rj0, hipStream_t s);
+// ... and f.2's (A = g_u2, B = h1 fp16, both pixel-tile-major, A pre-scaled) as the third
+int launch_wgrad_trio(const float* gu2, const void* h1_half, float* partial2, float* dw2, double* rowsum2,
+                      const float* gpre, long gpre_bs, const void* h2_half, float* partial4, float* dw4, int m4, int m4_real,
+                      const float* gu0, const float* y1, long y1_bs, float* partial0, float* dw0, int n0, int n0_real,
+                      int N, int HW, int hid, float sh_scale, double* rowsum0, const WgradTaps& t4, const WgradTaps& t0,
+                      struct WgradReduceJob* rj2, struct WgradReduceJob* rj4, struct WgradReduceJob* rj0, hipStream_t s);
 // fp16 pixel-tile-major [pixel / 32][R][pixel % 32] -> fp32 (N, R, HW): a taped hidden tensor for the per-layer backward kernels
 int launch_half_to_float(const void* src_half, float* dst, int N, int R, int HW, hipStream_t s);
 struct WgradReduceJob { const float* partial; float* dw; int splits, Mpad, Npad, Mreal, Nreal, mode; };

@@ -418,9 +418,12 @@ static int backward_sweep(glowhip_plan* p, const void* packed, const float* x_in
                 const WgradTaps t4{0, L.Cout, d.H, d.W, -1}, t0{1, Ch, d.H, d.W, +1};
                 WgradReduceJobs rj{};      // the three split-K reductions of this step run as one launch at its end
                 rj.n = 3;
-                // f.4's GEMM does not depend on the chain below, but it shares a launch with f.0's, which does (launch_wgrad_pair);
-                // shapes that launch does not take run here, alone
+                // f.4's GEMM does not depend on the chain below, but it shares a launch with f.2's and f.0's, which do
+                // (launch_wgrad_trio); shapes that launch does not take run here, alone
                 const bool pair = vtaps && wgrad_pair_ok(HW, m4, hid, n0);
+                // short pixel axes (<= 512 k-tiles of 32 pixels): f.2's GEMM joins the launch as well -- at 12 - 18 pixel slices
+                // instead of 32 its workgroups' loops are two to three times as long and a third of the partial tiles is left
+                const bool trio = pair && (long)N * HW / 32 <= 512;
                 if (pair) {      // (launched below, behind the chain)
                 } else if (vtaps) {
                     { ScopedTimer tw(p, GLOWHIP_K_WGRAD, 1, s); GH_TRY(launch_wgrad_mfma(w.gpre, (long)L.Cout * HW, h2, (long)hid * HW, w.partial, G.f4_w, N, HW, m4, hid,
@@ -446,9 +449,17 @@ static int backward_sweep(glowhip_plan* p, const void* packed, const float* x_in
                     GH_TRY(launch_cnet_main(c, s, &pend));
                 }
                 // (its finishing step -- g_y1 += the partial sums -- rides in k_chanmix_bwd below)
-                { ScopedTimer tw(p, GLOWHIP_K_WGRAD, 1, s); GH_TRY(launch_wgrad_mfma(w.gh2, (long)hid * HW, h1, (long)hid * HW, w.partial + w.partial_floats, G.f2_w, N, HW, hid, hid,
-                                         hid, hid, 0, s, sh_grad_scale, a2b, nullptr, &rj.job[1], 0, 1, 7)); }
-                if (pair) {
+                if (trio) {      // all three GEMMs side by side in one launch
+                    ScopedTimer tw(p, GLOWHIP_K_WGRAD, 1, s);
+                    GH_TRY(launch_wgrad_trio(w.gh2, h1, w.partial + w.partial_floats, G.f2_w, a2b, w.gpre, (long)L.Cout * HW, h2, w.partial, G.f4_w, m4, L.Cout * 9,
+                                             w.gh1, out, chw, w.partial + 2 * w.partial_floats, G.f0_w, n0, Ch * 9, N, HW, hid, sh_grad_scale, a0b, t4, t0,
+                                             &rj.job[1], &rj.job[0], &rj.job[2], s));
+                } else {
+                    ScopedTimer tw(p, GLOWHIP_K_WGRAD, 1, s); GH_TRY(launch_wgrad_mfma(w.gh2, (long)hid * HW, h1, (long)hid * HW, w.partial + w.partial_floats, G.f2_w, N, HW, hid, hid,
+                                         hid, hid, 0, s, sh_grad_scale, a2b, nullptr, &rj.job[1], 0, 1, 7));
+                }
+                if (trio) {
+                } else if (pair) {
                     ScopedTimer tw(p, GLOWHIP_K_WGRAD, 1, s);
                     GH_TRY(launch_wgrad_pair(w.gpre, (long)L.Cout * HW, h2, w.partial, G.f4_w, m4, L.Cout * 9, w.gh1, out, chw, w.partial + 2 * w.partial_floats,
                                              G.f0_w, n0, Ch * 9, N, HW, hid, sh_grad_scale, a0b, t4, t0, 2, 5, &rj.job[0], &rj.job[2], s));

@@ -493,12 +493,13 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_gemm_pair(WgArgs a4, WgArgs a0
 // parameters; the gathered / two-plane instances measured slower in this form -- a gathered value's in-image select pinned
 // into the slot of its request waits out the request -- and stay on the kernel above.)
 template <int BN, bool VA = false, bool VB = false, bool BV = false, bool BH = false, bool PS = false>
-__global__ void __launch_bounds__(256, 2)      // two workgroups per CU: at 269 registers (141 + 128 accumulators) the kernel ran ONE
-                                               // wave per SIMD and every k-tile waited out its own HBM round trip (7.4 k cycles per
-                                               // k-tile against 768 of MFMA work)
-k_wgrad_gemm_ps(const float* __restrict__ A, long a_bs, const float* __restrict__ B, long b_bs, float* __restrict__ partial,
-                int HW, int Mpad, int Npad, int ktiles_total, int ktiles_per_split, float a_scale, float a_pre, double* __restrict__ rowsum,
-                int vC, int vH, int vW, int vsign, int b_valid, int tiled) {
+__device__ __forceinline__ void wgrad_ps_body(const WgArgs& wa, const int block /* logical, as in wgrad_sh_body */, char* lds) {
+    const float* __restrict__ A = wa.A; const long a_bs = wa.a_bs; const float* __restrict__ B = wa.B; const long b_bs = wa.b_bs;
+    float* __restrict__ partial = wa.partial;
+    const int HW = wa.HW, Mpad = wa.Mpad, Npad = wa.Npad, ktiles_total = wa.ktiles_total, ktiles_per_split = wa.ktiles_per_split;
+    const float a_scale = wa.a_scale, a_pre = wa.a_pre; double* __restrict__ rowsum = wa.rowsum;
+    const int vC = wa.vC, vH = wa.vH, vW = wa.vW, vsign = wa.vsign, b_valid = wa.b_valid, tiled = wa.tiled;
+    (void)a_bs; (void)b_bs; (void)vC; (void)vH; (void)vW; (void)vsign; (void)b_valid;
     constexpr int BM = 128, BK = 32;
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
     constexpr int A_F4 = BM * BK / 4 / 256, B_F4 = BN * BK / 4 / 256;   // float4 per thread per K-tile (4, 4|2)
@@ -507,8 +508,10 @@ k_wgrad_gemm_ps(const float* __restrict__ A, long a_bs, const float* __restrict_
     // the same 4 banks (SQ_LDS_BANK_CONFLICT: 0.6 of the LDS-active cycles); now each group has its own 8 banks.  Rows stay
     // contiguous: the fragment reads (32 rows x 16 bytes) are as before.
     constexpr int GPAD = 2;                      // (rows of padding per k group)
-    __shared__ __attribute__((aligned(16))) _Float16 As[2][2][BK / 8][BM + GPAD][8];
-    __shared__ __attribute__((aligned(16))) _Float16 Bs[2][BH ? 1 : 2][BK / 8][BN + GPAD][8];
+    typedef _Float16 (*AsT)[2][BK / 8][BM + GPAD][8];
+    typedef _Float16 (*BsT)[BH ? 1 : 2][BK / 8][BN + GPAD][8];
+    const AsT As = reinterpret_cast<AsT>(lds);
+    const BsT Bs = reinterpret_cast<BsT>(lds + 2 * 2 * (BK / 8) * (BM + GPAD) * 8 * sizeof(_Float16));
     static_assert(!BH || (!VB && !BV), "an fp16 operand B is a plain one");
     static_assert(!PS || !VA, "a pre-scaled A is a plain one");
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -519,7 +522,7 @@ k_wgrad_gemm_ps(const float* __restrict__ A, long a_bs, const float* __restrict_
     // 4x the operand bytes from memory at 512 x 512).
     const int tiles_n = Npad / BN;
     const int ntiles = (Mpad / BM) * tiles_n;
-    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int logical = block;
     const int split = logical / ntiles, tile = logical - split * ntiles;
     const int tile_m = tile / tiles_n, tile_n = tile % tiles_n;
     const int kt0 = split * ktiles_per_split;
@@ -845,6 +848,32 @@ k_wgrad_gemm_ps(const float* __restrict__ A, long a_bs, const float* __restrict_
             }
 }
 
+template <int BN>
+__global__ void __launch_bounds__(256, 2) k_wgrad_gemm_ps(WgArgs a) {
+    __shared__ __attribute__((aligned(16))) char lds[wgrad_sh_lds_bytes<BN, true>()];
+    wgrad_ps_body<BN, false, false, false, true, true>(a, xcd_remap(blockIdx.x, gridDim.x), lds);
+}
+
+// All three weight-gradient GEMMs of a FlowStep behind the backward k_cnet in ONE launch: blocks [0, a2.nblocks) are f.2's
+// (wgrad_ps_body), the next a4.nblocks f.4's, the rest f.0's (both counts multiples of 8: xcd_remap; live2 / live4 of them have
+// a tile).  What k_wgrad_gemm_pair did for two: ~512 workgroups shared out by MFMA work, each GEMM cut into as few pixel slices
+// as its share allows -- 30 MB of partial tiles per level-1 step instead of 80 when each GEMM filled the chip alone.
+template <int BN0>
+__global__ void __launch_bounds__(256, 2) k_wgrad_gemm_trio(WgArgs a2, WgArgs a4, WgArgs a0, int live2, int live4) {
+    constexpr int L2 = wgrad_sh_lds_bytes<128, true>(), L0 = wgrad_sh_lds_bytes<BN0, false>();
+    __shared__ __attribute__((aligned(16))) char lds[L2 > L0 ? L2 : L0];
+    const int b = blockIdx.x;
+    if (b < a2.nblocks) {
+        const int l = xcd_remap(b, a2.nblocks);
+        if (l < live2) wgrad_ps_body<128, false, false, false, true, true>(a2, l, lds);
+    } else if (b < a2.nblocks + a4.nblocks) {
+        const int l = xcd_remap(b - a2.nblocks, a4.nblocks);
+        if (l < live4) wgrad_sh_body<128, true, false, false, true>(a4, l, lds);
+    } else {
+        wgrad_sh_body<BN0, false, true, false, false>(a0, xcd_remap(b - a2.nblocks - a4.nblocks, a0.nblocks), lds);
+    }
+}
+
 // dW[f(m, n)] = sum_split partial[split][m][n], splits added in order.
 //   mode 0: dW[m*Nreal + n]                      (f.2: [512][512];  f.0: [512][Ch*9] = dW0[o][i][tap] flat)
 //   mode 1: m = o*9 + tap, n = i: dW[(o*Nreal + i)*9 + tap]      (f.4: dW4[o][i][tap])
@@ -954,6 +983,46 @@ int launch_wgrad_pair(const float* gpre, long gpre_bs, const void* h2_half, floa
     return GLOWHIP_OK;
 }
 
+// The same with f.2's GEMM (A = g_u2, B = h1 fp16, both pixel-tile-major; wgrad_ps_body) as the third: k_wgrad_gemm_trio.
+int launch_wgrad_trio(const float* gu2, const void* h1_half, float* partial2, float* dw2, double* rowsum2,
+                      const float* gpre, long gpre_bs, const void* h2_half, float* partial4, float* dw4, int m4, int m4_real,
+                      const float* gu0, const float* y1, long y1_bs, float* partial0, float* dw0, int n0, int n0_real,
+                      int N, int HW, int hid, float sh_scale, double* rowsum0, const WgradTaps& t4, const WgradTaps& t0,
+                      WgradReduceJob* rj2, WgradReduceJob* rj4, WgradReduceJob* rj0, hipStream_t s) {
+    const bool ok = sh_scale > 0.f && N > 0 && wgrad_pair_ok(HW, m4, hid, n0) && t4.operand == 0 && t1_ok(t4, HW) && t0.operand == 1 && t1_ok(t0, HW);
+    if (!ok) return GLOWHIP_EINVAL;
+    const int total = (int)((long)N * HW / 32);
+    const int bn0 = n0 == 64 ? 64 : 128;
+    const int tiles2 = (hid / 128) * (hid / 128), tiles4 = (m4 / 128) * (hid / 128), tiles0 = (hid / 128) * (n0 / bn0);
+    // Shares by MFMAs per k-tile: two per product with an fp16 B (f.2, f.4), three for f.0.  (By measured cost per (workgroup,
+    // k-tile) -- 1.37 us for f.2's kernel, 2.4 - 2.7 us for the gathering ones -- the launch got slower: f.2's steps slow down
+    // next to gathering workgroups on the same CU.  With long pixel axes (level 1 of config B: 2 048 k-tiles) the launch is slower
+    // than f.2 and the pair one after the other either way, 185 vs 87 + 73 us: the caller takes it only for short ones.)
+    const double w2 = 2.0 * hid * hid, w4 = 2.0 * m4 * hid, w0 = 3.0 * hid * n0, wsum = w2 + w4 + w0;
+    auto slices = [&](int tiles, double share, int* per) {
+        int sp = std::max(1, std::min(total, (int)(512.0 * share / tiles + 0.5)));
+        *per = (total + sp - 1) / sp;
+        return (total + *per - 1) / *per;
+    };
+    int per2, per4, per0;
+    const int sp2 = slices(tiles2, w2 / wsum, &per2), sp4 = slices(tiles4, w4 / wsum, &per4), sp0 = slices(tiles0, w0 / wsum, &per0);
+    const int live2 = tiles2 * sp2, live4 = tiles4 * sp4, nb2 = (live2 + 7) / 8 * 8, nb4 = (live4 + 7) / 8 * 8, nb0 = tiles0 * sp0;
+    const long hb = (long)hid * HW;
+    WgArgs a2{gu2, hb, reinterpret_cast<const float*>(h1_half), hb, partial2, HW, hid, hid, total, per2, sh_scale, SH_LO_INV, rowsum2,
+              0, 0, 1, 0, hid, 7, nb2};
+    WgArgs a4{gpre, gpre_bs, reinterpret_cast<const float*>(h2_half), hb, partial4, HW, m4, hid, total, per4, sh_scale, sh_scale, nullptr,
+              t4.C, t4.H, t4.W, t4.sign, hid, 2, nb4};
+    WgArgs a0{gu0, hb, y1, y1_bs, partial0, HW, hid, n0, total, per0, sh_scale, SH_LO_INV, rowsum0,
+              t0.C, t0.H, t0.W, t0.sign, n0, 5, nb0};
+    if (bn0 == 64) hipLaunchKernelGGL(k_wgrad_gemm_trio<64>, dim3(nb2 + nb4 + nb0), dim3(256), 0, s, a2, a4, a0, live2, live4);
+    else hipLaunchKernelGGL(k_wgrad_gemm_trio<128>, dim3(nb2 + nb4 + nb0), dim3(256), 0, s, a2, a4, a0, live2, live4);
+    GH_LAUNCH_CHECK("k_wgrad_gemm_trio");
+    *rj2 = WgradReduceJob{partial2, dw2, sp2, hid, hid, hid, hid, 0};
+    *rj4 = WgradReduceJob{partial4, dw4, sp4, m4, hid, m4_real, hid, 1};
+    *rj0 = WgradReduceJob{partial0, dw0, sp0, hid, n0, hid, n0_real, 0};
+    return GLOWHIP_OK;
+}
+
 int launch_wgrad_mfma(const float* A, long a_bs, const float* B, long b_bs, float* partial, float* dw, int N, int HW,
                       int Mpad, int Npad, int Mreal, int Nreal, int mode, hipStream_t s, float sh_scale, double* rowsum,
                       const WgradTaps* taps, WgradReduceJob* defer, int b_valid, int b_half, int tiled) {
@@ -983,12 +1052,8 @@ int launch_wgrad_mfma(const float* A, long a_bs, const float* B, long b_bs, floa
 #define GH_WG(bn, va, vb) hipLaunchKernelGGL((k_wgrad_gemm_sh<bn, va, vb>), dim3(tiles * splits), dim3(256), 0, s, wa)
 #define GH_WGH(bn, va) hipLaunchKernelGGL((k_wgrad_gemm_sh<bn, va, false, false, true>), dim3(tiles * splits), dim3(256), 0, s, wa)
     if (b_half && ps) {                // f.2 behind the backward k_cnet: its own kernel
-        if (bn128)
-            hipLaunchKernelGGL((k_wgrad_gemm_ps<128, false, false, false, true, true>), dim3(tiles * splits), dim3(256), 0, s, A, a_bs, B, b_bs, partial,
-                               HW, Mpad, Npad, total, per, sh_scale, a_pre, rowsum, vC, vH, vW, vs, Npad, tiled);
-        else
-            hipLaunchKernelGGL((k_wgrad_gemm_ps<64, false, false, false, true, true>), dim3(tiles * splits), dim3(256), 0, s, A, a_bs, B, b_bs, partial,
-                               HW, Mpad, Npad, total, per, sh_scale, a_pre, rowsum, vC, vH, vW, vs, Npad, tiled);
+        if (bn128) hipLaunchKernelGGL(k_wgrad_gemm_ps<128>, dim3(tiles * splits), dim3(256), 0, s, wa);
+        else hipLaunchKernelGGL(k_wgrad_gemm_ps<64>, dim3(tiles * splits), dim3(256), 0, s, wa);
     } else
     if (b_half) {                      // B = h1 / h2 as fp16 from the tape
         const bool va = taps && taps->operand == 0;
