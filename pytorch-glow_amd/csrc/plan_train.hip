@@ -450,6 +450,7 @@ static int backward_sweep(glowhip_plan* p, const void* packed, const float* x_in
                 }
                 // (its finishing step -- g_y1 += the partial sums -- rides in k_chanmix_bwd below)
                 if (trio) {      // all three GEMMs side by side in one launch
+                    count_launch(p, "k_wgrad(trio)");
                     ScopedTimer tw(p, GLOWHIP_K_WGRAD, 1, s);
                     GH_TRY(launch_wgrad_trio(w.gh2, h1, w.partial + w.partial_floats, G.f2_w, a2b, w.gpre, (long)L.Cout * HW, h2, w.partial, G.f4_w, m4, L.Cout * 9,
                                              w.gh1, out, chw, w.partial + 2 * w.partial_floats, G.f0_w, n0, Ch * 9, N, HW, hid, sh_grad_scale, a0b, t4, t0,
@@ -460,6 +461,7 @@ static int backward_sweep(glowhip_plan* p, const void* packed, const float* x_in
                 }
                 if (trio) {
                 } else if (pair) {
+                    count_launch(p, "k_wgrad(pair)");
                     ScopedTimer tw(p, GLOWHIP_K_WGRAD, 1, s);
                     GH_TRY(launch_wgrad_pair(w.gpre, (long)L.Cout * HW, h2, w.partial, G.f4_w, m4, L.Cout * 9, w.gh1, out, chw, w.partial + 2 * w.partial_floats,
                                              G.f0_w, n0, Ch * 9, N, HW, hid, sh_grad_scale, a0b, t4, t0, 2, 5, &rj.job[0], &rj.job[2], s));

@@ -431,6 +431,46 @@ def test_training_step_runs_on_k_cnet_and_agrees_with_the_per_layer_kernels():
                 (hex(flag), name, scale, err.max().item())
 
 
+def test_grouped_weight_gradient_launches_agree_with_the_per_layer_kernels():
+    """The weight-gradient GEMMs of a FlowStep behind the backward k_cnet run grouped: all three in one launch where the pixel axis
+    is short (<= 512 k-tiles of 32 pixels), f.2's own kernel + f.4 / f.0 as a pair where it is long (level 1 from 17 images on).
+    Batch 20 has both (level 1: 640 k-tiles, levels 2 / 3: 160 / 40): asserted from the launch counters, every gradient compared
+    with the same step's per-layer backward (debug flag 0x80000000: plain fp32 tape reads, one GEMM per launch, which the oracle
+    tests pin separately)."""
+    from pytorch_glow_amd import _lib
+    K, batch = 1, 20
+    cfg = O.default_cfg(K=K, batch=batch)
+    sd = O.seeded_state_dict(cfg, seed=33, invconv_perturb=0.02, zeros_std=0.01)
+    g = torch.Generator().manual_seed(33)
+    x = torch.rand(batch, 3, 64, 64, generator=g)
+    noise = torch.rand(batch, 3, 64, 64, generator=g) / 256
+    sd = O.glow_init_actnorm(x[:4], noise[:4], sd, cfg)
+    res = {}
+    try:
+        for flag in (0x80000000, 0):
+            _lib.lib().glowhip_debug_force_tail_tile(flag - (1 << 32) if flag >= (1 << 31) else flag)
+            glow = G.Glow(hps_for(cfg, batch))
+            glow.load_state_dict(sd)
+            glow.set_actnorm_inited()
+            glow = glow.to(DEV).train()
+            with torch.enable_grad():
+                z, nll, _ = glow.normal_flow(x.to(DEV), None, noise=noise.to(DEV))
+                G.Glow.generative_loss(nll).backward()
+            counts = glow.flow.plan_for(x.to(DEV)).launch_counts()
+            res[flag] = ({n: p.grad.cpu().double() for n, p in glow.named_parameters() if p.grad is not None}, counts)
+    finally:
+        _lib.lib().glowhip_debug_force_tail_tile(0)
+    g0, c0 = res[0x80000000]
+    g1, c1 = res[0]
+    assert c0.get("k_wgrad(trio)", 0) == 0 and c0.get("k_wgrad(pair)", 0) == 0, c0
+    assert c1.get("k_wgrad(pair)", 0) == K and c1.get("k_wgrad(trio)", 0) == 2 * K and c1.get("k_cnet(bwd)", 0) == 3 * K, c1
+    for name, a in g0.items():
+        scale = a.abs().max().item()
+        err = (g1[name] - a).abs()
+        assert err.pow(2).mean().sqrt().item() <= 1e-3 * scale + 1e-9 and err.max().item() <= 0.05 * scale + 1e-8, \
+            (name, scale, err.max().item())
+
+
 @pytest.mark.parametrize("kind", ["adam", "adamax"])
 def test_hip_optimizer_matches_torch_optim(kind):
     """csrc/optim.hip against torch.optim.Adam / Adamax + clip_grad_value_ + clip_grad_norm_ (network/trainer.py:142-150) over
