@@ -48,6 +48,7 @@ struct ChanMixBwdArgs {
     // in add_part: MS row-split copies + halo rows, geometry add_*) -- gathered here instead of by a k_cbwd_finish launch
     const float* add_part = nullptr; float add_scale = 0.f;
     int add_C = 0, add_MS = 0, add_tiles = 0, add_R = 0, add_NI = 0, add_lpxt = 0, add_H = 0, add_W = 0;
+    int w_lds = 0;     // (set by launch_chanmix_bwd: the matrix is staged in LDS)
 };
 int launch_chanmix_bwd(const ChanMixBwdArgs& a, hipStream_t s);
 

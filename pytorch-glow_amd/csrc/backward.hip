@@ -16,6 +16,7 @@
 // below fp32 resolution after the final rounding) and converted by k_grad_finalize.
 #include "kernels.h"
 #include "backward.h"
+#include <type_traits>
 #include "sh.h"
 #include "cnet_fin.h"
 
@@ -364,6 +365,15 @@ __global__ void __launch_bounds__(256) k_chanmix_bwd(ChanMixBwdArgs a) {
     float* v = sm;                   // [C][64]
     float* gy = sm + C * CB_LD;      // [C][64 (+1)]
     float* gv = gy + C * CB_LD;      // [C][64 (+1)]
+    // W in LDS where it fits (launch_chanmix_bwd: a.w_lds): the g_v loop below read it from memory eight elements per trip, C / 8
+    // trips per output channel, twelve channels per thread at C = 48 -- 72 round trips to the L2 in a row, most of the launch's 39 us
+    float* wl = gv + C * CB_LD;      // [C][C]
+    if (a.matrix && a.w_lds) {
+        for (int e0 = threadIdx.x * 4; e0 < C * C; e0 += 1024) {
+            const f32x4_t w4 = *reinterpret_cast<const f32x4_t*>(a.matrix + e0);       // (C * C is a multiple of 4: C is even)
+            *reinterpret_cast<f32x4_t*>(wl + e0) = w4;
+        }
+    }
     const int px = threadIdx.x & (CB_PX - 1);
     const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // wave-uniform: the matrix element W[o][i] of the g_v loop
                                                                            // below is then a scalar load (it was a vector load per
@@ -380,26 +390,53 @@ __global__ void __launch_bounds__(256) k_chanmix_bwd(ChanMixBwdArgs a) {
         pd.mode = TAIL_ADD_FWD; pd.Cout = a.add_C;
         addf = fin_src(pd, a.N, a.add_H, a.add_W, a.HW, __builtin_ctz(a.add_W));
     }
-    for (int c = grp; c < C; c += 4) {
-        float xv = 0.f, g = 0.f;
-        if (valid) {
-            xv = (a.x[n * a.x_bs + (long)c * a.HW + p] + a.bias[c]) * a.scale[c];
-            g = a.gy[n * a.g_bs + (long)c * a.HW + p];
-            if (a.add_part && c < a.add_C) {      // + d L / d y1 from the backward k_cnet launch's partial sums (cnet_fin.h)
-                float se, so;
-                fin_gather_t<0, true>(addf, n, c, p, se, so);
-                g += se * a.add_scale;
+    // Staging, four channels of the thread at a time: every load of the four -- x, g_y, and for the first add_C channels the MS
+    // partial sums + 2 MS halo rows of the backward k_cnet launch (cnet_fin.h; the row split as a template argument unrolls them) --
+    // is unconditional from a clamped address and issued before the first LDS store.  One channel per iteration with the gather
+    // behind a branch was 2 round trips per channel: 24 in a row at C = 48, most of that launch's 37 us.
+    auto stage = [&](auto msv) {
+        constexpr int MSV = decltype(msv)::value, U = 4;
+        const long nn = valid ? n : 0;
+        const int pp = valid ? p : 0;
+        for (int c0 = grp; c0 < C; c0 += 4 * U) {
+            float xr[U], gr[U], se[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int c = min(c0 + 4 * u, C - 1);
+                xr[u] = a.x[nn * a.x_bs + (long)c * a.HW + pp];
+                gr[u] = a.gy[nn * a.g_bs + (long)c * a.HW + pp];
+                se[u] = 0.f;
+            }
+            if (a.add_part) {      // (uniform)
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    float so;
+                    fin_gather_t<MSV, true>(addf, nn, min(c0 + 4 * u, a.add_C - 1), pp, se[u], so);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int c = c0 + 4 * u;
+                if (c < C) {
+                    const float g = gr[u] + ((a.add_part && c < a.add_C) ? se[u] * a.add_scale : 0.f);
+                    v[c * CB_LD + px] = valid ? (xr[u] + a.bias[c]) * a.scale[c] : 0.f;
+                    gy[c * CB_LD + px] = valid ? g : 0.f;
+                }
             }
         }
-        v[c * CB_LD + px] = xv;
-        gy[c * CB_LD + px] = g;
-    }
+    };
+    if (a.add_MS == 1) stage(std::integral_constant<int, 1>{});
+    else if (a.add_MS == 2) stage(std::integral_constant<int, 2>{});
+    else if (a.add_MS == 4) stage(std::integral_constant<int, 4>{});
+    else stage(std::integral_constant<int, 0>{});
     __syncthreads();
     // g_v = W^T g_y : g_v[i] = sum_o W[o][i] g_y[o]   (gather: g_v[idx[o]] = g_y[o])
     for (int i = grp; i < C; i += 4) {
         float r = 0.f;
         if (a.matrix) {
-            for (int o = 0; o < C; ++o) r = fmaf(a.matrix[o * C + i], gy[o * CB_LD + px], r);
+            if (a.w_lds) { for (int o = 0; o < C; ++o) r = fmaf(wl[o * C + i], gy[o * CB_LD + px], r); }
+            else { for (int o = 0; o < C; ++o) r = fmaf(a.matrix[o * C + i], gy[o * CB_LD + px], r); }
         } else {
             r = gy[(a.gather_inv ? a.gather_inv[i] : i) * CB_LD + px];
         }
@@ -410,13 +447,14 @@ __global__ void __launch_bounds__(256) k_chanmix_bwd(ChanMixBwdArgs a) {
     // reductions over the 64 pixels of this workgroup
     const int tid = threadIdx.x;
     const long aco = (long)(blockIdx.x % a.acc_copies) * a.acc_stride;      // this workgroup's copy of the accumulators
+    const bool own = (int)gridDim.x <= a.acc_copies;      // ... and nobody else's (zeroed per step): plain stores
     if (a.matrix) {
         for (int pair = tid; pair < C * C; pair += 256) {
             const int o = pair / C, i = pair - o * C;
             float s = 0.f;
 #pragma unroll 8
             for (int q = 0; q < CB_PX; ++q) s = fmaf(gy[o * CB_LD + q], v[i * CB_LD + q], s);
-            atomic_add_f64(a.acc_w + aco + pair, (double)s);
+            if (own) a.acc_w[aco + pair] = (double)s; else atomic_add_f64(a.acc_w + aco + pair, (double)s);
         }
     }
     for (int c = tid; c < C; c += 256) {
@@ -425,8 +463,8 @@ __global__ void __launch_bounds__(256) k_chanmix_bwd(ChanMixBwdArgs a) {
             sb = fmaf(gv[c * CB_LD + q], a.scale[c], sb);
             sl = fmaf(gv[c * CB_LD + q], v[c * CB_LD + q], sl);
         }
-        atomic_add_f64(a.acc_b + aco + c, (double)sb);
-        atomic_add_f64(a.acc_l + aco + c, (double)sl * 3.0);
+        if (own) { a.acc_b[aco + c] = (double)sb; a.acc_l[aco + c] = (double)sl * 3.0; }
+        else { atomic_add_f64(a.acc_b + aco + c, (double)sb); atomic_add_f64(a.acc_l + aco + c, (double)sl * 3.0); }
     }
 }
 
@@ -434,10 +472,13 @@ int launch_chanmix_bwd(const ChanMixBwdArgs& a, hipStream_t s) {
     GH_REQUIRE(a.C > 0 && a.C <= 192, "chanmix backward: C=%d unsupported (1..192)", a.C);
     const long total = (long)a.N * a.HW;
     if (total == 0) return GLOWHIP_OK;
-    const size_t lds = (size_t)3 * a.C * CB_LD * sizeof(float);
+    size_t lds = (size_t)3 * a.C * CB_LD * sizeof(float);
+    ChanMixBwdArgs b = a;
+    b.w_lds = a.matrix && lds + (size_t)a.C * a.C * sizeof(float) <= 64 * 1024 && (reinterpret_cast<uintptr_t>(a.matrix) & 15) == 0;
+    if (b.w_lds) lds += (size_t)a.C * a.C * sizeof(float);
     if (lds > 32 * 1024)
         (void)hipFuncSetAttribute((const void*)k_chanmix_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_chanmix_bwd, dim3(cdiv(total, CB_PX)), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(k_chanmix_bwd, dim3(cdiv(total, CB_PX)), dim3(256), lds, s, b);
     GH_LAUNCH_CHECK("k_chanmix_bwd");
     return GLOWHIP_OK;
 }
