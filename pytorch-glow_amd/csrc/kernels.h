@@ -104,7 +104,7 @@ struct RepackJob {
 // dst[i][o][ks-1-tap] = src[o][i][tap] (ks = 9: 3x3 weights, 1: a plain transpose): the weight of the input-gradient convolution,
 // in the reference layout, for the SH2 image kernels of the backward k_cnet launch (plan_train.hip)
 struct FlipJob { const float* src; size_t dst_off; int O, I, ks; };
-int launch_flipT_batched(const FlipJob* jobs_dev, int n_jobs, int max_tiles, void* packed, hipStream_t s);
+int launch_flipT_batched(const FlipJob* jobs_dev, int n_jobs, const int* max_tiles3 /* per member of a (f.4, f.2, f.0) triple */, void* packed, hipStream_t s);
 // rj_dev: the repack jobs SORTED by kind group (legacy kinds | SH2_GEMM | SH2_FIRST | SH2_TAIL), n_kind[4] their counts;
 // tail_blocks: workgroups per SH2_TAIL job (8 output channels each)
 // s_legacy: the stream of the legacy-kind image kernel (the same as s, or a side stream forked from it)

@@ -402,9 +402,12 @@ __global__ void __launch_bounds__(256) k_repack_sh2_batched(const RepackJob* __r
 
 // dst[i][o][ks-1-tap] = src[o][i][tap]: a workgroup moves a 32 (o) x 32 (i) tile through LDS -- reads are runs of 32 ks floats of
 // one source row, writes runs of 32 ks floats of one destination row
-__global__ void __launch_bounds__(256) k_flipT_batched(const FlipJob* __restrict__ jobs, char* packed) {
+// (jobs come in triples -- f.4, f.2, f.0 of a FlowStep -- with 16 .. 32, 256 and 16 tiles at hidden 512: one launch per member
+// (first, stride 3) with that member's tile count, not one grid of 256 x jobs whose two other thirds were 45 k workgroups that
+// looked at their job and left: 317 -> 1xx us per pack)
+__global__ void __launch_bounds__(256) k_flipT_batched(const FlipJob* __restrict__ jobs, char* packed, int first, int stride) {
     __shared__ float tile[32][32 * 9 + 1];
-    const FlipJob j = jobs[blockIdx.y];
+    const FlipJob j = jobs[first + blockIdx.y * stride];
     const int ti = (j.I + 31) / 32, to = (j.O + 31) / 32;
     if ((int)blockIdx.x >= ti * to) return;
     const int o0 = (blockIdx.x / ti) * 32, i0 = (blockIdx.x % ti) * 32;
@@ -424,10 +427,13 @@ __global__ void __launch_bounds__(256) k_flipT_batched(const FlipJob* __restrict
     }
 }
 
-int launch_flipT_batched(const FlipJob* jobs_dev, int n_jobs, int max_tiles, void* packed, hipStream_t s) {
+int launch_flipT_batched(const FlipJob* jobs_dev, int n_jobs, const int* max_tiles3, void* packed, hipStream_t s) {
     if (n_jobs == 0) return GLOWHIP_OK;
-    hipLaunchKernelGGL(k_flipT_batched, dim3(max_tiles, n_jobs), dim3(256), 0, s, jobs_dev, (char*)packed);
-    GH_LAUNCH_CHECK("k_flipT_batched");
+    GH_REQUIRE(n_jobs % 3 == 0, "flipT: jobs come in triples");
+    for (int k = 0; k < 3; ++k) {
+        hipLaunchKernelGGL(k_flipT_batched, dim3(std::max(1, max_tiles3[k]), n_jobs / 3), dim3(256), 0, s, jobs_dev, (char*)packed, k, 3);
+        GH_LAUNCH_CHECK("k_flipT_batched");
+    }
     return GLOWHIP_OK;
 }
 

@@ -745,7 +745,10 @@ glowhip_plan* glowhip_plan_create(const glowhip_layer_desc* layers, int n_layers
                 p->flip_jobs.push_back(FlipJob{d.f4_w, L.wt4, L.Cout, d.hidden, 9});     // wt4[k][co][8 - tap] = W4[co][k][tap]
                 p->flip_jobs.push_back(FlipJob{d.f2_w, L.wt2, d.hidden, d.hidden, 1});   // wt2[i][o] = W2[o][i]
                 p->flip_jobs.push_back(FlipJob{d.f0_w, L.wt0, d.hidden, Ch, 9});         // wt0[ci][k][8 - tap] = W0[k][ci][tap]
-                p->flip_tiles = std::max(p->flip_tiles, ((d.hidden + 31) / 32) * ((std::max(d.hidden, L.Cout) + 31) / 32));
+                const int th = (d.hidden + 31) / 32;
+                p->flip_tiles[0] = std::max(p->flip_tiles[0], th * ((L.Cout + 31) / 32));
+                p->flip_tiles[1] = std::max(p->flip_tiles[1], th * th);
+                p->flip_tiles[2] = std::max(p->flip_tiles[2], th * ((Ch + 31) / 32));
                 RepackJob r0{}; r0.w = nullptr; r0.w_off = L.wt4; r0.out_off = L.cb_w0; r0.kind = REPACK_SH2_FIRST; r0.Cin = L.Cout; r0.Cout = d.hidden;
                 r0.K = cnet_g0(L.Cout); r0.fold_bias = nullptr; r0.fold_logs = d.f2_an_logs; r0.use = 2;      // g_u2 = g_h2 (h2 > 0) exp(3 logs2)
                 p->repack_jobs.push_back(r0);

@@ -52,7 +52,7 @@ struct glowhip_plan {
     std::vector<StepPrepJob> prep_jobs;
     std::vector<ScaleJob> scale_jobs;
     std::vector<RepackJob> repack_jobs;
-    std::vector<FlipJob> flip_jobs; int flip_tiles = 1; size_t flip_off = 0;
+    std::vector<FlipJob> flip_jobs; int flip_tiles[3] = {1, 1, 1}; size_t flip_off = 0;      // (tiles: max per member of a (f.4, f.2, f.0) triple)
     std::vector<RepackJob> repack_sel;    // the subset selected by the last glowhip_plan_pack_for (kept alive for the async copy)
     size_t prep_off = 0, scale_off = 0, repack_off = 0;
     // glowhip_plan_pack forks onto a side stream what the first kernels of a forward do not wait for: the round-1 / fp32 weight images
