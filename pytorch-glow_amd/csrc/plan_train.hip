@@ -76,9 +76,10 @@ static size_t max_weight_floats(const glowhip_plan* p) {
 }
 
 // fp64 accumulators of every layer's reduction-type gradients live side by side: zeroed once, converted once
-constexpr int MIX_ACC_COPIES = 64;     // copies of a FlowStep's mixer accumulators [W C*C][an_b C][an_l C] (backward.h ChanMixBwdArgs):
-                                       // at 8 x 8 x 64 images k_chanmix_bwd is 64 workgroups with 2 400 sums each -- one copy per
-                                       // workgroup and they are stores, not 154 k fp64 atomics (the launch was 36 us of their queue)
+constexpr int MIX_ACC_COPIES = 16;     // copies of a FlowStep's mixer accumulators [W C*C][an_b C][an_l C] (backward.h ChanMixBwdArgs).
+                                       // (64 copies, one per workgroup of the C = 48 launch and plain stores instead of its 154 k fp64
+                                       // atomics, changed nothing in that launch -- it was not waiting for them -- and cost the
+                                       // finalize kernel 43 us per step for the 4 x longer sums)
 static size_t layer_acc_doubles(const LayerPlan& L) {
     const glowhip_layer_desc& d = L.d;
     if (d.kind == GLOWHIP_LAYER_FLOWSTEP) return MIX_ACC_COPIES * ((size_t)d.C * d.C + 2 * d.C + 2 * L.Cout) + 4 * d.hidden;
