@@ -590,18 +590,20 @@ __device__ __forceinline__ void wgrad_ps_body(const WgArgs& wa, const int block 
             return;
         }
 #endif
-        const int img = kt / tiles_per_img, tin = kt - img * tiles_per_img, p0 = tin * BK;
+        // (both operands are pixel-tile-major here -- launch_wgrad_mfma / _trio require it: a k-tile's panel is kt * rows * 32
+        // elements in, no division by the tiles per image in front of the requests)
+        const int img = VA || VB || BV ? kt / tiles_per_img : 0, tin = VA || VB || BV ? kt - img * tiles_per_img : 0, p0 = tin * BK;
         (void)p0;
         if constexpr (VA) {
             load_virtual(A, a_bs, img, p0, ra, q);
         } else {
             // (uniform base + the thread's 32-bit offset: no 64-bit address arithmetic per request)
-            const char* ap = reinterpret_cast<const char*>(A + a_base + img * a_img + tin * a_tin);
+            const char* ap = reinterpret_cast<const char*>(A + a_base + (PS ? (long)kt * Mpad * BK : img * a_img + tin * a_tin));
             ra[q] = *reinterpret_cast<const f32x4*>(ap + (long)q * 32 * a_rs * 4 + lane_off_a * 4u);
         }
         if (q >= B_F4) return;
         if constexpr (BH) {
-            const char* bp = reinterpret_cast<const char*>(reinterpret_cast<const _Float16*>(B) + b_base + img * b_img + tin * b_tin);
+            const char* bp = reinterpret_cast<const char*>(reinterpret_cast<const _Float16*>(B) + b_base + (PS ? (long)kt * Npad * BK : img * b_img + tin * b_tin));
             rbh[q] = *reinterpret_cast<const h4*>(bp + (long)q * 32 * b_rs * 2 + lane_off_b * 2u);
         } else if constexpr (VB) {
             load_virtual(B, b_bs, img, p0, rb, q);
@@ -1052,6 +1054,7 @@ int launch_wgrad_mfma(const float* A, long a_bs, const float* B, long b_bs, floa
 #define GH_WG(bn, va, vb) hipLaunchKernelGGL((k_wgrad_gemm_sh<bn, va, vb>), dim3(tiles * splits), dim3(256), 0, s, wa)
 #define GH_WGH(bn, va) hipLaunchKernelGGL((k_wgrad_gemm_sh<bn, va, false, false, true>), dim3(tiles * splits), dim3(256), 0, s, wa)
     if (b_half && ps) {                // f.2 behind the backward k_cnet: its own kernel
+        GH_REQUIRE((tiled & 3) == 3, "wgrad_mfma: f.2's kernel reads pixel-tile-major operands");
         if (bn128) hipLaunchKernelGGL(k_wgrad_gemm_ps<128>, dim3(tiles * splits), dim3(256), 0, s, wa);
         else hipLaunchKernelGGL(k_wgrad_gemm_ps<64>, dim3(tiles * splits), dim3(256), 0, s, wa);
     } else
