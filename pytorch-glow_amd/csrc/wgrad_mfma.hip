@@ -947,8 +947,8 @@ bool wgrad_pair_ok(int HW, int m4, int hid, int n0) {
 
 // f.4's and f.0's weight-gradient GEMMs of one FlowStep (both behind the backward k_cnet, both with a gathered 3x3 operand) as ONE
 // launch (k_wgrad_gemm_pair): the ~512 workgroups that fill the chip are shared out by MFMA work, so each GEMM is cut into half
-// as many pixel slices as it would take alone -- half the partial tiles to write and to reduce.  Returns GLOWHIP_EINVAL without
-// launching anything when the shapes are not the pair kernel's (the caller then launches the two GEMMs one by one).
+// as many pixel slices as it would take alone -- half the partial tiles to write and to reduce.  The caller asks wgrad_pair_ok first;
+// shapes outside it are an error here (GLOWHIP_EINVAL, nothing launched).
 //   f.4: A = gathered g_pre (t4: Cout x 9 rows -> m4), B = h2 fp16 (hid rows);   f.0: A = g_u0 (hid rows, pre-scaled), B = gathered y1 (t0 -> n0)
 int launch_wgrad_pair(const float* gpre, long gpre_bs, const void* h2_half, float* partial4, float* dw4, int m4, int m4_real,
                       const float* gu0, const float* y1, long y1_bs, float* partial0, float* dw0, int n0, int n0_real,
@@ -956,7 +956,7 @@ int launch_wgrad_pair(const float* gpre, long gpre_bs, const void* h2_half, floa
                       int tiled0, WgradReduceJob* rj4, WgradReduceJob* rj0, hipStream_t s) {
     const bool ok = sh_scale > 0.f && N > 0 && wgrad_pair_ok(HW, m4, hid, n0) && t4.operand == 0 && t1_ok(t4, HW) && t0.operand == 1 && t1_ok(t0, HW) &&
                     tiled4 == 2 && tiled0 == 5;
-    if (!ok) return GLOWHIP_EINVAL;
+    GH_REQUIRE(ok, "wgrad grouped launch: shapes outside wgrad_pair_ok / operands not as documented");
     const int total = (int)((long)N * HW / 32);
     const int bn0 = n0 == 64 ? 64 : 128;
     const int tiles4 = (m4 / 128) * (hid / 128), tiles0 = (hid / 128) * (n0 / bn0);
@@ -992,7 +992,7 @@ int launch_wgrad_trio(const float* gu2, const void* h1_half, float* partial2, fl
                       int N, int HW, int hid, float sh_scale, double* rowsum0, const WgradTaps& t4, const WgradTaps& t0,
                       WgradReduceJob* rj2, WgradReduceJob* rj4, WgradReduceJob* rj0, hipStream_t s) {
     const bool ok = sh_scale > 0.f && N > 0 && wgrad_pair_ok(HW, m4, hid, n0) && t4.operand == 0 && t1_ok(t4, HW) && t0.operand == 1 && t1_ok(t0, HW);
-    if (!ok) return GLOWHIP_EINVAL;
+    GH_REQUIRE(ok, "wgrad grouped launch: shapes outside wgrad_pair_ok / operands not as documented");
     const int total = (int)((long)N * HW / 32);
     const int bn0 = n0 == 64 ? 64 : 128;
     const int tiles2 = (hid / 128) * (hid / 128), tiles4 = (m4 / 128) * (hid / 128), tiles0 = (hid / 128) * (n0 / bn0);
