@@ -13,7 +13,7 @@ rng = random.Random(int(os.environ.get("SEED", "1")))
 bad = 0
 for case in range(int(os.environ.get("CASES", "14"))):
     hidden = rng.choice([128, 256, 512]); coup = rng.choice(["affine", "additive"]); perm = rng.choice(["invconv", "reverse", "shuffle"])
-    image = rng.choice([32, 64]); L = rng.choice([2, 3]); K = rng.choice([1, 2]); batch = rng.choice([1, 2, 3, 5, 8])
+    image = rng.choice([32, 64]); L = rng.choice([2, 3]); K = rng.choice([1, 2]); batch = rng.choice([1, 2, 3, 5, 8, 20, 33])      # (from 17 images on level 1 of a 64 x 64 model takes the f.2 + pair launches, below that the trio)
     cfg = O.default_cfg(image_shape=(image, image, 3), hidden_channels=hidden, K=K, L=L, flow_permutation=perm, flow_coupling=coup, batch=batch)
     np.random.seed(case)
     g = torch.Generator().manual_seed(100 + case)
@@ -50,5 +50,5 @@ for case in range(int(os.environ.get("CASES", "14"))):
     ok = (z1 - z0).abs().max().item() <= 5e-5 and (n1 - n0).abs().max().item() <= 5e-6 and worst <= 0.05
     bad += not ok
     print(f"{'ok ' if ok else 'BAD'} hidden {hidden} {coup:8s} {perm:8s} image {image} L {L} K {K} batch {batch}: dz {(z1 - z0).abs().max().item():.1e} dnll {(n1 - n0).abs().max().item():.1e} "
-          f"worst grad rel {worst:.1e} ({wname}) tape {c1.get('k_cnet(tape)', 0)} bwd {c1.get('k_cnet(bwd)', 0)} finite {bool(torch.isfinite(n1).all())}")
+          f"worst grad rel {worst:.1e} ({wname}) tape {c1.get('k_cnet(tape)', 0)} bwd {c1.get('k_cnet(bwd)', 0)} pair {c1.get('k_wgrad(pair)', 0)} trio {c1.get('k_wgrad(trio)', 0)} finite {bool(torch.isfinite(n1).all())}")
 print("BAD cases:", bad)
