@@ -394,8 +394,9 @@ __global__ void __launch_bounds__(256) k_chanmix_bwd(ChanMixBwdArgs a) {
     // partial sums + 2 MS halo rows of the backward k_cnet launch (cnet_fin.h; the row split as a template argument unrolls them) --
     // is unconditional from a clamped address and issued before the first LDS store.  One channel per iteration with the gather
     // behind a branch was 2 round trips per channel: 24 in a row at C = 48, most of that launch's 37 us.
-    auto stage = [&](auto msv) {
+    auto stage = [&](auto msv, auto halo) {
         constexpr int MSV = decltype(msv)::value, U = 4;
+        constexpr bool HALO = decltype(halo)::value;      // (false: whole-image tiles -- no halo rows to gather: 4 instead of 20 loads per channel at MS = 4)
         const long nn = valid ? n : 0;
         const int pp = valid ? p : 0;
         for (int c0 = grp; c0 < C; c0 += 4 * U) {
@@ -411,7 +412,7 @@ __global__ void __launch_bounds__(256) k_chanmix_bwd(ChanMixBwdArgs a) {
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     float so;
-                    fin_gather_t<MSV, true>(addf, nn, min(c0 + 4 * u, a.add_C - 1), pp, se[u], so);
+                    fin_gather_t<MSV, HALO>(addf, nn, min(c0 + 4 * u, a.add_C - 1), pp, se[u], so);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -426,10 +427,13 @@ __global__ void __launch_bounds__(256) k_chanmix_bwd(ChanMixBwdArgs a) {
             }
         }
     };
-    if (a.add_MS == 1) stage(std::integral_constant<int, 1>{});
-    else if (a.add_MS == 2) stage(std::integral_constant<int, 2>{});
-    else if (a.add_MS == 4) stage(std::integral_constant<int, 4>{});
-    else stage(std::integral_constant<int, 0>{});
+    const bool halos = !a.add_part || addf.halos;
+    if (a.add_MS == 1 && halos) stage(std::integral_constant<int, 1>{}, std::true_type{});
+    else if (a.add_MS == 2 && halos) stage(std::integral_constant<int, 2>{}, std::true_type{});
+    else if (a.add_MS == 4 && halos) stage(std::integral_constant<int, 4>{}, std::true_type{});
+    else if (a.add_MS == 4) stage(std::integral_constant<int, 4>{}, std::false_type{});
+    else if (a.add_MS == 2) stage(std::integral_constant<int, 2>{}, std::false_type{});
+    else stage(std::integral_constant<int, 0>{}, std::true_type{});
     __syncthreads();
     // g_v = W^T g_y : g_v[i] = sum_o W[o][i] g_y[o]   (gather: g_v[idx[o]] = g_y[o])
     // (W in LDS and C a multiple of 4: four CONSECUTIVE output channels per thread -- one 16-byte broadcast read of W[o][i .. i+3]
