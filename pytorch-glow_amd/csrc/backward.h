@@ -50,7 +50,9 @@ struct ChanMixBwdArgs {
     int add_C = 0, add_MS = 0, add_tiles = 0, add_R = 0, add_NI = 0, add_lpxt = 0, add_H = 0, add_W = 0;
     int w_lds = 0;     // (set by launch_chanmix_bwd: the matrix is staged in LDS)
 };
-int launch_chanmix_bwd(const ChanMixBwdArgs& a, hipStream_t s);
+struct WgradReduceJobs;
+// reduce != null: the split-K reductions of the FlowStep's weight-gradient GEMMs run in the same launch (k_chanmix_bwd_reduce)
+int launch_chanmix_bwd(const ChanMixBwdArgs& a, hipStream_t s, const WgradReduceJobs* reduce = nullptr);
 
 int launch_prior_bwd(const float* z, const float* mean, const float* logs, long ml_bs, const float* gld,
                      const float* gz_in, float* gz, int N, long per, hipStream_t s);

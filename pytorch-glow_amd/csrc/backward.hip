@@ -16,6 +16,7 @@
 // below fp32 resolution after the final rounding) and converted by k_grad_finalize.
 #include "kernels.h"
 #include "backward.h"
+#include "wgrad_reduce.h"
 #include <type_traits>
 #include "sh.h"
 #include "cnet_fin.h"
@@ -359,8 +360,9 @@ int launch_act_bwd(float* g, const float* h, const float* e, int N, int Cm, int 
 constexpr int CB_PX = 64;
 constexpr int CB_LD = CB_PX + 1;    // LDS row stride: the reductions below read one COLUMN q of many rows per instruction -- with a stride of
                                     // 64 words every lane hit the same bank (64-way conflicts: 41 us per launch at C = 48)
-__global__ void __launch_bounds__(256) k_chanmix_bwd(ChanMixBwdArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
+// (the kernel body as a device function: k_chanmix_bwd launches it alone, k_chanmix_bwd_reduce beside the split-K reductions of the
+// FlowStep's weight-gradient GEMMs; `block` / `nblocks`: this launch part's block index / count)
+__device__ __forceinline__ void chanmix_bwd_body(const ChanMixBwdArgs& a, const int block, const int nblocks, float* sm) {
     const int C = a.C;
     float* v = sm;                   // [C][64]
     float* gy = sm + C * CB_LD;      // [C][64 (+1)]
@@ -378,7 +380,7 @@ __global__ void __launch_bounds__(256) k_chanmix_bwd(ChanMixBwdArgs a) {
     const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // wave-uniform: the matrix element W[o][i] of the g_v loop
                                                                            // below is then a scalar load (it was a vector load per
                                                                            // FMA: 41 us per launch at C = 48)
-    const long gp = (long)blockIdx.x * CB_PX + px;
+    const long gp = (long)block * CB_PX + px;
     const long total = (long)a.N * a.HW;
     const bool valid = gp < total;
     const long n = valid ? gp / a.HW : 0;
@@ -467,8 +469,8 @@ __global__ void __launch_bounds__(256) k_chanmix_bwd(ChanMixBwdArgs a) {
     __syncthreads();
     // reductions over the 64 pixels of this workgroup
     const int tid = threadIdx.x;
-    const long aco = (long)(blockIdx.x % a.acc_copies) * a.acc_stride;      // this workgroup's copy of the accumulators
-    const bool own = (int)gridDim.x <= a.acc_copies;      // ... and nobody else's (zeroed per step): plain stores
+    const long aco = (long)(block % a.acc_copies) * a.acc_stride;      // this workgroup's copy of the accumulators
+    const bool own = nblocks <= a.acc_copies;      // ... and nobody else's (zeroed per step): plain stores
     if (a.matrix) {
         // many sums per thread (C >= 32, C even): 2 x 2 blocks of (o, i) -- four LDS reads per four FMAs instead of two per FMA
         // (C = 48: 26.9 -> 24.4 us; at C = 12 the 36 blocks would leave most of the workgroup idle: 10.6 -> 12.9 us)
@@ -508,17 +510,47 @@ __global__ void __launch_bounds__(256) k_chanmix_bwd(ChanMixBwdArgs a) {
     }
 }
 
-int launch_chanmix_bwd(const ChanMixBwdArgs& a, hipStream_t s) {
+__global__ void __launch_bounds__(256) k_chanmix_bwd(ChanMixBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    chanmix_bwd_body(a, blockIdx.x, gridDim.x, sm);
+}
+
+// The mixer backward of a FlowStep and the split-K reductions of its (up to three) weight-gradient GEMMs in ONE launch: blocks
+// [0, mix_blocks) are k_chanmix_bwd's, then rblocks blocks per reduction job.  The two have nothing to do with each other except
+// their place in the sweep -- both short (11 - 19 us and 8 - 15 us), one latency-bound with little data, the other pure
+// bandwidth: side by side they take about as long as the longer one.
+__global__ void __launch_bounds__(256) k_chanmix_bwd_reduce(ChanMixBwdArgs a, WgradReduceJobs j, int mix_blocks, int rblocks) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int b = blockIdx.x;
+    if (b < mix_blocks) { chanmix_bwd_body(a, b, mix_blocks, sm); return; }
+    const int rb = b - mix_blocks, job = rb / rblocks;
+    const WgradReduceJob& r = j.job[job];
+    wgrad_reduce_body(r.partial, r.dw, r.splits, r.Mpad, r.Npad, r.Mreal, r.Nreal, r.mode, rb - job * rblocks);
+}
+
+int launch_chanmix_bwd(const ChanMixBwdArgs& a, hipStream_t s, const WgradReduceJobs* reduce) {
     GH_REQUIRE(a.C > 0 && a.C <= 192, "chanmix backward: C=%d unsupported (1..192)", a.C);
     const long total = (long)a.N * a.HW;
-    if (total == 0) return GLOWHIP_OK;
+    if (total == 0) return reduce ? launch_wgrad_reduce_batched(*reduce, s) : GLOWHIP_OK;
     size_t lds = (size_t)3 * a.C * CB_LD * sizeof(float);
     ChanMixBwdArgs b = a;
     b.w_lds = a.matrix && lds + (size_t)a.C * a.C * sizeof(float) <= 64 * 1024 && (reinterpret_cast<uintptr_t>(a.matrix) & 15) == 0;
     if (b.w_lds) lds += (size_t)a.C * a.C * sizeof(float);
+    const int mix_blocks = cdiv(total, CB_PX);
+    // (the reductions ride along where the mixer's LDS block leaves room for several workgroups per CU: they want occupancy)
+    if (reduce && reduce->n > 0 && lds <= 48 * 1024) {
+        long rblocks = 1;
+        for (int i = 0; i < reduce->n; ++i) rblocks = std::max(rblocks, (long)cdiv((long)reduce->job[i].Mreal * ((reduce->job[i].Nreal + 3) / 4), 256));
+        if (lds > 32 * 1024)
+            (void)hipFuncSetAttribute((const void*)k_chanmix_bwd_reduce, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_chanmix_bwd_reduce, dim3((unsigned)(mix_blocks + rblocks * reduce->n)), dim3(256), lds, s, b, *reduce, mix_blocks, (int)rblocks);
+        GH_LAUNCH_CHECK("k_chanmix_bwd_reduce");
+        return GLOWHIP_OK;
+    }
+    if (reduce) GH_TRY(launch_wgrad_reduce_batched(*reduce, s));
     if (lds > 32 * 1024)
         (void)hipFuncSetAttribute((const void*)k_chanmix_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_chanmix_bwd, dim3(cdiv(total, CB_PX)), dim3(256), lds, s, b);
+    hipLaunchKernelGGL(k_chanmix_bwd, dim3(mix_blocks), dim3(256), lds, s, b);
     GH_LAUNCH_CHECK("k_chanmix_bwd");
     return GLOWHIP_OK;
 }

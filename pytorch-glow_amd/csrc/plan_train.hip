@@ -476,7 +476,7 @@ static int backward_sweep(glowhip_plan* p, const void* packed, const float* x_in
                     { ScopedTimer tw(p, GLOWHIP_K_WGRAD, 1, s); GH_TRY(launch_wgrad_mfma(w.gh1, (long)hid * HW, w.col, (long)n0 * HW, w.partial + 2 * w.partial_floats, G.f0_w, N, HW,
                                              hid, n0, hid, Ch * 9, 0, s, sh_grad_scale, a0b, nullptr, &rj.job[2], 0, 0, 5)); }
                 }
-                { ScopedTimer tw(p, GLOWHIP_K_WGRAD, 0, s); GH_TRY(launch_wgrad_reduce_batched(rj, s)); }
+                // (the three reductions ride in the mixer backward's launch below: k_chanmix_bwd_reduce)
                 if (G.f2_an_logs) p->logs_jobs.push_back(LogsJob{d.f2_w, G.f2_w, d.f2_an_bias, a2b, G.f2_an_logs, hid, hid});
                 if (G.f0_an_logs) p->logs_jobs.push_back(LogsJob{d.f0_w, G.f0_w, d.f0_an_bias, a0b, G.f0_an_logs, hid, Ch * 9});
                 ChanMixBwdArgs mb{xin, chw, g, g, chw, d.an_bias, at<float>(packed, L.an_scale),
@@ -485,7 +485,7 @@ static int backward_sweep(glowhip_plan* p, const void* packed, const float* x_in
                 mb.acc_copies = MIX_ACC_COPIES; mb.acc_stride = mstride;
                 mb.add_part = pend.scratch; mb.add_scale = 1.0f / sh_grad_scale; mb.add_C = Ch; mb.add_MS = pend.MS;
                 mb.add_tiles = pend.tiles; mb.add_R = pend.R; mb.add_NI = pend.NI; mb.add_lpxt = pend.lpxt; mb.add_H = d.H; mb.add_W = d.W;
-                GH_TRY(launch_chanmix_bwd(mb, s));
+                GH_TRY(launch_chanmix_bwd(mb, s, &rj));
                 if (d.permutation == GLOWHIP_PERM_INVCONV) fin(aW, G.invconv_w, d.C * d.C, (double)HW, at<float>(packed, L.winv), d.C, MIX_ACC_COPIES, mstride);
                 fin(aAb, G.an_bias, d.C, 0.0, nullptr, 0, MIX_ACC_COPIES, mstride);
                 fin(aAl, G.an_logs, d.C, 3.0 * HW, nullptr, 0, MIX_ACC_COPIES, mstride);

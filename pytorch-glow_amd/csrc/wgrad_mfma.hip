@@ -11,6 +11,7 @@
 // them in a fixed order (deterministic) while scattering into the reference weight layout.
 #include "backward.h"
 #include "sh.h"
+#include "wgrad_reduce.h"
 #include <type_traits>
 
 GH_STAMPS_DEFINE(wgrad)
@@ -876,50 +877,16 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_gemm_trio(WgArgs a2, WgArgs a4
     }
 }
 
-// dW[f(m, n)] = sum_split partial[split][m][n], splits added in order.
-//   mode 0: dW[m*Nreal + n]                      (f.2: [512][512];  f.0: [512][Ch*9] = dW0[o][i][tap] flat)
-//   mode 1: m = o*9 + tap, n = i: dW[(o*Nreal + i)*9 + tap]      (f.4: dW4[o][i][tap])
-__device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ partial, float* __restrict__ dw, int splits,
-                                                  int Mpad, int Npad, int Mreal, int Nreal, int mode) {
-    // four consecutive columns per thread (Npad % 64 == 0: 16-byte loads), eight splits' loads in flight, added in split order
-    const int n4 = (Nreal + 3) >> 2;
-    const long e = (long)blockIdx.x * 256 + threadIdx.x;
-    if (e >= (long)Mreal * n4) return;
-    const int m = (int)(e / n4), n0 = (int)(e - (long)m * n4) * 4;
-    f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    const float* src = partial + (long)m * Npad + n0;
-    const long stride = (long)Mpad * Npad;
-    int k = 0;
-    for (; k + 8 <= splits; k += 8) {
-        f32x4 v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(src + (k + u) * stride);
-#pragma unroll
-        for (int u = 0; u < 8; ++u) s += v[u];
-    }
-    for (; k < splits; ++k) s += *reinterpret_cast<const f32x4*>(src + k * stride);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int n = n0 + j;
-        if (n >= Nreal) break;
-        if (mode == 0) dw[(long)m * Nreal + n] = s[j];
-        else {
-            const int o = m / 9, tap = m - o * 9;
-            dw[((long)o * Nreal + n) * 9 + tap] = s[j];
-        }
-    }
-}
-
 __global__ void __launch_bounds__(256) k_wgrad_reduce(const float* __restrict__ partial, float* __restrict__ dw, int splits,
                                                       int Mpad, int Npad, int Mreal, int Nreal, int mode) {
-    wgrad_reduce_body(partial, dw, splits, Mpad, Npad, Mreal, Nreal, mode);
+    wgrad_reduce_body(partial, dw, splits, Mpad, Npad, Mreal, Nreal, mode, blockIdx.x);
 }
 
 // the reductions of up to three weight-gradient GEMMs in ONE launch (blockIdx.y = job): a FlowStep's three were three launches
 // of ~7 us each, mostly launch latency
 __global__ void __launch_bounds__(256) k_wgrad_reduce_batched(WgradReduceJobs j) {
     const WgradReduceJob& r = j.job[blockIdx.y];
-    wgrad_reduce_body(r.partial, r.dw, r.splits, r.Mpad, r.Npad, r.Mreal, r.Nreal, r.mode);
+    wgrad_reduce_body(r.partial, r.dw, r.splits, r.Mpad, r.Npad, r.Mreal, r.Nreal, r.mode, blockIdx.x);
 }
 
 int launch_wgrad_reduce_batched(const WgradReduceJobs& j, hipStream_t s) {
