@@ -1,0 +1,666 @@
+// cnet1w_sh.hip -- the coupling network  h = f(z1) = f.4(relu(f.2(relu(f.0(z1)))))  (network/module.py:300-319) of one FlowStep with
+// ONE wave per SIMD: four waves per workgroup, 512 registers each, and NO activation ever leaves the register file.
+//
+// k_cnet (cnet_sh.hip) gives a wave a block of h2 ROWS for all 128 pixels of the tile; h1 and h2 then have to travel between waves
+// through LDS (split + store epilogues, barriers, a hand-over of h2 before f.4), and those phases issue no MFMA: 35 k of a level-1
+// workgroup's 116 k cycles.  Here a wave owns 32 PIXELS and every row of them:
+//   * the accumulator layout of v_mfma_f32_32x32x16_f16 (lane = pixel column, 16 registers = rows 8 g + 4 (lane / 32) + t) IS the
+//     B-operand layout of the next layer's MFMA (lane = pixel column, 8 consecutive k) up to a permutation of k inside a 32-row
+//     block -- and a contraction does not care in which order its k are visited as long as A and B agree.  The f.2 / f.4 weight
+//     images are therefore k-PERMUTED at pack time (sh.h sh2_kperm_src), and relu + (hi, lo) split of a 32-row block of h1 / h2 turns 16 accumulator registers into the two k-steps of B fragments
+//     the next layer multiplies -- in registers.  h1 exists 32 channels at a time (16 registers), h2 as the 256 accumulator
+//     registers of the wave (AGPRs), T = f.4's taps-as-rows output as 16 * NRT4 more.
+//   * all four waves need every weight, so the weights stream L2 -> LDS ONCE per workgroup by LDS-DMA (global_load_lds_dwordx4:
+//     no staging registers) into a three-slot ring of 32 KiB k-steps of the f.2 image, later the f.4 image; f.0's rows of the
+//     next chunk go to a small double buffer.  Weight bytes per MFMA are those of k_cnet's 128-pixel tile.
+//   * f.0 of chunk c + 1 (15 - 27 MFMAs) and its epilogue (64 VALU instructions) ride between the 96 MFMAs f.2 spends on chunk c:
+//     one wave per SIMD issues up to five other instructions in the shadow of each MFMA (MI355X_MICROARCH.md), so the matrix pipe
+//     stays busy through what used to be separate phases.
+// Output: the partial sums `hpart` / `hup` / `hdn` of k_cnet at MS = 1 with 128-pixel tiles -- k_cfinish does not know the difference.
+// Product forward / inverse only (no taping, no chained prologue, one group of f.4 output channels).
+#include "sh.h"
+#include <algorithm>
+#include <type_traits>
+
+#include "conv_mfma.h"
+#include "cnet_geo.h"
+
+GH_STAMPS_DEFINE(cnet1w)
+
+namespace glowhip {
+
+__device__ __forceinline__ void c1_dma16(const void* gsrc, void* ldst) {      // 64 lanes x 16 bytes -> 1 KiB at ldst (wave-uniform)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc, (__attribute__((address_space(3))) void*)ldst, 16, 0, 0);
+}
+template <int OFF>
+__device__ __forceinline__ void c1_dma16o(const void* gsrc, void* ldst) {   // the immediate offset OFF is added to BOTH addresses
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc, (__attribute__((address_space(3))) void*)ldst, 16, OFF, 0);
+}
+template <int OFF>
+__device__ __forceinline__ void c1_bdma16o(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff, void* ldst) {      // the same through a buffer descriptor
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)ldst, 16, voff, soff, OFF, 0);
+}
+#define C1_MFMA(A_, B_, C_) __builtin_amdgcn_mfma_f32_32x32x16_f16(A_, B_, C_, 0, 0, 0)
+#define C1_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+// f.0's accumulator block lives in VGPRs: the 256 AGPRs hold h2, and hipcc selects the AGPR form for every MFMA builtin of a kernel
+// that may use AGPRs (a 17th accumulator block made it shuttle blocks between the two files: 224 v_accvgpr_* per chunk).  So f.0's
+// MFMAs are inline asm with "v" operands.  hipcc pads nothing around an asm statement (cdna_hip_programming.md 5.7): the `s_nop 1`
+// covers a compiler VALU copy into an operand right before it; a chain on one accumulator needs no states; and every reader of
+// the result goes through c1_settle first (an 8-pass MFMA's result may be read 12 states after it issued).
+__device__ __forceinline__ void c1_mfma_v0(f32x16_t& acc, const h8& a, const h8& b) {
+#ifndef C1_ASM_MFMA_PAD
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "v"(b));
+#else
+    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "v"(b));
+#endif
+}
+__device__ __forceinline__ void c1_mfma_v(f32x16_t& acc, const h8& a, const h8& b) {
+#ifndef C1_ASM_MFMA_PAD
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+#else
+    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+#endif
+}
+__device__ __forceinline__ void c1_settle(f32x16_t& acc) { asm volatile("s_nop 12" : "+v"(acc)); }
+
+// 16 accumulator values of a 32-row block (already scaled / biased / rectified, NEGATED activations: sh.h) -> the B fragments of
+// the two k-steps the block spans: bh[s], bl[s] = (hi, lo) of registers 8 s .. 8 s + 7
+__device__ __forceinline__ void c1_frag(const f32x4_t& v, h8& bh, h8& bl, int half) {
+    h4 hi, lo;
+    sh2_split4<true>(v, hi, lo);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { bh[4 * half + t] = hi[t]; bl[4 * half + t] = lo[t]; }
+}
+
+template <int HID, int G0, int NRT4>
+__global__ void __launch_bounds__(256) k_cnet1w(CnetArgs a, CnetGeo g) {
+    constexpr int NT = 256, LPXT = 7;
+    constexpr int NCH = HID / 32;             // 32-channel chunks of the hidden width = row tiles of h1 / h2
+    constexpr int NKS = HID / 16;             // k-steps of f.2 (and of f.4)
+    constexpr int SLOT = HID * 64;            // ring slot: one k-step of the f.2 image, both planes (32 KiB at hidden 512)
+    constexpr int NST0 = G0 / 2;              // k-steps of f.0
+    constexpr int NP0 = (G0 + 3) / 4;         // DMA pieces per wave of a chunk's f.0 rows (G0 KiB)
+    constexpr int MP4 = NRT4 * 32;            // rows of the taps-as-rows f.4 image
+    constexpr int K4 = SLOT / (MP4 * 64) >= 4 ? 4 : (SLOT / (MP4 * 64) >= 2 ? 2 : 1);      // k-steps of the f.4 image per ring slot
+    constexpr int NF4 = NKS / K4;             // fills of the f.4 image
+    constexpr int PP4 = K4 * NRT4;            // 1-KiB pieces per plane of such a fill
+    constexpr int PPW4 = PP4 / 2;             // ... per wave (both planes over four waves)
+    static_assert(PP4 % 2 == 0 && PPW4 <= 8 && NF4 >= 3 && NCH % 2 == 0, "ring bookkeeping");
+    constexpr int FL = NKS + NF4 - 1;         // last fill of the stream: fills 0 .. NKS - 1 = f.2 k-steps, NKS .. FL = f.4 fills
+    constexpr int W0B = 3 * SLOT;             // byte offsets of the LDS regions: ring | f.0 double buffer | window | tables
+    constexpr int WINB = W0B + 2 * G0 * 1024;
+
+    extern __shared__ __attribute__((aligned(16))) char lds1[];
+    _Float16* win = reinterpret_cast<_Float16*>(lds1 + WINB);
+    float* t_rs0 = reinterpret_cast<float*>(win + 2 * g.winplane);
+    float* t_b0 = t_rs0 + HID;
+    float* t_rs2 = t_b0 + HID;
+    float* t_b2 = t_rs2 + HID;
+    float* t_rs4 = t_b2 + HID;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);       // = the wave's pixel tile
+    const int kl = lane >> 5, ml = lane & 31;
+    const int W = a.W, H = a.H, HW = g.HW;
+    const int tb = blockIdx.x;
+    const long gp0 = (long)tb * 128;
+    const long n0 = g.NI == 1 ? gp0 / HW : (long)tb * g.NI;
+    const int y0 = g.NI == 1 ? (int)((gp0 - n0 * HW) >> g.wshift) : 0;
+    const int submask = (1 << g.lsub) - 1;
+
+    [[maybe_unused]] const _Float16* W0 = (const _Float16*)a.w0;
+    const long w0_plane = (long)G0 * HID * 8;
+    const float* rs0 = (const float*)((const char*)a.w0 + sh2_rowscale_off(G0 * 8, HID));
+    [[maybe_unused]] const _Float16* W2 = (const _Float16*)a.w2;
+    constexpr long w2_plane = (long)HID * HID;
+    const float* rs2 = (const float*)((const char*)a.w2 + sh2_rowscale_off(HID, HID));
+    [[maybe_unused]] const _Float16* W4 = (const _Float16*)a.w4;
+    constexpr long w4_plane = (long)HID * MP4;
+    const float* rs4 = (const float*)((const char*)a.w4 + sh2_rowscale_off(HID, MP4));
+
+    // ---- the weight stream.  Fill f of the ring: f < NKS the k-step f of the f.2 image (16 pieces per plane), else fill f - NKS of
+    // the f.4 image (K4 k-steps, PP4 pieces per plane).  A wave issues 8 pieces per fill (a surplus piece repeats the wave's last).
+    // The pieces of a wave are contiguous in the image and in the slot (1 KiB apart in both), and the instruction's immediate offset
+    // applies to BOTH addresses: one base pair (source pointer, LDS offset) per fill serves four pieces each -- per piece the wave
+    // issues the load itself instead of three scalar address instructions in front of it.
+#ifndef C1_GLOBAL_DMA
+    // (through buffer descriptors: scalar base + scalar offset + lane offset are added by the address unit; an LDS-DMA piece issued
+    // this way takes 10 - 11 cycles out of the MFMA stream, 17 - 27 as global_load_lds -- scripts/ubench/mfma_burst.hip)
+    const __amdgpu_buffer_rsrc_t rs_w2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w2), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w4 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w4), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w0), 0, 0x7fffffff, 0x00020000);
+    int f_w2 = 1;                         // the fill in progress reads the f.2 image (else f.4)
+    int f_soff = 0;                       // byte offset of this wave's first piece in that image
+#else
+    const _Float16* f_src = nullptr;      // of the fill in progress: this wave's first source half (uniform; + lane * 8)
+#endif
+    int f_dst = 0;                        // ... and its LDS byte offset
+    auto ring_begin = [&](int f, int slot_off) {
+        const bool w2f = f < NKS;
+        const int ppw = w2f ? 8 : PPW4, pp = w2f ? 16 : PP4;
+        const int j = wid * ppw;
+        const int p = j >= pp ? 1 : 0, r = j - p * pp;
+#ifndef C1_GLOBAL_DMA
+        f_w2 = w2f ? 1 : 0;
+        f_soff = w2f ? (int)((p * w2_plane + (long)f * (2 * HID * 8) + r * 512) * 2) : (int)((p * w4_plane + (long)(f - NKS) * (K4 * 2 * MP4 * 8) + r * 512) * 2);
+#else
+        f_src = w2f ? W2 + p * w2_plane + (long)f * (2 * HID * 8) + r * 512 : W4 + p * w4_plane + (long)(f - NKS) * (K4 * 2 * MP4 * 8) + r * 512;
+#endif
+        f_dst = slot_off + j * 1024;
+    };
+    auto ring_piece = [&](int f, int i) {       // piece i (0 .. 7) of the fill in progress (f: which image, for the piece count)
+        const int ii = PPW4 == 8 ? i : min(i, f < NKS ? 7 : PPW4 - 1);
+        char* dst = lds1 + f_dst;
+#ifndef C1_GLOBAL_DMA
+        const __amdgpu_buffer_rsrc_t rs = f_w2 ? rs_w2 : rs_w4;
+        if (PPW4 == 8) {      // (the piece index is a constant after unrolling: the switch folds)
+            const int sb = i < 4 ? f_soff : f_soff + 4096;
+            char* db = i < 4 ? dst : dst + 4096;
+            switch (i & 3) {
+            case 0: c1_bdma16o<0>(rs, lane * 16, sb, db); break;
+            case 1: c1_bdma16o<1024>(rs, lane * 16, sb, db); break;
+            case 2: c1_bdma16o<2048>(rs, lane * 16, sb, db); break;
+            default: c1_bdma16o<3072>(rs, lane * 16, sb, db); break;
+            }
+        } else {
+            c1_bdma16o<0>(rs, lane * 16, f_soff + ii * 1024, dst + ii * 1024);
+        }
+#else
+        const _Float16* src = f_src + lane * 8;
+        if (PPW4 == 8) {      // (the piece index is a constant after unrolling: the switch folds)
+            const _Float16* sb = i < 4 ? src : src + 2048;
+            char* db = i < 4 ? dst : dst + 4096;
+            switch (i & 3) {
+            case 0: c1_dma16o<0>(sb, db); break;
+            case 1: c1_dma16o<1024>(sb, db); break;
+            case 2: c1_dma16o<2048>(sb, db); break;
+            default: c1_dma16o<3072>(sb, db); break;
+            }
+        } else {
+            c1_dma16(src + ii * 512, dst + ii * 1024);
+        }
+#endif
+    };
+    // f.0 rows of chunk c (32 rows, both planes, G0 groups: G0 KiB) -> buffer c & 1 as [plane][group][32 rows][8]; piece j = groups
+    // 2 j', 2 j' + 1 of plane j / (G0 / 2) (the two half-waves read one group each)
+    auto w0_piece = [&](int c, int i) {
+        const int j = min(wid + 4 * i, G0 - 1);
+        const int p = j >= G0 / 2 ? 1 : 0, gp = j - p * (G0 / 2);
+#ifndef C1_GLOBAL_DMA
+        c1_bdma16o<0>(rs_w0, (kl * HID + ml) * 16, (int)((p * w0_plane + ((long)(2 * gp) * HID + 32 * c) * 8) * 2), lds1 + W0B + (c & 1) * (G0 * 1024) + j * 1024);
+#else
+        const _Float16* src = W0 + p * w0_plane + ((long)(2 * gp + kl) * HID + 32 * c + ml) * 8;
+        c1_dma16(src, lds1 + W0B + (c & 1) * (G0 * 1024) + j * 1024);
+#endif
+    };
+    GH_STAMP(0);
+#pragma unroll
+    for (int i = 0; i < NP0; ++i) w0_piece(0, i);
+    ring_begin(0, 0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ring_piece(0, i);
+#pragma unroll
+    for (int i = 0; i < NP0; ++i) w0_piece(1, i);
+    ring_begin(1, SLOT);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ring_piece(1, i);
+    ring_begin(2, 2 * SLOT);
+    ring_piece(2, 0);
+    ring_piece(2, 1);
+
+    // ---- P0: tables and the z1 window (tile rows + one halo row / column each side, zero padded) as (hi, lo) halves in LDS; slot e =
+    // (8-channel chunk, sub-image, window pixel).  Every load of the round is issued from a clamped address before the first store.
+    const int nwin = g.NI * g.Wpx;
+    const int nslots = g.nchunk * nwin;
+    auto slot_src = [&](int e, bool& in, int& ch) {
+        ch = (int)__umulhi((unsigned)e, g.m_nwin);
+        const int rem = e - ch * nwin;
+        const int sub = (int)__umulhi((unsigned)rem, g.m_Wpx), wp = rem - sub * g.Wpx;
+        const int r = (int)__umulhi((unsigned)wp, g.m_WP), c = wp - r * g.WP;
+        const int yy = y0 - 1 + r, xx = c - 1;
+        const long n = n0 + sub;
+        in = yy >= 0 && yy < H && xx >= 0 && xx < W && n < a.N;
+        return a.x + (n < a.N ? n : (long)a.N - 1) * a.x_bs + min(max(yy, 0), H - 1) * W + min(max(xx, 0), W - 1);
+    };
+    {
+        constexpr int N0 = 2 * HID / NT, N2 = HID / NT;
+        float tv0[N0], tv2[N2], tvb[N2], tv4;
+#pragma unroll
+        for (int i = 0; i < N0; ++i) tv0[i] = rs0[tid + NT * i];                  // rs0 | b0 are adjacent in the image
+#pragma unroll
+        for (int i = 0; i < N2; ++i) { tv2[i] = rs2[tid + NT * i]; tvb[i] = rs2[HID + tid + NT * i]; }
+        tv4 = rs4[min(tid, MP4 - 1)];
+        for (int e0 = 0; e0 < nslots; e0 += NT) {
+            const int e = min(e0 + tid, nslots - 1);
+            bool in; int ch;
+            const float* xin = slot_src(e, in, ch);
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = xin[(long)min(ch * 8 + q, a.Cin - 1) * HW];
+            h8 hi, lo;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float vv = (in && ch * 8 + q < a.Cin) ? canon_nan(v[q] * SH2_ACT_SCALE) : 0.f;
+                _Float16 x0, x1;
+                sh2_split(vv, x0, x1);
+                hi[q] = x0; lo[q] = x1;
+            }
+            if (e0 + tid < nslots) {
+                *reinterpret_cast<h8*>(win + (long)e * 8) = hi;
+                *reinterpret_cast<h8*>(win + g.winplane + (long)e * 8) = lo;
+            }
+        }
+        // (signs: the activations travel NEGATED from the first epilogue on -- sh.h nrelu_bits, cnet_sh.hip)
+#pragma unroll
+        for (int i = 0; i < N0; ++i) t_rs0[tid + NT * i] = canon_nan(-tv0[i]);
+#pragma unroll
+        for (int i = 0; i < N2; ++i) { t_rs2[tid + NT * i] = canon_nan(tv2[i]); t_b2[tid + NT * i] = canon_nan(-tvb[i]); }
+        if (tid < MP4) t_rs4[tid] = canon_nan(-tv4);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    GH_STAMP(1);
+
+    // ---- per-lane constants of the contractions
+    // f.0: window byte address of this lane's pixel for k-step st (the lane's group 2 st + kl = (chunk, tap); past 9 * nchunk: zero
+    // weights, offset 0)
+    const int qpix = wid * 32 + ml;
+    const int pbase = [&]() {
+        const int sub = qpix >> g.lsub, qq = qpix & submask;
+        return (sub * g.Wpx + (qq >> g.wshift) * g.WP + (qq & (W - 1))) * 16;
+    }();
+    int woff[NST0];
+#pragma unroll
+    for (int st = 0; st < NST0; ++st) {
+        const int gk = 2 * st + kl;
+        const int ch = gk / 9, tap = gk - ch * 9;
+        const int dy = tap / 3, dx = tap - dy * 3;
+        woff[st] = WINB + pbase + (ch < g.nchunk ? (ch * g.NI * g.Wpx + dy * g.WP + dx) * 16 : 0);
+    }
+    const int wlo = g.winplane * 2;                        // bytes from the window's hi plane to its lo plane
+    const int a0lane = W0B + lane * 16;                    // f.0 A fragment: + buffer * G0 KiB + (plane * G0 + 2 st) * 512
+    const int a2lane = (kl * HID + ml) * 16;               // f.2 A fragment: + slot + plane * SLOT / 2 + row tile * 512
+    const int a4lane = (kl * MP4 + ml) * 16;               // f.4 A fragment: + slot + plane * K4 MP4 32 + k-step * MP4 32 + row tile * 512
+
+    auto ldA0 = [&](int buf, int st, h8& hi, h8& lo) {
+        const char* p = lds1 + a0lane + buf * (G0 * 1024) + 2 * st * 512;
+        hi = *reinterpret_cast<const h8*>(p);
+        lo = *reinterpret_cast<const h8*>(p + G0 * 512);
+    };
+    auto ldB0 = [&](int st, h8& hi, h8& lo) {
+        const char* p = lds1 + woff[st];
+        hi = *reinterpret_cast<const h8*>(p);
+        lo = *reinterpret_cast<const h8*>(p + wlo);
+    };
+    // epilogue of f.0 for group gq (rows 8 gq + 4 kl + t of chunk c): -h1 = -relu(.) as halves of the B fragments
+    auto epi1 = [&](const f32x16_t& acc, int c, int gq, h8 (&bh)[2], h8 (&bl)[2]) {
+        const int o = 32 * c + 8 * gq + 4 * kl;
+        const f32x4_t rs = *reinterpret_cast<const f32x4_t*>(t_rs0 + o);
+        const f32x4_t bb = *reinterpret_cast<const f32x4_t*>(t_b0 + o);
+        f32x4_t v;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v[t] = nrelu_bits(fmaf(acc[4 * gq + t], rs[t], bb[t]));
+        c1_frag(v, bh[gq >> 1], bl[gq >> 1], gq & 1);
+    };
+
+    // ---- f.0 of chunk 0 on its own (the only MFMAs of the kernel without f.2 or f.4 MFMAs around them)
+    h8 Bh[2], Bl[2];           // B fragments of the chunk f.2 is multiplying: k-steps 2 c, 2 c + 1
+    {
+        f32x16_t acc1;
+#pragma unroll
+        for (int st = 0; st < NST0; ++st) {
+            h8 ah, al, bh, bl;
+            ldA0(0, st, ah, al);
+            ldB0(st, bh, bl);
+            if (st == 0) c1_mfma_v0(acc1, ah, bh); else c1_mfma_v(acc1, ah, bh);
+            c1_mfma_v(acc1, ah, bl);
+            c1_mfma_v(acc1, al, bh);
+        }
+        c1_settle(acc1);
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) epi1(acc1, 0, gq, Bh, Bl);
+    }
+    __syncthreads();          // every wave is done with f.0 buffer 0 before the loop refills it
+    GH_STAMP(2);
+
+    // ---- P2 with P1 of the next chunk inside: acc2[rt] += W2'[rows of tile rt, chunk c] h1[chunk c]
+    f32x16_t acc2[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[i][r] = 0.f;
+
+    int s_cur = 0;             // ring slot (byte offset) of the k-step being multiplied
+    int s_fill = 2 * SLOT;     // ... of the fill in progress
+    // ---- issue discipline.  With one wave per SIMD nothing but this wave's own stream keeps the matrix pipe busy: an MFMA occupies it
+    // for 32 cycles, and whatever the wave issues before its NEXT MFMA has to fit into those 32 cycles (a 16-byte LDS read ~ 8 of
+    // them, a VALU instruction ~ 4, an LDS-DMA piece more).  hipcc clusters loads (eight ds_read_b128 back to back = 64 cycles of
+    // issue behind one MFMA: the first version of this loop ran at 0.73 of the MFMA rate).  So the stream is written SLOT by slot:
+    // one MFMA + at most a few fillers, closed by a scheduling barrier that nothing crosses.
+    // A fragments of a quad = four row tiles x (hi, lo), SINGLE-buffered: the hi fragment of tile i is read by slots i and 4 + i of a
+    // quad and reloaded (next quad's) in slot 4 + i; the lo fragment by slot 8 + i, reloaded there.  Every read of a ring slot is thus
+    // issued before the TOP that hands the slot back to the stream (the TOP sits at the head of a k-step's last quad).
+    h8 AH[4], AL[4];
+    auto ldA2one = [&](int slot_off, int q4, int i, int pl, h8& dst) {
+        dst = *reinterpret_cast<const h8*>(lds1 + a2lane + slot_off + (q4 * 4 + i) * 512 + pl * (SLOT / 2));
+    };
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { ldA2one(0, 0, i, 0, AH[i]); ldA2one(0, 0, i, 1, AL[i]); }
+    // f.0 operands, single-buffered as well: the three MFMAs of a k-step sit behind slots 3 (A0h, B0l), 7 (A0h, B0h) and 11 (A0l, B0h) of
+    // its quad, and each operand is reloaded for the next k-step right behind its last use
+    h8 A0h, A0l, B0h, B0l;
+    ldA0(1, 0, A0h, A0l);
+    ldB0(0, B0h, B0l);
+    // ---- the epilogue of a 32-row block (16 values per lane -> the B fragments of two k-steps), software-pipelined over 24 slots.
+    // With one wave per SIMD a DEPENDENT VALU instruction waits out its producer's latency in the issue stream, and that wait comes
+    // straight out of the next MFMA's time (five dependent instructions per pair of values, as one piece behind one MFMA, cost 6 k of
+    // the 74 k cycles of the f.2 loop).  So the 8 pairs of values move through five stages -- S1 scale + bias, S2 relu, S3 hi halves,
+    // S4 residuals, S5 lo halves -- one stage per slot: pair p is at stage S in tick 2 p + 2 + S, every tick issues four
+    // INDEPENDENT instructions (S1, S3, S5 of three pairs in odd ticks; S2, S4 of two pairs in even ones), and the tables of row
+    // group gq are requested in tick 4 gq, three ticks ahead of their first use.
+    // (agpr: the block is one of h2's, in AGPRs; its values are read with an explicit v_accvgpr_read in S1 -- left to the register
+    // allocator, the copies of ALL blocks of the fully unrolled f.4 phase move to the head of that one basic block, 256 VGPRs live
+    // at once, and the loop-invariant addresses of the whole kernel get spilled)
+    f32x4_t E_rs[2], E_bb[2];         // [gq & 1]
+    float E_v[8][2], E_m[8][2];       // per pair: value (S1, S2), residual (S4)
+    unsigned E_x[8];                  // per pair: the packed hi halves (S3)
+    auto epi_tick = [&](const f32x16_t& acc, const float* trs, const float* tbb, int c, int e, h8 (&bh)[2], h8 (&bl)[2], auto agpr) {
+        if ((e & 3) == 0 && e < 16) {
+            const int gq = e >> 2, o = 32 * c + 8 * gq + 4 * kl;
+            E_rs[gq & 1] = *reinterpret_cast<const f32x4_t*>(trs + o);
+            E_bb[gq & 1] = *reinterpret_cast<const f32x4_t*>(tbb + o);
+        }
+#pragma unroll
+        for (int S = 1; S <= 5; ++S) {
+            if ((e - 2 - S) & 1) continue;
+            const int p = (e - 2 - S) / 2;
+            if (e - 2 - S < 0 || p > 7) continue;
+            const int gq = p >> 1, t0 = 2 * (p & 1);
+            if (S == 1) {
+                float a0, a1;
+                if constexpr (decltype(agpr)::value) {
+                    asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(a0) : "a"(acc[4 * gq + t0]));
+                    asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(a1) : "a"(acc[4 * gq + t0 + 1]));
+                } else {
+                    a0 = acc[4 * gq + t0]; a1 = acc[4 * gq + t0 + 1];
+                }
+                E_v[p][0] = fmaf(a0, E_rs[gq & 1][t0], E_bb[gq & 1][t0]);
+                E_v[p][1] = fmaf(a1, E_rs[gq & 1][t0 + 1], E_bb[gq & 1][t0 + 1]);
+                asm volatile("" : "+v"(E_v[p][0]), "+v"(E_v[p][1]));      // (each stage is computed in ITS slot: the optimizer otherwise sinks it to its use)
+            } else if (S == 2) {
+                E_v[p][0] = nrelu_bits(E_v[p][0]);
+                E_v[p][1] = nrelu_bits(E_v[p][1]);
+                asm volatile("" : "+v"(E_v[p][0]), "+v"(E_v[p][1]));
+            } else if (S == 3) {
+                const f32x2_t vv = {E_v[p][0], E_v[p][1]};
+                E_x[p] = __builtin_bit_cast(unsigned, __builtin_convertvector(vv, h2));
+                asm volatile("" : "+v"(E_x[p]));
+            } else if (S == 4) {
+                asm volatile("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(E_m[p][0]) : "v"(E_x[p]), "v"(E_v[p][0]));
+                asm volatile("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(E_m[p][1]) : "v"(E_x[p]), "v"(E_v[p][1]));
+            } else {
+                const f32x2_t mm = {E_m[p][0], E_m[p][1]};
+                const h2 y = __builtin_convertvector(mm, h2);
+                const h2 x = __builtin_bit_cast(h2, E_x[p]);
+                const int e0 = 4 * (gq & 1) + t0;
+                bh[gq >> 1][e0] = x[0]; bh[gq >> 1][e0 + 1] = x[1];
+                bl[gq >> 1][e0] = y[0]; bl[gq >> 1][e0 + 1] = y[1];
+            }
+        }
+    };
+
+#pragma unroll 1
+    for (int c = 0; c < NCH; ++c) {
+        const int cn = min(c + 1, NCH - 1);        // chunk whose f.0 rides along (the last iteration repeats chunk NCH - 1 for nothing)
+        const int nbuf = cn & 1;
+        f32x16_t acc1;
+        h8 Bnh[2], Bnl[2];
+#pragma unroll
+        for (int Q = 0; Q < 8; ++Q) {
+            const int s = Q >> 2, q4 = Q & 3;
+            const int f = 2 * c + s;                // k-step
+            static_assert(NST0 <= 5, "f.0 k-step st rides in quad st; its epilogue in quads 5 and 6");
+            C1_FENCE();
+            if (q4 == 3) {
+                // TOP: fill f + 1 has landed (this wave's pieces: counted wait; everybody's: barrier) and every wave has read all it
+                // wanted from slot s_cur (lgkmcnt(0) before the barrier) -- which fill f + 3 may then overwrite
+#ifndef C1_DBG_NO_VMWAIT
+                if (s == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(8 + NP0) : "memory");
+                else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+#endif
+#ifndef C1_DBG_NO_BARRIER
+                __builtin_amdgcn_s_barrier();
+#endif
+                asm volatile("" ::: "memory");
+                s_fill = s_cur;
+                s_cur = s_cur + SLOT == 3 * SLOT ? 0 : s_cur + SLOT;
+                ring_begin(f + 3, s_fill);
+                C1_FENCE();
+            }
+            const int ff = q4 == 3 ? f + 3 : f + 2, i0 = q4 == 3 ? 0 : 2 + 2 * q4;      // the fill in progress, this quad's two pieces
+            const int st = Q;                       // f.0 k-step of this quad (Q < NST0)
+            const int nq4 = (q4 + 1) & 3;           // the next quad (after a TOP: the next k-step's first quad, from the slot that has just landed)
+#pragma unroll
+            for (int k = 0; k < 12; ++k) {
+                const int i = k & 3, sw = k >> 2;
+                acc2[4 * q4 + i] = C1_MFMA(sw == 2 ? AL[i] : AH[i], sw == 1 ? Bl[s] : Bh[s], acc2[4 * q4 + i]);
+#ifndef C1_DBG_NO_AREAD
+                if (sw == 1) ldA2one(s_cur, nq4, i, 0, AH[i]);
+                if (sw == 2) ldA2one(s_cur, nq4, i, 1, AL[i]);
+#endif
+                // the stream: two ring pieces per quad; f.0 rows of chunk c + 2 in the first three quads of the chunk
+#ifndef C1_DBG_NO_DMA
+                if (k == 0) ring_piece(ff, i0);
+                if (k == 2) ring_piece(ff, i0 + 1);
+                if (k == 1 && s == 0 && q4 < 3) {
+#pragma unroll
+                    for (int i3 = q4; i3 < NP0; i3 += 3) w0_piece(min(c + 2, NCH - 1), i3);
+                }
+#endif
+                // f.0 of chunk cn: k-step st in quad st; in quad 7 the first operands of the chunk after (its rows landed with this quad's TOP)
+#ifndef C1_DBG_NO_P1
+                if (Q < NST0) {
+                    const char* pa = lds1 + a0lane + nbuf * (G0 * 1024) + 2 * (st + 1) * 512;
+                    const char* pb = lds1 + woff[st + 1 < NST0 ? st + 1 : 0];
+                    if (k == 3) {
+                        if (st == 0) c1_mfma_v0(acc1, A0h, B0l); else c1_mfma_v(acc1, A0h, B0l);
+                        if (st + 1 < NST0) B0l = *reinterpret_cast<const h8*>(pb + wlo);
+                    }
+                    if (k == 7) {
+                        c1_mfma_v(acc1, A0h, B0h);
+                        if (st + 1 < NST0) A0h = *reinterpret_cast<const h8*>(pa);
+                    }
+                    if (k == 11) {
+                        c1_mfma_v(acc1, A0l, B0h);
+                        if (st + 1 < NST0) { B0h = *reinterpret_cast<const h8*>(pb); A0l = *reinterpret_cast<const h8*>(pa + G0 * 512); }
+                    }
+                }
+                if (Q == 7 && k < 4) {
+                    const char* pa = lds1 + a0lane + (min(c + 2, NCH - 1) & 1) * (G0 * 1024);
+                    const char* pb = lds1 + woff[0];
+                    if (k == 0) B0l = *reinterpret_cast<const h8*>(pb + wlo);
+                    if (k == 1) A0h = *reinterpret_cast<const h8*>(pa);
+                    if (k == 2) B0h = *reinterpret_cast<const h8*>(pb);
+                    if (k == 3) A0l = *reinterpret_cast<const h8*>(pa + G0 * 512);
+                }
+                // its epilogue: the 24 slots of quads 5 and 6
+                if (Q == 5 || Q == 6) {
+#ifndef C1_DBG_NO_EPI
+                    if (Q == 5 && k == 0) c1_settle(acc1);
+                    epi_tick(acc1, t_rs0, t_b0, cn, (Q - 5) * 12 + k, Bnh, Bnl, std::false_type{});
+#endif
+                }
+#endif
+                C1_FENCE();
+            }
+        }
+#if !defined(C1_DBG_NO_P1) && !defined(C1_DBG_NO_EPI)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) { Bh[s] = Bnh[s]; Bl[s] = Bnl[s]; }
+#endif
+    }
+    GH_STAMP(3);
+
+    // ---- P3: T[m][px] += W4t[m][k] h2[k][px] with h2 = relu + split of the accumulator block k / 32, two k-steps per block.
+    // (slot bookkeeping continues: the last TOP of the loop above made fill NKS = the first of the f.4 image readable in s_cur)
+    f32x16_t accT[NRT4];       // in VGPRs like f.0's block (asm MFMAs): h2 holds every AGPR until its last block has been consumed
+    h8 Hh[2][2], Hl[2][2];      // [chunk & 1][k-step of the chunk]
+#pragma unroll
+    for (int e = 0; e < 24; ++e) epi_tick(acc2[0], t_rs2, t_b2, 0, e, Hh[0], Hl[0], std::true_type{});
+    static_assert(NRT4 == 4, "the slot plan of f.4 (12 MFMAs per k-step, fragments reloaded behind their last use) is laid out for four row tiles");
+    h8 A4H[NRT4], A4L[NRT4];
+    auto ldA4one = [&](int slot_off, int kk, int i, int pl, h8& dst) {
+        dst = *reinterpret_cast<const h8*>(lds1 + a4lane + slot_off + kk * (MP4 * 32) + i * 512 + pl * (K4 * MP4 * 32));
+    };
+#pragma unroll
+    for (int i = 0; i < NRT4; ++i) { ldA4one(s_cur, 0, i, 0, A4H[i]); ldA4one(s_cur, 0, i, 1, A4L[i]); }
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        const int c = ks >> 1, s = ks & 1;
+        const int F = NKS + ks / K4, kk = ks % K4;        // fill being read, k-step inside it
+        C1_FENCE();
+        if (kk == K4 - 1 && F + 1 <= FL) {
+            if (F + 2 <= FL) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            s_fill = s_cur;
+            s_cur = s_cur + SLOT == 3 * SLOT ? 0 : s_cur + SLOT;
+            if (F + 3 <= FL) ring_begin(F + 3, s_fill);
+            C1_FENCE();
+        }
+        // pieces of the fill in progress: two with the TOP, the other six over the first K4 - 1 k-steps of a fill
+        const int ff = kk == K4 - 1 ? F + 3 : F + 2;
+        constexpr int PER = K4 > 1 ? (6 + K4 - 2) / (K4 - 1) : 6;
+        const int i0 = kk == K4 - 1 ? 0 : 2 + kk * PER, i1 = kk == K4 - 1 ? 2 : min(8, 2 + (kk + 1) * PER);
+        const int cn = min(c + 1, NCH - 1);
+        constexpr int NM = 3 * NRT4;
+#pragma unroll
+        for (int k = 0; k < NM; ++k) {
+            const int i = k % NRT4, sw = k / NRT4;
+            if (ks == 0 && sw == 0) c1_mfma_v0(accT[i], A4H[i], Hh[0][0]);
+            else c1_mfma_v(accT[i], sw == 2 ? A4L[i] : A4H[i], sw == 1 ? Hl[c & 1][s] : Hh[c & 1][s]);
+            if (ks + 1 < NKS && sw == 1) ldA4one(s_cur, (kk + 1) % K4, i, 0, A4H[i]);
+            if (ks + 1 < NKS && sw == 2) ldA4one(s_cur, (kk + 1) % K4, i, 1, A4L[i]);
+            // h2 of the next block: its epilogue over the 24 slots of this block's two k-steps
+            if (c + 1 < NCH) epi_tick(acc2[cn], t_rs2, t_b2, cn, 12 * s + k, Hh[cn & 1], Hl[cn & 1], std::true_type{});
+            if (ff <= FL && k >= NM - (i1 - i0)) ring_piece(ff, i0 + k - (NM - (i1 - i0)));
+            C1_FENCE();
+        }
+    }
+    GH_STAMP(4);
+#pragma unroll
+    for (int i = 0; i < NRT4; ++i) c1_settle(accT[i]);
+    __syncthreads();           // every wave is done with the ring: it becomes the staging area of T
+
+    // ---- P4 (as k_cnet's): T -> LDS as fp32 [row m][pixel] (row scale applied), then the 9-tap sums
+    float* T = reinterpret_cast<float*>(lds1);
+    const int Cout = g.Cg;
+    {
+        const int q = wid * 32 + ml;
+#pragma unroll
+        for (int i = 0; i < NRT4; ++i) {
+            float* dst = T + ((i * 32 + 4 * kl) << LPXT) + q;
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const f32x4_t rsv = *reinterpret_cast<const f32x4_t*>(t_rs4 + i * 32 + 8 * gq + 4 * kl);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) dst[(8 * gq + t) << LPXT] = accT[i][4 * gq + t] * rsv[t];
+            }
+        }
+    }
+    __syncthreads();
+    GH_STAMP(5);
+    float* hpart = a.scratch;
+    float* hup = a.scratch + (long)a.N * a.Cout * HW;
+    float* hdn = hup + (long)g.tiles * a.Cout * W;
+    {
+        // a thread keeps ITS pixel (tid & 127) and walks the channels ce = tid >> 7, + 2, ...
+        const int q = tid & 127;
+        const int sub = q >> g.lsub, qq = q & submask;
+        const int r = qq >> g.wshift, x = qq & (W - 1);
+        const long n = n0 + sub;
+        int off[9];
+        bool ok[9];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int tap = dy * 3 + dx;              // out(r, x) += T[tap (dy, dx)][source (r + dy - 1, x + dx - 1)]
+                ok[tap] = r + dy - 1 >= 0 && r + dy - 1 < g.R && x + dx - 1 >= 0 && x + dx - 1 < W;
+                off[tap] = ((tap * Cout) << LPXT) + q + (ok[tap] ? (dy - 1) * W + (dx - 1) : 0);
+            }
+        if (n < a.N) {
+            float* hp = hpart + (n * a.Cout) * HW + (long)(y0 + r) * W + x;
+            for (int ce = tid >> LPXT; ce < Cout; ce += NT >> LPXT) {
+                const float* tp = T + (ce << LPXT);
+                float v[9];
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) v[tap] = tp[off[tap]];
+                float sum = 0.f;
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) sum += ok[tap] ? v[tap] : 0.f;
+                hp[(long)ce * HW] = sum;
+            }
+        }
+    }
+    // halo rows (NI = 1 only): what the tile's first row gives to image row y0 - 1, its last row to row y0 + R
+    if (g.NI == 1 && g.R < H) {
+        const int hitems = 2 * Cout * W;
+        for (int e = tid; e < hitems; e += NT) {
+            const int dn = e >= Cout * W;
+            const int rem = e - dn * (Cout * W);
+            const int co = rem >> g.wshift, x = rem & (W - 1);
+            if (dn ? (y0 + g.R >= H) : (y0 == 0)) continue;
+            const int rsrc = dn ? g.R - 1 : 0;
+            const int dyt = dn ? 0 : 2;                 // filter row applied by the outside pixel to this source row
+            float sacc = 0.f;
+            float v[3]; bool ok[3];
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                ok[dx] = x + dx - 1 >= 0 && x + dx - 1 < W;
+                v[dx] = T[(((dyt * 3 + dx) * Cout + co) << LPXT) + rsrc * W + (ok[dx] ? x + dx - 1 : x)];
+            }
+            sacc += (ok[0] ? v[0] : 0.f) + (ok[1] ? v[1] : 0.f) + (ok[2] ? v[2] : 0.f);
+            (dn ? hdn : hup)[((long)tb * a.Cout + co) * W + x] = sacc;
+        }
+    }
+    GH_STAMP(6);
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+static size_t cnet1w_lds_bytes(const CnetGeo& g, int hidden) {
+    return (size_t)3 * hidden * 64 + (size_t)2 * g.G * 1024 + (size_t)2 * g.winplane * sizeof(_Float16) + ((size_t)4 * hidden + g.Mpad4) * sizeof(float);
+}
+
+static int cnet1w_instance(const CnetArgs& a, const CnetGeo& g) {      // 0: none
+    if (a.hidden != 512 || g.ng != 1 || g.pxt != 128) return 0;
+    if (g.G == 10 && g.NRT4 == 4) return 1;
+    return 0;
+}
+
+bool cnet1w_takes(const CnetArgs& a, const CnetGeo& g) {
+    if (a.tape_h1 || a.pre_on || a.bwd) return false;
+    if (!cnet1w_instance(a, g)) return false;
+    if (cnet1w_lds_bytes(g, a.hidden) > 160 * 1024) return false;
+    if ((size_t)g.Mpad4 * 128 * sizeof(float) > (size_t)3 * a.hidden * 64 + (size_t)2 * g.G * 1024) return false;      // T staging in front of the window
+    return true;
+}
+
+int launch_cnet1w(const CnetArgs& a, const CnetGeo& g, hipStream_t s) {
+    const size_t lds = cnet1w_lds_bytes(g, a.hidden);
+    switch (cnet1w_instance(a, g)) {
+    case 1:
+        (void)hipFuncSetAttribute((const void*)k_cnet1w<512, 10, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((k_cnet1w<512, 10, 4>), dim3(g.tiles), dim3(256), lds, s, a, g);
+        break;
+    default:
+        set_error("cnet1w: no kernel instance");
+        return GLOWHIP_EINVAL;
+    }
+    GH_LAUNCH_CHECK("k_cnet1w");
+    return GLOWHIP_OK;
+}
+
+}  // namespace glowhip

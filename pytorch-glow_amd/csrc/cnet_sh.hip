@@ -23,6 +23,7 @@
 
 #include "conv_mfma.h"
 #include "cnet_fin.h"
+#include "cnet_geo.h"
 
 GH_STAMPS_DEFINE(cnet)
 GH_WGTIMES_DEFINE(cnet)
@@ -35,26 +36,6 @@ GH_WGTIMES_DEFINE(cnet)
 #endif
 
 namespace glowhip {
-
-constexpr int CN_HBUF = 128 * 1024;          // bytes of the h1 / h2 / T region
-constexpr int CN_MAXMS = 4;
-
-struct CnetGeo {
-    int wshift, lsub, NI, R, WP, Wpx, nchunk, G, steps0, Mpad4, NRT4, NU4, KS, npass, tiles;
-    int winplane;     // halfs per window plane
-    int HW, lhw;      // pixels per image and its log2
-    int lpp;          // log2(pixels per staging pass)
-    int pxt, lpxt;    // pixels per workgroup tile (128 or 64) and its log2
-    unsigned m_nwin, m_Wpx, m_WP;     // ceil(2^32 / d) of the window's three divisors: n / d = umulhi(n, m) for the slot indices (< 2^16)
-    int ng, Cg;       // f.4 in ng groups of Cg output channels (Mpad4, NRT4, NU4, KS, npass describe ONE group): wide steps
-                      // (C = 96: Cout = 96 = 2 x 48) run P3 + P4 once per group, h2 handed over again from the registers
-};
-
-__host__ __device__ inline int cnet_trow(int M9) {   // T row stride (floats): multiple of 4, an odd multiple (bank spread)
-    int r = (M9 + 3) / 4;
-    if ((r & 1) == 0) ++r;
-    return r * 4;
-}
 
 // (FinSrc, fin_src, fin_gather_t: cnet_fin.h -- shared with the backward's k_chanmix_bwd)
 __device__ __forceinline__ void fin_gather(const FinSrc& f, long n, int c, int p, float& se, float& so) { fin_gather_t<0>(f, n, c, p, se, so); }
@@ -608,7 +589,7 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
                 const int o = hh * HK + (rt1 + i) * 32 + 8 * gq + 4 * kl;
                 const f32x4_t rs = *reinterpret_cast<const f32x4_t*>(t_rs0 + o);
                 const f32x4_t bb = *reinterpret_cast<const f32x4_t*>(t_b0 + o);
-                const int chunk = (rt1 + i) * 4 + gq;
+                const int chunk = (rt1 + i) * 4 + (gq & 2) + kl;      // k-permuted position of rows 8 gq + 4 kl + t (sh.h sh2_kperm_src)
                 h4 hi, lo;
                 f32x4_t v;
 #pragma unroll
@@ -621,7 +602,7 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
                     if (TAPE) mbw = __builtin_amdgcn_alignbit(mbw, __float_as_uint(v[t]), 31);
                 }
                 sh2_split4<MIXSPLIT>(v, hi, lo);
-                _Float16* dst = hbuf + ((long)chunk * PXT + (pt1 + sp * PTSV + j) * 32 + ml) * 8 + 4 * kl;
+                _Float16* dst = hbuf + ((long)chunk * PXT + (pt1 + sp * PTSV + j) * 32 + ml) * 8 + 4 * (gq & 1);
                 *reinterpret_cast<h4*>(dst) = hi;
                 *reinterpret_cast<h4*>(dst + (long)NCH * PXT * 8) = lo;
                 if (F32ST) {     // (with a row split every workgroup computes all of these rows: each stores its own rows' share)
@@ -648,7 +629,7 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
                         const int o = hh * HK + (rt1 + i) * 32 + 8 * gq + 4 * kl;
                         const f32x4_t rs = *reinterpret_cast<const f32x4_t*>(t_rs0 + o);
                         const f32x4_t bb = *reinterpret_cast<const f32x4_t*>(t_b0 + o);
-                        const int chunk = (rt1 + i) * 4 + gq;
+                        const int chunk = (rt1 + i) * 4 + (gq & 2) + kl;      // k-permuted position (sh.h sh2_kperm_src)
 #pragma unroll
                         for (int j = 0; j < PTSV; ++j) {
                             h4 hi, lo;
@@ -656,7 +637,7 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
 #pragma unroll
                             for (int t = 0; t < 4; ++t) v[t] = nrelu_bits(fmaf(acc1[i][j][4 * gq + t], rs[t], bb[t]));
                             sh2_split4<MIXSPLIT>(v, hi, lo);
-                            _Float16* dst = hbuf + ((long)chunk * PXT + (pt1 + sp * PTSV + j) * 32 + ml) * 8 + 4 * kl;
+                            _Float16* dst = hbuf + ((long)chunk * PXT + (pt1 + sp * PTSV + j) * 32 + ml) * 8 + 4 * (gq & 1);
                             *reinterpret_cast<h4*>(dst) = hi;
                             *reinterpret_cast<h4*>(dst + (long)NCH * PXT * 8) = lo;
                         }
@@ -891,13 +872,13 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
             if (wr / LK != l) continue;
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
-                const int chunk = (wr - l * LK) / 8 + gq;
+                const int chunk = (wr - l * LK) / 8 + (gq & 2) + kl;      // k-permuted position (sh.h sh2_kperm_src)
 #pragma unroll
                 for (int j = 0; j < PT2; ++j) {
                     h4 hi, lo;
                     const f32x4_t v = {acc2[i][j][4 * gq], acc2[i][j][4 * gq + 1], acc2[i][j][4 * gq + 2], acc2[i][j][4 * gq + 3]};
                     sh2_split4<MIXSPLIT>(v, hi, lo);
-                    _Float16* dst = hbuf + ((long)chunk * PXT + (pt2 + j) * 32 + ml) * 8 + 4 * kl;
+                    _Float16* dst = hbuf + ((long)chunk * PXT + (pt2 + j) * 32 + ml) * 8 + 4 * (gq & 1);
                     *reinterpret_cast<h4*>(dst) = hi;
                     *reinterpret_cast<h4*>(dst + (long)LCH * PXT * 8) = lo;
                 }
@@ -1320,7 +1301,7 @@ size_t cnet_w4_bytes(int hidden, int Cout) {
     return ng ? (size_t)ng * sh2_image_bytes(hidden, cnet_mpad4(Cout / ng)) : 0;
 }
 
-static bool cnet_geo(int Cin, int H, int W, int hidden, int Cout, int N, int pxt, CnetGeo* out) {
+bool cnet_geo(int Cin, int H, int W, int hidden, int Cout, int N, int pxt, CnetGeo* out) {
     if (!(hidden == 64 || hidden == 128 || hidden == 256 || hidden == 512)) return false;
     if (pxt == 64 && hidden < 128) return false;
     if (!pow2(W) || !pow2(H) || W < 4 || W > pxt) return false;
@@ -1466,13 +1447,20 @@ int launch_cnet_main(const CnetArgs& a, hipStream_t s, CnetPending* out) {
                          cnet_tape_instance(a.hidden, ms, upw, g.pxt, g.ng)),
                "cnet: no taping / backward instance for this launch");
     int rc = GLOWHIP_EINVAL;
+    // one wave per SIMD (cnet1w_sh.hip) wherever an instance exists for the launch: plain forward / inverse, 128-pixel tiles, no row split
+    bool one_wave = false;
+    if (!tape && !a.pre_on && ms == 1 && g.pxt == 128 && !(g_cnet_flags & 16) && cnet1w_takes(a, g)) {
+        GH_TRY(launch_cnet1w(a, g, s));
+        rc = GLOWHIP_OK;
+        one_wave = true;
+    }
 #define GH_CNT(hid, m, px)                                                                                     \
     if (tape && a.hidden == hid && ms == m && g.pxt == px)                                                     \
         rc = a.bwd ? launch_cnet_tape<hid, m, px, 2>(a, g, s) : launch_cnet_tape<hid, m, px, 1>(a, g, s);
     GH_CNT(512, 1, 128) GH_CNT(512, 2, 128) GH_CNT(512, 4, 128) GH_CNT(512, 1, 64) GH_CNT(512, 2, 64) GH_CNT(512, 4, 64)
     GH_CNT(256, 1, 128) GH_CNT(256, 2, 128) GH_CNT(256, 1, 64) GH_CNT(256, 2, 64) GH_CNT(128, 1, 128) GH_CNT(128, 1, 64)
 #undef GH_CNT
-#define GH_CN(hid, m, u, px) if (!tape && g.ng == 1 && a.hidden == hid && ms == m && upw == u && g.pxt == px) rc = launch_cnet_inst<hid, m, u, px>(a, g, s);
+#define GH_CN(hid, m, u, px) if (rc == GLOWHIP_EINVAL && !tape && g.ng == 1 && a.hidden == hid && ms == m && upw == u && g.pxt == px) rc = launch_cnet_inst<hid, m, u, px>(a, g, s);
 #define GH_CN2(hid, m, u, px) if (!tape && g.ng == 2 && a.hidden == hid && ms == m && upw == u && g.pxt == px) rc = launch_cnet_inst2<hid, m, u, px>(a, g, s);
     GH_CN2(512, 1, 1, 64) GH_CN2(512, 2, 1, 64) GH_CN2(512, 4, 1, 64) GH_CN2(256, 1, 1, 64) GH_CN2(256, 2, 1, 64) GH_CN2(128, 1, 1, 64)
 #undef GH_CN2
@@ -1490,6 +1478,7 @@ int launch_cnet_main(const CnetArgs& a, hipStream_t s, CnetPending* out) {
         out->bias = a.bias; out->scale = a.scale; out->mode = a.mode; out->Cout = a.Cout;
         out->z = a.pre_on ? a.pre_z_new : a.z_in;
         out->z_bs = a.pre_on ? a.pre_z_new_bs : a.z_in_bs;
+        out->one_wave = one_wave ? 1 : 0;
     }
     return GLOWHIP_OK;
 }

@@ -100,6 +100,8 @@ struct RepackJob {
                                  // element (o, ci, tap) = w[ci][o][8 - tap]
     size_t w_off;                // w == nullptr: the source is packed + w_off (a transposed copy made by launch_flipT_batched, or W^-1)
     int after_lu;                // the source is W^-1 (packed + w_off): built after the LU factorisations, on their stream
+    int kperm;                   // SH2_GEMM / SH2_TAIL: k-permuted image (sh.h sh2_kperm: the coupling-network kernels of cnet_sh.hip /
+                                 // cnet1w_sh.hip, whose B operand of f.2 / f.4 is the previous layer's accumulator block)
 };
 // dst[i][o][ks-1-tap] = src[o][i][tap] (ks = 9: 3x3 weights, 1: a plain transpose): the weight of the input-gradient convolution,
 // in the reference layout, for the SH2 image kernels of the backward k_cnet launch (plan_train.hip)

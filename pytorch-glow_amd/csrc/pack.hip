@@ -97,14 +97,16 @@ __device__ __forceinline__ void repack_sh2_rows(const RepackJob& j, char* packed
             for (int k8 = 0; k8 < 8; ++k8) v[k8] = 0.f;
             if (!rv || gi >= ngroups) return;
             if (KIND == REPACK_SH2_GEMM) {          // contiguous in memory: two 16-byte loads when the row length allows
-                const float* src = jw + (long)r * j.Cin + gi * 8;
+                // (k-permuted image: the group's two halves are 4 consecutive k each, 8 apart -- sh.h sh2_kperm_src)
+                const float* src = jw + (long)r * j.Cin + (j.kperm ? sh2_kperm_src(gi * 8) : gi * 8);
+                const int h2o = j.kperm ? 8 : 4;
                 if ((j.Cin & 3) == 0) {
-                    const f32x4_t a = *reinterpret_cast<const f32x4_t*>(src), b = *reinterpret_cast<const f32x4_t*>(src + 4);
+                    const f32x4_t a = *reinterpret_cast<const f32x4_t*>(src), b = *reinterpret_cast<const f32x4_t*>(src + h2o);
 #pragma unroll
                     for (int k8 = 0; k8 < 4; ++k8) { v[k8] = a[k8] * fold; v[4 + k8] = b[k8] * fold; }
                 } else {
 #pragma unroll
-                    for (int k8 = 0; k8 < 8; ++k8) v[k8] = src[k8] * fold;
+                    for (int k8 = 0; k8 < 8; ++k8) v[k8] = src[(k8 & 3) + (k8 >> 2) * h2o] * fold;
                 }
             } else if (KIND == REPACK_SH2_FIRST) {
                 const int ch = gi / 9, tap = gi - ch * 9;
@@ -318,6 +320,28 @@ __device__ __forceinline__ void repack_sh2_first_wide(const RepackJob& j, char* 
     }
 }
 
+// k-permuted group gi of a row of bricks (sh.h sh2_kperm_src): channels 4 kl .. 4 kl + 3 of the 32-block's bricks 2 s and 2 s + 1 --
+// two half bricks of 36 contiguous floats each; b[k8 * 9 + tap] as load_brick leaves it
+__device__ __forceinline__ void load_brick_kperm(const float* row, int gi, bool valid, float (&b)[72]) {
+#pragma unroll
+    for (int i = 0; i < 72; ++i) b[i] = 0.f;
+    if (!valid) return;
+    const int k0 = sh2_kperm_src(gi * 8);            // first of the group's first four channels; the other four are k0 + 8 ...
+    const float* s0 = row + (long)k0 * 9;
+    const float* s1 = row + (long)(k0 + 8) * 9;
+    if ((((size_t)s0 | (size_t)s1) & 15) == 0) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const f32x4_t v = reinterpret_cast<const f32x4_t*>(s0)[i], w = reinterpret_cast<const f32x4_t*>(s1)[i];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { b[i * 4 + q] = v[q]; b[36 + i * 4 + q] = w[q]; }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 36; ++i) { b[i] = s0[i]; b[36 + i] = s1[i]; }
+    }
+}
+
 // SH2_TAIL: a block takes EIGHT output channels (lane = brick-in-pass * 8 + channel, the four waves split the bricks) and emits
 // their 9 x 8 rows; row maxima go through LDS.  Rows beyond 9 Cout (the padding to whole row tiles) are zero-filled.
 __device__ __forceinline__ void repack_sh2_tail(const RepackJob& j, char* packed) {
@@ -336,7 +360,7 @@ __device__ __forceinline__ void repack_sh2_tail(const RepackJob& j, char* packed
         for (int t = 0; t < 9; ++t) mx[t] = 0.f;
         for (int gi = wave * 8 + gl; gi < ngroups; gi += 32) {
             float b[72];
-            load_brick(row + gi * 72, 8, rv, b);
+            if (j.kperm) load_brick_kperm(row, gi, rv, b); else load_brick(row + gi * 72, 8, rv, b);
 #pragma unroll
             for (int t = 0; t < 9; ++t)
 #pragma unroll
@@ -357,7 +381,7 @@ __device__ __forceinline__ void repack_sh2_tail(const RepackJob& j, char* packed
         __syncthreads();
         for (int gi = wave * 8 + gl; gi < ngroups; gi += 32) {
             float b[72];
-            load_brick(row + gi * 72, 8, rv, b);
+            if (j.kperm) load_brick_kperm(row, gi, rv, b); else load_brick(row + gi * 72, 8, rv, b);
             if (rv) {
 #pragma unroll
                 for (int t = 0; t < 9; ++t) {

@@ -185,7 +185,7 @@ static CnetArgs cnet_base(const LayerPlan& L, const void* packed, int N, int rev
 // which instance of k_cnet ran (run-time evidence for the tests): "variant:k_cnet<hidden,row split,pixel tile>"
 static void count_cnet_variant(glowhip_plan* p, const CnetArgs& c, const CnetPending& pend) {
     char name[64];
-    snprintf(name, sizeof name, "variant:k_cnet<%d,%d,%d>", c.hidden, pend.MS, 1 << pend.lpxt);
+    snprintf(name, sizeof name, "variant:k_cnet%s<%d,%d,%d>", pend.one_wave ? "1w" : "", c.hidden, pend.MS, 1 << pend.lpxt);
     count_launch(p, name);
 }
 static CnetMixer mixer_fwd(const LayerPlan& L, const void* packed) {      // ActNorm + permutation of step L, forward
@@ -719,12 +719,12 @@ glowhip_plan* glowhip_plan_create(const glowhip_layer_desc* layers, int n_layers
                 RepackJob r0{}; r0.w = d.f0_w; r0.out_off = L.cn_w0; r0.kind = REPACK_SH2_FIRST; r0.Cin = d.C / 2; r0.Cout = d.hidden;
                 r0.K = cnet_g0(d.C / 2); r0.fold_bias = d.f0_an_bias; r0.fold_logs = d.f0_an_logs; r0.use = 3;
                 p->repack_jobs.push_back(r0);
-                RepackJob r2{}; r2.w = d.f2_w; r2.out_off = L.cn_w2; r2.kind = REPACK_SH2_GEMM; r2.Cin = d.hidden; r2.Cout = d.hidden;
+                RepackJob r2{}; r2.kperm = 1; r2.w = d.f2_w; r2.out_off = L.cn_w2; r2.kind = REPACK_SH2_GEMM; r2.Cin = d.hidden; r2.Cout = d.hidden;
                 r2.K = d.hidden; r2.fold_bias = d.f2_an_bias; r2.fold_logs = d.f2_an_logs; r2.use = 3; p->repack_jobs.push_back(r2);
                 const int ng = cnet_groups(L.Cout), cg = L.Cout / ng;       // one image per group of f.4 output channels
                 for (int gi = 0; gi < ng; ++gi) {
                     RepackJob r4{}; r4.w = d.f4_w + (size_t)gi * cg * d.hidden * 9; r4.out_off = L.cn_w4 + gi * sh2_image_bytes(d.hidden, cnet_mpad4(cg));
-                    r4.kind = REPACK_SH2_TAIL; r4.Cin = d.hidden; r4.Cout = cg;
+                    r4.kind = REPACK_SH2_TAIL; r4.kperm = 1; r4.Cin = d.hidden; r4.Cout = cg;
                     r4.Kpad = cnet_mpad4(cg); r4.use = 3; p->repack_jobs.push_back(r4);
                 }
             }
@@ -752,9 +752,9 @@ glowhip_plan* glowhip_plan_create(const glowhip_layer_desc* layers, int n_layers
                 RepackJob r0{}; r0.w = nullptr; r0.w_off = L.wt4; r0.out_off = L.cb_w0; r0.kind = REPACK_SH2_FIRST; r0.Cin = L.Cout; r0.Cout = d.hidden;
                 r0.K = cnet_g0(L.Cout); r0.fold_bias = nullptr; r0.fold_logs = d.f2_an_logs; r0.use = 2;      // g_u2 = g_h2 (h2 > 0) exp(3 logs2)
                 p->repack_jobs.push_back(r0);
-                RepackJob r2{}; r2.w = nullptr; r2.w_off = L.wt2; r2.out_off = L.cb_w2; r2.kind = REPACK_SH2_GEMM; r2.Cin = d.hidden; r2.Cout = d.hidden;
+                RepackJob r2{}; r2.kperm = 1; r2.w = nullptr; r2.w_off = L.wt2; r2.out_off = L.cb_w2; r2.kind = REPACK_SH2_GEMM; r2.Cin = d.hidden; r2.Cout = d.hidden;
                 r2.K = d.hidden; r2.fold_bias = nullptr; r2.fold_logs = d.f0_an_logs; r2.use = 2; p->repack_jobs.push_back(r2);
-                RepackJob r4{}; r4.w = nullptr; r4.w_off = L.wt0; r4.out_off = L.cb_w4; r4.kind = REPACK_SH2_TAIL; r4.Cin = d.hidden; r4.Cout = Ch;
+                RepackJob r4{}; r4.kperm = 1; r4.w = nullptr; r4.w_off = L.wt0; r4.out_off = L.cb_w4; r4.kind = REPACK_SH2_TAIL; r4.Cin = d.hidden; r4.Cout = Ch;
                 r4.Kpad = cnet_mpad4(Ch); r4.use = 2; p->repack_jobs.push_back(r4);
             }
             if (L.mfma_last) {

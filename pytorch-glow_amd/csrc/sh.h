@@ -105,6 +105,19 @@ __device__ __forceinline__ float canon_nan(float v) { return v != v ? __uint_as_
 __host__ __device__ static inline size_t sh2_image_bytes(int Kp, int M) { return (size_t)2 * Kp * M * sizeof(_Float16) + (size_t)2 * M * sizeof(float); }
 __host__ __device__ static inline size_t sh2_rowscale_off(int Kp, int M) { return (size_t)2 * Kp * M * sizeof(_Float16); }
 
+// k-PERMUTED images (RepackJob::kperm; f.2 and f.4 of the layers that run on k_cnet / k_cnet1w).  The accumulator block of a
+// v_mfma_f32_32x32x16_f16 holds, per lane, rows 8 g + 4 kl + t (g = 0..3, t = 0..3, kl = lane / 32) of one pixel column; the next
+// layer's B fragment wants 8 consecutive k of that column per lane and k-step.  A contraction may visit its k in any order as long
+// as both operands agree, so inside every 32-k block the image's position (k-step s, 8-wide group kl, element j) holds
+//     k = 16 s + 8 (j / 4) + 4 kl + j % 4            <=>  accumulator register 8 s + j of lane group kl
+// and registers 8 s .. 8 s + 7 of an accumulator block ARE the B fragment of k-step s (k_cnet1w: h1 / h2 never leave the register
+// file; k_cnet stores them to LDS in the same order).  sh2_kperm_src(P): the original k of image position P (any multiple of 4
+// positions maps to 4 consecutive k).
+__host__ __device__ static inline int sh2_kperm_src(int P) {
+    const int b = P >> 5, s = (P >> 4) & 1, kl = (P >> 3) & 1, j = P & 7;
+    return 32 * b + 16 * s + 8 * (j >> 2) + 4 * kl + (j & 3);
+}
+
 // ---- the whole coupling network f() = f.0 -> f.2 -> f.4 as ONE kernel + a light finishing kernel (cnet_sh.hip) --------
 bool cnet_supported(int Cin, int H, int W, int hidden, int Cout);
 int cnet_g0(int Cin);                 // 8-wide k groups of the f.0 image (even count)
@@ -120,6 +133,7 @@ struct CnetPending {
     const float* bias; const float* scale;       // f.4 bias (Cout), exp(3 logs) (Cout) of that step
     int mode, Cout;                              // TailMode of that step's coupling
     const float* z; long z_bs;                   // the state that step read: z1 = channels [0, C/2), z2 = [C/2, C)
+    int one_wave;                                // the launch ran on k_cnet1w (cnet1w_sh.hip); run-time evidence for the tests
 };
 // channel mixer applied to a finished state (C = 0: none)
 //   forward: the NEXT step's  y = M ((z + bias) * scale);   reverse: THIS step's  x = (M z) * scale - bias
