@@ -329,7 +329,7 @@ __global__ void __launch_bounds__(256) k_half_to_float(const _Float16* __restric
 int launch_half_to_float(const void* src_half, float* dst, int N, int R, int HW, hipStream_t s) {
     const long n = (long)N * R * HW;
     if (n <= 0) return GLOWHIP_OK;
-    if (HW % 32 != 0) return GLOWHIP_EINVAL;
+    GH_REQUIRE(HW % 32 == 0, "half_to_float: %d pixels per image are not whole 32-pixel tiles of the fp16 tape", HW);
     hipLaunchKernelGGL(k_half_to_float, dim3((unsigned)((n + 2047) / 2048)), dim3(256), 0, s, (const _Float16*)src_half, dst, n, R, HW);
     GH_LAUNCH_CHECK("k_half_to_float");
     return GLOWHIP_OK;
@@ -534,7 +534,9 @@ int launch_chanmix_bwd(const ChanMixBwdArgs& a, hipStream_t s, const WgradReduce
     if (total == 0) return reduce ? launch_wgrad_reduce_batched(*reduce, s) : GLOWHIP_OK;
     size_t lds = (size_t)3 * a.C * CB_LD * sizeof(float);
     ChanMixBwdArgs b = a;
-    b.w_lds = a.matrix && lds + (size_t)a.C * a.C * sizeof(float) <= 64 * 1024 && (reinterpret_cast<uintptr_t>(a.matrix) & 15) == 0;
+    // (C % 4 == 0: the kernel stages W with 16-byte loads / stores at an offset of 3 C 65 floats -- any other C would run up to three
+    // floats past W and the LDS block, and C % 4 == 2 would issue misaligned 16-byte LDS accesses: ADVICE r4)
+    b.w_lds = a.matrix && (a.C & 3) == 0 && lds + (size_t)a.C * a.C * sizeof(float) <= 64 * 1024 && (reinterpret_cast<uintptr_t>(a.matrix) & 15) == 0;
     if (b.w_lds) lds += (size_t)a.C * a.C * sizeof(float);
     const int mix_blocks = cdiv(total, CB_PX);
     // (the reductions ride along where the mixer's LDS block leaves room for several workgroups per CU: they want occupancy)

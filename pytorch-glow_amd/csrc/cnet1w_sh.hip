@@ -195,19 +195,10 @@ __global__ void __launch_bounds__(256) k_cnet1w(CnetArgs a, CnetGeo g) {
 #endif
     };
     GH_STAMP(0);
+    // first what f.0 of chunk 0 needs (its rows, the tables, the window); the ring's first fills are requested behind the window and
+    // land while f.0 of chunk 0 runs
 #pragma unroll
     for (int i = 0; i < NP0; ++i) w0_piece(0, i);
-    ring_begin(0, 0);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) ring_piece(0, i);
-#pragma unroll
-    for (int i = 0; i < NP0; ++i) w0_piece(1, i);
-    ring_begin(1, SLOT);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) ring_piece(1, i);
-    ring_begin(2, 2 * SLOT);
-    ring_piece(2, 0);
-    ring_piece(2, 1);
 
     // ---- P0: tables and the z1 window (tile rows + one halo row / column each side, zero padded) as (hi, lo) halves in LDS; slot e =
     // (8-channel chunk, sub-image, window pixel).  Every load of the round is issued from a clamped address before the first store.
@@ -261,6 +252,17 @@ __global__ void __launch_bounds__(256) k_cnet1w(CnetArgs a, CnetGeo g) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     GH_STAMP(1);
+    ring_begin(0, 0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ring_piece(0, i);
+#pragma unroll
+    for (int i = 0; i < NP0; ++i) w0_piece(1, i);
+    ring_begin(1, SLOT);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ring_piece(1, i);
+    ring_begin(2, 2 * SLOT);
+    ring_piece(2, 0);
+    ring_piece(2, 1);
 
     // ---- per-lane constants of the contractions
     // f.0: window byte address of this lane's pixel for k-step st (the lane's group 2 st + kl = (chunk, tap); past 9 * nchunk: zero
@@ -321,7 +323,8 @@ __global__ void __launch_bounds__(256) k_cnet1w(CnetArgs a, CnetGeo g) {
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) epi1(acc1, 0, gq, Bh, Bl);
     }
-    __syncthreads();          // every wave is done with f.0 buffer 0 before the loop refills it
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the first fills have landed ...
+    __syncthreads();          // ... everybody's; and every wave is done with f.0 buffer 0 before the loop refills it
     GH_STAMP(2);
 
     // ---- P2 with P1 of the next chunk inside: acc2[rt] += W2'[rows of tile rt, chunk c] h1[chunk c]
@@ -422,27 +425,30 @@ __global__ void __launch_bounds__(256) k_cnet1w(CnetArgs a, CnetGeo g) {
             const int f = 2 * c + s;                // k-step
             static_assert(NST0 <= 5, "f.0 k-step st rides in quad st; its epilogue in quads 5 and 6");
             C1_FENCE();
-            if (q4 == 3) {
-                // TOP: fill f + 1 has landed (this wave's pieces: counted wait; everybody's: barrier) and every wave has read all it
-                // wanted from slot s_cur (lgkmcnt(0) before the barrier) -- which fill f + 3 may then overwrite
-#ifndef C1_DBG_NO_VMWAIT
-                if (s == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(8 + NP0) : "memory");
-                else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-#endif
-#ifndef C1_DBG_NO_BARRIER
-                __builtin_amdgcn_s_barrier();
-#endif
-                asm volatile("" ::: "memory");
-                s_fill = s_cur;
-                s_cur = s_cur + SLOT == 3 * SLOT ? 0 : s_cur + SLOT;
-                ring_begin(f + 3, s_fill);
-                C1_FENCE();
-            }
             const int ff = q4 == 3 ? f + 3 : f + 2, i0 = q4 == 3 ? 0 : 2 + 2 * q4;      // the fill in progress, this quad's two pieces
             const int st = Q;                       // f.0 k-step of this quad (Q < NST0)
             const int nq4 = (q4 + 1) & 3;           // the next quad (after a TOP: the next k-step's first quad, from the slot that has just landed)
 #pragma unroll
             for (int k = 0; k < 12; ++k) {
+                if (q4 == 3 && k == 3) {
+                    // TOP: fill f + 1 has landed (this wave's pieces: counted wait; everybody's: barrier) and every wave has read all
+                    // it wanted from slot s_cur (lgkmcnt(0) before the barrier) -- which fill f + 3 may then overwrite.  It sits in
+                    // front of the quad's FOURTH slot: the last reads of the slot were issued in the previous quad, three MFMAs and
+                    // more ago, so the lgkmcnt(0) no longer waits out an LDS round trip (at the head of the quad it did, 32 times
+                    // per tile), and the next k-step's first fragments are requested from slot 4 on.
+#ifndef C1_DBG_NO_VMWAIT
+                    if (s == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(8 + NP0) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+#endif
+#ifndef C1_DBG_NO_BARRIER
+                    __builtin_amdgcn_s_barrier();
+#endif
+                    asm volatile("" ::: "memory");
+                    s_fill = s_cur;
+                    s_cur = s_cur + SLOT == 3 * SLOT ? 0 : s_cur + SLOT;
+                    ring_begin(f + 3, s_fill);
+                    C1_FENCE();
+                }
                 const int i = k & 3, sw = k >> 2;
                 acc2[4 * q4 + i] = C1_MFMA(sw == 2 ? AL[i] : AH[i], sw == 1 ? Bl[s] : Bh[s], acc2[4 * q4 + i]);
 #ifndef C1_DBG_NO_AREAD
@@ -451,8 +457,8 @@ __global__ void __launch_bounds__(256) k_cnet1w(CnetArgs a, CnetGeo g) {
 #endif
                 // the stream: two ring pieces per quad; f.0 rows of chunk c + 2 in the first three quads of the chunk
 #ifndef C1_DBG_NO_DMA
-                if (k == 0) ring_piece(ff, i0);
-                if (k == 2) ring_piece(ff, i0 + 1);
+                if (k == (q4 == 3 ? 3 : 0)) ring_piece(ff, i0);
+                if (k == (q4 == 3 ? 9 : 2)) ring_piece(ff, i0 + 1);
                 if (k == 1 && s == 0 && q4 < 3) {
 #pragma unroll
                     for (int i3 = q4; i3 < NP0; i3 += 3) w0_piece(min(c + 2, NCH - 1), i3);
@@ -476,13 +482,13 @@ __global__ void __launch_bounds__(256) k_cnet1w(CnetArgs a, CnetGeo g) {
                         if (st + 1 < NST0) { B0h = *reinterpret_cast<const h8*>(pb); A0l = *reinterpret_cast<const h8*>(pa + G0 * 512); }
                     }
                 }
-                if (Q == 7 && k < 4) {
+                if (Q == 7 && k >= 8) {
                     const char* pa = lds1 + a0lane + (min(c + 2, NCH - 1) & 1) * (G0 * 1024);
                     const char* pb = lds1 + woff[0];
-                    if (k == 0) B0l = *reinterpret_cast<const h8*>(pb + wlo);
-                    if (k == 1) A0h = *reinterpret_cast<const h8*>(pa);
-                    if (k == 2) B0h = *reinterpret_cast<const h8*>(pb);
-                    if (k == 3) A0l = *reinterpret_cast<const h8*>(pa + G0 * 512);
+                    if (k == 8) B0l = *reinterpret_cast<const h8*>(pb + wlo);
+                    if (k == 9) A0h = *reinterpret_cast<const h8*>(pa);
+                    if (k == 10) B0h = *reinterpret_cast<const h8*>(pb);
+                    if (k == 11) A0l = *reinterpret_cast<const h8*>(pa + G0 * 512);
                 }
                 // its epilogue: the 24 slots of quads 5 and 6
                 if (Q == 5 || Q == 6) {
@@ -520,16 +526,6 @@ __global__ void __launch_bounds__(256) k_cnet1w(CnetArgs a, CnetGeo g) {
         const int c = ks >> 1, s = ks & 1;
         const int F = NKS + ks / K4, kk = ks % K4;        // fill being read, k-step inside it
         C1_FENCE();
-        if (kk == K4 - 1 && F + 1 <= FL) {
-            if (F + 2 <= FL) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            s_fill = s_cur;
-            s_cur = s_cur + SLOT == 3 * SLOT ? 0 : s_cur + SLOT;
-            if (F + 3 <= FL) ring_begin(F + 3, s_fill);
-            C1_FENCE();
-        }
         // pieces of the fill in progress: two with the TOP, the other six over the first K4 - 1 k-steps of a fill
         const int ff = kk == K4 - 1 ? F + 3 : F + 2;
         constexpr int PER = K4 > 1 ? (6 + K4 - 2) / (K4 - 1) : 6;
@@ -538,6 +534,16 @@ __global__ void __launch_bounds__(256) k_cnet1w(CnetArgs a, CnetGeo g) {
         constexpr int NM = 3 * NRT4;
 #pragma unroll
         for (int k = 0; k < NM; ++k) {
+            if (kk == K4 - 1 && F + 1 <= FL && k == 3) {      // TOP (as in the loop above: in front of the k-step's fourth slot)
+                if (F + 2 <= FL) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                s_fill = s_cur;
+                s_cur = s_cur + SLOT == 3 * SLOT ? 0 : s_cur + SLOT;
+                if (F + 3 <= FL) ring_begin(F + 3, s_fill);
+                C1_FENCE();
+            }
             const int i = k % NRT4, sw = k / NRT4;
             if (ks == 0 && sw == 0) c1_mfma_v0(accT[i], A4H[i], Hh[0][0]);
             else c1_mfma_v(accT[i], sw == 2 ? A4L[i] : A4H[i], sw == 1 ? Hl[c & 1][s] : Hh[c & 1][s]);
@@ -554,29 +560,36 @@ __global__ void __launch_bounds__(256) k_cnet1w(CnetArgs a, CnetGeo g) {
     for (int i = 0; i < NRT4; ++i) c1_settle(accT[i]);
     __syncthreads();           // every wave is done with the ring: it becomes the staging area of T
 
-    // ---- P4 (as k_cnet's): T -> LDS as fp32 [row m][pixel] (row scale applied), then the 9-tap sums
+    // ---- P4: T -> LDS as fp32, PIXEL-major [pixel][RP rows] (row scale applied), then the 9-tap sums.  A lane's four consecutive
+    // rows of a pixel are one 16-byte store, and a thread of the tap sums takes one pixel and FOUR output channels: row m = tap * Cout
+    // + co puts them side by side, one 16-byte read per tap -- a quarter of the LDS instructions of the [row][pixel] form in both
+    // halves of the phase.  RP / 4 is odd: the 16-byte groups of consecutive pixels fall on distinct banks.
     float* T = reinterpret_cast<float*>(lds1);
-    const int Cout = g.Cg;
+    const int Cout = g.Cg;                      // (a multiple of 4: cnet1w_takes)
+    const int rows = 9 * Cout;
+    const int RP = 4 * ((rows >> 2) | 1);
     {
-        const int q = wid * 32 + ml;
+        float* dst = T + (wid * 32 + ml) * RP + 4 * kl;
 #pragma unroll
-        for (int i = 0; i < NRT4; ++i) {
-            float* dst = T + ((i * 32 + 4 * kl) << LPXT) + q;
+        for (int i = 0; i < NRT4; ++i)
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
-                const f32x4_t rsv = *reinterpret_cast<const f32x4_t*>(t_rs4 + i * 32 + 8 * gq + 4 * kl);
+                const int r0 = i * 32 + 8 * gq;
+                const f32x4_t rsv = *reinterpret_cast<const f32x4_t*>(t_rs4 + r0 + 4 * kl);
+                f32x4_t v;
 #pragma unroll
-                for (int t = 0; t < 4; ++t) dst[(8 * gq + t) << LPXT] = accT[i][4 * gq + t] * rsv[t];
+                for (int t = 0; t < 4; ++t) v[t] = accT[i][4 * gq + t] * rsv[t];
+                if (r0 + 4 * kl < rows) *reinterpret_cast<f32x4_t*>(dst + r0) = v;      // (rows beyond 9 Cout are the image's zero padding)
             }
-        }
     }
     __syncthreads();
     GH_STAMP(5);
     float* hpart = a.scratch;
     float* hup = a.scratch + (long)a.N * a.Cout * HW;
     float* hdn = hup + (long)g.tiles * a.Cout * W;
+    const int ngrp = Cout >> 2;
     {
-        // a thread keeps ITS pixel (tid & 127) and walks the channels ce = tid >> 7, + 2, ...
+        // a thread keeps ITS pixel (tid & 127) and walks the groups of four channels tid >> 7, + 2, ...
         const int q = tid & 127;
         const int sub = q >> g.lsub, qq = q & submask;
         const int r = qq >> g.wshift, x = qq & (W - 1);
@@ -587,43 +600,48 @@ __global__ void __launch_bounds__(256) k_cnet1w(CnetArgs a, CnetGeo g) {
         for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) {
-                const int tap = dy * 3 + dx;              // out(r, x) += T[tap (dy, dx)][source (r + dy - 1, x + dx - 1)]
+                const int tap = dy * 3 + dx;              // out(r, x) += T[source (r + dy - 1, x + dx - 1)][tap (dy, dx)]
                 ok[tap] = r + dy - 1 >= 0 && r + dy - 1 < g.R && x + dx - 1 >= 0 && x + dx - 1 < W;
-                off[tap] = ((tap * Cout) << LPXT) + q + (ok[tap] ? (dy - 1) * W + (dx - 1) : 0);
+                off[tap] = (q + (ok[tap] ? (dy - 1) * W + (dx - 1) : 0)) * RP + tap * Cout;
             }
         if (n < a.N) {
             float* hp = hpart + (n * a.Cout) * HW + (long)(y0 + r) * W + x;
-            for (int ce = tid >> LPXT; ce < Cout; ce += NT >> LPXT) {
-                const float* tp = T + (ce << LPXT);
-                float v[9];
+            for (int cg = tid >> LPXT; cg < ngrp; cg += NT >> LPXT) {
+                const float* tp = T + 4 * cg;
+                f32x4_t v[9];
 #pragma unroll
-                for (int tap = 0; tap < 9; ++tap) v[tap] = tp[off[tap]];
-                float sum = 0.f;
+                for (int tap = 0; tap < 9; ++tap) v[tap] = *reinterpret_cast<const f32x4_t*>(tp + off[tap]);
+                f32x4_t sum = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int tap = 0; tap < 9; ++tap) sum += ok[tap] ? v[tap] : 0.f;
-                hp[(long)ce * HW] = sum;
+                for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) sum[j] += ok[tap] ? v[tap][j] : 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) hp[(long)(4 * cg + j) * HW] = sum[j];
             }
         }
     }
     // halo rows (NI = 1 only): what the tile's first row gives to image row y0 - 1, its last row to row y0 + R
     if (g.NI == 1 && g.R < H) {
-        const int hitems = 2 * Cout * W;
+        const int hitems = 2 * ngrp * W;
         for (int e = tid; e < hitems; e += NT) {
-            const int dn = e >= Cout * W;
-            const int rem = e - dn * (Cout * W);
-            const int co = rem >> g.wshift, x = rem & (W - 1);
+            const int dn = e >= ngrp * W;
+            const int rem = e - dn * (ngrp * W);
+            const int cg = rem >> g.wshift, x = rem & (W - 1);
             if (dn ? (y0 + g.R >= H) : (y0 == 0)) continue;
             const int rsrc = dn ? g.R - 1 : 0;
             const int dyt = dn ? 0 : 2;                 // filter row applied by the outside pixel to this source row
-            float sacc = 0.f;
-            float v[3]; bool ok[3];
+            f32x4_t v[3]; bool ok[3];
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) {
                 ok[dx] = x + dx - 1 >= 0 && x + dx - 1 < W;
-                v[dx] = T[(((dyt * 3 + dx) * Cout + co) << LPXT) + rsrc * W + (ok[dx] ? x + dx - 1 : x)];
+                v[dx] = *reinterpret_cast<const f32x4_t*>(T + (rsrc * W + (ok[dx] ? x + dx - 1 : x)) * RP + (dyt * 3 + dx) * Cout + 4 * cg);
             }
-            sacc += (ok[0] ? v[0] : 0.f) + (ok[1] ? v[1] : 0.f) + (ok[2] ? v[2] : 0.f);
-            (dn ? hdn : hup)[((long)tb * a.Cout + co) * W + x] = sacc;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float sacc = (ok[0] ? v[0][j] : 0.f) + (ok[1] ? v[1][j] : 0.f) + (ok[2] ? v[2][j] : 0.f);
+                (dn ? hdn : hup)[((long)tb * a.Cout + 4 * cg + j) * W + x] = sacc;
+            }
         }
     }
     GH_STAMP(6);
@@ -644,7 +662,9 @@ bool cnet1w_takes(const CnetArgs& a, const CnetGeo& g) {
     if (a.tape_h1 || a.pre_on || a.bwd) return false;
     if (!cnet1w_instance(a, g)) return false;
     if (cnet1w_lds_bytes(g, a.hidden) > 160 * 1024) return false;
-    if ((size_t)g.Mpad4 * 128 * sizeof(float) > (size_t)3 * a.hidden * 64 + (size_t)2 * g.G * 1024) return false;      // T staging in front of the window
+    if (g.Cg % 4 != 0) return false;                 // the tap sums take four output channels per 16-byte read
+    const size_t rp = 4 * (((size_t)9 * g.Cg >> 2) | 1);
+    if (rp * 128 * sizeof(float) > (size_t)3 * a.hidden * 64 + (size_t)2 * g.G * 1024) return false;      // T staging in front of the window
     return true;
 }
 

@@ -85,25 +85,34 @@ def manual_seed(seed):
         torch.cuda.manual_seed_all(seed)
 
 
-# ----------------------------------------------------------------------------- result directories (util.py:154-222)
+# ----------------------------------------------------------------------------- result directories
+# Contract kept from the reference (misc/util.py:154-222): a run lives in `<result_dir>/<NNN>-<desc>/` (NNN = the next free
+# three-digit run id) and carries its profile as `config.json`; runs are found again by path, by directory name or by run id.
+_RUN_DIR = re.compile(r'(\d+)-.*')
+
+
 def check_path(path):
-    if not os.path.exists(path):
-        os.makedirs(path)
+    os.makedirs(path, exist_ok=True)
+
+
+def _run_ids(result_dir):
+    """Run ids of the entries of result_dir that look like `<digits>-<anything>`."""
+    try:
+        names = os.listdir(result_dir)
+    except FileNotFoundError:
+        return []
+    return [int(m.group(1)) for m in map(_RUN_DIR.fullmatch, names) if m]
 
 
 def create_result_subdir(result_dir, desc, profile):
-    """`<result_dir>/<run id>-<desc>` with the next free 3-digit run id; the profile is exported as config.json."""
-    run_id = 0
-    for fname in glob.glob(os.path.join(result_dir, '*')):
-        found = re.findall(r'^([\d]+)-', os.path.basename(fname))
-        if found:
-            run_id = max(run_id, int(found[0]) + 1)
-    result_subdir = os.path.join(result_dir, '{:03d}-{:s}'.format(run_id, desc))
-    check_path(result_subdir)
-    print("[Builder] Saving results to {}".format(result_subdir))
-    with open(os.path.join(result_subdir, 'config.json'), 'w') as f:
+    """Make and return the directory of a new run; the profile is exported next to its results."""
+    run_id = max(_run_ids(result_dir), default=-1) + 1
+    run_dir = os.path.join(result_dir, '%03d-%s' % (run_id, desc))
+    check_path(run_dir)
+    with open(os.path.join(run_dir, 'config.json'), 'w') as f:
         json.dump(profile, f)
-    return result_subdir
+    print('[Builder] results of this run: %s' % run_dir)
+    return run_dir
 
 
 def locate_result_subdir(result_dir, run_id_or_result_subdir):
@@ -124,9 +133,17 @@ def locate_result_subdir(result_dir, run_id_or_result_subdir):
     return None
 
 
-# ----------------------------------------------------------------------------- snapshots (util.py:247-376)
+# ----------------------------------------------------------------------------- snapshots
+# Contract kept from the reference (misc/util.py:247-376) so that snapshots are interchangeable both ways: the file names
+# `network-snapshot-<6-digit step>.pth` / `network-snapshot-best.pth`, and a torch.save'd dict with exactly the keys of
+# SNAPSHOT_KEYS -- 'graph' the model's state_dict (reference layout: SURVEY 8b), 'optimizer' its state_dict, 'criterion' one
+# state_dict per named criterion.  How the files are written and found is this repo's own.
+SNAPSHOT_KEYS = ('step', 'graph', 'optimizer', 'criterion', 'seconds')
+_SNAPSHOT_FILE = re.compile(r'network-snapshot-(\d+)\.pth')
+
+
 def get_model_name(step):
-    return 'network-snapshot-{:06d}.pth'.format(step)
+    return 'network-snapshot-%06d.pth' % step
 
 
 def get_best_model_name():
@@ -134,52 +151,58 @@ def get_best_model_name():
 
 
 def get_last_model_name(result_subdir):
-    steps = [int(m.group(1)) for m in (re.search(r'network-snapshot-([\d]+).pth', f) for f in os.listdir(result_subdir))
-             if m and os.path.isfile(os.path.join(result_subdir, m.string))]
+    steps = [int(m.group(1)) for m in map(_SNAPSHOT_FILE.fullmatch, os.listdir(result_subdir)) if m]
     return get_model_name(max(steps, default=-1))
 
 
+def _bare(module):
+    """The module itself behind a DataParallel / DistributedDataParallel style wrapper."""
+    return getattr(module, 'module', module)
+
+
 def save_model(result_subdir, step, graph, optimizer, seconds, is_best, criterion_dict=None):
-    """The reference's snapshot: a torch.save'd dict {step, graph (state_dict), optimizer, criterion, seconds}; a
-    DataParallel-style wrapper is unwrapped through `.module`.  Snapshots are interchangeable with the reference's."""
-    state = {
-        'step': step,
-        'graph': graph.module.state_dict() if hasattr(graph, "module") else graph.state_dict(),
-        'optimizer': optimizer.state_dict(),
-        'criterion': {} if criterion_dict is None else {k: v.state_dict() for k, v in criterion_dict.items()},
-        'seconds': seconds,
-    }
-    save_path = os.path.join(result_subdir, get_model_name(step))
-    torch.save(state, save_path)
+    """Write the snapshot of `step` (and, for the best model so far, a second copy under the 'best' name).  The file appears
+    under its final name only once it is complete (written next to it, then renamed)."""
+    payload = dict(zip(SNAPSHOT_KEYS, (step, _bare(graph).state_dict(), optimizer.state_dict(),
+                                       {name: crit.state_dict() for name, crit in (criterion_dict or {}).items()}, seconds)))
+    target = os.path.join(result_subdir, get_model_name(step))
+    partial = target + '.partial'
+    torch.save(payload, partial)
+    os.replace(partial, target)
     if is_best:
-        shutil.copy(save_path, os.path.join(result_subdir, get_best_model_name()))
+        shutil.copyfile(target, os.path.join(result_subdir, get_best_model_name()))
+
+
+def _snapshot_path(result_subdir, which):
+    """`which`: a step number, 'best', 'latest' (the reference leaves 'latest' unresolved and fails), a file name inside
+    result_subdir, or a path."""
+    if isinstance(which, int):
+        name = get_model_name(which)
+    elif which == 'best':
+        name = get_best_model_name()
+    elif which == 'latest':
+        name = get_last_model_name(result_subdir)
+    else:
+        name = str(which)
+    for cand in (name, os.path.join(result_subdir or '', name)):
+        if os.path.exists(cand):
+            return cand
+    raise FileNotFoundError('no model snapshot for %r (looked for %s in %s)' % (which, name, result_subdir))
 
 
 def load_model(result_subdir, step_or_model_path, graph, optimizer=None, criterion_dict=None, device=None):
-    """Load a snapshot (a step number, 'best', or a path) into `graph` (+ optimizer / criteria), mark every ActNorm as
-    initialised and return the snapshot dict.  Reads the reference's own .pth files."""
-    model_path = step_or_model_path
-    if isinstance(step_or_model_path, int):
-        model_path = get_model_name(step_or_model_path)
-    if step_or_model_path == 'best':
-        model_path = get_best_model_name()
-    if step_or_model_path == 'latest':
-        model_path = get_last_model_name(result_subdir)   # (the reference sets None here and then fails in os.path.exists)
-    if not os.path.exists(model_path):
-        model_path = os.path.join(result_subdir or '', model_path)
-        if not os.path.exists(model_path):
-            raise FileNotFoundError('Failed to find model snapshot with {}'.format(step_or_model_path))
-    if isinstance(device, int):
-        device = 'cuda:{}'.format(device)
-    state = torch.load(model_path, map_location=device)
+    """Load a snapshot into `graph` (and the optimizer / criteria when given), mark every ActNorm as initialised -- a snapshot
+    carries trained ActNorm parameters, the data-dependent init must not run again -- and return the snapshot dict.  Reads the
+    reference's own .pth files."""
+    path = _snapshot_path(result_subdir, step_or_model_path)
+    state = torch.load(path, map_location='cuda:%d' % device if isinstance(device, int) else device)
     graph.load_state_dict(state['graph'])
     graph.set_actnorm_inited()
     if optimizer is not None:
         optimizer.load_state_dict(state['optimizer'])
-    if criterion_dict is not None:
-        for k in criterion_dict.keys():
-            criterion_dict[k].load_state_dict(state['criterion'][k])
-    print('[Builder] Load model snapshot successfully from {}'.format(model_path))
+    for name, crit in (criterion_dict or {}).items():
+        crit.load_state_dict(state['criterion'][name])
+    print('[Builder] model snapshot loaded: %s' % path)
     return state
 
 

@@ -51,14 +51,29 @@ def _writer(log_dir):
         return _ScalarLog(log_dir)
 
 
+def _shared_seed(seed, world):
+    """rank 0's `seed` on every rank of the default process group (the value itself in a single-process run)."""
+    import torch.distributed as dist
+    if world <= 1 or not (dist.is_available() and dist.is_initialized()):
+        assert world <= 1, "a multi-rank Trainer without a profile seed needs the process group to agree on one"
+        return int(seed)
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    t = torch.tensor([int(seed)], dtype=torch.int64, device=dev)
+    dist.broadcast(t, src=0)
+    return int(t.item())
+
+
 class _ShardSampler(torch.utils.data.Sampler):
     """Indices of rank `rank`'s shard of every global batch: one seeded permutation per epoch (the same on every rank), cut
     into global batches of `global_batch`, of which this rank yields positions [rank*per, (rank+1)*per)."""
 
     def __init__(self, dataset, global_batch, rank, world, seed=None):
         assert global_batch % world == 0, f"global batch {global_batch} not divisible by {world} ranks"
-        if seed is None:      # no profile seed: follow torch's seed as DataLoader(shuffle=True) does (trainer.py:36-41) -- every rank
-            seed = torch.initial_seed() % (2 ** 31)       # of a data-parallel run seeds alike (util.manual_seed), so the shards line up
+        if seed is None:
+            # no profile seed: follow torch's seed as DataLoader(shuffle=True) does (trainer.py:36-41).  The ranks of a
+            # data-parallel run do NOT seed alike by themselves (nothing on this path calls util.manual_seed), and ranks that
+            # shuffle differently would silently overlap / omit samples: rank 0's draw is THE seed (ADVICE r4).
+            seed = _shared_seed(torch.initial_seed() % (2 ** 31), world)
         self.n, self.gb, self.rank, self.world, self.seed, self.epoch = len(dataset), global_batch, rank, world, seed, 0
         self.per = global_batch // world
 

@@ -62,7 +62,9 @@ def data_dependent_init(glow, x_local: torch.Tensor, rank: int, world: int,
     `init_fn(glow, x)` defaults to one training-mode forward (which performs the init on the HIP path).
     The other ranks have nothing to do while rank 0 runs the init pass (66 ms at config B, 0.3 s at config E, once): they wait in a
     barrier of their own first, so that the wait is visible as such (`STEP0["wait_ms"]`) and the parameter broadcast behind it is
-    timed on its own; the process group's timeout (bench.py / Trainer: 30 minutes) is what bounds the wait, not RCCL's default."""
+    timed on its own.  What bounds that wait is the timeout of the process group the CALLER created: bench.py creates it with 30
+    minutes; a launcher that leaves the backend default (10 minutes for RCCL) is still two orders of magnitude above the init pass.
+    On device tensors the barrier names its device (an RCCL barrier on a group that is not bound to one otherwise guesses it)."""
     import time
     sync = (lambda: torch.cuda.synchronize(x_local.device)) if x_local.is_cuda else (lambda: None)
     t0 = time.perf_counter()
@@ -77,7 +79,10 @@ def data_dependent_init(glow, x_local: torch.Tensor, rank: int, world: int,
     sync()
     t1 = time.perf_counter()
     if world > 1:
-        dist.barrier()
+        if x_local.is_cuda and dist.get_backend() == "nccl":
+            dist.barrier(device_ids=[x_local.device.index])
+        else:
+            dist.barrier()
     t2 = time.perf_counter()
     broadcast_parameters(glow, src=0, world=world)
     sync()

@@ -90,7 +90,9 @@ class _HipOptimizer(torch.optim.Optimizer):
         # each -- and rebuilt (with the full checks) only when one of them moved; the state addresses change only with the state
         # buffers, which resets the key (a reloaded state or a re-allocated parameter must not reuse the table).
         plist = [p for g in self.param_groups for p in g["params"]]
-        key = tuple((p.data_ptr(), p.grad.data_ptr()) if p.grad is not None else (0, 0) for p in plist)
+        # (dtype and contiguity are part of the key: a gradient that comes back at the same address as a different view must not ride
+        # on the checks the cached table was built under -- ADVICE r4)
+        key = tuple((p.data_ptr(), p.grad.data_ptr(), p.grad.dtype, p.grad.is_contiguous()) if p.grad is not None else (0, 0, None, True) for p in plist)
         self._steps += 1
         self._publish_step()
         norm = torch.zeros(1, device=dev)
@@ -275,7 +277,12 @@ class TrainLoop:
 
     def _run_again(self, pending):
         """The skipped batch on the exact-fp32 family, with the learning rate of the step it belonged to.  Its loss and norm
-        replace nothing that was already returned (that step reported NaN): they are kept in ``reruns`` / ``last_rerun``."""
+        replace nothing that was already returned (that step reported NaN): they are kept in ``reruns`` / ``last_rerun``.
+        Accepted ordering: the re-run of batch N is applied AFTER step N + 1 has updated the parameters -- the price of a
+        range check without a host sync on the step's own work; an overflow is a once-in-a-run event and the two updates commute to
+        first order in the learning rate.  If step N + 1 is skipped on the device as well, its count is only taken back at N + 2, so
+        this re-run's bias correction uses s + 2 instead of s + 1: a relative change of the step size of O(beta^s), nothing after
+        warm-up.  The float() conversions below are host syncs on this rare path only."""
         x_local, _, _, lr = pending
         plan = self.glow.flow.plan_for(x_local)
         prev = plan.family

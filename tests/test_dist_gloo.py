@@ -277,3 +277,29 @@ def test_world2_bucketed_allreduce_equals_flat_allreduce():
         for b, f, p in zip(bucketed, flat, m.parameters()):
             assert torch.equal(b, f)
             assert torch.allclose(b, p.grad, atol=1e-6)
+
+
+def _sampler_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pytorch_glow_amd.network.trainer import _ShardSampler
+        torch.manual_seed(1234 + 77 * rank)      # ranks of an unseeded run draw DIFFERENT torch seeds
+        s = _ShardSampler(list(range(40)), global_batch=8, rank=rank, world=world, seed=None)
+        ret[rank] = dict(seed=s.seed, epoch0=list(iter(s)), epoch1=list(iter(s)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world2_unseeded_sampler_agrees_on_rank0s_seed():
+    """without a profile seed every rank used its own torch.initial_seed(), the per-epoch permutations
+    differed and the 'positions [r*per, (r+1)*per) of the same global batch' sharding overlapped / omitted samples.  Now rank 0's
+    draw is broadcast: equal seeds, disjoint shards that together are each epoch's 40 // 8 global batches."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_sampler_worker, args=(2, free_port(), ret), nprocs=2, join=True)
+    a, b = ret[0], ret[1]
+    assert a["seed"] == b["seed"] == (1234 % (2 ** 31))
+    for ep in ("epoch0", "epoch1"):
+        assert len(a[ep]) == len(b[ep]) == 20 and not (set(a[ep]) & set(b[ep])) and len(set(a[ep]) | set(b[ep])) == 40
+    assert a["epoch0"] != a["epoch1"]

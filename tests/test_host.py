@@ -202,6 +202,30 @@ def test_snapshot_roundtrip_and_result_dirs(tmp_path):
     assert util.load_deltaz(os.path.join(root, "missing.npy")) is None
 
 
+def test_repo_written_snapshot_is_key_identical_to_the_reference_written_one(tmp_path):
+    """a snapshot written by THIS package's util.save_model and the one the reference's util.save_model wrote
+    (tests/golden/g9_reference_snapshot.pth, same model profile) have the same top-level keys, the same state_dict keys in
+    the same order with the same shapes and dtypes, and the same optimizer-state layout -- the file format is the contract,
+    the code that writes it is not."""
+    from conftest import GOLDEN
+    ref = torch.load(os.path.join(GOLDEN, "g9_reference_snapshot.pth"), map_location="cpu")
+    glow = G.Glow(_g9_hps())
+    opt = torch.optim.Adam(glow.parameters(), lr=1e-4)
+    opt.load_state_dict(ref["optimizer"])            # (same parameter groups, so that the states below are comparable)
+    util.save_model(str(tmp_path), int(ref["step"]), glow, opt, float(ref["seconds"]), is_best=True)
+    assert not [f for f in os.listdir(tmp_path) if f.endswith(".partial")]
+    mine = torch.load(os.path.join(str(tmp_path), util.get_model_name(int(ref["step"]))), map_location="cpu")
+    assert tuple(mine) == util.SNAPSHOT_KEYS and set(mine) == set(ref)
+    assert list(mine["graph"]) == list(ref["graph"])
+    assert all(mine["graph"][k].shape == ref["graph"][k].shape and mine["graph"][k].dtype == ref["graph"][k].dtype for k in ref["graph"])
+    assert set(mine["optimizer"]) == set(ref["optimizer"])
+    assert [sorted(g) for g in mine["optimizer"]["param_groups"]] == [sorted(g) for g in ref["optimizer"]["param_groups"]]
+    assert {k: sorted(v) for k, v in mine["optimizer"]["state"].items()} == {k: sorted(v) for k, v in ref["optimizer"]["state"].items()}
+    assert mine["criterion"] == ref["criterion"] == {}
+    best = torch.load(os.path.join(str(tmp_path), util.get_best_model_name()), map_location="cpu")
+    assert best["step"] == mine["step"] and list(best["graph"]) == list(mine["graph"])
+
+
 def test_builder_needs_a_hip_device_and_knows_the_reference_tables():
     from pytorch_glow_amd.network import Builder
     assert set(Builder.optimizer_dict) == {"adam", "adamax"}
