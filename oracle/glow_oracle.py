@@ -408,9 +408,11 @@ def seeded_state_dict(cfg, seed: int = 2384, zeros_std: float = 0.002, invconv_p
     return sd
 
 
-def glow_init_actnorm(x, noise, sd, cfg) -> Dict[str, torch.Tensor]:
+def glow_init_actnorm(x, noise, sd, cfg, perm_tables=None) -> Dict[str, torch.Tensor]:
     """The first training-mode forward (network/trainer.py:112-115, module.py:45-46,66-67):
-    every ActNorm's bias/logs are set from the activations that reach it.  Returns a NEW dict."""
+    every ActNorm's bias/logs are set from the activations that reach it.  Returns a NEW dict.
+    ``perm_tables`` = {layer index: (indices, indices_inverse)} for the 'reverse' / 'shuffle' permutations
+    (network/module.py:372-397), as glow_forward takes them."""
     sd = dict(sd)
     z = x + noise
     for kind, i, _ in flow_layout(cfg):
@@ -426,7 +428,7 @@ def glow_init_actnorm(x, noise, sd, cfg) -> Dict[str, torch.Tensor]:
             if cfg["flow_permutation"] == "invconv":
                 y, _ = invconv(y, sd[p + "invconv.weight"], None)
             else:
-                raise NotImplementedError("init pass restated for invconv models only")
+                y = permute2d(y, perm_tables[i][0], perm_tables[i][1], reverse=False)
             z1, z2 = split_channel(y, "simple")
             h = F.conv2d(z1, sd[p + "f.0.weight"], None, padding=1)
             b0, l0 = actnorm_init(h, 1.0)

@@ -18,6 +18,8 @@ Fixtures:
   g6_split2d.npz         fwd logp; rev with injected eps for eps_std in {None, 0, 0.7}
   g7_glow_tiny.npz       Glow 16x16x3 L=2 K=2 hidden 32 (affine+invconv, additive+reverse):
                          noise, z, nll, decode with injected eps, data-dependent init
+  g7_glow_tiny_grads.npz d mean(nll) / d theta for every parameter + d / d x of the two G7 models, from the reference's own backward
+                         (F4 shim: misc.ops.split_channel returning clones)
   g9_inferer.npz + g9_reference_snapshot.pth
                          a snapshot WRITTEN BY the reference (misc/util.py save_model, after one Adam step) and what the
                          reference's Inferer (network/inferer.py) computes from it: encode, attribute deltaz (with the data
@@ -317,6 +319,50 @@ def g7(g):
     save("g7_glow_tiny.npz", out)
 
 
+def g7_grads():
+    """SURVEY 8c G7, second half: d mean(nll) / d theta for EVERY parameter and d mean(nll) / d x, recorded from the reference's own
+    backward.  Inputs are the committed G7 fixture (eval state_dict `sd`, batch `x`, dequantisation noise `noise`), so the other
+    fixtures' random streams are untouched.  The reference's backward trips over its in-place coupling ops (`z2 += ...` on a VIEW
+    made by misc.ops.split_channel, network/model.py:105-113): the F4 shim of SURVEY 8c -- split_channel returning CLONES of the
+    two halves -- changes no value and lets autograd run."""
+    fx = dict(np.load(os.path.join(HERE, "g7_glow_tiny.npz")))
+    orig_split = rops.split_channel
+    shim = lambda t, s="simple": tuple(a.clone() for a in orig_split(t, s))
+    rops.split_channel = shim
+    out = {}
+    try:
+        for coup, perm in (("affine", "invconv"), ("additive", "reverse")):
+            tag = f"{coup}_{perm}"
+            np.random.seed(5)
+            glow = rmodel.Glow(tiny_hps(coup, perm))
+            sd = {k[len(tag) + 4:]: torch.from_numpy(v) for k, v in fx.items() if k.startswith(tag + ".sd.")}
+            glow.load_state_dict(sd)
+            if perm != "invconv":           # the fixed channel permutations are attributes, not parameters
+                for i, layer in enumerate(glow.flow.layers):
+                    if hasattr(layer, perm):
+                        getattr(layer, perm).indices = fx[f"{tag}.indices.{i}"].copy()
+                        getattr(layer, perm).indices_inverse = fx[f"{tag}.indices_inverse.{i}"].copy()
+            glow.set_actnorm_inited()
+            glow.eval()
+            x = torch.from_numpy(fx[f"{tag}.x"]).clone().requires_grad_(True)
+            z, nll, noise = run_glow(glow, x, 12)          # same seed as G7 (b): the same noise
+            assert np.array_equal(noise.numpy(), fx[f"{tag}.noise"]) and np.allclose(nll.detach().numpy(), fx[f"{tag}.nll"], atol=1e-6)
+            loss = rmodel.Glow.generative_loss(nll)
+            loss.backward()
+            out[f"{tag}.loss"] = loss.detach()
+            out[f"{tag}.dx"] = x.grad.detach()
+            n_none = 0
+            for name, p_ in glow.named_parameters():
+                if p_.grad is None:
+                    n_none += 1          # h_top: detached by the reference (model.py:372)
+                    continue
+                out[f"{tag}.grad.{name}"] = p_.grad.detach()
+            assert n_none == 1, n_none
+    finally:
+        rops.split_channel = orig_split
+    save("g7_glow_tiny_grads.npz", out)
+
+
 def g8():
     """celeba.json-sized model driven by the ORACLE's seeded weight procedure: commit digests only."""
     cfg = O.default_cfg(batch=2)
@@ -433,7 +479,11 @@ if __name__ == "__main__":
     if os.environ.get("ONLY") == "g9":
         g9(torch.Generator().manual_seed(99))
         sys.exit(0)
+    if os.environ.get("ONLY") == "g7_grads":
+        g7_grads()
+        sys.exit(0)
     g1(g); g2(g); g3(g); g4(g); g5(g); g6(g); g7(g)
+    g7_grads()
     g8()
     g9(torch.Generator().manual_seed(99))
     leftovers = [os.path.join(r, d) for r, ds, _ in os.walk(REF) for d in ds if d == "__pycache__"]

@@ -93,6 +93,43 @@ def test_glow_gradients_vs_autograd_oracle(coup, perm, hidden, image):
     print(f"worst parameter {worst[0]} at {worst[1]:.2f} of its bound; dL/dx err {egx:.2e}")
 
 
+@pytest.mark.parametrize("coup,perm", [("affine", "invconv"), ("additive", "reverse")])
+def test_glow_gradients_vs_the_reference_recorded_goldens(coup, perm):
+    """the HIP training step against gradients recorded from the REFERENCE's own backward
+    (tests/golden/g7_glow_tiny_grads.npz: tiny Glow, every parameter + dL/dx) -- N1's parity pinned directly, not through the
+    oracle's autograd.  Same tolerance as the oracle comparison: 2e-4 max|g| + 1e-7 per tensor."""
+    from conftest import load_golden, sub
+    g = sub(load_golden("g7_glow_tiny"), f"{coup}_{perm}.")
+    gr = sub(load_golden("g7_glow_tiny_grads"), f"{coup}_{perm}.")
+    cfg = O.default_cfg(image_shape=(16, 16, 3), hidden_channels=32, K=2, L=2, flow_permutation=perm, flow_coupling=coup, batch=4)
+    np.random.seed(5)
+    glow = G.Glow(hps_for(cfg, 4))
+    glow.load_state_dict(sub(g, "sd."))
+    glow.set_actnorm_inited()
+    if perm != "invconv":       # the fixed permutation tables are attributes, not parameters: the fixture's
+        for i, layer in enumerate(glow.flow.layers):
+            if hasattr(layer, perm):
+                getattr(layer, perm).indices = g[f"indices.{i}"]
+                getattr(layer, perm).indices_inverse = g[f"indices_inverse.{i}"]
+    glow = glow.to(DEV).train()
+    with torch.enable_grad():
+        xd = g["x"].to(DEV).requires_grad_(True)
+        _, nll, _ = glow.normal_flow(xd, None, noise=g["noise"].to(DEV))
+        loss = G.Glow.generative_loss(nll)
+        loss.backward()
+    assert abs(loss.item() - float(gr["loss"])) < 1e-4
+    ref = sub(gr, "grad.")
+    for name, p in glow.named_parameters():
+        if name == "h_top":
+            assert p.grad is None and name not in ref
+            continue
+        r = ref[name]
+        err = (p.grad.cpu() - r).abs().max().item()
+        assert err <= 2e-4 * r.abs().max().item() + 1e-7, f"{name}: err {err:.3e} (|g| max {r.abs().max().item():.3e})"
+    egx = (xd.grad.cpu() - gr["dx"]).abs().max().item()
+    assert egx <= 2e-4 * gr["dx"].abs().max().item() + 1e-7, f"dL/dx err {egx:.3e}"
+
+
 def test_train_steps_reduce_the_loss():
     """Three optimiser steps of the reference's training loop (trainer.py:123-150) on the HIP path: data-dependent
     ActNorm init, forward with tape, HIP backward, clip by value 5 / by norm 100, Adam -- the loss must fall and every

@@ -119,12 +119,38 @@ def test_g7_glow_tiny(golden, coup, perm):
     eps = [g["dec_eps0"]]
     x = O.glow_reverse(g["z"], sd, cfg, eps, perm_tables=tables)
     close(x, g["dec_x"], atol=5e-5)
-    if perm == "invconv":  # data-dependent init pass restated for invconv only
-        post = O.glow_init_actnorm(g["x"], g["init_noise"], sub(g, "pre."), cfg)
-        for k, v in sub(g, "post.").items():
-            close(post[k], v, atol=1e-5)
-        z0, nll0, _ = O.glow_forward(g["x"], g["init_noise"], post, cfg)
-        close(z0, g["init_z"], atol=2e-5); close(nll0, g["init_nll"], atol=2e-6)
+    # data-dependent init pass (both permutation kinds: VERDICT r4 #6)
+    post = O.glow_init_actnorm(g["x"], g["init_noise"], sub(g, "pre."), cfg, perm_tables=tables)
+    for k, v in sub(g, "post.").items():
+        close(post[k], v, atol=1e-5)
+    z0, nll0, _ = O.glow_forward(g["x"], g["init_noise"], post, cfg, perm_tables=tables)
+    close(z0, g["init_z"], atol=2e-5); close(nll0, g["init_nll"], atol=2e-6)
+
+
+@pytest.mark.parametrize("coup,perm", [("affine", "invconv"), ("additive", "reverse")])
+def test_g7_gradients_recorded_from_the_reference(golden, coup, perm):
+    """SURVEY 8c G7, second half: d mean(nll) / d theta for every parameter and d / d x, recorded from the
+    REFERENCE's own backward (tests/golden/make_golden.py g7_grads, F4 shim) -- autograd through the oracle must reproduce them.
+    This pins the gradient oracle of tests/test_gpu_grad.py directly instead of through the forward."""
+    g = sub(golden("g7_glow_tiny"), f"{coup}_{perm}.")
+    gr = sub(golden("g7_glow_tiny_grads"), f"{coup}_{perm}.")
+    cfg = dict(TINY, flow_coupling=coup, flow_permutation=perm)
+    tables = None
+    if perm != "invconv":
+        tables = {i: (g[f"indices.{i}"], g[f"indices_inverse.{i}"]) for k, i, _ in O.flow_layout(cfg) if k == "step"}
+    sd = sub(g, "sd.")
+    with torch.enable_grad():
+        leaf = {k: v.clone().requires_grad_(k != "h_top") for k, v in sd.items()}
+        x = g["x"].clone().requires_grad_(True)
+        _, nll, _ = O.glow_forward(x, g["noise"], leaf, cfg, perm_tables=tables)
+        loss = nll.mean()
+        loss.backward()
+    close(loss.detach(), gr["loss"], atol=1e-6)
+    ref = sub(gr, "grad.")
+    assert set(ref) == {k for k in sd if k != "h_top"} and leaf["h_top"].grad is None
+    for k, want in ref.items():
+        close(leaf[k].grad, want, atol=2e-5 * float(want.abs().max()) + 1e-8)
+    close(x.grad, gr["dx"], atol=2e-5 * float(gr["dx"].abs().max()) + 1e-8)
 
 
 def test_g8_glow_celeba64(golden):
