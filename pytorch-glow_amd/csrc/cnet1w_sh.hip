@@ -26,6 +26,7 @@
 #include "cnet_geo.h"
 
 GH_STAMPS_DEFINE(cnet1w)
+GH_WGTIMES_DEFINE(cnet1w)
 
 namespace glowhip {
 
@@ -195,6 +196,7 @@ __global__ void __launch_bounds__(256) k_cnet1w(CnetArgs a, CnetGeo g) {
 #endif
     };
     GH_STAMP(0);
+    GH_WG_BEGIN();
     // first what f.0 of chunk 0 needs (its rows, the tables, the window); the ring's first fills are requested behind the window and
     // land while f.0 of chunk 0 runs
 #pragma unroll
@@ -645,6 +647,7 @@ __global__ void __launch_bounds__(256) k_cnet1w(CnetArgs a, CnetGeo g) {
         }
     }
     GH_STAMP(6);
+    GH_WG_END();
 }
 
 // ------------------------------------------------------------------------------------------------ host side

@@ -585,6 +585,7 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
             }
             // -relu (sh.h nrelu_bits), split, store into the B-operand image: a lane's 4 consecutive channels = 8 bytes per plane
             // one 32 x 32 tile's group gq of four rows; mbw: the tile's sign word (read in BWD, built in TAPE)
+            h4 pg_hi, pg_lo;       // the even row group's halves of the (tile, pixel tile) p1_group is walking
             auto p1_group = [&](int i, int j, int gq, unsigned& mbw) {
                 const int o = hh * HK + (rt1 + i) * 32 + 8 * gq + 4 * kl;
                 const f32x4_t rs = *reinterpret_cast<const f32x4_t*>(t_rs0 + o);
@@ -602,9 +603,14 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
                     if (TAPE) mbw = __builtin_amdgcn_alignbit(mbw, __float_as_uint(v[t]), 31);
                 }
                 sh2_split4<MIXSPLIT>(v, hi, lo);
-                _Float16* dst = hbuf + ((long)chunk * PXT + (pt1 + sp * PTSV + j) * 32 + ml) * 8 + 4 * (gq & 1);
-                *reinterpret_cast<h4*>(dst) = hi;
-                *reinterpret_cast<h4*>(dst + (long)NCH * PXT * 8) = lo;
+                if ((gq & 1) == 0) { pg_hi = hi; pg_lo = lo; }
+                else {           // (one 16-byte store per pair of row groups, as in the product epilogue below)
+                    const h8 hi8 = {pg_hi[0], pg_hi[1], pg_hi[2], pg_hi[3], hi[0], hi[1], hi[2], hi[3]};
+                    const h8 lo8 = {pg_lo[0], pg_lo[1], pg_lo[2], pg_lo[3], lo[0], lo[1], lo[2], lo[3]};
+                    _Float16* dst = hbuf + ((long)chunk * PXT + (pt1 + sp * PTSV + j) * 32 + ml) * 8;
+                    *reinterpret_cast<h8*>(dst) = hi8;
+                    *reinterpret_cast<h8*>(dst + (long)NCH * PXT * 8) = lo8;
+                }
                 if (F32ST) {     // (with a row split every workgroup computes all of these rows: each stores its own rows' share)
                     const long px0 = gp0 + (pt1 + sp * PTSV + j) * 32;
                     if (px0 < P_all && (MS == 1 || (o >= ms_row0 && o < ms_row0 + MR))) {
@@ -622,6 +628,7 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
                 }
             };
             if (!STORE) {        // product kernel: row groups outermost (the tables are read once per group)
+                h4 st_hi[PTSV], st_lo[PTSV];
 #pragma unroll
                 for (int i = 0; i < RT1; ++i)
 #pragma unroll
@@ -637,9 +644,14 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
 #pragma unroll
                             for (int t = 0; t < 4; ++t) v[t] = nrelu_bits(fmaf(acc1[i][j][4 * gq + t], rs[t], bb[t]));
                             sh2_split4<MIXSPLIT>(v, hi, lo);
-                            _Float16* dst = hbuf + ((long)chunk * PXT + (pt1 + sp * PTSV + j) * 32 + ml) * 8 + 4 * (gq & 1);
-                            *reinterpret_cast<h4*>(dst) = hi;
-                            *reinterpret_cast<h4*>(dst + (long)NCH * PXT * 8) = lo;
+                            // (row groups 2 s and 2 s + 1 are the two 8-byte halves of the lane's 16-byte slot: ONE 16-byte store per
+                            // plane -- as two 8-byte stores 16 bytes apart from lane to lane they conflict two-way on the LDS banks)
+                            if ((gq & 1) == 0) { st_hi[j] = hi; st_lo[j] = lo; continue; }
+                            const h8 hi8 = {st_hi[j][0], st_hi[j][1], st_hi[j][2], st_hi[j][3], hi[0], hi[1], hi[2], hi[3]};
+                            const h8 lo8 = {st_lo[j][0], st_lo[j][1], st_lo[j][2], st_lo[j][3], lo[0], lo[1], lo[2], lo[3]};
+                            _Float16* dst = hbuf + ((long)chunk * PXT + (pt1 + sp * PTSV + j) * 32 + ml) * 8;
+                            *reinterpret_cast<h8*>(dst) = hi8;
+                            *reinterpret_cast<h8*>(dst + (long)NCH * PXT * 8) = lo8;
                         }
                     }
             } else {             // taping / backward: tile by tile, one sign word live at a time
@@ -870,6 +882,7 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
         for (int i = 0; i < RT2; ++i) {
             const int wr = (rt2 + i) * 32;                   // first workgroup-local row of this tile
             if (wr / LK != l) continue;
+            h4 ho_hi[PT2], ho_lo[PT2];
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
                 const int chunk = (wr - l * LK) / 8 + (gq & 2) + kl;      // k-permuted position (sh.h sh2_kperm_src)
@@ -878,9 +891,12 @@ __global__ void __launch_bounds__(512) k_cnet(CnetArgs a, CnetGeo g) {
                     h4 hi, lo;
                     const f32x4_t v = {acc2[i][j][4 * gq], acc2[i][j][4 * gq + 1], acc2[i][j][4 * gq + 2], acc2[i][j][4 * gq + 3]};
                     sh2_split4<MIXSPLIT>(v, hi, lo);
-                    _Float16* dst = hbuf + ((long)chunk * PXT + (pt2 + j) * 32 + ml) * 8 + 4 * (gq & 1);
-                    *reinterpret_cast<h4*>(dst) = hi;
-                    *reinterpret_cast<h4*>(dst + (long)LCH * PXT * 8) = lo;
+                    if ((gq & 1) == 0) { ho_hi[j] = hi; ho_lo[j] = lo; continue; }      // (one 16-byte store per pair of row groups, as in P1)
+                    const h8 hi8 = {ho_hi[j][0], ho_hi[j][1], ho_hi[j][2], ho_hi[j][3], hi[0], hi[1], hi[2], hi[3]};
+                    const h8 lo8 = {ho_lo[j][0], ho_lo[j][1], ho_lo[j][2], ho_lo[j][3], lo[0], lo[1], lo[2], lo[3]};
+                    _Float16* dst = hbuf + ((long)chunk * PXT + (pt2 + j) * 32 + ml) * 8;
+                    *reinterpret_cast<h8*>(dst) = hi8;
+                    *reinterpret_cast<h8*>(dst + (long)LCH * PXT * 8) = lo8;
                 }
             }
         }

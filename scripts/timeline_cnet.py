@@ -23,7 +23,7 @@ with torch.no_grad():
     for _ in range(3): glow.normal_flow(x, None)
 torch.cuda.synchronize()
 buf = (ctypes.c_ulonglong * (4 * NWG))()
-G.lib().glowhip_debug_read_wgtimes_cnet(buf, NWG)
+getattr(G.lib(), "glowhip_debug_read_wgtimes_" + os.environ.get("KERNEL", "cnet"))(buf, NWG)
 t = np.array(list(buf), dtype=np.int64).reshape(NWG, 4)
 t0 = t[:, 0].min()
 start, end = (t[:, 0] - t0) * 10.0, (t[:, 1] - t0) * 10.0        # ns
