@@ -316,10 +316,12 @@ def secondary_workloads(G, util, parallel, device, steps=3, warmup=3):
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             t0 = time.perf_counter()
+            c0, m0 = time.process_time(), time.thread_time()
             e0.record()
             for _ in range(n_timed):
                 last = step()
             e1.record()
+            dt_host, dt_cpu, dt_main = time.perf_counter() - t0, time.process_time() - c0, time.thread_time() - m0
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
             if "loop" in wl:
@@ -332,6 +334,10 @@ def secondary_workloads(G, util, parallel, device, steps=3, warmup=3):
             name = f"{cfg_name}_{mode}"
             out[name] = {"value": round(B * n_timed / dt, 2), "unit": "images/sec", "ms_per_step": round(1e3 * dt / n_timed, 3),
                          "ms_per_step_gpu_events": round(e0.elapsed_time(e1) / n_timed, 3), "steps": n_timed,
+                         # host side of a step: wall time of the enqueue loop (includes any wait for the device: the training loop
+                         # lets the host run at most two steps ahead) and the CPU time the process burnt in it (all threads)
+                         "host_enqueue_ms_per_step": round(1e3 * dt_host / n_timed, 3), "host_cpu_ms_per_step": round(1e3 * dt_cpu / n_timed, 3),
+                         "host_cpu_main_thread_ms_per_step": round(1e3 * dt_main / n_timed, 3),
                          "warmup": warmup + (7 if mode == "train" else 0), "batch": B,
                          "workload": f"{cfg['label']}, {mode}, batch {B} ({cfg['ref']})",
                          "finite": bool(torch.isfinite(last).all()), "data_dependent_init_ms": wl["init_ms"],
@@ -504,11 +510,14 @@ def main():
     # inside the timed region
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
+    c0, m0 = time.process_time(), time.thread_time()
     marks[0].record()
     for i in range(args.steps):
         loss = step()
         marks[i + 1].record()
     dt_host = time.perf_counter() - t0      # host time to ENQUEUE the steps (how far the CPU runs ahead of the GPU)
+    dt_cpu, dt_main = time.process_time() - c0, time.thread_time() - m0     # CPU time burnt doing so: the whole process (HIP runtime
+                                                                            # threads included) | this thread (Python + launches)
     sync()
     dt = time.perf_counter() - t0
     per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
@@ -536,6 +545,8 @@ def main():
             "vs_baseline": None, "dtype": "f32 (2xf16 split operands, fp32 accumulate)", "data": "synthetic",
             "ms_per_step_min": round(per_step[0], 4), "ms_per_step_median": round(per_step[len(per_step) // 2], 4),
             "ms_per_step_max": round(per_step[-1], 4), "host_enqueue_ms_per_step": round(1e3 * dt_host / args.steps, 4),
+            "host_cpu_ms_per_step": round(1e3 * dt_cpu / args.steps, 4),     # what a rank costs its host: eight ranks share the node's cores
+            "host_cpu_main_thread_ms_per_step": round(1e3 * dt_main / args.steps, 4),
             "rccl_world_size": dist.get_world_size() if world > 1 else 1, "launch": wl["launch"],
             "data_dependent_init_ms": wl["init_ms"],     # first training-mode forward (ActNorm statistics layer by layer + one forward), once
             "step0_exchange_ms": wl["step0"],            # rank 0: init pass | wait of the others in the barrier | flat parameter broadcast

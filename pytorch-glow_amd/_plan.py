@@ -311,8 +311,12 @@ class FlowPlan:
             self._tws = ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         return ws
 
-    def glow_backward(self, x, tape, nll_grad, z_grad, prior_mean, prior_logs, prior_stride, want_grad_x=False):
-        """Parameter gradients (list aligned with trainable_parameters()) and optionally dL/dx."""
+    def glow_backward(self, x, tape, nll_grad, z_grad, prior_mean, prior_logs, prior_stride, want_grad_x=False, persistent=False):
+        """Parameter gradients (list aligned with trainable_parameters()) and optionally dL/dx.
+        ``persistent``: the flat gradient buckets, the views into them, the pointer table handed to the C sweep and the
+        gradient-ready events are created ONCE per plan and reused by every call (the sweep writes every gradient in full) -- the
+        per-step host cost of ~1 000 tensor views and ~1 000 ctypes assignments disappears; the caller must have consumed the
+        previous call's gradients (training.TrainLoop: the optimiser step of step N is enqueued before the sweep of step N + 1)."""
         n = x.shape[0]
         if (self._version_signature() != getattr(self, "_tape_version", None) or self._packed_version != self._tape_version
                 or not (getattr(self, "_packed_use", 0) & self.PACK_TRAINING)):
@@ -323,18 +327,24 @@ class FlowPlan:
         # Gradients live in one flat buffer per bucket (the convolution weights of one LEVEL; everything small in a last one):
         # a data-parallel run all-reduces each bucket in place -- no concatenation, no copy back -- and starts with a level's
         # bucket as soon as the sweep has left that level (gradient-ready marks), while the lower levels are still being swept.
-        flats = [torch.empty(nel, dtype=torch.float32, device=self.device) for nel in layout["sizes"]]
-        grads = [flats[b][off:off + p.numel()].view_as(p) for (_, _, p), (b, off) in zip(fields, layout["slots"])]
-        arr = (_lib.LayerGrads * len(self.layers))()
-        for (i, name, _), gt in zip(fields, grads):
-            setattr(arr[i], name, gt.data_ptr())
+        cached = getattr(self, "_pgrad", None) if persistent else None
+        if cached is None:
+            flats = [torch.empty(nel, dtype=torch.float32, device=self.device) for nel in layout["sizes"]]
+            grads = [flats[b][off:off + p.numel()].view_as(p) for (_, _, p), (b, off) in zip(fields, layout["slots"])]
+            arr = (_lib.LayerGrads * len(self.layers))()
+            for (i, name, _), gt in zip(fields, grads):
+                setattr(arr[i], name, gt.data_ptr())
+            events = [torch.cuda.Event() for _ in layout["marks"]]
+            for ev in events:
+                ev.record()                  # (creates the handle; the C sweep records it again where it belongs)
+            marks = (ctypes.c_int32 * max(len(events), 1))(*layout["marks"])
+            handles = (ctypes.c_void_p * max(len(events), 1))(*[ev.cuda_event for ev in events])
+            if persistent:
+                self._pgrad = (flats, grads, arr, events, marks, handles)
+        else:
+            flats, grads, arr, events, marks, handles = cached
         gx = torch.empty_like(x) if want_grad_x else None
         ws = self._train_workspace(n)
-        events = [torch.cuda.Event() for _ in layout["marks"]]
-        for ev in events:
-            ev.record()                  # (creates the handle; the C sweep records it again where it belongs)
-        marks = (ctypes.c_int32 * max(len(events), 1))(*layout["marks"])
-        handles = (ctypes.c_void_p * max(len(events), 1))(*[ev.cuda_event for ev in events])
         check(lib().glowhip_plan_backward_marks(self._h, marks, handles, len(events)))
         try:
             check(lib().glowhip_glow_backward(self._h, ptr(self.packed), ptr(x), ptr(tape), tape.numel(), ptr(nll_grad),

@@ -28,10 +28,12 @@ def _all_actnorms(mod):
 def _maybe_data_dependent_init(owner, plan, x, noise, actnorm_scale):
     """First training-mode forward: set every ActNorm of the plan from this batch
     (reference network/module.py:45-46,66-67; trainer.py:112-115)."""
-    if not owner.training:
+    if not owner.training or getattr(owner, "_actnorms_all_inited", None) == module.ActNorm.RESET_EPOCH[0]:
         return
     pending = _uninited_actnorms(owner)
     if not pending:
+        # (the walk over ~6 400 sub-modules costs 1.5 ms: remembered until any ActNorm flag anywhere is cleared again)
+        owner._actnorms_all_inited = module.ActNorm.RESET_EPOCH[0]
         return
     if len(pending) != len(_all_actnorms(owner)):
         raise _lib.GlowHipError("partially initialised ActNorm layers: call set_actnorm_inited() or reset all flags")
@@ -39,6 +41,7 @@ def _maybe_data_dependent_init(owner, plan, x, noise, actnorm_scale):
     for m in pending:
         m.bias_inited = True
         m.logs_inited = True
+    owner._actnorms_all_inited = module.ActNorm.RESET_EPOCH[0]
 
 
 class FlowStep(nn.Module):
@@ -398,6 +401,42 @@ class Glow(nn.Module):
             z, nll = self._forward_exact_fp32(plan, x.float() / 255.0 if x.dtype == torch.uint8 else x, noise, mean, logs, stride, n_bits)
         return z, nll, None
 
+    def loss_and_grads(self, x, noise=None):
+        """mean(nll) of the batch (`generative_loss`) and its gradient for every trainable parameter, WITHOUT an autograd graph:
+        the HIP forward with tape and the HIP reverse sweep are called directly, and the gradients land in the plan's persistent
+        flat buckets, whose views are the parameters' ``.grad`` (assigned once).  This is `Trainer`'s step (network/trainer.py:123-133:
+        forward, `loss.backward()`) minus ~10 ms of per-step host work in autograd's bookkeeping for ~1 060 parameter tensors --
+        eight data-parallel ranks share one host.  Same kernels, same bits as ``normal_flow(x)`` + ``loss.backward()``
+        (tests/test_gpu_grad.py).  Returns the loss (a device scalar); gradient buckets: ``flow.pop_grad_buckets()``."""
+        assert self.training, "loss_and_grads is the training step: call glow.train() first"
+        x = require_device_tensor(x, "Glow input", allow_uint8=True)
+        if x.dtype == torch.uint8:
+            x = x.float() / 255.0
+        n_bits = self.hps.model.n_bits_x
+        plan = self.flow.plan_for(x)
+        if noise is None:
+            noise = torch.empty(x.shape, dtype=torch.float32, device=x.device).uniform_(0, 1. / 2 ** n_bits)
+        else:
+            noise = require_device_tensor(noise, "noise")
+        plan.set_dequant_rng(0, False)
+        _maybe_data_dependent_init(self.flow, plan, x, noise, self.flow.actnorm_scale)
+        if self.prior(None)[0] is not None:
+            raise NotImplementedError("learn_top with gradients is not on the HIP training path yet")
+        with torch.no_grad():
+            z, nll, tape = plan.glow_forward_train(x, noise, None, None, 0, n_bits)
+            loss = self.generative_loss(nll)
+            n = x.shape[0]
+            gn = getattr(plan, "_mean_grad", None)
+            if gn is None or gn.numel() != n:
+                gn = plan._mean_grad = torch.full((n,), 1.0 / n, dtype=torch.float32, device=x.device)      # d mean(nll) / d nll
+            grads, _ = plan.glow_backward(x, tape, gn, None, None, None, 0, want_grad_x=False, persistent=True)
+        if getattr(plan, "_pgrad_bound", None) is not grads:      # once per plan: the views ARE the parameters' gradients from now on
+            for p, g in zip(plan.trainable_parameters(), grads):
+                p.grad = g
+            plan._pgrad_bound = grads
+        self._train_plan = plan        # (parallel.train_step: the optimiser's table stays valid while this plan's buckets are the gradients)
+        return loss
+
     def capture_forward(self, x, repack=True):
         """The inference forward of this batch shape as ONE hipGraph launch (`GraphedForward`): the flow plan's launch list is
         static (~220 kernels for celeba64), so it is captured once and replayed -- host cost per step ~10 us instead of ~1 ms of
@@ -470,3 +509,4 @@ class Glow(nn.Module):
             if m.__class__.__name__.find("ActNorm") >= 0:
                 m.bias_inited = inited
                 m.logs_inited = inited
+

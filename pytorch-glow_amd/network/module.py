@@ -45,6 +45,30 @@ class ActNorm(nn.Module):
     The first training-mode forward sets bias/logs from the batch (data-dependent init, :86-120).
     """
 
+    # `bias_inited` / `logs_inited` are plain attributes in the reference (module.py:30-31).  Here every RESET of one bumps a class-wide
+    # epoch, which is what lets FlowModel cache "every ActNorm is initialised" (a walk over ~6 400 sub-modules per training forward
+    # otherwise) without missing a flag somebody clears by hand.
+    RESET_EPOCH = [0]
+
+    def _get_bias_inited(self):
+        return self.__dict__.get("_bias_inited", False)
+
+    def _set_bias_inited(self, v):
+        self.__dict__["_bias_inited"] = bool(v)
+        if not v:
+            ActNorm.RESET_EPOCH[0] += 1
+
+    def _get_logs_inited(self):
+        return self.__dict__.get("_logs_inited", False)
+
+    def _set_logs_inited(self, v):
+        self.__dict__["_logs_inited"] = bool(v)
+        if not v:
+            ActNorm.RESET_EPOCH[0] += 1
+
+    bias_inited = property(_get_bias_inited, _set_bias_inited)
+    logs_inited = property(_get_logs_inited, _set_logs_inited)
+
     def __init__(self, num_channels, scale=1., logscale_factor=3., batch_variance=False):
         super().__init__()
         assert logscale_factor == 3., "the HIP kernels hard-code logscale_factor=3 (the only value the reference uses)"

@@ -166,19 +166,28 @@ def allreduce_buckets(buckets, world: Optional[int] = None, average: bool = True
 
 def train_step(glow, optimizer, x_local: torch.Tensor, world: int = 1, max_grad_clip: float = 0.0,
                max_grad_norm: float = 0.0, skip_nonfinite: bool = False,
-               before_update: Optional[Callable[[], None]] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+               before_update: Optional[Callable[[], None]] = None, direct: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
     """One data-parallel training step of the reference's loop (network/trainer.py:123-150) on this rank's shard:
     forward (HIP, with tape) -> loss = mean(nll) -> backward (HIP reverse sweep) -> gradient all-reduce (RCCL) ->
     clip_grad_value_ / clip_grad_norm_ -> optimizer.step().  Returns (global mean loss, gradient norm).
     ``skip_nonfinite`` (HIP optimisers): a NaN / inf gradient norm skips the update on the device (training.TrainLoop's range check).
+    ``direct`` (default): forward and backward through `Glow.loss_and_grads` instead of an autograd graph (False: the reference's
+    `loss.backward()` route, kept for comparison and for models the direct call does not take).
     ``before_update``: called after forward, backward and the gradient exchange are enqueued and before the optimiser step is --
     the place where TrainLoop looks at the PREVIOUS step's norm (the device is still a whole forward + backward behind the host).
     The local loss is mean over the LOCAL shard; averaging the gradients over ranks makes it the global mean."""
-    optimizer.zero_grad(set_to_none=True)
-    with torch.enable_grad():
-        z, nll, _ = glow.normal_flow(x_local, None)
-        loss = glow.generative_loss(nll)
-        loss.backward()
+    direct = direct and hasattr(glow, "loss_and_grads") and x_local.is_cuda
+    if direct:
+        # HIP forward + reverse sweep called directly (Glow.loss_and_grads): same kernels and bits as the autograd route below,
+        # gradients in the plan's persistent buckets (the parameters' .grad are views into them: nothing to zero, nothing to
+        # re-assign) -- the per-step host work of autograd over ~1 060 parameter tensors is what eight ranks on one host cannot afford
+        loss = glow.loss_and_grads(x_local)
+    else:
+        optimizer.zero_grad(set_to_none=True)
+        with torch.enable_grad():
+            z, nll, _ = glow.normal_flow(x_local, None)
+            loss = glow.generative_loss(nll)
+            loss.backward()
     buckets = glow.flow.pop_grad_buckets() if hasattr(glow, "flow") and hasattr(glow.flow, "pop_grad_buckets") else None
     if buckets is not None:
         allreduce_buckets(buckets, world)       # per level, overlapped with the rest of the sweep (already enqueued)
@@ -187,7 +196,8 @@ def train_step(glow, optimizer, x_local: torch.Tensor, world: int = 1, max_grad_
     if before_update is not None:
         before_update()
     if hasattr(optimizer, "fused_step"):     # training.HipAdam / HipAdamax: both clippings + the update in two HIP launches
-        grad_norm = optimizer.fused_step(max_grad_clip, max_grad_norm, skip_nonfinite=skip_nonfinite)
+        token = getattr(getattr(glow, "_train_plan", None), "_pgrad_bound", None) if direct else None      # persistent gradients: the chunk table stays valid
+        grad_norm = optimizer.fused_step(max_grad_clip, max_grad_norm, skip_nonfinite=skip_nonfinite, grads_token=token)
     else:
         params = [p for p in glow.parameters() if p.grad is not None]
         if max_grad_clip and max_grad_clip > 0:

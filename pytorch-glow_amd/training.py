@@ -9,6 +9,8 @@ are ``torch.optim.Adam`` / ``Adamax`` exactly as in the reference (builder.py:10
 from functools import partial
 from typing import Iterable, Optional
 
+import time
+
 import torch
 
 from . import parallel
@@ -76,7 +78,7 @@ class _HipOptimizer(torch.optim.Optimizer):
         self._ensure_state()
 
     @torch.no_grad()
-    def fused_step(self, max_grad_clip=0.0, max_grad_norm=0.0, skip_nonfinite=False):
+    def fused_step(self, max_grad_clip=0.0, max_grad_norm=0.0, skip_nonfinite=False, grads_token=None):
         """``skip_nonfinite``: a NaN / inf total gradient norm leaves parameters and state untouched ON THE DEVICE (no host sync);
         the caller finds out from the returned norm when it next looks (``undo_step`` then takes the step count back)."""
         self._ensure_state()
@@ -89,10 +91,16 @@ class _HipOptimizer(torch.optim.Optimizer):
         # addresses again, so the table is keyed by (parameter address, gradient address) of every parameter -- two data_ptr() calls
         # each -- and rebuilt (with the full checks) only when one of them moved; the state addresses change only with the state
         # buffers, which resets the key (a reloaded state or a re-allocated parameter must not reuse the table).
-        plist = [p for g in self.param_groups for p in g["params"]]
+        plist = getattr(self, "_plist", None)
+        if plist is None:
+            plist = self._plist = [p for g in self.param_groups for p in g["params"]]
+        # ``grads_token``: an object that stands for "the gradients are the plan's persistent buckets" (Glow.loss_and_grads): as long
+        # as the caller shows the same token, parameter, gradient and state addresses cannot have moved and the key below -- four
+        # attribute reads for each of ~1 060 parameters, 1.2 ms -- is not recomputed
+        fast = grads_token is not None and grads_token is getattr(self, "_table_token", None) and self._table_key is not None
         # (dtype and contiguity are part of the key: a gradient that comes back at the same address as a different view must not ride
         # on the checks the cached table was built under -- ADVICE r4)
-        key = tuple((p.data_ptr(), p.grad.data_ptr(), p.grad.dtype, p.grad.is_contiguous()) if p.grad is not None else (0, 0, None, True) for p in plist)
+        key = self._table_key if fast else tuple((p.data_ptr(), p.grad.data_ptr(), p.grad.dtype, p.grad.is_contiguous()) if p.grad is not None else (0, 0, None, True) for p in plist)
         self._steps += 1
         self._publish_step()
         norm = torch.zeros(1, device=dev)
@@ -118,6 +126,7 @@ class _HipOptimizer(torch.optim.Optimizer):
             else:
                 table = None
             self._table_key, self._n_chunks = key, n_chunks
+        self._table_token = grads_token
         if not n_chunks:
             return norm[0]
         if self._partial is None or self._partial.numel() < n_chunks:
@@ -127,10 +136,9 @@ class _HipOptimizer(torch.optim.Optimizer):
             float(group0["eps"]), float(group0["weight_decay"]), self._steps, float(max_grad_clip or 0.0), float(max_grad_norm or 0.0),
             _lib.ptr(self._partial), _lib.ptr(norm), int(bool(skip_nonfinite)), _lib.stream_ptr(dev)))
         self._keep = table      # alive until the stream has consumed it (the next step replaces it)
-        for g in self.param_groups:            # the kernel wrote the parameters behind torch's back: bump their version counters,
-            for p in g["params"]:              # which is what tells the flow plans to re-derive their packed weight images
-                if p.grad is not None:
-                    torch.autograd.graph.increment_version(p)
+        # the kernel wrote the parameters behind torch's back: bump their version counters, which is what tells the flow plans to
+        # re-derive their packed weight images (one call for the whole list)
+        torch.autograd.graph.increment_version([p for p in plist if p.grad is not None])
         return norm[0]
 
     def step(self, closure=None):
@@ -219,7 +227,7 @@ class TrainLoop:
         self.reruns = []             # (global step at the time, loss, grad norm) of every batch that was run again (range check)
         self.last_rerun = None
         self._rerun = None
-        self._pending = None
+        self._pending = []           # checks not resolved yet, oldest first (at most MAX_LAG)
         self._host = None
         self.optimizer = optimizer or build_optimizer(hps, glow.parameters())
         self.scheduler = build_scheduler(hps)
@@ -245,35 +253,47 @@ class TrainLoop:
                                               skip_nonfinite=checked, before_update=self._check_previous if checked else None)
         self.global_step += 1
         if checked:
-            self._pending = self._stash(x_local, grad_norm, self.lr)
-            if self._rerun is not None:
-                self._run_again(self._rerun)
+            self._pending.append(self._stash(x_local, grad_norm, self.lr))
+            reruns, self._rerun = self._rerun, None
+            for pending in reruns or ():
+                self._run_again(pending)
         return loss, grad_norm
 
     # ---- deferred range check (no host sync on the step's own work)
     def _stash(self, x_local, grad_norm, lr):
-        if self._host is None:       # two pinned words, used alternately
-            self._host = [torch.zeros(1, pin_memory=True), torch.zeros(1, pin_memory=True)]
-        host = self._host[self.global_step & 1]
+        if self._host is None:       # pinned words, used in turn (one more than checks can be pending)
+            self._host = [torch.zeros(1, pin_memory=True) for _ in range(self.MAX_LAG + 1)]
+        host = self._host[self.global_step % (self.MAX_LAG + 1)]
         host.copy_(grad_norm.detach().reshape(1), non_blocking=True)
-        ev = torch.cuda.Event()
+        ev = torch.cuda.Event(blocking=True)       # (a forced wait yields the core instead of spinning: eight ranks share one host)
         ev.record()
         return x_local, host, ev, lr
 
-    def _check_previous(self):
-        """Runs between this step's gradient exchange and its optimiser step (`parallel.train_step`): the previous step's norm has
-        landed long ago -- the device still has this step's forward and backward in front of it, so the wait stalls nothing.  If
-        the device skipped that update, its count is taken back BEFORE this step's bias corrections are computed from it, and the
-        batch is queued to run again right after this step."""
-        pending, self._pending = self._pending, None
-        if pending is None:
-            return
-        pending[2].synchronize()
-        if bool(torch.isfinite(pending[1]).all()):
-            return
-        self.optimizer.undo_step()
-        self.range_fallbacks += 1
-        self._rerun = pending
+    MAX_LAG = 2      # a check is forced (host sync) once it is this many steps old
+
+    def _check_previous(self, drain=False):
+        """Runs between this step's gradient exchange and its optimiser step (`parallel.train_step`).  NON-BLOCKING: a norm that has
+        not landed yet is looked at one step later (the host may run up to MAX_LAG steps ahead of the device -- with a blocking wait
+        here it could never be more than one step ahead, and every step's host time included the device's previous step: 12 of
+        the 25 ms `host_enqueue_ms_per_step` of round 4); only a check MAX_LAG steps old is waited for.  If the device skipped an
+        update, its count is taken back before this step's bias corrections are computed from it, and the batch is queued to run
+        again right after this step."""
+        while self._pending:
+            pending = self._pending[0]
+            if not pending[2].query():
+                if not drain and len(self._pending) < self.MAX_LAG:
+                    break
+                # a forced wait: poll and SLEEP.  hipEventSynchronize spins on this runtime whatever the event's flags say (measured:
+                # main thread + one runtime thread at 100 % for the whole wait, 52 ms of CPU per 29 ms step) -- a rank that is two
+                # steps ahead of its GPU has nothing to do and must not take two of the host's cores to do it
+                while not pending[2].query():
+                    time.sleep(2e-4)
+            self._pending.pop(0)
+            if bool(torch.isfinite(pending[1]).all()):
+                continue
+            self.optimizer.undo_step()
+            self.range_fallbacks += 1
+            self._rerun = (self._rerun or []) + [pending]
 
     def _run_again(self, pending):
         """The skipped batch on the exact-fp32 family, with the learning rate of the step it belonged to.  Its loss and norm
@@ -306,7 +326,7 @@ class TrainLoop:
     def flush(self):
         """Resolve the check of the last step (call before reading parameters for a snapshot, and at the end of training)."""
         self._rerun = None
-        self._check_previous()
-        if self._rerun is not None:
-            self._run_again(self._rerun)
-            self._rerun = None
+        self._check_previous(drain=True)
+        reruns, self._rerun = self._rerun, None
+        for pending in reruns or ():
+            self._run_again(pending)
