@@ -132,7 +132,8 @@ def cpu_baseline(glow, x_cpu, cfg, budget_s=90.0, fallback_batch=None):
 
 KERNEL_KINDS = {0: "chanmix", 1: "conv_f0_3x3", 2: "conv_f2_1x1", 3: "conv_f4_3x3_tail", 5: "cnet_f0+f2+f4", 6: "cnet_finish",
                 7: "cnet_tape_f0+f2+f4", 8: "cnet_bwd_dgrad_chain", 9: "wgrad_gemms"}
-CNET_DESC = ("k_cnet (the coupling network of a FlowStep in ONE launch: f.0 3x3 conv C/2->512 + ActNorm + ReLU, f.2 1x1 conv 512->512 + "
+CNET_DESC = ("k_cnet / k_cnet1w (the coupling network of a FlowStep in ONE launch -- k_cnet1w, one wave per SIMD with h1 / h2 chained through "
+             "the register file, where a level gives >= 224 128-pixel tiles; k_cnet, two waves per SIMD, elsewhere: f.0 3x3 conv C/2->512 + ActNorm + ReLU, f.2 1x1 conv 512->512 + "
              "ActNorm + ReLU, f.4 3x3 conv 512->C as taps-as-rows GEMM + tap sums; h1, h2 stay in LDS / registers; fp32-accurate products "
              "as 3 f16 MFMAs, peak = 2500/3 TFLOP/s algorithmic; all levels' launches)")
 
@@ -140,7 +141,7 @@ CNET_DESC = ("k_cnet (the coupling network of a FlowStep in ONE launch: f.0 3x3 
 def traffic_record(cnet_path, sh_path):
     """HBM bytes per launch of the dominant kernel from the committed PMC summary (profiles/pmc_traffic.json: rocprofv3 --pmc
     FETCH_SIZE / WRITE_SIZE passes of this command, scripts/prof_pmc.sh) -- not re-measured by this run, so the record says which
-    commit it was collected at and whether the kernel's source has changed since (sha256 of csrc/cnet_sh.hip at collection time)."""
+    commit it was collected at and whether the kernel's source has changed since (sha256 of csrc/cnet_sh.hip + cnet1w_sh.hip at collection time)."""
     import hashlib
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if not os.path.exists(tpath):
@@ -151,13 +152,14 @@ def traffic_record(cnet_path, sh_path):
            "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (scripts/prof_pmc.sh), not re-measured by this run"}
     if cnet_path:
         try:
-            now = hashlib.sha256(open(os.path.join(ROOT, "pytorch-glow_amd", "csrc", "cnet_sh.hip"), "rb").read()).hexdigest()[:16]
+            now = hashlib.sha256(b"".join(open(os.path.join(ROOT, "pytorch-glow_amd", "csrc", f), "rb").read()
+                                          for f in ("cnet_sh.hip", "cnet1w_sh.hip"))).hexdigest()[:16]      # k_cnet + k_cnet1w
         except OSError:
             now = None
         src["kernel_source_sha16_at_collection"], src["kernel_source_sha16_now"] = tj.get("cnet_sh_sha16"), now
         src["stale"] = tj.get("cnet_sh_sha16") != now
         if src["stale"]:
-            print("bench.py: WARNING profiles/pmc_traffic.json was collected before the last change to csrc/cnet_sh.hip "
+            print("bench.py: WARNING profiles/pmc_traffic.json was collected before the last change to csrc/cnet_sh.hip / cnet1w_sh.hip "
                   "(re-run scripts/prof_pmc.sh + scripts/pmc_summary.py)", file=sys.stderr, flush=True)
     return tj.get(key), src
 

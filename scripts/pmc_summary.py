@@ -33,7 +33,8 @@ try:
 except Exception:
     out["commit"] = None
 import hashlib
-out["cnet_sh_sha16"] = hashlib.sha256(open(os.path.join(root, "pytorch-glow_amd", "csrc", "cnet_sh.hip"), "rb").read()).hexdigest()[:16]
+out["cnet_sh_sha16"] = hashlib.sha256(b"".join(open(os.path.join(root, "pytorch-glow_amd", "csrc", f), "rb").read()
+                                               for f in ("cnet_sh.hip", "cnet1w_sh.hip"))).hexdigest()[:16]      # k_cnet + k_cnet1w
 out["k_cnet_hbm_bytes_per_launch"] = int(2 * f + w)
 out["k_cnet_detail"] = {
     "fetch_bytes_corrected_x2": int(2 * f), "write_bytes": int(w),
