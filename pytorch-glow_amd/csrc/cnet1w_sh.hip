@@ -197,8 +197,7 @@ __global__ void __launch_bounds__(256) k_cnet1w(CnetArgs a, CnetGeo g) {
     };
     GH_STAMP(0);
     GH_WG_BEGIN();
-    // first what f.0 of chunk 0 needs (its rows, the tables, the window); the ring's first fills are requested behind the window and
-    // land while f.0 of chunk 0 runs
+    // first what f.0 of chunk 0 needs (its rows, the tables, the window)
 #pragma unroll
     for (int i = 0; i < NP0; ++i) w0_piece(0, i);
 
@@ -224,6 +223,9 @@ __global__ void __launch_bounds__(256) k_cnet1w(CnetArgs a, CnetGeo g) {
 #pragma unroll
         for (int i = 0; i < N2; ++i) { tv2[i] = rs2[tid + NT * i]; tvb[i] = rs2[HID + tid + NT * i]; }
         tv4 = rs4[min(tid, MP4 - 1)];
+        // the window in rounds of NT slots; the stream's first fills are REQUESTED between the first round's loads and their use:
+        // they need nothing, nobody needs them before the loop, and issued here their 21 pieces and their trip to L2 overlap the
+        // window's own trip and its conversion instead of standing in front of f.0 of chunk 0
         for (int e0 = 0; e0 < nslots; e0 += NT) {
             const int e = min(e0 + tid, nslots - 1);
             bool in; int ch;
@@ -231,6 +233,21 @@ __global__ void __launch_bounds__(256) k_cnet1w(CnetArgs a, CnetGeo g) {
             float v[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) v[q] = xin[(long)min(ch * 8 + q, a.Cin - 1) * HW];
+            if (e0 == 0) {
+                C1_FENCE();
+                ring_begin(0, 0);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) ring_piece(0, i);
+#pragma unroll
+                for (int i = 0; i < NP0; ++i) w0_piece(1, i);
+                ring_begin(1, SLOT);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) ring_piece(1, i);
+                ring_begin(2, 2 * SLOT);
+                ring_piece(2, 0);
+                ring_piece(2, 1);
+                C1_FENCE();
+            }
             h8 hi, lo;
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
@@ -251,20 +268,10 @@ __global__ void __launch_bounds__(256) k_cnet1w(CnetArgs a, CnetGeo g) {
         for (int i = 0; i < N2; ++i) { t_rs2[tid + NT * i] = canon_nan(tv2[i]); t_b2[tid + NT * i] = canon_nan(-tvb[i]); }
         if (tid < MP4) t_rs4[tid] = canon_nan(-tv4);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // f.0's rows of chunk 0 have landed: everything but the 18 + NP0 pieces of the fills requested behind them (in-order counter)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(18 + NP0) : "memory");
     __syncthreads();
     GH_STAMP(1);
-    ring_begin(0, 0);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) ring_piece(0, i);
-#pragma unroll
-    for (int i = 0; i < NP0; ++i) w0_piece(1, i);
-    ring_begin(1, SLOT);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) ring_piece(1, i);
-    ring_begin(2, 2 * SLOT);
-    ring_piece(2, 0);
-    ring_piece(2, 1);
 
     // ---- per-lane constants of the contractions
     // f.0: window byte address of this lane's pixel for k-step st (the lane's group 2 st + kl = (chunk, tap); past 9 * nchunk: zero
@@ -626,7 +633,8 @@ __global__ void __launch_bounds__(256) k_cnet1w(CnetArgs a, CnetGeo g) {
     // halo rows (NI = 1 only): what the tile's first row gives to image row y0 - 1, its last row to row y0 + R
     if (g.NI == 1 && g.R < H) {
         const int hitems = 2 * ngrp * W;
-        for (int e = tid; e < hitems; e += NT) {
+        // (items go to the threads of the tap sums' LIGHTER half first: those took one group of channels where the others took two)
+        for (int e = (tid + NT / 2) & (NT - 1); e < hitems; e += NT) {
             const int dn = e >= ngrp * W;
             const int rem = e - dn * (ngrp * W);
             const int cg = rem >> g.wshift, x = rem & (W - 1);
