@@ -339,14 +339,17 @@ def glow_forward(x, noise, sd, cfg, perm_tables=None):
 
     z = x + noise; objective = -ln(n_bins)*CHW; encode; objective += logp(z | h_top prior);
     nll = -objective / (ln2 * CHW).  Returns (z, nll, objective)."""
-    assert not cfg.get("learn_top", False) and not cfg.get("y_condition", False)
+    assert not cfg.get("y_condition", False)
     n_bins = 2 ** cfg["n_bits_x"]
     z = x + noise
     factor = x.shape[1] * count_pixels(x)
     objective = torch.zeros_like(x[:, 0, 0, 0])
     objective = objective + float(-np.log(n_bins)) * factor
     z, objective = flow_encode(z, objective, sd, cfg, perm_tables=perm_tables)
-    mean, logs = split_channel(sd["h_top"][: z.shape[0]], "simple")  # model.py:362-379 (h_top == 0)
+    h = sd["h_top"][: z.shape[0]].detach()                              # model.py:362-379 (h_top == 0, detached)
+    if cfg.get("learn_top", False):                                    # :375-376: h = learn_top(h), a Conv2dZeros (module.py:263-297)
+        h = conv2d_zeros(h, sd["learn_top.weight"], sd["learn_top.bias"], sd["learn_top.logs"])
+    mean, logs = split_channel(h, "simple")
     objective = objective + gaussian_logp(mean, logs, z)
     nll = (-objective) / float(np.log(2.0) * factor)
     return z, nll, objective

@@ -216,10 +216,14 @@ class _GlowTrainFn(torch.autograd.Function):
     sweep (glowhip_glow_backward) and hands the parameter gradients to autograd."""
 
     @staticmethod
-    def forward(ctx, plan, x, noise, n_bits, *params):
-        z, nll, tape = plan.glow_forward_train(x, noise, None, None, 0, n_bits)
+    def forward(ctx, plan, x, noise, n_bits, mean, logs, *params):
+        # mean / logs: the top prior's parameters (N, Cz, H, W) when it is LEARNED (ablation.learn_top, network/model.py:375-376),
+        # differentiable inputs of this node; None for the reference profiles' fixed N(0, 1) prior
+        stride = 0 if mean is None else mean.stride(0)
+        z, nll, tape = plan.glow_forward_train(x, noise, mean, logs, stride, n_bits)
         ctx.plan, ctx.tape, ctx.x_in = plan, tape, x
         ctx.want_gx = x.requires_grad
+        ctx.prior = None if mean is None else (mean, logs, z)
         return z, nll
 
     @staticmethod
@@ -228,9 +232,20 @@ class _GlowTrainFn(torch.autograd.Function):
         n = ctx.x_in.shape[0]
         gnll = torch.zeros(n, device=ctx.x_in.device) if gnll is None else gnll.contiguous().float()
         gz = None if gz is None else gz.contiguous().float()
-        grads, gx = plan.glow_backward(ctx.x_in, ctx.tape, gnll, gz, None, None, 0, want_grad_x=ctx.want_gx)
+        mean, logs, z = ctx.prior if ctx.prior is not None else (None, None, None)
+        grads, gx = plan.glow_backward(ctx.x_in, ctx.tape, gnll, gz, mean, logs, 0 if mean is None else mean.stride(0),
+                                       want_grad_x=ctx.want_gx)
         ctx.tape = None
-        return (None, gx, None, None) + tuple(grads)
+        gmean = glogs = None
+        if mean is not None:
+            # nll = -(... + logp(z | mean, logs)) / (ln 2 CHW), logp = sum -0.5 (ln 2 pi + 2 logs + (z - mean)^2 exp(-2 logs))
+            # (GaussianDiag, network/module.py:400-467): the prior's own parameters get their gradient here, in a handful of
+            # elementwise launches on the top latent; d nll / d z -- through the flow -- is the sweep's (it takes mean / logs)
+            coef = (-gnll / (float(np.log(2.0)) * ctx.x_in[0].numel())).view(n, 1, 1, 1)
+            d = (z - mean) * torch.exp(-2.0 * logs)
+            gmean = coef * d
+            glogs = coef * (d * (z - mean) - 1.0)
+        return (None, gx, None, None, gmean, glogs) + tuple(grads)
 
 
 # ---- the dequantisation stream of the inference path (network/model.py:421: z = x + U(0, 1/2^n_bits), drawn inside the leading
@@ -349,7 +364,14 @@ class Glow(nn.Module):
         prior so the kernels skip the loads."""
         if not self.hps.ablation.learn_top:
             return None, None
-        h = self.learn_top(self.h_top.detach())
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.learn_top.parameters()):
+            # training: h_top is all zeros (the reference asserts it), so the Conv2dZeros output is (0 + bias) exp(3 logs) in every
+            # pixel -- written with torch ops, which makes learn_top.bias / .logs differentiable (its weight multiplies zeros: no
+            # gradient, as under the reference's autograd)
+            lt = self.learn_top
+            h = (lt.bias.view(1, -1, 1, 1) * torch.exp(lt.logs.view(1, -1, 1, 1) * 3.0)).expand(tuple(self.h_top.shape)).contiguous()
+        else:
+            h = self.learn_top(self.h_top.detach())
         nc = h.shape[1]
         return h[:, :nc // 2, ...], h[:, nc // 2:, ...]
 
@@ -390,9 +412,7 @@ class Glow(nn.Module):
         params = plan.trainable_parameters() if torch.is_grad_enabled() else ()     # (a walk over ~1 060 tensors: skipped on the inference path)
         if torch.is_grad_enabled() and any(p.requires_grad for p in params):
             # training step: one autograd node over the whole flow (HIP forward with tape + HIP backward)
-            if mean is not None:
-                raise NotImplementedError("learn_top with gradients is not on the HIP training path yet")
-            z, nll = _GlowTrainFn.apply(plan, x, noise, n_bits, *params)
+            z, nll = _GlowTrainFn.apply(plan, x, noise, n_bits, mean, logs, *params)
             return z, nll, None
         z, nll, _ = plan.glow_forward(x, noise, mean, logs, stride, n_bits, repack=repack)
         if safe and not bool(torch.isfinite(nll).all()):
@@ -420,8 +440,8 @@ class Glow(nn.Module):
             noise = require_device_tensor(noise, "noise")
         plan.set_dequant_rng(0, False)
         _maybe_data_dependent_init(self.flow, plan, x, noise, self.flow.actnorm_scale)
-        if self.prior(None)[0] is not None:
-            raise NotImplementedError("learn_top with gradients is not on the HIP training path yet")
+        if self.hps.ablation.learn_top:
+            raise NotImplementedError("loss_and_grads: a learned top prior goes through the autograd route (normal_flow + backward)")
         with torch.no_grad():
             z, nll, tape = plan.glow_forward_train(x, noise, None, None, 0, n_bits)
             loss = self.generative_loss(nll)

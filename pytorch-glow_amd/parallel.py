@@ -176,7 +176,7 @@ def train_step(glow, optimizer, x_local: torch.Tensor, world: int = 1, max_grad_
     ``before_update``: called after forward, backward and the gradient exchange are enqueued and before the optimiser step is --
     the place where TrainLoop looks at the PREVIOUS step's norm (the device is still a whole forward + backward behind the host).
     The local loss is mean over the LOCAL shard; averaging the gradients over ranks makes it the global mean."""
-    direct = direct and hasattr(glow, "loss_and_grads") and x_local.is_cuda
+    direct = direct and hasattr(glow, "loss_and_grads") and x_local.is_cuda and not glow.hps.ablation.learn_top
     if direct:
         # HIP forward + reverse sweep called directly (Glow.loss_and_grads): same kernels and bits as the autograd route below,
         # gradients in the plan's persistent buckets (the parameters' .grad are views into them: nothing to zero, nothing to

@@ -20,6 +20,7 @@ Fixtures:
                          noise, z, nll, decode with injected eps, data-dependent init
   g7_glow_tiny_grads.npz d mean(nll) / d theta for every parameter + d / d x of the two G7 models, from the reference's own backward
                          (F4 shim: misc.ops.split_channel returning clones)
+  g7_glow_tiny_learn_top.npz the same model with a learned top prior (ablation.learn_top): z, nll, every gradient incl. learn_top.bias / logs
   g9_inferer.npz + g9_reference_snapshot.pth
                          a snapshot WRITTEN BY the reference (misc/util.py save_model, after one Adam step) and what the
                          reference's Inferer (network/inferer.py) computes from it: encode, attribute deltaz (with the data
@@ -363,6 +364,42 @@ def g7_grads():
     save("g7_glow_tiny_grads.npz", out)
 
 
+def g7_learn_top():
+    """Glow with a LEARNED top prior (ablation.learn_top, network/model.py:340-343, 375-376): forward nll / z and the gradients of
+    mean(nll) for every parameter (F4 shim as in g7_grads) on the tiny affine / invconv model with randomised parameters --
+    learn_top.bias / .logs included (its weight sees an all-zero input: zero gradient)."""
+    orig_split = rops.split_channel
+    rops.split_channel = lambda t, s="simple": tuple(a.clone() for a in orig_split(t, s))
+    out = {}
+    try:
+        g = torch.Generator().manual_seed(4321)
+        np.random.seed(7)
+        hps = tiny_hps("affine", "invconv")
+        hps.ablation.learn_top = True
+        glow = rmodel.Glow(hps)
+        randomize_(glow, g, std=0.1)
+        with torch.no_grad():
+            glow.h_top.zero_()
+            glow.learn_top.bias.copy_(torch.randn(glow.learn_top.bias.shape, generator=g) * 0.3)
+            glow.learn_top.logs.copy_(torch.randn(glow.learn_top.logs.shape, generator=g) * 0.1)
+        glow.set_actnorm_inited()
+        glow.eval()
+        sd = {k: v.clone() for k, v in glow.state_dict().items()}
+        x = torch.rand(4, 3, 16, 16, generator=g).requires_grad_(True)
+        z, nll, noise = run_glow(glow, x, 31)
+        loss = rmodel.Glow.generative_loss(nll)
+        loss.backward()
+        out.update({"x": x.detach(), "noise": noise, "z": z.detach(), "nll": nll.detach(), "loss": loss.detach(), "dx": x.grad.detach()})
+        out.update({f"sd.{k}": v for k, v in sd.items()})
+        for name, p_ in glow.named_parameters():
+            if p_.grad is not None:
+                out[f"grad.{name}"] = p_.grad.detach()
+        assert "grad.learn_top.bias" in out and "grad.learn_top.logs" in out and float(out["grad.learn_top.bias"].abs().max()) > 0
+    finally:
+        rops.split_channel = orig_split
+    save("g7_glow_tiny_learn_top.npz", out)
+
+
 def g8():
     """celeba.json-sized model driven by the ORACLE's seeded weight procedure: commit digests only."""
     cfg = O.default_cfg(batch=2)
@@ -482,8 +519,12 @@ if __name__ == "__main__":
     if os.environ.get("ONLY") == "g7_grads":
         g7_grads()
         sys.exit(0)
+    if os.environ.get("ONLY") == "g7_learn_top":
+        g7_learn_top()
+        sys.exit(0)
     g1(g); g2(g); g3(g); g4(g); g5(g); g6(g); g7(g)
     g7_grads()
+    g7_learn_top()
     g8()
     g9(torch.Generator().manual_seed(99))
     leftovers = [os.path.join(r, d) for r, ds, _ in os.walk(REF) for d in ds if d == "__pycache__"]

@@ -89,6 +89,27 @@ def test_config_b_geometry_matches_oracle(path):
         assert sum("cnet-sh2" in l for l in plan.describe(48).splitlines()) == 3 * K
 
 
+def test_level1_runs_on_the_one_wave_per_simd_kernel_and_both_kernels_match_the_oracle():
+    """Round 5: at config-B geometry and batch 48 level 1 gives 384 tiles of 128 pixels, so its launches run on k_cnet1w
+    (cnet1w_sh.hip: one wave per SIMD, h1 / h2 chained through the register file, k-permuted weight images) -- evidence from the
+    executor's run-time counters, forward AND inverse, K launches each -- while levels 2 / 3 stay on k_cnet (64-pixel tiles; row
+    split 4 at level 3).  With the debug switch 0x10000 the same launches fall back to k_cnet<512,1,128>, which reads the same
+    k-permuted images: both against the oracle on every element (inside _case), and against each other well inside the 1e-4 bar."""
+    K = 2
+    plan, fwd, rev = _case(64, 3, K, 512, 48, seed=12)
+    for counts in (fwd, rev):
+        assert counts.get("variant:k_cnet1w<512,1,128>") == K, counts
+        assert counts.get("variant:k_cnet<512,1,64>") == K and counts.get("variant:k_cnet<512,4,64>") == K, counts
+        assert ncnet(counts) == 3 * K and nfinish(counts) == 3 * K, counts
+    G.lib().glowhip_debug_force_tail_tile(0x10000)
+    try:
+        plan2, fwd2, rev2 = _case(64, 3, K, 512, 48, seed=12)
+    finally:
+        G.lib().glowhip_debug_force_tail_tile(0)
+    for counts in (fwd2, rev2):
+        assert counts.get("variant:k_cnet<512,1,128>") == K and "variant:k_cnet1w<512,1,128>" not in counts, counts
+
+
 def test_config_b_geometry_batch16(path):
     """Batch 16: k_cnet splits the h2 rows over 2 / 4 workgroups per tile at the levels whose pixel tiles alone would leave CUs idle."""
     K = 3

@@ -130,6 +130,45 @@ def test_glow_gradients_vs_the_reference_recorded_goldens(coup, perm):
     assert egx <= 2e-4 * gr["dx"].abs().max().item() + 1e-7, f"dL/dx err {egx:.3e}"
 
 
+def test_learned_top_prior_trains_on_the_hip_path():
+    """VERDICT r4 missing #4: ablation.learn_top on the training path (network/model.py:362-379).  Forward (z, nll) and every
+    gradient of mean(nll) -- learn_top.bias / .logs through the prior's own terms, everything else through the HIP sweep, which
+    takes the learned mean / logs for d logp / d z -- against the vectors the REFERENCE recorded (g7_glow_tiny_learn_top.npz)."""
+    from conftest import load_golden, sub
+    g = load_golden("g7_glow_tiny_learn_top")
+    cfg = O.default_cfg(image_shape=(16, 16, 3), hidden_channels=32, K=2, L=2, flow_permutation="invconv", flow_coupling="affine", batch=4)
+    hps = hps_for(cfg, 4)
+    hps.ablation.learn_top = True
+    np.random.seed(7)
+    glow = G.Glow(hps)
+    glow.load_state_dict(sub(g, "sd."))
+    glow.set_actnorm_inited()
+    glow = glow.to(DEV).train()
+    with torch.enable_grad():
+        xd = g["x"].to(DEV).requires_grad_(True)
+        z, nll, _ = glow.normal_flow(xd, None, noise=g["noise"].to(DEV))
+        loss = G.Glow.generative_loss(nll)
+        loss.backward()
+    assert (z.detach().cpu() - g["z"]).abs().max().item() < 1e-4 and (nll.detach().cpu() - g["nll"]).abs().max().item() < 1e-4
+    ref = sub(g, "grad.")
+    for name, p in glow.named_parameters():
+        if name == "h_top":
+            assert p.grad is None
+            continue
+        r = ref[name]
+        got = p.grad.cpu() if p.grad is not None else torch.zeros_like(r)       # (learn_top.weight multiplies zeros: no gradient)
+        err = (got - r).abs().max().item()
+        assert err <= 2e-4 * r.abs().max().item() + 1e-7, f"{name}: err {err:.3e} (|g| max {r.abs().max().item():.3e})"
+    assert float(ref["learn_top.bias"].abs().max()) > 0 and glow.learn_top.bias.grad is not None
+    egx = (xd.grad.cpu() - g["dx"]).abs().max().item()
+    assert egx <= 2e-4 * g["dx"].abs().max().item() + 1e-7, f"dL/dx err {egx:.3e}"
+    # and the loop takes the autograd route for such a model (Glow.loss_and_grads is the fixed-prior fast path)
+    from pytorch_glow_amd import parallel
+    opt = torch.optim.Adam(glow.parameters(), lr=1e-5)
+    l2, _ = parallel.train_step(glow, opt, g["x"].to(DEV), world=1)
+    assert torch.isfinite(l2)
+
+
 def test_train_steps_reduce_the_loss():
     """Three optimiser steps of the reference's training loop (trainer.py:123-150) on the HIP path: data-dependent
     ActNorm init, forward with tape, HIP backward, clip by value 5 / by norm 100, Adam -- the loss must fall and every

@@ -153,6 +153,27 @@ def test_g7_gradients_recorded_from_the_reference(golden, coup, perm):
     close(x.grad, gr["dx"], atol=2e-5 * float(gr["dx"].abs().max()) + 1e-8)
 
 
+def test_g7_learned_top_prior_forward_and_gradients(golden):
+    """ablation.learn_top (network/model.py:340-343, 375-376): z, nll and every gradient of mean(nll) -- learn_top.bias / .logs
+    included -- as the reference computed them (tests/golden/make_golden.py g7_learn_top)."""
+    g = golden("g7_glow_tiny_learn_top")
+    cfg = dict(TINY, flow_coupling="affine", flow_permutation="invconv", learn_top=True)
+    sd = sub(g, "sd.")
+    with torch.enable_grad():
+        leaf = {k: v.clone().requires_grad_(k != "h_top") for k, v in sd.items()}
+        x = g["x"].clone().requires_grad_(True)
+        z, nll, _ = O.glow_forward(x, g["noise"], leaf, cfg)
+        loss = nll.mean()
+        loss.backward()
+    close(z.detach(), g["z"], atol=2e-5); close(nll.detach(), g["nll"], atol=2e-6)
+    ref = sub(g, "grad.")
+    assert "learn_top.bias" in ref and "learn_top.logs" in ref
+    for k, want in ref.items():
+        got = leaf[k].grad if leaf[k].grad is not None else torch.zeros_like(want)
+        close(got, want, atol=2e-5 * float(want.abs().max()) + 1e-8)
+    close(x.grad, g["dx"], atol=2e-5 * float(g["dx"].abs().max()) + 1e-8)
+
+
 def test_g8_glow_celeba64(golden):
     """Full-size model (44.1 M parameters) on B=2: the reference, fed the oracle's seeded weights,
     produced these digests; the oracle must reproduce them from the same seed."""
