@@ -671,6 +671,7 @@ static int cnet1w_instance(const CnetArgs& a, const CnetGeo& g) {      // 0: non
 
 bool cnet1w_takes(const CnetArgs& a, const CnetGeo& g) {
     if (a.tape_h1 || a.pre_on || a.bwd) return false;
+    if (g.NI != 1) return false;                     // (tiles of whole small images stay on k_cnet: no level that large has them)
     if (!cnet1w_instance(a, g)) return false;
     if (cnet1w_lds_bytes(g, a.hidden) > 160 * 1024) return false;
     if (g.Cg % 4 != 0) return false;                 // the tap sums take four output channels per 16-byte read

@@ -110,6 +110,16 @@ def test_level1_runs_on_the_one_wave_per_simd_kernel_and_both_kernels_match_the_
         assert counts.get("variant:k_cnet<512,1,128>") == K and "variant:k_cnet1w<512,1,128>" not in counts, counts
 
 
+def test_one_wave_kernel_at_a_16_pixel_wide_level():
+    """k_cnet1w outside the BASELINE shapes: a 32x32 input, L = 1 -- C = 12 on 16x16 pixels, a 128-pixel tile is eight image rows
+    (the configs run it at 32, 64 and 128 pixels per row) -- at batch 112 = 224 tiles, the smallest launch it takes; forward and
+    inverse against the oracle on every element, the instance asserted from the run-time counters."""
+    K = 2
+    plan, fwd, rev = _case(32, 1, K, 512, 112, seed=13)
+    for counts in (fwd, rev):
+        assert counts.get("variant:k_cnet1w<512,1,128>") == K, counts
+
+
 def test_config_b_geometry_batch16(path):
     """Batch 16: k_cnet splits the h2 rows over 2 / 4 workgroups per tile at the levels whose pixel tiles alone would leave CUs idle."""
     K = 3
