@@ -17,7 +17,7 @@
 //     one wave per SIMD issues up to five other instructions in the shadow of each MFMA (MI355X_MICROARCH.md), so the matrix pipe
 //     stays busy through what used to be separate phases.
 // Output: the partial sums `hpart` / `hup` / `hdn` of k_cnet at MS = 1 with 128-pixel tiles -- k_cfinish does not know the difference.
-// Product forward / inverse only (no taping, no chained prologue, one group of f.4 output channels).
+// Product forward / inverse and the training forward (TAPE); no backward launch, no chained prologue, one group of f.4 output channels.
 #include "sh.h"
 #include <algorithm>
 #include <type_traits>
@@ -74,7 +74,13 @@ __device__ __forceinline__ void c1_frag(const f32x4_t& v, h8& bh, h8& bl, int ha
     for (int t = 0; t < 4; ++t) { bh[4 * half + t] = hi[t]; bl[4 * half + t] = lo[t]; }
 }
 
-template <int HID, int G0, int NRT4>
+// TAPE (the training forward, plan_train.hip): h1 and h2 also go to memory as fp16 [pixel / 32][row][pixel % 32] and their signs as
+// 16-bit words -- the formats k_cnet MODE 1 writes and the backward k_cnet / the weight-gradient GEMMs read (cnet_sh.hip).  A lane
+// holds two consecutive rows of ONE pixel per packed register; a quad-permute with the neighbouring lane turns that into one row of
+// TWO pixels (even lanes the even row, odd lanes the odd one): one 4-byte store per pair of values instead of two 2-byte ones.
+// The stores ride in the epilogue pipeline (five more stages); they count in vmcnt like the stream's pieces, in order, so the
+// counted waits of the stream allow for the stores issued behind the piece they wait for.
+template <int HID, int G0, int NRT4, bool TAPE = false>
 __global__ void __launch_bounds__(256) k_cnet1w(CnetArgs a, CnetGeo g) {
     constexpr int NT = 256, LPXT = 7;
     constexpr int NCH = HID / 32;             // 32-channel chunks of the hidden width = row tiles of h1 / h2
@@ -109,6 +115,46 @@ __global__ void __launch_bounds__(256) k_cnet1w(CnetArgs a, CnetGeo g) {
     const long n0 = g.NI == 1 ? gp0 / HW : (long)tb * g.NI;
     const int y0 = g.NI == 1 ? (int)((gp0 - n0 * HW) >> g.wshift) : 0;
     const int submask = (1 << g.lsub) - 1;
+    // TAPE: this wave's 32-pixel tile of the fp16 tensors (uniform) + the lane's place in a pair of rows; its sign words
+    [[maybe_unused]] char* tb1 = nullptr;
+    [[maybe_unused]] char* tb2 = nullptr;
+    [[maybe_unused]] unsigned short* mb1 = nullptr;
+    [[maybe_unused]] unsigned short* mb2 = nullptr;
+    [[maybe_unused]] const unsigned tlane = ((4 * kl + (lane & 1)) * 32 + (ml & ~1)) * 2;
+    [[maybe_unused]] const unsigned psel = (lane & 1) ? 0x03020706u : 0x05040100u;
+    [[maybe_unused]] const long mstride = (long)a.N * HW * 2;      // sign words from one 32-row tile to the next
+    [[maybe_unused]] const float nscale = -a.out_scale;
+    if constexpr (TAPE) {
+        const long tile32 = (gp0 >> 5) + wid;
+        tb1 = reinterpret_cast<char*>(a.tape_h1) + tile32 * (HID * 64);
+        tb2 = reinterpret_cast<char*>(a.tape_h2) + tile32 * (HID * 64);
+        mb1 = a.mask1 + (gp0 + wid * 32) * 2;
+        mb2 = a.mask2 + (gp0 + wid * 32) * 2;
+    }
+    // (values v0, v1 = the NEGATED, scaled activations of rows r, r + 1 of this lane's pixel)
+    [[maybe_unused]] auto tape_half = [&](unsigned x) -> unsigned {      // packed hi halves (of -16 h) -> packed fp16 h
+        const h2 ns = {(_Float16)nscale, (_Float16)nscale};
+        return __builtin_bit_cast(unsigned, __builtin_bit_cast(h2, x) * ns);
+    };
+    [[maybe_unused]] auto tape_pack = [&](float v0, float v1) -> unsigned {
+        const f32x2_t vv = {v0, v1};
+        return tape_half(__builtin_bit_cast(unsigned, __builtin_convertvector(vv, h2)));
+    };
+    [[maybe_unused]] auto tape_nbr = [&](unsigned tx) -> unsigned { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)tx, 0xB1, 0xF, 0xF, true); };      // quad_perm [1, 0, 3, 2]
+    [[maybe_unused]] auto tape_sel = [&](unsigned nb, unsigned tx) -> unsigned { return __builtin_amdgcn_perm(nb, tx, psel); };
+#ifdef C1_DBG_TAPE_NOSTORE
+    constexpr bool TST = false;           // (timing experiments only: the tape's arithmetic without its stores)
+#else
+    constexpr bool TST = TAPE;
+#endif
+    [[maybe_unused]] auto tape_put = [&](char* tb, int c, int p, unsigned to) {       // pair p of chunk c: rows 32 c + 8 (p / 2) + 4 kl + 2 (p % 2) (+ 1)
+        if (TST) *reinterpret_cast<unsigned*>(tb + (unsigned)(32 * c + 8 * (p >> 1) + 2 * (p & 1)) * 64u + tlane) = to;
+        else asm volatile("" ::"v"(to));
+    };
+    [[maybe_unused]] auto mask_put = [&](unsigned short* mb, int c, unsigned w) {
+        if (TST) mb[(long)c * mstride + ml * 2 + kl] = (unsigned short)w;
+        else asm volatile("" ::"v"(w));
+    };
 
     [[maybe_unused]] const _Float16* W0 = (const _Float16*)a.w0;
     const long w0_plane = (long)G0 * HID * 8;
@@ -251,7 +297,7 @@ __global__ void __launch_bounds__(256) k_cnet1w(CnetArgs a, CnetGeo g) {
             h8 hi, lo;
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                const float vv = (in && ch * 8 + q < a.Cin) ? canon_nan(v[q] * SH2_ACT_SCALE) : 0.f;
+                const float vv = (in && ch * 8 + q < a.Cin) ? canon_nan(v[q] * (TAPE ? a.in_scale : SH2_ACT_SCALE)) : 0.f;
                 _Float16 x0, x1;
                 sh2_split(vv, x0, x1);
                 hi[q] = x0; lo[q] = x1;
@@ -269,8 +315,11 @@ __global__ void __launch_bounds__(256) k_cnet1w(CnetArgs a, CnetGeo g) {
         if (tid < MP4) t_rs4[tid] = canon_nan(-tv4);
     }
     // f.0's rows of chunk 0 have landed: everything but the 18 + NP0 pieces of the fills requested behind them (in-order counter)
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(18 + NP0) : "memory");
-    __syncthreads();
+    // (a plain barrier: __syncthreads() puts a vmcnt(0) in front of it -- it counts the LDS-DMA pieces as LDS writes to be fenced --
+    // and would wait here for the 18 + NP0 pieces that have the whole of f.0 of chunk 0 to land)
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(18 + NP0) : "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
     GH_STAMP(1);
 
     // ---- per-lane constants of the contractions
@@ -304,6 +353,7 @@ __global__ void __launch_bounds__(256) k_cnet1w(CnetArgs a, CnetGeo g) {
         hi = *reinterpret_cast<const h8*>(p);
         lo = *reinterpret_cast<const h8*>(p + wlo);
     };
+    [[maybe_unused]] unsigned E_mw = 0u;     // TAPE: the sign word being built (value k = 4 gq + t shifted in at bit 0: ends up in bit 15 - k)
     // epilogue of f.0 for group gq (rows 8 gq + 4 kl + t of chunk c): -h1 = -relu(.) as halves of the B fragments
     auto epi1 = [&](const f32x16_t& acc, int c, int gq, h8 (&bh)[2], h8 (&bl)[2]) {
         const int o = 32 * c + 8 * gq + 4 * kl;
@@ -313,6 +363,16 @@ __global__ void __launch_bounds__(256) k_cnet1w(CnetArgs a, CnetGeo g) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) v[t] = nrelu_bits(fmaf(acc[4 * gq + t], rs[t], bb[t]));
         c1_frag(v, bh[gq >> 1], bl[gq >> 1], gq & 1);
+        if constexpr (TAPE) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const unsigned tx = tape_pack(v[2 * h], v[2 * h + 1]);
+                tape_put(tb1, c, 2 * gq + h, tape_sel(tape_nbr(tx), tx));
+                E_mw = __builtin_amdgcn_alignbit(E_mw, __float_as_uint(v[2 * h]), 31);
+                E_mw = __builtin_amdgcn_alignbit(E_mw, __float_as_uint(v[2 * h + 1]), 31);
+            }
+            if (gq == 3) mask_put(mb1, c, E_mw);
+        }
     };
 
     // ---- f.0 of chunk 0 on its own (the only MFMAs of the kernel without f.2 or f.4 MFMAs around them)
@@ -377,7 +437,13 @@ __global__ void __launch_bounds__(256) k_cnet1w(CnetArgs a, CnetGeo g) {
     f32x4_t E_rs[2], E_bb[2];         // [gq & 1]
     float E_v[8][2], E_m[8][2];       // per pair: value (S1, S2), residual (S4)
     unsigned E_x[8];                  // per pair: the packed hi halves (S3)
-    auto epi_tick = [&](const f32x16_t& acc, const float* trs, const float* tbb, int c, int e, h8 (&bh)[2], h8 (&bl)[2], auto agpr) {
+    // TAPE: four more stages per pair behind S3 -- T1 the hi halves times -1/16 (one packed fp16 multiply: exact but for results in
+    // fp16's subnormal range, |h| < 6.1e-5, where it rounds a second time -- k_cnet converts the fp32 product, one rounding; both are
+    // fp16 roundings of h within 2^-24) + the pair's two sign bits, T2 the neighbouring lane's, T3 select, T4 store: pair p is at
+    // stage T in tick 2 p + 5 + T (the last store in tick 23), the block's sign word goes out in tick 22
+    [[maybe_unused]] unsigned E_tx[8], E_tn[8];
+    auto epi_tick = [&](const f32x16_t& acc, const float* trs, const float* tbb, int c, int e, h8 (&bh)[2], h8 (&bl)[2], auto agpr,
+                        [[maybe_unused]] char* tb, [[maybe_unused]] unsigned short* mb) {
         if ((e & 3) == 0 && e < 16) {
             const int gq = e >> 2, o = 32 * c + 8 * gq + 4 * kl;
             E_rs[gq & 1] = *reinterpret_cast<const f32x4_t*>(trs + o);
@@ -420,6 +486,29 @@ __global__ void __launch_bounds__(256) k_cnet1w(CnetArgs a, CnetGeo g) {
                 bl[gq >> 1][e0] = y[0]; bl[gq >> 1][e0 + 1] = y[1];
             }
         }
+        if constexpr (TAPE) {
+#pragma unroll
+            for (int T = 1; T <= 4; ++T) {
+                const int d = e - 5 - T;
+                if (d < 0 || (d & 1) || d / 2 > 7) continue;
+                const int p = d / 2;
+                if (T == 1) {
+                    E_tx[p] = tape_half(E_x[p]);
+                    E_mw = __builtin_amdgcn_alignbit(E_mw, __float_as_uint(E_v[p][0]), 31);
+                    E_mw = __builtin_amdgcn_alignbit(E_mw, __float_as_uint(E_v[p][1]), 31);
+                    asm volatile("" : "+v"(E_tx[p]), "+v"(E_mw));
+                } else if (T == 2) {
+                    E_tn[p] = tape_nbr(E_tx[p]);
+                    asm volatile("" : "+v"(E_tn[p]));
+                } else if (T == 3) {
+                    E_tx[p] = tape_sel(E_tn[p], E_tx[p]);
+                    asm volatile("" : "+v"(E_tx[p]));
+                } else {
+                    tape_put(tb, c, p, E_tx[p]);
+                }
+            }
+            if (e == 22) mask_put(mb, c, E_mw);
+        }
     };
 
 #pragma unroll 1
@@ -446,8 +535,10 @@ __global__ void __launch_bounds__(256) k_cnet1w(CnetArgs a, CnetGeo g) {
                     // more ago, so the lgkmcnt(0) no longer waits out an LDS round trip (at the head of the quad it did, 32 times
                     // per tile), and the next k-step's first fragments are requested from slot 4 on.
 #ifndef C1_DBG_NO_VMWAIT
-                    if (s == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(8 + NP0) : "memory");
-                    else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+                    // (TAPE: + the stores issued behind the last piece of the fill waited for -- 6 of the previous chunk's 9 at s = 0,
+                    // all 9 of this chunk's at s = 1; one less each: a smaller count only waits for more)
+                    if (s == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(8 + NP0 + (TST ? 5 : 0)) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(8 + (TST ? 8 : 0)) : "memory");
 #endif
 #ifndef C1_DBG_NO_BARRIER
                     __builtin_amdgcn_s_barrier();
@@ -503,7 +594,7 @@ __global__ void __launch_bounds__(256) k_cnet1w(CnetArgs a, CnetGeo g) {
                 if (Q == 5 || Q == 6) {
 #ifndef C1_DBG_NO_EPI
                     if (Q == 5 && k == 0) c1_settle(acc1);
-                    epi_tick(acc1, t_rs0, t_b0, cn, (Q - 5) * 12 + k, Bnh, Bnl, std::false_type{});
+                    epi_tick(acc1, t_rs0, t_b0, cn, (Q - 5) * 12 + k, Bnh, Bnl, std::false_type{}, tb1, mb1);
 #endif
                 }
 #endif
@@ -522,7 +613,7 @@ __global__ void __launch_bounds__(256) k_cnet1w(CnetArgs a, CnetGeo g) {
     f32x16_t accT[NRT4];       // in VGPRs like f.0's block (asm MFMAs): h2 holds every AGPR until its last block has been consumed
     h8 Hh[2][2], Hl[2][2];      // [chunk & 1][k-step of the chunk]
 #pragma unroll
-    for (int e = 0; e < 24; ++e) epi_tick(acc2[0], t_rs2, t_b2, 0, e, Hh[0], Hl[0], std::true_type{});
+    for (int e = 0; e < 24; ++e) epi_tick(acc2[0], t_rs2, t_b2, 0, e, Hh[0], Hl[0], std::true_type{}, tb2, mb2);
     static_assert(NRT4 == 4, "the slot plan of f.4 (12 MFMAs per k-step, fragments reloaded behind their last use) is laid out for four row tiles");
     h8 A4H[NRT4], A4L[NRT4];
     auto ldA4one = [&](int slot_off, int kk, int i, int pl, h8& dst) {
@@ -544,7 +635,8 @@ __global__ void __launch_bounds__(256) k_cnet1w(CnetArgs a, CnetGeo g) {
 #pragma unroll
         for (int k = 0; k < NM; ++k) {
             if (kk == K4 - 1 && F + 1 <= FL && k == 3) {      // TOP (as in the loop above: in front of the k-step's fourth slot)
-                if (F + 2 <= FL) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+                // (TAPE: 19 stores are issued between the last piece of fill F + 1 -- at the end of fill F - 1's third k-step -- and here)
+                if (F + 2 <= FL) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(8 + (TST ? 16 : 0)) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
@@ -559,7 +651,7 @@ __global__ void __launch_bounds__(256) k_cnet1w(CnetArgs a, CnetGeo g) {
             if (ks + 1 < NKS && sw == 1) ldA4one(s_cur, (kk + 1) % K4, i, 0, A4H[i]);
             if (ks + 1 < NKS && sw == 2) ldA4one(s_cur, (kk + 1) % K4, i, 1, A4L[i]);
             // h2 of the next block: its epilogue over the 24 slots of this block's two k-steps
-            if (c + 1 < NCH) epi_tick(acc2[cn], t_rs2, t_b2, cn, 12 * s + k, Hh[cn & 1], Hl[cn & 1], std::true_type{});
+            if (c + 1 < NCH) epi_tick(acc2[cn], t_rs2, t_b2, cn, 12 * s + k, Hh[cn & 1], Hl[cn & 1], std::true_type{}, tb2, mb2);
             if (ff <= FL && k >= NM - (i1 - i0)) ring_piece(ff, i0 + k - (NM - (i1 - i0)));
             C1_FENCE();
         }
@@ -665,12 +757,13 @@ static size_t cnet1w_lds_bytes(const CnetGeo& g, int hidden) {
 
 static int cnet1w_instance(const CnetArgs& a, const CnetGeo& g) {      // 0: none
     if (a.hidden != 512 || g.ng != 1 || g.pxt != 128) return 0;
-    if (g.G == 10 && g.NRT4 == 4) return 1;
+    if (g.G == 10 && g.NRT4 == 4) return a.tape_h1 ? 2 : 1;
     return 0;
 }
 
 bool cnet1w_takes(const CnetArgs& a, const CnetGeo& g) {
-    if (a.tape_h1 || a.pre_on || a.bwd) return false;
+    if (a.pre_on || a.bwd) return false;
+    if (a.tape_h1 && (!a.tape_h2 || !a.mask1 || !a.mask2 || g.HW % 128 != 0)) return false;      // taping: whole 32-pixel tiles of the batch per wave
     if (g.NI != 1) return false;                     // (tiles of whole small images stay on k_cnet: no level that large has them)
     if (!cnet1w_instance(a, g)) return false;
     if (cnet1w_lds_bytes(g, a.hidden) > 160 * 1024) return false;
@@ -686,6 +779,10 @@ int launch_cnet1w(const CnetArgs& a, const CnetGeo& g, hipStream_t s) {
     case 1:
         (void)hipFuncSetAttribute((const void*)k_cnet1w<512, 10, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((k_cnet1w<512, 10, 4>), dim3(g.tiles), dim3(256), lds, s, a, g);
+        break;
+    case 2:
+        (void)hipFuncSetAttribute((const void*)k_cnet1w<512, 10, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((k_cnet1w<512, 10, 4, true>), dim3(g.tiles), dim3(256), lds, s, a, g);
         break;
     default:
         set_error("cnet1w: no kernel instance");

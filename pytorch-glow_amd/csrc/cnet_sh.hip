@@ -1414,6 +1414,8 @@ static bool cnet_select(const CnetArgs& a, CnetGeo* gout, int* ms_out, int* upw_
     // taping / backward launches: the 128-pixel instance is at the register limit and spills once the stores and the sign words
     // are in (184 B); 64-pixel tiles measured 2 % faster on the training step
     if (a.tape_h1 && ok64 && !(g_cnet_flags & 1)) use64 = true;
+    // ... except where the one-wave-per-SIMD kernel takes the taping forward (cnet1w_sh.hip: its registers hold the 128-pixel tile)
+    if (a.tape_h1 && !a.bwd && ok128 && g128.tiles >= 224 && !(g_cnet_flags & (2 | 16)) && cnet1w_takes(a, g128)) use64 = false;
     g = use64 ? g64 : g128;
     int ms = 1;
     const int ms_max = std::min(CN_MAXMS, a.hidden / (use64 ? 128 : 64));
@@ -1463,15 +1465,15 @@ int launch_cnet_main(const CnetArgs& a, hipStream_t s, CnetPending* out) {
                          cnet_tape_instance(a.hidden, ms, upw, g.pxt, g.ng)),
                "cnet: no taping / backward instance for this launch");
     int rc = GLOWHIP_EINVAL;
-    // one wave per SIMD (cnet1w_sh.hip) wherever an instance exists for the launch: plain forward / inverse, 128-pixel tiles, no row split
+    // one wave per SIMD (cnet1w_sh.hip) wherever an instance exists for the launch: forward / inverse / taping forward, 128-pixel tiles, no row split
     bool one_wave = false;
-    if (!tape && !a.pre_on && ms == 1 && g.pxt == 128 && !(g_cnet_flags & 16) && cnet1w_takes(a, g)) {
+    if (!a.bwd && !a.pre_on && ms == 1 && g.pxt == 128 && !(g_cnet_flags & 16) && cnet1w_takes(a, g)) {
         GH_TRY(launch_cnet1w(a, g, s));
         rc = GLOWHIP_OK;
         one_wave = true;
     }
 #define GH_CNT(hid, m, px)                                                                                     \
-    if (tape && a.hidden == hid && ms == m && g.pxt == px)                                                     \
+    if (rc == GLOWHIP_EINVAL && tape && a.hidden == hid && ms == m && g.pxt == px)                             \
         rc = a.bwd ? launch_cnet_tape<hid, m, px, 2>(a, g, s) : launch_cnet_tape<hid, m, px, 1>(a, g, s);
     GH_CNT(512, 1, 128) GH_CNT(512, 2, 128) GH_CNT(512, 4, 128) GH_CNT(512, 1, 64) GH_CNT(512, 2, 64) GH_CNT(512, 4, 64)
     GH_CNT(256, 1, 128) GH_CNT(256, 2, 128) GH_CNT(256, 1, 64) GH_CNT(256, 2, 64) GH_CNT(128, 1, 128) GH_CNT(128, 1, 64)

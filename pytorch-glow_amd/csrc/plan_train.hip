@@ -234,6 +234,7 @@ static int forward_train(glowhip_plan* p, const void* packed, const float* x, co
                         ScopedTimer t(p, GLOWHIP_K_CNET_TAPE, 1, s);
                         GH_TRY(launch_cnet_main(c, s, &pend));
                     }
+                    if (pend.one_wave) count_launch(p, "k_cnet1w(tape)");      // (run-time evidence for the tests: the taping instance of cnet1w_sh.hip took it)
                     ScopedTimer t(p, GLOWHIP_K_CFINISH, 0, s);
                     GH_TRY(launch_cnet_finish(c, pend, s));
                 }

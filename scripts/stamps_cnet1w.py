@@ -1,6 +1,6 @@
 """Debug: cycle stamps of one workgroup (all four waves) of the LAST k_cnet1w launch of a forward (stamps build only):
 make -C pytorch-glow_amd/csrc BUILD=build_stamps LIB=../libglowhip_stamps.so EXTRA=-DGLOWHIP_DEBUG_STAMPS
-env: K, L (model depth), B (batch), FLAGS (glowhip_debug_force_tail_tile)."""
+env: K, L (model depth), B (batch), FLAGS (glowhip_debug_force_tail_tile), TRAIN=1 (the taping instance)."""
 import ctypes, os, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, root)
@@ -17,8 +17,13 @@ if fl: G.lib().glowhip_debug_force_tail_tile(fl)
 glow.train()
 with torch.no_grad():
     glow.normal_flow(x, None)
-    glow.eval()
-    for _ in range(3): glow.normal_flow(x, None)
+if os.environ.get("TRAIN"):          # the taping instance: training forwards (the tape is written when a graph is recorded)
+    with torch.enable_grad():
+        for _ in range(3): glow.normal_flow(x, None)
+else:
+    with torch.no_grad():
+        glow.eval()
+        for _ in range(3): glow.normal_flow(x, None)
 torch.cuda.synchronize()
 buf = (ctypes.c_ulonglong * (8 * 64))()
 G.lib().glowhip_debug_read_stamps_all_cnet1w(buf)

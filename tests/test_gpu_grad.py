@@ -507,6 +507,51 @@ def test_training_step_runs_on_k_cnet_and_agrees_with_the_per_layer_kernels():
                 (hex(flag), name, scale, err.max().item())
 
 
+def test_taping_forward_on_the_one_wave_kernel_agrees_with_k_cnet():
+    """Round 5: where level 1 gives 224 or more 128-pixel tiles (batch 28 at config-B geometry) the TRAINING forward of its FlowSteps
+    runs on the taping instance of k_cnet1w (cnet1w_sh.hip: h1 / h2 stay in registers and go to the tape from the epilogue pipeline,
+    two pixels of one row per 4-byte store after a quad-permute, sign words as k_cnet writes them) -- evidence from the run-time
+    counter -- while the backward launch and the weight-gradient GEMMs read that tape unchanged.  With the debug switch 0x10000 the
+    same step tapes with k_cnet MODE 1 (pinned against the fp64 oracle above): z, nll and every gradient of the two agree."""
+    from pytorch_glow_amd import _lib
+    K, batch = 2, 28
+    cfg = O.default_cfg(K=K, batch=batch)
+    sd = O.seeded_state_dict(cfg, seed=23, invconv_perturb=0.02, zeros_std=0.01)
+    g = torch.Generator().manual_seed(23)
+    x = torch.rand(batch, 3, 64, 64, generator=g)
+    noise = torch.rand(batch, 3, 64, 64, generator=g) / 256
+    sd = O.glow_init_actnorm(x, noise, sd, cfg)
+    res = {}
+    try:
+        for flag in (0x10000, 0):
+            _lib.lib().glowhip_debug_force_tail_tile(flag)
+            glow = G.Glow(hps_for(cfg, batch))
+            glow.load_state_dict(sd)
+            glow.set_actnorm_inited()
+            glow = glow.to(DEV).train()
+            with torch.enable_grad():
+                xd = x.to(DEV).requires_grad_(True)
+                z, nll, _ = glow.normal_flow(xd, None, noise=noise.to(DEV))
+                G.Glow.generative_loss(nll).backward()
+            counts = glow.flow.plan_for(x.to(DEV)).launch_counts()
+            grads = {n: p.grad.cpu().double() for n, p in glow.named_parameters() if p.grad is not None}
+            grads["dx"] = xd.grad.cpu().double()
+            res[flag] = (z.detach().cpu(), nll.detach().cpu(), grads, counts)
+    finally:
+        _lib.lib().glowhip_debug_force_tail_tile(0)
+    z0, n0, g0, c0 = res[0x10000]
+    z1, n1, g1, c1 = res[0]
+    assert c0.get("k_cnet(tape)", 0) == 3 * K and c0.get("k_cnet1w(tape)", 0) == 0, c0
+    assert c1.get("k_cnet(tape)", 0) == 3 * K and c1.get("k_cnet1w(tape)", 0) == K and c1.get("k_cnet(bwd)", 0) == 3 * K, c1
+    assert torch.isfinite(n1).all()
+    assert (z1 - z0).abs().max().item() <= 2e-5 and (n1 - n0).abs().max().item() <= 2e-6 * max(1.0, n0.abs().max().item())
+    for name, a in g0.items():
+        scale = a.abs().max().item()
+        err = (g1[name] - a).abs()
+        assert err.pow(2).mean().sqrt().item() <= 1e-3 * scale + 1e-9 and err.max().item() <= 0.05 * scale + 1e-8, \
+            (name, scale, err.max().item())
+
+
 def test_grouped_weight_gradient_launches_agree_with_the_per_layer_kernels():
     """The weight-gradient GEMMs of a FlowStep behind the backward k_cnet run grouped: all three in one launch where the pixel axis
     is short (<= 512 k-tiles of 32 pixels), f.2's own kernel + f.4 / f.0 as a pair where it is long (level 1 from 17 images on).
