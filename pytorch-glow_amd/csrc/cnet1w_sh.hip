@@ -18,6 +18,10 @@
 //     stays busy through what used to be separate phases.
 // Output: the partial sums `hpart` / `hup` / `hdn` of k_cnet at MS = 1 with 128-pixel tiles -- k_cfinish does not know the difference.
 // Product forward / inverse and the training forward (TAPE); no backward launch, no chained prologue, one group of f.4 output channels.
+// MS = 2: the h2 rows of a 128-pixel tile split over TWO workgroups (grid.y), each computing all of h1 again (f.0 is the small
+// layer) and half of f.2 / a K-half of f.4 -- for the levels whose 128-pixel tiles alone leave half the CUs idle (C = 24 at 16 x 16
+// pixels and batch 64: 128 tiles).  Weight bytes per MFMA stay those of a 128-pixel tile (a 64-pixel tile needs twice that, and at
+// one workgroup per CU the launch is then bound by the L2 -> LDS stream); the partial sums are k_cnet's MS = 2 layout.
 #include "sh.h"
 #include <algorithm>
 #include <type_traits>
@@ -74,37 +78,56 @@ __device__ __forceinline__ void c1_frag(const f32x4_t& v, h8& bh, h8& bl, int ha
     for (int t = 0; t < 4; ++t) { bh[4 * half + t] = hi[t]; bl[4 * half + t] = lo[t]; }
 }
 
+// f.0's MFMA j (k-step j / 3, product j % 3) of the chunk riding along: its slot among the chunk's 24 NQ f.2 slots.  Four quads per
+// k-step (MS = 1): k-step st in quad st, behind slots 3, 7, 11.  Two (MS = 2): one per slot from slot 0 on -- 27 of them (G0 = 18)
+// in the 24 slots of the chunk's first k-step, every ninth doubled up -- so that the epilogue has the second k-step's 24 slots.
+__host__ __device__ constexpr int c1_f0slot(int nq, int j) { return nq == 4 ? 12 * (j / 3) + 3 + 4 * (j % 3) : j - (j + 1) / 9; }
+
 // TAPE (the training forward, plan_train.hip): h1 and h2 also go to memory as fp16 [pixel / 32][row][pixel % 32] and their signs as
 // 16-bit words -- the formats k_cnet MODE 1 writes and the backward k_cnet / the weight-gradient GEMMs read (cnet_sh.hip).  A lane
 // holds two consecutive rows of ONE pixel per packed register; a quad-permute with the neighbouring lane turns that into one row of
 // TWO pixels (even lanes the even row, odd lanes the odd one): one 4-byte store per pair of values instead of two 2-byte ones.
 // The stores ride in the epilogue pipeline (five more stages); they count in vmcnt like the stream's pieces, in order, so the
 // counted waits of the stream allow for the stores issued behind the piece they wait for.
-template <int HID, int G0, int NRT4, bool TAPE = false>
+template <int HID, int G0, int NRT4, bool TAPE = false, int MS = 1>
 __global__ void __launch_bounds__(256) k_cnet1w(CnetArgs a, CnetGeo g) {
     constexpr int NT = 256, LPXT = 7;
-    constexpr int NCH = HID / 32;             // 32-channel chunks of the hidden width = row tiles of h1 / h2
-    constexpr int NKS = HID / 16;             // k-steps of f.2 (and of f.4)
-    constexpr int SLOT = HID * 64;            // ring slot: one k-step of the f.2 image, both planes (32 KiB at hidden 512)
+    constexpr int NCH = HID / 32;             // 32-channel chunks of the hidden width = row tiles of h1
+    constexpr int NKS = HID / 16;             // k-steps of f.2
+    constexpr int MR = HID / MS;              // h2 rows of this workgroup
+    constexpr int NRT2 = MR / 32;             // ... as row tiles = accumulator blocks of the wave
+    constexpr int NQ = NRT2 / 4;              // quads of row tiles = quads of 12 slots per k-step of f.2
+    constexpr int NKS4 = MR / 16;             // k-steps of f.4 over this workgroup's h2 rows
+    constexpr int SLOT = MR * 64;             // ring slot: one k-step of the workgroup's rows of the f.2 image, both planes (32 / 16 KiB)
+    constexpr int PPF = 2 * NQ;               // 1-KiB pieces per wave of such a fill
     constexpr int NST0 = G0 / 2;              // k-steps of f.0
     constexpr int NP0 = (G0 + 3) / 4;         // DMA pieces per wave of a chunk's f.0 rows (G0 KiB)
     constexpr int MP4 = NRT4 * 32;            // rows of the taps-as-rows f.4 image
     constexpr int K4 = SLOT / (MP4 * 64) >= 4 ? 4 : (SLOT / (MP4 * 64) >= 2 ? 2 : 1);      // k-steps of the f.4 image per ring slot
-    constexpr int NF4 = NKS / K4;             // fills of the f.4 image
+    constexpr int NF4 = NKS4 / K4;            // fills of the f.4 image
     constexpr int PP4 = K4 * NRT4;            // 1-KiB pieces per plane of such a fill
-    constexpr int PPW4 = PP4 / 2;             // ... per wave (both planes over four waves)
-    static_assert(PP4 % 2 == 0 && PPW4 <= 8 && NF4 >= 3 && NCH % 2 == 0, "ring bookkeeping");
+    constexpr int PPW4 = (2 * PP4 + 3) / 4;   // ... per wave (both planes over four waves; a surplus piece repeats the last)
+    constexpr bool RUN4 = PP4 % 2 == 0;       // a wave's pieces of an f.4 fill are one run of one plane (else: placed piece by piece)
+    static_assert(PPW4 == PPF && NF4 >= 3 && NCH % 2 == 0 && NQ >= 2 && NKS4 % K4 == 0, "ring bookkeeping");
+    static_assert(!TAPE || MS == 1, "taping: every workgroup would store its share of h1 (a run-time count of stores in the counted waits)");
     constexpr int FL = NKS + NF4 - 1;         // last fill of the stream: fills 0 .. NKS - 1 = f.2 k-steps, NKS .. FL = f.4 fills
-    constexpr int W0B = 3 * SLOT;             // byte offsets of the LDS regions: ring | f.0 double buffer | window | tables
+    constexpr int NF0 = 3 * NST0;             // MFMAs of f.0 per chunk
+    constexpr int EP0 = NQ == 4 ? 60 : 24;    // first of the 24 slots of f.0's epilogue among the chunk's 24 NQ
+    static_assert(c1_f0slot(NQ, NF0 - 1) < EP0 && EP0 + 24 <= 24 * NQ, "f.0 and its epilogue inside the chunk");
+    // byte offsets of the LDS regions: tables | ring | f.0 double buffer | window.  (T, staged at the end, starts behind the tables.)
+    constexpr int TABS = ((4 * HID + MP4) * 4 + 1023) / 1024 * 1024;
+    constexpr int RINGB = TABS;
+    constexpr int W0B = RINGB + 3 * SLOT;
     constexpr int WINB = W0B + 2 * G0 * 1024;
 
     extern __shared__ __attribute__((aligned(16))) char lds1[];
     _Float16* win = reinterpret_cast<_Float16*>(lds1 + WINB);
-    float* t_rs0 = reinterpret_cast<float*>(win + 2 * g.winplane);
+    float* t_rs0 = reinterpret_cast<float*>(lds1);
     float* t_b0 = t_rs0 + HID;
     float* t_rs2 = t_b0 + HID;
     float* t_b2 = t_rs2 + HID;
     float* t_rs4 = t_b2 + HID;
+    const int ms_row0 = MS > 1 ? (int)blockIdx.y * MR : 0;       // first h2 row of this workgroup
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);       // = the wave's pixel tile
@@ -183,26 +206,45 @@ __global__ void __launch_bounds__(256) k_cnet1w(CnetArgs a, CnetGeo g) {
     const _Float16* f_src = nullptr;      // of the fill in progress: this wave's first source half (uniform; + lane * 8)
 #endif
     int f_dst = 0;                        // ... and its LDS byte offset
-    auto ring_begin = [&](int f, int slot_off) {
-        const bool w2f = f < NKS;
-        const int ppw = w2f ? 8 : PPW4, pp = w2f ? 16 : PP4;
-        const int j = wid * ppw;
-        const int p = j >= pp ? 1 : 0, r = j - p * pp;
+    // KIND (compile time): 0 = the fill is one of f.2's; 2 = one of f.4's; 1 = either (run time: the last two chunks of the f.2 loop
+    // request the first f.4 fills).  The loop bodies must not branch -- a branch splits the slot structure the scheduling barriers
+    // hold together -- so KIND 1 selects between the two forms with scalar selects.
+    auto ring_begin = [&](int f, int slot_off, auto kind) {
+        constexpr int KIND = decltype(kind)::value;
+        const bool w2f = KIND == 0 || (KIND == 1 && f < NKS);
+        // f.2: the wave's PPF pieces are one run -- plane wid / 2, k group wid % 2 of the k-step, the workgroup's MR rows of it
+        // f.4: fill f - NKS = K4 k-steps of the workgroup's K range; RUN4: PPW4 pieces of one plane, else see ring_piece
+        const int p = wid >> 1;
+        const long o2 = (p * w2_plane + ((long)(2 * f + (wid & 1)) * HID + ms_row0) * 8) * 2;
+        const long o4 = ((RUN4 ? p * w4_plane + (wid & 1) * (PPW4 * 512) : 0) + ((long)(ms_row0 / 16) + (long)(f - NKS) * K4) * (2 * MP4 * 8)) * 2;
 #ifndef C1_GLOBAL_DMA
         f_w2 = w2f ? 1 : 0;
-        f_soff = w2f ? (int)((p * w2_plane + (long)f * (2 * HID * 8) + r * 512) * 2) : (int)((p * w4_plane + (long)(f - NKS) * (K4 * 2 * MP4 * 8) + r * 512) * 2);
+        f_soff = (int)(w2f ? o2 : o4);
 #else
-        f_src = w2f ? W2 + p * w2_plane + (long)f * (2 * HID * 8) + r * 512 : W4 + p * w4_plane + (long)(f - NKS) * (K4 * 2 * MP4 * 8) + r * 512;
+        f_src = w2f ? W2 + o2 / 2 : W4 + o4 / 2;
 #endif
-        f_dst = slot_off + j * 1024;
+        f_dst = RINGB + slot_off + ((w2f || RUN4) ? wid * (PPF * 1024) : 0);
     };
-    auto ring_piece = [&](int f, int i) {       // piece i (0 .. 7) of the fill in progress (f: which image, for the piece count)
-        const int ii = PPW4 == 8 ? i : min(i, f < NKS ? 7 : PPW4 - 1);
+    auto ring_piece = [&](int i, auto kind) {       // piece i (0 .. PPF - 1) of the fill in progress
+        constexpr int KIND = decltype(kind)::value;
         char* dst = lds1 + f_dst;
+        if constexpr (!RUN4 && KIND != 0) {
+            // f.4 with an odd piece count per plane (MS = 2: 7 + 7 pieces of a k-step): piece wid + 4 i of the 2 PP4, plane and place
+            // worked out per piece (wave-uniform scalars; a few pieces per k-step of 21 MFMAs: their issue cost does not matter there)
+            const int j = min(wid + 4 * i, 2 * PP4 - 1);
+            const int pl = j >= PP4 ? 1 : 0, r = j - pl * PP4;
+            const int o4 = (int)((pl * w4_plane + r * 512) * 2), d4 = j * 1024;
 #ifndef C1_GLOBAL_DMA
-        const __amdgpu_buffer_rsrc_t rs = f_w2 ? rs_w2 : rs_w4;
-        if (PPW4 == 8) {      // (the piece index is a constant after unrolling: the switch folds)
-            const int sb = i < 4 ? f_soff : f_soff + 4096;
+            const bool w2f = KIND == 1 && f_w2;
+            c1_bdma16o<0>(w2f ? rs_w2 : rs_w4, lane * 16, f_soff + (w2f ? i * 1024 : o4), dst + (w2f ? i * 1024 : d4));
+#else
+            static_assert(KIND == 2 || RUN4, "global-form DMA: debug builds of the full-height instances only");
+            c1_dma16(f_src + o4 / 2 + lane * 8, dst + d4);
+#endif
+        } else {
+#ifndef C1_GLOBAL_DMA
+            const __amdgpu_buffer_rsrc_t rs = KIND == 0 ? rs_w2 : (KIND == 2 ? rs_w4 : (f_w2 ? rs_w2 : rs_w4));
+            const int sb = i < 4 ? f_soff : f_soff + 4096;        // (the piece index is a constant after unrolling: the switch folds)
             char* db = i < 4 ? dst : dst + 4096;
             switch (i & 3) {
             case 0: c1_bdma16o<0>(rs, lane * 16, sb, db); break;
@@ -210,12 +252,8 @@ __global__ void __launch_bounds__(256) k_cnet1w(CnetArgs a, CnetGeo g) {
             case 2: c1_bdma16o<2048>(rs, lane * 16, sb, db); break;
             default: c1_bdma16o<3072>(rs, lane * 16, sb, db); break;
             }
-        } else {
-            c1_bdma16o<0>(rs, lane * 16, f_soff + ii * 1024, dst + ii * 1024);
-        }
 #else
-        const _Float16* src = f_src + lane * 8;
-        if (PPW4 == 8) {      // (the piece index is a constant after unrolling: the switch folds)
+            const _Float16* src = f_src + lane * 8;
             const _Float16* sb = i < 4 ? src : src + 2048;
             char* db = i < 4 ? dst : dst + 4096;
             switch (i & 3) {
@@ -224,11 +262,12 @@ __global__ void __launch_bounds__(256) k_cnet1w(CnetArgs a, CnetGeo g) {
             case 2: c1_dma16o<2048>(sb, db); break;
             default: c1_dma16o<3072>(sb, db); break;
             }
-        } else {
-            c1_dma16(src + ii * 512, dst + ii * 1024);
-        }
 #endif
+        }
     };
+    using K_F2 = std::integral_constant<int, 0>;
+    using K_ANY = std::integral_constant<int, 1>;
+    using K_F4 = std::integral_constant<int, 2>;
     // f.0 rows of chunk c (32 rows, both planes, G0 groups: G0 KiB) -> buffer c & 1 as [plane][group][32 rows][8]; piece j = groups
     // 2 j', 2 j' + 1 of plane j / (G0 / 2) (the two half-waves read one group each)
     auto w0_piece = [&](int c, int i) {
@@ -272,28 +311,9 @@ __global__ void __launch_bounds__(256) k_cnet1w(CnetArgs a, CnetGeo g) {
         // the window in rounds of NT slots; the stream's first fills are REQUESTED between the first round's loads and their use:
         // they need nothing, nobody needs them before the loop, and issued here their 21 pieces and their trip to L2 overlap the
         // window's own trip and its conversion instead of standing in front of f.0 of chunk 0
-        for (int e0 = 0; e0 < nslots; e0 += NT) {
-            const int e = min(e0 + tid, nslots - 1);
-            bool in; int ch;
-            const float* xin = slot_src(e, in, ch);
-            float v[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = xin[(long)min(ch * 8 + q, a.Cin - 1) * HW];
-            if (e0 == 0) {
-                C1_FENCE();
-                ring_begin(0, 0);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) ring_piece(0, i);
-#pragma unroll
-                for (int i = 0; i < NP0; ++i) w0_piece(1, i);
-                ring_begin(1, SLOT);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) ring_piece(1, i);
-                ring_begin(2, 2 * SLOT);
-                ring_piece(2, 0);
-                ring_piece(2, 1);
-                C1_FENCE();
-            }
+        // (two rounds per pass: a window of more than NT slots -- 16-pixel rows with two channel chunks, 128-pixel rows -- has both
+        // rounds' loads in flight together instead of one global round trip behind the other)
+        auto win_put = [&](int e, bool live, bool in, int ch, const float (&v)[8]) {
             h8 hi, lo;
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
@@ -302,10 +322,44 @@ __global__ void __launch_bounds__(256) k_cnet1w(CnetArgs a, CnetGeo g) {
                 sh2_split(vv, x0, x1);
                 hi[q] = x0; lo[q] = x1;
             }
-            if (e0 + tid < nslots) {
+            if (live) {
                 *reinterpret_cast<h8*>(win + (long)e * 8) = hi;
                 *reinterpret_cast<h8*>(win + g.winplane + (long)e * 8) = lo;
             }
+        };
+        for (int e0 = 0; e0 < nslots; e0 += 2 * NT) {
+            const bool two = e0 + NT < nslots;
+            const int eA = min(e0 + tid, nslots - 1), eB = min(e0 + NT + tid, nslots - 1);
+            bool inA, inB = false; int chA, chB = 0;
+            const float* xa = slot_src(eA, inA, chA);
+            float vA[8], vB[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) vA[q] = xa[(long)min(chA * 8 + q, a.Cin - 1) * HW];
+            if (two) {
+                const float* xb = slot_src(eB, inB, chB);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) vB[q] = xb[(long)min(chB * 8 + q, a.Cin - 1) * HW];
+            } else {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) vB[q] = 0.f;
+            }
+            if (e0 == 0) {
+                C1_FENCE();
+                ring_begin(0, 0, K_F2{});
+#pragma unroll
+                for (int i = 0; i < PPF; ++i) ring_piece(i, K_F2{});
+#pragma unroll
+                for (int i = 0; i < NP0; ++i) w0_piece(1, i);
+                ring_begin(1, SLOT, K_F2{});
+#pragma unroll
+                for (int i = 0; i < PPF; ++i) ring_piece(i, K_F2{});
+                ring_begin(2, 2 * SLOT, K_F2{});
+                ring_piece(0, K_F2{});
+                ring_piece(1, K_F2{});
+                C1_FENCE();
+            }
+            win_put(eA, e0 + tid < nslots, inA, chA, vA);
+            if (two) win_put(eB, e0 + NT + tid < nslots, inB, chB, vB);
         }
         // (signs: the activations travel NEGATED from the first epilogue on -- sh.h nrelu_bits, cnet_sh.hip)
 #pragma unroll
@@ -314,10 +368,10 @@ __global__ void __launch_bounds__(256) k_cnet1w(CnetArgs a, CnetGeo g) {
         for (int i = 0; i < N2; ++i) { t_rs2[tid + NT * i] = canon_nan(tv2[i]); t_b2[tid + NT * i] = canon_nan(-tvb[i]); }
         if (tid < MP4) t_rs4[tid] = canon_nan(-tv4);
     }
-    // f.0's rows of chunk 0 have landed: everything but the 18 + NP0 pieces of the fills requested behind them (in-order counter)
+    // f.0's rows of chunk 0 have landed: everything but the 2 PPF + 2 + NP0 pieces of the fills requested behind them (in-order counter)
     // (a plain barrier: __syncthreads() puts a vmcnt(0) in front of it -- it counts the LDS-DMA pieces as LDS writes to be fenced --
     // and would wait here for the 18 + NP0 pieces that have the whole of f.0 of chunk 0 to land)
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(18 + NP0) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * PPF + 2 + NP0) : "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     GH_STAMP(1);
@@ -340,8 +394,8 @@ __global__ void __launch_bounds__(256) k_cnet1w(CnetArgs a, CnetGeo g) {
     }
     const int wlo = g.winplane * 2;                        // bytes from the window's hi plane to its lo plane
     const int a0lane = W0B + lane * 16;                    // f.0 A fragment: + buffer * G0 KiB + (plane * G0 + 2 st) * 512
-    const int a2lane = (kl * HID + ml) * 16;               // f.2 A fragment: + slot + plane * SLOT / 2 + row tile * 512
-    const int a4lane = (kl * MP4 + ml) * 16;               // f.4 A fragment: + slot + plane * K4 MP4 32 + k-step * MP4 32 + row tile * 512
+    const int a2lane = RINGB + (kl * MR + ml) * 16;        // f.2 A fragment: + slot + plane * SLOT / 2 + row tile * 512
+    const int a4lane = RINGB + (kl * MP4 + ml) * 16;       // f.4 A fragment: + slot + plane * K4 MP4 32 + k-step * MP4 32 + row tile * 512
 
     auto ldA0 = [&](int buf, int st, h8& hi, h8& lo) {
         const char* p = lds1 + a0lane + buf * (G0 * 1024) + 2 * st * 512;
@@ -377,16 +431,21 @@ __global__ void __launch_bounds__(256) k_cnet1w(CnetArgs a, CnetGeo g) {
 
     // ---- f.0 of chunk 0 on its own (the only MFMAs of the kernel without f.2 or f.4 MFMAs around them)
     h8 Bh[2], Bl[2];           // B fragments of the chunk f.2 is multiplying: k-steps 2 c, 2 c + 1
+    // f.0's B fragments -- this wave's window pixels, (hi, lo) per k-step -- are the same for every chunk of h1 rows: they stay in
+    // registers for the whole kernel (8 NST0 of the 512; re-read per chunk they were a fifth of the LDS traffic of the f.2 loop,
+    // which runs within 20 - 30 % of the LDS bandwidth)
+    h8 B0H[NST0], B0L[NST0];
+#pragma unroll
+    for (int st = 0; st < NST0; ++st) ldB0(st, B0H[st], B0L[st]);
     {
         f32x16_t acc1;
 #pragma unroll
         for (int st = 0; st < NST0; ++st) {
-            h8 ah, al, bh, bl;
+            h8 ah, al;
             ldA0(0, st, ah, al);
-            ldB0(st, bh, bl);
-            if (st == 0) c1_mfma_v0(acc1, ah, bh); else c1_mfma_v(acc1, ah, bh);
-            c1_mfma_v(acc1, ah, bl);
-            c1_mfma_v(acc1, al, bh);
+            if (st == 0) c1_mfma_v0(acc1, ah, B0H[st]); else c1_mfma_v(acc1, ah, B0H[st]);
+            c1_mfma_v(acc1, ah, B0L[st]);
+            c1_mfma_v(acc1, al, B0H[st]);
         }
         c1_settle(acc1);
 #pragma unroll
@@ -397,9 +456,9 @@ __global__ void __launch_bounds__(256) k_cnet1w(CnetArgs a, CnetGeo g) {
     GH_STAMP(2);
 
     // ---- P2 with P1 of the next chunk inside: acc2[rt] += W2'[rows of tile rt, chunk c] h1[chunk c]
-    f32x16_t acc2[NCH];
+    f32x16_t acc2[NRT2];
 #pragma unroll
-    for (int i = 0; i < NCH; ++i)
+    for (int i = 0; i < NRT2; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc2[i][r] = 0.f;
 
@@ -419,11 +478,10 @@ __global__ void __launch_bounds__(256) k_cnet1w(CnetArgs a, CnetGeo g) {
     };
 #pragma unroll
     for (int i = 0; i < 4; ++i) { ldA2one(0, 0, i, 0, AH[i]); ldA2one(0, 0, i, 1, AL[i]); }
-    // f.0 operands, single-buffered as well: the three MFMAs of a k-step sit behind slots 3 (A0h, B0l), 7 (A0h, B0h) and 11 (A0l, B0h) of
-    // its quad, and each operand is reloaded for the next k-step right behind its last use
-    h8 A0h, A0l, B0h, B0l;
+    // f.0's A fragments, single-buffered as well: the three MFMAs of a k-step are (A0h, B0l), (A0h, B0h), (A0l, B0h), and each A fragment
+    // is reloaded for the next k-step right behind its last use
+    h8 A0h, A0l;
     ldA0(1, 0, A0h, A0l);
-    ldB0(0, B0h, B0l);
     // ---- the epilogue of a 32-row block (16 values per lane -> the B fragments of two k-steps), software-pipelined over 24 slots.
     // With one wave per SIMD a DEPENDENT VALU instruction waits out its producer's latency in the issue stream, and that wait comes
     // straight out of the next MFMA's time (five dependent instructions per pair of values, as one piece behind one MFMA, cost 6 k of
@@ -511,24 +569,38 @@ __global__ void __launch_bounds__(256) k_cnet1w(CnetArgs a, CnetGeo g) {
         }
     };
 
-#pragma unroll 1
-    for (int c = 0; c < NCH; ++c) {
+    // (kind: K_F2 for the chunks whose fills are all f.2's -- all but the last two -- else K_ANY)
+    auto p2_chunk = [&](int c, auto kind) {
         const int cn = min(c + 1, NCH - 1);        // chunk whose f.0 rides along (the last iteration repeats chunk NCH - 1 for nothing)
         const int nbuf = cn & 1;
         f32x16_t acc1;
         h8 Bnh[2], Bnl[2];
+        // f.0's MFMA j of chunk cn and the operand reloads behind it
+        auto f0_mfma = [&](int j) {
+            const int st = j / 3, w = j % 3;
+            const char* pa = lds1 + a0lane + nbuf * (G0 * 1024) + 2 * (st + 1) * 512;
+            if (w == 0) {
+                if (st == 0) c1_mfma_v0(acc1, A0h, B0L[st]); else c1_mfma_v(acc1, A0h, B0L[st]);
+            } else if (w == 1) {
+                c1_mfma_v(acc1, A0h, B0H[st]);
+                if (st + 1 < NST0) A0h = *reinterpret_cast<const h8*>(pa);
+            } else {
+                c1_mfma_v(acc1, A0l, B0H[st]);
+                if (st + 1 < NST0) A0l = *reinterpret_cast<const h8*>(pa + G0 * 512);
+            }
+        };
 #pragma unroll
-        for (int Q = 0; Q < 8; ++Q) {
-            const int s = Q >> 2, q4 = Q & 3;
+        for (int Q = 0; Q < 2 * NQ; ++Q) {
+            const int s = Q / NQ, q4 = Q % NQ;
+            const bool lastq = q4 == NQ - 1;        // the k-step's last quad: the TOP sits in front of its fourth slot
             const int f = 2 * c + s;                // k-step
-            static_assert(NST0 <= 5, "f.0 k-step st rides in quad st; its epilogue in quads 5 and 6");
             C1_FENCE();
-            const int ff = q4 == 3 ? f + 3 : f + 2, i0 = q4 == 3 ? 0 : 2 + 2 * q4;      // the fill in progress, this quad's two pieces
-            const int st = Q;                       // f.0 k-step of this quad (Q < NST0)
-            const int nq4 = (q4 + 1) & 3;           // the next quad (after a TOP: the next k-step's first quad, from the slot that has just landed)
+            const int i0 = lastq ? 0 : 2 + 2 * q4;      // this quad's two pieces of the fill in progress (f + 3 behind the TOP, else f + 2)
+            const int nq4 = (q4 + 1) % NQ;          // the next quad (after a TOP: the next k-step's first quad, from the slot that has just landed)
 #pragma unroll
             for (int k = 0; k < 12; ++k) {
-                if (q4 == 3 && k == 3) {
+                const int sl = 12 * Q + k;          // slot of the chunk
+                if (lastq && k == 3) {
                     // TOP: fill f + 1 has landed (this wave's pieces: counted wait; everybody's: barrier) and every wave has read all
                     // it wanted from slot s_cur (lgkmcnt(0) before the barrier) -- which fill f + 3 may then overwrite.  It sits in
                     // front of the quad's FOURTH slot: the last reads of the slot were issued in the previous quad, three MFMAs and
@@ -537,8 +609,8 @@ __global__ void __launch_bounds__(256) k_cnet1w(CnetArgs a, CnetGeo g) {
 #ifndef C1_DBG_NO_VMWAIT
                     // (TAPE: + the stores issued behind the last piece of the fill waited for -- 6 of the previous chunk's 9 at s = 0,
                     // all 9 of this chunk's at s = 1; one less each: a smaller count only waits for more)
-                    if (s == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(8 + NP0 + (TST ? 5 : 0)) : "memory");
-                    else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(8 + (TST ? 8 : 0)) : "memory");
+                    if (s == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PPF + NP0 + (TST ? 5 : 0)) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PPF + (TST ? 8 : 0)) : "memory");
 #endif
 #ifndef C1_DBG_NO_BARRIER
                     __builtin_amdgcn_s_barrier();
@@ -546,7 +618,7 @@ __global__ void __launch_bounds__(256) k_cnet1w(CnetArgs a, CnetGeo g) {
                     asm volatile("" ::: "memory");
                     s_fill = s_cur;
                     s_cur = s_cur + SLOT == 3 * SLOT ? 0 : s_cur + SLOT;
-                    ring_begin(f + 3, s_fill);
+                    ring_begin(f + 3, s_fill, kind);
                     C1_FENCE();
                 }
                 const int i = k & 3, sw = k >> 2;
@@ -555,46 +627,28 @@ __global__ void __launch_bounds__(256) k_cnet1w(CnetArgs a, CnetGeo g) {
                 if (sw == 1) ldA2one(s_cur, nq4, i, 0, AH[i]);
                 if (sw == 2) ldA2one(s_cur, nq4, i, 1, AL[i]);
 #endif
-                // the stream: two ring pieces per quad; f.0 rows of chunk c + 2 in the first three quads of the chunk
+                // the stream: two ring pieces per quad; f.0 rows of chunk c + 2 in the quads of the chunk's first k-step but its last
 #ifndef C1_DBG_NO_DMA
-                if (k == (q4 == 3 ? 3 : 0)) ring_piece(ff, i0);
-                if (k == (q4 == 3 ? 9 : 2)) ring_piece(ff, i0 + 1);
-                if (k == 1 && s == 0 && q4 < 3) {
-#pragma unroll
-                    for (int i3 = q4; i3 < NP0; i3 += 3) w0_piece(min(c + 2, NCH - 1), i3);
-                }
+                if (k == (lastq ? 3 : 0)) ring_piece(i0, kind);
+                if (k == (lastq ? 9 : 2)) ring_piece(i0 + 1, kind);
+                if (s == 0 && !lastq && (k & 1) && q4 + (k >> 1) * (NQ - 1) < NP0) w0_piece(min(c + 2, NCH - 1), q4 + (k >> 1) * (NQ - 1));
 #endif
-                // f.0 of chunk cn: k-step st in quad st; in quad 7 the first operands of the chunk after (its rows landed with this quad's TOP)
+                // f.0 of chunk cn (c1_f0slot); in the chunk's last quad the first operands of the chunk after (its rows landed with
+                // that quad's TOP)
 #ifndef C1_DBG_NO_P1
-                if (Q < NST0) {
-                    const char* pa = lds1 + a0lane + nbuf * (G0 * 1024) + 2 * (st + 1) * 512;
-                    const char* pb = lds1 + woff[st + 1 < NST0 ? st + 1 : 0];
-                    if (k == 3) {
-                        if (st == 0) c1_mfma_v0(acc1, A0h, B0l); else c1_mfma_v(acc1, A0h, B0l);
-                        if (st + 1 < NST0) B0l = *reinterpret_cast<const h8*>(pb + wlo);
-                    }
-                    if (k == 7) {
-                        c1_mfma_v(acc1, A0h, B0h);
-                        if (st + 1 < NST0) A0h = *reinterpret_cast<const h8*>(pa);
-                    }
-                    if (k == 11) {
-                        c1_mfma_v(acc1, A0l, B0h);
-                        if (st + 1 < NST0) { B0h = *reinterpret_cast<const h8*>(pb); A0l = *reinterpret_cast<const h8*>(pa + G0 * 512); }
-                    }
-                }
-                if (Q == 7 && k >= 8) {
+#pragma unroll
+                for (int j = 0; j < NF0; ++j)
+                    if (c1_f0slot(NQ, j) == sl) f0_mfma(j);
+                if (Q == 2 * NQ - 1 && k >= 8) {
                     const char* pa = lds1 + a0lane + (min(c + 2, NCH - 1) & 1) * (G0 * 1024);
-                    const char* pb = lds1 + woff[0];
-                    if (k == 8) B0l = *reinterpret_cast<const h8*>(pb + wlo);
                     if (k == 9) A0h = *reinterpret_cast<const h8*>(pa);
-                    if (k == 10) B0h = *reinterpret_cast<const h8*>(pb);
                     if (k == 11) A0l = *reinterpret_cast<const h8*>(pa + G0 * 512);
                 }
-                // its epilogue: the 24 slots of quads 5 and 6
-                if (Q == 5 || Q == 6) {
+                // its epilogue: 24 slots from EP0 on
+                if (sl >= EP0 && sl < EP0 + 24) {
 #ifndef C1_DBG_NO_EPI
-                    if (Q == 5 && k == 0) c1_settle(acc1);
-                    epi_tick(acc1, t_rs0, t_b0, cn, (Q - 5) * 12 + k, Bnh, Bnl, std::false_type{}, tb1, mb1);
+                    if (sl == EP0) c1_settle(acc1);
+                    epi_tick(acc1, t_rs0, t_b0, cn, sl - EP0, Bnh, Bnl, std::false_type{}, tb1, mb1);
 #endif
                 }
 #endif
@@ -605,67 +659,93 @@ __global__ void __launch_bounds__(256) k_cnet1w(CnetArgs a, CnetGeo g) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) { Bh[s] = Bnh[s]; Bl[s] = Bnl[s]; }
 #endif
-    }
+    };
+    static_assert(2 * (NCH - 3) + 1 + 3 < NKS, "the fills of the chunks before the last two are f.2's");
+#pragma unroll 1
+    for (int c = 0; c < NCH - 2; ++c) p2_chunk(c, K_F2{});
+#pragma unroll 1
+    for (int c = NCH - 2; c < NCH; ++c) p2_chunk(c, K_ANY{});
     GH_STAMP(3);
 
     // ---- P3: T[m][px] += W4t[m][k] h2[k][px] with h2 = relu + split of the accumulator block k / 32, two k-steps per block.
     // (slot bookkeeping continues: the last TOP of the loop above made fill NKS = the first of the f.4 image readable in s_cur)
-    f32x16_t accT[NRT4];       // in VGPRs like f.0's block (asm MFMAs): h2 holds every AGPR until its last block has been consumed
-    h8 Hh[2][2], Hl[2][2];      // [chunk & 1][k-step of the chunk]
+    // MS = 1: T in VGPRs like f.0's block (asm MFMAs): h2 holds every AGPR until its last block has been consumed.  MS = 2: h2 is half
+    // as large and T (seven row tiles) takes the other AGPRs through the builtin.
+    constexpr bool T_ASM = NRT2 * 16 + NRT4 * 16 > 256;
+    f32x16_t accT[NRT4];
+    h8 Hh[2][2], Hl[2][2];      // [block & 1][k-step of the block]
+    const float* trs2 = t_rs2 + ms_row0;
+    const float* tbb2 = t_b2 + ms_row0;
 #pragma unroll
-    for (int e = 0; e < 24; ++e) epi_tick(acc2[0], t_rs2, t_b2, 0, e, Hh[0], Hl[0], std::true_type{}, tb2, mb2);
-    static_assert(NRT4 == 4, "the slot plan of f.4 (12 MFMAs per k-step, fragments reloaded behind their last use) is laid out for four row tiles");
+    for (int e = 0; e < 24; ++e) epi_tick(acc2[0], trs2, tbb2, 0, e, Hh[0], Hl[0], std::true_type{}, tb2, mb2);
     h8 A4H[NRT4], A4L[NRT4];
     auto ldA4one = [&](int slot_off, int kk, int i, int pl, h8& dst) {
         dst = *reinterpret_cast<const h8*>(lds1 + a4lane + slot_off + kk * (MP4 * 32) + i * 512 + pl * (K4 * MP4 * 32));
     };
 #pragma unroll
     for (int i = 0; i < NRT4; ++i) { ldA4one(s_cur, 0, i, 0, A4H[i]); ldA4one(s_cur, 0, i, 1, A4L[i]); }
+    if constexpr (!T_ASM) {
 #pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) {
+        for (int i = 0; i < NRT4; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accT[i][r] = 0.f;
+    }
+#pragma unroll
+    for (int ks = 0; ks < NKS4; ++ks) {
         const int c = ks >> 1, s = ks & 1;
         const int F = NKS + ks / K4, kk = ks % K4;        // fill being read, k-step inside it
         C1_FENCE();
-        // pieces of the fill in progress: two with the TOP, the other six over the first K4 - 1 k-steps of a fill
+        // pieces of the fill in progress: two of fill F + 3 behind the TOP (in the fill's last k-step: its last slots), the others of fill
+        // F + 2 over the last slots of its first K4 - 1 k-steps -- or, with one k-step per fill, in slots 0 and 2 in front of the TOP
+        constexpr int PA = 2;
+        static_assert(K4 > 1 || PPW4 - PA <= 2, "one k-step per fill: its other pieces in slots 0 and 2");
         const int ff = kk == K4 - 1 ? F + 3 : F + 2;
-        constexpr int PER = K4 > 1 ? (6 + K4 - 2) / (K4 - 1) : 6;
-        const int i0 = kk == K4 - 1 ? 0 : 2 + kk * PER, i1 = kk == K4 - 1 ? 2 : min(8, 2 + (kk + 1) * PER);
-        const int cn = min(c + 1, NCH - 1);
+        constexpr int PER = K4 > 1 ? (PPW4 - PA + K4 - 2) / (K4 - 1) : 0;
+        const int i0 = kk == K4 - 1 ? 0 : PA + kk * PER, i1 = kk == K4 - 1 ? PA : min(PPW4, PA + (kk + 1) * PER);
+        const int cn = min(c + 1, NRT2 - 1);
         constexpr int NM = 3 * NRT4;
+        static_assert(2 * NM >= 24 && NM - PPW4 > 3, "the next block's epilogue inside a block's two k-steps; the pieces behind the TOP");
 #pragma unroll
         for (int k = 0; k < NM; ++k) {
             if (kk == K4 - 1 && F + 1 <= FL && k == 3) {      // TOP (as in the loop above: in front of the k-step's fourth slot)
                 // (TAPE: 19 stores are issued between the last piece of fill F + 1 -- at the end of fill F - 1's third k-step -- and here)
-                if (F + 2 <= FL) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(8 + (TST ? 16 : 0)) : "memory");
+                if (F + 2 <= FL) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PPW4 + (TST ? 16 : 0)) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
                 s_fill = s_cur;
                 s_cur = s_cur + SLOT == 3 * SLOT ? 0 : s_cur + SLOT;
-                if (F + 3 <= FL) ring_begin(F + 3, s_fill);
+                if (F + 3 <= FL) ring_begin(F + 3, s_fill, K_F4{});
                 C1_FENCE();
             }
+            if (K4 == 1 && F + 2 <= FL && k < 3 && !(k & 1) && PA + k / 2 < PPW4) ring_piece(PA + k / 2, K_F4{});
             const int i = k % NRT4, sw = k / NRT4;
-            if (ks == 0 && sw == 0) c1_mfma_v0(accT[i], A4H[i], Hh[0][0]);
-            else c1_mfma_v(accT[i], sw == 2 ? A4L[i] : A4H[i], sw == 1 ? Hl[c & 1][s] : Hh[c & 1][s]);
-            if (ks + 1 < NKS && sw == 1) ldA4one(s_cur, (kk + 1) % K4, i, 0, A4H[i]);
-            if (ks + 1 < NKS && sw == 2) ldA4one(s_cur, (kk + 1) % K4, i, 1, A4L[i]);
-            // h2 of the next block: its epilogue over the 24 slots of this block's two k-steps
-            if (c + 1 < NCH) epi_tick(acc2[cn], t_rs2, t_b2, cn, 12 * s + k, Hh[cn & 1], Hl[cn & 1], std::true_type{}, tb2, mb2);
-            if (ff <= FL && k >= NM - (i1 - i0)) ring_piece(ff, i0 + k - (NM - (i1 - i0)));
+            if constexpr (T_ASM) {
+                if (ks == 0 && sw == 0) c1_mfma_v0(accT[i], A4H[i], Hh[0][0]);
+                else c1_mfma_v(accT[i], sw == 2 ? A4L[i] : A4H[i], sw == 1 ? Hl[c & 1][s] : Hh[c & 1][s]);
+            } else {
+                accT[i] = C1_MFMA(sw == 2 ? A4L[i] : A4H[i], sw == 1 ? Hl[c & 1][s] : Hh[c & 1][s], accT[i]);
+            }
+            if (ks + 1 < NKS4 && sw == 1) ldA4one(s_cur, (kk + 1) % K4, i, 0, A4H[i]);
+            if (ks + 1 < NKS4 && sw == 2) ldA4one(s_cur, (kk + 1) % K4, i, 1, A4L[i]);
+            // h2 of the next block: its epilogue over the first 24 slots of this block's two k-steps
+            if (c + 1 < NRT2 && s * NM + k < 24) epi_tick(acc2[cn], trs2, tbb2, cn, s * NM + k, Hh[cn & 1], Hl[cn & 1], std::true_type{}, tb2, mb2);
+            if (ff <= FL && k >= NM - (i1 - i0)) ring_piece(i0 + k - (NM - (i1 - i0)), K_F4{});
             C1_FENCE();
         }
     }
     GH_STAMP(4);
+    if constexpr (T_ASM) {
 #pragma unroll
-    for (int i = 0; i < NRT4; ++i) c1_settle(accT[i]);
+        for (int i = 0; i < NRT4; ++i) c1_settle(accT[i]);
+    }
     __syncthreads();           // every wave is done with the ring: it becomes the staging area of T
 
     // ---- P4: T -> LDS as fp32, PIXEL-major [pixel][RP rows] (row scale applied), then the 9-tap sums.  A lane's four consecutive
     // rows of a pixel are one 16-byte store, and a thread of the tap sums takes one pixel and FOUR output channels: row m = tap * Cout
     // + co puts them side by side, one 16-byte read per tap -- a quarter of the LDS instructions of the [row][pixel] form in both
     // halves of the phase.  RP / 4 is odd: the 16-byte groups of consecutive pixels fall on distinct banks.
-    float* T = reinterpret_cast<float*>(lds1);
+    float* T = reinterpret_cast<float*>(lds1 + TABS);       // (behind the tables: t_rs4 is read while T is written)
     const int Cout = g.Cg;                      // (a multiple of 4: cnet1w_takes)
     const int rows = 9 * Cout;
     const int RP = 4 * ((rows >> 2) | 1);
@@ -685,9 +765,12 @@ __global__ void __launch_bounds__(256) k_cnet1w(CnetArgs a, CnetGeo g) {
     }
     __syncthreads();
     GH_STAMP(5);
+    // (MS = 2: each half leaves its own copy of the sums, k_cnet's layout -- the finishing kernel adds them in a fixed order)
+    const long msN = MS > 1 ? (long)blockIdx.y * a.N : 0;
+    const long mstile = MS > 1 ? (long)blockIdx.y * g.tiles : 0;
     float* hpart = a.scratch;
-    float* hup = a.scratch + (long)a.N * a.Cout * HW;
-    float* hdn = hup + (long)g.tiles * a.Cout * W;
+    float* hup = a.scratch + (long)MS * a.N * a.Cout * HW;
+    float* hdn = hup + (long)MS * g.tiles * a.Cout * W;
     const int ngrp = Cout >> 2;
     {
         // a thread keeps ITS pixel (tid & 127) and walks the groups of four channels tid >> 7, + 2, ...
@@ -706,7 +789,7 @@ __global__ void __launch_bounds__(256) k_cnet1w(CnetArgs a, CnetGeo g) {
                 off[tap] = (q + (ok[tap] ? (dy - 1) * W + (dx - 1) : 0)) * RP + tap * Cout;
             }
         if (n < a.N) {
-            float* hp = hpart + (n * a.Cout) * HW + (long)(y0 + r) * W + x;
+            float* hp = hpart + ((msN + n) * a.Cout) * HW + (long)(y0 + r) * W + x;
             for (int cg = tid >> LPXT; cg < ngrp; cg += NT >> LPXT) {
                 const float* tp = T + 4 * cg;
                 f32x4_t v[9];
@@ -742,7 +825,7 @@ __global__ void __launch_bounds__(256) k_cnet1w(CnetArgs a, CnetGeo g) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float sacc = (ok[0] ? v[0][j] : 0.f) + (ok[1] ? v[1][j] : 0.f) + (ok[2] ? v[2][j] : 0.f);
-                (dn ? hdn : hup)[((long)tb * a.Cout + 4 * cg + j) * W + x] = sacc;
+                (dn ? hdn : hup)[((mstile + tb) * a.Cout + 4 * cg + j) * W + x] = sacc;
             }
         }
     }
@@ -751,31 +834,35 @@ __global__ void __launch_bounds__(256) k_cnet1w(CnetArgs a, CnetGeo g) {
 }
 
 // ------------------------------------------------------------------------------------------------ host side
-static size_t cnet1w_lds_bytes(const CnetGeo& g, int hidden) {
-    return (size_t)3 * hidden * 64 + (size_t)2 * g.G * 1024 + (size_t)2 * g.winplane * sizeof(_Float16) + ((size_t)4 * hidden + g.Mpad4) * sizeof(float);
+static size_t cnet1w_lds_bytes(const CnetGeo& g, int hidden, int ms) {
+    const size_t tabs = (((size_t)4 * hidden + g.Mpad4) * sizeof(float) + 1023) / 1024 * 1024;
+    const size_t work = (size_t)3 * (hidden / ms) * 64 + (size_t)2 * g.G * 1024 + (size_t)2 * g.winplane * sizeof(_Float16);
+    const size_t stage = (size_t)4 * (((size_t)9 * g.Cg >> 2) | 1) * 128 * sizeof(float);      // T, pixel-major
+    return tabs + std::max(work, stage);
 }
 
-static int cnet1w_instance(const CnetArgs& a, const CnetGeo& g) {      // 0: none
+// instances: 1 = product, 2 = taping (both: C = 12 levels, the workgroup owns all 512 h2 rows), 3 = product with the h2 rows split
+// over two workgroups (C = 24 levels)
+static int cnet1w_instance(const CnetArgs& a, const CnetGeo& g, int ms) {      // 0: none
     if (a.hidden != 512 || g.ng != 1 || g.pxt != 128) return 0;
-    if (g.G == 10 && g.NRT4 == 4) return a.tape_h1 ? 2 : 1;
+    if (ms == 1 && g.G == 10 && g.NRT4 == 4) return a.tape_h1 ? 2 : 1;
+    if (ms == 2 && g.G == 18 && g.NRT4 == 7 && !a.tape_h1) return 3;
     return 0;
 }
 
-bool cnet1w_takes(const CnetArgs& a, const CnetGeo& g) {
+bool cnet1w_takes(const CnetArgs& a, const CnetGeo& g, int ms) {
     if (a.pre_on || a.bwd) return false;
     if (a.tape_h1 && (!a.tape_h2 || !a.mask1 || !a.mask2 || g.HW % 128 != 0)) return false;      // taping: whole 32-pixel tiles of the batch per wave
     if (g.NI != 1) return false;                     // (tiles of whole small images stay on k_cnet: no level that large has them)
-    if (!cnet1w_instance(a, g)) return false;
-    if (cnet1w_lds_bytes(g, a.hidden) > 160 * 1024) return false;
+    if (!cnet1w_instance(a, g, ms)) return false;
+    if (cnet1w_lds_bytes(g, a.hidden, ms) > 160 * 1024) return false;
     if (g.Cg % 4 != 0) return false;                 // the tap sums take four output channels per 16-byte read
-    const size_t rp = 4 * (((size_t)9 * g.Cg >> 2) | 1);
-    if (rp * 128 * sizeof(float) > (size_t)3 * a.hidden * 64 + (size_t)2 * g.G * 1024) return false;      // T staging in front of the window
     return true;
 }
 
-int launch_cnet1w(const CnetArgs& a, const CnetGeo& g, hipStream_t s) {
-    const size_t lds = cnet1w_lds_bytes(g, a.hidden);
-    switch (cnet1w_instance(a, g)) {
+int launch_cnet1w(const CnetArgs& a, const CnetGeo& g, int ms, hipStream_t s) {
+    const size_t lds = cnet1w_lds_bytes(g, a.hidden, ms);
+    switch (cnet1w_instance(a, g, ms)) {
     case 1:
         (void)hipFuncSetAttribute((const void*)k_cnet1w<512, 10, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((k_cnet1w<512, 10, 4>), dim3(g.tiles), dim3(256), lds, s, a, g);
@@ -783,6 +870,10 @@ int launch_cnet1w(const CnetArgs& a, const CnetGeo& g, hipStream_t s) {
     case 2:
         (void)hipFuncSetAttribute((const void*)k_cnet1w<512, 10, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((k_cnet1w<512, 10, 4, true>), dim3(g.tiles), dim3(256), lds, s, a, g);
+        break;
+    case 3:
+        (void)hipFuncSetAttribute((const void*)k_cnet1w<512, 18, 7, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((k_cnet1w<512, 18, 7, false, 2>), dim3(g.tiles, 2), dim3(256), lds, s, a, g);
         break;
     default:
         set_error("cnet1w: no kernel instance");

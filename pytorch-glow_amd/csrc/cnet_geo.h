@@ -28,9 +28,9 @@ __host__ __device__ inline int cnet_trow(int M9) {   // T row stride (floats): m
 // geometry of a launch with pxt-pixel tiles (false: the shape has none); N = 0: shape check only
 bool cnet_geo(int Cin, int H, int W, int hidden, int Cout, int N, int pxt, CnetGeo* out);
 
-// ---- k_cnet1w (cnet1w_sh.hip): may this launch run on it, and the launch itself (same partial-sum layout as k_cnet at MS = 1,
-// 128-pixel tiles: the finishing kernel does not know the difference)
-bool cnet1w_takes(const CnetArgs& a, const CnetGeo& g128);
-int launch_cnet1w(const CnetArgs& a, const CnetGeo& g, hipStream_t s);
+// ---- k_cnet1w (cnet1w_sh.hip): may this launch run on it with the h2 rows split over ms workgroups per tile, and the launch itself
+// (same partial-sum layout as k_cnet with that row split and 128-pixel tiles: the finishing kernel does not know the difference)
+bool cnet1w_takes(const CnetArgs& a, const CnetGeo& g128, int ms);
+int launch_cnet1w(const CnetArgs& a, const CnetGeo& g, int ms, hipStream_t s);
 
 }  // namespace glowhip

@@ -110,6 +110,27 @@ def test_level1_runs_on_the_one_wave_per_simd_kernel_and_both_kernels_match_the_
         assert counts.get("variant:k_cnet<512,1,128>") == K and "variant:k_cnet1w<512,1,128>" not in counts, counts
 
 
+def test_row_split_instance_of_the_one_wave_kernel_matches_the_oracle():
+    """Round 5: k_cnet1w with the h2 rows of a 128-pixel tile split over TWO workgroups (each computes all of h1, half of f.2, a
+    K-half of f.4; partial sums in k_cnet's MS = 2 layout for the finishing kernel) -- built for the C = 24 levels whose 128-pixel
+    tiles alone fill half the CUs (config B's level 2 at batch 64: 128 tiles).  Measured 3 % slower there than k_cnet's 64-pixel
+    tiles, so it sits behind the debug switch 0x20000; this test is its parity evidence: forward and inverse at config-B geometry,
+    every element against the oracle (inside _case), the instance asserted from the run-time counters; without the switch the same
+    launches run on k_cnet<512,1,64>."""
+    K = 2
+    G.lib().glowhip_debug_force_tail_tile(0x20000)
+    try:
+        plan, fwd, rev = _case(64, 3, K, 512, 64, seed=14)
+    finally:
+        G.lib().glowhip_debug_force_tail_tile(0)
+    for counts in (fwd, rev):
+        assert counts.get("variant:k_cnet1w<512,1,128>") == K and counts.get("variant:k_cnet1w<512,2,128>") == K, counts
+        assert counts.get("variant:k_cnet<512,4,64>") == K and ncnet(counts) == 3 * K and nfinish(counts) == 3 * K, counts
+    plan2, fwd2, rev2 = _case(64, 3, K, 512, 64, seed=14)
+    for counts in (fwd2, rev2):
+        assert counts.get("variant:k_cnet<512,1,64>") == K and "variant:k_cnet1w<512,2,128>" not in counts, counts
+
+
 def test_one_wave_kernel_at_a_16_pixel_wide_level():
     """k_cnet1w outside the BASELINE shapes: a 32x32 input, L = 1 -- C = 12 on 16x16 pixels, a 128-pixel tile is eight image rows
     (the configs run it at 32, 64 and 128 pixels per row) -- at batch 112 = 224 tiles, the smallest launch it takes; forward and
