@@ -81,7 +81,10 @@ __device__ __forceinline__ void c1_frag(const f32x4_t& v, h8& bh, h8& bl, int ha
 // f.0's MFMA j (k-step j / 3, product j % 3) of the chunk riding along: its slot among the chunk's 24 NQ f.2 slots.  Four quads per
 // k-step (MS = 1): k-step st in quad st, behind slots 3, 7, 11.  Two (MS = 2): one per slot from slot 0 on -- 27 of them (G0 = 18)
 // in the 24 slots of the chunk's first k-step, every ninth doubled up -- so that the epilogue has the second k-step's 24 slots.
-__host__ __device__ constexpr int c1_f0slot(int nq, int j) { return nq == 4 ? 12 * (j / 3) + 3 + 4 * (j % 3) : j - (j + 1) / 9; }
+// (MS = 1 with more than five k-steps of f.0 -- the backward launch's first layer has C = 12 inputs, nine k-steps: every other slot.)
+__host__ __device__ constexpr int c1_f0slot(int nq, int nst0, int j) {
+    return nq == 4 ? (nst0 <= 5 ? 12 * (j / 3) + 3 + 4 * (j % 3) : 2 * j + 1) : j - (j + 1) / 9;
+}
 
 // TAPE (the training forward, plan_train.hip): h1 and h2 also go to memory as fp16 [pixel / 32][row][pixel % 32] and their signs as
 // 16-bit words -- the formats k_cnet MODE 1 writes and the backward k_cnet / the weight-gradient GEMMs read (cnet_sh.hip).  A lane
@@ -89,8 +92,14 @@ __host__ __device__ constexpr int c1_f0slot(int nq, int j) { return nq == 4 ? 12
 // TWO pixels (even lanes the even row, odd lanes the odd one): one 4-byte store per pair of values instead of two 2-byte ones.
 // The stores ride in the epilogue pipeline (five more stages); they count in vmcnt like the stream's pieces, in order, so the
 // counted waits of the stream allow for the stores issued behind the piece they wait for.
-template <int HID, int G0, int NRT4, bool TAPE = false, int MS = 1>
+// BWD (MODE 2; the input-gradient chain of the same network, cnet_sh.hip MODE 2: x = d L / d(f.4 output), the images are those of the
+// transposed weights): the "activation" of the first two layers is g_u = g_h * (h > 0) -- the ReLU masks READ from the tape's sign
+// words, one 16-bit word per lane and block, requested a block ahead -- and g_u2 / g_u0 go to memory as fp32 [pixel / 32][row][pixel % 32]
+// for the weight-gradient GEMMs: a lane's value of a row is 4 bytes of that row's 128-byte line, so a wave's store of one register
+// writes two full lines (no exchange between lanes), 16 stores per block.
+template <int HID, int G0, int NRT4, int MODE = 0, int MS = 1>
 __global__ void __launch_bounds__(256) k_cnet1w(CnetArgs a, CnetGeo g) {
+    constexpr bool TAPE = MODE == 1, BWD = MODE == 2;
     constexpr int NT = 256, LPXT = 7;
     constexpr int NCH = HID / 32;             // 32-channel chunks of the hidden width = row tiles of h1
     constexpr int NKS = HID / 16;             // k-steps of f.2
@@ -103,17 +112,17 @@ __global__ void __launch_bounds__(256) k_cnet1w(CnetArgs a, CnetGeo g) {
     constexpr int NST0 = G0 / 2;              // k-steps of f.0
     constexpr int NP0 = (G0 + 3) / 4;         // DMA pieces per wave of a chunk's f.0 rows (G0 KiB)
     constexpr int MP4 = NRT4 * 32;            // rows of the taps-as-rows f.4 image
-    constexpr int K4 = SLOT / (MP4 * 64) >= 4 ? 4 : (SLOT / (MP4 * 64) >= 2 ? 2 : 1);      // k-steps of the f.4 image per ring slot
+    constexpr int K4 = SLOT / (MP4 * 64) >= 8 ? 8 : (SLOT / (MP4 * 64) >= 4 ? 4 : (SLOT / (MP4 * 64) >= 2 ? 2 : 1));      // k-steps of the f.4 image per ring slot
     constexpr int NF4 = NKS4 / K4;            // fills of the f.4 image
     constexpr int PP4 = K4 * NRT4;            // 1-KiB pieces per plane of such a fill
     constexpr int PPW4 = (2 * PP4 + 3) / 4;   // ... per wave (both planes over four waves; a surplus piece repeats the last)
     constexpr bool RUN4 = PP4 % 2 == 0;       // a wave's pieces of an f.4 fill are one run of one plane (else: placed piece by piece)
     static_assert(PPW4 == PPF && NF4 >= 3 && NCH % 2 == 0 && NQ >= 2 && NKS4 % K4 == 0, "ring bookkeeping");
-    static_assert(!TAPE || MS == 1, "taping: every workgroup would store its share of h1 (a run-time count of stores in the counted waits)");
+    static_assert(MODE == 0 || MS == 1, "taping / backward: every workgroup would store its share of h1 (a run-time count of stores in the counted waits)");
     constexpr int FL = NKS + NF4 - 1;         // last fill of the stream: fills 0 .. NKS - 1 = f.2 k-steps, NKS .. FL = f.4 fills
     constexpr int NF0 = 3 * NST0;             // MFMAs of f.0 per chunk
     constexpr int EP0 = NQ == 4 ? 60 : 24;    // first of the 24 slots of f.0's epilogue among the chunk's 24 NQ
-    static_assert(c1_f0slot(NQ, NF0 - 1) < EP0 && EP0 + 24 <= 24 * NQ, "f.0 and its epilogue inside the chunk");
+    static_assert(c1_f0slot(NQ, NST0, NF0 - 1) < EP0 && EP0 + 24 <= 24 * NQ, "f.0 and its epilogue inside the chunk");
     // byte offsets of the LDS regions: tables | ring | f.0 double buffer | window.  (T, staged at the end, starts behind the tables.)
     constexpr int TABS = ((4 * HID + MP4) * 4 + 1023) / 1024 * 1024;
     constexpr int RINGB = TABS;
@@ -147,12 +156,15 @@ __global__ void __launch_bounds__(256) k_cnet1w(CnetArgs a, CnetGeo g) {
     [[maybe_unused]] const unsigned psel = (lane & 1) ? 0x03020706u : 0x05040100u;
     [[maybe_unused]] const long mstride = (long)a.N * HW * 2;      // sign words from one 32-row tile to the next
     [[maybe_unused]] const float nscale = -a.out_scale;
-    if constexpr (TAPE) {
+    [[maybe_unused]] const unsigned blane = kl * 512 + ml * 4;      // BWD: the lane's 4 bytes in the 128-byte line of row 4 kl (+ row * 128)
+    if constexpr (MODE != 0) {
         const long tile32 = (gp0 >> 5) + wid;
-        tb1 = reinterpret_cast<char*>(a.tape_h1) + tile32 * (HID * 64);
-        tb2 = reinterpret_cast<char*>(a.tape_h2) + tile32 * (HID * 64);
-        mb1 = a.mask1 + (gp0 + wid * 32) * 2;
-        mb2 = a.mask2 + (gp0 + wid * 32) * 2;
+        tb1 = reinterpret_cast<char*>(a.tape_h1) + tile32 * (HID * (BWD ? 128 : 64));
+        tb2 = reinterpret_cast<char*>(a.tape_h2) + tile32 * (HID * (BWD ? 128 : 64));
+        // (the sign words of the FIRST hidden layer this launch computes: written in TAPE -- h1's; read in BWD -- h2's, whose
+        // gradient the transposed network's first layer produces)
+        mb1 = (BWD ? a.mask2 : a.mask1) + (gp0 + wid * 32) * 2;
+        mb2 = (BWD ? a.mask1 : a.mask2) + (gp0 + wid * 32) * 2;
     }
     // (values v0, v1 = the NEGATED, scaled activations of rows r, r + 1 of this lane's pixel)
     [[maybe_unused]] auto tape_half = [&](unsigned x) -> unsigned {      // packed hi halves (of -16 h) -> packed fp16 h
@@ -166,10 +178,20 @@ __global__ void __launch_bounds__(256) k_cnet1w(CnetArgs a, CnetGeo g) {
     [[maybe_unused]] auto tape_nbr = [&](unsigned tx) -> unsigned { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)tx, 0xB1, 0xF, 0xF, true); };      // quad_perm [1, 0, 3, 2]
     [[maybe_unused]] auto tape_sel = [&](unsigned nb, unsigned tx) -> unsigned { return __builtin_amdgcn_perm(nb, tx, psel); };
 #ifdef C1_DBG_TAPE_NOSTORE
-    constexpr bool TST = false;           // (timing experiments only: the tape's arithmetic without its stores)
+    constexpr bool TST = false, BST = false;           // (timing experiments only: the tape's arithmetic without its stores)
 #else
-    constexpr bool TST = TAPE;
+    constexpr bool TST = TAPE, BST = BWD;
 #endif
+    [[maybe_unused]] auto bwd_put = [&](char* tb, int c, int p, const f32x2_t& v) {      // pair p of chunk c as fp32: rows 32 c + 8 (p / 2) + 4 kl + 2 (p % 2), + 1
+        float* q = reinterpret_cast<float*>(tb + (unsigned)(32 * c + 8 * (p >> 1) + 2 * (p & 1)) * 128u + blane);
+#ifdef C1_BWD_NT_STORES
+        if (BST) { __builtin_nontemporal_store(v[0], q); __builtin_nontemporal_store(v[1], q + 32); }
+#else
+        if (BST) { q[0] = v[0]; q[32] = v[1]; }
+#endif
+        else asm volatile("" ::"v"(v));
+    };
+    [[maybe_unused]] auto mask_get = [&](const unsigned short* mb, int c) -> unsigned { return (unsigned)mb[(long)c * mstride + ml * 2 + kl]; };
     [[maybe_unused]] auto tape_put = [&](char* tb, int c, int p, unsigned to) {       // pair p of chunk c: rows 32 c + 8 (p / 2) + 4 kl + 2 (p % 2) (+ 1)
         if (TST) *reinterpret_cast<unsigned*>(tb + (unsigned)(32 * c + 8 * (p >> 1) + 2 * (p & 1)) * 64u + tlane) = to;
         else asm volatile("" ::"v"(to));
@@ -317,7 +339,7 @@ __global__ void __launch_bounds__(256) k_cnet1w(CnetArgs a, CnetGeo g) {
             h8 hi, lo;
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                const float vv = (in && ch * 8 + q < a.Cin) ? canon_nan(v[q] * (TAPE ? a.in_scale : SH2_ACT_SCALE)) : 0.f;
+                const float vv = (in && ch * 8 + q < a.Cin) ? canon_nan(v[q] * (MODE != 0 ? a.in_scale : SH2_ACT_SCALE)) : 0.f;
                 _Float16 x0, x1;
                 sh2_split(vv, x0, x1);
                 hi[q] = x0; lo[q] = x1;
@@ -409,14 +431,21 @@ __global__ void __launch_bounds__(256) k_cnet1w(CnetArgs a, CnetGeo g) {
     };
     [[maybe_unused]] unsigned E_mw = 0u;     // TAPE: the sign word being built (value k = 4 gq + t shifted in at bit 0: ends up in bit 15 - k)
     // epilogue of f.0 for group gq (rows 8 gq + 4 kl + t of chunk c): -h1 = -relu(.) as halves of the B fragments
-    auto epi1 = [&](const f32x16_t& acc, int c, int gq, h8 (&bh)[2], h8 (&bl)[2]) {
+    auto epi1 = [&](const f32x16_t& acc, int c, int gq, h8 (&bh)[2], h8 (&bl)[2], [[maybe_unused]] unsigned mw) {
         const int o = 32 * c + 8 * gq + 4 * kl;
         const f32x4_t rs = *reinterpret_cast<const f32x4_t*>(t_rs0 + o);
         const f32x4_t bb = *reinterpret_cast<const f32x4_t*>(t_b0 + o);
         f32x4_t v;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) v[t] = nrelu_bits(fmaf(acc[4 * gq + t], rs[t], bb[t]));
+        for (int t = 0; t < 4; ++t) {
+            const float tt = fmaf(acc[4 * gq + t], rs[t], bb[t]);
+            v[t] = BWD ? ((mw >> (15 - (4 * gq + t))) & 1u ? tt : 0.f) : nrelu_bits(tt);
+        }
         c1_frag(v, bh[gq >> 1], bl[gq >> 1], gq & 1);
+        if constexpr (BWD) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) bwd_put(tb1, c, 2 * gq + h, f32x2_t{v[2 * h], v[2 * h + 1]} * nscale);
+        }
         if constexpr (TAPE) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -448,8 +477,10 @@ __global__ void __launch_bounds__(256) k_cnet1w(CnetArgs a, CnetGeo g) {
             c1_mfma_v(acc1, al, B0H[st]);
         }
         c1_settle(acc1);
+        unsigned mw0 = 0u;
+        if constexpr (BWD) mw0 = mask_get(mb1, 0);
 #pragma unroll
-        for (int gq = 0; gq < 4; ++gq) epi1(acc1, 0, gq, Bh, Bl);
+        for (int gq = 0; gq < 4; ++gq) epi1(acc1, 0, gq, Bh, Bl, mw0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the first fills have landed ...
     __syncthreads();          // ... everybody's; and every wave is done with f.0 buffer 0 before the loop refills it
@@ -499,9 +530,12 @@ __global__ void __launch_bounds__(256) k_cnet1w(CnetArgs a, CnetGeo g) {
     // fp16's subnormal range, |h| < 6.1e-5, where it rounds a second time -- k_cnet converts the fp32 product, one rounding; both are
     // fp16 roundings of h within 2^-24) + the pair's two sign bits, T2 the neighbouring lane's, T3 select, T4 store: pair p is at
     // stage T in tick 2 p + 5 + T (the last store in tick 23), the block's sign word goes out in tick 22
+    // BWD: S2 is the mask select (the block's sign word mw: value k in bit 15 - k), and two more stages per pair behind it -- T1 the
+    // two values times -out_scale, T2 their two stores: pair p at stage T in tick 2 p + 4 + T (the last stores in tick 20)
     [[maybe_unused]] unsigned E_tx[8], E_tn[8];
+    [[maybe_unused]] f32x2_t E_tm[8];
     auto epi_tick = [&](const f32x16_t& acc, const float* trs, const float* tbb, int c, int e, h8 (&bh)[2], h8 (&bl)[2], auto agpr,
-                        [[maybe_unused]] char* tb, [[maybe_unused]] unsigned short* mb) {
+                        [[maybe_unused]] char* tb, [[maybe_unused]] unsigned short* mb, [[maybe_unused]] unsigned mw) {
         if ((e & 3) == 0 && e < 16) {
             const int gq = e >> 2, o = 32 * c + 8 * gq + 4 * kl;
             E_rs[gq & 1] = *reinterpret_cast<const f32x4_t*>(trs + o);
@@ -525,8 +559,13 @@ __global__ void __launch_bounds__(256) k_cnet1w(CnetArgs a, CnetGeo g) {
                 E_v[p][1] = fmaf(a1, E_rs[gq & 1][t0 + 1], E_bb[gq & 1][t0 + 1]);
                 asm volatile("" : "+v"(E_v[p][0]), "+v"(E_v[p][1]));      // (each stage is computed in ITS slot: the optimizer otherwise sinks it to its use)
             } else if (S == 2) {
-                E_v[p][0] = nrelu_bits(E_v[p][0]);
-                E_v[p][1] = nrelu_bits(E_v[p][1]);
+                if constexpr (BWD) {      // 0 or all ones from the value's bit of the sign word, then AND
+                    E_v[p][0] = __uint_as_float(__float_as_uint(E_v[p][0]) & (unsigned)__builtin_amdgcn_sbfe((int)mw, 15 - 2 * p, 1));
+                    E_v[p][1] = __uint_as_float(__float_as_uint(E_v[p][1]) & (unsigned)__builtin_amdgcn_sbfe((int)mw, 14 - 2 * p, 1));
+                } else {
+                    E_v[p][0] = nrelu_bits(E_v[p][0]);
+                    E_v[p][1] = nrelu_bits(E_v[p][1]);
+                }
                 asm volatile("" : "+v"(E_v[p][0]), "+v"(E_v[p][1]));
             } else if (S == 3) {
                 const f32x2_t vv = {E_v[p][0], E_v[p][1]};
@@ -567,6 +606,20 @@ __global__ void __launch_bounds__(256) k_cnet1w(CnetArgs a, CnetGeo g) {
             }
             if (e == 22) mask_put(mb, c, E_mw);
         }
+        if constexpr (BWD) {
+#pragma unroll
+            for (int T = 1; T <= 2; ++T) {
+                const int d = e - 4 - T;
+                if (d < 0 || (d & 1) || d / 2 > 7) continue;
+                const int p = d / 2;
+                if (T == 1) {
+                    E_tm[p] = f32x2_t{E_v[p][0], E_v[p][1]} * nscale;
+                    asm volatile("" : "+v"(E_tm[p]));
+                } else {
+                    bwd_put(tb, c, p, E_tm[p]);
+                }
+            }
+        }
     };
 
     // (kind: K_F2 for the chunks whose fills are all f.2's -- all but the last two -- else K_ANY)
@@ -575,6 +628,7 @@ __global__ void __launch_bounds__(256) k_cnet1w(CnetArgs a, CnetGeo g) {
         const int nbuf = cn & 1;
         f32x16_t acc1;
         h8 Bnh[2], Bnl[2];
+        [[maybe_unused]] unsigned mwA = 0u;        // BWD: the sign word of chunk cn (requested in slot 17, used from slot EP0 + 4 on)
         // f.0's MFMA j of chunk cn and the operand reloads behind it
         auto f0_mfma = [&](int j) {
             const int st = j / 3, w = j % 3;
@@ -608,9 +662,10 @@ __global__ void __launch_bounds__(256) k_cnet1w(CnetArgs a, CnetGeo g) {
                     // per tile), and the next k-step's first fragments are requested from slot 4 on.
 #ifndef C1_DBG_NO_VMWAIT
                     // (TAPE: + the stores issued behind the last piece of the fill waited for -- 6 of the previous chunk's 9 at s = 0,
-                    // all 9 of this chunk's at s = 1; one less each: a smaller count only waits for more)
-                    if (s == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PPF + NP0 + (TST ? 5 : 0)) : "memory");
-                    else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PPF + (TST ? 8 : 0)) : "memory");
+                    // all 9 of this chunk's at s = 1; one less each: a smaller count only waits for more.  BWD: 6 of the previous
+                    // chunk's 16 stores + this chunk's sign-word load at s = 0, all 16 stores at s = 1; one less each.)
+                    if (s == 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PPF + NP0 + (TST ? 5 : 0) + (BST ? 6 : (BWD ? 1 : 0))) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PPF + (TST ? 8 : 0) + (BST ? 15 : 0)) : "memory");
 #endif
 #ifndef C1_DBG_NO_BARRIER
                     __builtin_amdgcn_s_barrier();
@@ -633,12 +688,13 @@ __global__ void __launch_bounds__(256) k_cnet1w(CnetArgs a, CnetGeo g) {
                 if (k == (lastq ? 9 : 2)) ring_piece(i0 + 1, kind);
                 if (s == 0 && !lastq && (k & 1) && q4 + (k >> 1) * (NQ - 1) < NP0) w0_piece(min(c + 2, NCH - 1), q4 + (k >> 1) * (NQ - 1));
 #endif
+                if constexpr (BWD) { if (sl == 17) mwA = mask_get(mb1, cn); }
                 // f.0 of chunk cn (c1_f0slot); in the chunk's last quad the first operands of the chunk after (its rows landed with
                 // that quad's TOP)
 #ifndef C1_DBG_NO_P1
 #pragma unroll
                 for (int j = 0; j < NF0; ++j)
-                    if (c1_f0slot(NQ, j) == sl) f0_mfma(j);
+                    if (c1_f0slot(NQ, NST0, j) == sl) f0_mfma(j);
                 if (Q == 2 * NQ - 1 && k >= 8) {
                     const char* pa = lds1 + a0lane + (min(c + 2, NCH - 1) & 1) * (G0 * 1024);
                     if (k == 9) A0h = *reinterpret_cast<const h8*>(pa);
@@ -648,7 +704,7 @@ __global__ void __launch_bounds__(256) k_cnet1w(CnetArgs a, CnetGeo g) {
                 if (sl >= EP0 && sl < EP0 + 24) {
 #ifndef C1_DBG_NO_EPI
                     if (sl == EP0) c1_settle(acc1);
-                    epi_tick(acc1, t_rs0, t_b0, cn, sl - EP0, Bnh, Bnl, std::false_type{}, tb1, mb1);
+                    epi_tick(acc1, t_rs0, t_b0, cn, sl - EP0, Bnh, Bnl, std::false_type{}, tb1, mb1, mwA);
 #endif
                 }
 #endif
@@ -676,8 +732,11 @@ __global__ void __launch_bounds__(256) k_cnet1w(CnetArgs a, CnetGeo g) {
     h8 Hh[2][2], Hl[2][2];      // [block & 1][k-step of the block]
     const float* trs2 = t_rs2 + ms_row0;
     const float* tbb2 = t_b2 + ms_row0;
+    // BWD: the sign word of h2-position block b (mask1 of the forward: h1's), requested a block ahead of its epilogue
+    [[maybe_unused]] unsigned mwB[NRT2];
+    if constexpr (BWD) { mwB[0] = mask_get(mb2, 0); mwB[1] = mask_get(mb2, 1); }
 #pragma unroll
-    for (int e = 0; e < 24; ++e) epi_tick(acc2[0], trs2, tbb2, 0, e, Hh[0], Hl[0], std::true_type{}, tb2, mb2);
+    for (int e = 0; e < 24; ++e) epi_tick(acc2[0], trs2, tbb2, 0, e, Hh[0], Hl[0], std::true_type{}, tb2, mb2, BWD ? mwB[0] : 0u);
     h8 A4H[NRT4], A4L[NRT4];
     auto ldA4one = [&](int slot_off, int kk, int i, int pl, h8& dst) {
         dst = *reinterpret_cast<const h8*>(lds1 + a4lane + slot_off + kk * (MP4 * 32) + i * 512 + pl * (K4 * MP4 * 32));
@@ -704,12 +763,18 @@ __global__ void __launch_bounds__(256) k_cnet1w(CnetArgs a, CnetGeo g) {
         const int i0 = kk == K4 - 1 ? 0 : PA + kk * PER, i1 = kk == K4 - 1 ? PA : min(PPW4, PA + (kk + 1) * PER);
         const int cn = min(c + 1, NRT2 - 1);
         constexpr int NM = 3 * NRT4;
-        static_assert(2 * NM >= 24 && NM - PPW4 > 3, "the next block's epilogue inside a block's two k-steps; the pieces behind the TOP");
+        constexpr int TPS = (24 + 2 * NM - 1) / (2 * NM);      // epilogue ticks per slot: the next block's 24 inside this block's 2 NM slots
+        static_assert(NM - PA >= 4, "the pieces behind the TOP");
 #pragma unroll
         for (int k = 0; k < NM; ++k) {
-            if (kk == K4 - 1 && F + 1 <= FL && k == 3) {      // TOP (as in the loop above: in front of the k-step's fourth slot)
-                // (TAPE: 19 stores are issued between the last piece of fill F + 1 -- at the end of fill F - 1's third k-step -- and here)
-                if (F + 2 <= FL) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PPW4 + (TST ? 16 : 0)) : "memory");
+            // TOP (as in the loop above: in front of the k-step's fourth slot -- or, with fewer than three row tiles, in front of the
+            // first slot that reloads a fragment for the NEXT k-step, which must come out of the slot that has just landed)
+            constexpr int TOPK = NRT4 < 3 ? NRT4 : 3;
+            if (kk == K4 - 1 && F + 1 <= FL && k == TOPK) {
+                // (TAPE: 19 stores are issued between the last piece of fill F + 1 -- at the end of fill F - 1's third k-step -- and here.
+                // BWD: more than a fill's worth -- 4 blocks x (16 stores + a sign-word load) -- so the largest count there is, 63, is valid:
+                // the pieces waited for are older than the 63 youngest operations.)
+                if (F + 2 <= FL) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(BST ? 63 : PPW4 + (TST ? 16 : 0)) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
@@ -728,8 +793,13 @@ __global__ void __launch_bounds__(256) k_cnet1w(CnetArgs a, CnetGeo g) {
             }
             if (ks + 1 < NKS4 && sw == 1) ldA4one(s_cur, (kk + 1) % K4, i, 0, A4H[i]);
             if (ks + 1 < NKS4 && sw == 2) ldA4one(s_cur, (kk + 1) % K4, i, 1, A4L[i]);
-            // h2 of the next block: its epilogue over the first 24 slots of this block's two k-steps
-            if (c + 1 < NRT2 && s * NM + k < 24) epi_tick(acc2[cn], trs2, tbb2, cn, s * NM + k, Hh[cn & 1], Hl[cn & 1], std::true_type{}, tb2, mb2);
+            // h2 of the next block: its epilogue's 24 ticks over this block's two k-steps, TPS per slot
+            if constexpr (BWD) { if (s == 0 && k == 0 && c + 2 < NRT2) mwB[c + 2] = mask_get(mb2, c + 2); }
+#pragma unroll
+            for (int u = 0; u < TPS; ++u) {
+                const int e = (s * NM + k) * TPS + u;
+                if (c + 1 < NRT2 && e < 24) epi_tick(acc2[cn], trs2, tbb2, cn, e, Hh[cn & 1], Hl[cn & 1], std::true_type{}, tb2, mb2, BWD ? mwB[cn] : 0u);
+            }
             if (ff <= FL && k >= NM - (i1 - i0)) ring_piece(i0 + k - (NM - (i1 - i0)), K_F4{});
             C1_FENCE();
         }
@@ -746,9 +816,11 @@ __global__ void __launch_bounds__(256) k_cnet1w(CnetArgs a, CnetGeo g) {
     // + co puts them side by side, one 16-byte read per tap -- a quarter of the LDS instructions of the [row][pixel] form in both
     // halves of the phase.  RP / 4 is odd: the 16-byte groups of consecutive pixels fall on distinct banks.
     float* T = reinterpret_cast<float*>(lds1 + TABS);       // (behind the tables: t_rs4 is read while T is written)
-    const int Cout = g.Cg;                      // (a multiple of 4: cnet1w_takes)
+    constexpr int CGW = BWD ? 2 : 4;            // output channels a tap-sum thread takes per read (BWD: C / 2 = 6 channels)
+    using tvec = std::conditional_t<CGW == 4, f32x4_t, f32x2_t>;
+    const int Cout = g.Cg;                      // (a multiple of CGW: cnet1w_takes)
     const int rows = 9 * Cout;
-    const int RP = 4 * ((rows >> 2) | 1);
+    const int RP = cnet_trow(rows);             // floats per pixel: whole 16-byte groups, an odd number of them
     {
         float* dst = T + (wid * 32 + ml) * RP + 4 * kl;
 #pragma unroll
@@ -771,7 +843,7 @@ __global__ void __launch_bounds__(256) k_cnet1w(CnetArgs a, CnetGeo g) {
     float* hpart = a.scratch;
     float* hup = a.scratch + (long)MS * a.N * a.Cout * HW;
     float* hdn = hup + (long)MS * g.tiles * a.Cout * W;
-    const int ngrp = Cout >> 2;
+    const int ngrp = Cout / CGW;
     {
         // a thread keeps ITS pixel (tid & 127) and walks the groups of four channels tid >> 7, + 2, ...
         const int q = tid & 127;
@@ -791,17 +863,19 @@ __global__ void __launch_bounds__(256) k_cnet1w(CnetArgs a, CnetGeo g) {
         if (n < a.N) {
             float* hp = hpart + ((msN + n) * a.Cout) * HW + (long)(y0 + r) * W + x;
             for (int cg = tid >> LPXT; cg < ngrp; cg += NT >> LPXT) {
-                const float* tp = T + 4 * cg;
-                f32x4_t v[9];
+                const float* tp = T + CGW * cg;
+                tvec v[9];
 #pragma unroll
-                for (int tap = 0; tap < 9; ++tap) v[tap] = *reinterpret_cast<const f32x4_t*>(tp + off[tap]);
-                f32x4_t sum = {0.f, 0.f, 0.f, 0.f};
+                for (int tap = 0; tap < 9; ++tap) v[tap] = *reinterpret_cast<const tvec*>(tp + off[tap]);
+                tvec sum;
+#pragma unroll
+                for (int j = 0; j < CGW; ++j) sum[j] = 0.f;
 #pragma unroll
                 for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) sum[j] += ok[tap] ? v[tap][j] : 0.f;
+                    for (int j = 0; j < CGW; ++j) sum[j] += ok[tap] ? v[tap][j] : 0.f;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) hp[(long)(4 * cg + j) * HW] = sum[j];
+                for (int j = 0; j < CGW; ++j) hp[(long)(CGW * cg + j) * HW] = sum[j];
             }
         }
     }
@@ -816,16 +890,16 @@ __global__ void __launch_bounds__(256) k_cnet1w(CnetArgs a, CnetGeo g) {
             if (dn ? (y0 + g.R >= H) : (y0 == 0)) continue;
             const int rsrc = dn ? g.R - 1 : 0;
             const int dyt = dn ? 0 : 2;                 // filter row applied by the outside pixel to this source row
-            f32x4_t v[3]; bool ok[3];
+            tvec v[3]; bool ok[3];
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) {
                 ok[dx] = x + dx - 1 >= 0 && x + dx - 1 < W;
-                v[dx] = *reinterpret_cast<const f32x4_t*>(T + (rsrc * W + (ok[dx] ? x + dx - 1 : x)) * RP + (dyt * 3 + dx) * Cout + 4 * cg);
+                v[dx] = *reinterpret_cast<const tvec*>(T + (rsrc * W + (ok[dx] ? x + dx - 1 : x)) * RP + (dyt * 3 + dx) * Cout + CGW * cg);
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < CGW; ++j) {
                 const float sacc = (ok[0] ? v[0][j] : 0.f) + (ok[1] ? v[1][j] : 0.f) + (ok[2] ? v[2][j] : 0.f);
-                (dn ? hdn : hup)[((mstile + tb) * a.Cout + 4 * cg + j) * W + x] = sacc;
+                (dn ? hdn : hup)[((mstile + tb) * a.Cout + CGW * cg + j) * W + x] = sacc;
             }
         }
     }
@@ -837,26 +911,28 @@ __global__ void __launch_bounds__(256) k_cnet1w(CnetArgs a, CnetGeo g) {
 static size_t cnet1w_lds_bytes(const CnetGeo& g, int hidden, int ms) {
     const size_t tabs = (((size_t)4 * hidden + g.Mpad4) * sizeof(float) + 1023) / 1024 * 1024;
     const size_t work = (size_t)3 * (hidden / ms) * 64 + (size_t)2 * g.G * 1024 + (size_t)2 * g.winplane * sizeof(_Float16);
-    const size_t stage = (size_t)4 * (((size_t)9 * g.Cg >> 2) | 1) * 128 * sizeof(float);      // T, pixel-major
+    const size_t stage = (size_t)cnet_trow(9 * g.Cg) * 128 * sizeof(float);      // T, pixel-major
     return tabs + std::max(work, stage);
 }
 
-// instances: 1 = product, 2 = taping (both: C = 12 levels, the workgroup owns all 512 h2 rows), 3 = product with the h2 rows split
-// over two workgroups (C = 24 levels)
+// instances: 1 = product, 2 = taping forward (both: C = 12 levels, the workgroup owns all 512 h2 rows), 3 = product with the h2 rows
+// split over two workgroups (C = 24 levels), 4 = the backward launch of the C = 12 levels (12 channels in, 6 out)
 static int cnet1w_instance(const CnetArgs& a, const CnetGeo& g, int ms) {      // 0: none
     if (a.hidden != 512 || g.ng != 1 || g.pxt != 128) return 0;
+    if (a.bwd) return (ms == 1 && g.G == 18 && g.NRT4 == 2 && a.tape_h1) ? 4 : 0;
     if (ms == 1 && g.G == 10 && g.NRT4 == 4) return a.tape_h1 ? 2 : 1;
     if (ms == 2 && g.G == 18 && g.NRT4 == 7 && !a.tape_h1) return 3;
     return 0;
 }
 
 bool cnet1w_takes(const CnetArgs& a, const CnetGeo& g, int ms) {
-    if (a.pre_on || a.bwd) return false;
-    if (a.tape_h1 && (!a.tape_h2 || !a.mask1 || !a.mask2 || g.HW % 128 != 0)) return false;      // taping: whole 32-pixel tiles of the batch per wave
+    if (a.pre_on) return false;
+    if ((a.tape_h1 || a.bwd) && (!a.tape_h1 || !a.tape_h2 || !a.mask1 || !a.mask2 || g.HW % 128 != 0)) return false;      // taping / backward: whole 32-pixel tiles of the batch per wave
     if (g.NI != 1) return false;                     // (tiles of whole small images stay on k_cnet: no level that large has them)
-    if (!cnet1w_instance(a, g, ms)) return false;
+    const int inst = cnet1w_instance(a, g, ms);
+    if (!inst) return false;
     if (cnet1w_lds_bytes(g, a.hidden, ms) > 160 * 1024) return false;
-    if (g.Cg % 4 != 0) return false;                 // the tap sums take four output channels per 16-byte read
+    if (g.Cg % (inst == 4 ? 2 : 4) != 0) return false;      // the tap sums take four (backward: two) output channels per read
     return true;
 }
 
@@ -868,12 +944,16 @@ int launch_cnet1w(const CnetArgs& a, const CnetGeo& g, int ms, hipStream_t s) {
         hipLaunchKernelGGL((k_cnet1w<512, 10, 4>), dim3(g.tiles), dim3(256), lds, s, a, g);
         break;
     case 2:
-        (void)hipFuncSetAttribute((const void*)k_cnet1w<512, 10, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((k_cnet1w<512, 10, 4, true>), dim3(g.tiles), dim3(256), lds, s, a, g);
+        (void)hipFuncSetAttribute((const void*)k_cnet1w<512, 10, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((k_cnet1w<512, 10, 4, 1>), dim3(g.tiles), dim3(256), lds, s, a, g);
         break;
     case 3:
-        (void)hipFuncSetAttribute((const void*)k_cnet1w<512, 18, 7, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((k_cnet1w<512, 18, 7, false, 2>), dim3(g.tiles, 2), dim3(256), lds, s, a, g);
+        (void)hipFuncSetAttribute((const void*)k_cnet1w<512, 18, 7, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((k_cnet1w<512, 18, 7, 0, 2>), dim3(g.tiles, 2), dim3(256), lds, s, a, g);
+        break;
+    case 4:
+        (void)hipFuncSetAttribute((const void*)k_cnet1w<512, 18, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((k_cnet1w<512, 18, 2, 2>), dim3(g.tiles), dim3(256), lds, s, a, g);
         break;
     default:
         set_error("cnet1w: no kernel instance");

@@ -1415,14 +1415,14 @@ static bool cnet_select(const CnetArgs& a, CnetGeo* gout, int* ms_out, int* upw_
     // are in (184 B); 64-pixel tiles measured 2 % faster on the training step
     if (a.tape_h1 && ok64 && !(g_cnet_flags & 1)) use64 = true;
     // ... except where the one-wave-per-SIMD kernel takes the taping forward (cnet1w_sh.hip: its registers hold the 128-pixel tile)
-    const bool c1w_ok = ok128 && !a.bwd && !a.pre_on && !(g_cnet_flags & (2 | 16));
-    if (a.tape_h1 && c1w_ok && g128.tiles >= 224 && cnet1w_takes(a, g128, 1)) use64 = false;
+    const bool c1w_ok = ok128 && !a.pre_on && !(g_cnet_flags & (2 | 16));
+    if (a.tape_h1 && c1w_ok && g128.tiles >= 224 && !(a.bwd && (g_cnet_flags & 64)) && cnet1w_takes(a, g128, 1)) use64 = false;      // (flag 64: no backward instance, A/B)
     // ... and, behind the debug switch 0x20000 only, that kernel's instance with the h2 rows split over two workgroups (128-pixel tiles
     // from 112 tiles on: the C = 24 levels that otherwise run one 64-pixel k_cnet workgroup per CU).  Measured slower than k_cnet
     // where it applies -- 47.0 against 45.5 us per launch at config B's level 2, 176 against 150 us at config E's (DESIGN.md 3.2:
     // each half computes all of f.0 again, 29 % of its MFMAs) -- so it is not selected by default; the parity tests run it.
     bool c1w_split = false;
-    if (c1w_ok && !g_cnet_ms && (g_cnet_flags & 32) && g128.tiles >= 112 && cnet1w_takes(a, g128, 2)) { use64 = false; c1w_split = true; }
+    if (c1w_ok && !a.bwd && !g_cnet_ms && (g_cnet_flags & 32) && g128.tiles >= 112 && cnet1w_takes(a, g128, 2)) { use64 = false; c1w_split = true; }
     g = use64 ? g64 : g128;
     int ms = 1;
     const int ms_max = std::min(CN_MAXMS, a.hidden / (use64 ? 128 : 64));
@@ -1475,7 +1475,7 @@ int launch_cnet_main(const CnetArgs& a, hipStream_t s, CnetPending* out) {
     int rc = GLOWHIP_EINVAL;
     // one wave per SIMD (cnet1w_sh.hip) wherever an instance exists for the launch: forward / inverse / taping forward, 128-pixel tiles, no row split
     bool one_wave = false;
-    if (!a.bwd && !a.pre_on && g.pxt == 128 && !(g_cnet_flags & 16) && cnet1w_takes(a, g, ms) && !(ms == 2 && (g_cnet_ms || !(g_cnet_flags & 32)))) {
+    if (!a.pre_on && g.pxt == 128 && !(g_cnet_flags & 16) && !(a.bwd && (g_cnet_flags & 64)) && cnet1w_takes(a, g, ms) && !(ms == 2 && (g_cnet_ms || !(g_cnet_flags & 32)))) {
         GH_TRY(launch_cnet1w(a, g, ms, s));
         rc = GLOWHIP_OK;
         one_wave = true;

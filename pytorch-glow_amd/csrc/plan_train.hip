@@ -452,6 +452,7 @@ static int backward_sweep(glowhip_plan* p, const void* packed, const float* x_in
                     ScopedTimer t(p, GLOWHIP_K_CNET_BWD, 1, s);
                     GH_TRY(launch_cnet_main(c, s, &pend));
                 }
+                if (pend.one_wave) count_launch(p, "k_cnet1w(bwd)");      // (run-time evidence for the tests: the backward instance of cnet1w_sh.hip took it)
                 // (its finishing step -- g_y1 += the partial sums -- rides in k_chanmix_bwd below)
                 if (trio) {      // all three GEMMs side by side in one launch
                     count_launch(p, "k_wgrad(trio)");

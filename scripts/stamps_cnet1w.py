@@ -1,6 +1,6 @@
 """Debug: cycle stamps of one workgroup (all four waves) of the LAST k_cnet1w launch of a forward (stamps build only):
 make -C pytorch-glow_amd/csrc BUILD=build_stamps LIB=../libglowhip_stamps.so EXTRA=-DGLOWHIP_DEBUG_STAMPS
-env: K, L (model depth), B (batch), FLAGS (glowhip_debug_force_tail_tile), TRAIN=1 (the taping instance)."""
+env: K, L (model depth), B (batch), FLAGS (glowhip_debug_force_tail_tile), TRAIN=1 (the taping instance), TRAIN=2 (the backward instance)."""
 import ctypes, os, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, root)
@@ -17,7 +17,12 @@ if fl: G.lib().glowhip_debug_force_tail_tile(fl)
 glow.train()
 with torch.no_grad():
     glow.normal_flow(x, None)
-if os.environ.get("TRAIN"):          # the taping instance: training forwards (the tape is written when a graph is recorded)
+if os.environ.get("TRAIN") == "2":   # the backward instance: the last k_cnet1w launch of a training step is its level-1 input-gradient launch
+    with torch.enable_grad():
+        for _ in range(3):
+            z, nll, _ = glow.normal_flow(x, None)
+            G.Glow.generative_loss(nll).backward()
+elif os.environ.get("TRAIN"):        # the taping instance: training forwards (the tape is written when a graph is recorded)
     with torch.enable_grad():
         for _ in range(3): glow.normal_flow(x, None)
 else:
