@@ -15,7 +15,8 @@ g = torch.Generator().manual_seed(23)
 x = torch.rand(batch, 3, 64, 64, generator=g); noise = torch.rand(batch, 3, 64, 64, generator=g) / 256
 sd = O.glow_init_actnorm(x, noise, sd, cfg)
 res = {}
-for flag in (0x40000, 0):
+FA = int(os.environ.get("FLAG_A", "0x40000"), 0)
+for flag in (FA, 0):
     _lib.lib().glowhip_debug_force_tail_tile(flag)
     glow = G.Glow(hps_for(cfg, batch)); glow.load_state_dict(sd); glow.set_actnorm_inited(); glow = glow.to("cuda:0").train()
     with torch.enable_grad():
@@ -27,7 +28,7 @@ for flag in (0x40000, 0):
     res[flag] = grads
     print(hex(flag), {k: v for k, v in glow.flow.plan_for(x.to("cuda:0")).launch_counts().items() if "cnet" in k})
 _lib.lib().glowhip_debug_force_tail_tile(0)
-for n, a in res[0x40000].items():
+for n, a in res[FA].items():
     b = res[0][n]; sc = a.abs().max().item(); err = (a - b).abs()
     if err.max().item() > 1e-4 * sc + 1e-12:
         print(f"{n:60s} shape {tuple(a.shape)} scale {sc:.3e} max err {err.max().item():.3e} rms {err.pow(2).mean().sqrt().item():.3e}")
