@@ -214,7 +214,7 @@ def instrumented_pass(plan, hps, B, run_once, passes=3, with_traffic=False, trai
     traffic, traffic_src = traffic_record(cnet_path, sh_path) if with_traffic else (None, None)
     peak = PEAK_SPLIT_TFLOPS if sh_path else PEAK_FP32_MFMA_TFLOPS
     name = (CNET_DESC + ("; here the taping forward (MODE 1: also stores h1 / h2 as fp16, pixel-tile-major, + sign words) and the input-gradient chain "
-                         "(MODE 2) launches of the training step" if train else "")) if cnet_path else \
+                         "(MODE 2) launches of the training step -- level 1 on the taping / backward instances of k_cnet1w, levels 2 / 3 on k_cnet" if train else "")) if cnet_path else \
            "k_gemm_glds (f.2: 1x1 conv 512->512 + ActNorm + ReLU, fp32-input MFMA, 128x128 tiles)"
     roof = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
             "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
