@@ -507,22 +507,24 @@ def test_training_step_runs_on_k_cnet_and_agrees_with_the_per_layer_kernels():
                 (hex(flag), name, scale, err.max().item())
 
 
-def test_training_launches_on_the_one_wave_kernel_agree_with_k_cnet():
+@pytest.mark.parametrize("image,L,batch", [(64, 3, 28), (32, 1, 112)])
+def test_training_launches_on_the_one_wave_kernel_agree_with_k_cnet(image, L, batch):
     """Round 5: where level 1 gives 224 or more 128-pixel tiles (batch 28 at config-B geometry) the TRAINING step's launches of its
     FlowSteps run on k_cnet1w (cnet1w_sh.hip):
       * the taping forward -- h1 / h2 stay in registers and go to the tape from the epilogue pipeline, two pixels of one row per
         4-byte store after a quad-permute, sign words as k_cnet writes them;
       * the input-gradient chain (the transposed network: 12 channels in, 6 out) -- ReLU masks read from those sign words a block
         ahead, g_u2 / g_u0 stored as fp32 for the weight-gradient GEMMs, the partial sums for k_chanmix_bwd in k_cnet's layout;
-    evidence from the run-time counters.  With the debug switches 0x10000 (no k_cnet1w at all) / 0x40000 (taping on k_cnet1w, backward
+    evidence from the run-time counters (config-B geometry: 32-pixel rows, four per tile; and a 32 x 32 input with L = 1: 16-pixel rows,
+    eight per tile, 224 tiles at batch 112).  With the debug switches 0x10000 (no k_cnet1w at all) / 0x40000 (taping on k_cnet1w, backward
     on k_cnet) the same step runs on k_cnet MODE 1 / 2 (pinned against the fp64 oracle above): z, nll and every gradient agree."""
     from pytorch_glow_amd import _lib
-    K, batch = 2, 28
-    cfg = O.default_cfg(K=K, batch=batch)
+    K = 2
+    cfg = O.default_cfg(image_shape=(image, image, 3), K=K, L=L, batch=batch)
     sd = O.seeded_state_dict(cfg, seed=23, invconv_perturb=0.02, zeros_std=0.01)
     g = torch.Generator().manual_seed(23)
-    x = torch.rand(batch, 3, 64, 64, generator=g)
-    noise = torch.rand(batch, 3, 64, 64, generator=g) / 256
+    x = torch.rand(batch, 3, image, image, generator=g)
+    noise = torch.rand(batch, 3, image, image, generator=g) / 256
     sd = O.glow_init_actnorm(x, noise, sd, cfg)
     res = {}
     try:
@@ -543,10 +545,10 @@ def test_training_launches_on_the_one_wave_kernel_agree_with_k_cnet():
     finally:
         _lib.lib().glowhip_debug_force_tail_tile(0)
     z0, n0, g0, c0 = res[0x10000]
-    assert c0.get("k_cnet(tape)", 0) == 3 * K and c0.get("k_cnet1w(tape)", 0) == 0 and c0.get("k_cnet1w(bwd)", 0) == 0, c0
+    assert c0.get("k_cnet(tape)", 0) == L * K and c0.get("k_cnet1w(tape)", 0) == 0 and c0.get("k_cnet1w(bwd)", 0) == 0, c0
     for flag, want_bwd in ((0x40000, 0), (0, K)):
         z1, n1, g1, c1 = res[flag]
-        assert c1.get("k_cnet(tape)", 0) == 3 * K and c1.get("k_cnet1w(tape)", 0) == K and c1.get("k_cnet(bwd)", 0) == 3 * K, c1
+        assert c1.get("k_cnet(tape)", 0) == L * K and c1.get("k_cnet1w(tape)", 0) == K and c1.get("k_cnet(bwd)", 0) == L * K, c1
         assert c1.get("k_cnet1w(bwd)", 0) == want_bwd, (hex(flag), c1)
         assert torch.isfinite(n1).all()
         assert (z1 - z0).abs().max().item() <= 2e-5 and (n1 - n0).abs().max().item() <= 2e-6 * max(1.0, n0.abs().max().item())
