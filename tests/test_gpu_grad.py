@@ -507,7 +507,7 @@ def test_training_step_runs_on_k_cnet_and_agrees_with_the_per_layer_kernels():
                 (hex(flag), name, scale, err.max().item())
 
 
-@pytest.mark.parametrize("image,L,batch", [(64, 3, 28), (32, 1, 112)])
+@pytest.mark.parametrize("image,L,batch", [(64, 3, 28), (32, 1, 112), (128, 1, 7)])
 def test_training_launches_on_the_one_wave_kernel_agree_with_k_cnet(image, L, batch):
     """Round 5: where level 1 gives 224 or more 128-pixel tiles (batch 28 at config-B geometry) the TRAINING step's launches of its
     FlowSteps run on k_cnet1w (cnet1w_sh.hip):
@@ -516,7 +516,7 @@ def test_training_launches_on_the_one_wave_kernel_agree_with_k_cnet(image, L, ba
       * the input-gradient chain (the transposed network: 12 channels in, 6 out) -- ReLU masks read from those sign words a block
         ahead, g_u2 / g_u0 stored as fp32 for the weight-gradient GEMMs, the partial sums for k_chanmix_bwd in k_cnet's layout;
     evidence from the run-time counters (config-B geometry: 32-pixel rows, four per tile; and a 32 x 32 input with L = 1: 16-pixel rows,
-    eight per tile, 224 tiles at batch 112).  With the debug switches 0x10000 (no k_cnet1w at all) / 0x40000 (taping on k_cnet1w, backward
+    eight per tile, 224 tiles at batch 112; a 128 x 128 input with L = 1: 64-pixel rows, two per tile, 224 tiles at batch 7).  With the debug switches 0x10000 (no k_cnet1w at all) / 0x40000 (taping on k_cnet1w, backward
     on k_cnet) the same step runs on k_cnet MODE 1 / 2 (pinned against the fp64 oracle above): z, nll and every gradient agree."""
     from pytorch_glow_amd import _lib
     K = 2
