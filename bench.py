@@ -255,7 +255,8 @@ def setup_workload(G, util, parallel, device, cfg_name, mode, B, rank, world, re
         wl["z_top"] = z_top = torch.randn((B,) + tuple(plan.out_chw), device=device) * 0.7
     if mode == "train":
         from pytorch_glow_amd import training
-        loop = training.TrainLoop(glow, hps, rank=rank, world=world)   # Adam + noam warm-up + clip 5/100 (celeba profile)
+        # Adam + noam warm-up + clip 5/100 (celeba profile); single rank: from its fourth step on the step is ONE hipGraph launch
+        loop = training.TrainLoop(glow, hps, rank=rank, world=world, graph=graph and world == 1)
         wl["loop"] = loop
         torch.set_grad_enabled(True)
     else:
@@ -328,6 +329,12 @@ def secondary_workloads(G, util, parallel, device, steps=3, warmup=3):
             dt = time.perf_counter() - t0
             if "loop" in wl:
                 wl["loop"].flush()
+            launch = None
+            if "loop" in wl:      # how the timed steps were launched; the instrumented pass below needs the eager launch list (per-launch events)
+                lp = wl["loop"]
+                launch = ("hipGraph (training step captured after the eager warm-up steps, one graph launch per step)" if lp._graphed is not None
+                          else "eager" + (f"; hipGraph capture failed: {lp.graph_error}" if lp.graph_error else ""))
+                lp.graph = False
             # roofline of this workload's dominant kernel: the same live-event pass as the headline's, after (outside) its timed steps
             inst = instrumented_pass(wl["plan"], wl["hps"], B, step, passes=3, train=(mode == "train"))
             torch.cuda.synchronize()
@@ -343,6 +350,7 @@ def secondary_workloads(G, util, parallel, device, steps=3, warmup=3):
                          "warmup": warmup + (7 if mode == "train" else 0), "batch": B,
                          "workload": f"{cfg['label']}, {mode}, batch {B} ({cfg['ref']})",
                          "finite": bool(torch.isfinite(last).all()), "data_dependent_init_ms": wl["init_ms"],
+                         **({"launch": launch} if launch else {}),
                          "kernel_families": sorted(inst["launches"]),
                          "roofline": inst["roofline"], "breakdown_ms_per_step": inst["breakdown"],
                          "wall_s_incl_setup": round(time.perf_counter() - t_wall, 1)}
@@ -529,6 +537,12 @@ def main():
         dt = float(t.item())
     total_images = world * B * args.steps
     value = total_images / dt
+    if "loop" in wl:      # how the timed training steps were launched
+        lp = wl["loop"]
+        wl["launch"] = ("hipGraph (training step captured after the eager warm-up steps, one graph launch per step)" if lp._graphed is not None
+                        else "eager (two C calls per step issuing the kernel lists + the optimiser's two launches)"
+                        + (f"; hipGraph capture failed: {lp.graph_error}" if lp.graph_error else ""))
+        lp.graph = False
 
     if rank == 0:
         fpi = flop_per_image(glow)

@@ -291,6 +291,13 @@ typedef struct glowhip_optim_chunk { float* param; float* grad; float* m; float*
 int glowhip_optim_step(const glowhip_optim_chunk* chunks_dev, int n_chunks, int kind, float lr, double beta1, double beta2,
                        float eps, float weight_decay, int step, float clip_value, float max_norm, double* partial_dev,
                        float* grad_norm_out, int skip_if_nonfinite, glowhip_stream_t stream);
+/* The same step with the values that change from step to step read from DEVICE memory -- hyper_dev[3] = {lr (a float's value),
+ * 1 - beta1^step, 1 - beta2^step} as doubles, computed by the caller the way glowhip_optim_step does (python-double arithmetic, as
+ * torch) -- so that the two launches can sit in a captured hipGraph whose kernel arguments are frozen (training.GraphedTrainStep:
+ * the caller uploads the three values before each replay).  Same arithmetic, same bits as glowhip_optim_step. */
+int glowhip_optim_step_dev(const glowhip_optim_chunk* chunks_dev, int n_chunks, int kind, const double* hyper_dev, double beta1,
+                           double beta2, float eps, float weight_decay, float clip_value, float max_norm, double* partial_dev,
+                           float* grad_norm_out, int skip_if_nonfinite, glowhip_stream_t stream);
 
 /* Per-launch timing for benchmarks (HIP events recorded on the execution stream around every kernel of
  * the coupling path).  enable=1 creates an event pool (host resource), enable=0 destroys it; while enabled

@@ -106,6 +106,7 @@ SIGNATURES = {
                                       _P, c_size_t, _P]),
     "glowhip_plan_backward_marks": (c_int, [_P, POINTER(c_int32), POINTER(c_void_p), c_int]),
     "glowhip_optim_step": (c_int, [_P, c_int, c_int, c_float, ctypes.c_double, ctypes.c_double, c_float, c_float, c_int, c_float, c_float, _P, _P, c_int, _P]),
+    "glowhip_optim_step_dev": (c_int, [_P, c_int, c_int, _P, ctypes.c_double, ctypes.c_double, c_float, c_float, c_float, c_float, _P, _P, c_int, _P]),
     "glowhip_plan_timing_enable": (c_int, [_P, c_int]),
     "glowhip_plan_timing_read": (c_int, [_P, POINTER(TimingRecord), c_int, POINTER(c_int)]),
 }

@@ -289,10 +289,11 @@ class FlowPlan:
         self._grad_fields()
         return self._trainable
 
-    def glow_forward_train(self, x, noise, prior_mean, prior_logs, prior_stride, n_bits):
-        """Forward that records the activation tape; returns (z, nll, tape)."""
+    def glow_forward_train(self, x, noise, prior_mean, prior_logs, prior_stride, n_bits, force_pack=False):
+        """Forward that records the activation tape; returns (z, nll, tape).  ``force_pack``: re-derive the weight images whatever the
+        version counters say (a captured training step: every replay follows an update the counters of capture time know nothing of)."""
         n = x.shape[0]
-        self.ensure_packed(False, use=self.PACK_TRAINING)   # re-packs when the weights changed since the last pack (optimizer step)
+        self.ensure_packed(force_pack, use=self.PACK_TRAINING)   # re-packs when the weights changed since the last pack (optimizer step)
         z = torch.empty((n,) + self.out_chw, dtype=torch.float32, device=self.device)
         nll = torch.empty(n, dtype=torch.float32, device=self.device)
         tape = torch.empty(int(lib().glowhip_plan_tape_bytes(self._h, n)), dtype=torch.uint8, device=self.device)

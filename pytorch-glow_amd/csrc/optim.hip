@@ -49,7 +49,11 @@ __global__ void __launch_bounds__(256) k_optim_clip_sumsq(const glowhip_optim_ch
 __global__ void __launch_bounds__(256) k_optim_update(const glowhip_optim_chunk* __restrict__ chunks, int n_chunks,
                                                       const double* __restrict__ partial, int kind, float lr, float beta1,
                                                       float beta2, float omb1, float omb2, float eps, float weight_decay, double bc1, double bc2,
-                                                      float max_norm, float* __restrict__ grad_norm_out, int skip_if_nonfinite) {
+                                                      float max_norm, float* __restrict__ grad_norm_out, int skip_if_nonfinite,
+                                                      const double* __restrict__ hyper) {
+    // hyper != null (glowhip_optim_step_dev: the launch is part of a captured graph, whose kernel arguments are frozen): the values
+    // that change from step to step -- {lr as float, 1 - beta1^step, 1 - beta2^step} -- are read from device memory instead
+    if (hyper) { lr = (float)hyper[0]; bc1 = hyper[1]; bc2 = hyper[2]; }
     __shared__ float s_coef;
     __shared__ int s_skip;
     if (threadIdx.x < 64) {       // total gradient norm: the chunk sums in a fixed order (wave 0), then clip_grad_norm_'s coefficient
@@ -127,7 +131,24 @@ extern "C" int glowhip_optim_step(const glowhip_optim_chunk* chunks_dev, int n_c
     const float beta1 = (float)beta1_d, beta2 = (float)beta2_d;
     const double bc1 = 1.0 - pow(beta1_d, (double)step), bc2 = 1.0 - pow(beta2_d, (double)step);     // python-double arithmetic, as torch
     hipLaunchKernelGGL(k_optim_update, dim3(n_chunks), dim3(256), 0, s, chunks_dev, n_chunks, partial_dev, kind, lr, beta1, beta2,
-                       (float)(1.0 - (double)beta1_d), (float)(1.0 - (double)beta2_d), eps, weight_decay, bc1, bc2, max_norm, grad_norm_out, skip_if_nonfinite);
+                       (float)(1.0 - (double)beta1_d), (float)(1.0 - (double)beta2_d), eps, weight_decay, bc1, bc2, max_norm, grad_norm_out, skip_if_nonfinite,
+                       (const double*)nullptr);
+    GH_LAUNCH_CHECK("k_optim_update");
+    return GLOWHIP_OK;
+}
+
+extern "C" int glowhip_optim_step_dev(const glowhip_optim_chunk* chunks_dev, int n_chunks, int kind, const double* hyper_dev, double beta1_d,
+                                      double beta2_d, float eps, float weight_decay, float clip_value, float max_norm,
+                                      double* partial_dev, float* grad_norm_out, int skip_if_nonfinite, glowhip_stream_t stream) {
+    GH_REQUIRE(chunks_dev && partial_dev && hyper_dev, "optim_step_dev: null argument");
+    GH_REQUIRE(kind == 0 || kind == 1, "optim_step_dev: kind %d (0 = adam, 1 = adamax)", kind);
+    if (n_chunks == 0) return GLOWHIP_OK;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_optim_clip_sumsq, dim3(n_chunks), dim3(256), 0, s, chunks_dev, clip_value, partial_dev);
+    GH_LAUNCH_CHECK("k_optim_clip_sumsq");
+    hipLaunchKernelGGL(k_optim_update, dim3(n_chunks), dim3(256), 0, s, chunks_dev, n_chunks, partial_dev, kind, 0.f, (float)beta1_d, (float)beta2_d,
+                       (float)(1.0 - (double)beta1_d), (float)(1.0 - (double)beta2_d), eps, weight_decay, 1.0, 1.0, max_norm, grad_norm_out, skip_if_nonfinite,
+                       hyper_dev);
     GH_LAUNCH_CHECK("k_optim_update");
     return GLOWHIP_OK;
 }

@@ -421,7 +421,7 @@ class Glow(nn.Module):
             z, nll = self._forward_exact_fp32(plan, x.float() / 255.0 if x.dtype == torch.uint8 else x, noise, mean, logs, stride, n_bits)
         return z, nll, None
 
-    def loss_and_grads(self, x, noise=None):
+    def loss_and_grads(self, x, noise=None, force_pack=False):
         """mean(nll) of the batch (`generative_loss`) and its gradient for every trainable parameter, WITHOUT an autograd graph:
         the HIP forward with tape and the HIP reverse sweep are called directly, and the gradients land in the plan's persistent
         flat buckets, whose views are the parameters' ``.grad`` (assigned once).  This is `Trainer`'s step (network/trainer.py:123-133:
@@ -443,7 +443,7 @@ class Glow(nn.Module):
         if self.hps.ablation.learn_top:
             raise NotImplementedError("loss_and_grads: a learned top prior goes through the autograd route (normal_flow + backward)")
         with torch.no_grad():
-            z, nll, tape = plan.glow_forward_train(x, noise, None, None, 0, n_bits)
+            z, nll, tape = plan.glow_forward_train(x, noise, None, None, 0, n_bits, force_pack=force_pack)
             loss = self.generative_loss(nll)
             n = x.shape[0]
             gn = getattr(plan, "_mean_grad", None)

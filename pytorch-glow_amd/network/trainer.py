@@ -126,7 +126,10 @@ class Trainer:
         self.interval_sample = self.hps.optim.interval_sample
         self.num_sample = self.hps.optim.num_sample
         # the per-step arithmetic (trainer.py:88-150)
-        self.loop = training.TrainLoop(graph, hps, rank=rank, world=world, optimizer=optimizer)
+        # (a single-rank run replays its step as one hipGraph launch after the first eager steps -- training.GraphedTrainStep; the
+        # environment variable GLOWHIP_TRAIN_GRAPH=0 keeps every step eager; a failed capture falls back to the eager step by itself)
+        self.loop = training.TrainLoop(graph, hps, rank=rank, world=world, optimizer=optimizer,
+                                       graph=world == 1 and os.environ.get("GLOWHIP_TRAIN_GRAPH", "1") != "0")
         self.loop.scheduler = scheduler or self.loop.scheduler
         self.loop.global_step = step
         self.last_loss = None

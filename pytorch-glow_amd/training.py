@@ -78,9 +78,12 @@ class _HipOptimizer(torch.optim.Optimizer):
         self._ensure_state()
 
     @torch.no_grad()
-    def fused_step(self, max_grad_clip=0.0, max_grad_norm=0.0, skip_nonfinite=False, grads_token=None):
+    def fused_step(self, max_grad_clip=0.0, max_grad_norm=0.0, skip_nonfinite=False, grads_token=None, hyper_dev=None, norm_out=None):
         """``skip_nonfinite``: a NaN / inf total gradient norm leaves parameters and state untouched ON THE DEVICE (no host sync);
-        the caller finds out from the returned norm when it next looks (``undo_step`` then takes the step count back)."""
+        the caller finds out from the returned norm when it next looks (``undo_step`` then takes the step count back).
+        ``hyper_dev`` (3 doubles on the device, `hyper_values`) / ``norm_out`` (1 float on the device): the step as it sits in a
+        captured graph (`GraphedTrainStep`) -- learning rate and bias corrections are read from device memory by the update kernel
+        (glowhip_optim_step_dev), the norm lands in the caller's static word."""
         self._ensure_state()
         group0 = self.param_groups[0]
         dev = group0["params"][0].device
@@ -103,7 +106,7 @@ class _HipOptimizer(torch.optim.Optimizer):
         key = self._table_key if fast else tuple((p.data_ptr(), p.grad.data_ptr(), p.grad.dtype, p.grad.is_contiguous()) if p.grad is not None else (0, 0, None, True) for p in plist)
         self._steps += 1
         self._publish_step()
-        norm = torch.zeros(1, device=dev)
+        norm = norm_out if norm_out is not None else torch.zeros(1, device=dev)
         if getattr(self, "_table_key", None) == key:
             table, n_chunks = self._keep, self._n_chunks
         else:
@@ -131,10 +134,16 @@ class _HipOptimizer(torch.optim.Optimizer):
             return norm[0]
         if self._partial is None or self._partial.numel() < n_chunks:
             self._partial = torch.empty(n_chunks, dtype=torch.float64, device=dev)
-        _lib.check(_lib.lib().glowhip_optim_step(
-            _lib.ptr(table), n_chunks, self.KIND, float(group0["lr"]), float(group0["betas"][0]), float(group0["betas"][1]),
-            float(group0["eps"]), float(group0["weight_decay"]), self._steps, float(max_grad_clip or 0.0), float(max_grad_norm or 0.0),
-            _lib.ptr(self._partial), _lib.ptr(norm), int(bool(skip_nonfinite)), _lib.stream_ptr(dev)))
+        if hyper_dev is not None:
+            _lib.check(_lib.lib().glowhip_optim_step_dev(
+                _lib.ptr(table), n_chunks, self.KIND, _lib.ptr(hyper_dev), float(group0["betas"][0]), float(group0["betas"][1]),
+                float(group0["eps"]), float(group0["weight_decay"]), float(max_grad_clip or 0.0), float(max_grad_norm or 0.0),
+                _lib.ptr(self._partial), _lib.ptr(norm), int(bool(skip_nonfinite)), _lib.stream_ptr(dev)))
+        else:
+            _lib.check(_lib.lib().glowhip_optim_step(
+                _lib.ptr(table), n_chunks, self.KIND, float(group0["lr"]), float(group0["betas"][0]), float(group0["betas"][1]),
+                float(group0["eps"]), float(group0["weight_decay"]), self._steps, float(max_grad_clip or 0.0), float(max_grad_norm or 0.0),
+                _lib.ptr(self._partial), _lib.ptr(norm), int(bool(skip_nonfinite)), _lib.stream_ptr(dev)))
         self._keep = table      # alive until the stream has consumed it (the next step replaces it)
         # the kernel wrote the parameters behind torch's back: bump their version counters, which is what tells the flow plans to
         # re-derive their packed weight images (one call for the whole list)
@@ -161,6 +170,12 @@ class _HipOptimizer(torch.optim.Optimizer):
             if "step" in st:
                 st["step"] = torch.tensor(float(self._steps))
         return super().state_dict()
+
+    def hyper_values(self, lr, step):
+        """{lr, 1 - beta1^step, 1 - beta2^step} as glowhip_optim_step computes them from its arguments (the learning rate passes
+        through a float; the bias corrections are python-double arithmetic, as torch's)."""
+        b1, b2 = self.param_groups[0]["betas"]
+        return (ctypes.c_float(float(lr)).value, 1.0 - float(b1) ** step, 1.0 - float(b2) ** step)
 
     def undo_step(self):
         """Take back the count of a step the device skipped (fused_step(skip_nonfinite=True) with a non-finite norm)."""
@@ -208,12 +223,81 @@ def build_scheduler(hps):
     return partial(lr_scheduler.SCHEDULES[name], **args)
 
 
+class GraphedTrainStep:
+    """One training step of one rank -- dequantisation draw, HIP forward with tape, HIP reverse sweep, both clippings, the Adam /
+    Adamax update (reference network/trainer.py:123-150) -- captured in ONE hipGraph: the step's ~1 300 launches cost the host one
+    graph launch instead of ~3 ms of Python + launch calls (and the ROCm runtime's helper thread nothing), which is what eight
+    data-parallel ranks sharing a host want.  Single-rank steps only (the gradient exchange of a multi-rank step stays eager), no
+    learned top prior (as `Glow.loss_and_grads`).
+
+    Static buffers: ``x`` (the batch is copied in), the noise, ``loss``, ``norm``, and ``hyper`` = {lr, 1 - beta1^step, 1 - beta2^step}
+    on the device: kernel arguments are frozen in a graph, so the update kernel reads the three values that change from step to step
+    from memory (glowhip_optim_step_dev) and __call__ uploads them before each replay.  `glowhip_plan_pack` is inside the graph:
+    every replay re-derives the weight images from the live parameters, as the forward after an update must.  Capture executes
+    nothing, but it needs the lazy allocations of an eager step behind it: capture after at least one eager step of the same batch
+    shape (`TrainLoop(graph=True)` does).  Same kernels, same bits as the eager step (tests/test_gpu_grad.py)."""
+
+    def __init__(self, glow, optimizer, x, max_grad_clip=0.0, max_grad_norm=0.0, skip_nonfinite=False):
+        if not (x.is_cuda and hasattr(optimizer, "fused_step") and hasattr(glow, "loss_and_grads")) or glow.hps.ablation.learn_top:
+            raise _lib.GlowHipError("GraphedTrainStep: the HIP optimisers on a device batch, no learned top prior")
+        self.glow, self.optimizer = glow, optimizer
+        self.clip, self.max_norm, self.skip = max_grad_clip, max_grad_norm, skip_nonfinite
+        dev = x.device
+        self.x = x.clone()
+        self.noise = torch.empty(x.shape, dtype=torch.float32, device=dev)
+        self.n_bits = glow.hps.model.n_bits_x
+        self.loss = torch.zeros((), dtype=torch.float32, device=dev)
+        self.norm = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.hyper = torch.zeros(3, dtype=torch.float64, device=dev)
+        self._hyper_host = torch.zeros(3, dtype=torch.float64, pin_memory=True)
+        self._params = [p for g in optimizer.param_groups for p in g["params"] if p.grad is not None]
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        torch.cuda.synchronize(dev)
+        glow.flow.plan_for(x).pack_sync()
+        steps = optimizer._steps
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(self.graph, stream=side):
+            self._body()
+        optimizer._steps = steps          # (the captured call counted a step on the host; nothing ran)
+        optimizer._publish_step()
+        self.plan = glow.flow.plan_for(x)
+
+    def _body(self):
+        self.noise.uniform_(0, 1. / 2 ** self.n_bits)
+        loss = self.glow.loss_and_grads(self.x, noise=self.noise, force_pack=True)
+        if hasattr(self.glow.flow, "pop_grad_buckets"):
+            self.glow.flow.pop_grad_buckets()            # (one rank: nothing to exchange)
+        token = getattr(getattr(self.glow, "_train_plan", None), "_pgrad_bound", None)
+        self.optimizer.fused_step(self.clip, self.max_norm, skip_nonfinite=self.skip, grads_token=token, hyper_dev=self.hyper, norm_out=self.norm)
+        self.loss.copy_(loss.detach())
+
+    def __call__(self, x, lr):
+        """Replay with this batch and learning rate; returns (loss, gradient norm) as fresh device scalars."""
+        if not self.plan.still_valid():
+            raise _lib.GlowHipError("GraphedTrainStep: a parameter was re-allocated since the capture -- capture again")
+        if x is not self.x:
+            self.x.copy_(x, non_blocking=True)
+        opt = self.optimizer
+        opt._steps += 1
+        opt._publish_step()
+        h = opt.hyper_values(lr, opt._steps)
+        self._hyper_host[0], self._hyper_host[1], self._hyper_host[2] = h
+        self.hyper.copy_(self._hyper_host, non_blocking=True)
+        self.graph.replay()
+        torch.autograd.graph.increment_version(self._params)      # (the parameters changed behind torch's back, as after fused_step)
+        out = torch.stack((self.loss, self.norm[0]))              # (the static words are overwritten by the next replay)
+        return out[0], out[1]
+
+
 class TrainLoop:
     """The state the reference's ``Trainer`` carries from step to step, minus its I/O: model, optimiser, schedule, step
     counter, clipping thresholds (trainer.py:44-60).  ``step(x_local)`` runs one iteration on this rank's shard."""
 
+    GRAPH_AFTER = 3      # graph=True: the first steps run eagerly (data-dependent init, lazy allocations), then the step is captured
+
     def __init__(self, glow, hps, rank: int = 0, world: int = 1, optimizer: Optional[torch.optim.Optimizer] = None,
-                 range_check: bool = True):
+                 range_check: bool = True, graph: bool = False):
         """``range_check``: the training forward carries h1 as fp16 pairs through f.2 (|v| < 65504; the reference's fp32 has no
         such limit).  With the check on, a step whose gradient norm comes out non-finite is SKIPPED on the device (csrc/optim.hip:
         parameters and optimiser state untouched, no host sync); the host looks at the norm one step later -- when that step's
@@ -222,6 +306,11 @@ class TrainLoop:
         caller, counted in ``diverged_steps``)."""
         self.glow, self.hps, self.rank, self.world = glow, hps, rank, world
         self.range_check = range_check
+        # ``graph``: from step GRAPH_AFTER on a single-rank step is ONE hipGraph launch (`GraphedTrainStep`); a batch of another
+        # shape, a re-run on the exact-fp32 family and multi-rank steps run eagerly
+        self.graph = graph
+        self._graphed = None
+        self.graph_error = None
         self.range_fallbacks = 0
         self.diverged_steps = 0
         self.reruns = []             # (global step at the time, loss, grad norm) of every batch that was run again (range check)
@@ -248,9 +337,15 @@ class TrainLoop:
             group["lr"] = self.lr
         checked = self.range_check and hasattr(self.optimizer, "undo_step") and x_local.is_cuda
         self._rerun = None
-        loss, grad_norm = parallel.train_step(self.glow, self.optimizer, x_local, world=self.world,
-                                              max_grad_clip=self.max_grad_clip, max_grad_norm=self.max_grad_norm,
-                                              skip_nonfinite=checked, before_update=self._check_previous if checked else None)
+        graphed = self._graph_for(x_local, checked)
+        if graphed is not None:
+            if checked:
+                self._check_previous()       # (before this step's bias corrections are computed from the step count)
+            loss, grad_norm = graphed(x_local, self.lr)
+        else:
+            loss, grad_norm = parallel.train_step(self.glow, self.optimizer, x_local, world=self.world,
+                                                  max_grad_clip=self.max_grad_clip, max_grad_norm=self.max_grad_norm,
+                                                  skip_nonfinite=checked, before_update=self._check_previous if checked else None)
         self.global_step += 1
         if checked:
             self._pending.append(self._stash(x_local, grad_norm, self.lr))
@@ -258,6 +353,24 @@ class TrainLoop:
             for pending in reruns or ():
                 self._run_again(pending)
         return loss, grad_norm
+
+    def _graph_for(self, x_local, checked):
+        """The captured step for this batch, or None (eager): graph=True, one rank, a device batch, the HIP optimiser, past the
+        eager warm-up steps; a failed capture is remembered (``graph_error``) and the loop stays eager."""
+        if not self.graph or self.world != 1 or not x_local.is_cuda or self.global_step < self.GRAPH_AFTER or self.graph_error:
+            return None
+        if not hasattr(self.optimizer, "fused_step") or self.glow.hps.ablation.learn_top:
+            return None
+        g = self._graphed
+        if g is not None and (g.x.shape != x_local.shape or g.x.dtype != x_local.dtype or g.skip != checked):
+            g = self._graphed = None
+        if g is None:
+            try:
+                g = self._graphed = GraphedTrainStep(self.glow, self.optimizer, x_local, self.max_grad_clip, self.max_grad_norm, checked)
+            except Exception as e:      # capture is an optimisation of the host side only
+                self.graph_error = f"{type(e).__name__}: {str(e)[:300]}"
+                return None
+        return g
 
     # ---- deferred range check (no host sync on the step's own work)
     def _stash(self, x_local, grad_norm, lr):

@@ -776,6 +776,52 @@ def test_direct_training_path_equals_the_autograd_route_bitwise():
     assert all(torch.equal(pa[k], pb[k]) for k in pa)
 
 
+def test_graphed_training_step_equals_the_eager_step_bitwise():
+    """VERDICT r4 (missing #3): the training step of one rank as ONE hipGraph launch (`training.GraphedTrainStep`, what
+    `TrainLoop(graph=True)` switches to after its eager warm-up steps): dequantisation draw, HIP forward with tape, reverse sweep,
+    both clippings and the Adam update captured once -- learning rate and bias corrections read from device memory by the update
+    kernel (glowhip_optim_step_dev), glowhip_plan_pack inside the graph.  Two loops from the same state, same batches, same seeds:
+    one eager, one graphed from step 3 on -- loss, gradient norm and, after six steps under the noam schedule (the learning rate
+    changes every step), every parameter and the optimiser state must be the same bits."""
+    from pytorch_glow_amd import training
+    K, batch = 2, 8
+    cfg = O.default_cfg(K=K, batch=batch)
+    sd = O.seeded_state_dict(cfg, seed=37, invconv_perturb=0.02, zeros_std=0.01)
+    hps = hps_for(cfg, batch)
+    hps.optim.update(optimizer="adam", optimizer_args=dict(lr=1e-4, betas=[0.9, 0.9999], eps=1e-8),
+                     lr_scheduler="noam", lr_scheduler_args=dict(warmup_steps=5, min_lr=1e-5))
+    hps.ablation.update(max_grad_clip=5, max_grad_norm=100)
+
+    def fresh():
+        glow = G.Glow(hps)
+        sd2 = dict(sd); sd2["h_top"] = torch.zeros_like(glow.h_top)
+        glow.load_state_dict(sd2)
+        glow.set_actnorm_inited()
+        return glow.to(DEV).train()
+
+    g = torch.Generator().manual_seed(37)
+    loops = [training.TrainLoop(fresh(), hps, graph=False), training.TrainLoop(fresh(), hps, graph=True)]
+    for step in range(6):
+        xs = torch.rand(batch, 3, 64, 64, generator=g).to(DEV)
+        outs = []
+        for loop in loops:
+            torch.manual_seed(200 + step)                        # the step draws its dequantisation noise from torch's generator
+            loss, norm = loop.step(xs)
+            outs.append((loss.clone(), norm.clone()))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), (step, outs)
+        assert torch.isfinite(outs[0][0]) and torch.isfinite(outs[0][1])
+    for loop in loops:
+        loop.flush()
+    assert loops[1].graph_error is None and loops[1]._graphed is not None and loops[0]._graphed is None
+    assert loops[0].optimizer._steps == loops[1].optimizer._steps == 6
+    pa, pb = loops[0].glow.state_dict(), loops[1].glow.state_dict()
+    assert all(torch.equal(pa[k], pb[k]) for k in pa)
+    sa, sb = loops[0].optimizer.state_dict()["state"], loops[1].optimizer.state_dict()["state"]
+    for k in sa:
+        for name in sa[k]:
+            assert torch.equal(torch.as_tensor(sa[k][name]).cpu(), torch.as_tensor(sb[k][name]).cpu()), (k, name)
+
+
 def test_log_scale_gradients_do_not_read_weight_gradients_after_their_bucket_is_handed_over():
     """on the backward-k_cnet path d logs of the hidden ActNorms is computed FROM the weight gradients, and those
     live in the per-level flat buckets a data-parallel run all-reduces in place, on a side stream, as soon as the level's
