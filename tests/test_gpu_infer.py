@@ -132,6 +132,9 @@ def test_trainer_runs_train_py_as_written(tmp_path):
     trainer.loop.step = lambda x: (lambda r: (first.append(r[0].item()), r)[1])(orig(x))
     trainer.train()
     assert trainer.step == 8 and len(first) == 8 and all(np.isfinite(first))
+    # (one rank: from its fourth step on the step was one hipGraph launch -- training.GraphedTrainStep -- with validation, a snapshot and
+    # sampling in between)
+    assert trainer.loop.graph_error is None and trainer.loop._graphed is not None, trainer.loop.graph_error
     assert min(first[-2:]) < first[0], first
     sub = state["result_subdir"]
     assert os.path.exists(os.path.join(sub, "network-snapshot-000004.pth")) and os.path.exists(os.path.join(sub, "all_scalars.json"))
