@@ -152,6 +152,9 @@ class FlowPlan:
         check(lib().glowhip_plan_pack_for(self._h, ptr(self.packed), self.packed.numel(), use, stream_ptr(self.device)))
         self._packed_version = version
         self._packed_use = use
+        # (a pack rebuilds the plan's host-side job tables, which the copy nodes of a CAPTURED pack read through the addresses of
+        # capture time: whoever replays a graph with this plan's pack inside compares this count -- training.GraphedTrainStep)
+        self._pack_epoch = getattr(self, "_pack_epoch", 0) + 1
 
     def ensure_packed(self, force: bool = False, use: int = 1) -> None:
         """Re-derive the packed data when the parameters changed since the last pack (or `force`), or when images `use` asks

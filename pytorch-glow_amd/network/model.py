@@ -311,6 +311,7 @@ class GraphedForward:
         with torch.no_grad(), torch.cuda.graph(self.graph, stream=side):
             self._body()
         self._version = plan._version_signature()
+        self._pack_epoch = getattr(plan, "_pack_epoch", 0)
 
     def _body(self):
         self.noise.uniform_(0, 1. / 2 ** self.n_bits)
@@ -324,6 +325,11 @@ class GraphedForward:
             raise _lib.GlowHipError("capture_forward: a parameter was re-allocated since the capture -- capture again")
         if not self.repack and self.plan._version_signature() != self._version:
             raise _lib.GlowHipError("capture_forward(repack=False): the parameters changed since the capture")
+        if self.repack and getattr(self.plan, "_pack_epoch", 0) != self._pack_epoch:
+            # (an eager pack rebuilds the plan's host-side job tables; the captured pack's copy nodes read them through the addresses
+            # of capture time -- a replay after a re-run on the other kernel family faulted on a host address when the training
+            # step's graph first met this, training.GraphedTrainStep)
+            raise _lib.GlowHipError("capture_forward: the plan was packed eagerly since the capture -- capture again")
         self.graph.replay()
         return self.z, self.nll
 

@@ -262,6 +262,25 @@ class GraphedTrainStep:
         optimizer._steps = steps          # (the captured call counted a step on the host; nothing ran)
         optimizer._publish_step()
         self.plan = glow.flow.plan_for(x)
+        self._buffers = self._buffer_signature()
+
+    def _buffer_signature(self):
+        """Addresses of everything the captured launches reach through the plan and the optimiser and that an EAGER call in between
+        may re-allocate (the workspaces grow with the batch size and differ by kernel family; the optimiser's table and scratch
+        follow the gradients): a replay over a moved buffer would write through a stale pointer."""
+        plan, opt = self.plan, self.optimizer
+        ptr = lambda t: t.data_ptr() if isinstance(t, torch.Tensor) else 0
+        pg = getattr(plan, "_pgrad", None)
+        return (ptr(plan.packed), ptr(getattr(plan, "_ws", None)), ptr(getattr(plan, "_tws", None)),
+                tuple(ptr(f) for f in pg[0]) if pg else (), ptr(getattr(opt, "_partial", None)), ptr(getattr(opt, "_keep", None)),
+                # an eager pack of this plan since the capture (a validation forward, a re-run on the other kernel family): it
+                # rebuilt the host-side job tables the captured pack's copy nodes read (measured: a replay after a re-run on the
+                # exact-fp32 family faulted on a host address)
+                getattr(plan, "_pack_epoch", 0))
+
+    def valid(self):
+        """False once a parameter or one of the buffers above moved: capture again (after an eager step)."""
+        return self.plan.still_valid() and self._buffer_signature() == self._buffers
 
     def _body(self):
         self.noise.uniform_(0, 1. / 2 ** self.n_bits)
@@ -274,8 +293,8 @@ class GraphedTrainStep:
 
     def __call__(self, x, lr):
         """Replay with this batch and learning rate; returns (loss, gradient norm) as fresh device scalars."""
-        if not self.plan.still_valid():
-            raise _lib.GlowHipError("GraphedTrainStep: a parameter was re-allocated since the capture -- capture again")
+        if not self.valid():
+            raise _lib.GlowHipError("GraphedTrainStep: a parameter or a workspace was re-allocated since the capture -- capture again")
         if x is not self.x:
             self.x.copy_(x, non_blocking=True)
         opt = self.optimizer
@@ -311,6 +330,7 @@ class TrainLoop:
         self.graph = graph
         self._graphed = None
         self.graph_error = None
+        self.graph_recaptures = 0
         self.range_fallbacks = 0
         self.diverged_steps = 0
         self.reruns = []             # (global step at the time, loss, grad norm) of every batch that was run again (range check)
@@ -364,6 +384,12 @@ class TrainLoop:
         g = self._graphed
         if g is not None and (g.x.shape != x_local.shape or g.x.dtype != x_local.dtype or g.skip != checked):
             g = self._graphed = None
+        if g is not None and not g.valid():
+            # an eager call in between (a validation forward, a re-run on the other kernel family) packed this plan again or moved a
+            # workspace: this step runs eagerly -- it brings the plan back to the training step's state -- and the next one captures again
+            self._graphed = None
+            self.graph_recaptures += 1
+            return None
         if g is None:
             try:
                 g = self._graphed = GraphedTrainStep(self.glow, self.optimizer, x_local, self.max_grad_clip, self.max_grad_norm, checked)

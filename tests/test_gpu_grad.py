@@ -717,6 +717,61 @@ def test_training_overflow_is_skipped_on_device_then_rerun_on_exact_fp32():
     assert glow.flow.plan_for(x.to(DEV)).family == 0 and loop.optimizer._steps == 1
 
 
+def test_overflow_inside_a_graphed_training_step_is_skipped_and_rerun():
+    """The range check around `training.GraphedTrainStep`: step 0 runs eagerly on a healthy model, then f.0's ActNorm scale is blown up
+    in place (h1 ~ 3e5: beyond the fp16 pairs, finite in fp32) and step 1 is a graph replay -- the device-side skip sits inside the
+    graph (parameters and optimiser state untouched, the step count taken back on the host before the next bias corrections), the
+    deferred check finds the non-finite norm and re-runs the batch EAGERLY on the exact-fp32 family, and the loop carries on graphed
+    (the plan is back on the product family, the weight images are re-derived inside the graph; if the eager call moved a workspace
+    the stale graph is dropped, one step runs eagerly and the step is captured again -- never replayed over a stale pointer)."""
+    from pytorch_glow_amd import training
+    torch.manual_seed(0)
+    cfg = O.default_cfg(image_shape=(16, 16, 3), hidden_channels=128, K=1, L=1, batch=4)
+    sd = O.seeded_state_dict(cfg, seed=3, zeros_std=1e-3)
+    hps = hps_for(cfg, 4)
+    hps.optim.update(optimizer="adam", optimizer_args=dict(lr=1e-4, betas=[0.9, 0.9999], eps=1e-8),
+                     lr_scheduler="noam", lr_scheduler_args=dict(warmup_steps=5, min_lr=1e-5))
+    hps.ablation.update(max_grad_clip=5, max_grad_norm=100)
+    glow = G.Glow(hps)
+    sd["h_top"] = torch.zeros_like(glow.h_top)
+    glow.load_state_dict(sd)
+    glow.set_actnorm_inited()
+    glow = glow.to(DEV)
+    g = torch.Generator().manual_seed(9)
+    x = torch.rand(4, 3, 16, 16, generator=g).to(DEV)
+    loop = training.TrainLoop(glow, hps, graph=True)
+    loop.GRAPH_AFTER = 1
+    loss0, norm0 = loop.step(x)
+    assert torch.isfinite(loss0) and torch.isfinite(norm0) and loop._graphed is None
+    params = dict(glow.named_parameters())
+    with torch.no_grad():
+        params["flow.layers.1.f.0.actnorm.logs"].add_(float(np.log(3e5)) / 3.0)
+        params["flow.layers.1.f.2.actnorm.logs"].sub_(float(np.log(3e5)) / 3.0)
+    before = {k: v.detach().clone() for k, v in glow.state_dict().items()}
+    loss1, norm1 = loop.step(x)
+    assert loop._graphed is not None and loop.graph_error is None, loop.graph_error
+    assert not torch.isfinite(loss1) and not torch.isfinite(norm1), (loss1, norm1)
+    after = glow.state_dict()
+    assert all(torch.equal(before[k], after[k]) for k in before), "a skipped step must not touch the parameters"
+    loop.flush()
+    assert loop.range_fallbacks == 1 and loop.diverged_steps == 0 and loop.optimizer._steps == 2
+    loss_r, norm_r = loop.last_rerun
+    assert torch.isfinite(loss_r) and torch.isfinite(norm_r)
+    after = glow.state_dict()
+    assert any(not torch.equal(before[k], after[k]) for k in before if k != "h_top"), "the re-run applies the update"
+    assert glow.flow.plan_for(x).family == 0
+    # the eager re-run packed the plan again (for the other family): the loop notices (GraphedTrainStep.valid), runs one step eagerly
+    # and captures again -- a replay of the old graph read freed host memory through its copy nodes when this was first tried; the
+    # model still overflows, so every one of these steps is skipped and re-run again
+    for _ in range(3):
+        loss2, norm2 = loop.step(x)
+        assert not torch.isfinite(norm2)
+        loop.flush()
+    assert loop.graph_error is None and loop.graph_recaptures >= 1, (loop.graph_error, loop.graph_recaptures)
+    assert loop.range_fallbacks == 4 and loop.optimizer._steps == 5
+    assert all(torch.isfinite(v).all() for v in glow.state_dict().values())
+
+
 def test_direct_training_path_equals_the_autograd_route_bitwise():
     """VERDICT r4 #4c: `Glow.loss_and_grads` (HIP forward + reverse sweep called directly, gradients in the plan's persistent buckets,
     no autograd graph -- what parallel.train_step runs) against the reference-shaped route `normal_flow` + `loss.backward()`:
