@@ -304,7 +304,7 @@ def secondary_workloads(G, util, parallel, device, steps=3, warmup=3):
         for mode in modes:
             t_wall = time.perf_counter()
             if wl is None or mode == "train":
-                wl = setup_workload(G, util, parallel, device, cfg_name, mode, B, 0, 1, repack=(mode == "forward"))
+                wl = setup_workload(G, util, parallel, device, cfg_name, mode, B, 0, 1, repack=(mode == "forward"), graph=(mode == "train"))
                 step = wl["step"]
             else:       # the same model and batch in another mode (config E: forward, then sampling)
                 plan, glow = wl["plan"], wl["glow"]
