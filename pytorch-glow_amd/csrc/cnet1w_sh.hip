@@ -17,11 +17,14 @@
 //     one wave per SIMD issues up to five other instructions in the shadow of each MFMA (MI355X_MICROARCH.md), so the matrix pipe
 //     stays busy through what used to be separate phases.
 // Output: the partial sums `hpart` / `hup` / `hdn` of k_cnet at MS = 1 with 128-pixel tiles -- k_cfinish does not know the difference.
-// Product forward / inverse and the training forward (TAPE); no backward launch, no chained prologue, one group of f.4 output channels.
+// Instances (launch_cnet1w): product forward / inverse, the training step's taping forward (MODE 1) and its input-gradient launch
+// (MODE 2: the transposed network) for the C = 12 levels; no chained prologue, one group of f.4 output channels.
 // MS = 2: the h2 rows of a 128-pixel tile split over TWO workgroups (grid.y), each computing all of h1 again (f.0 is the small
 // layer) and half of f.2 / a K-half of f.4 -- for the levels whose 128-pixel tiles alone leave half the CUs idle (C = 24 at 16 x 16
 // pixels and batch 64: 128 tiles).  Weight bytes per MFMA stay those of a 128-pixel tile (a 64-pixel tile needs twice that, and at
 // one workgroup per CU the launch is then bound by the L2 -> LDS stream); the partial sums are k_cnet's MS = 2 layout.
+// (Measured 3 % slower than k_cnet's 64-pixel tiles where it applies -- each half repeats f.0, 29 % of its MFMAs -- and therefore
+// selected only behind the debug switch 0x20000: cnet_sh.hip cnet_select.)
 #include "sh.h"
 #include <algorithm>
 #include <type_traits>
