@@ -325,6 +325,7 @@ int glowhip_plan_timing_read(glowhip_plan* plan, glowhip_timing_record* out, int
  * k_cnet;
  * | 0x2000000 = cnet with 128-pixel tiles only, | 0x4000000 = 64-pixel tiles wherever supported,
  * | 0x10000 = no k_cnet1w (the one-wave-per-SIMD coupling-network kernel of csrc/cnet1w_sh.hip; k_cnet takes its launches: A/B),
+ * | 0x80000 = f.2's weight-gradient GEMM on 128-column tiles at every level (no k_wgrad_gemm_ps512: A/B),
  * | 0x40000 = no backward instance of k_cnet1w (the level-1 input-gradient launch back on k_cnet's 64-pixel tiles: A/B),
  * | 0x20000 = the row-split instance of k_cnet1w where it applies (C = 24 levels with 112 .. tiles of 128 pixels; off by default:
  *   measured slower than k_cnet's 64-pixel tiles there; parity tests and A/B),

@@ -152,9 +152,15 @@ class FlowPlan:
         check(lib().glowhip_plan_pack_for(self._h, ptr(self.packed), self.packed.numel(), use, stream_ptr(self.device)))
         self._packed_version = version
         self._packed_use = use
-        # (a pack rebuilds the plan's host-side job tables, which the copy nodes of a CAPTURED pack read through the addresses of
-        # capture time: whoever replays a graph with this plan's pack inside compares this count -- training.GraphedTrainStep)
-        self._pack_epoch = getattr(self, "_pack_epoch", 0) + 1
+        # (a pack for the OTHER kernel family rebuilds the plan's host-side job tables with other contents and sizes -- and the copy
+        # nodes of a CAPTURED pack read them through the addresses of capture time: a replay of the training step's graph after a
+        # re-run on the exact-fp32 family faulted on a host address.  Whoever replays a graph with this plan's pack inside compares
+        # this count -- training.GraphedTrainStep, GraphedForward.  Packs of the same family, whatever their image set, keep their
+        # tables in place: tests/test_gpu_fused.py test_captured_forward_survives_packs_of_other_use_masks.)
+        key = self.family
+        if key != getattr(self, "_pack_key", None):
+            self._pack_key = key
+            self._pack_epoch = getattr(self, "_pack_epoch", 0) + 1
 
     def ensure_packed(self, force: bool = False, use: int = 1) -> None:
         """Re-derive the packed data when the parameters changed since the last pack (or `force`), or when images `use` asks

@@ -75,6 +75,7 @@ void plan_disable_sh(int off);   // testing hook (plan.hip)
 void plan_pack_one_stream(int on);   // testing hook (plan.hip): glowhip_plan_pack without its side-stream fork
 void plan_train_disable_sh(int off);   // testing hook (plan_train.hip)
 void plan_train_disable_cnet(int off); // testing hook (plan_train.hip): the training forward without the taping k_cnet
+void wgrad_force_narrow(int on);          // testing hook (wgrad_mfma.hip): f.2's weight-gradient GEMM on 128-column tiles everywhere (A/B)
 void plan_train_disable_cnet_bwd(int off); // testing hook (plan_train.hip): the input-gradient chain without the backward k_cnet
 int launch_tail_dma_narrow(const TailConvArgs& a, int paired, hipStream_t s, int TP, int Y);  // W in {8,16}
 int launch_tail_dma_wide(const TailConvArgs& a, int paired, hipStream_t s, int TP, int Y);    // W in {32,64,128}  // testing hook: 0 = automatic, else 16/32/64/128 pixels per block

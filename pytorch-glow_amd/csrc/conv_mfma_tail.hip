@@ -351,6 +351,7 @@ void conv_mfma_tail_force_tile(int v) {
     plan_disable_sh(((v & 0x800) ? 1 : 0) | ((v & 0x8000) ? 16 : 0));
     cnet_force((v >> 22) & 7, ((v >> 25) & 15) | ((v & 0x10000) ? 16 : 0) | ((v & 0x20000) ? 32 : 0) | ((v & 0x40000) ? 64 : 0));   // 0x40000: no backward instance of k_cnet1w;   // 0x10000: no k_cnet1w (one wave per SIMD); 0x20000: its row-split instance where it applies (off by default: measured slower);   // bits 22..24: row splits; bit 25: 128-pixel tiles only, bit 26: 64-pixel tiles, bit 27: finishing chained into the next k_cnet, bit 28: finishing kernel without the XCD-affine chunk order
     plan_train_disable_sh((v & 0x800) ? 1 : 0);
+    wgrad_force_narrow((v & 0x80000) ? 1 : 0);           // 0x80000: f.2's weight-gradient GEMM on 128-column tiles everywhere
     plan_pack_one_stream((v & 0x20000000) ? 1 : 0);      // bit 29: glowhip_plan_pack entirely on the caller's stream (A/B)
     plan_train_disable_cnet((v & 0x40000000) ? 1 : 0);   // bit 30: training forward on the per-layer kernels (no taping k_cnet)
     plan_train_disable_cnet_bwd(((unsigned)v & 0x80000000u) ? 1 : 0);   // bit 31: input-gradient chain on the per-layer kernels

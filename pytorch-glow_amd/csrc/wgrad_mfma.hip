@@ -168,6 +168,8 @@ k_wgrad_gemm(const float* __restrict__ A, long a_bs, const float* __restrict__ B
 // instead of three).  The gradient operand A keeps both planes: it is what needs the range.
 // One GEMM's arguments (the kernel body below is shared by the one-GEMM launch and by the launch that runs f.4's and f.0's GEMMs
 // side by side: k_wgrad_gemm_pair)
+static int g_wgrad_narrow = 0;
+void wgrad_force_narrow(int on) { g_wgrad_narrow = on; }
 struct WgArgs {
     const float* A; long a_bs; const float* B; long b_bs; float* partial;
     int HW, Mpad, Npad, ktiles_total, ktiles_per_split; float a_scale, a_pre; double* rowsum;
@@ -493,7 +495,9 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_gemm_pair(WgArgs a4, WgArgs a0
 // tape -- with the step rebuilt around the wave's own MFMA stream: see step().  (The template keeps the general kernel's
 // parameters; the gathered / two-plane instances measured slower in this form -- a gathered value's in-image select pinned
 // into the slot of its request waits out the request -- and stay on the kernel above.)
-template <int BN, bool VA = false, bool VB = false, bool BV = false, bool BH = false, bool PS = false>
+// NT = 512 (BN = 256 only): EIGHT waves -- two rows x four columns of the same 64 x 64 wave tiles -- share one 128-row A panel: see
+// k_wgrad_gemm_ps512 below.
+template <int BN, bool VA = false, bool VB = false, bool BV = false, bool BH = false, bool PS = false, int NT = 256>
 __device__ __forceinline__ void wgrad_ps_body(const WgArgs& wa, const int block /* logical, as in wgrad_sh_body */, char* lds) {
     const float* __restrict__ A = wa.A; const long a_bs = wa.a_bs; const float* __restrict__ B = wa.B; const long b_bs = wa.b_bs;
     float* __restrict__ partial = wa.partial;
@@ -502,8 +506,11 @@ __device__ __forceinline__ void wgrad_ps_body(const WgArgs& wa, const int block 
     const int vC = wa.vC, vH = wa.vH, vW = wa.vW, vsign = wa.vsign, b_valid = wa.b_valid, tiled = wa.tiled;
     (void)a_bs; (void)b_bs; (void)vC; (void)vH; (void)vW; (void)vsign; (void)b_valid;
     constexpr int BM = 128, BK = 32;
-    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
-    constexpr int A_F4 = BM * BK / 4 / 256, B_F4 = BN * BK / 4 / 256;   // float4 per thread per K-tile (4, 4|2)
+    constexpr int NWC = NT / 128;                 // columns of waves (two rows of them)
+    constexpr int RPC = NT / 8;                   // rows of a loader chunk: eight threads per row
+    constexpr int WM = BM / 2, WN = BN / NWC, TM = WM / 32, TN = WN / 32;
+    constexpr int A_F4 = BM * BK / 4 / NT, B_F4 = BN * BK / 4 / NT;   // float4 per thread per K-tile (4, 4|2; eight waves: 2, 4)
+    constexpr int NPARTS = A_F4 > B_F4 ? A_F4 : B_F4;                  // parts of a k-tile's requests: part q = chunk q of A (q < A_F4) and of B (q < B_F4)
     // [buffer][plane][k group][row][8], every k group 32 bytes longer than its rows: the loader's 8-byte stores of a quarter wave
     // are 2 rows x 4 k groups, and with a group stride of a whole number of 128-byte bank rounds the four groups of a row met in
     // the same 4 banks (SQ_LDS_BANK_CONFLICT: 0.6 of the LDS-active cycles); now each group has its own 8 banks.  Rows stay
@@ -516,7 +523,7 @@ __device__ __forceinline__ void wgrad_ps_body(const WgArgs& wa, const int block 
     static_assert(!BH || (!VB && !BV), "an fp16 operand B is a plain one");
     static_assert(!PS || !VA, "a pre-scaled A is a plain one");
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wr = wid >> 1, wc = wid & 1, kl = lane >> 5, ml = lane & 31;
+    const int wr = wid / NWC, wc = wid % NWC, kl = lane >> 5, ml = lane & 31;
     // XCD-aware order (8 XCDs with private L2s, block b lands on XCD b % 8): the tiles of ONE pixel slice share their operand
     // panels -- every A panel is read by all tile_n, every B panel by all tile_m -- so they go to the same XCD back to back and
     // the panels travel from HBM once per slice instead of once per tile (the tile-major grid spread a slice over all 8 L2s:
@@ -558,7 +565,7 @@ __device__ __forceinline__ void wgrad_ps_body(const WgArgs& wa, const int block 
     if (VA || VB) {
 #pragma unroll
         for (int j = 0; j < VN; ++j) {
-            const int r = (VA ? tile_m * BM : tile_n * BN) + l_row + 32 * j;
+            const int r = (VA ? tile_m * BM : tile_n * BN) + l_row + RPC * j;
             const int c = r / 9, tap = r - c * 9;
             v_dy[j] = (tap / 3 - 1) * vsign; v_dx[j] = (tap % 3 - 1) * vsign;
             v_off[j] = r < 9 * vC ? c * HW + v_dy[j] * vW + v_dx[j] : -(1 << 30);
@@ -595,33 +602,34 @@ __device__ __forceinline__ void wgrad_ps_body(const WgArgs& wa, const int block 
         // elements in, no division by the tiles per image in front of the requests)
         const int img = VA || VB || BV ? kt / tiles_per_img : 0, tin = VA || VB || BV ? kt - img * tiles_per_img : 0, p0 = tin * BK;
         (void)p0;
-        if constexpr (VA) {
+        if (q >= A_F4) {
+        } else if constexpr (VA) {
             load_virtual(A, a_bs, img, p0, ra, q);
         } else {
             // (uniform base + the thread's 32-bit offset: no 64-bit address arithmetic per request)
             const char* ap = reinterpret_cast<const char*>(A + a_base + (PS ? (long)kt * Mpad * BK : img * a_img + tin * a_tin));
-            ra[q] = *reinterpret_cast<const f32x4*>(ap + (long)q * 32 * a_rs * 4 + lane_off_a * 4u);
+            ra[q] = *reinterpret_cast<const f32x4*>(ap + (long)q * RPC * a_rs * 4 + lane_off_a * 4u);
         }
         if (q >= B_F4) return;
         if constexpr (BH) {
             const char* bp = reinterpret_cast<const char*>(reinterpret_cast<const _Float16*>(B) + b_base + (PS ? (long)kt * Npad * BK : img * b_img + tin * b_tin));
-            rbh[q] = *reinterpret_cast<const h4*>(bp + (long)q * 32 * b_rs * 2 + lane_off_b * 2u);
+            rbh[q] = *reinterpret_cast<const h4*>(bp + (long)q * RPC * b_rs * 2 + lane_off_b * 2u);
         } else if constexpr (VB) {
             load_virtual(B, b_bs, img, p0, rb, q);
         } else if constexpr (BV) {      // rows >= b_valid do not exist in the tensor: loaded from row 0, zeroed
-            const int row = tile_n * BN + l_row + 32 * q;
+            const int row = tile_n * BN + l_row + RPC * q;
             const bool ok = row < b_valid;
             const f32x4 v = *reinterpret_cast<const f32x4*>(B + (long)img * b_bs + (long)(ok ? row : 0) * HW + p0 + l_c * 4);
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
             rb[q] = ok ? v : z;
         } else {
             const char* bp = reinterpret_cast<const char*>(B + b_base + img * b_img + tin * b_tin);
-            rb[q] = *reinterpret_cast<const f32x4*>(bp + (long)q * 32 * b_rs * 4 + lane_off_b * 4u);
+            rb[q] = *reinterpret_cast<const f32x4*>(bp + (long)q * RPC * b_rs * 4 + lane_off_b * 4u);
         }
     };
     auto load_tile = [&](int kt, Stage& st) {
 #pragma unroll
-        for (int q = 0; q < A_F4; ++q) load_part(kt, st, q);
+        for (int q = 0; q < NPARTS; ++q) load_part(kt, st, q);
     };
     // Split of one pair of values into (hi, lo * 2^11) halves: same bits as sh_split on v * pre (the residual t - hi is exact).
     // PS -- a plain A written by the backward k_cnet, which stores T = g * a_scale * 2^11: hi = fp16(T * 2^-11) and
@@ -655,6 +663,7 @@ __device__ __forceinline__ void wgrad_ps_body(const WgArgs& wa, const int block 
     // bytes); B chunk q (fp16 tape: as it is; fp32: split like A, exact scale 1).
     u32x2 ahi, alo, bhi, blo;
     auto conv_a = [&](Stage& st, int q, int h) {
+        if (q >= A_F4) return;
         if (h == 0) rsum[q] += (st.ra[q][0] + st.ra[q][1]) + (st.ra[q][2] + st.ra[q][3]);     // (every workgroup: a branch here would cut the step into blocks)
 #ifdef WG_ABL_NOCONV        // (timing experiments only: no split)
         ahi[h] = __float_as_uint(st.ra[q][2 * h]); alo[h] = __float_as_uint(st.ra[q][2 * h + 1]);
@@ -665,8 +674,9 @@ __device__ __forceinline__ void wgrad_ps_body(const WgArgs& wa, const int block 
 #endif
     };
     auto store_a = [&](int buf, int q) {
-        *reinterpret_cast<u32x2*>(&As[buf][0][l_c >> 1][l_row + 32 * q][(l_c & 1) * 4]) = ahi;
-        *reinterpret_cast<u32x2*>(&As[buf][1][l_c >> 1][l_row + 32 * q][(l_c & 1) * 4]) = alo;
+        if (q >= A_F4) return;
+        *reinterpret_cast<u32x2*>(&As[buf][0][l_c >> 1][l_row + RPC * q][(l_c & 1) * 4]) = ahi;
+        *reinterpret_cast<u32x2*>(&As[buf][1][l_c >> 1][l_row + RPC * q][(l_c & 1) * 4]) = alo;
     };
     auto conv_b = [&](Stage& st, int q, int h) {
         if constexpr (!BH) {
@@ -680,15 +690,15 @@ __device__ __forceinline__ void wgrad_ps_body(const WgArgs& wa, const int block 
     auto store_b = [&](int buf, Stage& st, int q) {
         if (q >= B_F4) return;
         if constexpr (BH) {
-            *reinterpret_cast<h4*>(&Bs[buf][0][l_c >> 1][l_row + 32 * q][(l_c & 1) * 4]) = st.rbh[q];
+            *reinterpret_cast<h4*>(&Bs[buf][0][l_c >> 1][l_row + RPC * q][(l_c & 1) * 4]) = st.rbh[q];
         } else {
-            *reinterpret_cast<u32x2*>(&Bs[buf][0][l_c >> 1][l_row + 32 * q][(l_c & 1) * 4]) = bhi;
-            *reinterpret_cast<u32x2*>(&Bs[buf][BH ? 0 : 1][l_c >> 1][l_row + 32 * q][(l_c & 1) * 4]) = blo;
+            *reinterpret_cast<u32x2*>(&Bs[buf][0][l_c >> 1][l_row + RPC * q][(l_c & 1) * 4]) = bhi;
+            *reinterpret_cast<u32x2*>(&Bs[buf][BH ? 0 : 1][l_c >> 1][l_row + RPC * q][(l_c & 1) * 4]) = blo;
         }
     };
     auto store_tile = [&](int buf, Stage& st) {       // (the first tile: nothing to hide behind)
 #pragma unroll
-        for (int q = 0; q < A_F4; ++q) {
+        for (int q = 0; q < NPARTS; ++q) {
             conv_a(st, q, 0); conv_a(st, q, 1); store_a(buf, q);
             conv_b(st, q, 0); conv_b(st, q, 1); store_b(buf, st, q);
         }
@@ -716,13 +726,13 @@ __device__ __forceinline__ void wgrad_ps_body(const WgArgs& wa, const int block 
         // (scripts/stamps_wgrad.py; 512 would be the MFMAs alone): its VALU work ran at ~1/3 of its rate next to the partner
         // wave's MFMA stream and its own MFMAs at ~40 %.  In the shadow of the wave's OWN MFMA (32 clocks on the pipe, 4 to issue)
         // up to six plain VALU instructions are free (ubench: 39 clocks per MFMA + 6 v_fma_f32).  sched_barrier pins the order.
-        constexpr int NM = (BH ? 2 : 3) * TM * TN * (BK / 16), QM = NM / A_F4;       // MFMAs per step, per quarter (= per chunk q)
+        constexpr int NM = (BH ? 2 : 3) * TM * TN * (BK / 16), QM = NM / NPARTS;       // MFMAs per step, per part (= per chunk q)
         // (the gathered-A and two-plane instances at 128 columns have no registers for the pieces or a second stage -- they
         // spilled, and a spill's reload waits for every request in flight: they multiply first, then split + store tile t + 1
         // from their ONE stage and request tile t + 2 into it)
         constexpr bool SPREAD = BN == 64 || (BH && !VA);
         constexpr int AHEAD = SPREAD ? 3 : 2;
-        static_assert(NM % A_F4 == 0 && QM >= 2, "pieces per chunk over its MFMA slots");
+        static_assert(NM % NPARTS == 0 && QM >= 2, "pieces per chunk over its MFMA slots");
 #ifdef GLOWHIP_DEBUG_STAMPS
         unsigned long long tph[5] = {0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
 #define WG_PH(i) do { if (BH && !VA) { const unsigned long long c_ = __builtin_readcyclecounter(); tph[i] += c_ - tprev; tprev = c_; } } while (0)
@@ -835,7 +845,7 @@ __device__ __forceinline__ void wgrad_ps_body(const WgArgs& wa, const int block 
         for (int j = 0; j < A_F4; ++j) {
             float v = rsum[j];
             v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
-            if (l_c == 0) atomicAdd(rowsum + tile_m * BM + l_row + 32 * j, (double)v * (double)(PS ? SH_LO_INV / a_scale : a_pre / a_scale));      // (a pre-scaled A: back to g)
+            if (l_c == 0) atomicAdd(rowsum + tile_m * BM + l_row + RPC * j, (double)v * (double)(PS ? SH_LO_INV / a_scale : a_pre / a_scale));      // (a pre-scaled A: back to g)
         }
     }
     const float inv = 1.0f / a_scale;
@@ -855,6 +865,16 @@ template <int BN>
 __global__ void __launch_bounds__(256, 2) k_wgrad_gemm_ps(WgArgs a) {
     __shared__ __attribute__((aligned(16))) char lds[wgrad_sh_lds_bytes<BN, true>()];
     wgrad_ps_body<BN, false, false, false, true, true>(a, xcd_remap(blockIdx.x, gridDim.x), lds);
+}
+
+// The same with 256 output columns per workgroup and EIGHT waves (two rows x four columns of 64 x 64 wave tiles, one workgroup per
+// CU: the same two waves per SIMD as two 128 x 128 workgroups): at 128 x 128 every operand panel is fetched from L2 by the four
+// workgroups of its tile row / column -- 800 MB of L2 -> LDS traffic for the 201 MB of f.2's level-1 operands, 10 TB/s over the
+// launch, which is what it waits for; here the fp32 gradient panel is shared by twice as many waves: fetched twice, the fp16 tape
+// panel four times -- 536 MB.  (66 KiB of LDS: dynamic.)
+__global__ void __launch_bounds__(512, 1) k_wgrad_gemm_ps512(WgArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char lds_dyn[];
+    wgrad_ps_body<256, false, false, false, true, true, 512>(a, xcd_remap(blockIdx.x, gridDim.x), lds_dyn);
 }
 
 // All three weight-gradient GEMMs of a FlowStep behind the backward k_cnet in ONE launch: blocks [0, a2.nblocks) are f.2's
@@ -1010,9 +1030,11 @@ int launch_wgrad_mfma(const float* A, long a_bs, const float* B, long b_bs, floa
     GH_REQUIRE(wgrad_mfma_supported(HW, Mpad, Npad), "wgrad_mfma: unsupported shape");
     if (N == 0) return GLOWHIP_OK;
     const bool bn128 = Npad % 128 == 0;
-    const int tiles = (Mpad / 128) * (bn128 ? Npad / 128 : Npad / 64);
     const int total = (int)((long)N * HW / 32);
-    int splits = std::max(1, std::min(total, (512 + tiles - 1) / tiles));   // 2 workgroups per CU
+    // f.2 behind the backward k_cnet at a level with enough pixels: 256-column tiles, one eight-wave workgroup per CU (k_wgrad_gemm_ps512)
+    const bool wide = b_half && ps && Npad % 256 == 0 && total >= 512 && !g_wgrad_narrow;
+    const int tiles = (Mpad / 128) * (wide ? Npad / 256 : (bn128 ? Npad / 128 : Npad / 64));
+    int splits = std::max(1, std::min(total, ((wide ? 256 : 512) + tiles - 1) / tiles));   // 2 workgroups per CU (wide: 1, of twice the waves)
     const int per = (total + splits - 1) / splits;
     splits = (total + per - 1) / per;
     const int vC = taps ? taps->C : 0, vH = taps ? taps->H : 0, vW = taps ? taps->W : 1, vs = taps ? taps->sign : 0;
@@ -1020,6 +1042,12 @@ int launch_wgrad_mfma(const float* A, long a_bs, const float* B, long b_bs, floa
                     b_valid > 0 ? b_valid : Npad, tiled, tiles * splits};
 #define GH_WG(bn, va, vb) hipLaunchKernelGGL((k_wgrad_gemm_sh<bn, va, vb>), dim3(tiles * splits), dim3(256), 0, s, wa)
 #define GH_WGH(bn, va) hipLaunchKernelGGL((k_wgrad_gemm_sh<bn, va, false, false, true>), dim3(tiles * splits), dim3(256), 0, s, wa)
+    if (b_half && ps && wide) {        // ... with 256-column tiles and eight waves, one workgroup per CU
+        GH_REQUIRE((tiled & 3) == 3, "wgrad_mfma: f.2's kernel reads pixel-tile-major operands");
+        constexpr int lds256 = wgrad_sh_lds_bytes<256, true>();
+        (void)hipFuncSetAttribute((const void*)k_wgrad_gemm_ps512, hipFuncAttributeMaxDynamicSharedMemorySize, lds256);
+        hipLaunchKernelGGL(k_wgrad_gemm_ps512, dim3(tiles * splits), dim3(512), lds256, s, wa);
+    } else
     if (b_half && ps) {                // f.2 behind the backward k_cnet: its own kernel
         GH_REQUIRE((tiled & 3) == 3, "wgrad_mfma: f.2's kernel reads pixel-tile-major operands");
         if (bn128) hipLaunchKernelGGL(k_wgrad_gemm_ps<128>, dim3(tiles * splits), dim3(256), 0, s, wa);

@@ -326,10 +326,10 @@ class GraphedForward:
         if not self.repack and self.plan._version_signature() != self._version:
             raise _lib.GlowHipError("capture_forward(repack=False): the parameters changed since the capture")
         if self.repack and getattr(self.plan, "_pack_epoch", 0) != self._pack_epoch:
-            # (an eager pack rebuilds the plan's host-side job tables; the captured pack's copy nodes read them through the addresses
-            # of capture time -- a replay after a re-run on the other kernel family faulted on a host address when the training
-            # step's graph first met this, training.GraphedTrainStep)
-            raise _lib.GlowHipError("capture_forward: the plan was packed eagerly since the capture -- capture again")
+            # (an eager pack for the OTHER kernel family rebuilds the plan's host-side job tables; the captured pack's copy nodes read
+            # them through the addresses of capture time -- a replay after a re-run on the exact-fp32 family faulted on a host
+            # address when the training step's graph first met this, training.GraphedTrainStep)
+            raise _lib.GlowHipError("capture_forward: the plan was packed for the other kernel family since the capture -- capture again")
         self.graph.replay()
         return self.z, self.nll
 

@@ -273,9 +273,9 @@ class GraphedTrainStep:
         pg = getattr(plan, "_pgrad", None)
         return (ptr(plan.packed), ptr(getattr(plan, "_ws", None)), ptr(getattr(plan, "_tws", None)),
                 tuple(ptr(f) for f in pg[0]) if pg else (), ptr(getattr(opt, "_partial", None)), ptr(getattr(opt, "_keep", None)),
-                # an eager pack of this plan since the capture (a validation forward, a re-run on the other kernel family): it
-                # rebuilt the host-side job tables the captured pack's copy nodes read (measured: a replay after a re-run on the
-                # exact-fp32 family faulted on a host address)
+                # an eager pack of this plan for the OTHER kernel family since the capture (a re-run of an overflowed batch): it rebuilt
+                # the host-side job tables the captured pack's copy nodes read (measured: a replay after such a re-run faulted on a
+                # host address); packs of the same family keep them in place
                 getattr(plan, "_pack_epoch", 0))
 
     def valid(self):
@@ -385,8 +385,9 @@ class TrainLoop:
         if g is not None and (g.x.shape != x_local.shape or g.x.dtype != x_local.dtype or g.skip != checked):
             g = self._graphed = None
         if g is not None and not g.valid():
-            # an eager call in between (a validation forward, a re-run on the other kernel family) packed this plan again or moved a
-            # workspace: this step runs eagerly -- it brings the plan back to the training step's state -- and the next one captures again
+            # an eager call in between (a re-run on the other kernel family, a forward of a larger batch) rebuilt the plan's job tables
+            # or moved a workspace: this step runs eagerly -- it brings the plan back to the training step's state -- and the next one
+            # captures again
             self._graphed = None
             self.graph_recaptures += 1
             return None
