@@ -257,7 +257,8 @@ class GraphedTrainStep:
         glow.flow.plan_for(x).pack_sync()
         steps = optimizer._steps
         self.graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(self.graph, stream=side):
+        # (thread_local: a DataLoader's pinning thread may touch the device while this thread captures)
+        with torch.no_grad(), torch.cuda.graph(self.graph, stream=side, capture_error_mode="thread_local"):
             self._body()
         optimizer._steps = steps          # (the captured call counted a step on the host; nothing ran)
         optimizer._publish_step()
