@@ -515,6 +515,8 @@ def test_training_launches_on_the_one_wave_kernel_agree_with_k_cnet(image, L, ba
         4-byte store after a quad-permute, sign words as k_cnet writes them;
       * the input-gradient chain (the transposed network: 12 channels in, 6 out) -- ReLU masks read from those sign words a block
         ahead, g_u2 / g_u0 stored as fp32 for the weight-gradient GEMMs, the partial sums for k_chanmix_bwd in k_cnet's layout;
+    and f.2's weight-gradient GEMM behind it reads 128 x 256 tiles with eight waves per workgroup (k_wgrad_gemm_ps512; debug switch
+    0x80000: the 128-column kernel);
     evidence from the run-time counters (config-B geometry: 32-pixel rows, four per tile; and a 32 x 32 input with L = 1: 16-pixel rows,
     eight per tile, 224 tiles at batch 112; a 128 x 128 input with L = 1: 64-pixel rows, two per tile, 224 tiles at batch 7).  With the debug switches 0x10000 (no k_cnet1w at all) / 0x40000 (taping on k_cnet1w, backward
     on k_cnet) the same step runs on k_cnet MODE 1 / 2 (pinned against the fp64 oracle above): z, nll and every gradient agree."""
@@ -528,7 +530,7 @@ def test_training_launches_on_the_one_wave_kernel_agree_with_k_cnet(image, L, ba
     sd = O.glow_init_actnorm(x, noise, sd, cfg)
     res = {}
     try:
-        for flag in (0x10000, 0x40000, 0):
+        for flag in (0x10000, 0x40000, 0x80000, 0):
             _lib.lib().glowhip_debug_force_tail_tile(flag)
             glow = G.Glow(hps_for(cfg, batch))
             glow.load_state_dict(sd)
@@ -546,7 +548,7 @@ def test_training_launches_on_the_one_wave_kernel_agree_with_k_cnet(image, L, ba
         _lib.lib().glowhip_debug_force_tail_tile(0)
     z0, n0, g0, c0 = res[0x10000]
     assert c0.get("k_cnet(tape)", 0) == L * K and c0.get("k_cnet1w(tape)", 0) == 0 and c0.get("k_cnet1w(bwd)", 0) == 0, c0
-    for flag, want_bwd in ((0x40000, 0), (0, K)):
+    for flag, want_bwd in ((0x40000, 0), (0x80000, K), (0, K)):
         z1, n1, g1, c1 = res[flag]
         assert c1.get("k_cnet(tape)", 0) == L * K and c1.get("k_cnet1w(tape)", 0) == K and c1.get("k_cnet(bwd)", 0) == L * K, c1
         assert c1.get("k_cnet1w(bwd)", 0) == want_bwd, (hex(flag), c1)
