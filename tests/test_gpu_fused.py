@@ -538,6 +538,33 @@ def test_captured_forward_survives_packs_of_other_use_masks():
         close(z, z_ref, 1e-4, what="z (replay after a training step)"); close(n, nll_ref, 1e-4, what="nll")
 
 
+def test_captured_forward_refuses_a_replay_after_a_pack_for_the_other_kernel_family():
+    """A pack for the exact-fp32 family (a checked forward that fell back, a re-run of an overflowed training batch) rebuilds the
+    plan's host-side job tables with other contents; the copy nodes of a captured pack would read them through the addresses of
+    capture time (a replay of the training step's graph after such a re-run faulted on a host address when this was first met).  A
+    captured forward therefore refuses to replay -- with an error, not a fault -- until it is captured again; packs of the same
+    family, whatever their image set, are fine (test_captured_forward_survives_packs_of_other_use_masks)."""
+    cfg = O.default_cfg(image_shape=(32, 32, 3), hidden_channels=128, K=2, L=2, batch=4)
+    sd = O.seeded_state_dict(cfg, seed=9)
+    glow = make_glow(cfg, sd, 4).eval()
+    x = dev(torch.rand(4, 3, 32, 32, generator=torch.Generator().manual_seed(5)))
+    with torch.no_grad():
+        gf = glow.capture_forward(x, repack=True)
+        z1, n1 = (t.clone() for t in gf())
+        plan = gf.plan
+        plan.set_family(plan.FAMILY_EXACT_FP32)
+        try:
+            glow.normal_flow(x, None)                     # packs for the other family
+        finally:
+            plan.set_family(plan.FAMILY_AUTO)
+        with pytest.raises(G._lib.GlowHipError, match="other kernel family"):
+            gf()
+        gf2 = glow.capture_forward(x, repack=True)        # a new capture works on
+        z2, n2 = gf2()
+        ze, ne, _ = glow.normal_flow(x, None, noise=gf2.noise.clone())
+        assert torch.equal(z2, ze) and torch.equal(n2, ne) and torch.isfinite(n2).all()
+
+
 def test_eager_calls_after_a_capture_with_side_stream_pack():
     """plans with C > 128 fork part of their pack onto a side stream and consumers join through events.  Events
     last recorded INSIDE a capture cannot be waited for from an eager stream (hipErrorCapturedEvent): after
