@@ -54,6 +54,10 @@ int glowhip_squeeze2d(const float* x, float* y, int N, int C, int H, int W, int 
  * x may be a channel slice of a wider tensor: element (n,c,p) is x[n*batch_stride + c*HW + p]. */
 int glowhip_actnorm_init(const float* x, long batch_stride, int N, int C, int HW, float scale,
                          float* bias, float* logs, glowhip_stream_t stream);
+/* The same with ActNorm(batch_variance=True), network/module.py:109-110: bias per channel as above, but ONE log-scale for all
+ * channels from the second moment pooled over every dimension: logs[c] = log(scale / (sqrt(mean_{n,c,h,w} (x+bias)^2) + 1e-6)) / 3. */
+int glowhip_actnorm_init_batch_variance(const float* x, long batch_stride, int N, int C, int HW, float scale,
+                                        float* bias, float* logs, glowhip_stream_t stream);
 
 /* ActNorm.forward, network/module.py:122-149.  reverse=0: y=(x+bias)*exp(3 logs); reverse=1:
  * y = x*exp(-3 logs) - bias.  If logdet_out != NULL: logdet_out[n] = (logdet_in ? logdet_in[n] : 0)

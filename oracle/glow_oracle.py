@@ -100,17 +100,18 @@ def unsqueeze2d(x: torch.Tensor, factor: int = 2) -> torch.Tensor:
 
 
 # ----------------------------------------------------------------------------- ActNorm (R3, R4)
-def actnorm_init(x: torch.Tensor, scale: float = 1.0) -> Tuple[torch.Tensor, torch.Tensor]:
-    """Data-dependent init, network/module.py:86-120 (batch_variance=False).
+def actnorm_init(x: torch.Tensor, scale: float = 1.0, batch_variance: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Data-dependent init, network/module.py:86-120.
 
-    bias = -mean_{N,H,W}(x);  logs = log(scale / (sqrt(mean((x+bias)^2)) + 1e-6)) / 3.
+    bias = -mean_{N,H,W}(x);  logs = log(scale / (sqrt(mean((x+bias)^2)) + 1e-6)) / 3, the mean over (N,H,W) per channel --
+    or, with batch_variance=True (:109-110), over every dimension: one value, copied into all channels (`logs.data.copy_`).
     Returns (bias, logs), each (1, C, 1, 1).
     """
     bias = -1.0 * reduce_mean_dims(x, [0, 2, 3], keepdim=True)
     xc = x + bias
-    var = reduce_mean_dims(xc ** 2, [0, 2, 3], keepdim=True)
+    var = torch.mean(xc ** 2) if batch_variance else reduce_mean_dims(xc ** 2, [0, 2, 3], keepdim=True)
     logs = torch.log(scale / (torch.sqrt(var) + 1e-6)) / LOGSCALE_FACTOR
-    return bias, logs
+    return bias, logs.expand_as(bias).clone()
 
 
 def actnorm(x, bias, logs, logdet=None, reverse: bool = False):

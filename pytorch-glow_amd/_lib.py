@@ -67,6 +67,7 @@ SIGNATURES = {
     "glowhip_last_error": (c_char_p, []),
     "glowhip_squeeze2d": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "glowhip_actnorm_init": (c_int, [_P, c_long, c_int, c_int, c_int, c_float, _P, _P, _P]),
+    "glowhip_actnorm_init_batch_variance": (c_int, [_P, c_long, c_int, c_int, c_int, c_float, _P, _P, _P]),
     "glowhip_actnorm": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "glowhip_invconv_scratch_bytes": (c_size_t, [c_int]),
     "glowhip_invconv_prepare": (c_int, [_P, c_int, _P, _P, _P, _P]),

@@ -36,6 +36,12 @@ int glowhip_actnorm_init(const float* x, long batch_stride, int N, int C, int HW
     return launch_actnorm_init(x, batch_stride, N, C, HW, scale, bias, logs, (hipStream_t)stream);
 }
 
+int glowhip_actnorm_init_batch_variance(const float* x, long batch_stride, int N, int C, int HW, float scale, float* bias,
+                                        float* logs, glowhip_stream_t stream) {
+    GH_REQUIRE(x && bias && logs, "actnorm_init: null tensor");
+    return launch_actnorm_init(x, batch_stride, N, C, HW, scale, bias, logs, (hipStream_t)stream, 1);
+}
+
 // ActNorm.forward as a stand-alone elementwise pass (network/module.py:122-149)
 __global__ void __launch_bounds__(256) k_actnorm_elementwise(const float* __restrict__ x, float* __restrict__ y,
                                                              const float* __restrict__ bias,

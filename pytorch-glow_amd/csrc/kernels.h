@@ -14,7 +14,7 @@ int launch_squeeze_u8(const uint8_t* x, const float* noise, float* y, int N, int
 int launch_dequant_noise(float* out, long n, unsigned long long seed, unsigned long long call, float scale, hipStream_t s);
 int launch_copy_strided(const float* x, long xbs, float* y, long ybs, int N, long per_sample, hipStream_t s);
 int launch_actnorm_init(const float* x, long xbs, int N, int C, int HW, float scale, float* bias, float* logs,
-                        hipStream_t s);
+                        hipStream_t s, int batch_variance = 0);
 
 // Channel mixer: the ActNorm + (Invertible1x1Conv | Permutation2d) pair of a FlowStep as ONE pass.
 struct ChanMixArgs {

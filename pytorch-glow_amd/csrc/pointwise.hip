@@ -235,9 +235,11 @@ int launch_copy_strided(const float* x, long xbs, float* y, long ybs, int N, lon
 // ActNorm data-dependent init (network/module.py:86-120): one workgroup per channel, two passes
 // (mean, then mean of the centred square), fp64 accumulation, fixed reduction tree.
 // ------------------------------------------------------------------------------------------------
+// `pooled` (batch_variance=True, :109-110): logs[c] receives the channel's centred second moment instead; k_actnorm_pool_logs
+// turns the C moments into the one pooled value.
 __global__ void __launch_bounds__(256) k_actnorm_init(const float* __restrict__ x, long xbs, int N, int HW,
                                                       float scale, float* __restrict__ bias,
-                                                      float* __restrict__ logs) {
+                                                      float* __restrict__ logs, int pooled) {
     __shared__ double red[4];
     __shared__ float s_bias;
     const int c = blockIdx.x;
@@ -264,15 +266,37 @@ __global__ void __launch_bounds__(256) k_actnorm_init(const float* __restrict__ 
     if (threadIdx.x == 0) {
         float var = (float)(tot / (double)count);
         bias[c] = b;
-        logs[c] = logf(scale / (sqrtf(var) + 1e-6f)) / LOGSCALE;
+        logs[c] = pooled ? var : logf(scale / (sqrtf(var) + 1e-6f)) / LOGSCALE;
     }
 }
 
+// batch_variance=True: the reference takes mean((x + bias)^2) over ALL dimensions (`ops.reduce_mean(x ** 2, keepdim=True)`,
+// network/module.py:109-110 -- every channel holds N*HW elements, so that is the mean of the per-channel moments) and copies the one
+// resulting log-scale into every channel.  One workgroup: fp64 sum of the C moments in a fixed tree, then the broadcast.
+__global__ void __launch_bounds__(256) k_actnorm_pool_logs(float* __restrict__ logs, int C, float scale) {
+    __shared__ double red[4];
+    double acc = 0.0;
+    for (int c = threadIdx.x; c < C; c += 256) acc += (double)logs[c];
+    __shared__ float s_logs;
+    const double tot = block_sum<256>(acc, red);      // (valid on thread 0; ends with a barrier: every moment is read before the first is overwritten)
+    if (threadIdx.x == 0) {
+        const float var = (float)(tot / (double)C);
+        s_logs = logf(scale / (sqrtf(var) + 1e-6f)) / LOGSCALE;
+    }
+    __syncthreads();
+    const float v = s_logs;
+    for (int c = threadIdx.x; c < C; c += 256) logs[c] = v;
+}
+
 int launch_actnorm_init(const float* x, long xbs, int N, int C, int HW, float scale, float* bias, float* logs,
-                        hipStream_t s) {
+                        hipStream_t s, int batch_variance) {
     GH_REQUIRE(N > 0 && C > 0 && HW > 0, "actnorm_init: empty input");
-    hipLaunchKernelGGL(k_actnorm_init, dim3(C), dim3(256), 0, s, x, xbs, N, HW, scale, bias, logs);
+    hipLaunchKernelGGL(k_actnorm_init, dim3(C), dim3(256), 0, s, x, xbs, N, HW, scale, bias, logs, batch_variance);
     GH_LAUNCH_CHECK("k_actnorm_init");
+    if (batch_variance) {
+        hipLaunchKernelGGL(k_actnorm_pool_logs, dim3(1), dim3(256), 0, s, logs, C, scale);
+        GH_LAUNCH_CHECK("k_actnorm_pool_logs");
+    }
     return GLOWHIP_OK;
 }
 

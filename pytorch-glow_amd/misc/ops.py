@@ -28,37 +28,44 @@ def reduce_sum(tensor, dim=None, keepdim=False, out=None):
 
 
 def tensor_equal(a, b, eps=1e-6):
-    """Same shape and max-abs difference <= eps (reference misc/ops.py:76-92)."""
-    if a.shape != b.shape:
+    """True when the two tensors have one shape and no element differs by more than ``eps`` (reference misc/ops.py:76-92; a NaN
+    anywhere makes it False, as there)."""
+    if tuple(a.shape) != tuple(b.shape):
         return False
-    return 0 <= float(torch.max(torch.abs(a - b))) <= eps
+    if a.numel() == 0:
+        return True
+    worst = (a - b).abs().max().item()
+    return worst <= eps          # (a NaN difference compares False)
 
 
 def split_channel(tensor, split_type='simple'):
-    """'simple': first/second half of the channels; 'cross': even/odd channels (views).
-    Reference misc/ops.py:95-113."""
+    """Two channel halves of an NCHW tensor as views (reference misc/ops.py:95-113): 'simple' = the first C/2 channels and the
+    rest, 'cross' = the even-numbered and the odd-numbered channels."""
     assert len(tensor.shape) == 4
     assert split_type in ['simple', 'cross']
-    nc = tensor.shape[1]
-    if split_type == 'simple':
-        return tensor[:, :nc // 2, ...], tensor[:, nc // 2:, ...]
-    return tensor[:, 0::2, ...], tensor[:, 1::2, ...]
+    if split_type == 'cross':
+        return tensor[:, 0::2], tensor[:, 1::2]
+    half = tensor.shape[1] // 2
+    return tensor.narrow(1, 0, half), tensor.narrow(1, half, tensor.shape[1] - half)
 
 
 def cat_channel(a, b):
-    """Concatenate on the channel axis (reference misc/ops.py:116-127)."""
-    return torch.cat((a, b), dim=1)
+    """Inverse of the 'simple' split: the two tensors joined along dim 1 (reference misc/ops.py:116-127)."""
+    return torch.cat([a, b], 1)
 
 
 def count_pixels(tensor):
-    """H * W of an NCHW tensor (reference misc/ops.py:130-140)."""
+    """Spatial size H * W of an NCHW tensor (reference misc/ops.py:130-140)."""
     assert len(tensor.shape) == 4
-    return int(tensor.shape[2] * tensor.shape[3])
+    _, _, height, width = tensor.shape
+    return int(height) * int(width)
 
 
 def onehot(y, num_classes):
-    """One-hot labels (reference misc/ops.py:143-160; label path, outside the flow hot path)."""
+    """Class indices (B,) or (B, 1) -> one-hot rows (B, num_classes), float32 on y's device (reference misc/ops.py:143-160; the
+    label path, outside the flow hot path)."""
     assert len(y.shape) in [1, 2], "Label y should be 1D or 2D vector"
-    y_onehot = torch.zeros(y.shape[0], num_classes, device=y.device)
-    idx = y.unsqueeze(-1) if len(y.shape) == 1 else y
-    return y_onehot.scatter_(1, idx, 1)
+    index = y.reshape(y.shape[0], -1).long()
+    rows = torch.zeros((y.shape[0], num_classes), dtype=torch.float32, device=y.device)
+    rows.scatter_(1, index, 1.0)
+    return rows

@@ -51,29 +51,33 @@ def load_profile(filepath):
     return None
 
 
-def get_devices(devices, verbose=True):
-    """Usable devices among those a profile lists: ['cpu'] or a list of CUDA ordinals.
-    'cuda:N' entries beyond torch.cuda.device_count() are dropped; none left -> ['cpu']."""
-    def parse(device):
-        origin = str(device)
-        if isinstance(device, str) and re.search(r'cuda:(\d+)', device):
-            device = int(re.findall(r'cuda:(\d+)', device)[0])
-        if isinstance(device, int) and 0 <= device <= torch.cuda.device_count() - 1:
-            return device
-        if verbose:
-            print('[Builder] Incorrect device "{}"'.format(origin))
-        return None
+_CUDA_NAME = re.compile(r'cuda:(\d+)')
 
-    use_cpu = any(isinstance(d, str) and d.find('cpu') >= 0 for d in devices)
-    use_cuda = any(isinstance(d, int) or d.find('cuda') >= 0 for d in devices)
-    assert not (use_cpu and use_cuda), 'CPU and GPU cannot be mixed.'
-    if use_cuda:
-        devices = [d for d in (parse(d) for d in devices) if d is not None]
-        if len(devices) == 0:
-            if verbose:
-                print('[Builder] No available GPU found, use CPU only')
-            devices = ['cpu']
-    return devices
+
+def get_devices(devices, verbose=True):
+    """The devices of a profile's ``device.graph`` / ``device.data`` list that exist on this machine (the contract of the
+    reference's misc/util.py:34-75): ``['cpu']`` stays ``['cpu']``; ``'cuda:N'`` strings and bare ints become the list of ordinals
+    below ``torch.cuda.device_count()`` (each dropped entry is reported); an all-GPU list with nothing left degrades to ``['cpu']``;
+    a list that names both kinds is refused."""
+    names_cpu = [isinstance(d, str) and 'cpu' in d for d in devices]
+    names_gpu = [isinstance(d, int) or (isinstance(d, str) and 'cuda' in d) for d in devices]
+    assert not (any(names_cpu) and any(names_gpu)), 'CPU and GPU cannot be mixed.'
+    if not any(names_gpu):
+        return devices
+    present = torch.cuda.device_count()
+    ordinals = []
+    for entry in devices:
+        match = _CUDA_NAME.search(entry) if isinstance(entry, str) else None
+        ordinal = int(match.group(1)) if match else entry
+        if isinstance(ordinal, int) and not isinstance(ordinal, bool) and 0 <= ordinal < present:
+            ordinals.append(ordinal)
+        elif verbose:
+            print('[Builder] Incorrect device "{}"'.format(entry))
+    if ordinals:
+        return ordinals
+    if verbose:
+        print('[Builder] No available GPU found, use CPU only')
+    return ['cpu']
 
 
 def manual_seed(seed):

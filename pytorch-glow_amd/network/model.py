@@ -334,6 +334,15 @@ class GraphedForward:
         return self.z, self.nll
 
 
+class _GradBinding:
+    """Token for "the parameters' .grad are this plan's persistent gradient views" (`Glow.loss_and_grads`): the optimiser keeps its
+    chunk table while it is shown the same token object."""
+    __slots__ = ("grads",)
+
+    def __init__(self, grads):
+        self.grads = grads
+
+
 class Glow(nn.Module):
     """Glow (reference network/model.py:317-550): dequantisation noise, flow encode, top prior, nll in bits/dim."""
 
@@ -456,10 +465,15 @@ class Glow(nn.Module):
             if gn is None or gn.numel() != n:
                 gn = plan._mean_grad = torch.full((n,), 1.0 / n, dtype=torch.float32, device=x.device)      # d mean(nll) / d nll
             grads, _ = plan.glow_backward(x, tape, gn, None, None, None, 0, want_grad_x=False, persistent=True)
-        if getattr(plan, "_pgrad_bound", None) is not grads:      # once per plan: the views ARE the parameters' gradients from now on
-            for p, g in zip(plan.trainable_parameters(), grads):
+        # the views ARE the parameters' gradients: bound once per plan -- and again whenever somebody took them away in between
+        # (optimizer.zero_grad() sets .grad to None, an autograd backward assigns its own tensors): ~1 060 identity tests, 60 us.  A
+        # re-bind hands out a NEW token, so the optimiser rebuilds its chunk table from the gradients that are there now
+        params = plan.trainable_parameters()
+        bound = getattr(plan, "_pgrad_bound", None)
+        if bound is None or bound.grads is not grads or any(p.grad is not g for p, g in zip(params, grads)):
+            for p, g in zip(params, grads):
                 p.grad = g
-            plan._pgrad_bound = grads
+            plan._pgrad_bound = _GradBinding(grads)
         self._train_plan = plan        # (parallel.train_step: the optimiser's table stays valid while this plan's buckets are the gradients)
         return loss
 

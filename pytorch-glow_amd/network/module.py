@@ -72,8 +72,6 @@ class ActNorm(nn.Module):
     def __init__(self, num_channels, scale=1., logscale_factor=3., batch_variance=False):
         super().__init__()
         assert logscale_factor == 3., "the HIP kernels hard-code logscale_factor=3 (the only value the reference uses)"
-        if batch_variance:
-            raise NotImplementedError("batch_variance=True is never used by the reference's models")
         self.num_channels = num_channels
         self.scale = scale
         self.logscale_factor = logscale_factor
@@ -84,12 +82,13 @@ class ActNorm(nn.Module):
         self.register_parameter('logs', nn.Parameter(torch.zeros(1, self.num_channels, 1, 1)))
 
     def initialize_parameters(self, x):
-        """bias = -mean(x), logs = log(scale/(std+1e-6))/3 over (N,H,W); training mode only (:93,:109)."""
+        """bias = -mean(x), logs = log(scale/(std+1e-6))/3 over (N,H,W); training mode only (:93,:109).  batch_variance=True
+        (:109-110): the second moment is pooled over the channels as well -- one log-scale, copied into every channel."""
         if not self.training:
             return
         n, c, h, w = x.shape
-        check(lib().glowhip_actnorm_init(ptr(x), c * h * w, n, c, h * w, float(self.scale), ptr(self.bias.data),
-                                         ptr(self.logs.data), stream_ptr(x.device)))
+        init = lib().glowhip_actnorm_init_batch_variance if self.batch_variance else lib().glowhip_actnorm_init
+        check(init(ptr(x), c * h * w, n, c, h * w, float(self.scale), ptr(self.bias.data), ptr(self.logs.data), stream_ptr(x.device)))
         self.bias_inited = True
         self.logs_inited = True
 

@@ -249,7 +249,13 @@ class GraphedTrainStep:
         self.loss = torch.zeros((), dtype=torch.float32, device=dev)
         self.norm = torch.zeros(1, dtype=torch.float32, device=dev)
         self.hyper = torch.zeros(3, dtype=torch.float64, device=dev)
-        self._hyper_host = torch.zeros(3, dtype=torch.float64, pin_memory=True)
+        # A pinned-source H2D copy reads the host words when the STREAM gets to it, not at enqueue time, and the host may run several
+        # steps ahead of the device: one pinned slot per step in flight, each with the event recorded behind its copy, and a slot is
+        # written again only once that event has passed (ADVICE r5 -- with a single slot, step N could read step N + 1's learning rate
+        # and bias corrections)
+        self._hyper_host = [torch.zeros(3, dtype=torch.float64, pin_memory=True) for _ in range(self.HYPER_SLOTS)]
+        self._hyper_done = [None] * self.HYPER_SLOTS
+        self._hyper_next = 0
         self._params = [p for g in optimizer.param_groups for p in g["params"] if p.grad is not None]
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
@@ -257,13 +263,36 @@ class GraphedTrainStep:
         glow.flow.plan_for(x).pack_sync()
         steps = optimizer._steps
         self.graph = torch.cuda.CUDAGraph()
-        # (thread_local: a DataLoader's pinning thread may touch the device while this thread captures)
-        with torch.no_grad(), torch.cuda.graph(self.graph, stream=side, capture_error_mode="thread_local"):
-            self._body()
-        optimizer._steps = steps          # (the captured call counted a step on the host; nothing ran)
-        optimizer._publish_step()
+        try:
+            # (thread_local: a DataLoader's pinning thread may touch the device while this thread captures)
+            with torch.no_grad(), torch.cuda.graph(self.graph, stream=side, capture_error_mode="thread_local"):
+                self._body()
+        except BaseException:
+            optimizer._table_token = None     # (a table half-built under a failed capture must not be trusted by the eager steps that follow)
+            raise
+        finally:
+            # the captured call counted a step on the host; nothing ran -- also when the capture failed half-way and TrainLoop carries
+            # on eagerly: the bias corrections of every later step hang on this count
+            optimizer._steps = steps
+            optimizer._publish_step()
         self.plan = glow.flow.plan_for(x)
         self._buffers = self._buffer_signature()
+
+    HYPER_SLOTS = 4
+
+    def _upload_hyper(self, values):
+        i = self._hyper_next
+        self._hyper_next = (i + 1) % self.HYPER_SLOTS
+        ev = self._hyper_done[i]
+        if ev is not None:
+            while not ev.query():         # the copy that last read this slot has not run yet: sleep, do not spin (see _check_previous)
+                time.sleep(2e-4)
+        host = self._hyper_host[i]
+        host[0], host[1], host[2] = values
+        self.hyper.copy_(host, non_blocking=True)
+        if ev is None:
+            ev = self._hyper_done[i] = torch.cuda.Event()
+        ev.record()
 
     def _buffer_signature(self):
         """Addresses of everything the captured launches reach through the plan and the optimiser and that an EAGER call in between
@@ -301,9 +330,7 @@ class GraphedTrainStep:
         opt = self.optimizer
         opt._steps += 1
         opt._publish_step()
-        h = opt.hyper_values(lr, opt._steps)
-        self._hyper_host[0], self._hyper_host[1], self._hyper_host[2] = h
-        self.hyper.copy_(self._hyper_host, non_blocking=True)
+        self._upload_hyper(opt.hyper_values(lr, opt._steps))
         self.graph.replay()
         torch.autograd.graph.increment_version(self._params)      # (the parameters changed behind torch's back, as after fused_step)
         out = torch.stack((self.loss, self.norm[0]))              # (the static words are overwritten by the next replay)
@@ -384,7 +411,11 @@ class TrainLoop:
             return None
         g = self._graphed
         if g is not None and (g.x.shape != x_local.shape or g.x.dtype != x_local.dtype or g.skip != checked):
-            g = self._graphed = None
+            # another batch shape: its lazy allocations (workspaces, tape, gradient tables) need an eager step behind them before a
+            # capture, as the first one had -- this step runs eagerly, the next one captures
+            self._graphed = None
+            self.graph_recaptures += 1
+            return None
         if g is not None and not g.valid():
             # an eager call in between (a re-run on the other kernel family, a forward of a larger batch) rebuilt the plan's job tables
             # or moved a workspace: this step runs eagerly -- it brings the plan back to the training step's state -- and the next one
@@ -421,6 +452,12 @@ class TrainLoop:
         again right after this step."""
         while self._pending:
             pending = self._pending[0]
+            # world > 1: the check of step N is resolved at a FIXED lag (when MAX_LAG checks are pending), never earlier because its
+            # event happens to have passed -- every rank must take a skipped step back, and issue the re-run's bucket all-reduces, at the
+            # same point of its collective sequence (ADVICE r5: with the opportunistic look, rank A re-ran at N + 1 and rank B at N + 2,
+            # pairing the re-run's all-reduce with another batch's).  The norm is the all-reduced one, identical on all ranks.
+            if self.world > 1 and not drain and len(self._pending) < self.MAX_LAG:
+                break
             if not pending[2].query():
                 if not drain and len(self._pending) < self.MAX_LAG:
                     break

@@ -12,6 +12,7 @@ expected outputs) stored as .npz.
 Fixtures:
   g1_squeeze_split.npz   squeeze/unsqueeze, split/cat
   g2_actnorm.npz         data-dependent init; fwd/rev with logdet in {None, tensor}
+  g2_actnorm_bv.npz      data-dependent init with batch_variance=True (one pooled log-scale), scale 1 and 3
   g3_invconv.npz         C in {12,24,48,96}, non-orthogonal W: fwd, dlogdet, rev
   g4_coupling_net.npz    f(): 3x3 -> relu -> 1x1 -> relu -> zeros-3x3, all params random
   g5_flowstep.npz        {invconv,reverse,shuffle} x {additive,affine}: fwd z/logdet, rev x/logdet
@@ -156,6 +157,22 @@ def g2(g):
     assert ldn is None
     out.update(x=x, bias=an.bias, logs=an.logs, logdet=ld, fwd_y=yf, fwd_logdet=ldf, rev_y=yr, rev_logdet=ldr, fwd_y_nold=yn)
     save("g2_actnorm.npz", out)
+
+
+def g2_bv():
+    """ActNorm(batch_variance=True), network/module.py:109-110 (own generator: the other fixtures' draws stay what they were)."""
+    g = torch.Generator().manual_seed(4321)
+    out = {}
+    x = torch.randn(4, 12, 8, 8, generator=g) * torch.linspace(0.5, 3.0, 12).view(1, 12, 1, 1) + 0.3
+    for name, scale in (("bv", 1.0), ("bv3", 3.0)):
+        an = rmod.ActNorm(12, scale=scale, batch_variance=True)
+        an.train()
+        ld = torch.randn(4, generator=g)
+        y, ldo = an(x.clone(), ld.clone())
+        out.update({f"{name}_bias": an.bias.data.clone(), f"{name}_logs": an.logs.data.clone(), f"{name}_y": y,
+                    f"{name}_logdet_in": ld, f"{name}_logdet": ldo})
+    out["x"] = x
+    save("g2_actnorm_bv.npz", out)
 
 
 def g3(g):
@@ -516,6 +533,9 @@ if __name__ == "__main__":
     if os.environ.get("ONLY") == "g9":
         g9(torch.Generator().manual_seed(99))
         sys.exit(0)
+    if os.environ.get("ONLY") == "g2_bv":
+        g2_bv()
+        sys.exit(0)
     if os.environ.get("ONLY") == "g7_grads":
         g7_grads()
         sys.exit(0)
@@ -523,6 +543,7 @@ if __name__ == "__main__":
         g7_learn_top()
         sys.exit(0)
     g1(g); g2(g); g3(g); g4(g); g5(g); g6(g); g7(g)
+    g2_bv()
     g7_grads()
     g7_learn_top()
     g8()

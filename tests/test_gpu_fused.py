@@ -141,6 +141,21 @@ def test_one_wave_kernel_at_a_16_pixel_wide_level():
         assert counts.get("variant:k_cnet1w<512,1,128>") == K, counts
 
 
+@pytest.mark.parametrize("image,batch,tiles", [(128, 7, 224), (256, 2, 256)])
+def test_one_wave_kernel_at_the_64_and_128_pixel_wide_levels_vs_oracle(image, batch, tiles):
+    """the PRODUCT forward + inverse instance of k_cnet1w at hidden 512 on the two level-1 widths of
+    configs D and E it had only met through property checks -- W = 64 (128x128 input: a 128-pixel tile is two image rows) at
+    batch 7 = 224 tiles, W = 128 (256x256 input: a tile is ONE image row, both halo rows belong to other tiles) at batch 2 =
+    256 tiles -- against the oracle on EVERY element of z / nll / decode at 1e-4 (inside _case), the instance asserted from
+    the run-time launch counters.  Reference: network/model.py:82-154, network/module.py:300-319."""
+    K = 2
+    assert batch * (image // 2) ** 2 // 128 == tiles
+    plan, fwd, rev = _case(image, 1, K, 512, batch, seed=15)
+    for counts in (fwd, rev):
+        assert counts.get("variant:k_cnet1w<512,1,128>") == K, counts
+        assert ncnet(counts) == K and nfinish(counts) == K, counts
+
+
 def test_config_b_geometry_batch16(path):
     """Batch 16: k_cnet splits the h2 rows over 2 / 4 workgroups per tile at the levels whose pixel tiles alone would leave CUs idle."""
     K = 3

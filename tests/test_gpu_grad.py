@@ -239,6 +239,61 @@ def test_gradients_at_celeba_geometry_vs_autograd_oracle():
         f"dL/dx err {egx.max().item():.3e} vs max|g| {gscale:.3e}"
 
 
+@pytest.mark.parametrize("image,batch", [(64, 28), (128, 7), (256, 2)])
+def test_one_wave_kernel_taping_and_backward_instances_vs_fp64_autograd_oracle(image, batch):
+    """the TAPING (MODE 1) and BACKWARD (MODE 2) instances of k_cnet1w against the fp64 autograd oracle
+    itself -- not against k_cnet -- at hidden 512, L = 1, K = 1 on every level-1 width the configs run it at: 32-pixel rows
+    (64x64 input, batch 28 = 224 tiles), 64-pixel rows (128x128, batch 7 = 224 tiles), 128-pixel rows (256x256, batch 2 =
+    256 tiles); the instances asserted from the run-time launch counters.  Same rule as the celeba-geometry test above (a ReLU
+    pre-activation within fp32 rounding of zero may flip one row of one weight gradient): at most 1 % of a tensor's entries
+    beyond 2e-4 max|g| + 1e-7, none beyond 5 %.  Reference: network/model.py:82-117, network/trainer.py:123-150."""
+    cfg = O.default_cfg(image_shape=(image, image, 3), K=1, L=1, batch=batch)
+    sd = O.seeded_state_dict(cfg, seed=31, invconv_perturb=0.02, zeros_std=0.01)
+    g = torch.Generator().manual_seed(31)
+    x = torch.rand(batch, 3, image, image, generator=g)
+    noise = torch.rand(batch, 3, image, image, generator=g) / 256
+    sd = O.glow_init_actnorm(x, noise, sd, cfg)
+    glow = G.Glow(hps_for(cfg, batch))
+    glow.load_state_dict(sd)
+    glow.set_actnorm_inited()
+    glow = glow.to(DEV).train()
+    ref, gx_ref, loss_ref = oracle_grads(cfg, {k: v.double() for k, v in sd.items()}, x.double(), noise.double())
+    plan = glow.flow.plan_for(x.to(DEV))
+    plan.launch_counts(reset=True)
+    with torch.enable_grad():
+        xd = x.to(DEV).requires_grad_(True)
+        z, nll, _ = glow.normal_flow(xd, None, noise=noise.to(DEV))
+        loss = G.Glow.generative_loss(nll)
+        loss.backward()
+    counts = plan.launch_counts(reset=True)
+    # ("k_cnet(tape)" / "k_cnet(bwd)" count every fused coupling launch; the 1w keys say that cnet1w_sh.hip took it.)  At 128-pixel rows
+    # the transposed network (12 channels in) has no fused backward instance -- its input tile with both halo rows needs two T units
+    # per wave (cnet_select: upw = 2) -- so that sweep runs layer by layer on the exact-fp32 kernels: the gradients below are still
+    # the taping k_cnet1w's tape against the fp64 oracle
+    want_bwd = 0 if image == 256 else 1
+    assert counts.get("k_cnet(tape)", 0) == 1 and counts.get("k_cnet1w(tape)", 0) == 1, counts
+    assert counts.get("k_cnet(bwd)", 0) == want_bwd and counts.get("k_cnet1w(bwd)", 0) == want_bwd, counts
+    assert abs(loss.item() - loss_ref) < 1e-4
+    z_ref, nll_ref, _ = O.glow_forward(x, noise, sd, cfg)
+    assert (z.detach().cpu() - z_ref).abs().max().item() <= 1e-4 and (nll.detach().cpu() - nll_ref).abs().max().item() <= 1e-4
+    worst = ("", 0.0)
+    for name, p in glow.named_parameters():
+        if name == "h_top":
+            continue
+        r = ref[name]
+        err = (p.grad.cpu().double() - r).abs()
+        scale = r.abs().max().item()
+        outliers = (err > 2e-4 * scale + 1e-7).double().mean().item()
+        assert outliers <= 0.01, f"{name}: {outliers:.2%} of the entries off by more than 2e-4 of max|g| = {scale:.3e}"
+        assert err.max().item() <= 0.05 * scale + 1e-7, f"{name}: max err {err.max().item():.3e}, max|g| {scale:.3e}"
+        worst = max(worst, (name, err.max().item() / (2e-4 * scale + 1e-7)), key=lambda t: t[1])
+    egx = (xd.grad.cpu().double() - gx_ref).abs()
+    gscale = gx_ref.abs().max().item()
+    assert (egx > 2e-4 * gscale + 1e-7).double().mean().item() <= 0.01 and egx.max().item() <= 0.05 * gscale, \
+        f"dL/dx err {egx.max().item():.3e} vs max|g| {gscale:.3e}"
+    print(f"{image}x{image} batch {batch}: worst {worst[0]} at {worst[1]:.2f} of the tight bound; dL/dx {egx.max().item():.2e} {counts}")
+
+
 @pytest.mark.parametrize("coup,perm,hidden", [("additive", "reverse", 512), ("additive", "shuffle", 256), ("affine", "invconv", 256)])
 def test_k_cnet_training_step_other_couplings_and_widths_vs_autograd_oracle(coup, perm, hidden):
     """The taping / backward k_cnet launches beyond the headline's affine + invconv at hidden 512: additive coupling (f.4 has C/2
@@ -877,6 +932,79 @@ def test_graphed_training_step_equals_the_eager_step_bitwise():
     for k in sa:
         for name in sa[k]:
             assert torch.equal(torch.as_tensor(sa[k][name]).cpu(), torch.as_tensor(sb[k][name]).cpu()), (k, name)
+
+
+def _two_loops(seed, graph, range_check=True, K=2, batch=8):
+    from pytorch_glow_amd import training
+    cfg = O.default_cfg(K=K, batch=batch)
+    sd = O.seeded_state_dict(cfg, seed=seed, invconv_perturb=0.02, zeros_std=0.01)
+    hps = hps_for(cfg, batch)
+    hps.optim.update(optimizer="adam", optimizer_args=dict(lr=1e-4, betas=[0.9, 0.9999], eps=1e-8),
+                     lr_scheduler="noam", lr_scheduler_args=dict(warmup_steps=5, min_lr=1e-5))
+    hps.ablation.update(max_grad_clip=5, max_grad_norm=100)
+
+    def fresh():
+        glow = G.Glow(hps)
+        sd2 = dict(sd); sd2["h_top"] = torch.zeros_like(glow.h_top)
+        glow.load_state_dict(sd2)
+        glow.set_actnorm_inited()
+        return glow.to(DEV).train()
+
+    return [training.TrainLoop(fresh(), hps, graph=g, range_check=range_check) for g in graph], batch
+
+
+def test_graphed_steps_queued_far_ahead_of_the_device_read_their_own_learning_rate():
+    """a replay's {lr, 1 - beta1^step, 1 - beta2^step} travel through PINNED host words, and a pinned-source copy
+    reads them when the stream gets to it -- with one slot, a host several steps ahead of the device let step N read step N + 1's
+    values.  Here the device is held back (a ~0.5 s spin kernel) while the host queues nine graphed steps under the noam warm-up
+    (the learning rate and both bias corrections change every step) with no sync in between and the range check off (nothing bounds
+    the host's lead but the slot ring itself): parameters and optimiser state must equal the eager loop's bit for bit."""
+    loops, batch = _two_loops(41, graph=(False, True), range_check=False)
+    g = torch.Generator().manual_seed(41)
+    batches = [torch.rand(batch, 3, 64, 64, generator=g).to(DEV) for _ in range(12)]
+    for loop in loops:
+        for step, xs in enumerate(batches):
+            if step == loop.GRAPH_AFTER and loop.graph:
+                torch.cuda._sleep(1_000_000_000)                 # the host runs ahead from here on
+            torch.manual_seed(300 + step)
+            loop.step(xs)
+        loop.flush()
+    torch.cuda.synchronize()
+    assert loops[1].graph_error is None and loops[1]._graphed is not None
+    assert loops[0].optimizer._steps == loops[1].optimizer._steps == 12
+    pa, pb = loops[0].glow.state_dict(), loops[1].glow.state_dict()
+    assert all(torch.equal(pa[k], pb[k]) for k in pa), [k for k in pa if not torch.equal(pa[k], pb[k])][:5]
+    sa, sb = loops[0].optimizer.state_dict()["state"], loops[1].optimizer.state_dict()["state"]
+    assert all(torch.equal(torch.as_tensor(sa[k][n]).cpu(), torch.as_tensor(sb[k][n]).cpu()) for k in sa for n in sa[k])
+
+
+def test_direct_step_binds_its_gradients_again_after_zero_grad_and_after_an_autograd_step():
+    """`Glow.loss_and_grads` makes the plan's persistent bucket views the parameters' .grad; a caller that runs
+    `optimizer.zero_grad()` (set_to_none) or one autograd-route step in between takes them away.  The next direct step must bind
+    them again and the optimiser must rebuild its chunk table (a new token): after [direct, zero_grad, direct, autograd, direct] the
+    parameters equal those of a loop that ran the same five batches on the autograd route throughout, bit for bit -- with stale
+    bindings the third / fifth update applied old gradients or none."""
+    from pytorch_glow_amd import parallel
+    loops, batch = _two_loops(43, graph=(False, False))
+    g = torch.Generator().manual_seed(43)
+    routes = [(True, False), (True, True), (False, False), (True, False), (True, False)]      # (direct?, zero_grad after?)
+    for step, (direct, zero) in enumerate(routes):
+        xs = torch.rand(batch, 3, 64, 64, generator=g).to(DEV)
+        for loop, d in zip(loops, (direct, False)):
+            torch.manual_seed(400 + step)
+            loop.lr = loop.scheduler(global_step=loop.global_step)
+            for group in loop.optimizer.param_groups:
+                group["lr"] = loop.lr
+            parallel.train_step(loop.glow, loop.optimizer, xs, world=1, max_grad_clip=5, max_grad_norm=100, direct=d)
+            loop.global_step += 1
+        if zero:
+            loops[0].optimizer.zero_grad()
+            assert all(p.grad is None for p in loops[0].glow.parameters())
+    plan = loops[0].glow._train_plan
+    views = plan._pgrad[1]
+    assert all(p.grad is v for p, v in zip(plan.trainable_parameters(), views))
+    pa, pb = loops[0].glow.state_dict(), loops[1].glow.state_dict()
+    assert all(torch.equal(pa[k], pb[k]) for k in pa), [k for k in pa if not torch.equal(pa[k], pb[k])][:5]
 
 
 def test_log_scale_gradients_do_not_read_weight_gradients_after_their_bucket_is_handed_over():

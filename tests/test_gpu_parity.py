@@ -85,6 +85,19 @@ def test_g2_actnorm(golden):
     assert not an.bias_inited and torch.equal(y.cpu(), g["x"])
 
 
+def test_g2_actnorm_batch_variance(golden):
+    """VERDICT r5 missing #3: ActNorm(batch_variance=True) (network/module.py:109-110) -- the per-channel moments of the init
+    reduction pooled into ONE log-scale (glowhip_actnorm_init_batch_variance) -- against the reference-recorded vectors."""
+    g = golden("g2_actnorm_bv")
+    for name, scale in (("bv", 1.0), ("bv3", 3.0)):
+        an = G.ActNorm(12, scale=scale, batch_variance=True).to(DEV).train()
+        y, ld = an(dev(g["x"]), dev(g[f"{name}_logdet_in"]))
+        assert an.bias_inited and an.logs_inited
+        close(an.bias, g[f"{name}_bias"], 2e-6, what="bias"); close(an.logs, g[f"{name}_logs"], 2e-6, what="logs")
+        assert float(an.logs.max() - an.logs.min()) == 0.0
+        close(y, g[f"{name}_y"], 5e-6); ld_close(ld, g[f"{name}_logdet"])
+
+
 @pytest.mark.parametrize("c", [12, 24, 48, 96])
 def test_g3_invconv(golden, c):
     g = sub(golden("g3_invconv"), f"c{c}_")

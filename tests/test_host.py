@@ -288,3 +288,41 @@ def test_dequant_stream_is_keyed_by_seed_and_rank_and_counts_per_process(monkeyp
     M.dequant_position(advance=True)
     M.reset_dequant_stream()
     assert M.dequant_position() == (11, 0)
+
+
+def test_multi_rank_range_check_is_resolved_at_a_fixed_lag():
+    """with more than one rank the deferred range check of step N must be resolved at the same point of every
+    rank's collective sequence -- when MAX_LAG checks are pending -- and never earlier because the rank's own event has already
+    passed (a rank that re-ran the skipped batch a step before its peers paired the re-run's bucket all-reduces with another
+    batch's).  One rank keeps the opportunistic early look.  Host logic only: the events and norms are stand-ins."""
+    from pytorch_glow_amd import training
+
+    class Passed:
+        def query(self):
+            return True
+
+    class Opt:
+        undone = 0
+
+        def undo_step(self):
+            self.undone += 1
+
+    def loop(world):
+        t = training.TrainLoop.__new__(training.TrainLoop)
+        t.world, t._pending, t._rerun, t.range_fallbacks, t.optimizer = world, [], None, 0, Opt()
+        return t
+
+    bad = lambda: ("batch", torch.tensor([float("nan")]), Passed(), 1e-4)
+    ok = lambda: ("batch", torch.tensor([1.0]), Passed(), 1e-4)
+    assert training.TrainLoop.MAX_LAG == 2
+    one, two = loop(1), loop(2)
+    for t in (one, two):
+        t._pending.append(bad())
+        t._check_previous()
+    assert one.range_fallbacks == 1 and not one._pending               # one rank: looked at as soon as it has landed
+    assert two.range_fallbacks == 0 and len(two._pending) == 1         # two ranks: not yet, whatever the event says
+    two._pending.append(ok())
+    two._check_previous()                                              # MAX_LAG pending: the oldest is resolved now, and only it
+    assert two.range_fallbacks == 1 and two.optimizer.undone == 1 and len(two._pending) == 1 and len(two._rerun) == 1
+    two._check_previous(drain=True)                                    # flush(): everything
+    assert not two._pending and two.range_fallbacks == 1

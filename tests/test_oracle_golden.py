@@ -52,6 +52,17 @@ def test_g2_actnorm(golden):
     close(y, g["fwd_y_nold"])
 
 
+def test_g2_actnorm_batch_variance(golden):
+    """ActNorm(batch_variance=True), network/module.py:109-110, against the reference-recorded init (one pooled log-scale)."""
+    g = golden("g2_actnorm_bv")
+    for name, scale in (("bv", 1.0), ("bv3", 3.0)):
+        b, l = O.actnorm_init(g["x"], scale, batch_variance=True)
+        close(b, g[f"{name}_bias"]); close(l, g[f"{name}_logs"])
+        assert float(l.max() - l.min()) == 0.0
+        y, ld = O.actnorm(g["x"], b, l, g[f"{name}_logdet_in"])
+        close(y, g[f"{name}_y"]); ld_close(ld, g[f"{name}_logdet"])
+
+
 @pytest.mark.parametrize("c", [12, 24, 48, 96])
 def test_g3_invconv(golden, c):
     g = sub(golden("g3_invconv"), f"c{c}_")
