@@ -355,9 +355,9 @@ class FlowPlan:
             flats, grads, arr, events, marks, handles = cached
         if not persistent:
             # the sweep rewrites the plan's host-side gradient job tables with THIS call's temporary buffers, and the copy nodes of a
-            # captured training step read those tables at replay time: whoever replays a graph over this plan sees the epoch move and
-            # captures again after an eager step
-            self._pack_epoch = getattr(self, "_pack_epoch", 0) + 1
+            # captured training step read those tables at replay time: training.GraphedTrainStep sees this epoch move and captures
+            # again after an eager step.  (A captured inference forward reads none of them: it keeps to _pack_epoch.)
+            self._grad_table_epoch = getattr(self, "_grad_table_epoch", 0) + 1
         gx = torch.empty_like(x) if want_grad_x else None
         ws = self._train_workspace(n)
         check(lib().glowhip_plan_backward_marks(self._h, marks, handles, len(events)))

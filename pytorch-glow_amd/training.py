@@ -306,7 +306,10 @@ class GraphedTrainStep:
                 # an eager pack of this plan for the OTHER kernel family since the capture (a re-run of an overflowed batch): it rebuilt
                 # the host-side job tables the captured pack's copy nodes read (measured: a replay after such a re-run faulted on a
                 # host address); packs of the same family keep them in place
-                getattr(plan, "_pack_epoch", 0))
+                getattr(plan, "_pack_epoch", 0),
+                # an eager backward with NON-persistent gradients (normal_flow + loss.backward() on this plan) since the capture: it
+                # rewrote the gradient job tables with pointers to its own temporary buffers
+                getattr(plan, "_grad_table_epoch", 0))
 
     def valid(self):
         """False once a parameter or one of the buffers above moved: capture again (after an eager step)."""
