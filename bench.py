@@ -132,7 +132,7 @@ def cpu_baseline(glow, x_cpu, cfg, budget_s=90.0, fallback_batch=None):
 
 KERNEL_KINDS = {0: "chanmix", 1: "conv_f0_3x3", 2: "conv_f2_1x1", 3: "conv_f4_3x3_tail", 5: "cnet_f0+f2+f4", 6: "cnet_finish",
                 7: "cnet_tape_f0+f2+f4", 8: "cnet_bwd_dgrad_chain", 9: "wgrad_gemms"}
-CNET_DESC = ("k_cnet / k_cnet1w (the coupling network of a FlowStep in ONE launch -- k_cnet1w, one wave per SIMD with h1 / h2 chained through "
+CNET_DESC = ("k_cnet1w / k_cnet: a FlowStep's coupling net f.0+f.2+f.4 in ONE launch, all levels (k_cnet1w, one wave per SIMD with h1 / h2 chained through "
              "the register file, where a level gives >= 224 128-pixel tiles; k_cnet, two waves per SIMD, elsewhere: f.0 3x3 conv C/2->512 + ActNorm + ReLU, f.2 1x1 conv 512->512 + "
              "ActNorm + ReLU, f.4 3x3 conv 512->C as taps-as-rows GEMM + tap sums; h1, h2 stay in LDS / registers; fp32-accurate products "
              "as 3 f16 MFMAs, peak = 2500/3 TFLOP/s algorithmic; all levels' launches)")
@@ -216,8 +216,14 @@ def instrumented_pass(plan, hps, B, run_once, passes=3, with_traffic=False, trai
     name = (CNET_DESC + ("; here the taping forward (MODE 1: also stores h1 / h2 as fp16, pixel-tile-major, + sign words) and the input-gradient chain "
                          "(MODE 2) launches of the training step -- level 1 on the taping / backward instances of k_cnet1w, levels 2 / 3 on k_cnet" if train else "")) if cnet_path else \
            "k_gemm_glds (f.2: 1x1 conv 512->512 + ActNorm + ReLU, fp32-input MFMA, 128x128 tiles)"
+    # (flat, short values first: the driver's record keeps scalars and the head of strings; the full records follow)
+    tnote = None
+    if traffic_src is not None:
+        tnote = (f"{traffic_src['file']} @ {str(traffic_src.get('collected_at_commit'))[:10]}: rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes, "
+                 f"NOT re-measured in this run{'; STALE (kernel source changed since)' if traffic_src.get('stale') else ''}")
     roof = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-            "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
+            "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": tnote, "traffic_source_detail": traffic_src,
+            **{f"frac_{k}": round(v[1] / (v[0] * 1e-3) / 1e12 / peak, 4) for k, v in sorted(per_level.items()) if v[0] > 0},
             "launches": dom_n // passes, "avg_launch_us": round(1e3 * dom_ms / max(dom_n, 1), 2),
             "flop_per_launch_avg": dom_flop / max(dom_n, 1),
             "issued_mfma_tflops": round(achieved * (3 if sh_path else 1), 1),
@@ -263,6 +269,9 @@ def setup_workload(G, util, parallel, device, cfg_name, mode, B, rank, world, re
         torch.set_grad_enabled(False)   # forward+logdet metric: inference path (no activation tape)
 
     def step():
+        if mode == "checked":   # the DROP-IN call: glow(x) in eval under no_grad, range check on (what infer.py / Trainer validation run)
+            z, nll, _ = glow(x)
+            return nll.sum()
         if mode == "train":     # secondary metric: the reference's training step (trainer.py:123-150)
             loss, _ = loop.step(x)
             return loss * (world * B)
@@ -286,7 +295,7 @@ def setup_workload(G, util, parallel, device, cfg_name, mode, B, rank, world, re
     return wl
 
 
-SECONDARY = [("D", ["forward"]), ("E", ["forward", "inverse"]), ("B", ["train"])]
+SECONDARY = [("B", ["checked"]), ("D", ["forward"]), ("E", ["forward", "inverse"]), ("B", ["train"])]
 
 
 def secondary_workloads(G, util, parallel, device, steps=3, warmup=3):
@@ -313,7 +322,7 @@ def secondary_workloads(G, util, parallel, device, steps=3, warmup=3):
                 def step():
                     plan.ensure_packed(False, use=plan.PACK_INFERENCE | plan.PACK_INVERSE)
                     return glow.reverse_flow(z_top, None, eps_std=0.7).sum()
-            n_timed = steps + (2 if mode == "train" else 0)
+            n_timed = steps + (2 if mode == "train" else 0) + (17 if mode == "checked" else 0)
             for _ in range(warmup + (7 if mode == "train" else 0)):      # (the training step's first iterations still allocate:
                 step()                                                   #  12 GB of tape, gradient buckets, optimiser state)
             torch.cuda.synchronize()
@@ -340,7 +349,7 @@ def secondary_workloads(G, util, parallel, device, steps=3, warmup=3):
             torch.cuda.synchronize()
             if "loop" in wl:
                 wl["loop"].flush()
-            name = f"{cfg_name}_{mode}"
+            name = "B_forward_checked" if mode == "checked" else f"{cfg_name}_{mode}"
             out[name] = {"value": round(B * n_timed / dt, 2), "unit": "images/sec", "ms_per_step": round(1e3 * dt / n_timed, 3),
                          "ms_per_step_gpu_events": round(e0.elapsed_time(e1) / n_timed, 3), "steps": n_timed,
                          # host side of a step: wall time of the enqueue loop (includes any wait for the device: the training loop
@@ -351,6 +360,9 @@ def secondary_workloads(G, util, parallel, device, steps=3, warmup=3):
                          "workload": f"{cfg['label']}, {mode}, batch {B} ({cfg['ref']})",
                          "finite": bool(torch.isfinite(last).all()), "data_dependent_init_ms": wl["init_ms"],
                          **({"launch": launch} if launch else {}),
+                         **({"call": "glow(x) in eval mode under torch.no_grad(), Glow.range_check on (network/inferer.py:55,81, trainer.py:163): "
+                                     "the weights are not re-derived per call (eval: they do not change)",
+                             "range_fallbacks": type(wl["glow"])._RANGE_FALLBACKS} if mode == "checked" else {}),
                          "kernel_families": sorted(inst["launches"]),
                          "roofline": inst["roofline"], "breakdown_ms_per_step": inst["breakdown"],
                          "wall_s_incl_setup": round(time.perf_counter() - t_wall, 1)}
@@ -429,14 +441,53 @@ def dry_run_cpu(args, rank, world):
         t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    multi = None
+    if world > 1:      # the diagnostics the real N-rank line carries (same helpers, same collective order; tiny buffer, gloo)
+        from pytorch_glow_amd import parallel
+        per_rank = parallel.gather_scalars(1e3 * dt / max(args.steps, 1) + rank, "cpu")
+        multi = {"world": dist.get_world_size(), "backend": dist.get_backend(), "per_rank_device_ms_per_step": per_rank,
+                 "ms_per_step_rank_min": min(per_rank), "ms_per_step_rank_max": max(per_rank),
+                 "gradient_allreduce_flat": parallel.timed_allreduce(1 << 16, "cpu", reps=2, warmup=1)}
     if rank == 0:
-        print(json.dumps({"metric": "dry run (no GPU work)", "dry_run": True, "value": 0.0, "unit": "images/sec", "n_gpus": world,
+        print(json.dumps({"metric": "dry run (no GPU work)", "dry_run": True, "value": 0.0, "unit": "images/sec", "n_gpus": world, "multi_rank": multi,
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / max(args.steps, 1), 4),
                           "rccl_world_size": dist.get_world_size() if world > 1 else 1,
                           "allreduce_check": float(loss), "scaling": "weak"}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def multi_rank_diagnostics(torch, dist, parallel, device, args, wl, marks, world, rank, forced):
+    """What makes the first N-rank RCCL run diagnostic rather than merely green.  Runs on EVERY rank, after the
+    timed region and its MAX reduction (nothing of this is in `value`), in the same order on all of them -- the collectives below
+    pair up by construction:
+      * per-rank device time per step (events of each rank's own stream around its timed steps, no barrier inside): a slow rank
+        or a slow GPU shows as the spread, which the MAX alone hides;
+      * one flat fp32 all-reduce of the model's whole gradient (44.05 M elements = 176 MB at config B), timed on its own: what the
+        training step's exchange costs when nothing overlaps it, as algorithmic / bus GB/s against the ~153 GB/s of one xGMI link;
+      * train mode: three more steps with the bucket all-reduces stamped by events on the side stream (parallel.BUCKET_TIMING):
+        time of the collectives per step, the part still running after the backward sweep has finished, the fraction hidden."""
+    dev_ms = marks[0].elapsed_time(marks[-1]) / max(args.steps, 1)
+    per_rank = parallel.gather_scalars(dev_ms, device)
+    out = {"world": dist.get_world_size(), "backend": dist.get_backend(),
+           "per_rank_device_ms_per_step": [round(v, 4) for v in per_rank],
+           "ms_per_step_rank_min": round(min(per_rank), 4), "ms_per_step_rank_max": round(max(per_rank), 4)}
+    numel = sum(p.numel() for p in wl["glow"].parameters() if p.requires_grad and p is not wl["glow"].h_top)
+    out["gradient_allreduce_flat"] = parallel.timed_allreduce(numel, device)
+    if args.mode == "train":
+        loop = wl["loop"]
+        loop.flush()
+        parallel.BUCKET_TIMING = records = []
+        try:
+            for _ in range(3):
+                loop.step(wl["x"])
+            loop.flush()
+            torch.cuda.synchronize()
+        finally:
+            parallel.BUCKET_TIMING = None
+        out["gradient_bucket_overlap"] = parallel.bucket_overlap_report(records)
+    return out
 
 
 def main():
@@ -486,7 +537,13 @@ def main():
     assert torch.cuda.device_count() > local_rank, f"rank {rank}: no GPU {local_rank} (device_count={torch.cuda.device_count()})"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    # GLOWHIP_BENCH_FORCE_DIST=1 with --gpus 1: a ONE-rank RCCL group, and the exchange code of the N-rank run executed over it (the
+    # gradient buckets through the side-stream all-reduce, the timed flat all-reduce, the per-rank gather) -- so that a one-GPU box
+    # runs every line of the multi-rank path; the line is marked `forced_one_rank_group` and its metric `[diagnostic run]`
+    forced = world == 1 and os.environ.get("GLOWHIP_BENCH_FORCE_DIST") == "1"
+    if forced:
+        os.environ.update(RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT") or str(free_port()))
+    if world > 1 or forced:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         import datetime
         # (generous: ranks != 0 sit in the step-0 barrier while rank 0 runs the data-dependent init pass)
@@ -504,7 +561,9 @@ def main():
     cfg = CONFIGS[args.config]
     B = args.batch or cfg["batch"]
     repack = args.repack if args.mode == "inverse" else not args.no_repack
-    wl = setup_workload(G, util, parallel, device, args.config, args.mode, B, rank, world, repack, graph=not args.no_graph and not dbg)
+    parallel.FORCE_EXCHANGE = forced
+    wl = setup_workload(G, util, parallel, device, args.config, args.mode, B, rank, world, repack,
+                        graph=not args.no_graph and not dbg and not (forced and args.mode == "train"))
     glow, hps, plan, x, step = wl["glow"], wl["hps"], wl["plan"], wl["x"], wl["step"]
     z_top = wl.get("z_top")
 
@@ -537,6 +596,9 @@ def main():
         dt = float(t.item())
     total_images = world * B * args.steps
     value = total_images / dt
+    multi = None
+    if world > 1 or forced:
+        multi = multi_rank_diagnostics(torch, dist, parallel, device, args, wl, marks, world, rank, forced)
     if "loop" in wl:      # how the timed training steps were launched
         lp = wl["loop"]
         wl["launch"] = ("hipGraph (training step captured after the eager warm-up steps, one graph launch per step)" if lp._graphed is not None
@@ -554,6 +616,8 @@ def main():
             metric = f"images/sec Glow {what}, {cfg['image']}x{cfg['image']}x3 L={cfg['L']} K={cfg['K']} [secondary metric]"
         if dbg:
             metric += f" [debug run, flags {dbg:#x}]"
+        if forced:
+            metric += " [diagnostic run: one-rank RCCL group, exchange path forced]"
         out = {
             "metric": metric,
             "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -575,11 +639,15 @@ def main():
             "frac_of_fp32_mfma_peak_whole_model": round(value / world * fpi / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4),
             "frac_of_split_f16_peak_whole_model": round(value / world * fpi / (PEAK_SPLIT_TFLOPS * 1e12), 4),
         }
+        if multi is not None:
+            out["multi_rank"] = multi
+        if forced:
+            out["forced_one_rank_group"] = True
         if args.mode == "train":
             out.pop("model_tflops"), out.pop("frac_of_fp32_mfma_peak_whole_model"), out.pop("frac_of_split_f16_peak_whole_model")
             out["model_tflops_fwd_bwd"] = round(value * 3 * fpi / 1e12, 2)   # backward ~ 2x forward flops
             print(json.dumps(out), flush=True)
-            if world > 1:
+            if world > 1 or forced:
                 dist.barrier()
                 dist.destroy_process_group()
             return
@@ -632,7 +700,7 @@ def main():
             torch.cuda.empty_cache()
             out["secondary"] = secondary_workloads(G, util, parallel, device)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or forced:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -130,6 +130,15 @@ def allreduce_gradients(module: torch.nn.Module, world: Optional[int] = None, av
 
 
 _SIDE_STREAMS = {}
+# Diagnostics (bench.py --gpus N): a list here makes `allreduce_buckets` stamp its collectives with timing events -- one record per
+# call: {"sweep_done": event on the caller's stream behind the backward sweep, "spans": [(start, end, bytes)] on the side stream}.
+BUCKET_TIMING: Optional[list] = None
+# Run the exchange also in a ONE-rank process group (a sum over the one rank there is): lets a one-GPU box execute the RCCL path.
+FORCE_EXCHANGE = False
+
+
+def _exchange_off(world: int) -> bool:
+    return world <= 1 and not (FORCE_EXCHANGE and dist.is_available() and dist.is_initialized())
 
 
 def allreduce_buckets(buckets, world: Optional[int] = None, average: bool = True) -> None:
@@ -138,7 +147,7 @@ def allreduce_buckets(buckets, world: Optional[int] = None, average: bool = True
     below it (`FlowPlan.last_grad_buckets`, csrc glowhip_plan_backward_marks).  buckets: [(flat tensor, event or None)] in the
     order they become ready.  The current stream waits for the last collective before returning to the caller's work."""
     world = dist.get_world_size() if world is None else world
-    if world <= 1 or not buckets:
+    if _exchange_off(world) or not buckets:
         return
     if not buckets[0][0].is_cuda:                     # CPU / gloo (tests): same collectives, no streams
         for flat, _ in buckets:
@@ -151,14 +160,25 @@ def allreduce_buckets(buckets, world: Optional[int] = None, average: bool = True
     if side is None:
         side = _SIDE_STREAMS[dev] = torch.cuda.Stream(device=dev)
     cur = torch.cuda.current_stream(dev)
+    rec = None
+    if BUCKET_TIMING is not None:
+        rec = {"sweep_done": torch.cuda.Event(enable_timing=True), "spans": []}
+        rec["sweep_done"].record(cur)                 # (the whole sweep is already enqueued on the caller's stream)
+        BUCKET_TIMING.append(rec)
     with torch.cuda.stream(side):
         for flat, ready in buckets:
             if ready is not None:
                 side.wait_event(ready)
             flat.record_stream(side)
+            if rec is not None:
+                t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                t0.record(side)
             dist.all_reduce(flat, op=dist.ReduceOp.SUM)       # RCCL: ordered after the side stream's wait
-            if average:
+            if average and world > 1:
                 flat.div_(world)
+            if rec is not None:
+                t1.record(side)
+                rec["spans"].append((t0, t1, flat.numel() * flat.element_size()))
     done = torch.cuda.Event()
     done.record(side)
     cur.wait_event(done)
@@ -212,3 +232,63 @@ def train_step(glow, optimizer, x_local: torch.Tensor, world: int = 1, max_grad_
         dist.all_reduce(loss, op=dist.ReduceOp.SUM)
         loss /= world
     return loss, grad_norm
+
+
+# ------------------------------------------------------------------------------------------------ diagnostics (bench.py --gpus N)
+def bucket_overlap_report(records) -> Optional[dict]:
+    """What `BUCKET_TIMING` collected, after a device sync: per step the time the bucket all-reduces took on the side stream, the
+    part of it that was still running after the backward sweep had finished on the main stream (`exposed`), and the fraction
+    hidden under the sweep = 1 - exposed / total."""
+    steps = []
+    for rec in records or ():
+        if not rec["spans"]:
+            continue
+        total = sum(a.elapsed_time(b) for a, b, _ in rec["spans"])
+        exposed = max(0.0, rec["sweep_done"].elapsed_time(rec["spans"][-1][1]))
+        steps.append((total, min(exposed, total), sum(n for _, _, n in rec["spans"])))
+    if not steps:
+        return None
+    total = sum(t for t, _, _ in steps) / len(steps)
+    exposed = sum(e for _, e, _ in steps) / len(steps)
+    return {"steps": len(steps), "buckets_per_step": len(records[0]["spans"]), "bytes_per_step": steps[0][2],
+            "allreduce_ms_per_step": round(total, 3), "exposed_ms_per_step": round(exposed, 3),
+            "hidden_fraction": round(1.0 - exposed / total, 4) if total > 0 else None}
+
+
+def timed_allreduce(numel: int, device, reps: int = 5, warmup: int = 2) -> dict:
+    """One flat fp32 all-reduce of `numel` elements (the training step's whole gradient: 44.05 M = 176 MB at config B), timed with
+    events on the stream it runs on; algorithmic and bus bandwidth as nccl-tests define them (bus = alg x 2 (n-1) / n: what each
+    rank's links carry in a ring -- xGMI is point-to-point, so a ring all-reduce is bound by ONE ~153 GB/s link per direction)."""
+    world = dist.get_world_size()
+    flat = torch.ones(numel, dtype=torch.float32, device=device)
+    cuda = flat.is_cuda
+    for _ in range(warmup):
+        dist.all_reduce(flat)
+    if cuda:
+        torch.cuda.synchronize(device)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    import time
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        dist.all_reduce(flat)
+    if cuda:
+        e1.record()
+        torch.cuda.synchronize(device)
+        ms = e0.elapsed_time(e1) / reps
+    else:
+        ms = 1e3 * (time.perf_counter() - t0) / reps
+    nbytes = numel * 4
+    alg = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    return {"bytes": nbytes, "world": world, "allreduce_ms": round(ms, 3), "algbw_GBps": round(alg, 1),
+            "busbw_GBps": round(alg * 2 * (world - 1) / world, 1) if world > 1 else 0.0,
+            "xgmi_link_peak_GBps": 153.0, "reps": reps}
+
+
+def gather_scalars(value: float, device) -> list:
+    """One float from every rank, in rank order (per-rank step times for the bench line)."""
+    world = dist.get_world_size()
+    mine = torch.tensor([value], dtype=torch.float64, device=device)
+    out = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(out, mine)
+    return [float(t.item()) for t in out]

@@ -201,6 +201,14 @@ def test_bench_launches_its_own_ranks_dry_run():
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["rccl_world_size"] == 2 and rec["steps"] == 3 and rec["warmup"] == 1
     assert rec["allreduce_check"] == 3.0     # 1 + 2: both ranks took part in the step's collective
+    # the N-rank line's diagnostics: per-rank step times gathered in rank order (the dry run adds the rank to each so
+    # the order shows), their min / max, and the timed flat all-reduce -- the same parallel.* helpers the RCCL run calls
+    mr = rec["multi_rank"]
+    assert mr["world"] == 2 and mr["backend"] == "gloo" and len(mr["per_rank_device_ms_per_step"]) == 2
+    assert mr["per_rank_device_ms_per_step"][1] > mr["per_rank_device_ms_per_step"][0] + 0.5
+    assert mr["ms_per_step_rank_min"] == min(mr["per_rank_device_ms_per_step"]) and mr["ms_per_step_rank_max"] == max(mr["per_rank_device_ms_per_step"])
+    ar = mr["gradient_allreduce_flat"]
+    assert ar["bytes"] == 4 << 16 and ar["world"] == 2 and ar["allreduce_ms"] > 0 and ar["busbw_GBps"] == pytest.approx(ar["algbw_GBps"], rel=0.05)
     # a failing rank takes the job down with a non-zero exit code instead of hanging the others
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                          capture_output=True, text=True, timeout=300, env=dict(env, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES=""))

@@ -254,9 +254,15 @@ def test_bench_line_carries_the_contract_fields_and_the_secondary_workloads():
         assert k in d, k
     assert d["steps"] == 5 and d["n_gpus"] == 1 and d["roofline"]["bound"] == "mfma" and 0 < d["roofline"]["frac"] < 1
     sec = d["secondary"]
-    assert set(sec) == {"D_forward", "E_forward", "E_inverse", "B_train"}
+    assert set(sec) == {"B_forward_checked", "D_forward", "E_forward", "E_inverse", "B_train"}
     for name, r in sec.items():
-        assert r["finite"] and r["value"] > 0 and r["steps"] == (5 if name == "B_train" else 3), (name, r)
+        assert r["finite"] and r["value"] > 0 and r["steps"] == {"B_train": 5, "B_forward_checked": 20}.get(name, 3), (name, r)
+    # the drop-in call -- glow(x) in eval under no_grad with the range check on (network/inferer.py:55,81) -- next to the headline's
+    # unchecked graph replay; a healthy batch takes no fall-back
+    assert sec["B_forward_checked"]["range_fallbacks"] == 0 and sec["B_forward_checked"]["value"] > 0.8 * d["value"], (sec["B_forward_checked"], d["value"])
+    # what the driver's record keeps of `roofline` (scalars and short strings): the per-level fractions and the traffic's provenance flat
+    assert all(0 < d["roofline"][f"frac_{k}"] < 1 for k in ("C12_32x32", "C24_16x16", "C48_8x8"))
+    assert d["roofline"]["traffic"] is None or "NOT re-measured" in d["roofline"]["traffic_source"]
     assert "k_cnet" in sec["D_forward"]["kernel_families"] and "k_cnet" in sec["E_forward"]["kernel_families"]
     # every secondary workload carries the roofline of ITS dominant kernel from the same live-event pass as the headline's
     for name, r in sec.items():
@@ -265,3 +271,30 @@ def test_bench_line_carries_the_contract_fields_and_the_secondary_workloads():
         assert rf["dominant_kernel_ms_per_step"] < r["ms_per_step_gpu_events"] * 1.05, (name, rf)      # (a part of the step, not more)
     assert sec["B_train"]["roofline"]["launches"] == 2 * 96          # taping forward + input-gradient chain per FlowStep
     assert d["roofline"]["launches"] == 96 and set(d["roofline"]["per_level"]) == {"C12_32x32", "C24_16x16", "C48_8x8"}
+
+
+def test_bench_multi_rank_diagnostics_over_a_one_rank_rccl_group():
+    """VERDICT r5 #7 on a one-GPU box: GLOWHIP_BENCH_FORCE_DIST=1 makes `bench.py --gpus 1` join a ONE-rank RCCL group and run the
+    N-rank line's exchange code over it -- per-rank step times gathered, the 176 MB flat gradient all-reduce timed on its own, and in
+    train mode the per-level bucket all-reduces on the side stream stamped with events: time per step, the part exposed behind the
+    backward sweep, the fraction hidden.  The numbers of a one-rank group say nothing about xGMI; that every line of the path runs on
+    a device, and what the line looks like, is the point."""
+    import subprocess, sys, json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GLOWHIP_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for mode in ("train", "forward"):
+        proc = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "4", "--mode", mode,
+                               "--no-cpu-baseline", "--no-secondary", "--no-exact-leg"], capture_output=True, text=True, timeout=900, cwd=root, env=env)
+        assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-4000:]
+        d = json.loads([l for l in proc.stdout.splitlines() if l.startswith("{")][0])
+        assert d["forced_one_rank_group"] and "diagnostic run" in d["metric"] and d["rccl_world_size"] == 1
+        mr = d["multi_rank"]
+        assert mr["backend"] == "nccl" and mr["world"] == 1 and len(mr["per_rank_device_ms_per_step"]) == 1
+        assert mr["ms_per_step_rank_min"] == mr["ms_per_step_rank_max"] > 0
+        ar = mr["gradient_allreduce_flat"]
+        assert ar["bytes"] == 4 * 44052720 and ar["allreduce_ms"] > 0
+        if mode == "train":
+            ov = mr["gradient_bucket_overlap"]
+            assert ov["steps"] == 3 and ov["buckets_per_step"] == 4 and ov["bytes_per_step"] >= 4 * 44052720
+            assert ov["allreduce_ms_per_step"] > 0 and 0.0 <= ov["hidden_fraction"] <= 1.0
+            assert np.isfinite(d["config"]["loss_mean_nll_bits_per_dim"])
