@@ -31,6 +31,7 @@
 
 #include "conv_mfma.h"
 #include "cnet_geo.h"
+#include "cnet_fin.h"
 
 GH_STAMPS_DEFINE(cnet1w)
 GH_WGTIMES_DEFINE(cnet1w)
@@ -47,6 +48,13 @@ __device__ __forceinline__ void c1_dma16o(const void* gsrc, void* ldst) {   // t
 template <int OFF>
 __device__ __forceinline__ void c1_bdma16o(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff, void* ldst) {      // the same through a buffer descriptor
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)ldst, 16, voff, soff, OFF, 0);
+}
+// a partial sum of f.4 to the scratch buffer: plain store, or -- fused finishing -- an agent-scope relaxed atomic store (sc1: written
+// through the XCD's L2, so that a workgroup on another XCD reads it with the matching load)
+template <bool COH>
+__device__ __forceinline__ void c1_publish(float* p, float v) {
+    if constexpr (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
 }
 #define C1_MFMA(A_, B_, C_) __builtin_amdgcn_mfma_f32_32x32x16_f16(A_, B_, C_, 0, 0, 0)
 #define C1_FENCE() __builtin_amdgcn_sched_barrier(0)
@@ -100,8 +108,11 @@ __host__ __device__ constexpr int c1_f0slot(int nq, int nst0, int j) {
 // words, one 16-bit word per lane and block, requested a block ahead -- and g_u2 / g_u0 go to memory as fp32 [pixel / 32][row][pixel % 32]
 // for the weight-gradient GEMMs: a lane's value of a row is 4 bytes of that row's 128-byte line, so a wave's store of one register
 // writes two full lines (no exchange between lanes), 16 stores per block.
-template <int HID, int G0, int NRT4, int MODE = 0, int MS = 1>
+// FIN (product instance, MS = 1): the launch finishes the step itself (sh.h CnetArgs::fin_cnt; the tail of this kernel) -- no
+// finishing kernel, one kernel boundary per FlowStep instead of two.
+template <int HID, int G0, int NRT4, int MODE = 0, int MS = 1, bool FIN = false>
 __global__ void __launch_bounds__(256) k_cnet1w(CnetArgs a, CnetGeo g) {
+    static_assert(!FIN || (MODE == 0 && MS == 1), "fused finishing: the product instance without row split");
     constexpr bool TAPE = MODE == 1, BWD = MODE == 2;
     constexpr int NT = 256, LPXT = 7;
     constexpr int NCH = HID / 32;             // 32-channel chunks of the hidden width = row tiles of h1
@@ -878,7 +889,7 @@ __global__ void __launch_bounds__(256) k_cnet1w(CnetArgs a, CnetGeo g) {
 #pragma unroll
                     for (int j = 0; j < CGW; ++j) sum[j] += ok[tap] ? v[tap][j] : 0.f;
 #pragma unroll
-                for (int j = 0; j < CGW; ++j) hp[(long)(CGW * cg + j) * HW] = sum[j];
+                for (int j = 0; j < CGW; ++j) c1_publish<FIN>(hp + (long)(CGW * cg + j) * HW, sum[j]);
             }
         }
     }
@@ -902,11 +913,59 @@ __global__ void __launch_bounds__(256) k_cnet1w(CnetArgs a, CnetGeo g) {
 #pragma unroll
             for (int j = 0; j < CGW; ++j) {
                 const float sacc = (ok[0] ? v[0][j] : 0.f) + (ok[1] ? v[1][j] : 0.f) + (ok[2] ? v[2][j] : 0.f);
-                (dn ? hdn : hup)[((mstile + tb) * a.Cout + CGW * cg + j) * W + x] = sacc;
+                c1_publish<FIN>((dn ? hdn : hup) + ((mstile + tb) * a.Cout + CGW * cg + j) * W + x, sacc);
             }
         }
     }
     GH_STAMP(6);
+    if constexpr (FIN) {
+        // ---- fused finishing.  The sums above went out as agent-scope atomic stores (written through the XCD's L2); once this
+        // wave's are acknowledged (vmcnt) and every wave is here, thread 0 bumps the arrival counter of its own tile and of the
+        // neighbouring tiles of the image -- they need this tile's halo rows -- and whoever completes a counter finishes THAT tile
+        // with the finishing kernel's own code, reading the other workgroups' sums around the L2 as they were written
+        // (scripts/ubench/fence_cost.hip MODE 3: no stale word in 12 800 exchanges, ~6 us for the chain on the last arriver; an
+        // agent-scope fence per workgroup instead cost 94 us per round).  Nobody waits: a workgroup finishes zero to three tiles and exits.
+        __shared__ long long fin_red[4];
+        __shared__ int fin_do[3];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                  // (also: every thread is done reading T -- it becomes the finishing's staging area)
+        const bool halos = g.R < H;                       // (NI = 1: cnet1w_takes)
+        const int tpi = HW >> LPXT, j = tb & (tpi - 1);   // tiles per image (a power of two), this tile's place in its image
+        if (tid < 3) {
+            const int d = tid - 1, jj = j + d;
+            int mine = 0;
+            if (jj >= 0 && jj < tpi && (d == 0 || halos)) {
+                const unsigned need = halos ? 1u + (jj > 0) + (jj < tpi - 1) : 1u;
+                const unsigned old = __hip_atomic_fetch_add(a.fin_cnt + tb + d, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (old + 1 == need) {
+                    mine = 1;
+                    __hip_atomic_store(a.fin_cnt + tb + d, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (everyone who counts on it has: ready for the next launch)
+                }
+            }
+            fin_do[tid] = mine;
+        }
+        __syncthreads();
+        if (fin_do[0] | fin_do[1] | fin_do[2]) {
+            CfinArgs fa;
+            fa.p.scratch = a.scratch; fa.p.MS = 1; fa.p.tiles = g.tiles; fa.p.R = g.R; fa.p.NI = g.NI; fa.p.lpxt = LPXT;
+            fa.p.bias = a.bias; fa.p.scale = a.scale; fa.p.mode = a.mode; fa.p.Cout = a.Cout; fa.p.z = a.z_in; fa.p.z_bs = a.z_in_bs;
+            fa.p.one_wave = 1; fa.p.finished = 1;
+            fa.mix = a.mix; fa.z_out = a.z_out; fa.z_out_bs = a.z_out_bs; fa.acc = a.acc;
+            fa.N = a.N; fa.H = H; fa.W = W; fa.HW = HW; fa.wshift = g.wshift; fa.xcd_affine = 0; fa.tape_hout = nullptr;
+            const FinSrc fs = fin_src(fa.p, a.N, H, W, HW, g.wshift);
+            float* fsm = reinterpret_cast<float*>(lds1 + TABS);
+#pragma unroll 1
+            for (int d = 0; d < 3; ++d) {
+                if (!fin_do[d]) continue;
+#pragma unroll 1
+                for (int h = 0; h < 2; ++h) {             // a tile = two 64-pixel chunks of the finishing kernel
+                    const int chunk = 2 * (tb + d - 1) + h;
+                    cfinish_chunk<64, 1, true, true>(fa, fs, chunk, chunk & ACC_EXTRA, fsm, fin_red);
+                    __syncthreads();
+                }
+            }
+        }
+    }
     GH_WG_END();
 }
 
@@ -939,10 +998,28 @@ bool cnet1w_takes(const CnetArgs& a, const CnetGeo& g, int ms) {
     return true;
 }
 
+// Does the launch finish the step itself (CnetArgs::fin_cnt)?  The product instance at MS = 1, whole tiles (no tail tile whose
+// arrival count would differ), a mixer of at most 48 channels staged beside the values (the staging area is T's), 64-pixel chunks
+// that stay inside one image row pair.
+bool cnet1w_finishes(const CnetArgs& a, const CnetGeo& g, int ms) {
+    if (!a.fin_cnt || !a.z_out || a.tape_h1 || a.bwd || a.pre_on || ms != 1 || cnet1w_instance(a, g, ms) != 1) return false;
+    const bool paired = a.mode == TAIL_AFFINE_FWD || a.mode == TAIL_AFFINE_REV;
+    const int C = 2 * (paired ? a.Cout / 2 : a.Cout);
+    if (a.mix.C != 0 && a.mix.C != C) return false;
+    if (g.NI != 1 || g.HW % 128 != 0 || (g.HW & (g.HW - 1)) != 0) return false;
+    const size_t stage = (size_t)cnet_trow(9 * g.Cg) * 128 * sizeof(float);
+    return ((size_t)C * 64 + (size_t)C * C) * sizeof(float) <= stage;
+}
+
 int launch_cnet1w(const CnetArgs& a, const CnetGeo& g, int ms, hipStream_t s) {
     const size_t lds = cnet1w_lds_bytes(g, a.hidden, ms);
     switch (cnet1w_instance(a, g, ms)) {
     case 1:
+        if (cnet1w_finishes(a, g, ms)) {
+            (void)hipFuncSetAttribute((const void*)k_cnet1w<512, 10, 4, 0, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((k_cnet1w<512, 10, 4, 0, 1, true>), dim3(g.tiles), dim3(256), lds, s, a, g);
+            break;
+        }
         (void)hipFuncSetAttribute((const void*)k_cnet1w<512, 10, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((k_cnet1w<512, 10, 4>), dim3(g.tiles), dim3(256), lds, s, a, g);
         break;

@@ -63,7 +63,7 @@ int launch_split_tail(const SplitTailArgs& a, hipStream_t s);
 
 int launch_gaussian_logp(const float* x, long xbs, const float* mean, const float* logs, long mlbs, int N, int C,
                          int HW, unsigned long long* acc, hipStream_t s);
-int launch_zero_acc(unsigned long long* acc, int N, hipStream_t s, int extra_rows = 0);   // extra_rows: ACC_EXTRA for a plan's workspace (common.h)
+int launch_zero_acc(unsigned long long* acc, int N, hipStream_t s, int extra_rows = 0, unsigned* cnt = nullptr, size_t cnt_words = 0);   // extra_rows: ACC_EXTRA for a plan's workspace (common.h)
 // out[n] = scale * ((in ? in[n] : 0) + offset + sign*(konst ? *konst : 0) + fix(acc[n]))
 int launch_finalize(const float* in, const unsigned long long* acc, const double* konst, double sign, double offset,
                     double scale, float* out, float* out_unscaled, int N, hipStream_t s, int extra_rows = 0);

@@ -31,6 +31,7 @@ static int pack_scales(const float* logs, int n, float* scale, float* inv, hipSt
 
 // Workspace carving
 struct Workspace {
+    unsigned* fin_cnt;        // arrival counters of the fused finishing (sh.h CnetArgs::fin_cnt): one word per 64 pixels of the widest level
     unsigned long long* acc;
     float* bufA;
     float* bufB;
@@ -38,8 +39,16 @@ struct Workspace {
     float* h2;
 };
 
+static size_t fin_cnt_words(const glowhip_plan* p, int N) {
+    size_t px = 0;
+    for (const LayerPlan& L : p->layers)
+        if (L.d.kind == GLOWHIP_LAYER_FLOWSTEP) px = std::max(px, (size_t)L.d.H * L.d.W);
+    return ((size_t)N * px + 63) / 64 + 64;
+}
+
 static size_t workspace_bytes(const glowhip_plan* p, int N) {
     size_t off = 0;
+    take(off, fin_cnt_words(p, N) * 4);
     take(off, (size_t)N * 8 * (2 + ACC_EXTRA));
     take(off, (size_t)N * p->max_chw * 4);
     take(off, (size_t)N * p->max_chw * 4);
@@ -54,6 +63,7 @@ static int carve(const glowhip_plan* p, int N, void* ws, size_t bytes, Workspace
         return GLOWHIP_EWORKSPACE;
     }
     size_t off = 0;
+    w.fin_cnt = at<unsigned>(ws, take(off, fin_cnt_words(p, N) * 4));
     w.acc = at<unsigned long long>(ws, take(off, (size_t)N * 8 * (2 + ACC_EXTRA)));
     w.bufA = at<float>(ws, take(off, (size_t)N * p->max_chw * 4));
     w.bufB = at<float>(ws, take(off, (size_t)N * p->max_chw * 4));
@@ -67,10 +77,11 @@ static int carve(const glowhip_plan* p, int N, void* ws, size_t bytes, Workspace
 // coupling to z2.  x1: first-half channels (batch stride x1_bs).
 static bool g_pack_one_stream = false;     // testing hook: glowhip_plan_pack without the side-stream fork
 void plan_pack_one_stream(int on) { g_pack_one_stream = on != 0; }
-static bool g_sh_disabled = false, g_sh_mix_disabled = false;
+static bool g_sh_disabled = false, g_sh_mix_disabled = false, g_fuse_finish_off = false;
 void plan_disable_sh(int off) {
     g_sh_disabled = (off & 1) != 0;        // the whole split-half path off: every coupling network on the exact-fp32 MFMA kernels
     g_sh_mix_disabled = (off & 16) != 0;   // no mixer of the next step inside the finishing kernel, no squeeze folded into a mixer
+    g_fuse_finish_off = (off & 32) != 0;   // no fused finishing: every step's finishing as its own k_cfinish launch (the two forms must agree bit for bit)
 }
 
 // split-half f16 kernels off for this plan: its own family (glowhip_plan_set_family) or the process-wide testing hook
@@ -397,15 +408,8 @@ static int run_forward(glowhip_plan* p, const void* packed, const float* x, cons
                 }
                 premixed = false;
                 const bool chain = li + 1 < nl && cnet_chain(p, L, p->layers[li + 1]);
-                {
-                    ScopedTimer t(p, GLOWHIP_K_CNET, 1, s);
-                    count_launch(p, pending ? "k_cnet+prev_finish" : "k_cnet");
-                    GH_TRY(launch_cnet_main(c, s, &pend));
-                    count_cnet_variant(p, c, pend);
-                }
-                pending = chain;
-                if (!chain) {   // finish now; with the NEXT step's mixer when that is a same-shape FlowStep on another kernel family
-                    float* out = (li == nl - 1) ? z_out : const_cast<float*>(cur);
+                float* out = (li == nl - 1) ? z_out : const_cast<float*>(cur);
+                if (!chain) {   // the step is finished right behind its k_cnet: with the NEXT step's mixer when that is a same-shape FlowStep
                     c.z_out = out; c.z_out_bs = chw;
                     if (li + 1 < nl - 1 && !g_sh_mix_disabled && d.C <= 96) {
                         const LayerPlan& Ln = p->layers[li + 1];
@@ -415,9 +419,24 @@ static int run_forward(glowhip_plan* p, const void* packed, const float* x, cons
                             premixed = true;
                         }
                     }
-                    ScopedTimer t(p, GLOWHIP_K_CFINISH, 0, s);
-                    count_launch(p, c.mix.C ? "k_cfinish+mixer" : "k_cfinish");
-                    GH_TRY(launch_cnet_finish(c, pend, s));
+                    // ... by the launch itself where it can (fused finishing, sh.h CnetArgs::fin_cnt; per-launch event timing keeps the two apart)
+                    if (!g_fuse_finish_off && !p->timing) c.fin_cnt = w.fin_cnt;
+                }
+                {
+                    ScopedTimer t(p, GLOWHIP_K_CNET, 1, s);
+                    count_launch(p, pending ? "k_cnet+prev_finish" : "k_cnet");
+                    GH_TRY(launch_cnet_main(c, s, &pend));
+                    count_cnet_variant(p, c, pend);
+                }
+                pending = chain;
+                if (!chain) {
+                    if (pend.finished) {
+                        count_launch(p, "k_cnet(finishes the step)");
+                    } else {
+                        ScopedTimer t(p, GLOWHIP_K_CFINISH, 0, s);
+                        count_launch(p, c.mix.C ? "k_cfinish+mixer" : "k_cfinish");
+                        GH_TRY(launch_cnet_finish(c, pend, s));
+                    }
                     cur = out;
                 }
                 continue;
@@ -496,6 +515,12 @@ static int run_reverse(glowhip_plan* p, const void* packed, const float* z, cons
                     c.x = cur; c.x_bs = chw; c.z_in = cur; c.z_in_bs = chw;
                 }
                 const bool chain = d.C <= 96 && li - 1 >= 0 && cnet_chain(p, L, p->layers[li - 1]) && p->layers[li - 1].d.C <= 96;
+                float* fout = nullptr;
+                if (!chain && d.C <= 96) {      // (as in run_forward: the finishing's arguments are there at launch time, the launch may do it)
+                    fout = (li == 0) ? x_out : other_buf(w, cur);
+                    c.z_out = fout; c.z_out_bs = chw; c.mix = mixer_rev(L, packed);
+                    if (!g_fuse_finish_off && !p->timing) c.fin_cnt = w.fin_cnt;
+                }
                 {
                     ScopedTimer t(p, GLOWHIP_K_CNET, 1, s);
                     count_launch(p, pending ? "k_cnet+prev_finish" : "k_cnet");
@@ -504,11 +529,14 @@ static int run_reverse(glowhip_plan* p, const void* packed, const float* z, cons
                 }
                 pending = chain;
                 if (!chain && d.C <= 96) {
-                    float* out = (li == 0) ? x_out : other_buf(w, cur);
-                    c.z_out = out; c.z_out_bs = chw; c.mix = mixer_rev(L, packed);
-                    ScopedTimer t(p, GLOWHIP_K_CFINISH, 0, s);
-                    count_launch(p, "k_cfinish+mixer");
-                    GH_TRY(launch_cnet_finish(c, pend, s));
+                    float* out = fout;
+                    if (pend.finished) {
+                        count_launch(p, "k_cnet(finishes the step)");
+                    } else {
+                        ScopedTimer t(p, GLOWHIP_K_CFINISH, 0, s);
+                        count_launch(p, "k_cfinish+mixer");
+                        GH_TRY(launch_cnet_finish(c, pend, s));
+                    }
                     cur = out;
                 } else if (!chain) {
                     // wider than the finishing kernel's mixer (additive coupling, 96 < C <= 112: L.cnet holds, the fused mixer
@@ -1064,7 +1092,7 @@ int glowhip_plan_encode(glowhip_plan* plan, const void* packed, const float* x, 
     hipStream_t s = (hipStream_t)stream;
     Workspace w;
     GH_TRY(carve(plan, N, workspace, workspace_bytes, w));
-    GH_TRY(launch_zero_acc(w.acc, N, s, ACC_EXTRA));
+    GH_TRY(launch_zero_acc(w.acc, N, s, ACC_EXTRA, w.fin_cnt, fin_cnt_words(plan, N)));
     GH_TRY(run_forward(plan, packed, x, noise, z, N, w, s));
     GH_TRY(join_legacy(plan, s)); GH_TRY(join_lu(plan, s));
     if (logdet_out)
@@ -1083,7 +1111,7 @@ int glowhip_plan_decode(glowhip_plan* plan, const void* packed, const float* z, 
     hipStream_t s = (hipStream_t)stream;
     Workspace w;
     GH_TRY(carve(plan, N, workspace, workspace_bytes, w));
-    GH_TRY(launch_zero_acc(w.acc, N, s, ACC_EXTRA));
+    GH_TRY(launch_zero_acc(w.acc, N, s, ACC_EXTRA, w.fin_cnt, fin_cnt_words(plan, N)));
     GH_TRY(join_legacy(plan, s)); GH_TRY(join_lu(plan, s));      // decode reads W^-1 and the deep levels' images first
     GH_TRY(run_reverse(plan, packed, z, eps, n_eps, x, N, w, s));
     if (logdet_out)
@@ -1102,7 +1130,7 @@ int glowhip_glow_forward(glowhip_plan* plan, const void* packed, const float* x,
     hipStream_t s = (hipStream_t)stream;
     Workspace w;
     GH_TRY(carve(plan, N, workspace, workspace_bytes, w));
-    GH_TRY(launch_zero_acc(w.acc, N, s, ACC_EXTRA));
+    GH_TRY(launch_zero_acc(w.acc, N, s, ACC_EXTRA, w.fin_cnt, fin_cnt_words(plan, N)));
     RngSpec rng{plan->rng_on && !noise, plan->rng_seed, plan->rng_calls, (float)(1.0 / pow(2.0, n_bits))};
     if (rng.on) ++plan->rng_calls;
     GH_TRY(run_forward(plan, packed, x, noise, z, N, w, s, 0, rng.on ? &rng : nullptr));
@@ -1133,7 +1161,7 @@ int glowhip_glow_forward_u8(glowhip_plan* plan, const void* packed, const uint8_
     hipStream_t s = (hipStream_t)stream;
     Workspace w;
     GH_TRY(carve(plan, N, workspace, workspace_bytes, w));
-    GH_TRY(launch_zero_acc(w.acc, N, s, ACC_EXTRA));
+    GH_TRY(launch_zero_acc(w.acc, N, s, ACC_EXTRA, w.fin_cnt, fin_cnt_words(plan, N)));
     const glowhip_layer_desc& d0 = plan->layers[0].d;
     plan->cur_layer = 0;
     RngSpec rng{plan->rng_on && !noise, plan->rng_seed, plan->rng_calls, (float)(1.0 / pow(2.0, n_bits))};
@@ -1157,7 +1185,7 @@ int glowhip_plan_actnorm_init(glowhip_plan* plan, void* packed, size_t packed_by
     hipStream_t s = (hipStream_t)stream;
     Workspace w;
     GH_TRY(carve(plan, N, workspace, workspace_bytes, w));
-    GH_TRY(launch_zero_acc(w.acc, N, s, ACC_EXTRA));
+    GH_TRY(launch_zero_acc(w.acc, N, s, ACC_EXTRA, w.fin_cnt, fin_cnt_words(plan, N)));
     // plain (ActNorm-free) fp32 MFMA weight images of every convolution: the training family's + the init pass's own f.0 image
     // (no LU here: the invertible 1x1 convolutions are applied with W itself, and the pack at the end factorises them)
     GH_TRY(glowhip_plan_pack_for(plan, packed, packed_bytes, GLOWHIP_PACK_TRAINING | 16 | 32, stream));

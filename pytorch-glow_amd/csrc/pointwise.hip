@@ -660,15 +660,17 @@ int launch_gaussian_logp(const float* x, long xbs, const float* mean, const floa
     return GLOWHIP_OK;
 }
 
-__global__ void __launch_bounds__(256) k_zero_acc(unsigned long long* acc, int words) {
+__global__ void __launch_bounds__(256) k_zero_acc(unsigned long long* acc, int words, unsigned* cnt, int cnt_words) {
     int i = blockIdx.x * 256 + threadIdx.x;
     if (i < words) acc[i] = 0ull;      // accumulators, non-finite flags (and the extra accumulator rows)
+    if (i < cnt_words) cnt[i] = 0u;    // arrival counters of the fused finishing (they return to zero by themselves; a call that was cut short must not poison the next)
 }
 
-int launch_zero_acc(unsigned long long* acc, int N, hipStream_t s, int extra_rows) {
+int launch_zero_acc(unsigned long long* acc, int N, hipStream_t s, int extra_rows, unsigned* cnt, size_t cnt_words) {
     if (N == 0) return GLOWHIP_OK;
     const int words = (2 + extra_rows) * N;
-    hipLaunchKernelGGL(k_zero_acc, dim3(cdiv(words, 256)), dim3(256), 0, s, acc, words);
+    if (!cnt) cnt_words = 0;
+    hipLaunchKernelGGL(k_zero_acc, dim3(cdiv(std::max<long>(words, (long)cnt_words), 256)), dim3(256), 0, s, acc, words, cnt, (int)cnt_words);
     GH_LAUNCH_CHECK("k_zero_acc");
     return GLOWHIP_OK;
 }

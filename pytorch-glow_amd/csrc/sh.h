@@ -134,6 +134,7 @@ struct CnetPending {
     int mode, Cout;                              // TailMode of that step's coupling
     const float* z; long z_bs;                   // the state that step read: z1 = channels [0, C/2), z2 = [C/2, C)
     int one_wave;                                // the launch ran on k_cnet1w (cnet1w_sh.hip); run-time evidence for the tests
+    int finished;                                // the launch finished the step itself (CnetArgs::fin_cnt): no finishing kernel to launch
 };
 // channel mixer applied to a finished state (C = 0: none)
 //   forward: the NEXT step's  y = M ((z + bias) * scale);   reverse: THIS step's  x = (M z) * scale - bias
@@ -166,6 +167,12 @@ struct CnetArgs {
     // tape_h2 <- g_u0 (fp32 (N, hidden, H, W)); the partial sums in `scratch` are d L / d y1's contribution (Cout = C/2 channels),
     // added into the gradient by k_chanmix_bwd (backward.h ChanMixBwdArgs::add_part)
     int bwd;
+    // ---- optional: FUSED FINISHING.  fin_cnt != null: z_out / acc / mix above are valid at launch time and the launch may finish
+    // the step itself -- every workgroup publishes its partial sums, then bumps the arrival counters fin_cnt[tile] of its tile and
+    // of the neighbouring tiles of the image (they need its halo rows); whoever brings a counter to its full count finishes THAT tile
+    // (coupling + log-det + mixer, the finishing kernel's own code) and resets the counter.  Nobody waits for anybody.  fin_cnt: one
+    // zeroed word per tile.  CnetPending::finished tells the caller whether the launch took the offer.
+    unsigned* fin_cnt;
 };
 int launch_cnet_main(const CnetArgs& a, hipStream_t s, CnetPending* out);            // k_cnet only; *out describes its partial sums
 int launch_cnet_finish(const CnetArgs& a, const CnetPending& p, hipStream_t s);     // the finishing kernel for those sums
