@@ -348,7 +348,7 @@ void conv_mfma_tail_force_tile(int v) {
     g_disable_tail_dma = (v & 0x400) != 0;   // | 0x400: register-staged kernels only
     // 0x800: the split-half path off (every coupling network on the exact-fp32 kernels, training included); 0x8000: no mixer of the
     // next step inside the finishing kernel and no squeeze folded into a mixer (the fused and the separate forms must agree bit for bit)
-    // 0x100000: no fused finishing (k_cnet1w finishing the step itself): every step's finishing as its own k_cfinish launch
+    // 0x100000: FUSED finishing on (k_cnet1w finishing the step itself instead of a k_cfinish launch; off by default: measured slower)
     plan_disable_sh(((v & 0x800) ? 1 : 0) | ((v & 0x8000) ? 16 : 0) | ((v & 0x100000) ? 32 : 0));
     cnet_force((v >> 22) & 7, ((v >> 25) & 15) | ((v & 0x10000) ? 16 : 0) | ((v & 0x20000) ? 32 : 0) | ((v & 0x40000) ? 64 : 0));   // 0x40000: no backward instance of k_cnet1w;   // 0x10000: no k_cnet1w (one wave per SIMD); 0x20000: its row-split instance where it applies (off by default: measured slower);   // bits 22..24: row splits; bit 25: 128-pixel tiles only, bit 26: 64-pixel tiles, bit 27: finishing chained into the next k_cnet, bit 28: finishing kernel without the XCD-affine chunk order
     plan_train_disable_sh((v & 0x800) ? 1 : 0);

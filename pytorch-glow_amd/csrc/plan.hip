@@ -77,11 +77,16 @@ static int carve(const glowhip_plan* p, int N, void* ws, size_t bytes, Workspace
 // coupling to z2.  x1: first-half channels (batch stride x1_bs).
 static bool g_pack_one_stream = false;     // testing hook: glowhip_plan_pack without the side-stream fork
 void plan_pack_one_stream(int on) { g_pack_one_stream = on != 0; }
-static bool g_sh_disabled = false, g_sh_mix_disabled = false, g_fuse_finish_off = false;
+static bool g_sh_disabled = false, g_sh_mix_disabled = false, g_fuse_finish_off = true;
 void plan_disable_sh(int off) {
     g_sh_disabled = (off & 1) != 0;        // the whole split-half path off: every coupling network on the exact-fp32 MFMA kernels
     g_sh_mix_disabled = (off & 16) != 0;   // no mixer of the next step inside the finishing kernel, no squeeze folded into a mixer
-    g_fuse_finish_off = (off & 32) != 0;   // no fused finishing: every step's finishing as its own k_cfinish launch (the two forms must agree bit for bit)
+    // FUSED FINISHING (k_cnet1w finishing the step itself, cnet1w_sh.hip FIN) is OFF unless asked for: built, bit-identical to the
+    // finishing kernel (tests/test_gpu_fused.py), and measured SLOWER -- 7.68 against 6.80 ms per config-B forward, + 27 us per level-1
+    // launch: every workgroup arrives last at about one tile, so every CU pays the finishing's latency chain
+    // (store drain, counter round trip, a read-around-L2 round trip per 64-pixel chunk) twice per launch, one workgroup at a time,
+    // where the finishing kernel runs four workgroups per CU side by side.
+    g_fuse_finish_off = (off & 32) == 0;
 }
 
 // split-half f16 kernels off for this plan: its own family (glowhip_plan_set_family) or the process-wide testing hook

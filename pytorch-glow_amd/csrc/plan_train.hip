@@ -76,7 +76,10 @@ static size_t max_weight_floats(const glowhip_plan* p) {
 }
 
 // fp64 accumulators of every layer's reduction-type gradients live side by side: zeroed once, converted once
-constexpr int MIX_ACC_COPIES = 16;     // copies of a FlowStep's mixer accumulators [W C*C][an_b C][an_l C] (backward.h ChanMixBwdArgs).
+#ifndef GH_MIX_ACC_COPIES
+#define GH_MIX_ACC_COPIES 16
+#endif
+constexpr int MIX_ACC_COPIES = GH_MIX_ACC_COPIES;     // copies of a FlowStep's mixer accumulators [W C*C][an_b C][an_l C] (backward.h ChanMixBwdArgs).
                                        // (64 copies, one per workgroup of the C = 48 launch and plain stores instead of its 154 k fp64
                                        // atomics, changed nothing in that launch -- it was not waiting for them -- and cost the
                                        // finalize kernel 43 us per step for the 4 x longer sums)
