@@ -85,7 +85,8 @@ struct StepPrepJob {
     size_t winv_off, logabsdet_off, konst_off, scratch_off;
 };
 int launch_step_prepare_batched(const StepPrepJob* jobs_dev, int n, int max_lds_c, void* packed, hipStream_t s, int want_inverse = 1,
-                                int max_c = 0);   // want_inverse = 0: log|det W| only (W^-1 is left stale)
+                                int max_c = 0, int all_small = 0);   // want_inverse = 0: log|det W| only (W^-1 is left stale)
+bool step_prepare_small_takes(const StepPrepJob& j);   // all_small = every job of the table passes this (lu.hip k_step_prepare_small)
 
 struct ScaleJob { const float* logs; size_t scale_off, inv_off; int n; int has_inv; };
 enum { REPACK_WIDE = 0, REPACK_TAIL = 1, REPACK_FIRST = 2,                 // exact-fp32 MFMA kernels' images

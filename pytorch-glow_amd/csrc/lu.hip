@@ -347,6 +347,84 @@ __global__ void __launch_bounds__(256) k_step_prepare_batched(const StepPrepJob*
     }
 }
 
+// ---- log|det W| of the SMALL matrices of a plan (C = 12 / 24 / 48: every FlowStep of the 64 x 64 model), one WAVE per matrix with
+// the matrix in REGISTERS: lane r holds row r as C doubles.  The workgroup-wide LU above pays three barriers and an LDS round trip
+// per pivot -- 74 us per pack for the 96 matrices of config B, every step of a forward that re-derives its weights.  Measured
+// (rocprofv3, scripts/time_pack.py): 64 us for this form -- a modest gain: what bounds both is the serial chain of a pivot step
+// (cross-lane argmax, one fp64 division, the pivot row lane by lane), ~2 800 cycles per pivot here.  Same algorithm, same operations in the same order (partial pivoting with the
+// lowest-row tie-break, multipliers l = a / pivot, trailing update fma(-l, pivot row, a), sum of log|pivot| in pivot order): the
+// result is the workgroup kernel's, bit for bit.  Rows are never moved: a lane keeps the POSITION its row currently has, a swap
+// exchanges two positions, and the pivot row reaches the other lanes by v_readlane (its lane is wave-uniform).
+template <int C>
+__device__ __forceinline__ double lu_logdet_wave(const float* __restrict__ w, const int lane) {
+    double a[C];
+    const int row = lane < C ? lane : C - 1;
+#pragma unroll
+    for (int c = 0; c < C; ++c) a[c] = (double)w[row * C + c];
+    int pos = lane;
+    double mypiv = 1.0;
+#pragma unroll
+    for (int k = 0; k < C; ++k) {
+        double best = (lane < C && pos >= k) ? fabs(a[k]) : -1.0;
+        int bi = pos;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {       // (butterfly: every lane ends with the same winner -- the largest value, lowest position among equals)
+            const double ov = __shfl_xor(best, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        }
+        const int pr = __builtin_amdgcn_readfirstlane(bi);
+        const unsigned long long owner = __ballot(lane < C && pos == pr);
+        const int P = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(owner));      // the lane that holds the pivot row
+        auto from_pivot = [&](double v) {
+            const unsigned lo = __builtin_amdgcn_readlane((unsigned)__double_as_longlong(v), P);
+            const unsigned hi = __builtin_amdgcn_readlane((unsigned)((unsigned long long)__double_as_longlong(v) >> 32), P);
+            return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+        };
+        const double piv = from_pivot(a[k]);
+        if (lane == k) mypiv = piv;              // (the logarithms are taken once, all lanes at a time, behind the elimination: log() is a
+                                                 // few hundred dependent instructions, and in front of every step it was a third of the kernel)
+        const bool was_k = pos == k;
+        if (lane == P) pos = k;
+        else if (was_k) pos = pr;
+        if (k == C - 1) break;
+        const bool below = lane < C && pos > k;
+        const double l = a[k] / piv;
+#pragma unroll
+        for (int c = k + 1; c < C; ++c) {
+            const double rk = from_pivot(a[c]);
+            if (below) a[c] = fma(-l, rk, a[c]);
+        }
+    }
+    // sum of log|pivot| in pivot order, as the workgroup kernel adds them
+    const double lg = log(fabs(mypiv));
+    double logdet = 0.0;
+#pragma unroll
+    for (int k = 0; k < C; ++k) {
+        const unsigned lo = __builtin_amdgcn_readlane((unsigned)__double_as_longlong(lg), k);
+        const unsigned hi = __builtin_amdgcn_readlane((unsigned)((unsigned long long)__double_as_longlong(lg) >> 32), k);
+        logdet += __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+    }
+    return logdet;
+}
+
+// one wave per FlowStep (four per workgroup); launch_step_prepare_batched selects it when every job of the plan is one it takes
+__global__ void __launch_bounds__(256) k_step_prepare_small(const StepPrepJob* __restrict__ jobs, int n, char* packed) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const StepPrepJob j = jobs[i];
+    double lad = 0.0;
+    if (j.w) lad = j.C == 12 ? lu_logdet_wave<12>(j.w, lane) : (j.C == 24 ? lu_logdet_wave<24>(j.w, lane) : lu_logdet_wave<48>(j.w, lane));
+    // (the same tree as the workgroup kernel's block_sum: its waves 1 - 3 add exact zeros for C <= 64)
+    const double tot = wave_sum(lane < j.C ? (double)(j.an_logs[lane] * LOGSCALE) : 0.0);
+    if (lane == 0) {
+        if (j.w) *(float*)(packed + j.logabsdet_off) = (float)lad;
+        *(double*)(packed + j.konst_off) = tot * (double)j.HW + (j.w ? (double)(float)lad * (double)j.HW : 0.0);
+    }
+}
+bool step_prepare_small_takes(const StepPrepJob& j) { return j.C <= 64 && (!j.w || j.C == 12 || j.C == 24 || j.C == 48); }
+
 // plan-wide total of the per-step terms: fetched in parallel, summed in layer order by one thread (deterministic)
 __global__ void __launch_bounds__(256) k_sum_konst(const StepPrepJob* __restrict__ jobs, int n, char* packed) {
     __shared__ double v[256];
@@ -363,9 +441,16 @@ __global__ void __launch_bounds__(256) k_sum_konst(const StepPrepJob* __restrict
 }
 
 int launch_step_prepare_batched(const StepPrepJob* jobs_dev, int n, int max_lds_c, void* packed, hipStream_t s, int want_inverse,
-                                int max_c) {
+                                int max_c, int all_small) {
     if (n == 0) {
         (void)hipMemsetAsync(packed, 0, sizeof(double), s);
+        return GLOWHIP_OK;
+    }
+    if (!want_inverse && all_small) {      // log|det W| only and every matrix is 12 / 24 / 48 wide: one wave per matrix, in registers
+        hipLaunchKernelGGL(k_step_prepare_small, dim3((n + 3) / 4), dim3(256), 0, s, jobs_dev, n, (char*)packed);
+        GH_LAUNCH_CHECK("k_step_prepare_small");
+        hipLaunchKernelGGL(k_sum_konst, dim3(1), dim3(256), 0, s, jobs_dev, n, (char*)packed);
+        GH_LAUNCH_CHECK("k_sum_konst");
         return GLOWHIP_OK;
     }
     size_t lds = invconv_scratch_bytes(max_lds_c > 0 ? max_lds_c : 1);

@@ -77,7 +77,7 @@ static int carve(const glowhip_plan* p, int N, void* ws, size_t bytes, Workspace
 // coupling to z2.  x1: first-half channels (batch stride x1_bs).
 static bool g_pack_one_stream = false;     // testing hook: glowhip_plan_pack without the side-stream fork
 void plan_pack_one_stream(int on) { g_pack_one_stream = on != 0; }
-static bool g_sh_disabled = false, g_sh_mix_disabled = false, g_fuse_finish_off = true;
+static bool g_sh_disabled = false, g_sh_mix_disabled = false, g_fuse_finish_off = true, g_lu_small_off = false;
 void plan_disable_sh(int off) {
     g_sh_disabled = (off & 1) != 0;        // the whole split-half path off: every coupling network on the exact-fp32 MFMA kernels
     g_sh_mix_disabled = (off & 16) != 0;   // no mixer of the next step inside the finishing kernel, no squeeze folded into a mixer
@@ -87,6 +87,7 @@ void plan_disable_sh(int off) {
     // (store drain, counter round trip, a read-around-L2 round trip per 64-pixel chunk) twice per launch, one workgroup at a time,
     // where the finishing kernel runs four workgroups per CU side by side.
     g_fuse_finish_off = (off & 32) == 0;
+    g_lu_small_off = (off & 64) != 0;      // log|det W| of the small matrices on the workgroup-wide LU (A/B and bitwise test of the one-wave form)
 }
 
 // split-half f16 kernels off for this plan: its own family (glowhip_plan_set_family) or the process-wide testing hook
@@ -1041,9 +1042,12 @@ int glowhip_plan_pack_for(glowhip_plan* plan, void* packed, size_t packed_bytes,
         plan->legacy_pending = true; plan->pending_captured = stream_capturing(s);
     }
     if (!(use & 32)) {      // (32, internal: weight images and scale tables only -- the init pass' first pack)
+        bool all_small = !g_lu_small_off;
+        for (const StepPrepJob& pj : plan->prep_jobs) all_small = all_small && step_prepare_small_takes(pj);
+        const bool inv = (use & (GLOWHIP_PACK_INVERSE | GLOWHIP_PACK_TRAINING)) != 0;
+        count_launch(plan, (all_small && !inv) ? "pack:k_step_prepare_small" : "pack:k_step_prepare_batched");
         GH_TRY(launch_step_prepare_batched(at<StepPrepJob>(packed, plan->prep_off), (int)plan->prep_jobs.size(),
-                                           plan->max_lds_c, packed, side, (use & (GLOWHIP_PACK_INVERSE | GLOWHIP_PACK_TRAINING)) != 0,
-                                           plan->max_c));
+                                           plan->max_lds_c, packed, side, inv, plan->max_c, all_small ? 1 : 0));
         if ((use & GLOWHIP_PACK_INVERSE) && n_kind[4] > 0)
             GH_TRY(launch_repack_sh2_gemm(at<RepackJob>(packed, slot_off) + (n_kind[0] + n_kind[1] + n_kind[2] + n_kind[3]), n_kind[4], packed, side));
     }

@@ -209,6 +209,35 @@ def test_fused_finishing_equals_the_finishing_kernel_bitwise(image, L, batch, K)
     assert torch.isfinite(nll).all() and torch.isfinite(xr).all()
 
 
+def test_one_wave_per_matrix_logdet_equals_the_workgroup_lu_bitwise():
+    """Round 6: the inference pack takes log|det W| of the 12 / 24 / 48-wide invconv matrices from k_step_prepare_small (lu.hip) -- one
+    WAVE per matrix, the matrix in registers (lane = row, the pivot row by v_readlane) -- instead of the workgroup-wide LU with three
+    barriers per pivot (74 -> 64 us per pack at config B by rocprofv3 -- the serial chain pivot search -> division -> update bounds both
+    forms; the headline re-derives its weights every step).  Same algorithm and
+    operation order, so the nll -- which carries 3 sum(logs) HW + log|det W| HW of all 3 K steps -- must be the same BITS as with the
+    switch 0x200000 (the workgroup LU), with near-orthogonal and with badly scaled matrices (pivoting really swaps rows there), and
+    within 1e-4 of the oracle's torch.det route (inside _case).  Reference: network/module.py:356-357."""
+    K, batch = 3, 8
+    plan, fwd, rev = _case(64, 3, K, 512, batch, seed=33)          # (oracle parity of z / nll / decode on the default path)
+    cfg = O.default_cfg(image_shape=(64, 64, 3), hidden_channels=512, K=K, L=3, batch=batch)
+    for perturb in (0.02, 0.6):
+        sd = O.seeded_state_dict(cfg, seed=34, invconv_perturb=perturb)
+        g = torch.Generator().manual_seed(34)
+        x = torch.rand(batch, 3, 64, 64, generator=g)
+        noise = torch.rand(batch, 3, 64, 64, generator=g) / 256
+        sd = O.glow_init_actnorm(x, noise, sd, cfg)
+        glow = make_glow(cfg, sd, batch)
+        z, nll, _ = glow.normal_flow(dev(x), None, noise=dev(noise), repack=True)
+        G.lib().glowhip_debug_force_tail_tile(0x200000)
+        try:
+            z2, nll2, _ = glow.normal_flow(dev(x), None, noise=dev(noise), repack=True)
+        finally:
+            G.lib().glowhip_debug_force_tail_tile(0)
+        assert torch.isfinite(nll).all() and torch.equal(nll, nll2) and torch.equal(z, z2), perturb
+        _, nll_ref, _ = O.glow_forward(x, noise, sd, cfg)
+        close(nll, nll_ref, 1e-4, what=f"nll at invconv perturbation {perturb}")
+
+
 def test_config_b_geometry_batch16(path):
     """Batch 16: k_cnet splits the h2 rows over 2 / 4 workgroups per tile at the levels whose pixel tiles alone would leave CUs idle."""
     K = 3
