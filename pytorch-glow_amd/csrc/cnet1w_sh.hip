@@ -110,14 +110,9 @@ __host__ __device__ constexpr int c1_f0slot(int nq, int nst0, int j) {
 // writes two full lines (no exchange between lanes), 16 stores per block.
 // FIN (product instance, MS = 1): the launch finishes the step itself (sh.h CnetArgs::fin_cnt; the tail of this kernel) -- no
 // finishing kernel, one kernel boundary per FlowStep instead of two.
-// DENSE0 (product instance at Cin = 6, round 6): f.0 over the DENSE image (k = tap * 6 + channel, 54 of 64 k: G0 = 8, four k-steps)
-// instead of the padded one (a tap's 6 channels in an 8-wide group, 54 of 80 k: five) -- 48 MFMAs fewer per wave and tile.  The window
-// keeps its [pixel][8 channels] form; only the B fragments -- built ONCE per tile, they stay in registers -- are gathered element by
-// element (an 8-wide k group straddles two taps).
-template <int HID, int G0, int NRT4, int MODE = 0, int MS = 1, bool FIN = false, bool DENSE0 = false>
+template <int HID, int G0, int NRT4, int MODE = 0, int MS = 1, bool FIN = false>
 __global__ void __launch_bounds__(256) k_cnet1w(CnetArgs a, CnetGeo g) {
     static_assert(!FIN || (MODE == 0 && MS == 1), "fused finishing: the product instance without row split");
-    static_assert(!DENSE0 || (MODE == 0 && MS == 1 && G0 == CN_G0_DENSE6), "dense f.0 image: the product instance at Cin = 6");
     constexpr bool TAPE = MODE == 1, BWD = MODE == 2;
     constexpr int NT = 256, LPXT = 7;
     constexpr int NCH = HID / 32;             // 32-channel chunks of the hidden width = row tiles of h1
@@ -220,10 +215,9 @@ __global__ void __launch_bounds__(256) k_cnet1w(CnetArgs a, CnetGeo g) {
         else asm volatile("" ::"v"(w));
     };
 
-    [[maybe_unused]] const _Float16* W0 = (const _Float16*)(DENSE0 ? a.w0d : a.w0);
+    [[maybe_unused]] const _Float16* W0 = (const _Float16*)a.w0;
     const long w0_plane = (long)G0 * HID * 8;
-    const void* const w0img = DENSE0 ? a.w0d : a.w0;
-    const float* rs0 = (const float*)((const char*)w0img + sh2_rowscale_off(G0 * 8, HID));
+    const float* rs0 = (const float*)((const char*)a.w0 + sh2_rowscale_off(G0 * 8, HID));
     [[maybe_unused]] const _Float16* W2 = (const _Float16*)a.w2;
     constexpr long w2_plane = (long)HID * HID;
     const float* rs2 = (const float*)((const char*)a.w2 + sh2_rowscale_off(HID, HID));
@@ -241,7 +235,7 @@ __global__ void __launch_bounds__(256) k_cnet1w(CnetArgs a, CnetGeo g) {
     // this way takes 10 - 11 cycles out of the MFMA stream, 17 - 27 as global_load_lds -- scripts/ubench/mfma_burst.hip)
     const __amdgpu_buffer_rsrc_t rs_w2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w2), 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w4 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w4), 0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_w0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(DENSE0 ? a.w0d : a.w0), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w0), 0, 0x7fffffff, 0x00020000);
     int f_w2 = 1;                         // the fill in progress reads the f.2 image (else f.4)
     int f_soff = 0;                       // byte offset of this wave's first piece in that image
 #else
@@ -445,22 +439,9 @@ __global__ void __launch_bounds__(256) k_cnet1w(CnetArgs a, CnetGeo g) {
         lo = *reinterpret_cast<const h8*>(p + G0 * 512);
     };
     auto ldB0 = [&](int st, h8& hi, h8& lo) {
-        if constexpr (DENSE0) {      // group 2 st + kl of the dense image: element j is k = 8 (2 st + kl) + j = (tap k / 6, channel k % 6)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int k = 8 * (2 * st + kl) + j;
-                const bool live = k < 54;
-                const int tap = live ? (k * 43) >> 8 : 0, c = live ? k - 6 * tap : 0;      // (k / 6 for k < 64)
-                const int dy = (tap * 11) >> 5, dx = tap - 3 * dy;                          // (tap / 3 for tap < 9)
-                const char* p = lds1 + WINB + pbase + (dy * g.WP + dx) * 16 + c * 2;
-                const _Float16 vh = *reinterpret_cast<const _Float16*>(p), vl = *reinterpret_cast<const _Float16*>(p + wlo);
-                hi[j] = live ? vh : (_Float16)0.f; lo[j] = live ? vl : (_Float16)0.f;
-            }
-        } else {
-            const char* p = lds1 + woff[st];
-            hi = *reinterpret_cast<const h8*>(p);
-            lo = *reinterpret_cast<const h8*>(p + wlo);
-        }
+        const char* p = lds1 + woff[st];
+        hi = *reinterpret_cast<const h8*>(p);
+        lo = *reinterpret_cast<const h8*>(p + wlo);
     };
     [[maybe_unused]] unsigned E_mw = 0u;     // TAPE: the sign word being built (value k = 4 gq + t shifted in at bit 0: ends up in bit 15 - k)
     // epilogue of f.0 for group gq (rows 8 gq + 4 kl + t of chunk c): -h1 = -relu(.) as halves of the B fragments
@@ -1030,21 +1011,10 @@ bool cnet1w_finishes(const CnetArgs& a, const CnetGeo& g, int ms) {
     return ((size_t)C * 64 + (size_t)C * C) * sizeof(float) <= stage;
 }
 
-// ... on the dense f.0 image?  The product instance at Cin = 6, when the caller packed one (CnetArgs::w0d) and did not ask for the
-// fused finishing (the experiment keeps to the padded image).
-bool cnet1w_dense0(const CnetArgs& a, const CnetGeo& g, int ms) {
-    return a.w0d && a.Cin == 6 && !a.tape_h1 && !a.bwd && !a.pre_on && ms == 1 && cnet1w_instance(a, g, ms) == 1 && !cnet1w_finishes(a, g, ms);
-}
-
 int launch_cnet1w(const CnetArgs& a, const CnetGeo& g, int ms, hipStream_t s) {
     const size_t lds = cnet1w_lds_bytes(g, a.hidden, ms);
     switch (cnet1w_instance(a, g, ms)) {
     case 1:
-        if (cnet1w_dense0(a, g, ms)) {      // (the dense f.0 image: four k-steps of f.0 instead of five)
-            (void)hipFuncSetAttribute((const void*)k_cnet1w<512, CN_G0_DENSE6, 4, 0, 1, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL((k_cnet1w<512, CN_G0_DENSE6, 4, 0, 1, false, true>), dim3(g.tiles), dim3(256), lds, s, a, g);
-            break;
-        }
         if (cnet1w_finishes(a, g, ms)) {
             (void)hipFuncSetAttribute((const void*)k_cnet1w<512, 10, 4, 0, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             hipLaunchKernelGGL((k_cnet1w<512, 10, 4, 0, 1, true>), dim3(g.tiles), dim3(256), lds, s, a, g);

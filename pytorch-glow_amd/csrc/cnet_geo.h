@@ -32,7 +32,6 @@ bool cnet_geo(int Cin, int H, int W, int hidden, int Cout, int N, int pxt, CnetG
 // (same partial-sum layout as k_cnet with that row split and 128-pixel tiles: the finishing kernel does not know the difference)
 bool cnet1w_takes(const CnetArgs& a, const CnetGeo& g128, int ms);
 int launch_cnet1w(const CnetArgs& a, const CnetGeo& g, int ms, hipStream_t s);
-bool cnet1w_dense0(const CnetArgs& a, const CnetGeo& g, int ms);        // that launch reads the dense f.0 image (CnetArgs::w0d)
 bool cnet1w_finishes(const CnetArgs& a, const CnetGeo& g, int ms);      // that launch finishes the step itself (CnetArgs::fin_cnt)
 
 }  // namespace glowhip

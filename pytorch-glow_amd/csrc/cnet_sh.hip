@@ -1303,7 +1303,6 @@ int launch_cnet_main(const CnetArgs& a, hipStream_t s, CnetPending* out) {
         out->z = a.pre_on ? a.pre_z_new : a.z_in;
         out->z_bs = a.pre_on ? a.pre_z_new_bs : a.z_in_bs;
         out->one_wave = one_wave ? 1 : 0;
-        out->dense0 = one_wave && cnet1w_dense0(a, g, ms) ? 1 : 0;
         out->finished = one_wave && cnet1w_finishes(a, g, ms) ? 1 : 0;      // (launch_cnet1w took the fused-finishing instance)
     }
     return GLOWHIP_OK;

@@ -350,8 +350,7 @@ void conv_mfma_tail_force_tile(int v) {
     // next step inside the finishing kernel and no squeeze folded into a mixer (the fused and the separate forms must agree bit for bit)
     // 0x100000: FUSED finishing on (k_cnet1w finishing the step itself instead of a k_cfinish launch; off by default: measured slower)
     // 0x200000: log|det W| of the small invconv matrices on the workgroup-wide LU instead of one wave per matrix (lu.hip; same bits)
-    // 0x2000: k_cnet1w's product instance on the padded f.0 image (G0 = 10) instead of the dense one (G0 = 8)
-    plan_disable_sh(((v & 0x800) ? 1 : 0) | ((v & 0x8000) ? 16 : 0) | ((v & 0x100000) ? 32 : 0) | ((v & 0x200000) ? 64 : 0) | ((v & 0x2000) ? 128 : 0));
+    plan_disable_sh(((v & 0x800) ? 1 : 0) | ((v & 0x8000) ? 16 : 0) | ((v & 0x100000) ? 32 : 0) | ((v & 0x200000) ? 64 : 0));
     cnet_force((v >> 22) & 7, ((v >> 25) & 15) | ((v & 0x10000) ? 16 : 0) | ((v & 0x20000) ? 32 : 0) | ((v & 0x40000) ? 64 : 0));   // 0x40000: no backward instance of k_cnet1w;   // 0x10000: no k_cnet1w (one wave per SIMD); 0x20000: its row-split instance where it applies (off by default: measured slower);   // bits 22..24: row splits; bit 25: 128-pixel tiles only, bit 26: 64-pixel tiles, bit 27: finishing chained into the next k_cnet, bit 28: finishing kernel without the XCD-affine chunk order
     plan_train_disable_sh((v & 0x800) ? 1 : 0);
     wgrad_force_narrow((v & 0x80000) ? 1 : 0);           // 0x80000: f.2's weight-gradient GEMM on 128-column tiles everywhere

@@ -101,8 +101,6 @@ struct RepackJob {
                                  // element (o, ci, tap) = w[ci][o][8 - tap]
     size_t w_off;                // w == nullptr: the source is packed + w_off (a transposed copy made by launch_flipT_batched, or W^-1)
     int after_lu;                // the source is W^-1 (packed + w_off): built after the LU factorisations, on their stream
-    int dense;                   // SH2_FIRST with Cin = 6: k = tap * 6 + channel, the channels not padded to 8 (K = CN_G0_DENSE6 = 8 groups: 4 k-steps
-                                 // instead of 5; k_cnet1w's dense instance, cnet1w_sh.hip)
     int kperm;                   // SH2_GEMM / SH2_TAIL: k-permuted image (sh.h sh2_kperm: the coupling-network kernels of cnet_sh.hip /
                                  // cnet1w_sh.hip, whose B operand of f.2 / f.4 is the previous layer's accumulator block)
 };

@@ -242,23 +242,6 @@ __device__ __forceinline__ void repack_sh2_first(const RepackJob& j, char* packe
             load_brick(row + ch * 72, min(8, j.Cin - ch * 8), true, b);
 #pragma unroll
             for (int i = 0; i < 72; ++i) b[i] *= fold;      // same rounding order as the row maximum: (w * fold) * 2^e
-            if (j.dense) {      // Cin = 6 (one brick), k = tap * 6 + channel over CN_G0_DENSE6 groups; beyond 54: zero.  Every index is a
-                                // compile-time constant: b stays in registers
-#pragma unroll
-                for (int gi = 0; gi < CN_G0_DENSE6; ++gi) {
-                    h8 hi, lo;
-#pragma unroll
-                    for (int k8 = 0; k8 < 8; ++k8) {
-                        const int k = gi * 8 + k8, tap = k / 6, c = k - tap * 6;
-                        _Float16 x, y;
-                        sh2_split((k < 54 ? b[c * 9 + tap] : 0.f) * up, x, y);
-                        hi[k8] = x; lo[k8] = y;
-                    }
-                    *reinterpret_cast<h8*>(oh + ((long)gi * M + r) * 8) = hi;
-                    *reinterpret_cast<h8*>(oh + ((long)(G + gi) * M + r) * 8) = lo;
-                }
-                continue;
-            }
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 h8 hi, lo;
@@ -271,7 +254,7 @@ __device__ __forceinline__ void repack_sh2_first(const RepackJob& j, char* packe
         h8 z;
 #pragma unroll
         for (int k8 = 0; k8 < 8; ++k8) z[k8] = (_Float16)0.f;
-        for (int gi = j.dense ? G : nchunk * 9; gi < G; ++gi) {           // the k padding up to a whole number of pipeline steps
+        for (int gi = nchunk * 9; gi < G; ++gi) {           // the k padding up to a whole number of pipeline steps
             *reinterpret_cast<h8*>(oh + ((long)gi * M + r) * 8) = z;
             *reinterpret_cast<h8*>(oh + ((long)(G + gi) * M + r) * 8) = z;
         }

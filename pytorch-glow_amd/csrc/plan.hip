@@ -77,7 +77,7 @@ static int carve(const glowhip_plan* p, int N, void* ws, size_t bytes, Workspace
 // coupling to z2.  x1: first-half channels (batch stride x1_bs).
 static bool g_pack_one_stream = false;     // testing hook: glowhip_plan_pack without the side-stream fork
 void plan_pack_one_stream(int on) { g_pack_one_stream = on != 0; }
-static bool g_sh_disabled = false, g_sh_mix_disabled = false, g_fuse_finish_off = true, g_lu_small_off = false, g_dense0_off = false;
+static bool g_sh_disabled = false, g_sh_mix_disabled = false, g_fuse_finish_off = true, g_lu_small_off = false;
 void plan_disable_sh(int off) {
     g_sh_disabled = (off & 1) != 0;        // the whole split-half path off: every coupling network on the exact-fp32 MFMA kernels
     g_sh_mix_disabled = (off & 16) != 0;   // no mixer of the next step inside the finishing kernel, no squeeze folded into a mixer
@@ -87,7 +87,6 @@ void plan_disable_sh(int off) {
     // (store drain, counter round trip, a read-around-L2 round trip per 64-pixel chunk) twice per launch, one workgroup at a time,
     // where the finishing kernel runs four workgroups per CU side by side.
     g_fuse_finish_off = (off & 32) == 0;
-    g_dense0_off = (off & 128) != 0;       // k_cnet1w's product instance on the padded f.0 image (5 k-steps) instead of the dense one (4)
     g_lu_small_off = (off & 64) != 0;      // log|det W| of the small matrices on the workgroup-wide LU (A/B and bitwise test of the one-wave form)
 }
 
@@ -192,7 +191,6 @@ static CnetArgs cnet_base(const LayerPlan& L, const void* packed, int N, int rev
     const glowhip_layer_desc& d = L.d;
     CnetArgs c{};
     c.w0 = at<char>(packed, L.cn_w0); c.w2 = at<char>(packed, L.cn_w2); c.w4 = at<char>(packed, L.cn_w4);
-    c.w0d = (L.cn_w0d && !g_dense0_off) ? at<char>(packed, L.cn_w0d) : nullptr;
     c.N = N; c.Cin = d.C / 2; c.H = d.H; c.W = d.W; c.hidden = d.hidden; c.Cout = L.Cout;
     c.scratch = scratch;
     c.bias = d.f4_bias; c.scale = at<float>(packed, L.f4_scale);
@@ -206,7 +204,6 @@ static void count_cnet_variant(glowhip_plan* p, const CnetArgs& c, const CnetPen
     char name[64];
     snprintf(name, sizeof name, "variant:k_cnet%s<%d,%d,%d>", pend.one_wave ? "1w" : "", c.hidden, pend.MS, 1 << pend.lpxt);
     count_launch(p, name);
-    if (pend.dense0) count_launch(p, "k_cnet1w(dense f.0 image)");
 }
 static CnetMixer mixer_fwd(const LayerPlan& L, const void* packed) {      // ActNorm + permutation of step L, forward
     const glowhip_layer_desc& d = L.d;
@@ -670,7 +667,6 @@ glowhip_plan* glowhip_plan_create(const glowhip_layer_desc* layers, int n_layers
             L.cnet = cnet_supported(C / 2, H, W, d.hidden, L.Cout);
             if (L.cnet) {
                 L.cn_w0 = take(off, sh2_image_bytes(cnet_g0(C / 2) * 8, d.hidden));
-                if (C == 12 && d.hidden == 512) L.cn_w0d = take(off, sh2_image_bytes(CN_G0_DENSE6 * 8, d.hidden));
                 L.cn_w2 = take(off, sh2_image_bytes(d.hidden, d.hidden));
                 L.cn_w4 = take(off, cnet_w4_bytes(d.hidden, L.Cout));
                 p->max_hidden = std::max(p->max_hidden, (long)cnet_scratch_floats_per_sample(H, W, L.Cout));
@@ -757,10 +753,6 @@ glowhip_plan* glowhip_plan_create(const glowhip_layer_desc* layers, int n_layers
                 RepackJob r0{}; r0.w = d.f0_w; r0.out_off = L.cn_w0; r0.kind = REPACK_SH2_FIRST; r0.Cin = d.C / 2; r0.Cout = d.hidden;
                 r0.K = cnet_g0(d.C / 2); r0.fold_bias = d.f0_an_bias; r0.fold_logs = d.f0_an_logs; r0.use = 3;
                 p->repack_jobs.push_back(r0);
-                if (L.cn_w0d) {      // the same weights, k = tap * 6 + channel: 54 of 64 k instead of 54 of 80 (inference launches of k_cnet1w)
-                    RepackJob rd = r0; rd.out_off = L.cn_w0d; rd.K = CN_G0_DENSE6; rd.dense = 1; rd.use = 1;
-                    p->repack_jobs.push_back(rd);
-                }
                 RepackJob r2{}; r2.kperm = 1; r2.w = d.f2_w; r2.out_off = L.cn_w2; r2.kind = REPACK_SH2_GEMM; r2.Cin = d.hidden; r2.Cout = d.hidden;
                 r2.K = d.hidden; r2.fold_bias = d.f2_an_bias; r2.fold_logs = d.f2_an_logs; r2.use = 3; p->repack_jobs.push_back(r2);
                 const int ng = cnet_groups(L.Cout), cg = L.Cout / ng;       // one image per group of f.4 output channels

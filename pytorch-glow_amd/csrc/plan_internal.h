@@ -23,7 +23,6 @@ struct LayerPlan {
     // training: input-gradient convolutions run on the forward kernels with flipped/transposed weight images
     size_t f4T_wf = 0, f0T_wp = 0;
     bool dg4_first = false, dg0_tail = false;
-    size_t cn_w0d = 0;      // (0: none) the DENSE f.0 image of a C = 12 step at hidden 512: k_cnet1w's product instance (cnet1w_sh.hip DENSE0)
     bool cnet = false; size_t cn_w0 = 0, cn_w2 = 0, cn_w4 = 0;   // whole coupling network as one kernel (cnet_sh.hip), SH2 images
     // the input-gradient chain as one k_cnet launch (MODE 2): SH2 images of the transposed weights (cb_w0: f.4^T as the 3x3 first
     // layer, cb_w2: f.2^T, cb_w4: f.0^T as the 3x3 last layer) and the transposed fp32 copies they are built from (wt4 / wt2 / wt0)

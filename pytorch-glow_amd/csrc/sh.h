@@ -128,14 +128,12 @@ size_t cnet_scratch_floats(int N, int H, int W, int Cout);   // partial-sum scra
 size_t cnet_scratch_floats_per_sample(int H, int W, int Cout);
 // What a k_cnet launch leaves behind for whoever finishes the step -- the finishing kernel, or the NEXT step's k_cnet while it
 // builds its window: the partial sums of h = f(z1) in `scratch`, how they are tiled, and the coupling they feed.
-constexpr int CN_G0_DENSE6 = 8;               // 8-wide k groups of the dense f.0 image at Cin = 6: 54 of 64 k (the padded form: 54 of 80)
 struct CnetPending {
     const float* scratch; int MS, tiles, R, NI, lpxt;
     const float* bias; const float* scale;       // f.4 bias (Cout), exp(3 logs) (Cout) of that step
     int mode, Cout;                              // TailMode of that step's coupling
     const float* z; long z_bs;                   // the state that step read: z1 = channels [0, C/2), z2 = [C/2, C)
     int one_wave;                                // the launch ran on k_cnet1w (cnet1w_sh.hip); run-time evidence for the tests
-    int dense0;                                  // the launch read the dense f.0 image (CnetArgs::w0d); run-time evidence for the tests
     int finished;                                // the launch finished the step itself (CnetArgs::fin_cnt): no finishing kernel to launch
 };
 // channel mixer applied to a finished state (C = 0: none)
@@ -144,7 +142,6 @@ struct CnetMixer { int C, reverse; const float* bias; const float* scale; const 
 struct CnetArgs {
     const float* x; long x_bs;                   // z1: channels [0, Cin) of (N, *, H, W), batch stride x_bs (unused with `pre`)
     const void* w0; const void* w2; const void* w4;   // SH2 images (REPACK_SH2_FIRST / _GEMM / _TAIL)
-    const void* w0d;                                  // optional: the DENSE f.0 image (RepackJob::dense; Cin = 6: CN_G0_DENSE6 groups) for k_cnet1w's product instance
     int N, Cin, H, W, hidden, Cout;
     float* scratch;                              // cnet_scratch_floats(N, ...) floats
     // ---- finishing kernel of THIS step: coupling + log-det + channel mixer

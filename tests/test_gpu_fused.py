@@ -238,25 +238,6 @@ def test_one_wave_per_matrix_logdet_equals_the_workgroup_lu_bitwise():
         close(nll, nll_ref, 1e-4, what=f"nll at invconv perturbation {perturb}")
 
 
-def test_dense_f0_image_instance_of_the_one_wave_kernel():
-    """Round 6: k_cnet1w's product instance reads f.0's weights from a DENSE image at C = 12 (6 input channels: k = tap * 6 + channel,
-    54 of 64 k = four k-steps, where the padded image spends five on 54 of 80; RepackJob::dense, cnet1w_sh.hip DENSE0) -- 48 MFMAs
-    fewer per wave and tile.  The contraction visits its k in another order, so the result is not the padded instance's bits: both are
-    compared with the oracle on every element (inside _case: z, nll, decode at 1e-4) and with each other (2e-5), forward and inverse,
-    which image ran taken from the run-time counters; switch 0x2000 selects the padded image.  Reference: network/module.py:300-319."""
-    K = 2
-    plan, fwd, rev = _case(64, 3, K, 512, 48, seed=44)
-    for counts in (fwd, rev):
-        assert counts.get("variant:k_cnet1w<512,1,128>") == K and counts.get("k_cnet1w(dense f.0 image)") == K, counts
-    G.lib().glowhip_debug_force_tail_tile(0x2000)
-    try:
-        plan2, fwd2, rev2 = _case(64, 3, K, 512, 48, seed=44)
-    finally:
-        G.lib().glowhip_debug_force_tail_tile(0)
-    for counts in (fwd2, rev2):
-        assert counts.get("variant:k_cnet1w<512,1,128>") == K and "k_cnet1w(dense f.0 image)" not in counts, counts
-
-
 def test_config_b_geometry_batch16(path):
     """Batch 16: k_cnet splits the h2 rows over 2 / 4 workgroups per tile at the levels whose pixel tiles alone would leave CUs idle."""
     K = 3
