@@ -333,6 +333,9 @@ int glowhip_plan_timing_read(glowhip_plan* plan, glowhip_timing_record* out, int
  * | 0x40000 = no backward instance of k_cnet1w (the level-1 input-gradient launch back on k_cnet's 64-pixel tiles: A/B),
  * | 0x20000 = the row-split instance of k_cnet1w where it applies (C = 24 levels with 112 .. tiles of 128 pixels; off by default:
  *   measured slower than k_cnet's 64-pixel tiles there; parity tests and A/B),
+ * | 0x100000 = FUSED FINISHING on: a k_cnet1w launch finishes its FlowStep itself (arrival counters per tile, the last workgroup
+ *   to arrive runs the finishing kernel's code; bit-identical, off by default: measured slower),
+ * | 0x200000 = log|det W| of the 12 / 24 / 48-wide invconv matrices on the workgroup-wide LU instead of one wave per matrix (same bits: A/B),
  * | 0x8000000 = the finishing step of a FlowStep runs inside the next FlowStep's k_cnet (off by default: measured slower),
  * | 0x10000000 = the finishing kernel takes its pixel chunks in block order instead of the XCD-affine order (A/B),
  * | 0x20000000 = glowhip_plan_pack entirely on the caller's stream, no side-stream fork (A/B),
