@@ -326,3 +326,27 @@ def test_multi_rank_range_check_is_resolved_at_a_fixed_lag():
     assert two.range_fallbacks == 1 and two.optimizer.undone == 1 and len(two._pending) == 1 and len(two._rerun) == 1
     two._check_previous(drain=True)                                    # flush(): everything
     assert not two._pending and two.range_fallbacks == 1
+
+
+def test_bucket_overlap_report_arithmetic():
+    """`parallel.bucket_overlap_report` (the N-rank bench line's `gradient_bucket_overlap`): per step the time the bucket all-reduces
+    took on the side stream, the part still running after the backward sweep had finished on the main stream, the fraction hidden.
+    Stand-in events on a common clock: host logic only."""
+    from pytorch_glow_amd import parallel
+
+    class Ev:
+        def __init__(self, t):
+            self.t = t
+
+        def elapsed_time(self, other):
+            return other.t - self.t
+
+    # step 1: sweep done at t = 10; buckets [2, 5], [6, 9], [9.5, 12] -> 8.5 ms of collectives, 2 ms of them after the sweep
+    # step 2: everything over before the sweep ends -> nothing exposed
+    recs = [{"sweep_done": Ev(10.0), "spans": [(Ev(2.0), Ev(5.0), 100), (Ev(6.0), Ev(9.0), 200), (Ev(9.5), Ev(12.0), 300)]},
+            {"sweep_done": Ev(30.0), "spans": [(Ev(21.0), Ev(24.0), 100), (Ev(25.0), Ev(28.0), 200), (Ev(28.0), Ev(29.5), 300)]}]
+    r = parallel.bucket_overlap_report(recs)
+    assert r["steps"] == 2 and r["buckets_per_step"] == 3 and r["bytes_per_step"] == 600
+    assert r["allreduce_ms_per_step"] == pytest.approx((8.5 + 7.5) / 2) and r["exposed_ms_per_step"] == pytest.approx(1.0)
+    assert r["hidden_fraction"] == pytest.approx(1.0 - 1.0 / 8.0)
+    assert parallel.bucket_overlap_report([]) is None and parallel.bucket_overlap_report([{"sweep_done": Ev(0), "spans": []}]) is None
